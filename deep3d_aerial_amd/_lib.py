@@ -1,0 +1,92 @@
+"""ctypes binding of the C-ABI library (include/deep3d_planesweep.h).
+
+The library is built in-tree by deep3d_aerial_amd/csrc/Makefile (see __graft_entry__.build).
+There is NO fallback: if the shared object is missing or lacks a symbol, importing the
+operators raises, and every operator refuses tensors that are not on the GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libdeep3d_planesweep.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
+
+ABI_VERSION = 1
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+
+# name -> argtypes; restype is int except where noted.  Mirrors include/deep3d_planesweep.h.
+SIGNATURES = {
+    "d3d_version": [],
+    "d3d_last_error": [],
+    "d3d_compose_projections": [_vp, _i, _vp, _vp],
+    "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_pair_corr_mean": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_softargmin_conf4": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "d3d_online_regress_update": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "d3d_online_regress_finalize": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "d3d_depth_range_samples": [_vp, _i, _i, _f, _i, _i, _vp, _vp],
+    "d3d_resize_bilinear": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv3d_k3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_convtranspose3d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_convtranspose2d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_gru_gates": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
+    "d3d_gru_update": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "d3d_pair_softmax_max": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of the C-ABI library, in-tree (cross-compiles on CPU)."""
+    cmd = ["make", "-C", CSRC, "-j4", "libdeep3d_planesweep.so"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libdeep3d_planesweep.so failed")
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library and bind every symbol the header declares. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise LibraryMissing(
+            "%s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C deep3d_aerial_amd/csrc`. There is no CPU fallback." % SO_PATH)
+    lib = ctypes.CDLL(SO_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LibraryMissing("symbol %s missing from %s" % (name, SO_PATH)) from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "d3d_last_error" else ctypes.c_int
+    if lib.d3d_version() != ABI_VERSION:
+        raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().d3d_last_error().decode("utf-8", "replace")
+        kind = {-1: "invalid argument", -2: "unsupported", -3: "HIP error"}.get(rc, "error %d" % rc)
+        raise RuntimeError("%s failed (%s): %s" % (what, kind, msg))

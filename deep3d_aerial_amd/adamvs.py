@@ -1,0 +1,251 @@
+"""AdaMVS inference (the reference's default model) on the MI355X plane-sweep engine:
+per-pair visibility net, visibility-weighted correlation volume, slice-recurrent conv-GRU
+regulariser and online exp-sum regression.
+
+Mirror of mvs/mvs_cas/models/adamvs.py (inference classes only; same names, constructor
+arguments, forward() contract and state_dict keys).  Differences in HOW, not WHAT:
+  * the stage-1 pair pass (adamvs.py:466-475, 48 single-plane warps per source) is one
+    fused ops.pair_corr_mean launch per source;
+  * the per-plane warp + weighting + normalisation (adamvs.py:492-509, 4 warps and ~20
+    elementwise launches per plane) is one ops.weighted_corr launch per stage that writes
+    the whole [C,D,h,w] similarity volume; the GRU then walks its planes;
+  * view weights are resampled once per stage, not once per plane (adamvs.py:502).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, folded_bn,
+                     plane_depths)
+
+
+class FeatureNet(nn.Module):
+    """adamvs.py:50-153 -- image pyramid with pooled context branches (PyTorch-ROCm/MIOpen)."""
+
+    def __init__(self, base_channels, num_stage=3, stride=4):
+        super().__init__()
+        assert num_stage == 3
+        b = base_channels
+        self.stride, self.base_channels, self.num_stage = stride, b, num_stage
+        self.conv0, self.conv1, self.conv2 = _trunk(b)
+
+        def branch(pool, cin, cout):
+            return nn.Sequential(nn.AvgPool2d((pool, pool), stride=(pool, pool)),
+                                 Conv2d(cin, cout, 1, stride=1, padding=0, dilation=1))
+
+        self.branch1_1, self.branch1_2 = branch(4, b * 4, b * 2), branch(8, b * 4, b * 2)
+        self.out1 = nn.Conv2d(b * 8, b * 4, 1, bias=False)
+        self.deconv1 = DeConv2dFuse(b * 4, b * 2, 3)
+        self.deconv2 = DeConv2dFuse(b * 2, b, 3)
+        self.branch2_1, self.branch2_2 = branch(4, b * 2, b), branch(8, b * 2, b)
+        self.branch3_1, self.branch3_2 = branch(4, b, b // 2), branch(8, b, b // 2)
+        self.out2 = nn.Conv2d(b * 4, b * 2, 1, bias=False)
+        self.out3 = nn.Conv2d(b * 2, b, 1, bias=False)
+        self.out_channels = [4 * b, 2 * b, b]
+
+    @staticmethod
+    def _context(feat, br_a, br_b, head):
+        size = feat.shape[2:]
+        up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=False)
+        return head(torch.cat((up(br_a(feat)), up(br_b(feat)), feat), 1))
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1(c0)
+        c2 = self.conv2(c1)
+        out = {"stage1": self._context(c2, self.branch1_1, self.branch1_2, self.out1)}
+        f = self.deconv1(c1, c2)
+        out["stage2"] = self._context(f, self.branch2_1, self.branch2_2, self.out2)
+        f = self.deconv2(c0, f)
+        out["stage3"] = self._context(f, self.branch3_1, self.branch3_2, self.out3)
+        return out
+
+
+class _Up2D(nn.Sequential):
+    """ConvTranspose2d + BatchNorm2d + ReLU at indices 0,1,2 (adamvs.py:212-225 key layout)."""
+
+    def __init__(self, ch):
+        super().__init__(nn.ConvTranspose2d(ch, ch, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                         nn.BatchNorm2d(ch), nn.ReLU(inplace=True))
+
+    def forward(self, x, skip):
+        _no_train(self)
+        s, t = folded_bn(self[1])
+        return ops.convtranspose2d_k3s2(x, self[0].weight, s, t, skip, skip_after_act=True, act=1)
+
+
+class CostRegNet2D(nn.Module):
+    """adamvs.py:198-238 -- pair visibility UNet over depth-as-channels. forward(x [D,h,w]) -> [D,h,w]."""
+
+    def __init__(self, in_channels, base_channels=8):
+        super().__init__()
+        c = in_channels
+        self.conv0 = ConvBnReLU(c, c)
+        self.conv1 = ConvBnReLU(c, c, stride=2)
+        self.conv2 = ConvBnReLU(c, c)
+        self.conv3 = ConvBnReLU(c, c, stride=2)
+        self.conv4 = ConvBnReLU(c, c)
+        self.conv5 = ConvBnReLU(c, c, stride=2)
+        self.conv6 = ConvBnReLU(c, c)
+        self.conv7, self.conv9, self.conv11 = _Up2D(c), _Up2D(c), _Up2D(c)
+        self.prob = nn.Conv2d(c, c, 3, stride=1, padding=1)
+
+    def forward(self, x):
+        if x.shape[1] % 8 or x.shape[2] % 8:
+            raise ValueError("CostRegNet2D needs h,w divisible by 8 (got %s)" % (tuple(x.shape[1:]),))
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        y = self.conv6(self.conv5(c4))
+        y = self.conv7(y, c4)
+        y = self.conv9(y, c2)
+        y = self.conv11(y, c0)
+        return ops.conv2d_k3(y, self.prob.weight, None, self.prob.bias, None, act=0, stride=1)
+
+
+class SliceCostRegNetRED(nn.Module):
+    """adamvs.py:403-427 -- one depth slice through the 2-level conv-GRU encoder-decoder.
+    forward(cost [C,h,w], state1 [8,h,w], state2 [16,h/2,w/2]) -> (reg [1,2h,2w] | [1,h,w], state1, state2)."""
+
+    def __init__(self, in_channels, up=True, base_channels=8):
+        super().__init__()
+        b = base_channels
+        self.base_channels, self.up = b, up
+        self.conv1 = ConvReLU(in_channels, b, 3, 1, 1)
+        self.conv_gru1 = ConvGRUCell(b, b, 3)
+        self.conv2 = ConvReLU(b, b * 2, 3, 2, 1)
+        self.conv_gru2 = ConvGRUCell(b * 2, b * 2, 3)
+        self.upconv1 = nn.ConvTranspose2d(b * 2, b, kernel_size=3, stride=2, padding=1, output_padding=1)
+        if up:
+            self.upconv2d = nn.ConvTranspose2d(b, 1, kernel_size=3, stride=2, padding=1, output_padding=1)
+        else:
+            self.upconv2d = nn.Conv2d(b, 1, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, cost, state1, state2):
+        x1 = self.conv1(cost)
+        state1, _ = self.conv_gru1(x1, state1)
+        x2 = self.conv2(state1)
+        state2, _ = self.conv_gru2(x2, state2)
+        # relu(upconv1(state2) + state1): skip added before the activation (adamvs.py:423-424)
+        up = ops.convtranspose2d_k3s2(state2, self.upconv1.weight, None, self.upconv1.bias, state1,
+                                      skip_after_act=False, act=1)
+        if self.up:
+            reg = ops.convtranspose2d_k3s2(up, self.upconv2d.weight, None, self.upconv2d.bias, None, act=0)
+        else:
+            reg = ops.conv2d_k3(up, self.upconv2d.weight, None, self.upconv2d.bias, None, act=0)
+        return reg, state1, state2
+
+
+class InferDepthNet(nn.Module):
+    """adamvs.py:429-531."""
+
+    def __init__(self, in_depths, in_channels, in_up=True, base_channels=8):
+        super().__init__()
+        self.in_up = in_up
+        self.reg = CostRegNet2D(in_depths, base_channels)
+        self.reg_fuse = SliceCostRegNetRED(in_channels, in_up, base_channels)
+
+    def _one(self, feats, proj44, dv, D, conf_in):
+        """feats: V x [C,h,w]; dv [D] or [D,h,w]; conf_in: None or [V-1,hc,wc]."""
+        C, h, w = feats[0].shape
+        if h % 2 or w % 2:
+            raise ValueError("feature map must have even size (got %dx%d)" % (h, w))
+        dev = feats[0].device
+        p34 = ops.compose_projections(proj44)
+        pair_results = []
+        if conf_in is None:  # stage 1: per-pair visibility (adamvs.py:465-489)
+            vws = []
+            for i in range(1, len(feats)):
+                corr = ops.pair_corr_mean(feats[0], feats[i], p34[i - 1], dv)
+                score = self.reg(corr)
+                vw, pd = ops.pair_softmax_max(score, dv)
+                vws.append(vw)
+                pair_results.append(pd)
+            weights = torch.stack(vws)
+        elif tuple(conf_in.shape[1:]) == (h, w):
+            weights = conf_in
+        else:  # adamvs.py:502, once per stage instead of once per plane
+            weights = ops.resize_bilinear(conf_in, h, w)
+
+        sim = ops.weighted_corr(feats, p34, weights, dv)  # [C,D,h,w]
+        H, W = (2 * h, 2 * w) if self.in_up else (h, w)
+        s1 = torch.zeros((8, h, w), dtype=torch.float32, device=dev)
+        s2 = torch.zeros((16, h // 2, w // 2), dtype=torch.float32, device=dev)
+        max_p = torch.zeros((H, W), dtype=torch.float32, device=dev)
+        sum_d = torch.zeros_like(max_p)
+        sum_p = torch.zeros_like(max_p)
+        for d in range(D):
+            reg, s1, s2 = self.reg_fuse(sim[:, d].contiguous(), s1, s2)
+            dplane = dv[d].reshape(1, 1) if dv.dim() == 1 else dv[d]
+            ops.online_regress_update(reg[0], dplane.contiguous(), max_p, sum_d, sum_p)
+        depth, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
+        return depth, conf, weights, pair_results
+
+    def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None):
+        assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
+            depth_values.shape[1], num_depth)
+        _no_train(self)
+        B = features[0].shape[0]
+        nsrc = len(features) - 1
+        depths, confs, weights, pairs = [], [], [], []
+        for b in range(B):
+            conf_in = None
+            if confidence_map is not None:
+                conf_in = torch.stack([confidence_map[i][b, 0] for i in range(nsrc)]).contiguous()
+            d, c, wts, pr = self._one([f[b].contiguous() for f in features], proj_matrices[b].contiguous(),
+                                      depth_values[b].contiguous(), num_depth, conf_in)
+            depths.append(d)
+            confs.append(c)
+            weights.append(wts)
+            pairs.append(pr)
+        # pair_confidence: V-1 tensors [B,1,h,w] at this stage's resolution -- the entries of
+        # the reference's list that the next stage actually reads (adamvs.py:502,612).
+        pair_confidence = [torch.stack([weights[b][i] for b in range(B)]).unsqueeze(1) for i in range(nsrc)]
+        pair_result = [torch.stack([pairs[b][i] for b in range(B)]) for i in range(len(pairs[0]))]
+        return {"depth": torch.stack(depths), "photometric_confidence": torch.stack(confs),
+                "pair_confidence": pair_confidence, "pair_result": pair_result}
+
+
+class Infer_AdaMVSNet(nn.Module):
+    """adamvs.py:535-617. forward(imgs [B,V,3,H,W], proj_matrices {stageN: [B,V,4,4]}, depth_values [B,2])."""
+
+    def __init__(self, num_depth=384, ndepths=[48, 32, 8], depth_intervals_ratio=[4, 2, 1], share_cr=False,
+                 cr_base_chs=[8, 8, 8]):
+        super().__init__()
+        assert len(ndepths) == len(depth_intervals_ratio)
+        self.num_depth, self.share_cr, self.ndepths = num_depth, share_cr, list(ndepths)
+        self.depth_intervals_ratio, self.cr_base_chs = list(depth_intervals_ratio), list(cr_base_chs)
+        self.num_stage = len(ndepths)
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+        self.feature = FeatureNet(base_channels=8, stride=4, num_stage=self.num_stage)
+        oc = self.feature.out_channels
+        self.DepthNet = nn.ModuleList([InferDepthNet(in_depths=self.ndepths[0], in_channels=oc[0]),
+                                       InferDepthNet(in_depths=self.ndepths[0], in_channels=oc[1]),
+                                       InferDepthNet(in_depths=self.ndepths[0], in_up=False, in_channels=oc[2])])
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        B, V, _, img_h, img_w = imgs.shape
+        dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())
+        depth_interval = (dmax - dmin) / self.num_depth
+        features = [self.feature(imgs[:, v]) for v in range(V)]
+        outputs = {}
+        depth, pair_confidence = None, None
+        for s in range(self.num_stage):
+            key = "stage%d" % (s + 1)
+            feats = [f[key] for f in features]
+            D = self.ndepths[s]
+            if depth is None:
+                dv = plane_depths(depth_values, D)  # [B,D]: linspace(min,max) (module.py:637-642)
+            else:  # previous stage already has this stage's resolution (adamvs.py:589-592)
+                dv = torch.stack([ops.depth_range_samples(depth[b].contiguous(), D,
+                                                          self.depth_intervals_ratio[s] * depth_interval)
+                                  for b in range(B)])
+            out = self.DepthNet[s](feats, proj_matrices[key], depth_values=dv, num_depth=D,
+                                   confidence_map=pair_confidence)
+            depth = out["depth"]
+            pair_confidence = out["pair_confidence"]
+            outputs[key] = out
+            outputs.update(out)
+        return outputs

@@ -1,0 +1,141 @@
+"""CasMVSNet inference on the MI355X plane-sweep engine: variance cost volume, 3D-UNet
+regulariser, softmax / soft-argmin / 4-plane confidence.
+
+Mirror of the reference's mvs/mvs_cas/models/cas_mvsnet.py (class names, constructor
+arguments, forward() contract, state_dict keys).  Hot path per stage:
+
+    ops.compose_projections   module.py:528-530
+    ops.variance_volume       cas_mvsnet.py:45-60   (fused warp + variance, one kernel)
+    CostRegNet                cas_mvsnet.py:81-121  (ops.conv3d_k3 / convtranspose3d_k3s2)
+    ops.softargmin_conf4      cas_mvsnet.py:69-76
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .module import ConvBnReLU3D, FeatureNet_mvsnet, folded_bn, plane_depths, _no_train
+
+
+class _Up3D(nn.Sequential):
+    """ConvTranspose3d + BatchNorm3d + ReLU as indices 0,1,2 (cas_mvsnet.py:94-108 key layout)."""
+
+    def __init__(self, cin, cout):
+        super().__init__(nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2,
+                                            bias=False),
+                         nn.BatchNorm3d(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x, skip):
+        _no_train(self)
+        s, t = folded_bn(self[1])
+        return ops.convtranspose3d_k3s2(x, self[0].weight, s, t, skip, relu=True)
+
+
+class CostRegNet(nn.Module):
+    """cas_mvsnet.py:81-121.  forward(x [B,C,D,H,W]) -> [B,1,D,H,W]."""
+
+    def __init__(self, in_channels, base_channels=8):
+        super().__init__()
+        self.conv0 = ConvBnReLU3D(in_channels, 8)
+        self.conv1 = ConvBnReLU3D(8, 16, stride=2)
+        self.conv2 = ConvBnReLU3D(16, 16)
+        self.conv3 = ConvBnReLU3D(16, 32, stride=2)
+        self.conv4 = ConvBnReLU3D(32, 32)
+        self.conv5 = ConvBnReLU3D(32, 64, stride=2)
+        self.conv6 = ConvBnReLU3D(64, 64)
+        self.conv7 = _Up3D(64, 32)
+        self.conv9 = _Up3D(32, 16)
+        self.conv11 = _Up3D(16, 8)
+        self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
+
+    def forward_one(self, x):  # [C,D,H,W] -> [D,H,W]
+        D, H, W = x.shape[1:]
+        if D % 8 or H % 8 or W % 8:
+            raise ValueError("CostRegNet needs D,H,W divisible by 8 (got %s)" % (tuple(x.shape[1:]),))
+        c0 = self.conv0(x)
+        c2 = self.conv2(self.conv1(c0))
+        c4 = self.conv4(self.conv3(c2))
+        y = self.conv6(self.conv5(c4))
+        y = self.conv7(y, c4)
+        y = self.conv9(y, c2)
+        y = self.conv11(y, c0)
+        return ops.conv3d_k3(y, self.prob.weight, None, self.prob.bias, None, relu=False, stride=1)[0]
+
+    def forward(self, x):
+        return torch.stack([self.forward_one(x[b].contiguous()) for b in range(x.shape[0])]).unsqueeze(1)
+
+
+class DepthNet(nn.Module):
+    """cas_mvsnet.py:31-78."""
+
+    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, prob_volume_init=None):
+        assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
+            depth_values.shape[1], num_depth)
+        if prob_volume_init is not None:
+            raise NotImplementedError("prob_volume_init is never passed at inference (cas_mvsnet.py:228-230)")
+        depths, confs = [], []
+        for b in range(features[0].shape[0]):
+            p34 = ops.compose_projections(proj_matrices[b].contiguous())
+            dv = depth_values[b].contiguous()
+            var = ops.variance_volume([f[b].contiguous() for f in features], p34, dv)
+            cost = cost_regularization.forward_one(var)
+            d, c = ops.softargmin_conf4(cost, dv)
+            depths.append(d)
+            confs.append(c)
+        return {"depth": torch.stack(depths), "photometric_confidence": torch.stack(confs)}
+
+
+class Infer_CascadeMVSNet(nn.Module):
+    """cas_mvsnet.py:140-241.  forward(imgs [B,V,3,H,W], proj_matrices {stageN: [B,V,4,4]}, depth_values [B,2])."""
+
+    def __init__(self, refine=False, num_depth=384, ndepths=[48, 32, 8], depth_intervals_ratio=[4, 2, 1],
+                 share_cr=False, grad_method="detach", arch_mode="fpn", cr_base_chs=[8, 8, 8]):
+        super().__init__()
+        if refine:
+            raise NotImplementedError("RefineNet is broken in the reference (F.cat) and disabled there")
+        assert len(ndepths) == len(depth_intervals_ratio)
+        self.refine, self.share_cr, self.ndepths = refine, share_cr, list(ndepths)
+        self.depth_intervals_ratio, self.grad_method, self.arch_mode = list(depth_intervals_ratio), grad_method, arch_mode
+        self.cr_base_chs, self.num_stage, self.num_depth = list(cr_base_chs), len(ndepths), num_depth
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+        self.feature = FeatureNet_mvsnet(base_channels=8, stride=4, num_stage=self.num_stage, arch_mode=arch_mode)
+        if share_cr:
+            self.cost_regularization = CostRegNet(in_channels=self.feature.out_channels[1], base_channels=8)
+        else:
+            self.cost_regularization = nn.ModuleList(
+                [CostRegNet(in_channels=self.feature.out_channels[i], base_channels=self.cr_base_chs[i])
+                 for i in range(self.num_stage)])
+        self.DepthNet = DepthNet()
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        B, V, _, img_h, img_w = imgs.shape
+        # one device sync, like the reference's depth_values[0,0].cpu() (cas_mvsnet.py:184-185)
+        dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())
+        depth_interval = (dmax - dmin) / self.num_depth
+
+        features = [self.feature(imgs[:, v]) for v in range(V)]
+        outputs = {}
+        depth = None
+        for s in range(self.num_stage):
+            key = "stage%d" % (s + 1)
+            feats = [f[key] for f in features]
+            scale = int(self.stage_infos[key]["scale"])
+            h, w = img_h // scale, img_w // scale
+            D = self.ndepths[s]
+            if depth is None:
+                dv = plane_depths(depth_values, D)  # [B,D]
+            else:
+                # cas_mvsnet.py:211-226: depth -> full res (bilinear), hypotheses at full res,
+                # then the trilinear resample to the stage grid (identity along D).
+                dvs = []
+                for b in range(B):
+                    cur = ops.resize_bilinear(depth[b:b + 1].contiguous(), img_h, img_w)[0]
+                    full = ops.depth_range_samples(cur, D, self.depth_intervals_ratio[s] * depth_interval)
+                    dvs.append(full if (h, w) == (img_h, img_w) else ops.resize_bilinear(full, h, w))
+                dv = torch.stack(dvs)
+            cr = self.cost_regularization if self.share_cr else self.cost_regularization[s]
+            out = self.DepthNet(feats, proj_matrices[key], depth_values=dv, num_depth=D, cost_regularization=cr)
+            depth = out["depth"]
+            outputs[key] = out
+            outputs.update(out)
+        return outputs

@@ -1,0 +1,330 @@
+// Plane-sweep warp + aggregation kernels for gfx950 (MI355X), and the C-ABI entry points
+// that launch them.  See include/deep3d_planesweep.h for the contract and the reference
+// citations; DESIGN.md for the data layout and the roofline of each kernel.
+//
+// Two families live here:
+//   * sweep_direct_kernel  -- one lane per reference pixel, taps gathered straight from
+//     the planar [C,h,w] source maps through the vector L1/L2.  Handles any geometry,
+//     any C, any V.  It is the general path and the reference point for the tiled one.
+//   * sweep_tiled_kernel   -- (planesweep_tiled.hip) LDS-staged source footprints for
+//     the HBM-write-bound cost-volume shapes.
+#include "common.h"
+
+#include <cstring>
+
+namespace d3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return D3D_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return D3D_ERR_HIP;
+}
+
+// defined in planesweep_tiled.hip: returns D3D_ERR_UNSUPPORTED when the shape is outside
+// what the tiled kernel handles, in which case the caller uses the direct kernel.
+int launch_tiled(int mode, const struct SweepParams& p, hipStream_t stream);
+
+}  // namespace d3d
+
+#include "sweep_params.h"
+
+namespace d3d {
+
+// ---------------------------------------------------------------------------------------
+// module.py:528-530 on the device: fp64 cofactor inverse of ref_proj, product with each
+// src_proj, one rounding to fp32.  One thread per source view.
+// ---------------------------------------------------------------------------------------
+__global__ void compose_kernel(const float* __restrict__ proj44, int n_views, float* __restrict__ out34) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i >= n_views) return;
+    double m[16], inv[16];
+    for (int k = 0; k < 16; ++k) m[k] = (double)proj44[k];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] +
+             m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] -
+             m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] +
+             m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] -
+              m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] -
+             m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] +
+             m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] -
+             m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] +
+              m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] +
+             m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] -
+             m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] +
+              m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] -
+              m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] -
+             m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] +
+             m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] -
+              m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] +
+              m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    double idet = 1.0 / det;  // singular ref_proj -> inf/nan propagate, as torch.inverse would raise
+    const float* s = proj44 + 16 * i;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += (double)s[r * 4 + k] * (inv[k * 4 + c] * idet);
+            out34[(i - 1) * 12 + r * 4 + c] = (float)acc;
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// Direct kernel.  Block = 64 x 4 reference pixels, each lane walks d_chunk planes.
+// CC = channels kept in registers per pass.
+// ---------------------------------------------------------------------------------------
+struct TapD {
+    int off;      // clamped north-west tap offset (y0c*w + x0c)
+    int dx, dyw;  // 0/1 and 0/w steps to the east / south taps (clamped at the border)
+    float nw, ne, sw, se;  // weights, zero for taps outside the image
+};
+
+__device__ __forceinline__ TapD make_tap_direct(float u, float v, int h, int w) {
+    TapD t;
+    float fu = floorf(u), fv = floorf(v);
+    int x0 = (int)fu, y0 = (int)fv;
+    float ax = u - fu, ay = v - fv;
+    float bx = (fu + 1.0f) - u, by = (fv + 1.0f) - v;
+    bool vx0 = (x0 >= 0) && (x0 < w), vx1 = (x0 >= -1) && (x0 < w - 1);
+    bool vy0 = (y0 >= 0) && (y0 < h), vy1 = (y0 >= -1) && (y0 < h - 1);
+    t.nw = (vx0 && vy0) ? bx * by : 0.0f;
+    t.ne = (vx1 && vy0) ? ax * by : 0.0f;
+    t.sw = (vx0 && vy1) ? bx * ay : 0.0f;
+    t.se = (vx1 && vy1) ? ax * ay : 0.0f;
+    int x0c = min(max(x0, 0), w - 1), x1c = min(max(x0 + 1, 0), w - 1);
+    int y0c = min(max(y0, 0), h - 1), y1c = min(max(y0 + 1, 0), h - 1);
+    t.off = y0c * w + x0c;
+    t.dx = x1c - x0c;
+    t.dyw = (y1c - y0c) * w;
+    return t;
+}
+
+__device__ __forceinline__ float gather4(const float* __restrict__ f, const TapD& t) {
+    const float* q = f + t.off;
+    // same summation order as grid_sample: nw, ne, sw, se
+    float acc = q[0] * t.nw;
+    acc = fmaf(q[t.dx], t.ne, acc);
+    acc = fmaf(q[t.dyw], t.sw, acc);
+    acc = fmaf(q[t.dyw + t.dx], t.se, acc);
+    return acc;
+}
+
+template <int MODE, int CC>
+__global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.w || y >= p.h) return;
+    const int h = p.h, w = p.w, C = p.C, D = p.D;
+    const size_t plane = (size_t)h * w;
+    const size_t pix = (size_t)y * w + x;
+    const float xf = (float)x, yf = (float)y;
+    const int d0 = blockIdx.z * p.d_chunk;
+    const int d1 = min(d0 + p.d_chunk, D);
+    const float invV = 1.0f / (float)(p.n_src + 1);
+
+    for (int d = d0; d < d1; ++d) {
+        const float dv = p.depth_mode == D3D_DEPTH_PER_PIXEL ? p.depth[(size_t)d * plane + pix] : p.depth[d];
+        float den = 1e-5f;
+        if (MODE == MODE_WEIGHTED)
+            for (int i = 0; i < p.n_src; ++i) den += p.weights[(size_t)i * plane + pix];
+        float pair_acc = 0.0f;
+        for (int c0 = 0; c0 < C; c0 += CC) {
+            float s[CC], q[CC], r[CC];
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                r[c] = (MODE == MODE_WARP) ? 0.0f : p.feats[0][(size_t)(c0 + c) * plane + pix];
+                s[c] = (MODE == MODE_VARIANCE) ? r[c] : 0.0f;
+                q[c] = r[c] * r[c];
+            }
+            for (int i = 0; i < p.n_src; ++i) {
+                const float* __restrict__ P = p.proj34 + 12 * i;
+                Ray ray = make_ray(P, xf, yf);
+                float u, v;
+                project(ray, P[3], P[7], P[11], dv, h, w, u, v);
+                TapD t = make_tap_direct(u, v, h, w);
+                const float* __restrict__ f = p.feats[i + 1] + (size_t)c0 * plane;
+                float vw = (MODE == MODE_WEIGHTED) ? p.weights[(size_t)i * plane + pix] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    float val = gather4(f + (size_t)c * plane, t);
+                    if (MODE == MODE_VARIANCE) {
+                        s[c] += val;
+                        q[c] = fmaf(val, val, q[c]);
+                    } else if (MODE == MODE_WEIGHTED) {
+                        s[c] = fmaf(val * r[c], vw, s[c]);
+                    } else if (MODE == MODE_PAIR) {
+                        pair_acc = fmaf(r[c], val, pair_acc);
+                    } else {
+                        s[c] = val;
+                    }
+                }
+            }
+            if (MODE != MODE_PAIR) {
+#pragma unroll
+                for (int c = 0; c < CC; ++c) {
+                    float o;
+                    if (MODE == MODE_VARIANCE) {
+                        float m = s[c] * invV;
+                        o = fmaf(q[c], invV, -(m * m));
+                    } else if (MODE == MODE_WEIGHTED) {
+                        o = s[c] / den;
+                    } else {
+                        o = s[c];
+                    }
+                    p.out[((size_t)(c0 + c) * D + d) * plane + pix] = o;
+                }
+            }
+        }
+        if (MODE == MODE_PAIR) p.out[(size_t)d * plane + pix] = pair_acc / (float)C;
+    }
+}
+
+template <int MODE>
+static int launch_direct(const SweepParams& p, hipStream_t stream) {
+    SweepParams q = p;
+    q.d_chunk = 8;
+    dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4), ceil_div(p.D, q.d_chunk));
+    dim3 block(256);
+    if (p.C % 16 == 0)
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 16>), grid, block, 0, stream, q);
+    else if (p.C % 8 == 0)
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 8>), grid, block, 0, stream, q);
+    else if (p.C % 4 == 0)
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 4>), grid, block, 0, stream, q);
+    else
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 1>), grid, block, 0, stream, q);
+    D3D_LAUNCH_CHECK("sweep_direct_kernel launch");
+    return D3D_OK;
+}
+
+static int check_dims(int C, int D, int h, int w) {
+    D3D_REQUIRE(C > 0 && D > 0 && h > 1 && w > 1, "bad dims C=%d D=%d h=%d w=%d (need C,D>0 and h,w>1)", C, D, h, w);
+    D3D_REQUIRE((long)h * w < (1L << 30), "feature map too large: %d x %d", h, w);
+    D3D_REQUIRE(ceil_div(h, 4) <= 65535 && ceil_div(D, 8) <= 65535, "grid too large (h=%d D=%d)", h, D);
+    return D3D_OK;
+}
+
+static int sweep_dispatch(int mode, const SweepParams& p, hipStream_t stream) {
+    const char* force = getenv("D3D_FORCE_PATH");  // "direct" | "tiled" (testing / profiling only)
+    bool want_direct = force && !strcmp(force, "direct");
+    if (!want_direct) {
+        int rc = launch_tiled(mode, p, stream);
+        if (rc != D3D_ERR_UNSUPPORTED) return rc;
+        if (force && !strcmp(force, "tiled")) return rc;
+    }
+    switch (mode) {
+        case MODE_WARP: return launch_direct<MODE_WARP>(p, stream);
+        case MODE_VARIANCE: return launch_direct<MODE_VARIANCE>(p, stream);
+        case MODE_WEIGHTED: return launch_direct<MODE_WEIGHTED>(p, stream);
+        case MODE_PAIR: return launch_direct<MODE_PAIR>(p, stream);
+    }
+    set_error("internal: bad mode %d", mode);
+    return D3D_ERR_INVALID_ARG;
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+int d3d_version(void) { return D3D_ABI_VERSION; }
+
+const char* d3d_last_error(void) { return g_err; }
+
+int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_stream_t stream) {
+    D3D_REQUIRE(proj44 && out34, "null pointer");
+    D3D_REQUIRE(n_views >= 2 && n_views <= D3D_MAX_VIEWS, "n_views=%d out of range [2,%d]", n_views, D3D_MAX_VIEWS);
+    hipLaunchKernelGGL(compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, proj44, n_views, out34);
+    D3D_LAUNCH_CHECK("compose_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int depth_mode, int C, int D, int h,
+                  int w, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(src && proj34 && depth && out, "null pointer");
+    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    int rc = check_dims(C, D, h, w);
+    if (rc) return rc;
+    SweepParams p = {};
+    p.feats[0] = src;  // unused as reference in MODE_WARP
+    p.feats[1] = src;
+    p.proj34 = proj34;
+    p.depth = depth;
+    p.out = out;
+    p.n_src = 1;
+    p.C = C; p.D = D; p.h = h; p.w = w;
+    p.depth_mode = depth_mode;
+    return sweep_dispatch(MODE_WARP, p, (hipStream_t)stream);
+}
+
+static int fill_multi(SweepParams& p, const float* const* feats, const float* proj34, const float* depth,
+                      int depth_mode, int n_views, int C, int D, int h, int w, float* out) {
+    D3D_REQUIRE(feats && proj34 && depth && out, "null pointer");
+    D3D_REQUIRE(n_views >= 2 && n_views <= D3D_MAX_VIEWS, "n_views=%d out of range [2,%d]", n_views, D3D_MAX_VIEWS);
+    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    int rc = check_dims(C, D, h, w);
+    if (rc) return rc;
+    for (int i = 0; i < n_views; ++i) {
+        D3D_REQUIRE(feats[i], "feats[%d] is null", i);
+        p.feats[i] = feats[i];
+    }
+    p.proj34 = proj34;
+    p.depth = depth;
+    p.out = out;
+    p.n_src = n_views - 1;
+    p.C = C; p.D = D; p.h = h; p.w = w;
+    p.depth_mode = depth_mode;
+    return D3D_OK;
+}
+
+int d3d_variance_volume(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                        int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream) {
+    SweepParams p = {};
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out);
+    if (rc) return rc;
+    return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
+}
+
+int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
+                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream) {
+    SweepParams p = {};
+    D3D_REQUIRE(weights, "null weights");
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out);
+    if (rc) return rc;
+    p.weights = weights;
+    return sweep_dispatch(MODE_WEIGHTED, p, (hipStream_t)stream);
+}
+
+int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, const float* depth, int depth_mode,
+                       int C, int D, int h, int w, float* out, d3d_stream_t stream) {
+    const float* feats[2] = {ref, src};
+    SweepParams p = {};
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, 2, C, D, h, w, out);
+    if (rc) return rc;
+    return sweep_dispatch(MODE_PAIR, p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// Depth regression family for gfx950: softmax / soft-argmin / confidence, the online
+// exp-sum regression of the slice-recurrent models, depth-hypothesis generation and the
+// bilinear resampling that sits between stages.  All of these are HBM-bound streaming
+// kernels: one lane per output pixel, planes walked in registers, every global access
+// coalesced along x.  Reference citations are in include/deep3d_planesweep.h.
+#include "common.h"
+
+namespace d3d {
+
+// cas_mvsnet.py:69-76.  Two sweeps over D (max, then exp-sums); the 4-plane window is
+// re-read from cache at the end.
+__global__ __launch_bounds__(256) void softargmin_conf4_kernel(const float* __restrict__ cost,
+                                                                const float* __restrict__ depth, int depth_mode,
+                                                                int D, long plane, float* __restrict__ depth_out,
+                                                                float* __restrict__ conf_out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, cost[d * plane + i]);
+    float den = 0.0f, dep = 0.0f, idx = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        float e = __expf(cost[d * plane + i] - mx);
+        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
+        den += e;
+        dep = fmaf(e, dv, dep);
+        idx = fmaf(e, (float)d, idx);
+    }
+    float inv = 1.0f / den;
+    int k = (int)(idx * inv);  // .long() truncation (value >= 0)
+    k = min(max(k, 0), D - 1);
+    float conf = 0.0f;
+#pragma unroll
+    for (int j = -1; j <= 2; ++j) {
+        int kk = k + j;
+        if (kk >= 0 && kk < D) conf += __expf(cost[kk * plane + i] - mx);
+    }
+    depth_out[i] = dep * inv;
+    conf_out[i] = conf * inv;
+}
+
+// adamvs.py:478-486: softmax over D, max prob, expected depth.
+__global__ __launch_bounds__(256) void pair_softmax_max_kernel(const float* __restrict__ score,
+                                                                const float* __restrict__ depth, int depth_mode,
+                                                                int D, long plane, float* __restrict__ view_weight,
+                                                                float* __restrict__ pair_depth) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, score[d * plane + i]);
+    float den = 0.0f, dep = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        float e = __expf(score[d * plane + i] - mx);
+        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
+        den += e;
+        dep = fmaf(e, dv, dep);
+    }
+    float inv = 1.0f / den;
+    view_weight[i] = inv;  // max_d exp(s_d - mx)/den = 1/den
+    pair_depth[i] = dep * inv;
+}
+
+// F.interpolate(bilinear, align_corners=False) source index / weights for one axis.
+__device__ __forceinline__ void lin_coord(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float s = ((float)dst + 0.5f) * scale - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    i0 = (int)s;
+    i0 = min(i0, in_size - 1);
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__device__ __forceinline__ float bilerp(const float* __restrict__ in, int w, int y0, int y1, int x0, int x1,
+                                        float ly, float lx) {
+    float hy = 1.0f - ly, hx = 1.0f - lx;
+    return hy * (hx * in[(long)y0 * w + x0] + lx * in[(long)y0 * w + x1]) +
+           ly * (hx * in[(long)y1 * w + x0] + lx * in[(long)y1 * w + x1]);
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int n, int h, int w,
+                                                               int H, int W, float* __restrict__ out) {
+    int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= W || Y >= H) return;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    lin_coord(Y, (float)h / (float)H, h, y0, y1, ly);
+    lin_coord(X, (float)w / (float)W, w, x0, x1, lx);
+    for (int k = blockIdx.z; k < n; k += gridDim.z)
+        out[((long)k * H + Y) * W + X] = bilerp(in + (long)k * h * w, w, y0, y1, x0, x1, ly, lx);
+}
+
+// adamvs.py:514-525 with the optional depth-plane resample of adamvs.py:519-520 fused in.
+__global__ __launch_bounds__(256) void online_regress_update_kernel(const float* __restrict__ reg,
+                                                                     const float* __restrict__ dplane, int hd,
+                                                                     int wd, int H, int W, float* __restrict__ max_p,
+                                                                     float* __restrict__ sum_d,
+                                                                     float* __restrict__ sum_p) {
+    int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= W || Y >= H) return;
+    long i = (long)Y * W + X;
+    float dv;
+    if (hd == H && wd == W) {
+        dv = dplane[i];
+    } else {
+        int y0, y1, x0, x1;
+        float ly, lx;
+        lin_coord(Y, (float)hd / (float)H, hd, y0, y1, ly);
+        lin_coord(X, (float)wd / (float)W, wd, x0, x1, lx);
+        dv = bilerp(dplane, wd, y0, y1, x0, x1, ly, lx);
+    }
+    float p = __expf(reg[i]);
+    max_p[i] = fmaxf(max_p[i], p);
+    sum_d[i] = fmaf(dv, p, sum_d[i]);
+    sum_p[i] = sum_p[i] + p;
+}
+
+__global__ __launch_bounds__(256) void online_regress_finalize_kernel(const float* __restrict__ max_p,
+                                                                       const float* __restrict__ sum_d,
+                                                                       const float* __restrict__ sum_p, long n,
+                                                                       float* __restrict__ depth_out,
+                                                                       float* __restrict__ conf_out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float e = sum_p[i] + 1e-10f;
+    depth_out[i] = sum_d[i] / e;
+    conf_out[i] = max_p[i] / e;
+}
+
+// module.py:616-650.
+__global__ __launch_bounds__(256) void depth_samples_pixel_kernel(const float* __restrict__ cur, int D,
+                                                                   float interval, long plane,
+                                                                   float* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    float c = cur[i];
+    float half = (float)D / 2.0f * interval;
+    float lo = c - half, hi = c + half;
+    float step = (hi - lo) / (float)(D - 1);
+    for (int d = 0; d < D; ++d) out[d * plane + i] = __fadd_rn(lo, __fmul_rn((float)d, step));
+}
+
+__global__ void depth_samples_plane_kernel(const float* __restrict__ minmax, int D, float* __restrict__ out) {
+    int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float lo = minmax[0], hi = minmax[1];
+    float step = (hi - lo) / (float)(D - 1);
+    out[d] = __fadd_rn(lo, __fmul_rn((float)d, step));
+}
+
+// module.py:24-51 gate math.
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict__ gates,
+                                                         const float* __restrict__ h, int Hc, long plane,
+                                                         float* __restrict__ rh, float* __restrict__ u) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n = (long)Hc * plane;
+    if (i >= n) return;
+    float r = 1.0f / (1.0f + __expf(-gates[i]));
+    float uu = 1.0f / (1.0f + __expf(-gates[n + i]));
+    rh[i] = r * h[i];
+    u[i] = uu;
+}
+
+__global__ __launch_bounds__(256) void gru_update_kernel(const float* __restrict__ u, const float* __restrict__ h,
+                                                          const float* __restrict__ convc, long n,
+                                                          float* __restrict__ h_out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float uu = u[i];
+    h_out[i] = uu * h[i] + (1.0f - uu) * tanhf(convc[i]);
+}
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" {
+
+int d3d_softargmin_conf4(const float* cost, const float* depth, int depth_mode, int D, int h, int w,
+                         float* depth_out, float* conf_out, d3d_stream_t stream) {
+    D3D_REQUIRE(cost && depth && depth_out && conf_out, "null pointer");
+    D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
+    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    long plane = (long)h * w;
+    hipLaunchKernelGGL(softargmin_conf4_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cost,
+                       depth, depth_mode, D, plane, depth_out, conf_out);
+    D3D_LAUNCH_CHECK("softargmin_conf4_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_pair_softmax_max(const float* score, const float* depth, int depth_mode, int D, int h, int w,
+                         float* view_weight, float* pair_depth, d3d_stream_t stream) {
+    D3D_REQUIRE(score && depth && view_weight && pair_depth, "null pointer");
+    D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
+    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    long plane = (long)h * w;
+    hipLaunchKernelGGL(pair_softmax_max_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, score,
+                       depth, depth_mode, D, plane, view_weight, pair_depth);
+    D3D_LAUNCH_CHECK("pair_softmax_max_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_resize_bilinear(const float* in, int n, int h, int w, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && out, "null pointer");
+    D3D_REQUIRE(n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad dims n=%d %dx%d -> %dx%d", n, h, w, H, W);
+    dim3 grid(ceil_div(W, 64), ceil_div(H, 4), n < 64 ? n : 64);
+    D3D_REQUIRE(grid.y <= 65535, "H=%d too large", H);
+    hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, n, h, w, H, W, out);
+    D3D_LAUNCH_CHECK("resize_bilinear_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int wd, int H, int W, float* max_p,
+                              float* sum_d, float* sum_p, d3d_stream_t stream) {
+    D3D_REQUIRE(reg && dplane && max_p && sum_d && sum_p, "null pointer");
+    D3D_REQUIRE(hd > 0 && wd > 0 && H > 0 && W > 0, "bad dims %dx%d -> %dx%d", hd, wd, H, W);
+    dim3 grid(ceil_div(W, 64), ceil_div(H, 4));
+    D3D_REQUIRE(grid.y <= 65535, "H=%d too large", H);
+    hipLaunchKernelGGL(online_regress_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, reg, dplane, hd, wd, H,
+                       W, max_p, sum_d, sum_p);
+    D3D_LAUNCH_CHECK("online_regress_update_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const float* sum_p, int64_t n,
+                                float* depth_out, float* conf_out, d3d_stream_t stream) {
+    D3D_REQUIRE(max_p && sum_d && sum_p && depth_out && conf_out, "null pointer");
+    D3D_REQUIRE(n > 0, "bad n");
+    hipLaunchKernelGGL(online_regress_finalize_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       max_p, sum_d, sum_p, (long)n, depth_out, conf_out);
+    D3D_LAUNCH_CHECK("online_regress_finalize_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_depth_range_samples(const float* cur_depth, int mode, int D, float interval, int h, int w, float* out,
+                            d3d_stream_t stream) {
+    D3D_REQUIRE(cur_depth && out, "null pointer");
+    D3D_REQUIRE(D > 1, "need D > 1 (got %d)", D);
+    if (mode == D3D_DEPTH_PER_PLANE) {
+        hipLaunchKernelGGL(depth_samples_plane_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, (hipStream_t)stream,
+                           cur_depth, D, out);
+    } else if (mode == D3D_DEPTH_PER_PIXEL) {
+        D3D_REQUIRE(h > 0 && w > 0, "bad dims h=%d w=%d", h, w);
+        long plane = (long)h * w;
+        hipLaunchKernelGGL(depth_samples_pixel_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0,
+                           (hipStream_t)stream, cur_depth, D, interval, plane, out);
+    } else {
+        set_error("bad mode %d", mode);
+        return D3D_ERR_INVALID_ARG;
+    }
+    D3D_LAUNCH_CHECK("depth_samples kernel launch");
+    return D3D_OK;
+}
+
+int d3d_gru_gates(const float* gates, const float* h, int Hc, int64_t plane, float* rh, float* u,
+                  d3d_stream_t stream) {
+    D3D_REQUIRE(gates && h && rh && u, "null pointer");
+    D3D_REQUIRE(Hc > 0 && plane > 0, "bad dims");
+    long n = (long)Hc * plane;
+    hipLaunchKernelGGL(gru_gates_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, gates, h, Hc,
+                       (long)plane, rh, u);
+    D3D_LAUNCH_CHECK("gru_gates_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n, float* h_out,
+                   d3d_stream_t stream) {
+    D3D_REQUIRE(u && h && convc && h_out, "null pointer");
+    D3D_REQUIRE(n > 0, "bad n");
+    hipLaunchKernelGGL(gru_update_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, u, h, convc,
+                       (long)n, h_out);
+    D3D_LAUNCH_CHECK("gru_update_kernel launch");
+    return D3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+"""Host-side mirror of the reference operator library (mvs/mvs_cas/models/module.py).
+
+Same public names, argument order and meaning, and the same state_dict keys, so the
+reference's Infer_* drivers and checkpoints carry over -- but the arithmetic of the hot
+path runs in the gfx950 C-ABI kernels (deep3d_aerial_amd.ops).  torch.nn modules are used
+as PARAMETER CONTAINERS (they define the checkpoint layout); their forward()s call the
+HIP kernels.  The image feature pyramids stay on PyTorch-ROCm /
+MIOpen by design: they are upstream of the plane-sweep path.
+
+Everything here requires GPU tensors: there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------------------
+# warp / depth hypotheses (module.py:516-557, 616-650)
+# ----------------------------------------------------------------------------------------
+def compose_batch(proj_matrices):
+    """[B,V,4,4] -> list of B tensors [V-1,12] (module.py:528-530 for every source view)."""
+    return [ops.compose_projections(proj_matrices[b].contiguous()) for b in range(proj_matrices.shape[0])]
+
+
+def homo_warping_float(src_fea, src_proj, ref_proj, depth_values):
+    """module.py:516-557.  src_fea [B,C,H,W]; src_proj, ref_proj [B,4,4];
+    depth_values [B,D] or [B,D,H,W]  ->  [B,C,D,H,W]."""
+    B = src_fea.shape[0]
+    outs = []
+    for b in range(B):
+        p34 = ops.compose_projections(torch.stack([ref_proj[b], src_proj[b]]).contiguous())
+        outs.append(ops.homo_warp(src_fea[b].contiguous(), p34[0], depth_values[b].contiguous()))
+    return torch.stack(outs)
+
+
+def get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth=192.0, min_depth=0.0):
+    """module.py:616-630. cur_depth [B,H,W] -> [B,D,H,W]. (max_depth/min_depth unused, as in the reference.)"""
+    assert tuple(cur_depth.shape) == tuple(shape), "cur_depth:{}, input shape:{}".format(cur_depth.shape, shape)
+    return torch.stack([ops.depth_range_samples(cur_depth[b].contiguous(), ndepth, float(depth_inteval_pixel))
+                        for b in range(cur_depth.shape[0])])
+
+
+def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtype, shape, max_depth=192.0,
+                            min_depth=0.0):
+    """module.py:633-650. cur_depth [B,2]|(B,D) -> [B,D,H,W] tiled linspace; cur_depth [B,H,W] -> per-pixel."""
+    if cur_depth.dim() == 2:
+        planes = torch.stack([ops.depth_range_samples(cur_depth[b].contiguous(), ndepth, 0.0)
+                              for b in range(cur_depth.shape[0])])
+        return planes[:, :, None, None].expand(-1, -1, shape[1], shape[2]).contiguous()
+    return get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth, min_depth)
+
+
+def plane_depths(cur_depth, ndepth):
+    """Stage-1 hypotheses kept as [B,D] (one value per plane) instead of the tiled volume."""
+    return torch.stack([ops.depth_range_samples(cur_depth[b].contiguous(), ndepth, 0.0)
+                        for b in range(cur_depth.shape[0])])
+
+
+# ----------------------------------------------------------------------------------------
+# folded eval-mode BatchNorm
+# ----------------------------------------------------------------------------------------
+def folded_bn(bn):
+    """(scale, shift) with y = x*scale + shift == eval-mode BatchNorm; cached per parameter version."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.device)
+    cache = getattr(bn, "_d3d_fold", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        cache = (key, scale, shift)
+        bn._d3d_fold = cache
+    return cache[1], cache[2]
+
+
+def _no_train(m):
+    if m.training:
+        raise RuntimeError("%s: the MI355X engine implements inference only (call .eval())" % type(m).__name__)
+
+
+# ----------------------------------------------------------------------------------------
+# 3D blocks (module.py:297-304)
+# ----------------------------------------------------------------------------------------
+class ConvBnReLU3D(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        assert kernel_size == 3 and pad == 1 and stride in (1, 2)
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm3d(out_channels)
+        self.stride = stride
+
+    def forward(self, x, skip=None):  # x [C,D,H,W] (unbatched)
+        _no_train(self)
+        s, t = folded_bn(self.bn)
+        return ops.conv3d_k3(x, self.conv.weight, s, t, skip, relu=True, stride=self.stride)
+
+
+# ----------------------------------------------------------------------------------------
+# 2D blocks used by the regularisers (module.py:248-274, 5-51)
+# ----------------------------------------------------------------------------------------
+class ConvBnReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        assert kernel_size == 3 and pad == 1 and stride in (1, 2)
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.stride = stride
+
+    def forward(self, x):  # x [C,H,W]
+        _no_train(self)
+        s, t = folded_bn(self.bn)
+        return ops.conv2d_k3(x, self.conv.weight, s, t, None, act=1, stride=self.stride)
+
+
+class ConvReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        assert kernel_size == 3 and pad == 1 and stride in (1, 2)
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.stride = stride
+
+    def forward(self, x):
+        return ops.conv2d_k3(x, self.conv.weight, None, None, None, act=1, stride=self.stride)
+
+
+class ConvGRUCell(nn.Module):
+    """module.py:5-51.  forward(x [Cx,H,W], h [Ch,H,W]) -> (h', h')."""
+
+    def __init__(self, input_channels, hidden_channels, kernel_size=3):
+        super().__init__()
+        assert kernel_size == 3
+        self.input_channels = input_channels
+        self.hidden_channels = hidden_channels
+        cin = input_channels + hidden_channels
+        self.conv_gates = nn.Sequential(nn.Conv2d(cin, 2 * hidden_channels, 3, stride=1, padding=1, bias=True))
+        self.convc = nn.Sequential(nn.Conv2d(cin, hidden_channels, 3, stride=1, padding=1, bias=True))
+
+    def forward(self, x, h):
+        if h is None:
+            h = torch.zeros((self.hidden_channels,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        g = self.conv_gates[0]
+        gates = ops.conv2d_k3(x, g.weight, None, g.bias, None, act=0, stride=1, x2=h)
+        rh, u = ops.gru_gates(gates, h)
+        c = self.convc[0]
+        cand = ops.conv2d_k3(x, c.weight, None, c.bias, None, act=0, stride=1, x2=rh)
+        out = ops.gru_update(u, h, cand)
+        return out, out
+
+
+# ----------------------------------------------------------------------------------------
+# Image feature pyramids -- PyTorch-ROCm/MIOpen, checkpoint-compatible
+# with module.py:157-245,495-513,653-755.
+# ----------------------------------------------------------------------------------------
+class Conv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class Deconv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 **kwargs):
+        super().__init__()
+        assert stride in (1, 2)
+        self.stride = stride
+        self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn),
+                                       **kwargs)
+        self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+
+    def forward(self, x):
+        y = self.conv(x)
+        if self.stride == 2:
+            y = y[:, :, :2 * x.shape[2], :2 * x.shape[3]].contiguous()
+        if self.bn is not None:
+            y = self.bn(y)
+        return F.relu(y, inplace=True) if self.relu else y
+
+
+class DeConv2dFuse(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, relu=True, bn=True, bn_momentum=0.1):
+        super().__init__()
+        self.deconv = Deconv2d(in_channels, out_channels, kernel_size, stride=2, padding=1, output_padding=1,
+                               bn=True, relu=relu, bn_momentum=bn_momentum)
+        self.conv = Conv2d(2 * out_channels, out_channels, kernel_size, stride=1, padding=1, bn=bn, relu=relu,
+                           bn_momentum=bn_momentum)
+
+    def forward(self, x_pre, x):
+        return self.conv(torch.cat((self.deconv(x), x_pre), dim=1))
+
+
+def _trunk(base):
+    """conv0/conv1/conv2 of both feature nets (module.py:663-679, adamvs.py:59-75)."""
+    conv0 = nn.Sequential(Conv2d(3, base, 3, 1, padding=1), Conv2d(base, base, 3, 1, padding=1))
+    conv1 = nn.Sequential(Conv2d(base, base * 2, 5, stride=2, padding=2), Conv2d(base * 2, base * 2, 3, 1, padding=1),
+                          Conv2d(base * 2, base * 2, 3, 1, padding=1))
+    conv2 = nn.Sequential(Conv2d(base * 2, base * 4, 5, stride=2, padding=2),
+                          Conv2d(base * 4, base * 4, 3, 1, padding=1), Conv2d(base * 4, base * 4, 3, 1, padding=1))
+    return conv0, conv1, conv2
+
+
+class FeatureNet_mvsnet(nn.Module):
+    """module.py:653-755 (the 3-stage 'fpn' and 'unet' variants used at inference)."""
+
+    def __init__(self, base_channels, num_stage=3, stride=4, arch_mode="unet"):
+        super().__init__()
+        assert arch_mode in ("unet", "fpn") and num_stage == 3
+        self.arch_mode, self.stride, self.base_channels, self.num_stage = arch_mode, stride, base_channels, num_stage
+        b = base_channels
+        self.conv0, self.conv1, self.conv2 = _trunk(b)
+        self.out1 = nn.Conv2d(b * 4, b * 4, 1, bias=False)
+        if arch_mode == "unet":
+            self.deconv1 = DeConv2dFuse(b * 4, b * 2, 3)
+            self.deconv2 = DeConv2dFuse(b * 2, b, 3)
+            self.out2 = nn.Conv2d(b * 2, b * 2, 1, bias=False)
+            self.out3 = nn.Conv2d(b, b, 1, bias=False)
+        else:
+            self.inner1 = nn.Conv2d(b * 2, b * 4, 1, bias=True)
+            self.inner2 = nn.Conv2d(b, b * 4, 1, bias=True)
+            self.out2 = nn.Conv2d(b * 4, b * 2, 3, padding=1, bias=False)
+            self.out3 = nn.Conv2d(b * 4, b, 3, padding=1, bias=False)
+        self.out_channels = [4 * b, 2 * b, b]
+
+    def forward(self, x):
+        c0 = self.conv0(x)
+        c1 = self.conv1(c0)
+        c2 = self.conv2(c1)
+        out = {"stage1": self.out1(c2)}
+        if self.arch_mode == "unet":
+            f = self.deconv1(c1, c2)
+            out["stage2"] = self.out2(f)
+            f = self.deconv2(c0, f)
+            out["stage3"] = self.out3(f)
+        else:
+            f = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
+            out["stage2"] = self.out2(f)
+            f = F.interpolate(f, scale_factor=2, mode="nearest") + self.inner2(c0)
+            out["stage3"] = self.out3(f)
+        return out

@@ -1,0 +1,125 @@
+"""Seeded synthetic plane-sweep scenes (cameras, depth range) for tests and bench.py.
+
+The reference ships neither data nor checkpoints, so every parity case
+and the benchmark run on inputs built here.  Projection convention follows the
+reference dataset item builder (datasets/cas_normal_eval.py:138-162): a 4x4 matrix
+whose top three rows are K @ [R|t] (world -> pixel) and whose last row is [0,0,0,1].
+numpy only -- no torch, no GPU.
+"""
+import numpy as np
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def make_scene(n_views, h, w, num_planes, sweep_px=None, depth_min=400.0, depth_max=800.0, focal=None,
+               yaw_deg=1.0, seed=0, scale=1.0):
+    """Cameras for one reference view + (n_views-1) sources at feature resolution h x w.
+
+    The reference camera sits at the origin looking down +z.  Source i is displaced by a
+    baseline chosen so that its disparity changes by about `sweep_px` pixels across
+    [depth_min, depth_max] (default num_planes/2), converged on the
+    mid-depth plane so the sweep is centred in the frame, and rolled by a small yaw.
+
+    Returns proj [n_views,4,4] float32 and depth_values [2] float32 = (depth_min, depth_max).
+    `scale` multiplies the first two rows (the reference's stage scaling, e.g. 0.5, 0.25).
+    """
+    rng = np.random.default_rng(seed)
+    if sweep_px is None:
+        sweep_px = num_planes / 2.0
+    if focal is None:
+        focal = 1.2 * max(h, w)
+    K = np.array([[focal, 0, (w - 1) / 2.0], [0, focal, (h - 1) / 2.0], [0, 0, 1.0]])
+    d_mid = 2.0 / (1.0 / depth_min + 1.0 / depth_max)
+    base = sweep_px / (focal * (1.0 / depth_min - 1.0 / depth_max))
+    dirs = [(1, 0), (-1, 0), (0, 1), (0, -1), (0.7, 0.7), (-0.7, 0.7), (0.7, -0.7), (-0.7, -0.7)]
+    projs = []
+    for v in range(n_views):
+        if v == 0:
+            R, C = np.eye(3), np.zeros(3)
+        else:
+            dx, dy = dirs[(v - 1) % len(dirs)]
+            b = base * (1.0 + 0.15 * rng.standard_normal())
+            C = np.array([dx * b, dy * b, 0.02 * b * rng.standard_normal()])
+            # converge on the point (0,0,d_mid): rotate so that it projects to the principal point
+            ry = np.arctan2(C[0], d_mid)
+            rx = -np.arctan2(C[1], d_mid)
+            rz = np.deg2rad(yaw_deg) * rng.standard_normal()
+            R = _rot(rx, ry, rz)
+        t = -R @ C
+        P = np.eye(4)
+        P[:3, :3] = K @ R
+        P[:3, 3] = K @ t
+        P[:2, :] *= scale
+        projs.append(P)
+    return np.stack(projs).astype(np.float32), np.array([depth_min, depth_max], np.float32)
+
+
+def uniform_depths(depth_values, num_planes):
+    """linspace(min, max, D) as float32 -- the stage-1 hypothesis set (module.py:637-642)."""
+    lo, hi = np.float32(depth_values[0]), np.float32(depth_values[1])
+    step = np.float32((hi - lo) / np.float32(num_planes - 1))
+    return (lo + np.arange(num_planes, dtype=np.float32) * step).astype(np.float32)
+
+
+def make_features(n_views, channels, h, w, seed=0, smooth=False):
+    """N(0,1) features [V,C,h,w] float32 (optionally box-smoothed so they resemble CNN features)."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((n_views, channels, h, w), dtype=np.float32)
+    if smooth:
+        f = (f + np.roll(f, 1, -1) + np.roll(f, 1, -2) + np.roll(np.roll(f, 1, -1), 1, -2)) * 0.5
+    return f
+
+
+def in_frame_fraction(proj, depths, h, w, stride=8):
+    """Fraction of (src, d, y, x) samples whose bilinear footprint touches the source image."""
+    proj = proj.astype(np.float64)
+    ys, xs = np.meshgrid(np.arange(0, h, stride), np.arange(0, w, stride), indexing="ij")
+    pix = np.stack([xs.ravel(), ys.ravel(), np.ones(xs.size)])
+    tot, hit = 0, 0
+    for i in range(1, proj.shape[0]):
+        M = proj[i] @ np.linalg.inv(proj[0])
+        for d in np.asarray(depths, np.float64)[::max(1, len(depths) // 16)]:
+            p = M[:3, :3] @ pix * d + M[:3, 3:4]
+            u, v = p[0] / p[2], p[1] / p[2]
+            ok = (u > -1) & (u < w) & (v > -1) & (v < h) & (p[2] > 0)
+            tot += ok.size
+            hit += int(ok.sum())
+    return hit / max(tot, 1)
+
+
+def fill_state_dict_(state_dict, seed):
+    """Deterministic, reference-independent weights for any module's state_dict (in place).
+
+    Keys are visited in sorted order and filled from numpy's PCG64 stream, so the golden
+    generator (which fills the reference's modules) and the tests (which fill this
+    package's modules with the same keys) obtain identical weights without shipping a
+    checkpoint.  He-style scaling keeps activations O(1) so softmax outputs are not flat.
+    """
+    import torch
+
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for k in sorted(state_dict.keys()):
+            t = state_dict[k]
+            shape = tuple(t.shape)
+            if k.endswith("num_batches_tracked"):
+                continue
+            if k.endswith("running_var"):
+                a = rng.uniform(0.5, 1.5, shape)
+            elif k.endswith("running_mean"):
+                a = 0.1 * rng.standard_normal(shape)
+            elif t.dim() == 1 and k.endswith("weight"):
+                a = rng.uniform(0.5, 1.5, shape)
+            elif t.dim() == 1:
+                a = 0.1 * rng.standard_normal(shape)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                a = rng.standard_normal(shape) * np.sqrt(2.0 / max(fan_in, 1))
+            t.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(shape))
+    return state_dict

@@ -1,0 +1,206 @@
+/*
+ * deep3d_planesweep.h -- C ABI of the MI355X (gfx950) plane-sweep cost-volume engine.
+ *
+ * The reference (gpcv-liujin/Deep3D_Aerial) has no FFI or plugin API for this path
+ * (SURVEY.md F3): its operators are Python functions and nn.Module bodies that call
+ * PyTorch ATen kernels.  Each entry point below therefore replaces one such Python
+ * operator (or one fused group of them) and cites it; the host-side mirror that keeps
+ * the reference's names and argument meaning lives in the deep3d_aerial_amd Python package and binds
+ * these symbols with ctypes (see INTEGRATION.md for the binding a maintainer would add
+ * on the reference side).
+ *
+ * Conventions
+ *   - Plain C: raw DEVICE pointers owned by the caller, explicit sizes, a HIP stream,
+ *     int status.  No torch types, no exceptions across the boundary, no hidden
+ *     synchronisation, no allocation: every call is stream-ordered and reentrant.
+ *   - All tensors are contiguous fp32, batch handled by the caller (the reference runs
+ *     inference at batch 1, predict.py:49):
+ *         features  [C,h,w]      cost volume [C,D,h,w]      maps [h,w] / [D,h,w]
+ *   - Depth hypotheses are given either per plane (depth_mode = D3D_DEPTH_PER_PLANE,
+ *     pointer to [D]) or per pixel (D3D_DEPTH_PER_PIXEL, pointer to [D,h,w]); both are
+ *     accepted by the reference's homo_warping_float (module.py:520-521,539).
+ *   - proj34 is the composed homography of module.py:528-530,
+ *     (src_proj @ inverse(ref_proj))[:3,:4] = [rot | trans], row-major 12 floats per
+ *     source view, in DEVICE memory (d3d_compose_projections produces it).
+ *   - Return value: D3D_OK, or a negative D3D_ERR_*; d3d_last_error() gives the text of
+ *     the calling thread's last failure.
+ *   - Sampling semantics everywhere: bilinear, per-tap zero padding,
+ *     align_corners=True (module.py:548-553).  Samples whose projected
+ *     coordinate is non-finite contribute 0.
+ */
+#ifndef DEEP3D_PLANESWEEP_H
+#define DEEP3D_PLANESWEEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D3D_ABI_VERSION 1
+
+#define D3D_OK 0
+#define D3D_ERR_INVALID_ARG (-1)
+#define D3D_ERR_UNSUPPORTED (-2)
+#define D3D_ERR_HIP (-3)
+
+#define D3D_DEPTH_PER_PLANE 0
+#define D3D_DEPTH_PER_PIXEL 1
+
+#define D3D_MAX_VIEWS 16
+
+/* hipStream_t without dragging HIP headers into C callers. */
+typedef void* d3d_stream_t;
+
+/* ABI version of the loaded library (== D3D_ABI_VERSION it was built with). */
+int d3d_version(void);
+
+/* Text of the calling thread's last error ("" if none). Never NULL. */
+const char* d3d_last_error(void);
+
+/*
+ * module.py:528-530 -- proj = matmul(src_proj, inverse(ref_proj)); rot, trans.
+ * proj44: device [V,4,4] (index 0 = reference view).  out34: device [V-1,12].
+ * The 4x4 inverse and product are evaluated in fp64 on the device and rounded once.
+ */
+int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_stream_t stream);
+
+/*
+ * module.py:516-557 homo_warping_float -- warp ONE source feature map onto D planes.
+ * src [C,h,w] -> out [C,D,h,w].
+ */
+int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int depth_mode, int C, int D, int h,
+                  int w, float* out, d3d_stream_t stream);
+
+/*
+ * cas_mvsnet.py:45-60 (same arithmetic ucsnet.py:119-134, msrednet.py:217-230 and,
+ * with D = 1 per call, msrednet.py:400-414) -- fused warp + variance cost volume:
+ *     sum = ref + SUM_i warp_i ; sq = ref^2 + SUM_i warp_i^2 ; var = sq/V - (sum/V)^2
+ * feats: HOST array of n_views device pointers, feats[0] = reference [C,h,w].
+ * proj34: device [V-1,12].  out: device [C,D,h,w].
+ * Never materialises the warped volumes, sum or sq.
+ */
+int d3d_variance_volume(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                        int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream);
+
+/*
+ * adamvs.py:469-474 -- per-pair channel-mean correlation for the visibility net:
+ *     out[d] = mean_c( ref[c] * warp_d(src)[c] )          ref, src [C,h,w] -> out [D,h,w]
+ */
+int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, const float* depth, int depth_mode,
+                       int C, int D, int h, int w, float* out, d3d_stream_t stream);
+
+/*
+ * adamvs.py:492-509 -- visibility-weighted correlation:
+ *     sim[c,d] = SUM_i (warp_i[c,d] * ref[c]) * vw_i / (1e-5 + SUM_i vw_i)
+ * weights: device [V-1,h,w] at this stage's resolution.  out [C,D,h,w].
+ */
+int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
+                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream);
+
+/*
+ * cas_mvsnet.py:69-76 + module.py:605-613 -- softmax over D, soft-argmin depth and the
+ * 4-plane-window confidence around trunc(SUM_k p_k k):
+ * cost [D,h,w], depth ([D] or [D,h,w]) -> depth_out [h,w], conf_out [h,w].
+ */
+int d3d_softargmin_conf4(const float* cost, const float* depth, int depth_mode, int D, int h, int w,
+                         float* depth_out, float* conf_out, d3d_stream_t stream);
+
+/*
+ * adamvs.py:514-525 (same msrednet.py:418-429) -- one plane of the online regression:
+ *     p = exp(reg); max_p = max(max_p, p); sum_d += d*p; sum_p += p
+ * reg [H,W].  dplane [hd,wd]: the per-pixel depth of this plane; when (hd,wd) != (H,W)
+ * it is resampled bilinearly with align_corners=False (adamvs.py:519-520, the x2 case).
+ * max_p, sum_d, sum_p [H,W] are updated in place (zero them before the first plane).
+ */
+int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int wd, int H, int W, float* max_p,
+                              float* sum_d, float* sum_p, d3d_stream_t stream);
+
+/* adamvs.py:527-529 -- depth = sum_d/(sum_p+1e-10); conf = max_p/(sum_p+1e-10). */
+int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const float* sum_p, int64_t n,
+                                float* depth_out, float* conf_out, d3d_stream_t stream);
+
+/*
+ * module.py:616-650 get_depth_range_samples.
+ * mode D3D_DEPTH_PER_PLANE: cur_depth is [2] = (min,max) -> out [D] = linspace.
+ * mode D3D_DEPTH_PER_PIXEL: cur_depth is [h,w] -> out [D,h,w],
+ *     lo = cur - D/2*interval, hi = cur + D/2*interval, out[k] = lo + k*(hi-lo)/(D-1).
+ */
+int d3d_depth_range_samples(const float* cur_depth, int mode, int D, float interval, int h, int w, float* out,
+                            d3d_stream_t stream);
+
+/*
+ * F.interpolate(mode='bilinear', align_corners=False) for a stack of n maps, as used for
+ * the view weights (adamvs.py:502) and the inter-stage depth hand-off
+ * (cas_mvsnet.py:211-213).  in [n,h,w] -> out [n,H,W].
+ */
+int d3d_resize_bilinear(const float* in, int n, int h, int w, int H, int W, float* out, d3d_stream_t stream);
+
+/*
+ * cas_mvsnet.py:224-226 -- trilinear (align_corners=False) resample of the full
+ * resolution hypothesis volume [D,H,W] to the stage grid [D,h,w]; the depth axis keeps
+ * its size, so this is a per-plane bilinear resize.
+ * Provided as an alias of d3d_resize_bilinear with n = D.
+ */
+
+/*
+ * module.py:297-304 ConvBnReLU3D / cas_mvsnet.py:84-110 -- 3x3x3 convolution, pad 1,
+ * stride 1 or 2, with eval-mode BatchNorm folded to a per-channel affine
+ * (scale, shift; NULL = identity), optional ReLU and optional skip tensor added AFTER
+ * the activation (cas_mvsnet.py:116-118).
+ * in [Ci,D,H,W]; weight [Co,Ci,3,3,3] (nn.Conv3d layout); out [Co,Do,Ho,Wo].
+ */
+int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, const float* shift, const float* skip,
+                  int relu, int Ci, int Co, int D, int H, int W, int stride, float* out, d3d_stream_t stream);
+
+/*
+ * cas_mvsnet.py:94-108 -- ConvTranspose3d k=3, stride 2, padding 1, output_padding 1
+ * (output exactly 2x per axis) + folded BatchNorm + ReLU + skip add.
+ * in [Ci,D,H,W]; weight [Ci,Co,3,3,3] (nn.ConvTranspose3d layout); out [Co,2D,2H,2W].
+ */
+int d3d_convtranspose3d_k3s2(const float* in, const float* weight, const float* scale, const float* shift,
+                             const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                             d3d_stream_t stream);
+
+/*
+ * 2D family used by the slice-recurrent regulariser (adamvs.py:403-427) and the pair
+ * visibility net (adamvs.py:198-238): 3x3 conv pad 1 stride 1|2 over the channel-wise
+ * concatenation of up to two inputs (torch.cat((x,h),1), module.py:30,41), with
+ * per-channel affine (folded BN or bias), activation and optional skip add.
+ * act: 0 none, 1 ReLU.  in1 may be NULL (then Ci1 = 0).
+ * weight [Co,Ci0+Ci1,3,3].
+ */
+int d3d_conv2d_k3(const float* in0, int Ci0, const float* in1, int Ci1, const float* weight, const float* scale,
+                  const float* shift, const float* skip, int act, int Co, int H, int W, int stride, float* out,
+                  d3d_stream_t stream);
+
+/* ConvTranspose2d k=3 stride 2 pad 1 out_pad 1 (adamvs.py:411-414). weight [Ci,Co,3,3].
+ * skip (optional) is added BEFORE the activation here: adamvs.py:424,
+ * relu(upconv1(x) + reg_cost1); set skip_after_act = 1 for the UNet form
+ * (adamvs.py:233-235, conv4 + relu(bn(convT(x)))). */
+int d3d_convtranspose2d_k3s2(const float* in, const float* weight, const float* scale, const float* shift,
+                             const float* skip, int skip_after_act, int act, int Ci, int Co, int H, int W,
+                             float* out, d3d_stream_t stream);
+
+/*
+ * module.py:24-51 ConvGRUCell gate math, fused:
+ *   phase 0: gates [2Hc,H,W] (pre-activation, bias already applied) ->
+ *            r = sigmoid(gates[:Hc]); u = sigmoid(gates[Hc:]); rh = r*h; u stored.
+ *   phase 1: h' = u*h + (1-u)*tanh(convc)   (in place on h allowed)
+ */
+int d3d_gru_gates(const float* gates, const float* h, int Hc, int64_t plane, float* rh, float* u,
+                  d3d_stream_t stream);
+int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n, float* h_out,
+                   d3d_stream_t stream);
+
+/*
+ * adamvs.py:478-486 -- per-pair softmax over D, view weight = max_D prob,
+ * pair depth = SUM_D prob*d.  score [D,h,w], depth [D] or [D,h,w].
+ */
+int d3d_pair_softmax_max(const float* score, const float* depth, int depth_mode, int D, int h, int w,
+                         float* view_weight, float* pair_depth, d3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEP3D_PLANESWEEP_H */

@@ -1,0 +1,400 @@
+"""GPU parity tests: every C-ABI kernel against the CPU oracle on seeded inputs, against the
+committed golden vectors (outputs of the reference itself), and -- at BASELINE.json's full
+size -- through size-independent properties.  All calls go through the C-ABI library
+(deep3d_aerial_amd.ops -> ctypes -> libdeep3d_planesweep.so).
+
+Tolerances (fp32).  north_star asks <= 1e-3 relative L1 on depth/confidence.  The kernels
+are held to much tighter bounds; what remains is coordinate rounding (v_rcp_f32 instead of
+an IEEE divide, no normalise/un-normalise round trip): ~1e-4 px on a sample position,
+which white-noise N(0,1) features (the worst case for a gather) turn into ~3e-4 absolute.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l1
+from deep3d_aerial_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+ABS_GATHER = 1e-3     # max abs error of a warped N(0,1) white-noise feature
+REL_VOLUME = 5e-5     # relative L1 of a whole cost volume
+REL_DEPTH = 1e-5      # relative L1 of regressed depth maps (op level)
+REL_MODEL = 1e-3      # north_star: depth / confidence of a full cascade vs the reference
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from deep3d_aerial_amd import _lib, ops as _ops
+
+    _lib.load()  # raises if the HIP library is missing: no silent fallback
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(params=["auto", "direct", "tiled"])
+def path(request):
+    """Runs a test on the dispatcher's choice and with each kernel family forced."""
+    old = os.environ.get("D3D_FORCE_PATH")
+    if request.param == "auto":
+        os.environ.pop("D3D_FORCE_PATH", None)
+    else:
+        os.environ["D3D_FORCE_PATH"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("D3D_FORCE_PATH", None)
+    else:
+        os.environ["D3D_FORCE_PATH"] = old
+
+
+def _run_or_skip_unsupported(fn, path):
+    try:
+        return fn()
+    except RuntimeError as e:
+        if path == "tiled" and "unsupported" in str(e):
+            pytest.skip("shape outside the tiled kernel's domain (dispatcher uses the direct kernel)")
+        raise
+
+
+# ----------------------------------------------------------------------------------------
+# geometry + warp
+# ----------------------------------------------------------------------------------------
+def test_compose_projections(ops, oracle):
+    for seed in range(4):
+        proj, _ = S.make_scene(5, 96, 80, 16, seed=seed, yaw_deg=5.0)
+        got = host(ops.compose_projections(dev(proj))).reshape(-1, 3, 4)
+        for i in range(4):
+            want = oracle.compose_proj(proj[i + 1], proj[0])
+            assert np.abs(got[i] - want).max() <= 3e-6 * np.abs(want).max()
+    g = load_golden("ops_aggregate")
+    for i in range(int(g["n_cases"])):
+        got = host(ops.compose_projections(dev(g["c%d_proj" % i]))).reshape(-1, 3, 4)
+        want = g["c%d_proj34" % i]
+        assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
+
+
+def test_homo_warp_golden(ops, path):
+    g = load_golden("ops_warp")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        got = _run_or_skip_unsupported(
+            lambda: host(ops.homo_warp(dev(g[k + "src"]), dev(g[k + "proj34"]).reshape(12), dev(g[k + "depth"]))), path)
+        want = g[k + "out"]
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= ABS_GATHER, i
+        # zero padding must be exact zeros, not small numbers
+        far = np.abs(want) == 0
+        assert np.abs(got[far]).max(initial=0.0) <= ABS_GATHER
+
+
+def test_homo_warp_identity_is_copy(ops, path):
+    src = S.make_features(1, 8, 40, 72, seed=3)[0]
+    p34 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(12)
+    depth = np.array([1.0, 2.0, 7.5], np.float32)
+    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(p34), dev(depth))), path)
+    for d in range(3):
+        assert np.array_equal(got[:, d], src)
+
+
+def test_homo_warp_out_of_frustum_and_nonfinite(ops, path):
+    src = np.ones((4, 16, 64), np.float32)
+    depth = np.array([1.0, 2.0], np.float32)
+    shift = np.array([[1, 0, 0, 5000], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(12)  # far right
+    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(shift), dev(depth))), path)
+    assert np.count_nonzero(got) == 0
+    zero_z = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0]], np.float32).reshape(12)  # p.z == 0 -> inf/nan
+    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(zero_z), dev(depth))), path)
+    assert np.isfinite(got).all() and np.count_nonzero(got) == 0
+    # half-pixel shift at the border: partial taps (zero padding per tap)
+    half = np.array([[1, 0, 0, -0.5], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(12)
+    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(half), dev(np.array([1.0], np.float32)))), path)
+    assert np.allclose(got[:, 0, :, 0], 0.5) and np.allclose(got[:, 0, :, 1:], 1.0)
+
+
+# ----------------------------------------------------------------------------------------
+# aggregation kernels vs golden and vs oracle
+# ----------------------------------------------------------------------------------------
+def test_aggregation_golden(ops, path):
+    g = load_golden("ops_aggregate")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        feats = [dev(f) for f in g[k + "feats"]]
+        p34 = dev(g[k + "proj34"]).reshape(-1, 12)
+        depth = dev(g[k + "depth"])
+        var = _run_or_skip_unsupported(lambda: host(ops.variance_volume(feats, p34, depth)), path)
+        assert np.abs(var - g[k + "variance"]).max() <= 2 * ABS_GATHER, i
+        assert rel_l1(var, g[k + "variance"]) <= REL_VOLUME, i
+        wc = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(feats, p34, dev(g[k + "weights"]), depth)), path)
+        assert rel_l1(wc, g[k + "weighted"]) <= REL_VOLUME, i
+        for j in range(len(feats) - 1):
+            pm = _run_or_skip_unsupported(lambda: host(ops.pair_corr_mean(feats[0], feats[j + 1], p34[j], depth)), path)
+            assert np.abs(pm - g[k + "pair_mean"][j]).max() <= ABS_GATHER, (i, j)
+
+
+CASES = [
+    # V, C, h, w, D, depth kind, sweep px, yaw
+    (5, 32, 88, 72, 24, "plane", 12.0, 1.0),
+    (5, 32, 64, 96, 16, "pixel", 8.0, 1.0),
+    (3, 16, 96, 64, 16, "pixel", 6.0, 3.0),
+    (5, 8, 72, 136, 8, "plane", 4.0, 1.0),
+    (7, 32, 48, 80, 12, "plane", 6.0, 8.0),     # stronger rotation
+    (2, 32, 37, 53, 5, "plane", 3.0, 1.0),      # ragged sizes: not multiples of any tile
+    (4, 12, 33, 70, 3, "pixel", 3.0, 25.0),     # odd channel count multiple of 4, big yaw
+    (3, 5, 20, 30, 2, "plane", 2.0, 1.0),       # C not a multiple of 4
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "V%d_C%d_%dx%d_D%d_%s" % c[:6])
+def test_aggregation_vs_oracle(ops, oracle, path, case):
+    V, C, h, w, D, kind, sweep, yaw = case
+    proj, dv = S.make_scene(V, h, w, D, sweep_px=sweep, seed=V * 100 + C, yaw_deg=yaw)
+    feats = S.make_features(V, C, h, w, seed=C + D)
+    rng = np.random.default_rng(D)
+    if kind == "plane":
+        depth = S.uniform_depths(dv, D)
+    else:
+        depth = np.sort(rng.uniform(dv[0], dv[1], (D, h, w)).astype(np.float32), 0)
+    fd = [dev(f) for f in feats]
+    p34 = ops.compose_projections(dev(proj))
+    p34_host = host(p34).reshape(-1, 3, 4)
+    dd = dev(depth)
+
+    var = _run_or_skip_unsupported(lambda: host(ops.variance_volume(fd, p34, dd)), path)
+    want = oracle.variance_volume(feats[0], feats[1:], p34_host, depth)
+    assert np.abs(var - want).max() <= 2 * ABS_GATHER
+    assert rel_l1(var, want) <= REL_VOLUME
+
+    vw = rng.uniform(0.02, 1.0, (V - 1, h, w)).astype(np.float32)
+    wc = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(fd, p34, dev(vw), dd)), path)
+    want = oracle.weighted_corr(feats[0], feats[1:], p34_host, vw, depth)
+    assert rel_l1(wc, want) <= REL_VOLUME
+
+    pm = _run_or_skip_unsupported(lambda: host(ops.pair_corr_mean(fd[0], fd[1], p34[0], dd)), path)
+    want = oracle.pair_corr_mean(feats[0], feats[1], p34_host[0], depth)
+    assert np.abs(pm - want).max() <= ABS_GATHER
+
+    wp = _run_or_skip_unsupported(lambda: host(ops.homo_warp(fd[1], p34[0], dd)), path)
+    want = oracle.homo_warp(feats[1], p34_host[0], depth)
+    assert np.abs(wp - want).max() <= ABS_GATHER
+
+
+def test_variance_of_identical_views_is_zero(ops, path):
+    f = S.make_features(1, 16, 48, 64, seed=9)[0]
+    eye = np.tile(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(1, 12), (3, 1))
+    fd = dev(f)
+    var = _run_or_skip_unsupported(
+        lambda: host(ops.variance_volume([fd, fd, fd, fd], dev(eye), dev(np.array([1.0, 3.0], np.float32)))), path)
+    assert np.abs(var).max() <= 2e-6 * float((f ** 2).max())
+
+
+# ----------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json config 2: 5 views x 384 planes, 32 x 688 x 464)
+# ----------------------------------------------------------------------------------------
+def test_full_size_properties(ops):
+    V, C, h, w, D = 5, 32, 688, 464, 384
+    proj, dv = S.make_scene(V, h, w, D, seed=0)
+    feats = [dev(f) for f in S.make_features(V, C, h, w, seed=0)]
+    p34 = ops.compose_projections(dev(proj))
+    depth = dev(S.uniform_depths(dv, D))
+    out = ops.variance_volume(feats, p34, depth)
+    torch.cuda.synchronize()
+    assert out.shape == (C, D, h, w) and bool(torch.isfinite(out).all())
+    # (1) exact homogeneity: scaling every view by 2 scales the variance by exactly 4 (powers of two)
+    out2 = ops.variance_volume([f * 2 for f in feats], p34, depth)
+    assert bool((out2 == out * 4).all())
+    del out2
+    # (2) a depth sub-range computed alone is bit-identical to the same planes of the full sweep
+    sub = ops.variance_volume(feats, p34, depth[100:116].contiguous())
+    assert bool((sub == out[:, 100:116]).all())
+    # (3) a cropped spot check against the direct kernel (different code path, same arithmetic)
+    os.environ["D3D_FORCE_PATH"] = "direct"
+    try:
+        ref = ops.variance_volume(feats, p34, depth[200:204].contiguous())
+    finally:
+        os.environ.pop("D3D_FORCE_PATH", None)
+    err = (ref - out[:, 200:204]).abs().max().item()
+    assert err <= 1e-5, err
+    # (4) variance is non-negative up to cancellation noise
+    assert out.min().item() >= -1e-4
+
+
+# ----------------------------------------------------------------------------------------
+# regression family
+# ----------------------------------------------------------------------------------------
+def test_softargmin_conf4(ops, oracle):
+    g = load_golden("ops_regress")
+    for i in range(int(g["n_softargmin"])):
+        k = "sa%d_" % i
+        dep, conf = ops.softargmin_conf4(dev(g[k + "cost"]), dev(g[k + "depth_values"]))
+        assert rel_l1(host(dep), g[k + "depth"]) <= REL_DEPTH, i
+        assert np.abs(host(conf) - g[k + "conf"]).max() <= 1e-5, i
+    # larger seeded case against the oracle; the window index truncation is discontinuous, so
+    # pixels whose expected index sits within 1e-3 of an integer are excluded from the conf check
+    rng = np.random.default_rng(5)
+    D, h, w = 48, 40, 56
+    cost = (3 * rng.standard_normal((D, h, w))).astype(np.float32)
+    dmap = np.sort(rng.uniform(400, 800, (D, h, w)).astype(np.float32), 0)
+    dep, conf = ops.softargmin_conf4(dev(cost), dev(dmap))
+    odep, oconf = oracle.softargmin_conf4(cost, dmap)
+    assert rel_l1(host(dep), odep) <= REL_DEPTH
+    p = np.exp(cost - cost.max(0)) / np.exp(cost - cost.max(0)).sum(0)
+    idx = (p * np.arange(D)[:, None, None]).sum(0)
+    safe = np.abs(idx - np.round(idx)) > 1e-3
+    assert safe.mean() > 0.95
+    assert np.abs(host(conf) - oconf)[safe].max() <= 1e-5
+
+
+def test_online_regression(ops, oracle):
+    g = load_golden("ops_regress")
+    for i in range(int(g["n_online"])):
+        k = "on%d_" % i
+        reg, dpl = g[k + "reg"], g[k + "dplanes"]
+        D, H, W = reg.shape
+        mx = torch.zeros(H, W, device="cuda")
+        sd = torch.zeros_like(mx)
+        sp = torch.zeros_like(mx)
+        for d in range(D):
+            ops.online_regress_update(dev(reg[d]), dev(dpl[d]), mx, sd, sp)
+        dep, conf = ops.online_regress_finalize(mx, sd, sp)
+        assert rel_l1(host(dep), g[k + "depth"]) <= REL_DEPTH, i
+        assert rel_l1(host(conf), g[k + "conf"]) <= REL_DEPTH, i
+    # scalar plane broadcast ([1,1] depth plane) equals a constant map
+    reg = np.random.default_rng(1).standard_normal((4, 10, 12)).astype(np.float32)
+    acc = [torch.zeros(10, 12, device="cuda") for _ in range(6)]
+    for d in range(4):
+        ops.online_regress_update(dev(reg[d]), dev(np.full((1, 1), 500.0 + d)), *acc[:3])
+        ops.online_regress_update(dev(reg[d]), dev(np.full((10, 12), 500.0 + d)), *acc[3:])
+    for a, b in zip(acc[:3], acc[3:]):
+        assert torch.equal(a, b)
+
+
+def test_depth_samples_and_resize(ops, oracle):
+    g = load_golden("ops_regress")
+    o0 = host(ops.depth_range_samples(dev(g["dr0_cur"]), 4, 0.0))
+    assert np.array_equal(o0, g["dr0_out"][:, 0, 0])
+    o1 = host(ops.depth_range_samples(dev(g["dr1_cur"]), 8, float(g["dr1_interval"])))
+    assert np.abs(o1 - g["dr1_out"]).max() <= 2.5e-4
+    rng = np.random.default_rng(2)
+    x = rng.uniform(400, 800, (3, 17, 23)).astype(np.float32)
+    for (H, W) in [(34, 46), (68, 92), (17, 23), (8, 11)]:
+        got = host(ops.resize_bilinear(dev(x), H, W))
+        want = np.stack([oracle.resize_bilinear(x[i], H, W) for i in range(3)])
+        assert np.abs(got - want).max() <= 2.5e-4, (H, W)
+
+
+def test_pair_softmax_max(ops):
+    g = load_golden("ops_pairnet")
+    score, dv = g["score"], g["depth_values"]
+    vw, pd = ops.pair_softmax_max(dev(score), dev(dv))
+    assert np.abs(host(vw) - g["view_weight"]).max() <= 1e-6
+    assert rel_l1(host(pd), g["pair_depth"]) <= REL_DEPTH
+
+
+# ----------------------------------------------------------------------------------------
+# regularisers
+# ----------------------------------------------------------------------------------------
+def _fill(mod, seed):
+    S.fill_state_dict_(mod.state_dict(), seed)
+    return mod.cuda().eval()
+
+
+def test_conv_primitives_vs_oracle(ops, oracle):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((5, 6, 10, 14)).astype(np.float32)
+    w3 = (0.2 * rng.standard_normal((7, 5, 3, 3, 3))).astype(np.float32)
+    for stride in (1, 2):
+        got = host(ops.conv3d_k3(dev(x), dev(w3), relu=False, stride=stride))
+        want = oracle.conv3d_k3(x, w3, stride=stride)
+        assert np.abs(got - want).max() <= 1e-5, stride
+    wt = (0.2 * rng.standard_normal((5, 3, 3, 3, 3))).astype(np.float32)
+    got = host(ops.convtranspose3d_k3s2(dev(x), dev(wt), relu=False))
+    assert np.abs(got - oracle.convtranspose3d_k3s2(x, wt)).max() <= 1e-5
+    x2 = rng.standard_normal((6, 12, 18)).astype(np.float32)
+    h2 = rng.standard_normal((3, 12, 18)).astype(np.float32)
+    w2 = (0.2 * rng.standard_normal((4, 9, 3, 3))).astype(np.float32)
+    b2 = rng.standard_normal(4).astype(np.float32)
+    for stride in (1, 2):
+        got = host(ops.conv2d_k3(dev(x2), dev(w2), None, dev(b2), None, act=0, stride=stride, x2=dev(h2)))
+        want = oracle.conv2d_k3(np.concatenate([x2, h2]), w2, b2, stride=stride)
+        assert np.abs(got - want).max() <= 1e-5
+    wt2 = (0.2 * rng.standard_normal((6, 2, 3, 3))).astype(np.float32)
+    got = host(ops.convtranspose2d_k3s2(dev(x2), dev(wt2)))
+    assert np.abs(got - oracle.convtranspose2d_k3s2(x2, wt2)).max() <= 1e-5
+
+
+def test_costregnet3d_golden(ops):
+    from deep3d_aerial_amd.cas_mvsnet import CostRegNet
+
+    g = load_golden("ops_costreg3d")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        x = g[k + "x"]
+        net = _fill(CostRegNet(x.shape[0], 8), int(g[k + "seed"]))
+        with torch.no_grad():
+            y = host(net(dev(x)[None])[0])
+        assert rel_l1(y, g[k + "y"]) <= 2e-5, i
+
+
+def test_slice_gru_golden(ops):
+    from deep3d_aerial_amd.adamvs import SliceCostRegNetRED
+
+    g = load_golden("ops_gru")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        costs = g[k + "costs"]
+        up = bool(int(g[k + "up"]))
+        C, h, w = costs.shape[1:]
+        net = _fill(SliceCostRegNetRED(C, up, 8), int(g[k + "seed"]))
+        s1 = torch.zeros(8, h, w, device="cuda")
+        s2 = torch.zeros(16, h // 2, w // 2, device="cuda")
+        with torch.no_grad():
+            for t in range(costs.shape[0]):
+                reg, s1, s2 = net(dev(costs[t]), s1, s2)
+                assert np.abs(host(reg) - g[k + "regs"][t]).max() <= 3e-4, (i, t)
+        assert np.abs(host(s1) - g[k + "state1"]).max() <= 1e-4
+        assert np.abs(host(s2) - g[k + "state2"]).max() <= 1e-4
+
+
+def test_pairnet_golden(ops):
+    from deep3d_aerial_amd.adamvs import CostRegNet2D
+
+    g = load_golden("ops_pairnet")
+    net = _fill(CostRegNet2D(48, 8), int(g["seed"]))
+    with torch.no_grad():
+        score = host(net(dev(g["x"])))
+    assert rel_l1(score, g["score"]) <= 2e-5
+
+
+# ----------------------------------------------------------------------------------------
+# full cascades behind the reference's forward() contract, vs the reference's own outputs
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "model_adamvs_v5"])
+def test_model_forward_matches_reference(ops, tag):
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+    from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+
+    g = load_golden(tag)
+    ctor = Infer_CascadeMVSNet if "casmvsnet" in tag else Infer_AdaMVSNet
+    net = _fill(ctor(num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    with torch.no_grad():
+        out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    assert out["depth"].shape == (1,) + g["depth"].shape
+    for s in ("stage1", "stage2", "stage3"):
+        assert rel_l1(host(out[s]["depth"][0]), g[s + "_depth"]) <= REL_MODEL, s
+        assert rel_l1(host(out[s]["photometric_confidence"][0]), g[s + "_conf"]) <= 5 * REL_MODEL, s
+    assert rel_l1(host(out["depth"][0]), g["depth"]) <= REL_MODEL
+    assert rel_l1(host(out["photometric_confidence"][0]), g["photometric_confidence"]) <= 5 * REL_MODEL
+    if "adamvs" in tag:
+        vw = torch.stack([t[0, 0] for t in out["stage1"]["pair_confidence"]])
+        assert rel_l1(host(vw), g["stage1_view_weights"]) <= REL_MODEL
