@@ -32,7 +32,7 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // Geometry shared by every warp kernel.  module.py:532-546: p = (rot@[x,y,1])*d + trans,
 // (u,v) = p.xy/p.z, sampled bilinearly with align_corners=True so (u,v) are pixel
 // coordinates directly.  The multiply and add are kept as two roundings like the
-// reference's `rot_depth_xyz + trans`; the divide is a v_rcp_f32 (1 ulp).
+// reference's `rot_depth_xyz + trans`; the divide is v_rcp_f32 plus one Newton step.
 // ---------------------------------------------------------------------------------------
 struct Ray {  // rot @ [x,y,1] for one (pixel, source view)
     float rx, ry, rz;
@@ -53,9 +53,13 @@ __device__ __forceinline__ void project(const Ray& r, float tx, float ty, float 
     float px = __fadd_rn(__fmul_rn(r.rx, d), tx);
     float py = __fadd_rn(__fmul_rn(r.ry, d), ty);
     float pz = __fadd_rn(__fmul_rn(r.rz, d), tz);
+    // quotient = v_rcp_f32 estimate + one Newton correction: correctly rounded in practice, so
+    // integer-aligned homographies (identity, whole-pixel shifts) reproduce exact copies as the
+    // reference's IEEE divide does.
     float iz = __builtin_amdgcn_rcpf(pz);
-    u = px * iz;
-    v = py * iz;
+    float u0 = px * iz, v0 = py * iz;
+    u = fmaf(fmaf(-u0, pz, px), iz, u0);
+    v = fmaf(fmaf(-v0, pz, py), iz, v0);
     bool ok = (u > -2.0f) && (u < (float)w + 1.0f) && (v > -2.0f) && (v < (float)h + 1.0f);
     u = ok ? u : -2.0f;
     v = ok ? v : -2.0f;

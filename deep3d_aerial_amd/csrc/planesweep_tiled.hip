@@ -1,8 +1,847 @@
-// LDS-tiled plane-sweep kernels (placeholder until the tiled path lands: always defers to
-// the direct kernel).
+// LDS-tiled plane-sweep kernel for gfx950 (MI355X): the fast path behind d3d_variance_volume,
+// d3d_weighted_corr, d3d_pair_corr_mean and d3d_homo_warp.
+//
+// Why a tiled kernel: per voxel and source view a bilinear sample touches 4 taps x C channels
+// (2 KB per voxel at C = 32, V = 5) while only 4*C bytes are written, so the gather must not
+// go to L2 -- it is served from LDS.  Design (numbers in DESIGN.md):
+//
+//   * One workgroup (10 compute + 2 loader waves) = a 32 x 4 patch of reference pixels x a segment
+//     of depth planes x a group of CH channels.  It walks the segment in STEPS of SP = NSUB*m
+//     planes: compute wave (pw, sub) owns two patch rows and the planes d = step*SP + sub + NSUB*j.
+//   * The source footprint of (patch x step) is bounded per view by projecting the 8 corners of
+//     the frustum slab (valid because the map is projective and p.z > 0 at every corner).  All
+//     step windows of the segment are planned ONCE in the prologue, one lane per step.
+//   * Each view owns a RING in LDS: a torus of RW x RH positions, channel-last
+//     ([position][CH+4 floats]; the +4 pad spreads ds_read_b128 over all 64 banks), with column
+//     RW and row RH duplicating column 0 and row 0 so that the east/south taps never wrap.
+//     Moving to the next step only stages the thin L-shaped difference of consecutive windows.
+//     RW/RH are at least the span of the UNION of any two consecutive windows, so the slots
+//     that difference lands in are never part of the window being read: the loader waves
+//     write step k+1's difference while the compute waves work on step k, and one barrier per
+//     step is the only synchronisation.  Compute waves never wait on a global load.  Positions
+//     outside the source image are staged as zeros (= per-tap zero padding).
+//   * Compute: a lane owns one reference pixel and CH channels.  Per plane it does the geometry
+//     ONCE per view (3 mul/add, rcp + Newton, floor/fract, window test, ring address) and then,
+//     per channel quad and view, four ds_read_b128 feed 4 x (4 interpolation + 2 accumulation)
+//     VALU ops; the reads of the next (quad, view) unit are issued before the current one is
+//     blended.  Lanes are permuted so that each hardware ds_read_b128 lane group covers 16
+//     consecutive pixels (conflict-free for unit-scale sweeps).  Results leave as 128-byte row
+//     segments per (channel, plane) -- full-line HBM writes -- through scalar-base stores.
+//   * If the rings cannot be made to fit (p.z <= 0 at a corner, extreme scale/rotation) the
+//     workgroup runs the same loop nest with taps gathered from global memory instead.
+//
+// Nothing is reshaped into a GEMM: this is HBM-write-bound streaming work with an LDS-fed
+// gather, not MFMA work.
 #include "common.h"
 #include "sweep_params.h"
 
+#include <cstdlib>
+
 namespace d3d {
-int launch_tiled(int, const SweepParams&, hipStream_t) { return D3D_ERR_UNSUPPORTED; }
+
+namespace {
+
+constexpr int TW = 32;          // patch width  (one 128-byte output row segment per lane-row)
+constexpr int TH = 4;           // patch height
+constexpr int NPIXW = 2;        // pixel waves (2 patch rows each)
+constexpr int NSUB = 4;         // depth sub-ranges
+constexpr int NCOMP = NPIXW * NSUB;  // compute waves
+constexpr int NLOADW = 4;       // loader waves: stage the next step's window delta into the rings
+constexpr int NWAVES = NCOMP + NLOADW;  // 12 waves: 3 per SIMD, 168-VGPR budget
+constexpr int THREADS = 64 * NWAVES;
+constexpr int DSEG_MAX = 384;   // planes per workgroup segment upper bound
+constexpr int MAXSTEPS = 64;    // >= DSEG_MAX / NSUB, <= 64 (one lane per step)
+constexpr int PFD = 2;          // delta staging items (64 positions x CH channels) a loader wave keeps in flight
+constexpr int MAXRECTS = 256;   // non-empty delta rectangles per workgroup segment
+
+struct TiledArgs {
+    int ngroups;     // channel groups (C / CH), one workgroup pass each
+    int dseg;        // planes per workgroup segment
+    int cap_floats;  // floats available for the rings
+    int nseg;        // segments along depth
+    int tiles_x, tiles_y;
+    unsigned long long* tstats;  // debug timing (cycles, wave 0): [0] prologue [1] barrierA+write+barrierB [2] issue [3] compute [4] total
+    unsigned* stats;  // debug (D3D_TILED_STATS): [0] ring wgs [1] fallback wgs [2] sum m [3] sum nsteps [4] sum ring floats [5] overflow items
+};
+
+// LDS map (ints/floats):
+//   [zero cell 2*STRIDE][pmin DSEG_MAX][pmax DSEG_MAX][header 32][plan table MAXSTEPS*NSRC*8]
+//   [rect starts MAXSTEPS+4][rect descriptors MAXRECTS*8][rings ...]
+// header: 0 mode (1 rings, 0 global gather) | 1 m | 2 nsteps | 4+4i.. RW, RH, base, - per view
+// plan entry (per step, view): wx0, wy0, ww, wh, ox, oy, -, -
+// rect descriptor (non-empty delta rectangles, grouped by step): rx, ry, rw | view<<16, elements,
+//   first item (within the step), step item total (last rect of a step only),
+//   ring col | row << 16 of the rect origin (unwrapped), ring base | RW << 18 | RH << 25 ... see item()
+template <int CH, int NSRC>
+struct Lds {
+    static constexpr int STRIDE = CH + 4;
+    static constexpr int ZERO = 0;
+    static constexpr int PMIN = 2 * STRIDE;
+    static constexpr int PMAX = PMIN + DSEG_MAX;
+    static constexpr int HDR = PMAX + DSEG_MAX;
+    static constexpr int PLAN = HDR + 32;
+    static constexpr int SST = PLAN + MAXSTEPS * NSRC * 8;
+    static constexpr int RECTS = ((SST + MAXSTEPS + 4 + 3) / 4) * 4;
+    static constexpr int DATA = RECTS + (MAXRECTS + 1) * 8;  // 16-byte aligned
+};
+
+struct Win {  // wave-uniform window of one view at one step
+    int x0, y0, w, h, ox, oy;
+};
+
+struct Rects {  // window(k) minus window(k-1): left | right | top | bottom (any may be empty)
+    int rx[4], ry[4], rw[4], rh[4], start[5];
+};
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_maxi(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int posmod(int a, int n) {
+    int r = a % n;
+    return r < 0 ? r + n : r;
+}
+
+// Per-view sample geometry against the ring.
+struct TapL {
+    int a0, a1;            // byte addresses of the north / south tap rows (west tap; east = +STRIDE*4)
+    float nw, ne, sw, se;  // bilinear weights (taps outside the image are zeros in LDS)
+};
+
+template <int STRIDE>
+__device__ __forceinline__ TapL make_tap_ring(float u, float v, const Win& W, int RW, int RH, int base_bytes) {
+    TapL t;
+    float fu = floorf(u), fv = floorf(v);
+    float ax = u - fu, ay = v - fv;
+    float bx = (fu + 1.0f) - u, by = (fv + 1.0f) - v;
+    t.nw = bx * by;
+    t.ne = ax * by;
+    t.sw = bx * ay;
+    t.se = ax * ay;
+    int cx = (int)fu - W.x0, cy = (int)fv - W.y0;
+    // W.w == 0 (empty / unused view) must reject everything: max() keeps the unsigned bound at 0
+    bool in = ((unsigned)cx < (unsigned)max(W.w - 1, 0)) && ((unsigned)cy < (unsigned)max(W.h - 1, 0));
+    unsigned c = (unsigned)(cx + W.ox), r = (unsigned)(cy + W.oy);
+    c = min(c, c - (unsigned)RW);  // one conditional wrap: cx < RW and ox < RW
+    r = min(r, r - (unsigned)RH);
+    const int rowb = (RW + 1) * (STRIDE * 4);
+    int a = base_bytes + (int)r * rowb + (int)c * (STRIDE * 4);
+    t.a0 = in ? a : 0;  // zero cell: two all-zero positions at LDS offset 0
+    t.a1 = in ? a + rowb : 0;
+    return t;
+}
+
+// Global-memory variant (fallback workgroups).
+struct TapG {
+    int off, dx, dyw;
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ TapG make_tap_glb(float u, float v, int h, int w) {
+    TapG t;
+    float fu = floorf(u), fv = floorf(v);
+    int x0 = (int)fu, y0 = (int)fv;
+    float ax = u - fu, ay = v - fv;
+    float bx = (fu + 1.0f) - u, by = (fv + 1.0f) - v;
+    bool vx0 = (x0 >= 0) && (x0 < w), vx1 = (x0 >= -1) && (x0 < w - 1);
+    bool vy0 = (y0 >= 0) && (y0 < h), vy1 = (y0 >= -1) && (y0 < h - 1);
+    t.nw = (vx0 && vy0) ? bx * by : 0.0f;
+    t.ne = (vx1 && vy0) ? ax * by : 0.0f;
+    t.sw = (vx0 && vy1) ? bx * ay : 0.0f;
+    t.se = (vx1 && vy1) ? ax * ay : 0.0f;
+    int x0c = min(max(x0, 0), w - 1), x1c = min(max(x0 + 1, 0), w - 1);
+    int y0c = min(max(y0, 0), h - 1), y1c = min(max(y0 + 1, 0), h - 1);
+    t.off = y0c * w + x0c;
+    t.dx = x1c - x0c;
+    t.dyw = (y1c - y0c) * w;
+    return t;
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 lds_read4(const float* lds, int byte_addr) {
+    return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(lds) + byte_addr);
+}
+
+// same summation order as grid_sample: nw, ne, sw, se
+__device__ __forceinline__ f4 blend(f4 t00, f4 t01, f4 t10, f4 t11, float nw, float ne, float sw, float se) {
+    f4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = fmaf(t11[k], se, fmaf(t10[k], sw, fmaf(t01[k], ne, t00[k] * nw)));
+    return r;
+}
+
+// Store with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit
+// VALU address arithmetic per store.  Stores are never waited on inside the kernel.
+__device__ __forceinline__ void store_sbase(const char* base_uniform, unsigned byte_off, float v) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base_uniform);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    // no "memory" clobber: nothing in the kernel reads the output, and a clobber would stop the
+    // scheduler from hoisting the next unit's LDS reads above these stores
+#ifdef D3D_NOSTORE  // timing experiment build: keep the value alive, skip the store
+    asm volatile("" : : "v"(byte_off), "v"(v), "s"(sb));
+#else
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(sb));
+#endif
+}
+
+}  // namespace
+
+template <int MODE, int NSRC, int CH>
+__global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {
+    using L = Lds<CH, NSRC>;
+    constexpr int STRIDE = L::STRIDE;
+    constexpr int Q = CH / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* ldsi = reinterpret_cast<int*>(lds);
+
+    const long long t_start = clock64();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const bool loader = wave >= NCOMP;
+    const int lw = wave - NCOMP;                 // loader index
+    const int pw = (wave % NCOMP) % NPIXW;       // which pair of patch rows
+    const int sub = (wave % NCOMP) / NPIXW;      // depth sub-range
+    const int h = p.h, w = p.w, D = p.D;
+    const size_t plane = (size_t)h * w;
+
+    // block -> (segment, channel group, tile).  Blocks b, b+8, ... share an XCD (and its L2):
+    // give each XCD a contiguous run so neighbouring segments/patches reuse source lines there.
+    int b = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int per = nblk / 8;
+        if (nblk % 8 == 0) b = (b % 8) * per + b / 8;
+    }
+    const int seg = b % a.nseg;
+    const int grp = (b / a.nseg) % a.ngroups;
+    const int tile = b / (a.nseg * a.ngroups);
+    const int c0 = grp * CH;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int ds = seg * a.dseg;
+    const int de = min(ds + a.dseg, D);
+    const int nplanes = de - ds;
+    const int x1c = min(x0 + TW - 1, w - 1), y1c = min(y0 + TH - 1, h - 1);
+
+    // Lane -> pixel.  ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and
+    // {4-11,16-19,28-31} (+32): map each group to 16 consecutive pixels so that a unit-scale sweep
+    // puts its 16 lanes on 16 distinct 16-byte bank slots.  Quads of lanes stay on 4 consecutive
+    // pixels, so global stores still coalesce into the same 128-byte row segments.
+    const int l5 = lane & 31;
+    const int pxl = (l5 < 4) ? l5 : (l5 < 12) ? l5 + 12 : (l5 < 16) ? l5 - 8 : (l5 < 20) ? l5 + 8 : (l5 < 28) ? l5 - 12 : l5;
+    const int px = x0 + pxl;
+    const int py = y0 + pw * 2 + (lane >> 5);
+    const bool valid = (px < w) && (py < h);
+    const int pix = valid ? py * w + px : 0;
+    const unsigned pixb = (unsigned)pix * 4u;  // per-lane byte offset (h*w < 2^30)
+    const float xf = (float)px, yf = (float)py;
+
+    // --- zero cell and per-plane depth range of this patch -------------------------------------
+    for (int i = tid; i < 2 * STRIDE; i += THREADS) lds[L::ZERO + i] = 0.0f;
+    if (p.depth_mode == D3D_DEPTH_PER_PLANE) {
+        for (int i = tid; i < nplanes; i += THREADS) {
+            float dv = p.depth[ds + i];
+            lds[L::PMIN + i] = dv;
+            lds[L::PMAX + i] = dv;
+        }
+    } else {
+        for (int i = wave; i < nplanes; i += NWAVES) {
+            float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < (TW * TH) / 64; ++k) {
+                int q = lane + 64 * k;
+                int qx = x0 + (q & 31), qy = y0 + (q >> 5);
+                if (qx < w && qy < h) {
+                    float dv = p.depth[(size_t)(ds + i) * plane + (size_t)qy * w + qx];
+                    lo = fminf(lo, dv);
+                    hi = fmaxf(hi, dv);
+                }
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if (lane == 0) {
+                lds[L::PMIN + i] = lo;
+                lds[L::PMAX + i] = hi;
+            }
+        }
+    }
+    __syncthreads();
+
+    // --- plan every step of the segment (wave 0, one lane per step) ----------------------------
+    if (wave == 0) {
+        int mode = 0, m_sel = 1, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
+        for (int m = 4; m >= 1 && !mode; m >>= 1) {
+            const int SP = NSUB * m;
+            const int nsteps = (nplanes + SP - 1) / SP;
+            if (nsteps > MAXSTEPS) continue;
+            const bool act = lane < nsteps;
+            const int p0 = min(lane * SP, nplanes - 1), p1 = min(lane * SP + SP, nplanes);
+            float lo = INFINITY, hi = -INFINITY;
+            for (int i = p0; i < p1; ++i) {
+                lo = fminf(lo, lds[L::PMIN + i]);
+                hi = fmaxf(hi, lds[L::PMAX + i]);
+            }
+            int wx0[NSRC], wy0[NSRC], ww[NSRC], wh[NSRC], RW[NSRC], RH[NSRC];
+            int bad = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) {
+                const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
+                float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+                bool ok = true;
+#pragma unroll
+                for (int ck = 0; ck < 8; ++ck) {
+                    Ray cr = make_ray(M, (ck & 1) ? (float)x1c : (float)x0, (ck & 2) ? (float)y1c : (float)y0);
+                    const float dv = (ck & 4) ? hi : lo;
+                    float qx = __fadd_rn(__fmul_rn(cr.rx, dv), M[3]);
+                    float qy = __fadd_rn(__fmul_rn(cr.ry, dv), M[7]);
+                    float qz = __fadd_rn(__fmul_rn(cr.rz, dv), M[11]);
+                    ok = ok && (qz > 1e-20f) && (qz < 1e30f);
+                    float iz = 1.0f / qz;
+                    float u = qx * iz, v = qy * iz;
+                    ok = ok && (fabsf(u) < 1e30f) && (fabsf(v) < 1e30f);
+                    // clamp before the float->int conversion; windows are clipped to the image plus a zero ring
+                    u = fminf(fmaxf(u, -8.0f), (float)w + 8.0f);
+                    v = fminf(fmaxf(v, -8.0f), (float)h + 8.0f);
+                    umin = fminf(umin, u); umax = fmaxf(umax, u);
+                    vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+                }
+                // interior samples differ from the corner hull by fp32 rounding only (<< 1/16 px)
+                wx0[i] = max((int)floorf(umin - 0.0625f), -1);
+                wy0[i] = max((int)floorf(vmin - 0.0625f), -1);
+                int wx1 = min((int)floorf(umax + 0.0625f) + 1, w);
+                int wy1 = min((int)floorf(vmax + 0.0625f) + 1, h);
+                ww[i] = max(wx1 - wx0[i] + 1, 0);
+                wh[i] = max(wy1 - wy0[i] + 1, 0);
+                if (ww[i] < 2 || wh[i] < 2) { ww[i] = 0; wh[i] = 0; }  // nothing of the image is touched
+                if (i >= p.n_src || !act) { ww[i] = 0; wh[i] = 0; ok = true; }
+                bad |= ok ? 0 : 1;  // frustum reaches p.z <= 0: cannot bound it
+                // ring size: the union of consecutive windows must fit (asynchronous delta staging)
+                int ux = ww[i], uy = wh[i];
+                {
+                    const int qx0 = __shfl_up(wx0[i], 1), qy0 = __shfl_up(wy0[i], 1);
+                    const int qw = __shfl_up(ww[i], 1), qh = __shfl_up(wh[i], 1);
+                    if (lane > 0 && act && qw > 0 && ww[i] > 0) {
+                        ux = max(wx0[i] + ww[i], qx0 + qw) - min(wx0[i], qx0);
+                        uy = max(wy0[i] + wh[i], qy0 + qh) - min(wy0[i], qy0);
+                    }
+                }
+                RW[i] = max(wave_maxi(ux), 1);
+                RH[i] = max(wave_maxi(uy), 1);
+                total += (RW[i] + 1) * (RH[i] + 1) * STRIDE;
+            }
+            bad = __any(bad) ? 1 : 0;
+            if (!bad && total <= a.cap_floats) {
+                mode = 1;
+                m_sel = m;
+                nsteps_sel = nsteps;
+                int base = L::DATA;
+                int oxv[NSRC], oyv[NSRC], basev[NSRC];
+                bool dims_ok = true;
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    // ring coordinates are taken relative to the first step's window origin
+                    const int cx0 = __shfl(wx0[i], 0), cy0 = __shfl(wy0[i], 0);
+                    oxv[i] = posmod(wx0[i] - cx0, RW[i]);
+                    oyv[i] = posmod(wy0[i] - cy0, RH[i]);
+                    basev[i] = base;
+                    dims_ok = dims_ok && RW[i] < 256 && RH[i] < 256;
+                    if (act) {
+                        int* e = ldsi + L::PLAN + (lane * NSRC + i) * 8;
+                        e[0] = wx0[i]; e[1] = wy0[i]; e[2] = ww[i]; e[3] = wh[i];
+                        e[4] = oxv[i];
+                        e[5] = oyv[i];
+                    }
+                    if (lane == 0) {
+                        ldsi[L::HDR + 4 + 4 * i + 0] = RW[i];
+                        ldsi[L::HDR + 4 + 4 * i + 1] = RH[i];
+                        ldsi[L::HDR + 4 + 4 * i + 2] = base;
+                    }
+                    base += (RW[i] + 1) * (RH[i] + 1) * STRIDE;
+                }
+                // ---- staging items of every step: window(k) minus window(k-1) as <= 4 rectangles per
+                // view, cut into items of 64 positions (all CH channels of the group).
+                int cnt[NSRC][4], rx[NSRC][4], ry[NSRC][4], rwid[NSRC][4], nel[NSRC][4];
+                int T = 0;
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    const int xa = wx0[i], xb = wx0[i] + ww[i] - 1, ya = wy0[i], yb = wy0[i] + wh[i] - 1;
+                    const int pxa = __shfl_up(wx0[i], 1), pya = __shfl_up(wy0[i], 1);
+                    const int pxb = pxa + __shfl_up(ww[i], 1) - 1, pyb = pya + __shfl_up(wh[i], 1) - 1;
+                    int ix0 = 1, ix1 = 0, iy0 = 1, iy1 = 0;  // intersection with the previous window
+                    if (lane > 0) { ix0 = max(xa, pxa); ix1 = min(xb, pxb); iy0 = max(ya, pya); iy1 = min(yb, pyb); }
+                    const bool ov = (ix0 <= ix1) && (iy0 <= iy1);
+                    // left | right | top | bottom; without overlap "left" is the whole window
+                    int rh_[4];
+                    rx[i][0] = xa;      ry[i][0] = ya;      rwid[i][0] = (ov ? ix0 - 1 : xb) - xa + 1; rh_[0] = wh[i];
+                    rx[i][1] = ix1 + 1; ry[i][1] = ya;      rwid[i][1] = ov ? xb - ix1 : 0;             rh_[1] = wh[i];
+                    rx[i][2] = ix0;     ry[i][2] = ya;      rwid[i][2] = ov ? ix1 - ix0 + 1 : 0;        rh_[2] = ov ? iy0 - ya : 0;
+                    rx[i][3] = ix0;     ry[i][3] = iy1 + 1; rwid[i][3] = ov ? ix1 - ix0 + 1 : 0;        rh_[3] = ov ? yb - iy1 : 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        nel[i][r] = act ? max(rwid[i][r], 0) * max(rh_[r], 0) : 0;
+                        cnt[i][r] = (nel[i][r] + 63) >> 6;
+                        T += cnt[i][r];
+                    }
+                }
+                int nrect = 0;
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nrect += cnt[i][r] > 0 ? 1 : 0;
+                int incl = nrect;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    int o = __shfl_up(incl, sft);
+                    if (lane >= sft) incl += o;
+                }
+                const int total_rects = __shfl(incl, 63);
+                if (total_rects > MAXRECTS || !dims_ok) {
+                    mode = 0;  // cannot describe the staging work: gather from global memory instead
+                } else {
+                    int idx = incl - nrect;
+                    if (act) ldsi[L::SST + lane] = idx;
+                    if (lane == nsteps - 1) ldsi[L::SST + nsteps] = incl;
+                    int istart = 0;
+#pragma unroll
+                    for (int i = 0; i < NSRC; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (cnt[i][r] > 0) {
+                                int* e = ldsi + L::RECTS + 8 * idx;
+                                e[0] = rx[i][r];
+                                e[1] = ry[i][r];
+                                e[2] = rwid[i][r] | (i << 16);
+                                e[3] = nel[i][r];
+                                e[4] = istart;
+                                // ring coordinates of the rect origin (unwrapped: < 2*RW, 2*RH) and ring geometry
+                                e[6] = (rx[i][r] - wx0[i] + oxv[i]) | ((ry[i][r] - wy0[i] + oyv[i]) << 16);
+                                e[7] = RW[i] | (RH[i] << 8) | ((basev[i] >> 2) << 16);
+                                istart += cnt[i][r];
+                                ++idx;
+                            }
+                    // item total of the step, readable as "first item" of the following entry; the next
+                    // step's first rect overwrites e[4] with 0, so keep the total in slot 5 of the LAST rect too
+                    if (act && nrect > 0) ldsi[L::RECTS + 8 * (idx - 1) + 5] = istart;
+                }
+            }
+        }
+        if (lane == 0) {
+            ldsi[L::HDR + 0] = mode;
+            ldsi[L::HDR + 1] = m_sel;
+            ldsi[L::HDR + 2] = nsteps_sel;
+        }
+    }
+    __syncthreads();
+    const int ring = rfl(ldsi[L::HDR + 0]);
+    const int mplanes = rfl(ldsi[L::HDR + 1]);
+    const int nsteps = rfl(ldsi[L::HDR + 2]);
+    const int SP = NSUB * mplanes;
+    if (a.stats && tid == 0) {
+        atomicAdd(a.stats + (ring ? 0 : 1), 1u);
+        atomicAdd(a.stats + 2, (unsigned)mplanes);
+        atomicAdd(a.stats + 3, (unsigned)nsteps);
+        if (ring) {
+            unsigned tot = 0;
+            for (int i = 0; i < NSRC; ++i) tot += (ldsi[L::HDR + 4 + 4 * i] + 1) * (ldsi[L::HDR + 5 + 4 * i] + 1);
+            atomicAdd(a.stats + 4, tot);
+        }
+    }
+    auto load_win = [&](int k, int i) -> Win {  // k, i wave-uniform (may be run-time values)
+        Win W;
+        const int* e = ldsi + L::PLAN + (k * NSRC + i) * 8;
+        W.x0 = rfl(e[0]); W.y0 = rfl(e[1]); W.w = rfl(e[2]); W.h = rfl(e[3]); W.ox = rfl(e[4]); W.oy = rfl(e[5]);
+        return W;
+    };
+
+    // ---------------------------------------------------------------------------------------
+    // Delta staging: step k owns the item descriptors [sst[k], sst[k+1]); wave wv takes items
+    // wv, wv + NWAVES, ...; the first PFD of them are prefetched one step ahead.
+    // ---------------------------------------------------------------------------------------
+    struct Item {
+        const float* g;  // global address of the group's first channel (always dereferenceable)
+        int meta;        // LDS float index of the ring slot | ok << 20 | dup column << 21 | dup row << 22, or -1
+        int geo;         // RW | RH << 8 of the view's ring
+    };
+    // items of step k are numbered 0..nit-1; rb/re = the step's rect descriptor range
+    auto item = [&](int it, int rb, int re, int nit) -> Item {
+        Item I;
+        const bool live = it < nit;
+        // rect holding item `it`: the last one whose first item is <= it (<= 16 rects per step)
+        const int fi = (lane < re - rb) ? ldsi[L::RECTS + 8 * (rb + lane) + 4] : 0x7fffffff;
+        const unsigned long long mk = __ballot(fi <= it);
+        const int ridx = live ? rb + max((int)__popcll(mk) - 1, 0) : rb;
+        const int* e = ldsi + L::RECTS + 8 * ridx;
+        const int rx = rfl(e[0]), ry = rfl(e[1]), e2 = rfl(e[2]), nel = rfl(e[3]), fi0 = rfl(e[4]);
+        const int e6 = rfl(e[6]), e7 = rfl(e[7]);
+        const int rwid = e2 & 0xffff, vi = e2 >> 16;
+        const int RWv = e7 & 0xff, RHv = (e7 >> 8) & 0xff, bs = (e7 >> 16) << 2;
+        const int el = (it - fi0) * 64 + lane;
+        const int pos = el;
+        const int cy = (int)(((float)pos + 0.5f) * (1.0f / (float)max(rwid, 1)));
+        const int cx = pos - cy * rwid;
+        const int sx = rx + cx, sy = ry + cy;
+        const bool inr = live && (el < nel);
+        const bool ok = inr && ((unsigned)sx < (unsigned)w) && ((unsigned)sy < (unsigned)h);
+        const float* __restrict__ src = p.feats[min(vi + 1, p.n_src)];
+        I.g = src + (size_t)c0 * plane + (ok ? sy * w + sx : 0);
+        unsigned c = (unsigned)((e6 & 0xffff) + cx), r = (unsigned)((e6 >> 16) + cy);
+        c = min(c, c - (unsigned)RWv);
+        r = min(r, r - (unsigned)RHv);
+        const int dst = bs + (int)r * ((RWv + 1) * STRIDE) + (int)c * STRIDE;
+        I.meta = inr ? (dst | (ok ? 1 << 20 : 0) | (c == 0 ? 1 << 21 : 0) | (r == 0 ? 1 << 22 : 0)) : -1;
+        I.geo = e7 & 0xffff;
+        return I;
+    };
+    auto put = [&](int meta, int geo, int q, f4 v) {
+        if (meta >= 0) {
+            const int dst = (meta & 0xfffff) + 4 * q;
+            const int RWv = geo & 0xff, RHv = geo >> 8;
+            const int dupc = (meta >> 21) & 1 ? RWv * STRIDE : 0;
+            const int dupr = (meta >> 22) & 1 ? RHv * (RWv + 1) * STRIDE : 0;
+            f4 x = (meta >> 20) & 1 ? v : (f4){0, 0, 0, 0};
+            *reinterpret_cast<f4*>(lds + dst) = x;
+            if (dupc) *reinterpret_cast<f4*>(lds + dst + dupc) = x;
+            if (dupr) *reinterpret_cast<f4*>(lds + dst + dupr) = x;
+            if (dupc && dupr) *reinterpret_cast<f4*>(lds + dst + dupc + dupr) = x;
+        }
+    };
+    f4 pf[PFD][Q];
+    int pmeta[PFD], pgeo[PFD];
+    auto step_range = [&](int k, int& rb, int& re, int& nit) {
+        rb = rfl(ldsi[L::SST + k]);
+        re = rfl(ldsi[L::SST + k + 1]);
+        nit = (re > rb) ? rfl(ldsi[L::RECTS + 8 * (re - 1) + 5]) : 0;
+    };
+    // loads of items first + wave, first + wave + NWAVES, ... (PFD of them) into the prefetch slots
+    auto issue_round = [&](int first, int rb, int re, int nit) {
+#pragma unroll
+        for (int j = 0; j < PFD; ++j) {
+            Item I = item(first + lw + NLOADW * j, rb, re, nit);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
+                pf[j][q][0] = g[0];
+                pf[j][q][1] = g[plane];
+                pf[j][q][2] = g[2 * plane];
+                pf[j][q][3] = g[3 * plane];
+            }
+            pmeta[j] = I.meta;
+            pgeo[j] = I.geo;
+        }
+    };
+    auto write_round = [&]() {
+#pragma unroll
+        for (int j = 0; j < PFD; ++j)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) put(pmeta[j], pgeo[j], q, pf[j][q]);
+    };
+    auto stage = [&](int k) {  // loader waves: bring window(k) minus window(k-1) into the rings
+        int rb, re, nit;
+        step_range(k, rb, re, nit);
+        for (int first = 0; first < nit; first += NLOADW * PFD) {
+            issue_round(first, rb, re, nit);
+            write_round();
+        }
+    };
+
+    // Barrier k separates {compute step k-1, stage delta k} from {compute step k, stage delta k+1}.
+    // Both roles execute exactly nsteps barriers in ring mode and none in gather mode.
+    if (loader) {
+        if (ring) {
+            stage(0);
+            for (int k = 0; k < nsteps; ++k) {
+                __syncthreads();
+                if (k + 1 < nsteps) stage(k + 1);
+            }
+        }
+        return;
+    }
+
+    // --- per-lane constants: rays, reference features, weights -------------------------------
+    Ray ray[NSRC];
+    float T0[NSRC], T1[NSRC], T2[NSRC];
+    int RW[NSRC], RH[NSRC], rbase[NSRC];
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
+        ray[i] = make_ray(M, xf, yf);
+        T0[i] = M[3]; T1[i] = M[7]; T2[i] = M[11];
+        RW[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 0]) : 1;
+        RH[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 1]) : 1;
+        rbase[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 2]) : L::DATA;
+    }
+    f4 r[Q];
+    if (MODE != MODE_WARP) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
+                r[q][k] = valid ? t : 0.0f;
+            }
+    }
+    float vw[NSRC];
+    float rden = 0.0f;
+    if (MODE == MODE_WEIGHTED) {
+        float den = 1e-5f;
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) {
+            float t = p.weights[(size_t)min(i, p.n_src - 1) * plane + pix];
+            vw[i] = (valid && i < p.n_src) ? t : 0.0f;
+            den += vw[i];
+        }
+        rden = 1.0f / den;
+    }
+    const float invV = 1.0f / (float)(p.n_src + 1);
+    const size_t cstride_b = (size_t)D * plane * 4;
+
+    // all CH/4.. channels of one quad: accumulators -> output values -> stores
+    auto finalize_store = [&](const f4& s, const f4& qq, const char*& ob) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o;
+            if (MODE == MODE_VARIANCE) {
+                float m = s[k] * invV;
+                o = fmaf(qq[k], invV, -(m * m));
+            } else if (MODE == MODE_WEIGHTED) {
+                o = s[k] * rden;
+            } else {
+                o = s[k];
+            }
+            store_sbase(ob, pixb, o);
+            ob += cstride_b;
+        }
+    };
+    auto accumulate = [&](f4& s, f4& qq, float& pair_acc, const f4& val, int q, int i) {
+        if (MODE == MODE_VARIANCE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += val[k]; qq[k] = fmaf(val[k], val[k], qq[k]); }
+        } else if (MODE == MODE_WEIGHTED) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = fmaf(val[k] * r[q][k], vw[i], s[k]);
+        } else if (MODE == MODE_PAIR) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pair_acc = fmaf(r[q][k], val[k], pair_acc);
+        } else {
+            s = val;
+        }
+    };
+
+    // ================================ main loop over steps ======================================
+    const bool timing = a.tstats != nullptr && wave == 0;
+    long long t_w = 0, t_c = 0, t_mark = 0;
+    if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
+    for (int k = 0; k < nsteps; ++k) {
+        if (ring) {
+            long long ta = 0;
+            if (timing) ta = clock64();
+            __syncthreads();  // barrier k: rings hold window(k)
+            if (timing) { t_mark = clock64(); t_w += t_mark - ta; }
+        }
+        Win W[NSRC];
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) W[i] = load_win(ring ? k : 0, i);
+
+        for (int j = 0; j < mplanes; ++j) {
+            const int dl_ = k * SP + sub + NSUB * j;
+            if (dl_ >= nplanes) break;
+            const int d = ds + dl_;
+            float dv;
+            if (p.depth_mode == D3D_DEPTH_PER_PIXEL) {
+                float t = p.depth[(size_t)d * plane + pix];
+                dv = valid ? t : 1.0f;
+            } else {
+                dv = lds[L::PMIN + dl_];
+            }
+            const char* ob = reinterpret_cast<const char*>(p.out + ((size_t)c0 * D + d) * plane);
+            float pair_acc = 0.0f;
+            if (!valid) continue;  // one EXEC region per plane instead of one branch per store
+
+            if (ring) {
+                TapL t[NSRC];
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    float u, v;
+                    project(ray[i], T0[i], T1[i], T2[i], dv, h, w, u, v);
+                    t[i] = make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
+                }
+                // Units u = (quad q, view i) in q-major order; the four taps of unit u+1 are requested
+                // before unit u is blended, so LDS latency overlaps the 24 VALU ops of a unit.
+                constexpr int NU = Q * NSRC;
+                f4 c00, c01, c10, c11, n00, n01, n10, n11;
+                c00 = lds_read4(lds, t[0].a0);
+                c01 = lds_read4(lds, t[0].a0 + STRIDE * 4);
+                c10 = lds_read4(lds, t[0].a1);
+                c11 = lds_read4(lds, t[0].a1 + STRIDE * 4);
+                f4 s, qq;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int q = u / NSRC, i = u % NSRC;
+                    if (u + 1 < NU) {
+                        const int q2 = (u + 1) / NSRC, i2 = (u + 1) % NSRC;
+                        n00 = lds_read4(lds, t[i2].a0 + q2 * 16);
+                        n01 = lds_read4(lds, t[i2].a0 + q2 * 16 + STRIDE * 4);
+                        n10 = lds_read4(lds, t[i2].a1 + q2 * 16);
+                        n11 = lds_read4(lds, t[i2].a1 + q2 * 16 + STRIDE * 4);
+                    }
+                    if (i == 0) {
+                        if (MODE == MODE_VARIANCE) { s = r[q]; qq = r[q] * r[q]; }
+                        else { s = (f4){0, 0, 0, 0}; qq = s; }
+                    }
+                    f4 val = blend(c00, c01, c10, c11, t[i].nw, t[i].ne, t[i].sw, t[i].se);
+                    accumulate(s, qq, pair_acc, val, q, i);
+                    if (i == NSRC - 1 && MODE != MODE_PAIR) finalize_store(s, qq, ob);
+                    c00 = n00; c01 = n01; c10 = n10; c11 = n11;
+                }
+            } else {
+                TapG t[NSRC];
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    float u, v;
+                    project(ray[i], T0[i], T1[i], T2[i], dv, h, w, u, v);
+                    t[i] = make_tap_glb(u, v, h, w);
+                    if (i >= p.n_src) { t[i].nw = t[i].ne = t[i].sw = t[i].se = 0.0f; t[i].off = 0; t[i].dx = 0; t[i].dyw = 0; }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    f4 s, qq;
+                    if (MODE == MODE_VARIANCE) { s = r[q]; qq = r[q] * r[q]; }
+                    else { s = (f4){0, 0, 0, 0}; qq = s; }
+#pragma unroll
+                    for (int i = 0; i < NSRC; ++i) {
+                        const float* __restrict__ g = p.feats[min(i + 1, p.n_src)] + (size_t)(c0 + 4 * q) * plane + t[i].off;
+                        f4 val;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const float* __restrict__ gk = g + (size_t)kk * plane;
+                            val[kk] = fmaf(gk[t[i].dyw + t[i].dx], t[i].se,
+                                           fmaf(gk[t[i].dyw], t[i].sw, fmaf(gk[t[i].dx], t[i].ne, gk[0] * t[i].nw)));
+                        }
+                        accumulate(s, qq, pair_acc, val, q, i);
+                    }
+                    if (MODE != MODE_PAIR) finalize_store(s, qq, ob);
+                }
+            }
+            if (MODE == MODE_PAIR)
+                store_sbase(reinterpret_cast<const char*>(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
+        }
+        if (timing) t_c += clock64() - t_mark;
+    }
+    if (timing && lane == 0) {
+        atomicAdd(a.tstats + 1, (unsigned long long)t_w);
+        atomicAdd(a.tstats + 3, (unsigned long long)t_c);
+        atomicAdd(a.tstats + 4, (unsigned long long)(clock64() - t_start));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int NSRC, int CH>
+static int launch_one(const SweepParams& p, hipStream_t stream) {
+    using L = Lds<CH, NSRC>;
+    constexpr int LDS_BYTES = 160 * 1024;
+    auto kern = sweep_tiled_kernel<MODE, NSRC, CH>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
+                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (rc != D3D_OK) return rc;
+        attr_done = true;
+    }
+    TiledArgs a;
+    a.ngroups = p.C / CH;
+    a.tiles_x = ceil_div(p.w, TW);
+    a.tiles_y = ceil_div(p.h, TH);
+    a.cap_floats = LDS_BYTES / 4 - L::DATA;
+    // segments: enough workgroups to fill 256 CUs a few times over, each at most DSEG_MAX planes
+    int dseg_cap = DSEG_MAX;
+    if (const char* e = getenv("D3D_TILED_DSEG")) dseg_cap = max(NSUB, min(atoi(e), DSEG_MAX));  // experiments
+    int nseg = ceil_div(p.D, dseg_cap);
+    const long tiles = (long)a.tiles_x * a.tiles_y * a.ngroups;
+    while (tiles * nseg < 4096 && nseg * 2 <= ceil_div(p.D, 32)) nseg *= 2;
+    a.dseg = ceil_div(p.D, nseg);
+    a.nseg = ceil_div(p.D, a.dseg);
+    const long nblk = tiles * a.nseg;
+    if (nblk > 0x7fffffffL) return D3D_ERR_UNSUPPORTED;
+    a.stats = nullptr;
+    a.tstats = nullptr;
+    if (getenv("D3D_TILED_STATS")) {  // debug only: synchronous, allocates
+        hipMalloc(&a.stats, 8 * sizeof(unsigned) + 8 * sizeof(unsigned long long));
+        hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 8 * sizeof(unsigned long long));
+        a.tstats = reinterpret_cast<unsigned long long*>(a.stats + 8);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(THREADS), LDS_BYTES, stream, p, a);
+    D3D_LAUNCH_CHECK("sweep_tiled_kernel launch");
+    if (a.stats) {
+        unsigned hs[8];
+        unsigned long long ht[8];
+        hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
+        hipMemcpy(ht, a.tstats, sizeof(ht), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[d3d tiled timing] per-WG mean cycles (wave 0): prologue %.0f | barrier wait %.0f | - %.0f | compute %.0f | total %.0f\n",
+                ht[0] / (double)nblk, ht[1] / (double)nblk, ht[2] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk);
+        fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_m=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
+                CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
+                a.cap_floats / L::STRIDE, hs[5], a.dseg);
+        hipFree(a.stats);
+    }
+    return D3D_OK;
+}
+
+static int group_channels(int C) {
+    // channels per workgroup pass; D3D_TILED_CG overrides for experiments (must divide C)
+    const char* e = getenv("D3D_TILED_CG");
+    int cg = e ? atoi(e) : (C >= 16 ? 16 : C);
+    if (cg != 8 && cg != 16 && cg != 32) cg = 8;
+    while (C % cg) cg >>= 1;
+    return cg;
+}
+
+template <int MODE, int NSRC>
+static int launch_ch(const SweepParams& p, hipStream_t stream) {
+    const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C);
+    switch (cg) {
+        case 32: return launch_one<MODE, NSRC, 32>(p, stream);
+        case 16: return launch_one<MODE, NSRC, 16>(p, stream);
+        case 8: return launch_one<MODE, NSRC, 8>(p, stream);
+    }
+    return D3D_ERR_UNSUPPORTED;
+}
+
+int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
+    if (p.C % 8 != 0 || (mode == MODE_PAIR && p.C != 32 && p.C != 16 && p.C != 8)) {
+        set_error("tiled kernel unsupported: C=%d", p.C);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    if (p.n_src > 4) {
+        set_error("tiled kernel unsupported: %d source views (max 4)", p.n_src);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    switch (mode) {
+        case MODE_VARIANCE:
+            return p.n_src <= 2 ? launch_ch<MODE_VARIANCE, 2>(p, stream) : launch_ch<MODE_VARIANCE, 4>(p, stream);
+        case MODE_WEIGHTED:
+            return p.n_src <= 2 ? launch_ch<MODE_WEIGHTED, 2>(p, stream) : launch_ch<MODE_WEIGHTED, 4>(p, stream);
+        case MODE_PAIR: return launch_ch<MODE_PAIR, 1>(p, stream);
+        case MODE_WARP: return launch_ch<MODE_WARP, 1>(p, stream);
+    }
+    set_error("internal: bad mode %d", mode);
+    return D3D_ERR_INVALID_ARG;
+}
+
 }  // namespace d3d

@@ -1,0 +1,4 @@
+for cg in 32 16 8; do
+  D3D_TILED_DEBUG=1 D3D_TILED_CG=$cg python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('DEBUG(no staging) CG=$cg', d['value'], 'Mvox/s', d['ms_per_step'], 'ms', d['roofline']['frac'])"
+  D3D_TILED_CG=$cg python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('REAL              CG=$cg', d['value'], 'Mvox/s', d['ms_per_step'], 'ms', d['roofline']['frac'])"
+done
