@@ -185,17 +185,21 @@ __device__ __forceinline__ f4 blend(f4 t00, f4 t01, f4 t10, f4 t11, float nw, fl
 
 // Store with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit
 // VALU address arithmetic per store.  Stores are never waited on inside the kernel.
-__device__ __forceinline__ void store_sbase(const char* base_uniform, unsigned byte_off, float v) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base_uniform);
+__device__ __forceinline__ unsigned long long uniform64(const void* ptr) {  // force an SGPR pair
+    const unsigned long long b = reinterpret_cast<unsigned long long>(ptr);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte_off, float v) {
     // no "memory" clobber: nothing in the kernel reads the output, and a clobber would stop the
     // scheduler from hoisting the next unit's LDS reads above these stores
 #ifdef D3D_NOSTORE  // timing experiment build: keep the value alive, skip the store
     asm volatile("" : : "v"(byte_off), "v"(v), "s"(sb));
 #else
-    asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(sb));
+    // "nt": the cost volume is write-once streaming data; keep it from evicting the source windows
+    // (re-read by neighbouring workgroups) out of L2 / Infinity Cache
+    asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(byte_off), "v"(v), "s"(sb));
 #endif
 }
 
@@ -478,34 +482,28 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         int meta;        // LDS float index of the ring slot | ok << 20 | dup column << 21 | dup row << 22, or -1
         int geo;         // RW | RH << 8 of the view's ring
     };
-    // items of step k are numbered 0..nit-1; rb/re = the step's rect descriptor range
-    auto item = [&](int it, int rb, int re, int nit) -> Item {
+    // Rect descriptor fields of one item, wave-uniform.
+    struct Desc {
+        int rx, ry, e2, nel, fi0, e6, e7;
+    };
+    auto item = [&](int it, bool live, const Desc& dsc) -> Item {
         Item I;
-        const bool live = it < nit;
-        // rect holding item `it`: the last one whose first item is <= it (<= 16 rects per step)
-        const int fi = (lane < re - rb) ? ldsi[L::RECTS + 8 * (rb + lane) + 4] : 0x7fffffff;
-        const unsigned long long mk = __ballot(fi <= it);
-        const int ridx = live ? rb + max((int)__popcll(mk) - 1, 0) : rb;
-        const int* e = ldsi + L::RECTS + 8 * ridx;
-        const int rx = rfl(e[0]), ry = rfl(e[1]), e2 = rfl(e[2]), nel = rfl(e[3]), fi0 = rfl(e[4]);
-        const int e6 = rfl(e[6]), e7 = rfl(e[7]);
-        const int rwid = e2 & 0xffff, vi = e2 >> 16;
-        const int RWv = e7 & 0xff, RHv = (e7 >> 8) & 0xff, bs = (e7 >> 16) << 2;
-        const int el = (it - fi0) * 64 + lane;
-        const int pos = el;
+        const int rwid = dsc.e2 & 0xffff, vi = dsc.e2 >> 16;
+        const int RWv = dsc.e7 & 0xff, RHv = (dsc.e7 >> 8) & 0xff, bs = (dsc.e7 >> 16) << 2;
+        const int pos = (it - dsc.fi0) * 64 + lane;
         const int cy = (int)(((float)pos + 0.5f) * (1.0f / (float)max(rwid, 1)));
         const int cx = pos - cy * rwid;
-        const int sx = rx + cx, sy = ry + cy;
-        const bool inr = live && (el < nel);
+        const int sx = dsc.rx + cx, sy = dsc.ry + cy;
+        const bool inr = live && (pos < dsc.nel);
         const bool ok = inr && ((unsigned)sx < (unsigned)w) && ((unsigned)sy < (unsigned)h);
         const float* __restrict__ src = p.feats[min(vi + 1, p.n_src)];
         I.g = src + (size_t)c0 * plane + (ok ? sy * w + sx : 0);
-        unsigned c = (unsigned)((e6 & 0xffff) + cx), r = (unsigned)((e6 >> 16) + cy);
+        unsigned c = (unsigned)((dsc.e6 & 0xffff) + cx), r = (unsigned)((dsc.e6 >> 16) + cy);
         c = min(c, c - (unsigned)RWv);
         r = min(r, r - (unsigned)RHv);
         const int dst = bs + (int)r * ((RWv + 1) * STRIDE) + (int)c * STRIDE;
         I.meta = inr ? (dst | (ok ? 1 << 20 : 0) | (c == 0 ? 1 << 21 : 0) | (r == 0 ? 1 << 22 : 0)) : -1;
-        I.geo = e7 & 0xffff;
+        I.geo = dsc.e7 & 0xffff;
         return I;
     };
     auto put = [&](int meta, int geo, int q, f4 v) {
@@ -528,35 +526,53 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         re = rfl(ldsi[L::SST + k + 1]);
         nit = (re > rb) ? rfl(ldsi[L::RECTS + 8 * (re - 1) + 5]) : 0;
     };
-    // loads of items first + wave, first + wave + NWAVES, ... (PFD of them) into the prefetch slots
-    auto issue_round = [&](int first, int rb, int re, int nit) {
-#pragma unroll
-        for (int j = 0; j < PFD; ++j) {
-            Item I = item(first + lw + NLOADW * j, rb, re, nit);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
-                pf[j][q][0] = g[0];
-                pf[j][q][1] = g[plane];
-                pf[j][q][2] = g[2 * plane];
-                pf[j][q][3] = g[3 * plane];
-            }
-            pmeta[j] = I.meta;
-            pgeo[j] = I.geo;
-        }
-    };
     auto write_round = [&]() {
 #pragma unroll
         for (int j = 0; j < PFD; ++j)
 #pragma unroll
             for (int q = 0; q < Q; ++q) put(pmeta[j], pgeo[j], q, pf[j][q]);
     };
-    auto stage = [&](int k) {  // loader waves: bring window(k) minus window(k-1) into the rings
+    // Loader waves: bring window(k) minus window(k-1) into the rings.  One lane-parallel pass finds
+    // the rect descriptor of up to 64 items at once (lane = item); each item's fields then come from
+    // v_readlane, so there is no LDS round trip per item.
+    auto stage = [&](int k) {
         int rb, re, nit;
         step_range(k, rb, re, nit);
-        for (int first = 0; first < nit; first += NLOADW * PFD) {
-            issue_round(first, rb, re, nit);
-            write_round();
+        for (int base = 0; base < nit; base += 64) {
+            const int myit = base + lane;
+            int ridx = rb;
+            for (int rr = rb + 1; rr < re; ++rr) ridx = (ldsi[L::RECTS + 8 * rr + 4] <= myit) ? rr : ridx;
+            const int* e = ldsi + L::RECTS + 8 * ridx;
+            const int f0 = e[0], f1 = e[1], f2 = e[2], f3 = e[3], f4_ = e[4], f6 = e[6], f7 = e[7];
+            const int nhere = min(nit - base, 64);
+            for (int o = lw; o < nhere; o += NLOADW * PFD) {
+#pragma unroll
+                for (int j = 0; j < PFD; ++j) {
+                    const int sl = o + NLOADW * j;  // source lane = item index within this pass
+                    const bool live = sl < nhere;
+                    const int sll = live ? sl : 0;
+                    Desc dsc;
+                    dsc.rx = __builtin_amdgcn_readlane(f0, sll);
+                    dsc.ry = __builtin_amdgcn_readlane(f1, sll);
+                    dsc.e2 = __builtin_amdgcn_readlane(f2, sll);
+                    dsc.nel = __builtin_amdgcn_readlane(f3, sll);
+                    dsc.fi0 = __builtin_amdgcn_readlane(f4_, sll);
+                    dsc.e6 = __builtin_amdgcn_readlane(f6, sll);
+                    dsc.e7 = __builtin_amdgcn_readlane(f7, sll);
+                    Item I = item(base + sl, live, dsc);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
+                        pf[j][q][0] = g[0];
+                        pf[j][q][1] = g[plane];
+                        pf[j][q][2] = g[2 * plane];
+                        pf[j][q][3] = g[3 * plane];
+                    }
+                    pmeta[j] = I.meta;
+                    pgeo[j] = I.geo;
+                }
+                write_round();
+            }
         }
     };
 
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     const size_t cstride_b = (size_t)D * plane * 4;
 
     // all CH/4.. channels of one quad: accumulators -> output values -> stores
-    auto finalize_store = [&](const f4& s, const f4& qq, const char*& ob) {
+    auto finalize_store = [&](const f4& s, const f4& qq, unsigned long long& ob) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float o;
@@ -669,7 +685,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             } else {
                 dv = lds[L::PMIN + dl_];
             }
-            const char* ob = reinterpret_cast<const char*>(p.out + ((size_t)c0 * D + d) * plane);
+            unsigned long long ob = uniform64(p.out + ((size_t)c0 * D + d) * plane);  // scalar base, once per plane
             float pair_acc = 0.0f;
             if (!valid) continue;  // one EXEC region per plane instead of one branch per store
 
@@ -684,30 +700,33 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 // Units u = (quad q, view i) in q-major order; the four taps of unit u+1 are requested
                 // before unit u is blended, so LDS latency overlaps the 24 VALU ops of a unit.
                 constexpr int NU = Q * NSRC;
-                f4 c00, c01, c10, c11, n00, n01, n10, n11;
-                c00 = lds_read4(lds, t[0].a0);
-                c01 = lds_read4(lds, t[0].a0 + STRIDE * 4);
-                c10 = lds_read4(lds, t[0].a1);
-                c11 = lds_read4(lds, t[0].a1 + STRIDE * 4);
+                constexpr int PD = 1;  // units requested ahead of the one being blended
+                f4 tp[PD + 1][4];
+                auto request = [&](int u, f4 (&dst)[4]) {
+                    const int q2 = u / NSRC, i2 = u % NSRC;
+                    dst[0] = lds_read4(lds, t[i2].a0 + q2 * 16);
+                    dst[1] = lds_read4(lds, t[i2].a0 + q2 * 16 + STRIDE * 4);
+                    dst[2] = lds_read4(lds, t[i2].a1 + q2 * 16);
+                    dst[3] = lds_read4(lds, t[i2].a1 + q2 * 16 + STRIDE * 4);
+                };
+#pragma unroll
+                for (int u = 0; u < PD && u < NU; ++u) request(u, tp[u % (PD + 1)]);
                 f4 s, qq;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int q = u / NSRC, i = u % NSRC;
-                    if (u + 1 < NU) {
-                        const int q2 = (u + 1) / NSRC, i2 = (u + 1) % NSRC;
-                        n00 = lds_read4(lds, t[i2].a0 + q2 * 16);
-                        n01 = lds_read4(lds, t[i2].a0 + q2 * 16 + STRIDE * 4);
-                        n10 = lds_read4(lds, t[i2].a1 + q2 * 16);
-                        n11 = lds_read4(lds, t[i2].a1 + q2 * 16 + STRIDE * 4);
-                    }
+                    if (u + PD < NU) request(u + PD, tp[(u + PD) % (PD + 1)]);
                     if (i == 0) {
                         if (MODE == MODE_VARIANCE) { s = r[q]; qq = r[q] * r[q]; }
                         else { s = (f4){0, 0, 0, 0}; qq = s; }
                     }
-                    f4 val = blend(c00, c01, c10, c11, t[i].nw, t[i].ne, t[i].sw, t[i].se);
+                    f4 (&c)[4] = tp[u % (PD + 1)];
+                    // LDS returns in order: touching the last-requested tap first makes the compiler emit ONE
+                    // s_waitcnt for the unit instead of one per tap
+                    asm volatile("" : "+v"(c[3]));
+                    f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
                     accumulate(s, qq, pair_acc, val, q, i);
                     if (i == NSRC - 1 && MODE != MODE_PAIR) finalize_store(s, qq, ob);
-                    c00 = n00; c01 = n01; c10 = n10; c11 = n11;
                 }
             } else {
                 TapG t[NSRC];
@@ -739,7 +758,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 }
             }
             if (MODE == MODE_PAIR)
-                store_sbase(reinterpret_cast<const char*>(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
+                store_sbase(uniform64(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
         }
         if (timing) t_c += clock64() - t_mark;
     }
