@@ -41,12 +41,24 @@ def algorithmic_bytes():
     return reads + writes
 
 
+def host_threads():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(proj34_host, feats_host, depth_host):
     """Times the CPU oracle on a depth sub-range of the same workload (bounded to ~10-20 s)."""
     import oracle
 
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     oracle.set_num_threads(cores)
     probe = 4
     t0 = time.perf_counter()

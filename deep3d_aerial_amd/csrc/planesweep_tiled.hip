@@ -224,19 +224,22 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     const int h = p.h, w = p.w, D = p.D;
     const size_t plane = (size_t)h * w;
 
-    // block -> (segment, channel group, tile).  Blocks b, b+8, ... share an XCD (and its L2):
-    // give each XCD a contiguous run so neighbouring segments/patches reuse source lines there.
+    // block -> (patch row, segment, channel group, patch column).  Blocks b, b+8, ... share an XCD
+    // (and its L2): give each XCD a contiguous run of the logical order.
     int b = blockIdx.x;
     {
         const int nblk = gridDim.x;
         const int per = nblk / 8;
         if (nblk % 8 == 0) b = (b % 8) * per + b / 8;
     }
-    const int seg = b % a.nseg;
-    const int grp = (b / a.nseg) % a.ngroups;
-    const int tile = b / (a.nseg * a.ngroups);
+    // Within an XCD's run, vertically adjacent patches come first: they share most of their source
+    // rows (same depth segment, same channel group), so the windows of the ~32 workgroups an XCD runs
+    // concurrently overlap in its L2 instead of each being fetched from HBM.
+    const int ty = b % a.tiles_y;
+    const int seg = (b / a.tiles_y) % a.nseg;
+    const int grp = (b / (a.tiles_y * a.nseg)) % a.ngroups;
+    const int tx = b / (a.tiles_y * a.nseg * a.ngroups);
     const int c0 = grp * CH;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
     const int ds = seg * a.dseg;
     const int de = min(ds + a.dseg, D);
@@ -789,7 +792,9 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     a.tiles_y = ceil_div(p.h, TH);
     a.cap_floats = LDS_BYTES / 4 - L::DATA;
     // segments: enough workgroups to fill 256 CUs a few times over, each at most DSEG_MAX planes
-    int dseg_cap = DSEG_MAX;
+    // 128-plane segments measured best on config 2 (rings sized per segment follow the depth-dependent
+    // window size; shorter segments pay the planning prologue more often)
+    int dseg_cap = 128;
     if (const char* e = getenv("D3D_TILED_DSEG")) dseg_cap = max(NSUB, min(atoi(e), DSEG_MAX));  // experiments
     int nseg = ceil_div(p.D, dseg_cap);
     const long tiles = (long)a.tiles_x * a.tiles_y * a.ngroups;

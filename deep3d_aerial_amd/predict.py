@@ -1,0 +1,197 @@
+"""Inference harness with the reference's predict.py boundary (mvs/mvs_cas/predict.py).
+
+What is kept identical for the rest of the pipeline (mvs_dl.py upstream, fuse/ downstream):
+  * the CLI flags mvs_dl.py formats (predict.py:30-58, mvs/mvs_dl.py:61-63);
+  * the model switch and its error for unknown names (predict.py:71-97);
+  * checkpoint layout {'model': state_dict} with DataParallel 'module.' prefixes (predict.py:105-106);
+  * the products per reference view: {name}_init.pfm, {name}_prob.pfm, {name}.txt
+    (predict.py:146-183; PFM layout data_io.py:196-223; camera text data_io.py:291-314).
+What is new: reference views are sharded over ranks (one process per GPU, sharding.py).
+
+The reference's dataset class needs cv2/GDAL (datasets/cas_normal_eval.py:7, data_io.py:11-12),
+which this image does not have; any iterable yielding the same sample dicts can be passed to
+predict_views(), and SyntheticBlock provides one for plumbing tests (BASELINE.json config 1).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import sharding, synthetic
+
+
+# ----------------------------------------------------------------------------------------
+# output files
+# ----------------------------------------------------------------------------------------
+def save_pfm(filename, image, scale=1):
+    """data_io.py:196-223 save_pfm_utf8: 'Pf', 'W H', scale (negative = little endian), rows bottom-up."""
+    image = np.asarray(image)
+    if image.dtype.name != "float32":
+        raise Exception("Image dtype must be float32.")
+    if image.ndim == 3 and image.shape[2] == 3:
+        color = True
+    elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
+        color = False
+    else:
+        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
+    image = np.flipud(image)
+    endian = image.dtype.byteorder
+    if endian == "<" or (endian == "=" and sys.byteorder == "little"):
+        scale = -scale
+    with open(filename, "wb") as f:
+        f.write(b"PF\n" if color else b"Pf\n")
+        f.write(("%d %d\n" % (image.shape[1], image.shape[0])).encode("utf-8"))
+        f.write(("%f\n" % scale).encode("utf-8"))
+        image.tofile(f)
+
+
+def load_pfm(filename):
+    with open(filename, "rb") as f:
+        header = f.readline().decode("utf-8").rstrip()
+        if header not in ("PF", "Pf"):
+            raise Exception("Not a PFM file.")
+        w, h = (int(t) for t in f.readline().decode("utf-8").split())
+        scale = float(f.readline().decode("utf-8").rstrip())
+        data = np.fromfile(f, "<f4" if scale < 0 else ">f4")
+    shape = (h, w, 3) if header == "PF" else (h, w)
+    return np.flipud(data.reshape(shape)).astype(np.float32), abs(scale)
+
+
+def write_red_cam(file, cam, location, ref_path):
+    """data_io.py:291-314: extrinsic 4x4, intrinsic 3x3, 'dmin interval D dmax', location + ref path."""
+    with open(file, "w") as f:
+        f.write("extrinsic: XrightYdown, [Rcw|tcw]\n")
+        for i in range(4):
+            for j in range(4):
+                f.write(str(cam[0][i][j]) + " ")
+            f.write("\n")
+        f.write("\n")
+        f.write("intrinsic\n")
+        for i in range(3):
+            for j in range(3):
+                f.write(str(cam[1][i][j]) + " ")
+            f.write("\n")
+        f.write("\n" + str(cam[1][3][0]) + " " + str(cam[1][3][1]) + " " + str(cam[1][3][2]) + " " +
+                str(cam[1][3][3]) + "\n")
+        f.write("\n")
+        for word in location:
+            f.write(str(word) + " ")
+        f.write(str(ref_path) + "\n")
+
+
+# ----------------------------------------------------------------------------------------
+# model switch (predict.py:71-97) and checkpoint loading (predict.py:105-106)
+# ----------------------------------------------------------------------------------------
+def build_model(name, numdepth, ndepths=(48, 32, 8), depth_inter_r=(4, 2, 1), share_cr=False,
+                cr_base_chs=(8, 8, 8)):
+    if name == "casmvsnet":
+        from .cas_mvsnet import Infer_CascadeMVSNet
+        return Infer_CascadeMVSNet(num_depth=numdepth, ndepths=list(ndepths),
+                                   depth_intervals_ratio=list(depth_inter_r), share_cr=share_cr,
+                                   cr_base_chs=list(cr_base_chs))
+    if name == "adamvs":
+        from .adamvs import Infer_AdaMVSNet
+        return Infer_AdaMVSNet(num_depth=numdepth, ndepths=list(ndepths), depth_intervals_ratio=list(depth_inter_r),
+                               share_cr=share_cr, cr_base_chs=list(cr_base_chs))
+    # msrednet / ucsnet inference are not built yet (ucsnet is broken in the reference)
+    raise Exception("{}? Not implemented yet!".format(name))
+
+
+def load_checkpoint(model, path):
+    """Accepts the reference's {'model': sd} files, with or without DataParallel's 'module.' prefix."""
+    sd = torch.load(path, map_location="cpu")
+    sd = sd["model"] if "model" in sd else sd
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+    model.load_state_dict(sd)
+    return model
+
+
+# ----------------------------------------------------------------------------------------
+# a synthetic block with the dataset item layout of cas_normal_eval.py:94-182
+# ----------------------------------------------------------------------------------------
+class SyntheticBlock:
+    def __init__(self, n_items, view_num, max_h, max_w, numdepth, seed=0):
+        self.n, self.v, self.h, self.w, self.nd, self.seed = n_items, view_num, max_h, max_w, numdepth, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        rng = np.random.default_rng(self.seed + idx)
+        imgs = rng.standard_normal((self.v, 3, self.h, self.w), dtype=np.float32)
+        proj, dv = synthetic.make_scene(self.v, self.h, self.w, self.nd, sweep_px=min(self.nd, self.w) / 4.0,
+                                        seed=self.seed + idx)
+        pm = {}
+        for name, sc in (("stage1", 0.25), ("stage2", 0.5), ("stage3", 1.0)):
+            q = proj.copy()
+            q[:, :2, :] = proj[:, :2, :] * np.float32(sc)
+            pm[name] = q
+        cam = np.zeros((2, 4, 4), np.float32)
+        cam[0] = np.eye(4)
+        cam[1, :3, :3] = np.array([[1.2 * max(self.h, self.w), 0, (self.w - 1) / 2],
+                                   [0, 1.2 * max(self.h, self.w), (self.h - 1) / 2], [0, 0, 1]])
+        cam[1, 3] = [dv[0], (dv[1] - dv[0]) / self.nd, self.nd, dv[1]]
+        name = "view_%04d" % idx
+        return {"imgs": imgs, "proj_matrices": pm, "depth_values": dv, "outcam": cam,
+                "outlocation": [str(self.w), str(self.h), str(idx), name + ".png"], "ref_image_path": name + ".png"}
+
+
+# ----------------------------------------------------------------------------------------
+# the per-view loop of predict.py:126-183, sharded over ranks
+# ----------------------------------------------------------------------------------------
+def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda"):
+    os.makedirs(output_folder, exist_ok=True)
+    model.eval()
+    done = []
+    with torch.no_grad():
+        for idx in sharding.shard_views(len(dataset), rank, world_size):
+            s = dataset[idx]
+            imgs = torch.from_numpy(np.ascontiguousarray(s["imgs"]))[None].to(device)
+            pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(device) for k, v in s["proj_matrices"].items()}
+            dv = torch.from_numpy(np.ascontiguousarray(s["depth_values"]))[None].to(device)
+            out = model(imgs, pm, dv)
+            depth = np.float32(np.squeeze(out["depth"].cpu().numpy()))
+            prob = np.float32(np.squeeze(out["photometric_confidence"].cpu().numpy()))
+            name = os.path.splitext(s["outlocation"][3])[0]
+            save_pfm(os.path.join(output_folder, "%s_init.pfm" % name), depth)
+            save_pfm(os.path.join(output_folder, "%s_prob.pfm" % name), prob)
+            write_red_cam(os.path.join(output_folder, "%s.txt" % name), s["outcam"], s["outlocation"],
+                          s["ref_image_path"])
+            done.append(name)
+    return done
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="plane-sweep depth inference (predict.py-compatible flags)")
+    ap.add_argument("--model", default="adamvs")
+    ap.add_argument("--data_folder", default=None)
+    ap.add_argument("--output_folder", required=True)
+    ap.add_argument("--loadckpt", default=None)
+    ap.add_argument("--view_num", type=int, default=5)
+    ap.add_argument("--numdepth", type=int, default=384)
+    ap.add_argument("--max_w", type=int, default=768)
+    ap.add_argument("--max_h", type=int, default=384)
+    ap.add_argument("--min_interval", type=float, default=0.1)
+    ap.add_argument("--ndepths", type=str, default="48,32,8")
+    ap.add_argument("--depth_inter_r", type=str, default="4,2,1")
+    ap.add_argument("--display", default="False")
+    ap.add_argument("--synthetic_items", type=int, default=0, help="run on a synthetic block of this many views")
+    a = ap.parse_args(argv)
+    rank, world = sharding.init_from_env()
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    model = build_model(a.model, a.numdepth, [int(x) for x in a.ndepths.split(",")],
+                        [float(x) for x in a.depth_inter_r.split(",")]).cuda()
+    if a.loadckpt:
+        load_checkpoint(model, a.loadckpt)
+    if a.synthetic_items <= 0:
+        raise SystemExit("reading WHU-OMVS blocks needs cv2/GDAL (absent here): pass --synthetic_items N, or call "
+                         "predict_views() with your own dataset object")
+    ds = SyntheticBlock(a.synthetic_items, a.view_num, a.max_h, a.max_w, a.numdepth)
+    names = predict_views(model, ds, a.output_folder, rank, world)
+    print("rank %d/%d wrote %d views" % (rank, world, len(names)))
+
+
+if __name__ == "__main__":
+    main()

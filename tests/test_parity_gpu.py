@@ -398,3 +398,22 @@ def test_model_forward_matches_reference(ops, tag):
     if "adamvs" in tag:
         vw = torch.stack([t[0, 0] for t in out["stage1"]["pair_confidence"]])
         assert rel_l1(host(vw), g["stage1_view_weights"]) <= REL_MODEL
+
+
+def test_predict_views_writes_reference_products(ops, tmp_path):
+    """predict.py boundary: per view {name}_init.pfm, {name}_prob.pfm, {name}.txt; sharding by rank."""
+    from deep3d_aerial_amd import predict
+
+    net = _fill(predict.build_model("casmvsnet", 64), 11)
+    ds = predict.SyntheticBlock(3, 3, 64, 96, 64, seed=5)
+    names0 = predict.predict_views(net, ds, str(tmp_path), rank=0, world_size=2)
+    names1 = predict.predict_views(net, ds, str(tmp_path), rank=1, world_size=2)
+    assert sorted(names0 + names1) == ["view_0000", "view_0001", "view_0002"] and len(names0) == 2
+    s = ds[1]
+    with torch.no_grad():
+        out = net(dev(s["imgs"])[None], {k: dev(v)[None] for k, v in s["proj_matrices"].items()},
+                  dev(s["depth_values"])[None])
+    depth, _ = predict.load_pfm(str(tmp_path / "view_0001_init.pfm"))
+    prob, _ = predict.load_pfm(str(tmp_path / "view_0001_prob.pfm"))
+    assert np.array_equal(depth, host(out["depth"][0])) and np.array_equal(prob, host(out["photometric_confidence"][0]))
+    assert (tmp_path / "view_0001.txt").read_text().startswith("extrinsic: XrightYdown, [Rcw|tcw]")
