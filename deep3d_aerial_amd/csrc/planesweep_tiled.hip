@@ -290,69 +290,95 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     }
     __syncthreads();
 
-    // --- plan every step of the segment (wave 0, one lane per step) ----------------------------
-    if (wave == 0) {
-        int mode = 0, m_sel = 1, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
-        for (int m = 4; m >= 1 && !mode; m >>= 1) {
-            const int SP = NSUB * m;
-            const int nsteps = (nplanes + SP - 1) / SP;
-            if (nsteps > MAXSTEPS) continue;
-            const bool act = lane < nsteps;
-            const int p0 = min(lane * SP, nplanes - 1), p1 = min(lane * SP + SP, nplanes);
+    // --- plan every step of the segment ---------------------------------------------------------
+    // P1: wave (candidate, view) computes, one lane per step, that view's windows for the candidate
+    //     step size m in {4, 2, 1}; results go to a scratch table in the (still unused) ring area.
+    // P2: wave 0 picks the largest candidate whose rings fit and builds the plan / rectangle tables.
+    constexpr int CT = L::DATA;                          // [cand][view][step][4] windows
+    constexpr int CHD = CT + 3 * NSRC * 64 * 4;          // [cand][view][4]: RW, RH, bad, nsteps
+    {
+        const int cand = wave / NSRC, vsel = wave % NSRC;
+        if (cand < 3) {
+            const int m = 4 >> cand;
+            const int SPc = NSUB * m;
+            const int nstepc = (nplanes + SPc - 1) / SPc;
+            const bool feasible = nstepc <= MAXSTEPS;
+            const bool act = feasible && lane < nstepc;
+            const int p0 = min(lane * SPc, nplanes - 1), p1 = min(lane * SPc + SPc, nplanes);
             float lo = INFINITY, hi = -INFINITY;
             for (int i = p0; i < p1; ++i) {
                 lo = fminf(lo, lds[L::PMIN + i]);
                 hi = fmaxf(hi, lds[L::PMAX + i]);
             }
+            const float* __restrict__ M = p.proj34 + 12 * min(vsel, p.n_src - 1);
+            float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
+            bool ok = true;
+#pragma unroll
+            for (int ck = 0; ck < 8; ++ck) {
+                Ray cr = make_ray(M, (ck & 1) ? (float)x1c : (float)x0, (ck & 2) ? (float)y1c : (float)y0);
+                const float dv = (ck & 4) ? hi : lo;
+                float qx = __fadd_rn(__fmul_rn(cr.rx, dv), M[3]);
+                float qy = __fadd_rn(__fmul_rn(cr.ry, dv), M[7]);
+                float qz = __fadd_rn(__fmul_rn(cr.rz, dv), M[11]);
+                ok = ok && (qz > 1e-20f) && (qz < 1e30f);
+                float iz = 1.0f / qz;
+                float u = qx * iz, v = qy * iz;
+                ok = ok && (fabsf(u) < 1e30f) && (fabsf(v) < 1e30f);
+                // clamp before the float->int conversion; windows are clipped to the image plus a zero ring
+                u = fminf(fmaxf(u, -8.0f), (float)w + 8.0f);
+                v = fminf(fmaxf(v, -8.0f), (float)h + 8.0f);
+                umin = fminf(umin, u); umax = fmaxf(umax, u);
+                vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+            }
+            // interior samples differ from the corner hull by fp32 rounding only (<< 1/16 px)
+            int wx0 = max((int)floorf(umin - 0.0625f), -1);
+            int wy0 = max((int)floorf(vmin - 0.0625f), -1);
+            int wx1 = min((int)floorf(umax + 0.0625f) + 1, w);
+            int wy1 = min((int)floorf(vmax + 0.0625f) + 1, h);
+            int ww = max(wx1 - wx0 + 1, 0), wh = max(wy1 - wy0 + 1, 0);
+            if (ww < 2 || wh < 2) { ww = 0; wh = 0; }  // nothing of the image is touched
+            if (vsel >= p.n_src || !act) { ww = 0; wh = 0; ok = true; }
+            // ring size: the union of consecutive windows must fit (asynchronous delta staging)
+            int ux = ww, uy = wh;
+            {
+                const int qx0 = __shfl_up(wx0, 1), qy0 = __shfl_up(wy0, 1);
+                const int qw = __shfl_up(ww, 1), qh = __shfl_up(wh, 1);
+                if (lane > 0 && act && qw > 0 && ww > 0) {
+                    ux = max(wx0 + ww, qx0 + qw) - min(wx0, qx0);
+                    uy = max(wy0 + wh, qy0 + qh) - min(wy0, qy0);
+                }
+            }
+            const int RWc = max(wave_maxi(ux), 1), RHc = max(wave_maxi(uy), 1);
+            const int badc = (__any(!ok) || !feasible) ? 1 : 0;  // p.z <= 0 somewhere: cannot bound the frustum
+            int* e = ldsi + CT + ((cand * NSRC + vsel) * 64 + lane) * 4;
+            e[0] = wx0; e[1] = wy0; e[2] = ww; e[3] = wh;
+            if (lane == 0) {
+                int* hd = ldsi + CHD + (cand * NSRC + vsel) * 4;
+                hd[0] = RWc; hd[1] = RHc; hd[2] = badc; hd[3] = nstepc;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int mode = 0, m_sel = 1, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
+        for (int cand = 0; cand < 3 && !mode; ++cand) {
+            const int m = 4 >> cand;
+            const int nsteps = ldsi[CHD + (cand * NSRC) * 4 + 3];
+            const bool act = lane < nsteps;
             int wx0[NSRC], wy0[NSRC], ww[NSRC], wh[NSRC], RW[NSRC], RH[NSRC];
             int bad = 0, total = 0;
 #pragma unroll
             for (int i = 0; i < NSRC; ++i) {
-                const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
-                float umin = INFINITY, umax = -INFINITY, vmin = INFINITY, vmax = -INFINITY;
-                bool ok = true;
-#pragma unroll
-                for (int ck = 0; ck < 8; ++ck) {
-                    Ray cr = make_ray(M, (ck & 1) ? (float)x1c : (float)x0, (ck & 2) ? (float)y1c : (float)y0);
-                    const float dv = (ck & 4) ? hi : lo;
-                    float qx = __fadd_rn(__fmul_rn(cr.rx, dv), M[3]);
-                    float qy = __fadd_rn(__fmul_rn(cr.ry, dv), M[7]);
-                    float qz = __fadd_rn(__fmul_rn(cr.rz, dv), M[11]);
-                    ok = ok && (qz > 1e-20f) && (qz < 1e30f);
-                    float iz = 1.0f / qz;
-                    float u = qx * iz, v = qy * iz;
-                    ok = ok && (fabsf(u) < 1e30f) && (fabsf(v) < 1e30f);
-                    // clamp before the float->int conversion; windows are clipped to the image plus a zero ring
-                    u = fminf(fmaxf(u, -8.0f), (float)w + 8.0f);
-                    v = fminf(fmaxf(v, -8.0f), (float)h + 8.0f);
-                    umin = fminf(umin, u); umax = fmaxf(umax, u);
-                    vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
-                }
-                // interior samples differ from the corner hull by fp32 rounding only (<< 1/16 px)
-                wx0[i] = max((int)floorf(umin - 0.0625f), -1);
-                wy0[i] = max((int)floorf(vmin - 0.0625f), -1);
-                int wx1 = min((int)floorf(umax + 0.0625f) + 1, w);
-                int wy1 = min((int)floorf(vmax + 0.0625f) + 1, h);
-                ww[i] = max(wx1 - wx0[i] + 1, 0);
-                wh[i] = max(wy1 - wy0[i] + 1, 0);
-                if (ww[i] < 2 || wh[i] < 2) { ww[i] = 0; wh[i] = 0; }  // nothing of the image is touched
-                if (i >= p.n_src || !act) { ww[i] = 0; wh[i] = 0; ok = true; }
-                bad |= ok ? 0 : 1;  // frustum reaches p.z <= 0: cannot bound it
-                // ring size: the union of consecutive windows must fit (asynchronous delta staging)
-                int ux = ww[i], uy = wh[i];
-                {
-                    const int qx0 = __shfl_up(wx0[i], 1), qy0 = __shfl_up(wy0[i], 1);
-                    const int qw = __shfl_up(ww[i], 1), qh = __shfl_up(wh[i], 1);
-                    if (lane > 0 && act && qw > 0 && ww[i] > 0) {
-                        ux = max(wx0[i] + ww[i], qx0 + qw) - min(wx0[i], qx0);
-                        uy = max(wy0[i] + wh[i], qy0 + qh) - min(wy0[i], qy0);
-                    }
-                }
-                RW[i] = max(wave_maxi(ux), 1);
-                RH[i] = max(wave_maxi(uy), 1);
+                const int* hd = ldsi + CHD + (cand * NSRC + i) * 4;
+                RW[i] = hd[0]; RH[i] = hd[1]; bad |= hd[2];
                 total += (RW[i] + 1) * (RH[i] + 1) * STRIDE;
             }
-            bad = __any(bad) ? 1 : 0;
+            if (bad || total > a.cap_floats) continue;
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) {
+                const int* e = ldsi + CT + ((cand * NSRC + i) * 64 + lane) * 4;
+                wx0[i] = e[0]; wy0[i] = e[1]; ww[i] = e[2]; wh[i] = e[3];
+            }
             if (!bad && total <= a.cap_floats) {
                 mode = 1;
                 m_sel = m;
