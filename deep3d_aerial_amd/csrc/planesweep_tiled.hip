@@ -69,8 +69,8 @@ struct TiledArgs {
 //   [rect starts MAXSTEPS+4][rect descriptors MAXRECTS*8][rings ...]
 // header: 0 mode (1 rings, 0 global gather) | 1 m | 2 nsteps | 4+4i.. RW, RH, base, - per view
 // plan entry (per step, view): wx0, wy0, ww, wh, ox, oy, -, -
-// rect descriptor (non-empty delta rectangles, grouped by step): rx, ry, rw | view<<16, elements,
-//   first item (within the step), step item total (last rect of a step only),
+// rect descriptor (non-empty delta rectangles, grouped by step): rx, ry, rw | view<<16, positions,
+//   first position (cumulative within the step), -,
 //   ring col | row << 16 of the rect origin (unwrapped), ring base | RW << 18 | RH << 25 ... see item()
 template <int CH, int NSRC>
 struct Lds {
@@ -81,7 +81,8 @@ struct Lds {
     static constexpr int HDR = PMAX + DSEG_MAX;
     static constexpr int PLAN = HDR + 32;
     static constexpr int SST = PLAN + MAXSTEPS * NSRC * 8;
-    static constexpr int RECTS = ((SST + MAXSTEPS + 4 + 3) / 4) * 4;
+    static constexpr int STOT = SST + MAXSTEPS + 4;   // positions to stage per step
+    static constexpr int RECTS = ((STOT + MAXSTEPS + 3) / 4) * 4;
     static constexpr int DATA = RECTS + (MAXRECTS + 1) * 8;  // 16-byte aligned
 };
 
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                     int idx = incl - nrect;
                     if (act) ldsi[L::SST + lane] = idx;
                     if (lane == nsteps - 1) ldsi[L::SST + nsteps] = incl;
-                    int istart = 0;
+                    int pstart = 0;
 #pragma unroll
                     for (int i = 0; i < NSRC; ++i)
 #pragma unroll
@@ -461,16 +462,14 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                                 e[1] = ry[i][r];
                                 e[2] = rwid[i][r] | (i << 16);
                                 e[3] = nel[i][r];
-                                e[4] = istart;
+                                e[4] = pstart;
                                 // ring coordinates of the rect origin (unwrapped: < 2*RW, 2*RH) and ring geometry
                                 e[6] = (rx[i][r] - wx0[i] + oxv[i]) | ((ry[i][r] - wy0[i] + oyv[i]) << 16);
                                 e[7] = RW[i] | (RH[i] << 8) | ((basev[i] >> 2) << 16);
-                                istart += cnt[i][r];
+                                pstart += nel[i][r];
                                 ++idx;
                             }
-                    // item total of the step, readable as "first item" of the following entry; the next
-                    // step's first rect overwrites e[4] with 0, so keep the total in slot 5 of the LAST rect too
-                    if (act && nrect > 0) ldsi[L::RECTS + 8 * (idx - 1) + 5] = istart;
+                    if (act) ldsi[L::STOT + lane] = pstart;
                 }
             }
         }
@@ -511,28 +510,46 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         int meta;        // LDS float index of the ring slot | ok << 20 | dup column << 21 | dup row << 22, or -1
         int geo;         // RW | RH << 8 of the view's ring
     };
-    // Rect descriptor fields of one item, wave-uniform.
-    struct Desc {
-        int rx, ry, e2, nel, fi0, e6, e7;
-    };
-    auto item = [&](int it, bool live, const Desc& dsc) -> Item {
+    long long fdelta[NSRC];  // byte distance from the first source map to source map i (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        const long long d0 = reinterpret_cast<long long>(p.feats[1]);
+        const long long di = reinterpret_cast<long long>(p.feats[i + 1]);
+        fdelta[i] = (i < p.n_src) ? di - d0 : 0;
+    }
+    // Element `el` (0..T-1) of step k's flattened delta -> source address and ring slot of this lane.
+    // Each lane finds its own rectangle (<= 16 per step), so items are densely packed.
+    auto item = [&](int el, int T, int rb, const int (&pst16)[16]) -> Item {
         Item I;
-        const int rwid = dsc.e2 & 0xffff, vi = dsc.e2 >> 16;
-        const int RWv = dsc.e7 & 0xff, RHv = (dsc.e7 >> 8) & 0xff, bs = (dsc.e7 >> 16) << 2;
-        const int pos = (it - dsc.fi0) * 64 + lane;
-        const int cy = (int)(((float)pos + 0.5f) * (1.0f / (float)max(rwid, 1)));
+        const bool live = el < T;
+        // rect holding element el: count the rect starts <= el (starts beyond the step's rects are INT_MAX)
+        int ridx = rb - 1;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) ridx += (pst16[rr] <= el) ? 1 : 0;
+        ridx = max(ridx, rb);
+        const int* e = ldsi + L::RECTS + 8 * ridx;
+        const int rx = e[0], ry = e[1], e2 = e[2], pst = e[4], e6 = e[6], e7 = e[7];
+        const int rwid = e2 & 0xffff, vi = e2 >> 16;
+        const int RWv = e7 & 0xff, RHv = (e7 >> 8) & 0xff, bs = (e7 >> 16) << 2;
+        const int pos = el - pst;
+        const int cy = (int)(((float)pos + 0.5f) * __builtin_amdgcn_rcpf((float)max(rwid, 1)));
         const int cx = pos - cy * rwid;
-        const int sx = dsc.rx + cx, sy = dsc.ry + cy;
-        const bool inr = live && (pos < dsc.nel);
-        const bool ok = inr && ((unsigned)sx < (unsigned)w) && ((unsigned)sy < (unsigned)h);
-        const float* __restrict__ src = p.feats[min(vi + 1, p.n_src)];
-        I.g = src + (size_t)c0 * plane + (ok ? sy * w + sx : 0);
-        unsigned c = (unsigned)((dsc.e6 & 0xffff) + cx), r = (unsigned)((dsc.e6 >> 16) + cy);
+        const int sx = rx + cx, sy = ry + cy;
+        const bool ok = live && ((unsigned)sx < (unsigned)w) && ((unsigned)sy < (unsigned)h);
+        // per-lane source view: feats[1] + (uniform) byte distance to view vi's map.  Kept as integer
+        // arithmetic on purpose: a select chain over the pointers is turned back into an indexed load
+        // of the argument block, whose s_waitcnt vmcnt(0) would serialise the staging loads.
+        long long dsel = 0;
+#pragma unroll
+        for (int i = 1; i < NSRC; ++i) dsel = (vi == i) ? fdelta[i] : dsel;
+        I.g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.feats[1]) + dsel) + (size_t)c0 * plane +
+              (ok ? sy * w + sx : 0);
+        unsigned c = (unsigned)((e6 & 0xffff) + cx), r = (unsigned)((e6 >> 16) + cy);
         c = min(c, c - (unsigned)RWv);
         r = min(r, r - (unsigned)RHv);
         const int dst = bs + (int)r * ((RWv + 1) * STRIDE) + (int)c * STRIDE;
-        I.meta = inr ? (dst | (ok ? 1 << 20 : 0) | (c == 0 ? 1 << 21 : 0) | (r == 0 ? 1 << 22 : 0)) : -1;
-        I.geo = dsc.e7 & 0xffff;
+        I.meta = live ? (dst | (ok ? 1 << 20 : 0) | (c == 0 ? 1 << 21 : 0) | (r == 0 ? 1 << 22 : 0)) : -1;
+        I.geo = e7 & 0xffff;
         return I;
     };
     auto put = [&](int meta, int geo, int q, f4 v) {
@@ -550,70 +567,68 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     };
     f4 pf[PFD][Q];
     int pmeta[PFD], pgeo[PFD];
-    auto step_range = [&](int k, int& rb, int& re, int& nit) {
-        rb = rfl(ldsi[L::SST + k]);
-        re = rfl(ldsi[L::SST + k + 1]);
-        nit = (re > rb) ? rfl(ldsi[L::RECTS + 8 * (re - 1) + 5]) : 0;
-    };
     auto write_round = [&]() {
 #pragma unroll
         for (int j = 0; j < PFD; ++j)
 #pragma unroll
             for (int q = 0; q < Q; ++q) put(pmeta[j], pgeo[j], q, pf[j][q]);
     };
-    // Loader waves: bring window(k) minus window(k-1) into the rings.  One lane-parallel pass finds
-    // the rect descriptor of up to 64 items at once (lane = item); each item's fields then come from
-    // v_readlane, so there is no LDS round trip per item.
+    // Loader waves: bring window(k) minus window(k-1) into the rings.
+    const bool ltiming = a.tstats != nullptr && lw == 0;
+    long long lt_desc = 0, lt_issue = 0, lt_write = 0, lt_bar = 0;
     auto stage = [&](int k) {
-        int rb, re, nit;
-        step_range(k, rb, re, nit);
-        for (int base = 0; base < nit; base += 64) {
-            const int myit = base + lane;
-            int ridx = rb;
-            for (int rr = rb + 1; rr < re; ++rr) ridx = (ldsi[L::RECTS + 8 * rr + 4] <= myit) ? rr : ridx;
-            const int* e = ldsi + L::RECTS + 8 * ridx;
-            const int f0 = e[0], f1 = e[1], f2 = e[2], f3 = e[3], f4_ = e[4], f6 = e[6], f7 = e[7];
-            const int nhere = min(nit - base, 64);
-            for (int o = lw; o < nhere; o += NLOADW * PFD) {
+        const int rb = rfl(ldsi[L::SST + k]), re = rfl(ldsi[L::SST + k + 1]);
+        const int T = rfl(ldsi[L::STOT + k]);
+        const int nitems = (T + 63) >> 6;
+        // first positions of the step's (<= 16) rects: one LDS read by 16 lanes, then wave-uniform copies
+        const int psv = (lane < re - rb) ? ldsi[L::RECTS + 8 * (rb + min(lane, 15)) + 4] : 0x7fffffff;
+        int pst16[16];
 #pragma unroll
-                for (int j = 0; j < PFD; ++j) {
-                    const int sl = o + NLOADW * j;  // source lane = item index within this pass
-                    const bool live = sl < nhere;
-                    const int sll = live ? sl : 0;
-                    Desc dsc;
-                    dsc.rx = __builtin_amdgcn_readlane(f0, sll);
-                    dsc.ry = __builtin_amdgcn_readlane(f1, sll);
-                    dsc.e2 = __builtin_amdgcn_readlane(f2, sll);
-                    dsc.nel = __builtin_amdgcn_readlane(f3, sll);
-                    dsc.fi0 = __builtin_amdgcn_readlane(f4_, sll);
-                    dsc.e6 = __builtin_amdgcn_readlane(f6, sll);
-                    dsc.e7 = __builtin_amdgcn_readlane(f7, sll);
-                    Item I = item(base + sl, live, dsc);
+        for (int rr = 0; rr < 16; ++rr) pst16[rr] = __builtin_amdgcn_readlane(psv, rr);
+        for (int it0 = lw; it0 < nitems; it0 += NLOADW * PFD) {
+            long long tq1 = 0, tq2 = 0;
+            if (ltiming) tq1 = clock64();
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
-                        pf[j][q][0] = g[0];
-                        pf[j][q][1] = g[plane];
-                        pf[j][q][2] = g[2 * plane];
-                        pf[j][q][3] = g[3 * plane];
-                    }
-                    pmeta[j] = I.meta;
-                    pgeo[j] = I.geo;
+            for (int j = 0; j < PFD; ++j) {
+                const int it = it0 + NLOADW * j;
+                Item I = item(it < nitems ? it * 64 + lane : T, T, rb, pst16);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
+                    pf[j][q][0] = g[0];
+                    pf[j][q][1] = g[plane];
+                    pf[j][q][2] = g[2 * plane];
+                    pf[j][q][3] = g[3 * plane];
                 }
-                write_round();
+                pmeta[j] = I.meta;
+                pgeo[j] = I.geo;
             }
+            if (ltiming) { tq2 = clock64(); lt_issue += tq2 - tq1; }
+            write_round();
+            if (ltiming) lt_write += clock64() - tq2;
         }
     };
 
     // Barrier k separates {compute step k-1, stage delta k} from {compute step k, stage delta k+1}.
     // Both roles execute exactly nsteps barriers in ring mode and none in gather mode.
     if (loader) {
+        // (Raising the loaders' issue priority with s_setprio was measured: their decode time halves,
+        // but the compute waves lose the same slots and the kernel gets 5 % slower -- left at default.)
         if (ring) {
             stage(0);
             for (int k = 0; k < nsteps; ++k) {
+                long long tb = 0;
+                if (ltiming) tb = clock64();
                 __syncthreads();
+                if (ltiming) lt_bar += clock64() - tb;
                 if (k + 1 < nsteps) stage(k + 1);
             }
+        }
+        if (ltiming && lane == 0) {
+            atomicAdd(a.tstats + 2, (unsigned long long)lt_bar);
+            atomicAdd(a.tstats + 5, (unsigned long long)lt_desc);
+            atomicAdd(a.tstats + 6, (unsigned long long)lt_issue);
+            atomicAdd(a.tstats + 7, (unsigned long long)lt_write);
         }
         return;
     }
@@ -843,8 +858,9 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         unsigned long long ht[8];
         hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
         hipMemcpy(ht, a.tstats, sizeof(ht), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[d3d tiled timing] per-WG mean cycles (wave 0): prologue %.0f | barrier wait %.0f | - %.0f | compute %.0f | total %.0f\n",
-                ht[0] / (double)nblk, ht[1] / (double)nblk, ht[2] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk);
+        fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f | compute %.0f | total %.0f || loader 0: barrier wait %.0f | descriptors %.0f | decode+issue %.0f | wait+write %.0f\n",
+                ht[0] / (double)nblk, ht[1] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk, ht[2] / (double)nblk,
+                ht[5] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
         fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_m=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
                 CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
                 a.cap_floats / L::STRIDE, hs[5], a.dseg);
