@@ -52,6 +52,8 @@ constexpr int THREADS = 64 * NWAVES;
 constexpr int DSEG_MAX = 384;   // planes per workgroup segment upper bound
 constexpr int MAXSTEPS = 64;    // >= DSEG_MAX / NSUB, <= 64 (one lane per step)
 constexpr int PFD = 2;          // delta staging items (64 positions x CH channels) a loader wave keeps in flight
+constexpr int LDS_PIPE = 1;     // (quad, view) units whose taps are requested ahead of the one being blended
+constexpr int NCAND = 4;        // candidate step sizes: 4, 2, 1, 1/2 times NSUB planes
 constexpr int MAXRECTS = 256;   // non-empty delta rectangles per workgroup segment
 
 struct TiledArgs {
@@ -67,7 +69,7 @@ struct TiledArgs {
 // LDS map (ints/floats):
 //   [zero cell 2*STRIDE][pmin DSEG_MAX][pmax DSEG_MAX][header 32][plan table MAXSTEPS*NSRC*8]
 //   [rect starts MAXSTEPS+4][rect descriptors MAXRECTS*8][rings ...]
-// header: 0 mode (1 rings, 0 global gather) | 1 m | 2 nsteps | 4+4i.. RW, RH, base, - per view
+// header: 0 mode (1 rings, 0 global gather) | 1 planes per step | 2 nsteps | 4+4i.. RW, RH, base, - per view
 // plan entry (per step, view): wx0, wy0, ww, wh, ox, oy, -, -
 // rect descriptor (non-empty delta rectangles, grouped by step): rx, ry, rw | view<<16, positions,
 //   first position (cumulative within the step), -,
@@ -296,12 +298,14 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     //     step size m in {4, 2, 1}; results go to a scratch table in the (still unused) ring area.
     // P2: wave 0 picks the largest candidate whose rings fit and builds the plan / rectangle tables.
     constexpr int CT = L::DATA;                          // [cand][view][step][4] windows
-    constexpr int CHD = CT + 3 * NSRC * 64 * 4;          // [cand][view][4]: RW, RH, bad, nsteps
-    {
-        const int cand = wave / NSRC, vsel = wave % NSRC;
-        if (cand < 3) {
-            const int m = 4 >> cand;
-            const int SPc = NSUB * m;
+    constexpr int CHD = CT + NCAND * NSRC * 64 * 4;      // [cand][view][4]: RW, RH, bad, nsteps
+    // candidate c steps by NSUB*4, NSUB*2, NSUB, NSUB/2 planes (the last leaves half the sub-waves idle,
+    // which is still far better than gathering from global memory)
+    auto cand_planes = [](int c) { return c < 3 ? NSUB * (4 >> c) : max(NSUB / 2, 1); };
+    for (int wk = wave; wk < NCAND * NSRC; wk += NWAVES) {
+        const int cand = wk / NSRC, vsel = wk % NSRC;
+        {
+            const int SPc = cand_planes(cand);
             const int nstepc = (nplanes + SPc - 1) / SPc;
             const bool feasible = nstepc <= MAXSTEPS;
             const bool act = feasible && lane < nstepc;
@@ -361,9 +365,8 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     }
     __syncthreads();
     if (wave == 0) {
-        int mode = 0, m_sel = 1, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
-        for (int cand = 0; cand < 3 && !mode; ++cand) {
-            const int m = 4 >> cand;
+        int mode = 0, sp_sel = NSUB, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
+        for (int cand = 0; cand < NCAND && !mode; ++cand) {
             const int nsteps = ldsi[CHD + (cand * NSRC) * 4 + 3];
             const bool act = lane < nsteps;
             int wx0[NSRC], wy0[NSRC], ww[NSRC], wh[NSRC], RW[NSRC], RH[NSRC];
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             }
             if (!bad && total <= a.cap_floats) {
                 mode = 1;
-                m_sel = m;
+                sp_sel = cand_planes(cand);
                 nsteps_sel = nsteps;
                 int base = L::DATA;
                 int oxv[NSRC], oyv[NSRC], basev[NSRC];
@@ -475,18 +478,17 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         }
         if (lane == 0) {
             ldsi[L::HDR + 0] = mode;
-            ldsi[L::HDR + 1] = m_sel;
+            ldsi[L::HDR + 1] = sp_sel;
             ldsi[L::HDR + 2] = nsteps_sel;
         }
     }
     __syncthreads();
     const int ring = rfl(ldsi[L::HDR + 0]);
-    const int mplanes = rfl(ldsi[L::HDR + 1]);
+    const int SP = rfl(ldsi[L::HDR + 1]);  // planes per step
     const int nsteps = rfl(ldsi[L::HDR + 2]);
-    const int SP = NSUB * mplanes;
     if (a.stats && tid == 0) {
         atomicAdd(a.stats + (ring ? 0 : 1), 1u);
-        atomicAdd(a.stats + 2, (unsigned)mplanes);
+        atomicAdd(a.stats + 2, (unsigned)SP);
         atomicAdd(a.stats + 3, (unsigned)nsteps);
         if (ring) {
             unsigned tot = 0;
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #pragma unroll
         for (int i = 0; i < NSRC; ++i) W[i] = load_win(ring ? k : 0, i);
 
-        for (int j = 0; j < mplanes; ++j) {
+        for (int j = 0; sub + NSUB * j < SP; ++j) {
             const int dl_ = k * SP + sub + NSUB * j;
             if (dl_ >= nplanes) break;
             const int d = ds + dl_;
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 // Units u = (quad q, view i) in q-major order; the four taps of unit u+1 are requested
                 // before unit u is blended, so LDS latency overlaps the 24 VALU ops of a unit.
                 constexpr int NU = Q * NSRC;
-                constexpr int PD = 1;  // units requested ahead of the one being blended
+                constexpr int PD = LDS_PIPE;  // units requested ahead of the one being blended
                 f4 tp[PD + 1][4];
                 auto request = [&](int u, f4 (&dst)[4]) {
                     const int q2 = u / NSRC, i2 = u % NSRC;
@@ -755,11 +757,12 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 };
 #pragma unroll
                 for (int u = 0; u < PD && u < NU; ++u) request(u, tp[u % (PD + 1)]);
+                if (PD == 0) request(0, tp[0]);
                 f4 s, qq;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     const int q = u / NSRC, i = u % NSRC;
-                    if (u + PD < NU) request(u + PD, tp[(u + PD) % (PD + 1)]);
+                    if (PD > 0 ? (u + PD < NU) : (u > 0)) request(u + PD, tp[(u + PD) % (PD + 1)]);
                     if (i == 0) {
                         if (MODE == MODE_VARIANCE) { s = r[q]; qq = r[q] * r[q]; }
                         else { s = (f4){0, 0, 0, 0}; qq = s; }
@@ -861,7 +864,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f | compute %.0f | total %.0f || loader 0: barrier wait %.0f | descriptors %.0f | decode+issue %.0f | wait+write %.0f\n",
                 ht[0] / (double)nblk, ht[1] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk, ht[2] / (double)nblk,
                 ht[5] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
-        fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_m=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
+        fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
                 CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
                 a.cap_floats / L::STRIDE, hs[5], a.dseg);
         hipFree(a.stats);
