@@ -38,6 +38,10 @@ SIGNATURES = {
     "d3d_convtranspose3d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv_gemm_f32": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                          _i, _i, _i, _i, _i, ctypes.c_char_p, _vp, _vp],
+    "d3d_conv_fold_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                          ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
     "d3d_gru_gates": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "d3d_gru_update": [_vp, _vp, _vp, _i64, _vp, _vp],
     "d3d_pair_softmax_max": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
@@ -83,6 +87,9 @@ def load():
         raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3
 
 
 def check(rc, what):

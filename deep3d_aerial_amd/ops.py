@@ -208,6 +208,8 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
     Co = weight.shape[0]
     if tuple(weight.shape) != (Co, Ci, 3, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    if _use_mfma() and Co <= 64:
+        return conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)
     o = lambda n: (n - 1) // stride + 1
     out = torch.empty((Co, o(D), o(H), o(W)), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
@@ -225,6 +227,8 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    if _use_mfma() and Co <= 64:
+        return convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=1 if relu else 0)
     out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
@@ -244,6 +248,8 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
+    if _use_mfma() and Co <= 64:
+        return conv_k3_mfma(x, weight, scale, shift, skip, act=act, stride=stride, x2=x2)
     o = lambda n: (n - 1) // stride + 1
     out = torch.empty((Co, o(H), o(W)), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
@@ -261,6 +267,8 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    if _use_mfma() and Co <= 64:
+        return convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
     out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape mismatch")
@@ -290,4 +298,280 @@ def gru_update(u, h, convc):
     rc = _lib.load().d3d_gru_update(_chk(u, "u"), _chk(h, "h"), _chk(convc, "convc"), h.numel(), _chk(out, "out"),
                                     _stream())
     _lib.check(rc, "d3d_gru_update")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# MFMA implicit-GEMM convolution (d3d_conv_gemm_f32): weight packing, tap lists, dispatch
+# ----------------------------------------------------------------------------------------
+import os as _os
+import weakref as _weakref
+
+import numpy as _np
+
+_pack_cache = {}
+
+
+def _mpad(co):
+    mt = (co + 15) // 16
+    return 16 * (4 if mt == 3 else mt)
+
+
+def _use_mfma():
+    return _os.environ.get("D3D_CONV", "mfma") != "direct"
+
+
+def _packed(weight, transposed):
+    """Packed GEMM operands of a k=3 conv weight, cached per parameter version.
+
+    conv  [Co,Ci,(3,)3,3] -> one (wpack [T*Ci, mpad], taps int8 [T,3]) with offsets -1..1.
+    convT [Ci,Co,(3,)3,3] -> one entry per output-parity class: (parity zyx, wpack, taps) with
+    offsets 0/+1 (even outputs: kernel index 1 at o/2; odd: index 0 at (o+1)/2, index 2 at (o-1)/2).
+    """
+    # keyed by the tensor OBJECT (weak), validated by storage address and in-place version counter:
+    # load_state_dict / copy_ / optimizer steps bump the version; writes through `.data` do not --
+    # call clear_weight_cache() after those.
+    key = (id(weight), transposed)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+        return hit[2]
+    nd = weight.dim() - 2
+    with torch.no_grad():
+        w = weight.detach().float()
+        if nd == 2:
+            w = w.unsqueeze(2)  # [.., 1, 3, 3]: z kernel of size 1
+        kz_n = w.shape[2]
+        if not transposed:
+            Co, Ci = w.shape[0], w.shape[1]
+            taps = [(kz - (kz_n // 2), ky - 1, kx - 1) for kz in range(kz_n) for ky in range(3) for kx in range(3)]
+            wp = w.reshape(Co, Ci, -1).permute(2, 1, 0).reshape(-1, Co)
+            pad = torch.zeros((wp.shape[0], _mpad(Co)), dtype=torch.float32, device=w.device)
+            pad[:, :Co] = wp
+            out = (pad.contiguous(), _np.array(taps, _np.int8).tobytes(), len(taps))
+        else:
+            Ci, Co = w.shape[0], w.shape[1]
+            dim_opts = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}  # parity -> [(kernel index, input offset)]
+            out = []
+            zpar = [0] if kz_n == 1 else [0, 1]
+            for pz in zpar:
+                for py in (0, 1):
+                    for px in (0, 1):
+                        zl = [(0, 0)] if kz_n == 1 else dim_opts[pz]
+                        taps, cols = [], []
+                        for (kz, oz) in zl:
+                            for (ky, oy) in dim_opts[py]:
+                                for (kx, ox) in dim_opts[px]:
+                                    taps.append((oz, oy, ox))
+                                    cols.append(w[:, :, kz, ky, kx])  # [Ci, Co]
+                        wp = torch.stack(cols, 0).reshape(-1, Co)      # [T*Ci, Co]
+                        pad = torch.zeros((wp.shape[0], _mpad(Co)), dtype=torch.float32, device=w.device)
+                        pad[:, :Co] = wp
+                        out.append(((pz, py, px), pad.contiguous(), _np.array(taps, _np.int8).tobytes(), len(taps)))
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), out)
+    return out
+
+
+def clear_weight_cache():
+    """Drop every packed-weight entry (needed only after writing weights through `.data`)."""
+    _pack_cache.clear()
+
+
+def _gemm(x, x2, wpack, taps, ntaps, Co, scale, shift, skip, skip_after_act, act, in_dims, grid, out, istride,
+          ostride, ooff):
+    D, H, W = in_dims
+    Dg, Hg, Wg = grid
+    Do, Ho, Wo = out.shape[-3:] if out.dim() == 4 else (1,) + tuple(out.shape[-2:])
+    Ci0 = x.shape[0]
+    Ci1 = 0 if x2 is None else x2.shape[0]
+    rc = _lib.load().d3d_conv_gemm_f32(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), wpack.shape[1],
+                                       _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
+                                       int(skip_after_act), int(act), Co, D, H, W, Dg, Hg, Wg, Do, Ho, Wo, istride,
+                                       ostride, ooff[0], ooff[1], ooff[2], ntaps, taps, _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_conv_gemm_f32")
+
+
+def conv_k3_mfma(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None, skip_after_act=True):
+    """k=3, pad 1 conv (2D: x [Ci,H,W]; 3D: x [Ci,D,H,W]) over cat(x, x2) on the matrix cores."""
+    if _os.environ.get("D3D_CONV", "mfma") != "mfma_slice":
+        y = conv_fold(x, weight, scale, shift, skip, act, stride, x2, skip_after_act, transposed=False)
+        if y is not None:
+            return y
+    three_d = x.dim() == 4
+    dims = tuple(x.shape[1:]) if three_d else (1,) + tuple(x.shape[1:])
+    Co = weight.shape[0]
+    wpack, taps, nt = _packed(weight, False)
+    o = lambda n: (n - 1) // stride + 1
+    od = (o(dims[0]) if three_d else 1, o(dims[1]), o(dims[2]))
+    out = torch.empty((Co,) + (od if three_d else od[1:]), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+    _gemm(x, x2, wpack, taps, nt, Co, scale, shift, skip, skip_after_act, act, dims, od, out, stride, 1, (0, 0, 0))
+    return out
+
+
+def convtranspose_k3s2_mfma(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=True):
+    """k=3, stride 2, pad 1, output_pad 1 transposed conv as 4 (2D) / 8 (3D) parity-class launches."""
+    if _os.environ.get("D3D_CONV", "mfma") != "mfma_slice":
+        y = conv_fold(x, weight, scale, shift, skip, act, 2, None, skip_after_act, transposed=True)
+        if y is not None:
+            return y
+    three_d = x.dim() == 4
+    dims = tuple(x.shape[1:]) if three_d else (1,) + tuple(x.shape[1:])
+    Co = weight.shape[1]
+    od = (2 * dims[0] if three_d else 1, 2 * dims[1], 2 * dims[2])
+    out = torch.empty((Co,) + (od if three_d else od[1:]), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+    for (par, wpack, taps, nt) in _packed(weight, True):
+        _gemm(x, None, wpack, taps, nt, Co, scale, shift, skip, skip_after_act, act, dims, dims, out, 1, 2, par)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# z-streaming folded implicit GEMM (d3d_conv_fold_f32): tap lists / packed weights per layer
+# ----------------------------------------------------------------------------------------
+def _dim_conv(K, stride, fold):
+    """One dimension of an ordinary k=3 (or k=1) convolution folded over `fold` neighbouring outputs:
+    (tap offsets, fold positions, k(tap, fold) -> kernel index or -1, input step, output step, base)."""
+    if K == 1:
+        return [0], [0], (lambda t, f: 0), 1, 1, 0
+    taps = list(range(-1, (fold - 1) * stride + 2))
+    k = lambda t, f: (t - f * stride + 1) if 0 <= t - f * stride + 1 <= 2 else -1
+    return taps, list(range(fold)), k, fold * stride, fold, 0
+
+
+def _dim_convT(K, parities):
+    """One dimension of a k=3 stride-2 pad-1 output_pad-1 transposed convolution: output 2g+p reads input
+    g+o with kernel index k(o,p): p even -> (o=0: 1); p odd -> (o=0: 2, o=1: 0)."""
+    if K == 1:
+        return [0], [0], (lambda t, f: 0), 1, 1, 0
+    table = {(0, 0): 1, (0, 1): 2, (1, 1): 0}
+    k = lambda o, f: table.get((o, parities[f]), -1)
+    return [0, 1], list(range(len(parities))), k, 1, 2, (parities[0] if len(parities) == 1 else 0)
+
+
+def _fold_pack(wk, dims, Co):
+    """wk [Co,Ci,KZ*KY*KX] -> (wpack [T,Ci,mpad], taps bytes (sorted by z), T, M, geom tail [c,s,b,f per dim])."""
+    (tz, fz, kz, cz, sz, bz), (ty, fy, ky, cy, sy, by), (tx, fx, kx, cx, sx, bx) = dims
+    KY = 3
+    KX = 3
+    F = len(fz) * len(fy) * len(fx)
+    M = Co * F
+    if M > 64:
+        raise ValueError("fold %dx%dx%d of %d channels exceeds 64 GEMM rows" % (len(fz), len(fy), len(fx), Co))
+    mpad = 16 if M <= 16 else (32 if M <= 32 else 64)
+    nk = wk.shape[2]
+    taps, kidx = [], []
+    for oz in tz:
+        for oy in ty:
+            for ox in tx:
+                row = []
+                for a in fz:
+                    for b in fy:
+                        for c in fx:
+                            i, jj, l = kz(oz, a), ky(oy, b), kx(ox, c)
+                            row.append(nk if min(i, jj, l) < 0 else (i * KY + jj) * KX + l)
+                if any(r != nk for r in row):
+                    taps.append((oz, oy, ox))
+                    kidx.append(row)
+    T = len(taps)
+    Ci = wk.shape[1]
+    wz = torch.cat([wk, torch.zeros((Co, Ci, 1), dtype=wk.dtype, device=wk.device)], 2)
+    idx = torch.tensor(kidx, dtype=torch.long, device=wk.device)        # [T, F]
+    a = wz[:, :, idx]                                                    # [Co, Ci, T, F]
+    a = a.permute(2, 1, 3, 0).reshape(T, Ci, M)                          # row m = fold*Co + co
+    wpack = torch.zeros((T, Ci, mpad), dtype=torch.float32, device=wk.device)
+    wpack[:, :, :M] = a
+    tail = [cz, cy, cx, sz, sy, sx, bz, by, bx, len(fz), len(fy), len(fx)]
+    return wpack.contiguous(), _np.array(taps, _np.int8).tobytes(), T, M, mpad, tail
+
+
+def _conv_fold_choice(Co, KZ, stride):
+    """Fold (fz,fy,fx) that fills the 16 GEMM rows of a narrow layer, within the kernel's 128-tap limit."""
+    if _os.environ.get("D3D_CONV_NOFOLD"):
+        return (1, 1, 1)
+    want = [(1, 4, 4), (1, 2, 4), (1, 2, 2), (1, 1, 2)]
+    ntaps = lambda f: (KZ if KZ == 1 else 3) * ((f[1] - 1) * stride + 3) * ((f[2] - 1) * stride + 3)
+    for f in want:
+        if Co * f[1] * f[2] <= 16 and ntaps(f) <= 128:
+            return f
+    return (1, 1, 1)
+
+
+def _packed_fold(weight, transposed, stride):
+    """List of launches [(wpack, taps, T, M, mpad, geom tail)] for one layer, cached like _packed."""
+    key = (id(weight), "fold", transposed, stride)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+        return hit[2]
+    with torch.no_grad():
+        w = weight.detach().float()
+        three_d = w.dim() == 5
+        if not three_d:
+            w = w.unsqueeze(2)
+        KZ = w.shape[2]
+        if transposed:
+            w = w.transpose(0, 1)
+        Co, Ci = w.shape[0], w.shape[1]
+        wk = w.reshape(Co, Ci, -1).contiguous()
+        launches = []
+        if not transposed:
+            f = _conv_fold_choice(Co, KZ, stride)
+            dims = (_dim_conv(KZ, stride, f[0]), _dim_conv(3, stride, f[1]), _dim_conv(3, stride, f[2]))
+            launches.append(_fold_pack(wk, dims, Co))
+        else:
+            # all output parities as GEMM rows while they fit 64 rows; otherwise one launch per z (then y) parity
+            zsets = [[0, 1]] if (KZ == 3 and Co * 8 <= 64) else ([[0], [1]] if KZ == 3 else [[0]])
+            nz = 2 if (KZ == 3 and len(zsets) == 1) else 1
+            ysets = [[0, 1]] if Co * nz * 4 <= 64 else [[0], [1]]
+            ny = len(ysets[0])
+            xsets = [[0, 1]] if Co * nz * ny * 2 <= 64 else [[0], [1]]
+            for zs in zsets:
+                for ys in ysets:
+                    for xs in xsets:
+                        dims = (_dim_convT(KZ, zs), _dim_convT(3, ys), _dim_convT(3, xs))
+                        launches.append(_fold_pack(wk, dims, Co))
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), launches)
+    return launches
+
+
+def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None, skip_after_act=True,
+              transposed=False):
+    """k=3 convolution (2D [C,H,W] or 3D [C,D,H,W]; ordinary stride 1|2 over cat(x,x2), or transposed
+    stride 2) through the z-streaming folded GEMM.  Returns None when the layer's resident weights do not fit
+    LDS (D3D_ERR_UNSUPPORTED): the caller then takes the per-slice MFMA path."""
+    three_d = x.dim() == 4
+    D, H, W = tuple(x.shape[1:]) if three_d else (1,) + tuple(x.shape[1:])
+    Co = weight.shape[1] if transposed else weight.shape[0]
+    if transposed:
+        od = (2 * D if three_d else 1, 2 * H, 2 * W)
+    else:
+        o = lambda n: (n - 1) // stride + 1
+        od = (o(D) if three_d else 1, o(H), o(W))
+    out = torch.empty((Co,) + (od if three_d else od[1:]), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+    lib = _lib.load()
+    Ci0 = x.shape[0]
+    Ci1 = 0 if x2 is None else x2.shape[0]
+    for (wpack, taps, T, M, mpad, tail) in _packed_fold(weight, transposed, stride):
+        if wpack.shape[1] != Ci0 + Ci1:
+            raise ValueError("weight has %d input channels, inputs have %d" % (wpack.shape[1], Ci0 + Ci1))
+        cz, cy, cx, sz, sy, sx, bz, by, bx, fz, fy, fx = tail
+        if transposed:
+            G = (D, H, W)
+        else:
+            G = tuple((od[i] + (fz, fy, fx)[i] - 1) // (fz, fy, fx)[i] for i in range(3))
+        geom = (ctypes.c_int * 15)(G[0], G[1], G[2], cz, cy, cx, sz, sy, sx, bz, by, bx, fz, fy, fx)
+        rc = lib.d3d_conv_fold_f32(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
+                                   _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
+                                   int(skip_after_act), int(act), Co, D, H, W, od[0], od[1], od[2], geom, T, taps,
+                                   _chk(out, "out"), _stream())
+        if rc == _lib.ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, "d3d_conv_fold_f32")
     return out

@@ -183,6 +183,43 @@ int d3d_convtranspose2d_k3s2(const float* in, const float* weight, const float* 
                              float* out, d3d_stream_t stream);
 
 /*
+ * The same convolution family on the matrix cores (v_mfma_f32_16x16x4_f32: fp32 in, fp32 accumulate,
+ * numerically an fmaf chain, so parity with the fp32 reference is unchanged) as ONE implicit-GEMM
+ * entry point driven by a tap list.  It serves module.py:297-304 / cas_mvsnet.py:84-121 (Conv3d,
+ * ConvTranspose3d) and module.py:5-51 / adamvs.py:198-238,403-427 (Conv2d over a channel concat,
+ * ConvTranspose2d); the Python host packs the weights and emits the tap lists (ops.conv_gemm).
+ *   wpack  [ntaps*(Ci0+Ci1)][mpad]: packed weights, row (t*Ci + ci), mpad = 16*ceil(Co/16) (64 if 48),
+ *          zero padded; value = W[co][ci][tap t] (conv) or W[ci][co][tap t] (transposed).
+ *   taps_zyx [ntaps][3] (HOST, signed char): input offset of tap t; input index = g*istride + offset.
+ *   The launch iterates an output grid Dg x Hg x Wg; output index = g*ostride + (oz,oy,ox) in a
+ *   [Co,Do,Ho,Wo] tensor (ostride 2 = one output-parity class of a stride-2 transposed conv).
+ *   scale/shift/skip/act/skip_after_act as for d3d_conv2d_k3.  2D tensors use D = Dg = Do = 1.
+ */
+int d3d_conv_gemm_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad,
+                      const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
+                      int Co, int D, int H, int W, int Dg, int Hg, int Wg, int Do, int Ho, int Wo, int istride,
+                      int ostride, int oz, int oy, int ox, int ntaps, const signed char* taps_zyx, float* out,
+                      d3d_stream_t stream);
+
+/*
+ * z-streaming variant of the matrix-core convolution (conv_stream.hip): every input plane is staged into
+ * LDS once per (x,y) tile and feeds up to three live output planes; all packed weights stay resident in
+ * LDS; GEMM rows are (fold position, c_out), so narrow layers fill the 16-row MFMA tile with neighbouring
+ * outputs and a stride-2 transposed convolution is ONE launch (fold = its 2x2(x2) output parities).
+ * Serves the same reference modules as d3d_conv_gemm_f32; returns D3D_ERR_UNSUPPORTED when the resident
+ * weights do not fit LDS (callers then use d3d_conv_gemm_f32).
+ *   geom (HOST int[15]) = {Gz,Gy,Gx, cz,cy,cx, sz,sy,sx, bz,by,bx, fz,fy,fx}: column grid; per dimension
+ *        input index = g*c + tap offset, output index = g*s + b + fold position (clipped to Do/Ho/Wo).
+ *   M = Co*fz*fy*fx <= 64 GEMM rows, row m = ((fz_i*fy + fy_i)*fx + fx_i)*Co + co;  mpad = 16 | 32 | 64.
+ *   wpack [ntaps][Ci0+Ci1][mpad] (zero where a fold position does not use a tap);
+ *   taps_zyx (HOST signed char[ntaps][3]) sorted by z offset, ntaps <= 128.
+ */
+int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
+                      const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
+                      int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
+                      const signed char* taps_zyx, float* out, d3d_stream_t stream);
+
+/*
  * module.py:24-51 ConvGRUCell gate math, fused:
  *   phase 0: gates [2Hc,H,W] (pre-activation, bias already applied) ->
  *            r = sigmoid(gates[:Hc]); u = sigmoid(gates[Hc:]); rh = r*h; u stored.

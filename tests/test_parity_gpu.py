@@ -308,7 +308,15 @@ def _fill(mod, seed):
     return mod.cuda().eval()
 
 
-def test_conv_primitives_vs_oracle(ops, oracle):
+@pytest.fixture(params=["mfma", "mfma_slice", "direct"])
+def convpath(request, monkeypatch):
+    """The implementations of the conv family: z-streaming folded MFMA GEMM (default, with the per-slice
+    MFMA kernel where the weights do not fit LDS), per-slice MFMA only, and the direct VALU kernels."""
+    monkeypatch.setenv("D3D_CONV", request.param)
+    return request.param
+
+
+def test_conv_primitives_vs_oracle(ops, oracle, convpath):
     rng = np.random.default_rng(11)
     x = rng.standard_normal((5, 6, 10, 14)).astype(np.float32)
     w3 = (0.2 * rng.standard_normal((7, 5, 3, 3, 3))).astype(np.float32)
@@ -332,7 +340,54 @@ def test_conv_primitives_vs_oracle(ops, oracle):
     assert np.abs(got - oracle.convtranspose2d_k3s2(x2, wt2)).max() <= 1e-5
 
 
-def test_costregnet3d_golden(ops):
+@pytest.mark.parametrize("Ci,Co", [(1, 8), (8, 16), (19, 32), (32, 48), (16, 64), (40, 1)])
+@pytest.mark.parametrize("mode", ["mfma", "mfma_slice"])
+def test_conv_gemm_channel_counts_and_epilogue(ops, oracle, Ci, Co, mode, monkeypatch):
+    """MFMA implicit GEMMs across their tile variants (MT 1..4, folds, chunk tails), ragged rows, full epilogue."""
+    monkeypatch.setenv("D3D_CONV", mode)
+    rng = np.random.default_rng(100 + Ci + Co)
+    x = rng.standard_normal((Ci, 3, 9, 71)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    for stride in (1, 2):
+        want = oracle.conv3d_k3(x, w, stride=stride)
+        skip = rng.standard_normal(want.shape).astype(np.float32)
+        want = np.maximum(want * sc[:, None, None, None] + sh[:, None, None, None], 0) + skip
+        got = host(ops.conv_k3_mfma(dev(x), dev(w), dev(sc), dev(sh), dev(skip), act=1, stride=stride))
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), stride
+    wt = (0.2 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
+    want = oracle.convtranspose3d_k3s2(x, wt)
+    got = host(ops.convtranspose_k3s2_mfma(dev(x), dev(wt)))
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    # 2D, two-input concat, skip before the activation
+    x2 = x[:, 0]
+    a, b = x2[: (Ci + 1) // 2], x2[(Ci + 1) // 2:]
+    w2 = (0.2 * rng.standard_normal((Co, Ci, 3, 3))).astype(np.float32)
+    want = oracle.conv2d_k3(x2, w2, sh, stride=1)
+    skip = rng.standard_normal(want.shape).astype(np.float32)
+    want = np.maximum(want + skip, 0)
+    got = host(ops.conv_k3_mfma(dev(a), dev(w2), None, dev(sh), dev(skip), act=1, stride=1,
+                                x2=dev(b) if b.shape[0] else None, skip_after_act=False))
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    wt2 = (0.2 * rng.standard_normal((Ci, Co, 3, 3))).astype(np.float32)
+    got = host(ops.convtranspose_k3s2_mfma(dev(x2), dev(wt2)))
+    want = oracle.convtranspose2d_k3s2(x2, wt2)
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_conv_gemm_weight_cache_follows_updates(ops, oracle):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4, 8, 20)).astype(np.float32)
+    w = torch.from_numpy((0.2 * rng.standard_normal((8, 4, 3, 3))).astype(np.float32)).cuda()
+    y0 = host(ops.conv_k3_mfma(dev(x), w))
+    w.mul_(2.0)  # in-place update bumps the version -> repacked
+    y1 = host(ops.conv_k3_mfma(dev(x), w))
+    assert np.abs(y1 - 2 * y0).max() <= 1e-5
+
+
+def test_costregnet3d_golden(ops, convpath):
     from deep3d_aerial_amd.cas_mvsnet import CostRegNet
 
     g = load_golden("ops_costreg3d")
@@ -345,7 +400,7 @@ def test_costregnet3d_golden(ops):
         assert rel_l1(y, g[k + "y"]) <= 2e-5, i
 
 
-def test_slice_gru_golden(ops):
+def test_slice_gru_golden(ops, convpath):
     from deep3d_aerial_amd.adamvs import SliceCostRegNetRED
 
     g = load_golden("ops_gru")
@@ -365,7 +420,7 @@ def test_slice_gru_golden(ops):
         assert np.abs(host(s2) - g[k + "state2"]).max() <= 1e-4
 
 
-def test_pairnet_golden(ops):
+def test_pairnet_golden(ops, convpath):
     from deep3d_aerial_amd.adamvs import CostRegNet2D
 
     g = load_golden("ops_pairnet")
