@@ -19,6 +19,8 @@
 // Geometry per dimension d:  input index  = g_d*c_d + tap_d,   output index = g_d*s_d + b_d + fold_d.
 // GEMM: D[m][col] += A[m][k] * B[k][col], k = (tap, ci); A = wpack[t][ci][m] (LDS), B = input patch (LDS).
 // Workgroup = 4 waves = 4 column rows (g_y) x 16*NT columns (g_x); lanes: k-group g = lane>>4, j = lane&15.
+#include <climits>
+
 #include "common.h"
 
 namespace d3d {
@@ -54,6 +56,16 @@ struct ConvZParams {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+#ifdef D3D_CONV_STATS
+// debug build only (tools/run_convstats.sh): per-phase cycle sums of wave 0 of every workgroup
+__device__ unsigned long long g_conv_stats[8];
+#define ZS_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define ZS_ADD(i, a, b) st[i] += (b) - (a)
+#else
+#define ZS_T(var)
+#define ZS_ADD(i, a, b)
+#endif
+
 template <int MT, int NT, int NS, int CK>
 __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -62,12 +74,25 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int Ci = p.Ci0 + p.Ci1, CiP = p.CiP, PX = p.PX, PY = p.PY, CS = p.CS;
+    const int srows = CK * PY, srows16 = (srows + 15) & ~15;
 
-    float* wl = lds;                                          // [ntaps*CiP][WS]
-    int* tofft = reinterpret_cast<int*>(lds + p.ntaps * CiP * WS);  // [ntaps] patch offset of each tap
-    float* xin = reinterpret_cast<float*>(tofft + ((p.ntaps + 3) & ~3));  // [CK][CS] one input plane chunk
+    float* wl = lds;                                                     // [ntaps*CiP][WS] resident weights
+    int* tofft = reinterpret_cast<int*>(lds + p.ntaps * CiP * WS);       // [ntaps] patch offset of each tap
+    float* ssl = reinterpret_cast<float*>(tofft + ((p.ntaps + 3) & ~3)); // [2][64] per-channel scale, shift
+    int2* rowt = reinterpret_cast<int2*>(ssl + 128);                     // [srows16] staging row table
+    float* xin = reinterpret_cast<float*>(rowt + srows16);               // [CK][CS] one input plane chunk
 
-    // ---- one-time: resident weights (rows beyond Ci are zero), tap offsets
+    const int gx0 = blockIdx.x * (16 * NT);
+    const int gy = blockIdx.y * 4 + wave;
+    const int gz_lo = blockIdx.z * p.zseg;
+    const int gz_hi = min(p.Gz, gz_lo + p.zseg);
+    const int iy0 = blockIdx.y * 4 * p.cy + p.ymin, ix0 = gx0 * p.cx + p.xmin;
+    const int bbase = g * CS + (wave * p.cy) * PX + j * p.cx;
+    const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
+    const long out_plane = (long)p.Ho * p.Wo;
+    const int zmax = p.zmin + p.zspan - 1;
+
+    // ---- one-time: resident weights (rows beyond Ci are zero), tap offsets, epilogue constants, row table
     {
         const int rows = p.ntaps * CiP;
         const int n4 = rows * (MP / 4);
@@ -91,34 +116,56 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
                 if (dsto[u] >= 0) *reinterpret_cast<float4*>(wl + dsto[u]) = v[u];
         }
         if (tid < p.ntaps) tofft[tid] = (p.ty[tid] - p.ymin) * PX + (p.tx[tid] - p.xmin);
+        if (tid < 64) {
+            ssl[tid] = (p.scale && tid < p.Co) ? p.scale[tid] : 1.0f;
+            ssl[64 + tid] = (p.shift && tid < p.Co) ? p.shift[tid] : 0.0f;
+        }
+        // row r = (chunk channel cc, patch row y): source element offset inside a (chunk, plane) block, INT_MIN
+        // when the row lies outside the image; LDS offset of the row (| cc << 20), or -1 for a padding row
+        for (int r = tid; r < srows16; r += 256) {
+            int2 e = make_int2(INT_MIN, -1);
+            if (r < srows) {
+                const int cc = r / PY, y = r - cc * PY;
+                const int sy = iy0 + y;
+                if ((unsigned)sy < (unsigned)p.H) e.x = (int)(cc * in_vol + (long)sy * p.W + ix0);
+                e.y = (cc * CS + y * PX) | (cc << 20);
+            }
+            rowt[r] = e;
+        }
     }
 
-    // ---- GEMM row -> (c_out, fold position) of this lane's accumulator rows m = mt*16 + 4g + r
-    int rowinfo[MT][4];
+    // ---- this lane's accumulator rows m = mt*16 + 4g + r -> output element offset of (c_out, fold position)
+    // relative to the column origin, -1 when the row is unused or its y position is outside the output
+    int rowoff[MT][4];
+    int rowco[MT];
+    unsigned long long colmask = 0;  // bit (mt*4+r)*NT+n: column n of that row lands inside the output
+    int coloff[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int n = 0; n < NT; ++n) coloff[n] = (gx0 + n * 16 + j) * p.sx + p.bx;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        rowco[mt] = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * g + r;
-            int info = -1;
-            if (m < p.M) {
+            int off = -1;
+            if (m < p.M && gy < p.Gy) {
                 const int q0 = m / p.Co, co = m - q0 * p.Co;
                 const int q1 = q0 / p.fx, fxv = q0 - q1 * p.fx;
                 const int fzv = q1 / p.fy, fyv = q1 - fzv * p.fy;
-                info = co | (fxv << 8) | (fyv << 16) | (fzv << 24);
+                const int oy = gy * p.sy + p.by + fyv;
+                if (oy < p.Ho) {
+                    off = (int)(((long)co * p.Do + fzv) * out_plane + (long)oy * p.Wo + fxv);
+                    rowco[mt] |= co << (8 * r);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        if (gx0 + n * 16 + j < p.Gx && coloff[n] + fxv < p.Wo)
+                            colmask |= 1ull << ((mt * 4 + r) * NT + n);
+                }
             }
-            rowinfo[mt][r] = info;
+            rowoff[mt][r] = off;
         }
-
-    const int gx0 = blockIdx.x * (16 * NT);
-    const int gy = blockIdx.y * 4 + wave;
-    const int gz_lo = blockIdx.z * p.zseg;
-    const int gz_hi = min(p.Gz, gz_lo + p.zseg);
-    const int iy0 = blockIdx.y * 4 * p.cy + p.ymin, ix0 = gx0 * p.cx + p.xmin;
-    const int bbase = g * CS + (wave * p.cy) * PX + j * p.cx;
-    const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
-    const long out_plane = (long)p.Ho * p.Wo;
-    const int zmax = p.zmin + p.zspan - 1;
+    }
 
     f4v acc[NS][MT][NT];
 #pragma unroll
@@ -128,49 +175,40 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[s][m][n] = (f4v){0, 0, 0, 0};
 
-    // staging constants of this thread: 16-lane group `grp` walks patch rows grp, grp+16, ...; lanes run along x
-    const int grp = tid >> 4, xs = tid & 15;
-    const int srows = CK * PY;
-    const int nitems = ((srows + 15) >> 4) * p.nseg;
-
+    // flush accumulator slot 0 as output column gz (affine, skip, ReLU, store), then rotate the slots
     auto flush = [&](int gz) {
-        if (gy < p.Gy) {
-            const int oyb = gy * p.sy + p.by, ozb = gz * p.sz + p.bz;
+        const long ubase = (long)(gz * p.sz + p.bz) * out_plane;  // uniform part of the output offset
+        float* __restrict__ outp = p.out + ubase;
+        const float* __restrict__ skp = p.skip ? p.skip + ubase : nullptr;
+        // (values laundered through empty asm statements are loop invariant: left visible, the compiler hoists
+        // every per-element offset and predicate out of the plane loop and pins them in registers)
+        unsigned mlo = (unsigned)colmask, mhi = (unsigned)(colmask >> 32);
+        asm volatile("" : "+v"(mlo), "+v"(mhi));
+        const unsigned long long cmask = ((unsigned long long)mhi << 32) | mlo;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int info = rowinfo[mt][r];
-                    // opaque to loop-invariant code motion: otherwise every row's 64-bit output address is
-                    // precomputed outside the z loop and held in registers (32*MT VGPRs)
-                    asm volatile("" : "+v"(info));
-                    if (info < 0) continue;
-                    const int co = info & 255, fxv = (info >> 8) & 255, fyv = (info >> 16) & 255, fzv = info >> 24;
-                    const int oz = ozb + fzv, oy = oyb + fyv;
-                    if (oz >= p.Do || oy >= p.Ho) continue;
-                    const float sc = p.scale ? p.scale[co] : 1.0f;
-                    const float sh = p.shift ? p.shift[co] : 0.0f;
-                    const long obase = ((long)co * p.Do + oz) * out_plane + (long)oy * p.Wo;
+            for (int r = 0; r < 4; ++r) {
+                int off = rowoff[mt][r];
+                asm volatile("" : "+v"(off));
+                if (off >= 0) {
+                    const int co = (rowco[mt] >> (8 * r)) & 255;
+                    const float sc = ssl[co], sh = ssl[64 + co];
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const int gx = gx0 + n * 16 + j;
-                        const int ox = gx * p.sx + p.bx + fxv;
-                        if (gx >= p.Gx || ox >= p.Wo) continue;
-                        const long oidx = obase + ox;
-                        float y = acc[0][mt][n][r];
-                        if (p.scale) y *= sc;
-                        if (p.shift) y += sh;
-                        if (p.skip && !p.skip_after_act) y += p.skip[oidx];
-                        if (p.act == 1) y = fmaxf(y, 0.0f);
-                        if (p.skip && p.skip_after_act) y = p.skip[oidx] + y;
-                        p.out[oidx] = y;
+                        if ((cmask >> ((mt * 4 + r) * NT + n)) & 1ull) {
+                            const unsigned e = (unsigned)(off + coloff[n]);
+                            float y = acc[0][mt][n][r] * sc + sh;
+                            if (skp && !p.skip_after_act) y += skp[e];
+                            if (p.act == 1) y = fmaxf(y, 0.0f);
+                            if (skp && p.skip_after_act) y = skp[e] + y;
+                            outp[e] = y;
+                        }
                     }
-                    // keep the unrolled rows sequential: hoisting every row's skip loads and addresses
-                    // together costs >100 VGPRs and an occupancy step
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-        }
-        // rotate the live sets: slot s <- slot s+1, last slot cleared
+                // four rows (one 16-row tile) at a time: their skip loads overlap, registers stay bounded
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
         for (int s = 0; s + 1 < NS; ++s)
 #pragma unroll
@@ -183,80 +221,188 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             for (int n = 0; n < NT; ++n) acc[NS - 1][m][n] = (f4v){0, 0, 0, 0};
     };
 
+#ifdef D3D_CONV_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     int gbase = gz_lo;  // output column (z) held by accumulator slot 0
     const int zi_first = gz_lo * p.cz + p.zmin, zi_last = (gz_hi - 1) * p.cz + zmax;
     const int nchunks = CiP / CK;
 
-    for (int zi = zi_first; zi <= zi_last; ++zi) {
-        while (gbase < gz_hi && zi > gbase * p.cz + zmax) {
-            flush(gbase);
-            ++gbase;
-        }
-        if ((unsigned)zi >= (unsigned)p.D) continue;  // plane outside the volume: zero padding
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();  // previous plane chunk consumed (and, first time, weights/tap table written)
-            // ---- stage channels [c*CK, c*CK+CK) of plane zi: zeros outside the image / beyond Ci
-            for (int i0 = 0; i0 < nitems; i0 += 8) {
-                float v[8];
-                int dsto[8];
+    // ---- staging of one step = (input plane zi, channel chunk c), software-pipelined through registers: the
+    // loads of step k+1 are issued before the tap sweep of step k and land in LDS after it.  A 16-lane group
+    // `grp` takes patch rows grp, grp+16, ...; its lanes run along x in 16-wide segments.  Item i = (row
+    // iteration k, segment seg); the row table supplies the row's source / LDS offsets, so an item costs a
+    // handful of integer instructions.
+    constexpr int PF = 48;  // items a thread can hold in flight (larger patches finish synchronously)
+    float pv[PF];
+    const int grp = tid >> 4, xs = tid & 15;
+    const int nitems = (srows16 >> 4) * p.nseg;
+    unsigned xbits = 0;  // bit seg: column seg*16+xs of the patch lies inside the image
+    for (int seg = 0; seg < p.nseg; ++seg) {
+        const int x = seg * 16 + xs;
+        if (x < PX && (unsigned)(ix0 + x) < (unsigned)p.W) xbits |= 1u << seg;
+    }
+    auto step_base = [&](int zi, int c) -> const float* {
+        const int c0 = c * CK;  // a chunk never straddles the two inputs (host: Ci0 % CK == 0 when Ci1 > 0)
+        const float* b = (c0 < p.Ci0) ? p.in0 + (long)c0 * in_vol : p.in1 + (long)(c0 - p.Ci0) * in_vol;
+        return b + (long)zi * in_plane;
+    };
+    // returns the LDS slot (or -1) and the clamped source offset of item i; ok = the source element exists
+    auto item = [&](int i, int grpo, int xso, unsigned xbo, int cmax, int& dst, unsigned& soff, bool& ok) {
+        const bool live = i < nitems;                                      // uniform: batches are padded to 8
+        const int k = live ? (i * p.mg_nseg) >> 16 : 0, seg = i - k * p.nseg;  // uniform
+        const int2 e = rowt[grpo + 16 * k];
+        const int x = seg * 16 + xso;
+        const int cc = e.y >> 20;
+        ok = live && (e.x != INT_MIN) && ((xbo >> (seg & 31)) & 1u) && (cc < cmax);
+        soff = ok ? (unsigned)(e.x + x) : 0u;
+        dst = (live && e.y >= 0 && x < PX) ? (e.y & 0xfffff) + x : -1;
+    };
+    auto issue = [&](int zi, int c) {
+        const float* __restrict__ base = step_base(zi, c);
+        const int cmax = Ci - c * CK;
+        int grpo = grp, xso = xs;
+        unsigned xbo = xbits;
+        asm volatile("" : "+v"(grpo), "+v"(xso), "+v"(xbo));  // see flush(): keep the item arithmetic in the loop
+#pragma unroll
+        for (int b8 = 0; b8 < PF; b8 += 8) {
+            if (b8 < nitems) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u;
-                    const int k = (i * p.mg_nseg) >> 16, seg = i - k * p.nseg;
-                    const int r = grp + 16 * k;
-                    const int cc = (r * p.mg_py) >> 16, y = r - cc * PY;
-                    const int x = seg * 16 + xs;
-                    const int ci = c * CK + cc;
-                    const int sy = iy0 + y, sx = ix0 + x;
-                    const bool slot = (i < nitems) && (r < srows) && (x < PX);
-                    const bool ok = slot && (ci < Ci) && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
-                    const float* __restrict__ src = (ci < p.Ci0 || !ok) ? p.in0 + (long)(ok ? ci : 0) * in_vol
-                                                                         : p.in1 + (long)(ci - p.Ci0) * in_vol;
-                    const float val = src[ok ? (long)zi * in_plane + (long)sy * p.W + sx : 0];
-                    v[u] = ok ? val : 0.0f;
-                    dsto[u] = slot ? cc * CS + y * PX + x : -1;
+                    int dst;
+                    unsigned soff;
+                    bool ok;
+                    item(b8 + u, grpo, xso, xbo, cmax, dst, soff, ok);
+                    pv[b8 + u] = base[soff];
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (dsto[u] >= 0) xin[dsto[u]] = v[u];
             }
-            __syncthreads();
-
-            // ---- every open output column takes the taps whose tz links it to this plane
+        }
+    };
+    auto land = [&](int zi, int c) {
+        const float* __restrict__ base = step_base(zi, c);
+        const int cmax = Ci - c * CK;
+        int grpo = grp, xso = xs;
+        unsigned xbo = xbits;
+        asm volatile("" : "+v"(grpo), "+v"(xso), "+v"(xbo));  // see flush(): keep the item arithmetic in the loop
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int gzs = gbase + s;
-                const int tzv = zi - gzs * p.cz;
-                if (gzs >= gz_hi || tzv < p.zmin || tzv > zmax) continue;
-                const int tb = p.tzstart[tzv - p.zmin], te = p.tzstart[tzv - p.zmin + 1];
-                if (tb >= te) continue;
-                int toff = tofft[tb];
-                for (int t = tb; t < te; ++t) {
-                    const int toff_next = tofft[min(t + 1, p.ntaps - 1)];
-                    const float* __restrict__ xb = xin + bbase + toff;
-                    const float* __restrict__ wa = wl + ((t * CiP + c * CK + g) * WS + j);
+        for (int b8 = 0; b8 < PF; b8 += 8) {
+            if (b8 < nitems) {
 #pragma unroll
-                    for (int kk = 0; kk < CK / 4; ++kk) {
-                        float b[NT];
+                for (int u = 0; u < 8; ++u) {
+                    int dst;
+                    unsigned soff;
+                    bool ok;
+                    item(b8 + u, grpo, xso, xbo, cmax, dst, soff, ok);
+                    if (dst >= 0) xin[dst] = ok ? pv[b8 + u] : 0.0f;
+                }
+            }
+        }
+        for (int i0 = PF; i0 < nitems; i0 += 8) {  // beyond the register window
+            float v[8];
+            int dsto[8];
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) b[n] = xb[kk * 4 * CS + n * 16 * p.cx];
+            for (int u = 0; u < 8; ++u) {
+                unsigned soff;
+                bool ok;
+                item(i0 + u, grpo, xso, xbo, cmax, dsto[u], soff, ok);
+                const float val = base[soff];
+                v[u] = ok ? val : 0.0f;
+            }
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const float av = wa[kk * 4 * WS + m * 16];
+            for (int u = 0; u < 8; ++u)
+                if (dsto[u] >= 0) xin[dsto[u]] = v[u];
+        }
+    };
+    auto sweep = [&](int zi, int c) {
+        // every open output column takes the taps whose tz links it to this plane
 #pragma unroll
-                            for (int n = 0; n < NT; ++n)
-                                acc[s][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[s][m][n], 0, 0, 0);
-                        }
+        for (int s = 0; s < NS; ++s) {
+            const int gzs = gbase + s;
+            const int tzv = zi - gzs * p.cz;
+            if (gzs >= gz_hi || tzv < p.zmin || tzv > zmax) continue;
+            const int tb = p.tzstart[tzv - p.zmin], te = p.tzstart[tzv - p.zmin + 1];
+            if (tb >= te) continue;
+            int toff = tofft[tb];
+            for (int t = tb; t < te; ++t) {
+                const int toff_next = tofft[min(t + 1, p.ntaps - 1)];
+                const float* __restrict__ xb = xin + bbase + toff;
+                const float* __restrict__ wa = wl + ((t * CiP + c * CK + g) * WS + j);
+#pragma unroll
+                for (int kk = 0; kk < CK / 4; ++kk) {
+                    float b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = xb[kk * 4 * CS + n * 16 * p.cx];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float av = wa[kk * 4 * WS + m * 16];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[s][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[s][m][n], 0, 0, 0);
                     }
-                    toff = toff_next;
                 }
+                toff = toff_next;
             }
+        }
+    };
+
+    int zi = zi_first < 0 ? 0 : zi_first;  // planes outside the volume are zero padding: skipped
+    const int zend = zi_last >= p.D ? p.D - 1 : zi_last;
+    int c = 0;
+    __syncthreads();  // row table, weights, tap table, epilogue constants written
+    if (zi <= zend) {
+        issue(zi, 0);
+        land(zi, 0);
+        __syncthreads();
+        for (;;) {
+            if (c == 0) {
+                ZS_T(f0);
+                while (gbase < gz_hi && zi > gbase * p.cz + zmax) {
+                    flush(gbase);
+                    ++gbase;
+                }
+                ZS_T(f1);
+                ZS_ADD(3, f0, f1);
+            }
+            int nzi = zi, nc = c + 1;
+            if (nc == nchunks) {
+                nc = 0;
+                ++nzi;
+            }
+            const bool has_next = nzi <= zend;
+            ZS_T(s0);
+            if (has_next) issue(nzi, nc);
+            ZS_T(c0);
+            ZS_ADD(0, s0, c0);
+            sweep(zi, c);
+            ZS_T(c1);
+            ZS_ADD(2, c0, c1);
+#ifdef D3D_CONV_STATS
+            st[6] += 1;
+#endif
+            if (!has_next) break;
+            __syncthreads();  // every wave has finished reading the current patch
+            ZS_T(b1);
+            ZS_ADD(4, c1, b1);
+            land(nzi, nc);
+            ZS_T(l1);
+            ZS_ADD(1, b1, l1);
+            __syncthreads();
+            zi = nzi;
+            c = nc;
         }
     }
     while (gbase < gz_hi) {
         flush(gbase);
         ++gbase;
     }
+#ifdef D3D_CONV_STATS
+    if (tid == 0) {
+        st[5] = __builtin_amdgcn_s_memtime() - t_begin;
+        st[7] = 1;
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_conv_stats[i], st[i]);
+    }
+#endif
 }
 
 struct StreamCfg {
@@ -276,7 +422,8 @@ static int lds_bytes_for(const ConvZParams& p, int MT, int NT, int CK) {
     const int MP = 16 * MT, WS = (MP == 16) ? 16 : MP + 16;
     const int Ci = p.Ci0 + p.Ci1, CiP = (Ci + CK - 1) / CK * CK;
     const int PY = p.yspan + 3 * p.cy, PX = p.xspan + (16 * NT - 1) * p.cx;
-    return 4 * (p.ntaps * CiP * WS + ((p.ntaps + 3) & ~3) + CK * patch_stride(PY, PX, p.cx));
+    const int srows16 = (CK * PY + 15) & ~15;
+    return 4 * (p.ntaps * CiP * WS + ((p.ntaps + 3) & ~3) + 128 + 2 * srows16 + CK * patch_stride(PY, PX, p.cx));
 }
 
 template <int MT, int NT, int NS, int CK>
@@ -334,6 +481,19 @@ static int launch_ck(ConvZParams& p, int NS, int CK, hipStream_t stream) {
 using namespace d3d;
 
 extern "C" {
+
+#ifdef D3D_CONV_STATS
+// debug build only: [issue loads, land in LDS (incl. wait), sweep, flush, barrier after sweep, total, steps, workgroups]
+int d3d_conv_stream_stats(unsigned long long* out8, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return D3D_ERR_HIP;
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_conv_stats), 64) != hipSuccess) return D3D_ERR_HIP;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stats), z, 64) != hipSuccess) return D3D_ERR_HIP;
+    }
+    return D3D_OK;
+}
+#endif
 
 int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                       const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
@@ -398,6 +558,15 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
     int NT = 4, CK = (Ci > 8) ? 16 : 8;
     if (MT == 1 && lds_bytes_for(p, MT, 4, 8) > 72 * 1024) NT = 1;
     if (CK == 16 && lds_bytes_for(p, MT, NT, 16) > 72 * 1024) CK = 8;
+    const long in_plane = (long)H * W, in_vol = in_plane * D;
+    // 32-bit element offsets inside one (chunk, plane) block and inside the output; a chunk must not straddle
+    // the two concatenated inputs
+    if (CK == 16 && (15 * in_vol + in_plane >= (1L << 30) || (Ci1 > 0 && Ci0 % 16 != 0))) CK = 8;
+    if (7 * in_vol + in_plane >= (1L << 30) || (Ci1 > 0 && Ci0 % 8 != 0) || (long)Co * Do * Ho * Wo >= (1L << 30)) {
+        set_error("conv_stream: tensor too large for 32-bit offsets, or input split %d+%d not chunk aligned", Ci0, Ci1);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    D3D_REQUIRE((p.Gz - 1) * p.sz + p.bz + p.fz - 1 < Do, "z fold overhangs the output");
     const int bytes = lds_bytes_for(p, MT, NT, CK);
     if (bytes > 156 * 1024) {
         set_error("conv_stream: resident weights + patch need %d B of LDS (ntaps=%d Ci=%d M=%d)", bytes, ntaps, Ci, M);
@@ -408,7 +577,7 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
         const int PY = p.yspan + 3 * p.cy, PX = p.xspan + (16 * NT - 1) * p.cx;
         const int nseg = (PX + 15) / 16, rows = CK * PY;
         const int items = ((rows + 15) / 16) * nseg + 8;
-        D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 64 && PY <= 64, "patch %dx%d too large", PY, PX);
+        D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 32 && PY <= 64, "patch %dx%d too large", PY, PX);
     }
     hipStream_t st = (hipStream_t)stream;
     if (NT == 1) return launch_ck<1, 1>(p, NS, CK, st);
