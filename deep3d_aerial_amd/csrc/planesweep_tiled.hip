@@ -54,7 +54,16 @@ constexpr int MAXSTEPS = 64;    // >= DSEG_MAX / NSUB, <= 64 (one lane per step)
 constexpr int PFD = 2;          // delta staging items (64 positions x CH channels) a loader wave keeps in flight
 constexpr int LDS_PIPE = 1;     // (quad, view) units whose taps are requested ahead of the one being blended
 constexpr int NCAND = 4;        // candidate step sizes: 4, 2, 1, 1/2 times NSUB planes
-constexpr int MAXRECTS = 256;   // non-empty delta rectangles per workgroup segment
+constexpr int MAXRECTS = 256;
+#ifndef RING_ALIGN
+#define RING_ALIGN 0
+#endif
+// Floats between ring rows.  Padded to a multiple of the 64 LDS banks: a sample row change inside a 16-lane
+// ds_read_b128 group then keeps every column's bank, so only column skips / repeats can conflict.
+template <int STRIDE>
+__host__ __device__ __forceinline__ int ring_row_floats(int RW) {
+    return RING_ALIGN ? (((RW + 1) * STRIDE + 63) & ~63) : (RW + 1) * STRIDE;
+}   // non-empty delta rectangles per workgroup segment
 
 struct TiledArgs {
     int ngroups;     // channel groups (C / CH), one workgroup pass each
@@ -139,7 +148,7 @@ __device__ __forceinline__ TapL make_tap_ring(float u, float v, const Win& W, in
     unsigned c = (unsigned)(cx + W.ox), r = (unsigned)(cy + W.oy);
     c = min(c, c - (unsigned)RW);  // one conditional wrap: cx < RW and ox < RW
     r = min(r, r - (unsigned)RH);
-    const int rowb = (RW + 1) * (STRIDE * 4);
+    const int rowb = ring_row_floats<STRIDE>(RW) * 4;
     int a = base_bytes + (int)r * rowb + (int)c * (STRIDE * 4);
     t.a0 = in ? a : 0;  // zero cell: two all-zero positions at LDS offset 0
     t.a1 = in ? a + rowb : 0;
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             for (int i = 0; i < NSRC; ++i) {
                 const int* hd = ldsi + CHD + (cand * NSRC + i) * 4;
                 RW[i] = hd[0]; RH[i] = hd[1]; bad |= hd[2];
-                total += (RW[i] + 1) * (RH[i] + 1) * STRIDE;
+                total += ring_row_floats<STRIDE>(RW[i]) * (RH[i] + 1);
             }
             if (bad || total > a.cap_floats) continue;
 #pragma unroll
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                         ldsi[L::HDR + 4 + 4 * i + 1] = RH[i];
                         ldsi[L::HDR + 4 + 4 * i + 2] = base;
                     }
-                    base += (RW[i] + 1) * (RH[i] + 1) * STRIDE;
+                    base += ring_row_floats<STRIDE>(RW[i]) * (RH[i] + 1);
                 }
                 // ---- staging items of every step: window(k) minus window(k-1) as <= 4 rectangles per
                 // view, cut into items of 64 positions (all CH channels of the group).
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         unsigned c = (unsigned)((e6 & 0xffff) + cx), r = (unsigned)((e6 >> 16) + cy);
         c = min(c, c - (unsigned)RWv);
         r = min(r, r - (unsigned)RHv);
-        const int dst = bs + (int)r * ((RWv + 1) * STRIDE) + (int)c * STRIDE;
+        const int dst = bs + (int)r * ring_row_floats<STRIDE>(RWv) + (int)c * STRIDE;
         I.meta = live ? (dst | (ok ? 1 << 20 : 0) | (c == 0 ? 1 << 21 : 0) | (r == 0 ? 1 << 22 : 0)) : -1;
         I.geo = e7 & 0xffff;
         return I;
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             const int dst = (meta & 0xfffff) + 4 * q;
             const int RWv = geo & 0xff, RHv = geo >> 8;
             const int dupc = (meta >> 21) & 1 ? RWv * STRIDE : 0;
-            const int dupr = (meta >> 22) & 1 ? RHv * (RWv + 1) * STRIDE : 0;
+            const int dupr = (meta >> 22) & 1 ? RHv * ring_row_floats<STRIDE>(RWv) : 0;
             f4 x = (meta >> 20) & 1 ? v : (f4){0, 0, 0, 0};
             *reinterpret_cast<f4*>(lds + dst) = x;
             if (dupc) *reinterpret_cast<f4*>(lds + dst + dupc) = x;

@@ -170,6 +170,86 @@ __global__ __launch_bounds__(256) void gru_update_kernel(const float* __restrict
     h_out[i] = uu * h[i] + (1.0f - uu) * tanhf(convc[i]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ConvGRUCell2 (module.py:53-99, the msrednet recurrent cell): the gate / candidate convolutions are each
+// followed by nn.GroupNorm(1, C): mean and biased variance over ALL C*H*W elements, then a per-channel
+// affine.  Stage 1 reduces sum and sum of squares (fp64 partials, one atomic pair per workgroup); the
+// elementwise stages read the two sums, so nothing synchronises with the host.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ stats) {
+    double s = 0.0, q = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        } else {
+            for (long k = i; k < n; ++k) { s += x[k]; q += (double)x[k] * x[k]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_down(s, o);
+        q += __shfl_down(q, o);
+    }
+    __shared__ double ws[4], wq[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { ws[wave] = s; wq[wave] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(stats, ws[0] + ws[1] + ws[2] + ws[3]);
+        atomicAdd(stats + 1, wq[0] + wq[1] + wq[2] + wq[3]);
+    }
+}
+
+struct GnAffine {  // y = x*a + b with the group statistics folded in
+    float mean, rstd;
+};
+__device__ __forceinline__ GnAffine gn_fold(const double* __restrict__ stats, long n, float eps) {
+    const double m = stats[0] / (double)n;
+    double var = stats[1] / (double)n - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    GnAffine g;
+    g.mean = (float)m;
+    g.rstd = (float)(1.0 / sqrt(var + (double)eps));
+    return g;
+}
+
+// gates [2Hc,plane] -> r = sigmoid(gn_r(gates[:Hc])), u = sigmoid(gn_u(gates[Hc:])); rh = r*h (module.py:71-82,85)
+__global__ __launch_bounds__(256) void gru2_gates_kernel(const float* __restrict__ gates, const double* __restrict__ st_r,
+                                                          const double* __restrict__ st_u, const float* __restrict__ g_r,
+                                                          const float* __restrict__ b_r, const float* __restrict__ g_u,
+                                                          const float* __restrict__ b_u, const float* __restrict__ h,
+                                                          int Hc, long plane, float eps, float* __restrict__ rh,
+                                                          float* __restrict__ u) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)Hc * plane;
+    if (i >= n) return;
+    const int c = (int)(i / plane);
+    const GnAffine ar = gn_fold(st_r, n, eps), au = gn_fold(st_u, n, eps);
+    const float rn = (gates[i] - ar.mean) * ar.rstd * g_r[c] + b_r[c];
+    const float un = (gates[n + i] - au.mean) * au.rstd * g_u[c] + b_u[c];
+    const float r = 1.0f / (1.0f + __expf(-rn));
+    rh[i] = r * h[i];
+    u[i] = 1.0f / (1.0f + __expf(-un));
+}
+
+// h' = u*h + (1-u)*tanh(gn_o(o))   (module.py:84-98)
+__global__ __launch_bounds__(256) void gru2_update_kernel(const float* __restrict__ o, const double* __restrict__ st_o,
+                                                           const float* __restrict__ g_o, const float* __restrict__ b_o,
+                                                           const float* __restrict__ u, const float* __restrict__ h,
+                                                           int Hc, long plane, float eps, float* __restrict__ h_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)Hc * plane;
+    if (i >= n) return;
+    const int c = (int)(i / plane);
+    const GnAffine a = gn_fold(st_o, n, eps);
+    const float on = (o[i] - a.mean) * a.rstd * g_o[c] + b_o[c];
+    const float uu = u[i];
+    h_out[i] = uu * h[i] + (1.0f - uu) * tanhf(on);
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -273,4 +353,41 @@ int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n
     return D3D_OK;
 }
 
+int d3d_groupnorm_stats(const float* x, int64_t n, double* stats2, d3d_stream_t stream) {
+    D3D_REQUIRE(x && stats2, "null pointer");
+    D3D_REQUIRE(n > 0, "bad n");
+    D3D_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
+    int rc = hip_status(hipMemsetAsync(stats2, 0, 2 * sizeof(double), (hipStream_t)stream), "hipMemsetAsync(stats)");
+    if (rc != D3D_OK) return rc;
+    long blocks = ceil_div(n, 256 * 4 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, stats2);
+    D3D_LAUNCH_CHECK("gn_stats_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* stats_u, const float* gamma_r,
+                     const float* beta_r, const float* gamma_u, const float* beta_u, const float* h, int Hc,
+                     int64_t plane, float eps, float* rh, float* u, d3d_stream_t stream) {
+    D3D_REQUIRE(gates && stats_r && stats_u && gamma_r && beta_r && gamma_u && beta_u && h && rh && u, "null pointer");
+    D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
+    const long n = (long)Hc * plane;
+    hipLaunchKernelGGL(gru2_gates_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, gates, stats_r,
+                       stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
+    D3D_LAUNCH_CHECK("gru2_gates_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* u,
+                      const float* h, int Hc, int64_t plane, float eps, float* h_out, d3d_stream_t stream) {
+    D3D_REQUIRE(o && stats_o && gamma && beta && u && h && h_out, "null pointer");
+    D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
+    const long n = (long)Hc * plane;
+    hipLaunchKernelGGL(gru2_update_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, o, stats_o, gamma,
+                       beta, u, h, Hc, (long)plane, eps, h_out);
+    D3D_LAUNCH_CHECK("gru2_update_kernel launch");
+    return D3D_OK;
+}
+
 }  // extern "C"
+

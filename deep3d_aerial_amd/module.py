@@ -149,6 +149,53 @@ class ConvGRUCell(nn.Module):
         return out, out
 
 
+class ConvTransReLU(nn.Module):
+    """module.py:287-294 (k=3, stride 2, pad 1, output_pad 1, no bias): relu(convT(x)) [+ skip, added after]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=2, pad=1, output_pad=1):
+        super().__init__()
+        assert kernel_size == 3 and stride == 2 and pad == 1 and output_pad == 1
+        self.conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, output_padding=1,
+                                       bias=False)
+
+    def forward(self, x, skip=None):
+        return ops.convtranspose2d_k3s2(x, self.conv.weight, None, None, skip, skip_after_act=True, act=1)
+
+
+class ConvGRUCell2(nn.Module):
+    """module.py:53-99: conv-GRU whose gate and candidate convolutions are followed by GroupNorm(1, C).
+    forward(x [Cx,H,W], h [Ch,H,W], negate_x=False) -> (h', h').  negate_x evaluates the cell on -x by negating
+    the x-columns of the two weight tensors (msrednet.py:354,367 feed -cost)."""
+
+    def __init__(self, input_channel, output_channel, kernel_size=3):
+        super().__init__()
+        assert kernel_size == 3
+        self.input_channel, self.output_channel = input_channel, output_channel
+        cin = input_channel + output_channel
+        self.gate_conv = nn.Conv2d(cin, output_channel * 2, 3, padding=1)
+        self.reset_gate_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.update_gate_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+        self.output_conv = nn.Conv2d(cin, output_channel, 3, padding=1)
+        self.output_norm = nn.GroupNorm(1, output_channel, 1e-5, True)
+
+    def _w(self, conv, negate_x):
+        if not negate_x:
+            return conv.weight
+        ci = self.input_channel
+        return ops.derived_weight(conv.weight, "negx", lambda w: torch.cat([-w[:, :ci], w[:, ci:]], 1))
+
+    def forward(self, x, h=None, negate_x=False):
+        if h is None:
+            h = torch.zeros((self.output_channel,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        f = ops.conv2d_k3(x, self._w(self.gate_conv, negate_x), None, self.gate_conv.bias, None, act=0, stride=1, x2=h)
+        rn, un = self.reset_gate_norm, self.update_gate_norm
+        rh, u = ops.gru_gates_gn(f, h, rn.weight, rn.bias, un.weight, un.bias, rn.eps)
+        o = ops.conv2d_k3(x, self._w(self.output_conv, negate_x), None, self.output_conv.bias, None, act=0, stride=1,
+                          x2=rh)
+        out = ops.gru_update_gn(o, u, h, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
+        return out, out
+
+
 # ----------------------------------------------------------------------------------------
 # Image feature pyramids -- PyTorch-ROCm/MIOpen (SURVEY.md 8a a12), checkpoint-compatible
 # with module.py:157-245,495-513,653-755.

@@ -1,0 +1,142 @@
+"""Cascade RED-Net inference (reference: mvs/mvs_cas/models/msrednet.py:337-527) on the HIP plane-sweep engine.
+
+Same constructor, forward() contract and state_dict keys as the reference's Infer_CascadeREDNet.  Per depth
+plane: fused warp + variance (d3d_variance_volume, D = 1) -> slice_RED_Regularization (four GroupNorm conv-GRUs
+in a 2D encoder-decoder, on the matrix-core convolutions) -> online exp-sum regression.  Inference only.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .module import ConvGRUCell2, ConvReLU, ConvTransReLU, FeatureNet_mvsnet, plane_depths
+
+
+class slice_RED_Regularization(nn.Module):
+    """msrednet.py:337-370.  forward(cost [C,h,w], state1..4) -> (reg [1,h,w], state1..4).
+    The reference feeds -cost to conv1 and conv_gru1; here the sign is folded into their weights."""
+
+    def __init__(self, in_channels, base_channels=8):
+        super().__init__()
+        b = base_channels
+        self.base_channels = b
+        self.conv_gru1 = ConvGRUCell2(in_channels, b, 3)
+        self.conv_gru2 = ConvGRUCell2(b * 2, b * 2, 3)
+        self.conv_gru3 = ConvGRUCell2(b * 4, b * 4, 3)
+        self.conv_gru4 = ConvGRUCell2(b * 8, b * 8, 3)
+        self.conv1 = ConvReLU(in_channels, b * 2, 3, 2, 1)
+        self.conv2 = ConvReLU(b * 2, b * 4, 3, 2, 1)
+        self.conv3 = ConvReLU(b * 4, b * 8, 3, 2, 1)
+        self.upconv3 = ConvTransReLU(b * 8, b * 4, 3, 2, 1, 1)
+        self.upconv2 = ConvTransReLU(b * 4, b * 2, 3, 2, 1, 1)
+        self.upconv1 = ConvTransReLU(b * 2, b, 3, 2, 1, 1)
+        self.upconv2d = nn.ConvTranspose2d(b, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
+
+    def forward(self, cost, state1, state2, state3, state4):
+        w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
+        c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)             # conv1(-cost)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        state4, _ = self.conv_gru4(c3, state4)
+        state3, _ = self.conv_gru3(c2, state3)
+        up33 = self.upconv3(state4, skip=state3)                                      # relu(convT) + reg_cost3
+        state2, _ = self.conv_gru2(c1, state2)
+        up22 = self.upconv2(up33, skip=state2)
+        state1, _ = self.conv_gru1(cost, state1, negate_x=True)                       # conv_gru1(-cost)
+        up11 = self.upconv1(up22, skip=state1)
+        # ConvTranspose2d(stride 1, pad 1) = correlation with the spatially flipped, transposed kernel
+        wc = ops.derived_weight(self.upconv2d.weight, "flipT", lambda w: w.flip(2, 3).transpose(0, 1))
+        reg = ops.conv2d_k3(up11, wc, None, self.upconv2d.bias, None, act=0)
+        return reg, state1, state2, state3, state4
+
+
+class InferDepthNet(nn.Module):
+    """msrednet.py:373-438: plane-by-plane variance cost, recurrent regularisation, online regression."""
+
+    def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization):
+        V = len(features)
+        assert V == proj_matrices.shape[1], "Different number of images and projection matrices"
+        assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
+            depth_values.shape[1], num_depth)
+        B, C, h, w = features[0].shape
+        if h % 8 or w % 8:
+            raise ValueError("feature maps must be divisible by 8 (three stride-2 levels), got %dx%d" % (h, w))
+        depths, confs = [], []
+        for b in range(B):
+            feats = [f[b].contiguous() for f in features]
+            p34 = ops.compose_projections(proj_matrices[b].contiguous())
+            dvb = depth_values[b]
+            dev = feats[0].device
+            states = [torch.zeros((8 << i, h >> i, w >> i), dtype=torch.float32, device=dev) for i in range(4)]
+            max_p = torch.zeros((h, w), dtype=torch.float32, device=dev)
+            sum_d = torch.zeros_like(max_p)
+            sum_p = torch.zeros_like(max_p)
+            for d in range(num_depth):
+                if dvb.dim() == 1:   # [D] uniform planes
+                    dsel = dvb[d:d + 1].contiguous()
+                    dplane = dsel.expand(h * w).reshape(h, w).contiguous()
+                else:                # [D,h,w] per-pixel hypotheses
+                    dsel = dvb[d:d + 1].contiguous()
+                    dplane = dsel[0]
+                var = ops.variance_volume(feats, p34, dsel)[:, 0]                      # [C,h,w]
+                reg, *states = cost_regularization(var.contiguous(), *states)
+                ops.online_regress_update(reg[0], dplane, max_p, sum_d, sum_p)
+            dep, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
+            depths.append(dep)
+            confs.append(conf)
+        return {"depth": torch.stack(depths), "photometric_confidence": torch.stack(confs)}
+
+
+class Infer_CascadeREDNet(nn.Module):
+    """msrednet.py:442-527."""
+
+    def __init__(self, num_depth=384, ndepths=[48, 32, 8], depth_intervals_ratio=[4, 2, 1], share_cr=False,
+                 cr_base_chs=[8, 8, 8]):
+        super().__init__()
+        assert len(ndepths) == len(depth_intervals_ratio)
+        self.num_depth, self.share_cr, self.ndepths = num_depth, share_cr, list(ndepths)
+        self.depth_intervals_ratio, self.cr_base_chs = list(depth_intervals_ratio), list(cr_base_chs)
+        self.num_stage = len(ndepths)
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+        self.feature = FeatureNet_mvsnet(base_channels=8, stride=4, num_stage=self.num_stage, arch_mode="unet")
+        if share_cr:
+            # the reference passes the channel LIST here (msrednet.py:467), which cannot construct; share_cr
+            # is therefore only meaningful with equal channels -- use the stage-1 width like cas_mvsnet.py
+            self.cost_regularization = slice_RED_Regularization(self.feature.out_channels[0], 8)
+        else:
+            self.cost_regularization = nn.ModuleList(
+                [slice_RED_Regularization(self.feature.out_channels[i], self.cr_base_chs[i])
+                 for i in range(self.num_stage)])
+        self.DepthNet = InferDepthNet()
+
+    def forward(self, imgs, proj_matrices, depth_values):
+        if self.training:
+            raise RuntimeError("inference only: call .eval()")
+        B, V, _, img_h, img_w = imgs.shape
+        dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())   # msrednet.py:477-478 (one host sync)
+        depth_interval = (dmax - dmin) / self.num_depth
+        features = [self.feature(imgs[:, v]) for v in range(V)]
+        outputs = {}
+        depth = None
+        for s in range(self.num_stage):
+            key = "stage%d" % (s + 1)
+            feats = [f[key] for f in features]
+            scale = int(self.stage_infos[key]["scale"])
+            h, w = img_h // scale, img_w // scale
+            D = self.ndepths[s]
+            if depth is None:
+                dv = plane_depths(depth_values, D)                              # [B,D]: constant planes
+            else:
+                # msrednet.py:497-516: depth -> full res (bilinear), hypotheses at full res, trilinear resample
+                dvs = []
+                for b in range(B):
+                    cur = ops.resize_bilinear(depth[b:b + 1].contiguous(), img_h, img_w)[0]
+                    full = ops.depth_range_samples(cur, D, self.depth_intervals_ratio[s] * depth_interval)
+                    dvs.append(full if (h, w) == (img_h, img_w) else ops.resize_bilinear(full, h, w))
+                dv = torch.stack(dvs)
+            cr = self.cost_regularization if self.share_cr else self.cost_regularization[s]
+            with torch.no_grad():
+                out = self.DepthNet(feats, proj_matrices[key], depth_values=dv, num_depth=D, cost_regularization=cr)
+            depth = out["depth"]
+            outputs[key] = out
+            outputs.update(out)
+        return outputs

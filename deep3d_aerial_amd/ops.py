@@ -301,6 +301,67 @@ def gru_update(u, h, convc):
     return out
 
 
+def groupnorm_stats(x):
+    """sum and sum of squares of x (any shape) as a device fp64 pair, for GroupNorm(1, C) (module.py:62-67)."""
+    st = torch.empty(2, dtype=torch.float64, device=x.device)
+    rc = _lib.load().d3d_groupnorm_stats(_chk(x, "x"), x.numel(), ctypes.c_void_p(st.data_ptr()), _stream())
+    _lib.check(rc, "d3d_groupnorm_stats")
+    return st
+
+
+def _dptr(t):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.numel() == 2):
+        raise TypeError("statistics must be a CUDA float64 pair")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def gru_gates_gn(gates, h, gamma_r, beta_r, gamma_u, beta_u, eps=1e-5):
+    """ConvGRUCell2 gates (module.py:71-82): gates [2Hc,H,W] pre-norm, h [Hc,H,W] -> (r*h, u)."""
+    Hc = h.shape[0]
+    plane = h[0].numel()
+    if gates.shape[0] != 2 * Hc or gates[0].numel() != plane:
+        raise ValueError("gates must be [2*Hc,H,W]")
+    st_r = groupnorm_stats(gates[:Hc])
+    st_u = groupnorm_stats(gates[Hc:])
+    rh = torch.empty_like(h)
+    u = torch.empty_like(h)
+    rc = _lib.load().d3d_gru_gates_gn(_chk(gates, "gates"), _dptr(st_r), _dptr(st_u), _chk(gamma_r, "gamma_r"),
+                                      _chk(beta_r, "beta_r"), _chk(gamma_u, "gamma_u"), _chk(beta_u, "beta_u"),
+                                      _chk(h, "h"), Hc, plane, float(eps), _chk(rh, "rh"), _chk(u, "u"), _stream())
+    _lib.check(rc, "d3d_gru_gates_gn")
+    return rh, u
+
+
+def gru_update_gn(o, u, h, gamma, beta, eps=1e-5):
+    """ConvGRUCell2 state update (module.py:84-98): h' = u*h + (1-u)*tanh(GroupNorm(o))."""
+    Hc = h.shape[0]
+    plane = h[0].numel()
+    st = groupnorm_stats(o)
+    out = torch.empty_like(h)
+    rc = _lib.load().d3d_gru_update_gn(_chk(o, "o"), _dptr(st), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(u, "u"),
+                                       _chk(h, "h"), Hc, plane, float(eps), _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_gru_update_gn")
+    return out
+
+
+_derived_cache = {}
+
+
+def derived_weight(weight, tag, fn):
+    """A tensor computed from a parameter (negated / flipped / re-laid-out weights), cached per parameter
+    version like the packed GEMM operands; host-side weight preparation, not data-path arithmetic."""
+    key = (id(weight), tag)
+    hit = _derived_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
+        return hit[2]
+    with torch.no_grad():
+        out = fn(weight.detach()).contiguous()
+    if len(_derived_cache) > 4096:
+        _derived_cache.clear()
+    _derived_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), out)
+    return out
+
+
 # ----------------------------------------------------------------------------------------
 # MFMA implicit-GEMM convolution (d3d_conv_gemm_f32): weight packing, tap lists, dispatch
 # ----------------------------------------------------------------------------------------
@@ -374,8 +435,9 @@ def _packed(weight, transposed):
 
 
 def clear_weight_cache():
-    """Drop every packed-weight entry (needed only after writing weights through `.data`)."""
+    """Drop every packed / derived weight entry (needed only after writing weights through `.data`)."""
     _pack_cache.clear()
+    _derived_cache.clear()
 
 
 def _gemm(x, x2, wpack, taps, ntaps, Co, scale, shift, skip, skip_after_act, act, in_dims, grid, out, istride,

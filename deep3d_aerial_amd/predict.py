@@ -95,7 +95,12 @@ def build_model(name, numdepth, ndepths=(48, 32, 8), depth_inter_r=(4, 2, 1), sh
         from .adamvs import Infer_AdaMVSNet
         return Infer_AdaMVSNet(num_depth=numdepth, ndepths=list(ndepths), depth_intervals_ratio=list(depth_inter_r),
                                share_cr=share_cr, cr_base_chs=list(cr_base_chs))
-    # msrednet / ucsnet inference are not built yet (ucsnet is broken in the reference)
+    if name == "msrednet":
+        from .msrednet import Infer_CascadeREDNet
+        return Infer_CascadeREDNet(num_depth=numdepth, ndepths=list(ndepths),
+                                   depth_intervals_ratio=list(depth_inter_r), share_cr=share_cr,
+                                   cr_base_chs=list(cr_base_chs))
+    # ucsnet cannot be constructed by the reference's own predict.py call
     raise Exception("{}? Not implemented yet!".format(name))
 
 

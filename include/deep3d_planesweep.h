@@ -231,6 +231,21 @@ int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n
                    d3d_stream_t stream);
 
 /*
+ * module.py:53-99 ConvGRUCell2 (msrednet.py:337-371): like ConvGRUCell, but every convolution output passes
+ * nn.GroupNorm(1, C) (one group: statistics over all C*H*W elements; per-channel gamma/beta) first.
+ *   d3d_groupnorm_stats: stats2[0] = sum(x), stats2[1] = sum(x^2) over n elements (device doubles; zeroed by
+ *     the call, stream-ordered).  Call once per normalised tensor (the r and u halves of the gates separately).
+ *   d3d_gru_gates_gn:  r = sigmoid(gn_r(gates[:Hc])); u = sigmoid(gn_u(gates[Hc:])); rh = r*h.
+ *   d3d_gru_update_gn: h' = u*h + (1-u)*tanh(gn_o(o)).
+ */
+int d3d_groupnorm_stats(const float* x, int64_t n, double* stats2, d3d_stream_t stream);
+int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* stats_u, const float* gamma_r,
+                     const float* beta_r, const float* gamma_u, const float* beta_u, const float* h, int Hc,
+                     int64_t plane, float eps, float* rh, float* u, d3d_stream_t stream);
+int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* u,
+                      const float* h, int Hc, int64_t plane, float eps, float* h_out, d3d_stream_t stream);
+
+/*
  * adamvs.py:478-486 -- per-pair softmax over D, view weight = max_D prob,
  * pair depth = SUM_D prob*d.  score [D,h,w], depth [D] or [D,h,w].
  */

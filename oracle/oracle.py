@@ -236,6 +236,15 @@ def gru_update(u, h, convc):
     return out
 
 
+def groupnorm1(x, gamma, beta, eps=1e-5):
+    """nn.GroupNorm(1, C) on x [C,...] (module.py:62-67)."""
+    x = _c(x).copy()
+    L = lib()
+    L.d3d_oracle_groupnorm1.argtypes = [_f32p, ctypes.c_int, ctypes.c_long, _f32p, _f32p, ctypes.c_float]
+    L.d3d_oracle_groupnorm1(_p(x), x.shape[0], x[0].size, _p(_c(gamma)), _p(_c(beta)), eps)
+    return x
+
+
 # ---- compositions restating the reference modules --------------------------------------
 
 def conv_gru_cell(x, h, p, prefix):
@@ -288,3 +297,36 @@ def cost_reg_net_3d(x, p, prefix=""):
     x = _ctbr3d(x, p, prefix + "conv9.", c2)
     x = _ctbr3d(x, p, prefix + "conv11.", c0)
     return conv3d_k3(x, p[prefix + "prob.weight"], p[prefix + "prob.bias"])
+
+
+def conv_gru_cell2(x, h, p, prefix):
+    """module.py:53-99 ConvGRUCell2.forward."""
+    H = h.shape[0]
+    f = conv2d_k3(np.concatenate([x, h], 0), p[prefix + "gate_conv.weight"], p[prefix + "gate_conv.bias"])
+    r = sigmoid(groupnorm1(f[:H], p[prefix + "reset_gate_norm.weight"], p[prefix + "reset_gate_norm.bias"]))
+    u = sigmoid(groupnorm1(f[H:], p[prefix + "update_gate_norm.weight"], p[prefix + "update_gate_norm.bias"]))
+    o = conv2d_k3(np.concatenate([x, r * h], 0), p[prefix + "output_conv.weight"], p[prefix + "output_conv.bias"])
+    on = groupnorm1(o, p[prefix + "output_norm.weight"], p[prefix + "output_norm.bias"])
+    return gru_update(u, h, on)
+
+
+def slice_red_regularization(cost, states, p, prefix):
+    """msrednet.py:353-370 slice_RED_Regularization.forward (one depth slice); states = [s1, s2, s3, s4]."""
+    relu = lambda a: np.maximum(a, 0.0).astype(np.float32)
+    s1, s2, s3, s4 = states
+    neg = (-cost).astype(np.float32)
+    c1 = relu(conv2d_k3(neg, p[prefix + "conv1.conv.weight"], stride=2))
+    c2 = relu(conv2d_k3(c1, p[prefix + "conv2.conv.weight"], stride=2))
+    c3 = relu(conv2d_k3(c2, p[prefix + "conv3.conv.weight"], stride=2))
+    s4 = conv_gru_cell2(c3, s4, p, prefix + "conv_gru4.")
+    up3 = relu(convtranspose2d_k3s2(s4, p[prefix + "upconv3.conv.weight"]))
+    s3 = conv_gru_cell2(c2, s3, p, prefix + "conv_gru3.")
+    up2 = relu(convtranspose2d_k3s2(up3 + s3, p[prefix + "upconv2.conv.weight"]))
+    s2 = conv_gru_cell2(c1, s2, p, prefix + "conv_gru2.")
+    up1 = relu(convtranspose2d_k3s2(up2 + s2, p[prefix + "upconv1.conv.weight"]))
+    s1 = conv_gru_cell2(neg, s1, p, prefix + "conv_gru1.")
+    # nn.ConvTranspose2d(8, 1, 3, stride=1, padding=1) == a correlation with the flipped, transposed kernel
+    wt = p[prefix + "upconv2d.weight"]
+    wc = np.ascontiguousarray(np.flip(wt, (2, 3)).transpose(1, 0, 2, 3))
+    reg = conv2d_k3(up1 + s1, wc, p[prefix + "upconv2d.bias"])
+    return reg, [s1, s2, s3, s4]

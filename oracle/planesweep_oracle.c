@@ -489,3 +489,20 @@ API void d3d_oracle_gru_update(const float* u, const float* h, const float* conv
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < n; ++i) out[i] = u[i] * h[i] + (1.0f - u[i]) * tanhf(convc[i]);
 }
+
+/* module.py:62-67,78-79,87 nn.GroupNorm(1, C, eps, affine): one group = statistics over all C*plane
+ * elements (biased variance), then per-channel gamma/beta.  In place. */
+API void d3d_oracle_groupnorm1(float* x, int C, long plane, const float* gamma, const float* beta, float eps) {
+    const long n = (long)C * plane;
+    double s = 0.0, q = 0.0;
+    for (long i = 0; i < n; ++i) { s += x[i]; q += (double)x[i] * x[i]; }
+    const double m = s / (double)n;
+    double var = q / (double)n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = 0; c < C; ++c)
+        for (long i = 0; i < plane; ++i) {
+            float* p = x + (long)c * plane + i;
+            *p = (*p - mean) * rstd * gamma[c] + beta[c];
+        }
+}

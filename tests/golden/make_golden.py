@@ -37,6 +37,7 @@ torch.set_num_threads(8)
 from models import module as RM  # noqa: E402
 from models import adamvs as RA  # noqa: E402
 from models import cas_mvsnet as RC  # noqa: E402
+from models import msrednet as RR  # noqa: E402
 
 T = torch.from_numpy
 
@@ -278,6 +279,41 @@ def gen_gru():
     save("ops_gru", **out)
 
 
+def gen_gru2():
+    """slice_RED_Regularization rollouts (msrednet.py:337-370) with GroupNorm conv-GRUs (module.py:53-99)."""
+    out = {}
+    n = 0
+    for (C, h, w, steps) in [(8, 8, 16, 1), (32, 16, 8, 5), (16, 8, 8, 3)]:
+        rng = np.random.default_rng(450 + n)
+        net = RR.slice_RED_Regularization(C, 8).eval()
+        S.fill_state_dict_(net.state_dict(), 4500 + n)
+        costs = np.abs(rng.standard_normal((steps, C, h, w))).astype(np.float32)
+        st = [torch.zeros(1, 8 << i, h >> i, w >> i) for i in range(4)]
+        regs = []
+        with torch.no_grad():
+            for t in range(steps):
+                r, *st = net(T(costs[t])[None], *st)
+                regs.append(r[0].numpy())
+        k = "c%d_" % n
+        out[k + "costs"] = costs
+        out[k + "seed"] = np.array(4500 + n)
+        out[k + "regs"] = np.stack(regs)
+        for i in range(4):
+            out[k + "state%d" % (i + 1)] = st[i][0].numpy()
+        n += 1
+    out["n_cases"] = np.array(n)
+    # one bare cell, non-zero initial state
+    rng = np.random.default_rng(460)
+    cell = RM.ConvGRUCell2(8, 8, 3).eval()
+    S.fill_state_dict_(cell.state_dict(), 4600)
+    x = rng.standard_normal((8, 6, 10)).astype(np.float32)
+    h0 = rng.standard_normal((8, 6, 10)).astype(np.float32)
+    with torch.no_grad():
+        h1, _ = cell(T(x)[None], T(h0)[None])
+    out["cell_x"], out["cell_h0"], out["cell_h1"], out["cell_seed"] = x, h0, h1[0].numpy(), np.array(4600)
+    save("ops_gru2", **out)
+
+
 def gen_costreg3d():
     """CostRegNet 3D UNet, eval-mode BN (cas_mvsnet.py:81-121)."""
     out = {}
@@ -335,13 +371,17 @@ def model_inputs(V, H, W, num_depth, seed):
     return imgs.astype(np.float32), pm, dv[None]
 
 
-def gen_models():
+def gen_models(only=None):
     for tag, ctor, V, nd, seed in [
         ("model_casmvsnet_v3", lambda nd: RC.Infer_CascadeMVSNet(num_depth=nd), 3, 64, 7001),
         ("model_casmvsnet_v5", lambda nd: RC.Infer_CascadeMVSNet(num_depth=nd), 5, 384, 7002),
         ("model_adamvs_v3", lambda nd: RA.Infer_AdaMVSNet(num_depth=nd), 3, 64, 7003),
         ("model_adamvs_v5", lambda nd: RA.Infer_AdaMVSNet(num_depth=nd), 5, 384, 7004),
+        ("model_msrednet_v3", lambda nd: RR.Infer_CascadeREDNet(num_depth=nd), 3, 64, 7005),
+        ("model_msrednet_v5", lambda nd: RR.Infer_CascadeREDNet(num_depth=nd), 5, 384, 7006),
     ]:
+        if only and tag not in only:
+            continue
         H, W = 64, 96
         net = ctor(nd).eval()
         S.fill_state_dict_(net.state_dict(), seed)
@@ -367,6 +407,9 @@ def gen_models():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "costreg3d", "pairnet", "models"]
+    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models"]
     for wname in which:
-        globals()["gen_" + wname]()
+        if wname.startswith("model_"):
+            gen_models(only=[wname])
+        else:
+            globals()["gen_" + wname]()

@@ -52,14 +52,16 @@ def test_operators_refuse_cpu_tensors():
         ops.softargmin_conf4(torch.zeros(4, 8, 8), torch.zeros(4))
 
 
-@pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_adamvs_v3"])
+@pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_adamvs_v3", "model_msrednet_v3"])
 def test_state_dict_is_checkpoint_compatible(tag):
     """Same keys, same order, same shapes as the reference module (recorded in the golden file)."""
     from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
     from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
 
     g = load_golden(tag)
-    net = (Infer_CascadeMVSNet if "casmvsnet" in tag else Infer_AdaMVSNet)(num_depth=int(g["num_depth"]))
+    ctor = {"casmvsnet": Infer_CascadeMVSNet, "adamvs": Infer_AdaMVSNet, "msrednet": Infer_CascadeREDNet}[tag.split("_")[1]]
+    net = ctor(num_depth=int(g["num_depth"]))
     sd = net.state_dict()
     assert list(sd.keys()) == [str(k) for k in g["state_keys"]]
     assert [",".join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g["state_shapes"]]

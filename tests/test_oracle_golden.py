@@ -122,6 +122,28 @@ def test_slice_gru_regulariser(oracle):
         assert np.abs(s2 - g[k + "state2"]).max() <= 1e-4
 
 
+def test_groupnorm_gru_cell_and_slice_red(oracle):
+    """module.py:53-99 ConvGRUCell2 and msrednet.py:337-370 slice_RED_Regularization restated on the oracle."""
+    from deep3d_aerial_amd.module import ConvGRUCell2
+    from deep3d_aerial_amd.msrednet import slice_RED_Regularization
+
+    g = load_golden("ops_gru2")
+    p = _weights(lambda: ConvGRUCell2(8, 8, 3), int(g["cell_seed"]))
+    h1 = oracle.conv_gru_cell2(g["cell_x"], g["cell_h0"], p, "")
+    assert np.abs(h1 - g["cell_h1"]).max() <= 2e-5
+    for i in _cases(g):
+        k = "c%d_" % i
+        costs = g[k + "costs"]
+        C, h, w = costs.shape[1:]
+        p = _weights(lambda: slice_RED_Regularization(C, 8), int(g[k + "seed"]))
+        st = [np.zeros((8 << j, h >> j, w >> j), np.float32) for j in range(4)]
+        for t in range(costs.shape[0]):
+            reg, st = oracle.slice_red_regularization(costs[t], st, p, "")
+            assert np.abs(reg - g[k + "regs"][t]).max() <= 2e-4, (i, t)
+        for j in range(4):
+            assert np.abs(st[j] - g[k + "state%d" % (j + 1)]).max() <= 1e-4, (i, j)
+
+
 def test_costregnet_3d(oracle):
     from deep3d_aerial_amd.cas_mvsnet import CostRegNet
 

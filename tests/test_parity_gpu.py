@@ -420,6 +420,50 @@ def test_slice_gru_golden(ops, convpath):
         assert np.abs(host(s2) - g[k + "state2"]).max() <= 1e-4
 
 
+def test_slice_red_gru2_golden(ops, convpath):
+    """msrednet.py:337-370 slice regulariser (GroupNorm conv-GRUs) vs the reference's rollouts."""
+    from deep3d_aerial_amd.module import ConvGRUCell2
+    from deep3d_aerial_amd.msrednet import slice_RED_Regularization
+
+    g = load_golden("ops_gru2")
+    cell = _fill(ConvGRUCell2(8, 8, 3), int(g["cell_seed"]))
+    with torch.no_grad():
+        h1, _ = cell(dev(g["cell_x"]), dev(g["cell_h0"]))
+    assert np.abs(host(h1) - g["cell_h1"]).max() <= 2e-5
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        costs = g[k + "costs"]
+        C, h, w = costs.shape[1:]
+        net = _fill(slice_RED_Regularization(C, 8), int(g[k + "seed"]))
+        st = [torch.zeros(8 << j, h >> j, w >> j, device="cuda") for j in range(4)]
+        with torch.no_grad():
+            for t in range(costs.shape[0]):
+                reg, *st = net(dev(costs[t]), *st)
+                assert np.abs(host(reg) - g[k + "regs"][t]).max() <= 3e-4, (i, t)
+        for j in range(4):
+            assert np.abs(host(st[j]) - g[k + "state%d" % (j + 1)]).max() <= 1e-4, (i, j)
+
+
+def test_groupnorm_stats_and_gates_vs_oracle(ops, oracle):
+    rng = np.random.default_rng(77)
+    Hc, h, w = 16, 9, 12
+    f = (3.0 + 2.0 * rng.standard_normal((2 * Hc, h, w))).astype(np.float32)
+    hh = rng.standard_normal((Hc, h, w)).astype(np.float32)
+    gr, br, gu, bu = (rng.uniform(0.5, 1.5, Hc).astype(np.float32) for _ in range(4))
+    st = host(ops.groupnorm_stats(dev(f[:Hc])))
+    assert abs(st[0] - f[:Hc].astype(np.float64).sum()) <= 1e-6 * abs(st[0]) + 1e-6
+    assert abs(st[1] - (f[:Hc].astype(np.float64) ** 2).sum()) <= 1e-6 * st[1]
+    rh, u = ops.gru_gates_gn(dev(f), dev(hh), dev(gr), dev(br), dev(gu), dev(bu))
+    r_want = oracle.sigmoid(oracle.groupnorm1(f[:Hc], gr, br))
+    u_want = oracle.sigmoid(oracle.groupnorm1(f[Hc:], gu, bu))
+    assert np.abs(host(rh) - r_want * hh).max() <= 2e-6
+    assert np.abs(host(u) - u_want).max() <= 2e-6
+    o = rng.standard_normal((Hc, h, w)).astype(np.float32)
+    got = host(ops.gru_update_gn(dev(o), dev(u_want), dev(hh), dev(gr), dev(br)))
+    want = oracle.gru_update(u_want, hh, oracle.groupnorm1(o, gr, br))
+    assert np.abs(got - want).max() <= 2e-6
+
+
 def test_pairnet_golden(ops, convpath):
     from deep3d_aerial_amd.adamvs import CostRegNet2D
 
@@ -433,13 +477,15 @@ def test_pairnet_golden(ops, convpath):
 # ----------------------------------------------------------------------------------------
 # full cascades behind the reference's forward() contract, vs the reference's own outputs
 # ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "model_adamvs_v5"])
+@pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "model_adamvs_v5",
+                                 "model_msrednet_v3", "model_msrednet_v5"])
 def test_model_forward_matches_reference(ops, tag):
     from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
     from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
 
     g = load_golden(tag)
-    ctor = Infer_CascadeMVSNet if "casmvsnet" in tag else Infer_AdaMVSNet
+    ctor = {"casmvsnet": Infer_CascadeMVSNet, "adamvs": Infer_AdaMVSNet, "msrednet": Infer_CascadeREDNet}[tag.split("_")[1]]
     net = _fill(ctor(num_depth=int(g["num_depth"])), int(g["seed"]))
     pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
     with torch.no_grad():
