@@ -50,11 +50,14 @@ struct ConvZParams {
     int PY, PX, CS, CiP;
     int nseg, mg_nseg, mg_py;  // staging: 16-lane segments per patch row, 16-bit reciprocal multipliers
     int zseg;                  // output columns in z per workgroup
-    int tzstart[5];            // taps sorted by tz: taps of tz = zmin+i are [tzstart[i], tzstart[i+1])
+    int vec, sh;               // vec: staging by 16-byte loads (W % 4 == 0); patch origin moved left by sh columns to a multiple of 4
+    int wyn;                   // waves along y: 4 (tile 4 rows x 16*NT columns) or 1 (1 row x 64*NT columns)
+    int tzstart[16];           // taps sorted by tz: taps of tz = zmin+i are [tzstart[i], tzstart[i+1])
     signed char ty[ZS_MAXTAPS], tx[ZS_MAXTAPS];
 };
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 #ifdef D3D_CONV_STATS
 // debug build only (tools/run_convstats.sh): per-phase cycle sums of wave 0 of every workgroup
@@ -76,18 +79,25 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     const int Ci = p.Ci0 + p.Ci1, CiP = p.CiP, PX = p.PX, PY = p.PY, CS = p.CS;
     const int srows = CK * PY, srows16 = (srows + 15) & ~15;
 
+#ifdef D3D_CONV_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     float* wl = lds;                                                     // [ntaps*CiP][WS] resident weights
     int* tofft = reinterpret_cast<int*>(lds + p.ntaps * CiP * WS);       // [ntaps] patch offset of each tap
     float* ssl = reinterpret_cast<float*>(tofft + ((p.ntaps + 3) & ~3)); // [2][64] per-channel scale, shift
     int2* rowt = reinterpret_cast<int2*>(ssl + 128);                     // [srows16] staging row table
     float* xin = reinterpret_cast<float*>(rowt + srows16);               // [CK][CS] one input plane chunk
 
-    const int gx0 = blockIdx.x * (16 * NT);
-    const int gy = blockIdx.y * 4 + wave;
+    // wave arrangement inside the tile: 4 x 1 (volumes) or 1 x 4 (single-row planes: 2D images streamed row by row)
+    const int wy = p.wyn == 4 ? wave : 0, wx = p.wyn == 4 ? 0 : wave, wxn = 4 / p.wyn;
+    const int tx0 = blockIdx.x * wxn * (16 * NT);  // first column of the workgroup's tile
+    const int gx0 = tx0 + wx * (16 * NT);          // first column of this wave
+    const int gy = blockIdx.y * p.wyn + wy;
     const int gz_lo = blockIdx.z * p.zseg;
     const int gz_hi = min(p.Gz, gz_lo + p.zseg);
-    const int iy0 = blockIdx.y * 4 * p.cy + p.ymin, ix0 = gx0 * p.cx + p.xmin;
-    const int bbase = g * CS + (wave * p.cy) * PX + j * p.cx;
+    const int iy0 = blockIdx.y * p.wyn * p.cy + p.ymin, ix0 = tx0 * p.cx + p.xmin;
+    const int bbase = g * CS + (wy * p.cy) * PX + (wx * (16 * NT) + j) * p.cx;
     const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
     const long out_plane = (long)p.Ho * p.Wo;
     const int zmax = p.zmin + p.zspan - 1;
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             for (int u = 0; u < 4; ++u)
                 if (dsto[u] >= 0) *reinterpret_cast<float4*>(wl + dsto[u]) = v[u];
         }
-        if (tid < p.ntaps) tofft[tid] = (p.ty[tid] - p.ymin) * PX + (p.tx[tid] - p.xmin);
+        if (tid < p.ntaps) tofft[tid] = (p.ty[tid] - p.ymin) * PX + (p.tx[tid] - p.xmin) + p.sh;
         if (tid < 64) {
             ssl[tid] = (p.scale && tid < p.Co) ? p.scale[tid] : 1.0f;
             ssl[64 + tid] = (p.shift && tid < p.Co) ? p.shift[tid] : 0.0f;
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             if (r < srows) {
                 const int cc = r / PY, y = r - cc * PY;
                 const int sy = iy0 + y;
-                if ((unsigned)sy < (unsigned)p.H) e.x = (int)(cc * in_vol + (long)sy * p.W + ix0);
+                if ((unsigned)sy < (unsigned)p.H) e.x = (int)(cc * in_vol + (long)sy * p.W + ix0 - p.sh);
                 e.y = (cc * CS + y * PX) | (cc << 20);
             }
             rowt[r] = e;
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     // ---- this lane's accumulator rows m = mt*16 + 4g + r -> output element offset of (c_out, fold position)
     // relative to the column origin, -1 when the row is unused or its y position is outside the output
     int rowoff[MT][4];
-    int rowco[MT];
+    int rowco[MT], rowfz[MT];  // c_out / z fold position of the four rows, one byte each
     unsigned long long colmask = 0;  // bit (mt*4+r)*NT+n: column n of that row lands inside the output
     int coloff[NT];
 #pragma unroll
@@ -145,6 +155,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         rowco[mt] = 0;
+        rowfz[mt] = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = mt * 16 + 4 * g + r;
@@ -157,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
                 if (oy < p.Ho) {
                     off = (int)(((long)co * p.Do + fzv) * out_plane + (long)oy * p.Wo + fxv);
                     rowco[mt] |= co << (8 * r);
+                    rowfz[mt] |= fzv << (8 * r);
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
                         if (gx0 + n * 16 + j < p.Gx && coloff[n] + fxv < p.Wo)
@@ -177,7 +189,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
 
     // flush accumulator slot 0 as output column gz (affine, skip, ReLU, store), then rotate the slots
     auto flush = [&](int gz) {
-        const long ubase = (long)(gz * p.sz + p.bz) * out_plane;  // uniform part of the output offset
+        const int ozb = gz * p.sz + p.bz;
+        const long ubase = (long)ozb * out_plane;  // uniform part of the output offset
         float* __restrict__ outp = p.out + ubase;
         const float* __restrict__ skp = p.skip ? p.skip + ubase : nullptr;
         // (values laundered through empty asm statements are loop invariant: left visible, the compiler hoists
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             for (int r = 0; r < 4; ++r) {
                 int off = rowoff[mt][r];
                 asm volatile("" : "+v"(off));
-                if (off >= 0) {
+                if (off >= 0 && ozb + ((rowfz[mt] >> (8 * r)) & 255) < p.Do) {  // (a z fold may overhang the volume)
                     const int co = (rowco[mt] >> (8 * r)) & 255;
                     const float sc = ssl[co], sh = ssl[64 + co];
 #pragma unroll
@@ -221,10 +234,6 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             for (int n = 0; n < NT; ++n) acc[NS - 1][m][n] = (f4v){0, 0, 0, 0};
     };
 
-#ifdef D3D_CONV_STATS
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-#endif
     int gbase = gz_lo;  // output column (z) held by accumulator slot 0
     const int zi_first = gz_lo * p.cz + p.zmin, zi_last = (gz_hi - 1) * p.cz + zmax;
     const int nchunks = CiP / CK;
@@ -238,76 +247,158 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     float pv[PF];
     const int grp = tid >> 4, xs = tid & 15;
     const int nitems = (srows16 >> 4) * p.nseg;
-    unsigned xbits = 0;  // bit seg: column seg*16+xs of the patch lies inside the image
-    for (int seg = 0; seg < p.nseg; ++seg) {
-        const int x = seg * 16 + xs;
-        if (x < PX && (unsigned)(ix0 + x) < (unsigned)p.W) xbits |= 1u << seg;
-    }
-    auto step_base = [&](int zi, int c) -> const float* {
+    // Staging loads are raw buffer loads: base (uniform, per step) + 32-bit byte offset, and the hardware range
+    // check returns 0 for offset 0x80000000 -- out-of-image / beyond-C_in elements need no branch and no select.
+    // Per item: a row-table read and about ten full-rate integer instructions (no 64-bit or multiply ops).
+    auto step_rsrc = [&](int zi, int c) {
         const int c0 = c * CK;  // a chunk never straddles the two inputs (host: Ci0 % CK == 0 when Ci1 > 0)
         const float* b = (c0 < p.Ci0) ? p.in0 + (long)c0 * in_vol : p.in1 + (long)(c0 - p.Ci0) * in_vol;
-        return b + (long)zi * in_plane;
+        b += (long)zi * in_plane;
+        const long span = (long)(CK - 1) * in_vol + in_plane;  // bytes reachable from b inside this (chunk, plane)
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, (int)(span * 4),
+                                                 0x00020000);
     };
-    // returns the LDS slot (or -1) and the clamped source offset of item i; ok = the source element exists
-    auto item = [&](int i, int grpo, int xso, unsigned xbo, int cmax, int& dst, unsigned& soff, bool& ok) {
-        const bool live = i < nitems;                                      // uniform: batches are padded to 8
-        const int k = live ? (i * p.mg_nseg) >> 16 : 0, seg = i - k * p.nseg;  // uniform
-        const int2 e = rowt[grpo + 16 * k];
-        const int x = seg * 16 + xso;
-        const int cc = e.y >> 20;
-        ok = live && (e.x != INT_MIN) && ((xbo >> (seg & 31)) & 1u) && (cc < cmax);
-        soff = ok ? (unsigned)(e.x + x) : 0u;
-        dst = (live && e.y >= 0 && x < PX) ? (e.y & 0xfffff) + x : -1;
+    // item i -> LDS slot (or -1) and source byte offset (0x80000000 = reads as zero).  Slots beyond the last item
+    // repeat it (same load, same LDS word), so batches of 8 carry no branches.
+    auto item_row = [&](int i, int nit, int grpo, int& seg) -> int2 {
+        const int ic = min(i, nit - 1);                                    // uniform
+        const int k = (ic * p.mg_nseg) >> 16;                              // uniform
+        seg = ic - k * p.nseg;
+        return rowt[grpo + 16 * k];
+    };
+    const int ix0s = ix0 - p.sh;  // image column of patch column 0
+    auto item_addr = [&](int2 e, int seg, int xso, int cmax, int& dst, unsigned& boff) {
+        // scalar mode: 16 lanes x 1 float per segment; vec mode: 16 lanes x 4 floats (xso = 4 * lane-in-group)
+        const int x = (p.vec ? seg * 64 : seg * 16) + xso;
+        // (bitwise &, not &&: short-circuit evaluation turns each item into branches with its own LDS waits)
+        const bool ok = (e.x != INT_MIN) & ((unsigned)(ix0s + x) < (unsigned)p.W) & ((e.y >> 20) < cmax);
+        boff = ok ? (unsigned)(e.x + x) << 2 : 0x80000000u;  // beyond num_records (< 2 GiB): reads as zero
+        dst = ((e.y >= 0) & (x < PX)) ? (e.y & 0xfffff) + x : -1;
     };
     auto issue = [&](int zi, int c) {
-        const float* __restrict__ base = step_base(zi, c);
+        const auto rs = step_rsrc(zi, c);
         const int cmax = Ci - c * CK;
-        int grpo = grp, xso = xs;
-        unsigned xbo = xbits;
-        asm volatile("" : "+v"(grpo), "+v"(xso), "+v"(xbo));  // see flush(): keep the item arithmetic in the loop
+        int grpo = grp, xso = p.vec ? 4 * xs : xs, nit = nitems;
+        // laundered: the item arithmetic is loop invariant; hoisted out of the plane loop it would pin hundreds
+        // of registers (and the uniform parts would be spilled SGPRs read back with VALU instructions)
+        asm volatile("" : "+v"(grpo), "+v"(xso), "+s"(nit));
+        if (p.vec) {  // 16-byte loads: a quarter of the instructions
+#pragma unroll
+            for (int b4 = 0; b4 < PF / 4; b4 += 4) {
+                if (b4 < nit) {
+                    int2 e[4];
+                    int seg[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = item_row(b4 + u, nit, grpo, seg[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int dst;
+                        unsigned boff;
+                        item_addr(e[u], seg[u], xso, cmax, dst, boff);
+                        // (bit-cast the whole vector: extracting u32 elements and casting each makes this compiler
+                        // narrow the load to one dword and splat it)
+                        const u4v q = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 0);
+                        const f4v f = __builtin_bit_cast(f4v, q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pv[4 * (b4 + u) + k] = f[k];
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int b8 = 0; b8 < PF; b8 += 8) {
-            if (b8 < nitems) {
+            if (b8 < nit) {
+                int2 e[8];
+                int seg[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = item_row(b8 + u, nit, grpo, seg[u]);
+                __builtin_amdgcn_sched_barrier(0);  // the eight row-table reads in flight together, one wait
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     int dst;
-                    unsigned soff;
-                    bool ok;
-                    item(b8 + u, grpo, xso, xbo, cmax, dst, soff, ok);
-                    pv[b8 + u] = base[soff];
+                    unsigned boff;
+                    item_addr(e[u], seg[u], xso, cmax, dst, boff);
+                    pv[b8 + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, boff, 0, 0));
                 }
             }
         }
     };
     auto land = [&](int zi, int c) {
-        const float* __restrict__ base = step_base(zi, c);
+        const auto rs = step_rsrc(zi, c);
         const int cmax = Ci - c * CK;
-        int grpo = grp, xso = xs;
-        unsigned xbo = xbits;
-        asm volatile("" : "+v"(grpo), "+v"(xso), "+v"(xbo));  // see flush(): keep the item arithmetic in the loop
+        int grpo = grp, xso = p.vec ? 4 * xs : xs, nit = nitems;
+        asm volatile("" : "+v"(grpo), "+v"(xso), "+s"(nit));
+        if (p.vec) {
+#pragma unroll
+            for (int b4 = 0; b4 < PF / 4; b4 += 4) {
+                if (b4 < nit) {
+                    int2 e[4];
+                    int seg[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[u] = item_row(b4 + u, nit, grpo, seg[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int dst;
+                        unsigned boff;
+                        item_addr(e[u], seg[u], xso, cmax, dst, boff);
+                        if (dst >= 0) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) xin[dst + k] = pv[4 * (b4 + u) + k];
+                        }
+                    }
+                }
+            }
+            for (int i0 = PF / 4; i0 < nit; i0 += 4) {  // beyond the register window
+                f4v v[4];
+                int dsto[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    unsigned boff;
+                    int seg;
+                    const int2 e = item_row(i0 + u, nit, grpo, seg);
+                    item_addr(e, seg, xso, cmax, dsto[u], boff);
+                    const u4v q = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 0);
+                    v[u] = __builtin_bit_cast(f4v, q);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (dsto[u] >= 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) xin[dsto[u] + k] = v[u][k];
+                    }
+            }
+            return;
+        }
 #pragma unroll
         for (int b8 = 0; b8 < PF; b8 += 8) {
-            if (b8 < nitems) {
+            if (b8 < nit) {
+                int2 e[8];
+                int seg[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = item_row(b8 + u, nit, grpo, seg[u]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     int dst;
-                    unsigned soff;
-                    bool ok;
-                    item(b8 + u, grpo, xso, xbo, cmax, dst, soff, ok);
-                    if (dst >= 0) xin[dst] = ok ? pv[b8 + u] : 0.0f;
+                    unsigned boff;
+                    item_addr(e[u], seg[u], xso, cmax, dst, boff);
+                    if (dst >= 0) xin[dst] = pv[b8 + u];
                 }
             }
         }
-        for (int i0 = PF; i0 < nitems; i0 += 8) {  // beyond the register window
+        for (int i0 = PF; i0 < nit; i0 += 8) {  // beyond the register window
             float v[8];
             int dsto[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                unsigned soff;
-                bool ok;
-                item(i0 + u, grpo, xso, xbo, cmax, dsto[u], soff, ok);
-                const float val = base[soff];
-                v[u] = ok ? val : 0.0f;
+                unsigned boff;
+                int seg;
+                const int2 e = item_row(i0 + u, nit, grpo, seg);
+                item_addr(e, seg, xso, cmax, dsto[u], boff);
+                v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, boff, 0, 0));
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -349,10 +440,17 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     int zi = zi_first < 0 ? 0 : zi_first;  // planes outside the volume are zero padding: skipped
     const int zend = zi_last >= p.D ? p.D - 1 : zi_last;
     int c = 0;
+    ZS_T(p0);
     __syncthreads();  // row table, weights, tap table, epilogue constants written
+    ZS_T(p1);
+    ZS_ADD(4, p0, p1);
     if (zi <= zend) {
         issue(zi, 0);
+        ZS_T(p2);
+        ZS_ADD(0, p1, p2);
         land(zi, 0);
+        ZS_T(p3);
+        ZS_ADD(1, p2, p3);
         __syncthreads();
         for (;;) {
             if (c == 0) {
@@ -392,9 +490,14 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             c = nc;
         }
     }
-    while (gbase < gz_hi) {
-        flush(gbase);
-        ++gbase;
+    {
+        ZS_T(e0);
+        while (gbase < gz_hi) {
+            flush(gbase);
+            ++gbase;
+        }
+        ZS_T(e1);
+        ZS_ADD(3, e0, e1);
     }
 #ifdef D3D_CONV_STATS
     if (tid == 0) {
@@ -418,10 +521,16 @@ static int patch_stride(int PY, int PX, int cx) {
     return cs;
 }
 
+static int patch_rows(const ConvZParams& p) { return p.yspan + (p.wyn - 1) * p.cy; }
+static int patch_cols(const ConvZParams& p, int NT) {  // LDS row length (vec mode: origin shifted, whole float4s)
+    const int px = p.xspan + (16 * NT * (4 / p.wyn) - 1) * p.cx;
+    return p.vec ? ((px + p.sh + 3) & ~3) : px;
+}
+
 static int lds_bytes_for(const ConvZParams& p, int MT, int NT, int CK) {
     const int MP = 16 * MT, WS = (MP == 16) ? 16 : MP + 16;
     const int Ci = p.Ci0 + p.Ci1, CiP = (Ci + CK - 1) / CK * CK;
-    const int PY = p.yspan + 3 * p.cy, PX = p.xspan + (16 * NT - 1) * p.cx;
+    const int PY = patch_rows(p), PX = patch_cols(p, NT);
     const int srows16 = (CK * PY + 15) & ~15;
     return 4 * (p.ntaps * CiP * WS + ((p.ntaps + 3) & ~3) + 128 + 2 * srows16 + CK * patch_stride(PY, PX, p.cx));
 }
@@ -430,10 +539,10 @@ template <int MT, int NT, int NS, int CK>
 static int launch_stream(ConvZParams& p, hipStream_t stream) {
     const int Ci = p.Ci0 + p.Ci1;
     p.CiP = (Ci + CK - 1) / CK * CK;
-    p.PY = p.yspan + 3 * p.cy;
-    p.PX = p.xspan + (16 * NT - 1) * p.cx;
+    p.PY = patch_rows(p);
+    p.PX = patch_cols(p, NT);
     p.CS = patch_stride(p.PY, p.PX, p.cx);
-    p.nseg = (p.PX + 15) / 16;
+    p.nseg = p.vec ? (p.PX + 63) / 64 : (p.PX + 15) / 16;
     p.mg_nseg = 65536 / p.nseg + 1;
     p.mg_py = 65536 / p.PY + 1;
     const int bytes = lds_bytes_for(p, MT, NT, CK);
@@ -446,9 +555,10 @@ static int launch_stream(ConvZParams& p, hipStream_t stream) {
         if (rc != D3D_OK) return rc;
         attr_set = true;
     }
-    const int nx = ceil_div(p.Gx, 16 * NT), ny = ceil_div(p.Gy, 4);
-    // enough workgroups to fill 256 CUs several times over, at the price of 2 halo planes per z segment
-    int nz = ceil_div(4096, (long)nx * ny);
+    const int nx = ceil_div(p.Gx, 16 * NT * (4 / p.wyn)), ny = ceil_div(p.Gy, p.wyn);
+    // enough workgroups to fill 256 CUs several times over, at the price of the halo planes and the one-time
+    // prologue per z segment (row-streamed images: fewer, longer segments)
+    int nz = ceil_div(p.wyn == 1 ? 1024 : 4096, (long)nx * ny);
     nz = nz < 1 ? 1 : (nz > p.Gz ? p.Gz : nz);
     p.zseg = ceil_div(p.Gz, nz);
     nz = ceil_div(p.Gz, p.zseg);
@@ -541,7 +651,7 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
     p.zmin = lo[0]; p.zspan = hi[0] - lo[0] + 1;
     p.ymin = lo[1]; p.yspan = hi[1] - lo[1] + 1;
     p.xmin = lo[2]; p.xspan = hi[2] - lo[2] + 1;
-    D3D_REQUIRE(p.zspan <= 4, "z tap span %d too large", p.zspan);
+    D3D_REQUIRE(p.zspan <= 15, "z tap span %d too large", p.zspan);
     {
         int t = 0;
         for (int i = 0; i <= p.zspan; ++i) {
@@ -549,6 +659,13 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
             p.tzstart[i] = t;
         }
     }
+    // 16-byte staging loads when every patch row starts on a 16-byte boundary: W % 4 == 0, aligned tensors, and the
+    // patch origin moved left to a multiple of 4 columns (tile origins are multiples of 16 columns)
+    p.vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1)) & 15) == 0 &&
+            !getenv("D3D_CONV_SCALAR_STAGING");
+    p.sh = p.vec ? (p.xmin & 3) : 0;
+    // single-row planes (a 2D image handed over as [C, rows, 1, W]): the four waves sit side by side
+    p.wyn = (H == 1 && Ho == 1 && p.yspan == 1 && p.fy == 1 && p.Gy == 1) ? 1 : 4;
     const int open_cols = (p.zspan + p.cz - 1) / p.cz;
     D3D_REQUIRE(open_cols <= 3, "more than 3 open output columns in z (span %d, step %d)", p.zspan, p.cz);
     const int NS = open_cols;
@@ -557,16 +674,16 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
     // room for two workgroups per CU
     int NT = 4, CK = (Ci > 8) ? 16 : 8;
     if (MT == 1 && lds_bytes_for(p, MT, 4, 8) > 72 * 1024) NT = 1;
+    if (MT == 1 && ((8 * patch_rows(p) + 15) / 16) * ((patch_cols(p, 4) + 15) / 16) > 48) NT = 1;  // register window
     if (CK == 16 && lds_bytes_for(p, MT, NT, 16) > 72 * 1024) CK = 8;
     const long in_plane = (long)H * W, in_vol = in_plane * D;
     // 32-bit element offsets inside one (chunk, plane) block and inside the output; a chunk must not straddle
     // the two concatenated inputs
-    if (CK == 16 && (15 * in_vol + in_plane >= (1L << 30) || (Ci1 > 0 && Ci0 % 16 != 0))) CK = 8;
-    if (7 * in_vol + in_plane >= (1L << 30) || (Ci1 > 0 && Ci0 % 8 != 0) || (long)Co * Do * Ho * Wo >= (1L << 30)) {
+    if (CK == 16 && (15 * in_vol + in_plane >= (1L << 29) || (Ci1 > 0 && Ci0 % 16 != 0))) CK = 8;
+    if (7 * in_vol + in_plane >= (1L << 29) || (Ci1 > 0 && Ci0 % 8 != 0) || (long)Co * Do * Ho * Wo >= (1L << 30)) {
         set_error("conv_stream: tensor too large for 32-bit offsets, or input split %d+%d not chunk aligned", Ci0, Ci1);
         return D3D_ERR_UNSUPPORTED;
     }
-    D3D_REQUIRE((p.Gz - 1) * p.sz + p.bz + p.fz - 1 < Do, "z fold overhangs the output");
     const int bytes = lds_bytes_for(p, MT, NT, CK);
     if (bytes > 156 * 1024) {
         set_error("conv_stream: resident weights + patch need %d B of LDS (ntaps=%d Ci=%d M=%d)", bytes, ntaps, Ci, M);
@@ -574,10 +691,10 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
     }
     {
         // staging index arithmetic uses 16-bit reciprocals: check their exact range on the host
-        const int PY = p.yspan + 3 * p.cy, PX = p.xspan + (16 * NT - 1) * p.cx;
-        const int nseg = (PX + 15) / 16, rows = CK * PY;
+        const int PY = patch_rows(p), PX = patch_cols(p, NT);
+        const int nseg = p.vec ? (PX + 63) / 64 : (PX + 15) / 16, rows = CK * PY;
         const int items = ((rows + 15) / 16) * nseg + 8;
-        D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 32 && PY <= 64, "patch %dx%d too large", PY, PX);
+        D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 64 && PY <= 64, "patch %dx%d too large", PY, PX);
     }
     hipStream_t st = (hipStream_t)stream;
     if (NT == 1) return launch_ck<1, 1>(p, NS, CK, st);

@@ -514,29 +514,29 @@ def _dim_convT(K, parities):
     return [0, 1], list(range(len(parities))), k, 1, 2, (parities[0] if len(parities) == 1 else 0)
 
 
-def _fold_pack(wk, dims, Co):
-    """wk [Co,Ci,KZ*KY*KX] -> (wpack [T,Ci,mpad], taps bytes (sorted by z), T, M, geom tail [c,s,b,f per dim])."""
-    (tz, fz, kz, cz, sz, bz), (ty, fy, ky, cy, sy, by), (tx, fx, kx, cx, sx, bx) = dims
-    KY = 3
-    KX = 3
-    F = len(fz) * len(fy) * len(fx)
+def _fold_pack(wk, dims, Co, ksizes):
+    """wk [Co,Ci,K0*K1*K2] (kernel sizes ksizes, in the streaming/row/column order of `dims`) ->
+    (wpack [T,Ci,mpad], taps bytes (sorted by the first dimension), T, M, mpad, [c,s,b,f per dim])."""
+    (t0, f0, k0, c0, s0, b0), (t1, f1, k1, c1, s1, b1), (t2, f2, k2, c2, s2, b2) = dims
+    K1, K2 = ksizes[1], ksizes[2]
+    F = len(f0) * len(f1) * len(f2)
     M = Co * F
     if M > 64:
-        raise ValueError("fold %dx%dx%d of %d channels exceeds 64 GEMM rows" % (len(fz), len(fy), len(fx), Co))
+        raise ValueError("fold %dx%dx%d of %d channels exceeds 64 GEMM rows" % (len(f0), len(f1), len(f2), Co))
     mpad = 16 if M <= 16 else (32 if M <= 32 else 64)
     nk = wk.shape[2]
     taps, kidx = [], []
-    for oz in tz:
-        for oy in ty:
-            for ox in tx:
+    for o0 in t0:
+        for o1 in t1:
+            for o2 in t2:
                 row = []
-                for a in fz:
-                    for b in fy:
-                        for c in fx:
-                            i, jj, l = kz(oz, a), ky(oy, b), kx(ox, c)
-                            row.append(nk if min(i, jj, l) < 0 else (i * KY + jj) * KX + l)
+                for a in f0:
+                    for b in f1:
+                        for c in f2:
+                            i, jj, l = k0(o0, a), k1(o1, b), k2(o2, c)
+                            row.append(nk if min(i, jj, l) < 0 else (i * K1 + jj) * K2 + l)
                 if any(r != nk for r in row):
-                    taps.append((oz, oy, ox))
+                    taps.append((o0, o1, o2))
                     kidx.append(row)
     T = len(taps)
     Ci = wk.shape[1]
@@ -546,24 +546,27 @@ def _fold_pack(wk, dims, Co):
     a = a.permute(2, 1, 3, 0).reshape(T, Ci, M)                          # row m = fold*Co + co
     wpack = torch.zeros((T, Ci, mpad), dtype=torch.float32, device=wk.device)
     wpack[:, :, :M] = a
-    tail = [cz, cy, cx, sz, sy, sx, bz, by, bx, len(fz), len(fy), len(fx)]
+    tail = [c0, c1, c2, s0, s1, s2, b0, b1, b2, len(f0), len(f1), len(f2)]
     return wpack.contiguous(), _np.array(taps, _np.int8).tobytes(), T, M, mpad, tail
 
 
-def _conv_fold_choice(Co, KZ, stride):
-    """Fold (fz,fy,fx) that fills the 16 GEMM rows of a narrow layer, within the kernel's 128-tap limit."""
+def _conv_fold_choice(Co, three_d, stride):
+    """Fold (f_y, f_x) that fills the 16 GEMM rows of a narrow layer, within the kernel's 128-tap limit."""
     if _os.environ.get("D3D_CONV_NOFOLD"):
-        return (1, 1, 1)
-    want = [(1, 4, 4), (1, 2, 4), (1, 2, 2), (1, 1, 2)]
-    ntaps = lambda f: (KZ if KZ == 1 else 3) * ((f[1] - 1) * stride + 3) * ((f[2] - 1) * stride + 3)
-    for f in want:
-        if Co * f[1] * f[2] <= 16 and ntaps(f) <= 128:
+        return (1, 1)
+    ntaps = lambda f: (3 if three_d else 1) * ((f[0] - 1) * stride + 3) * ((f[1] - 1) * stride + 3)
+    for f in [(4, 4), (2, 4), (2, 2), (1, 2)]:
+        if Co * f[0] * f[1] <= 16 and ntaps(f) <= 128:
             return f
-    return (1, 1, 1)
+    return (1, 1)
 
 
 def _packed_fold(weight, transposed, stride):
-    """List of launches [(wpack, taps, T, M, mpad, geom tail)] for one layer, cached like _packed."""
+    """List of launches [(wpack, taps, T, M, mpad, geom tail)] for one layer, cached like _packed.
+
+    Dimension order of the kernel is (streamed, row, column).  A volume [C,D,H,W] maps (z, y, x) onto it; an
+    image [C,H,W] is handed over as [C, H, 1, W] -- its rows are the streamed planes, so every input row is
+    staged once and the kernel's z machinery (open accumulator sets, z fold) serves the image's y axis."""
     key = (id(weight), "fold", transposed, stride)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
@@ -571,30 +574,32 @@ def _packed_fold(weight, transposed, stride):
     with torch.no_grad():
         w = weight.detach().float()
         three_d = w.dim() == 5
-        if not three_d:
-            w = w.unsqueeze(2)
-        KZ = w.shape[2]
         if transposed:
             w = w.transpose(0, 1)
         Co, Ci = w.shape[0], w.shape[1]
         wk = w.reshape(Co, Ci, -1).contiguous()
+        ks = (3, 3, 3) if three_d else (3, 1, 3)
         launches = []
         if not transposed:
-            f = _conv_fold_choice(Co, KZ, stride)
-            dims = (_dim_conv(KZ, stride, f[0]), _dim_conv(3, stride, f[1]), _dim_conv(3, stride, f[2]))
-            launches.append(_fold_pack(wk, dims, Co))
+            fy, fx = _conv_fold_choice(Co, three_d, stride)
+            if three_d:
+                dims = (_dim_conv(3, stride, 1), _dim_conv(3, stride, fy), _dim_conv(3, stride, fx))
+            else:
+                dims = (_dim_conv(3, stride, fy), _dim_conv(1, stride, 1), _dim_conv(3, stride, fx))
+            launches.append(_fold_pack(wk, dims, Co, ks))
         else:
-            # all output parities as GEMM rows while they fit 64 rows; otherwise one launch per z (then y) parity
-            zsets = [[0, 1]] if (KZ == 3 and Co * 8 <= 64) else ([[0], [1]] if KZ == 3 else [[0]])
-            nz = 2 if (KZ == 3 and len(zsets) == 1) else 1
-            ysets = [[0, 1]] if Co * nz * 4 <= 64 else [[0], [1]]
-            ny = len(ysets[0])
-            xsets = [[0, 1]] if Co * nz * ny * 2 <= 64 else [[0], [1]]
-            for zs in zsets:
-                for ys in ysets:
-                    for xs in xsets:
-                        dims = (_dim_convT(KZ, zs), _dim_convT(3, ys), _dim_convT(3, xs))
-                        launches.append(_fold_pack(wk, dims, Co))
+            # all output parities as GEMM rows while they fit 64 rows; otherwise one launch per parity of the
+            # leading dimensions
+            sets = [[[0, 1]] if k == 3 else [None] for k in ks]
+            rows = lambda: Co * int(_np.prod([len(ss[0]) if ss[0] else 1 for ss in sets]))
+            for d in range(3):
+                if rows() > 64 and ks[d] == 3:
+                    sets[d] = [[0], [1]]
+            for p0 in sets[0]:
+                for p1 in sets[1]:
+                    for p2 in sets[2]:
+                        dims = tuple(_dim_convT(ks[d], pp) for d, pp in enumerate((p0, p1, p2)))
+                        launches.append(_fold_pack(wk, dims, Co, ks))
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
     _pack_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), launches)
@@ -607,14 +612,15 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
     stride 2) through the z-streaming folded GEMM.  Returns None when the layer's resident weights do not fit
     LDS (D3D_ERR_UNSUPPORTED): the caller then takes the per-slice MFMA path."""
     three_d = x.dim() == 4
-    D, H, W = tuple(x.shape[1:]) if three_d else (1,) + tuple(x.shape[1:])
+    # kernel dimension order (streamed, row, column): a volume is (D,H,W), an image (H,1,W) -- see _packed_fold
+    D, H, W = tuple(x.shape[1:]) if three_d else (x.shape[1], 1, x.shape[2])
     Co = weight.shape[1] if transposed else weight.shape[0]
     if transposed:
-        od = (2 * D if three_d else 1, 2 * H, 2 * W)
+        od = (2 * D, 2 * H if three_d else 1, 2 * W)
     else:
         o = lambda n: (n - 1) // stride + 1
-        od = (o(D) if three_d else 1, o(H), o(W))
-    out = torch.empty((Co,) + (od if three_d else od[1:]), dtype=torch.float32, device=x.device)
+        od = (o(D), o(H) if three_d else 1, o(W))
+    out = torch.empty((Co,) + (od if three_d else (od[0], od[2])), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
     lib = _lib.load()

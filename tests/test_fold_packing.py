@@ -61,8 +61,10 @@ def test_conv2d_fold_packing(oracle, Co):
     w = (0.3 * rng.standard_normal((Co, 5, 3, 3))).astype(np.float32)
     for stride in (1, 2):
         want = oracle.conv2d_k3(x, w, None, stride=stride)
-        got = emulate(x[:, None], ops._packed_fold(torch.from_numpy(w), False, stride), (1,) + want.shape[1:], False)
-        assert np.abs(got[:, 0] - want).max() <= 1e-5
+        # images go through the kernel as [C, rows, 1, W] (rows are the streamed planes)
+        got = emulate(x[:, :, None, :], ops._packed_fold(torch.from_numpy(w), False, stride),
+                      (want.shape[1], 1, want.shape[2]), False)
+        assert np.abs(got[:, :, 0] - want).max() <= 1e-5
 
 
 @pytest.mark.parametrize("Co", [1, 8, 16, 32])
@@ -77,5 +79,6 @@ def test_convtranspose_fold_packing(oracle, Co):
     assert np.abs(got - want).max() <= 1e-5
     wt2 = (0.3 * rng.standard_normal((4, Co, 3, 3))).astype(np.float32)
     want = oracle.convtranspose2d_k3s2(x[:, 0], wt2)
-    got = emulate(x[:, :1], ops._packed_fold(torch.from_numpy(wt2), True, 2), (1,) + want.shape[1:], True)
-    assert np.abs(got[:, 0] - want).max() <= 1e-5
+    got = emulate(x[:, 0][:, :, None, :], ops._packed_fold(torch.from_numpy(wt2), True, 2),
+                  (want.shape[1], 1, want.shape[2]), True)
+    assert np.abs(got[:, :, 0] - want).max() <= 1e-5

@@ -43,3 +43,15 @@ del x
 x = torch.randn(32, 48, H // 4, W // 4, device="cuda")
 w0 = torch.randn(8, 32, 3, 3, 3, device="cuda") * 0.1
 report("s1 conv0 32->8", lambda: ops.conv3d_k3(x, w0))
+del x
+# 2D slice-regulariser layers at stage-3 resolution (AdaMVS / RED-Net)
+x = torch.randn(8, H, W, device="cuda")
+h8 = torch.randn(8, H, W, device="cuda")
+wg = torch.randn(16, 16, 3, 3, device="cuda") * 0.1
+report("2D gates 8+8->16", lambda: ops.conv2d_k3(x, wg, x2=h8))
+wc = torch.randn(8, 16, 3, 3, device="cuda") * 0.1
+report("2D cand 8+8->8", lambda: ops.conv2d_k3(x, wc, x2=h8))
+w1 = torch.randn(8, 8, 3, 3, device="cuda") * 0.1
+report("2D conv1 8->8", lambda: ops.conv2d_k3(x, w1, act=1))
+wo = torch.randn(1, 8, 3, 3, device="cuda") * 0.1
+report("2D out 8->1", lambda: ops.conv2d_k3(x, wo))
