@@ -70,15 +70,16 @@ class InferDepthNet(nn.Module):
             max_p = torch.zeros((h, w), dtype=torch.float32, device=dev)
             sum_d = torch.zeros_like(max_p)
             sum_p = torch.zeros_like(max_p)
+            # The reference warps plane by plane (msrednet.py:400-414) because it holds one slice at a time; the
+            # whole variance volume of a stage is at most 2.6 GB here, so it is swept in ONE fused launch and the
+            # recurrent regulariser then walks its depth slices.
+            var = ops.variance_volume(feats, p34, dvb.contiguous())                    # [C,D,h,w]
             for d in range(num_depth):
                 if dvb.dim() == 1:   # [D] uniform planes
-                    dsel = dvb[d:d + 1].contiguous()
-                    dplane = dsel.expand(h * w).reshape(h, w).contiguous()
+                    dplane = dvb[d:d + 1].expand(h * w).reshape(h, w).contiguous()
                 else:                # [D,h,w] per-pixel hypotheses
-                    dsel = dvb[d:d + 1].contiguous()
-                    dplane = dsel[0]
-                var = ops.variance_volume(feats, p34, dsel)[:, 0]                      # [C,h,w]
-                reg, *states = cost_regularization(var.contiguous(), *states)
+                    dplane = dvb[d]
+                reg, *states = cost_regularization(var[:, d].contiguous(), *states)
                 ops.online_regress_update(reg[0], dplane, max_p, sum_d, sum_p)
             dep, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
             depths.append(dep)

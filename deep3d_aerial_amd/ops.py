@@ -250,6 +250,14 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("x2 spatial size mismatch")
     if _use_mfma() and Co <= 64:
         return conv_k3_mfma(x, weight, scale, shift, skip, act=act, stride=stride, x2=x2)
+    if _use_mfma() and Co % 64 == 0:
+        # wide layers (RED-Net's 128-channel gate convolution): 64 output channels per matrix-core launch
+        parts = []
+        for c0 in range(0, Co, 64):
+            wsl = derived_weight(weight, "rows%d" % c0, lambda w, c0=c0: w[c0:c0 + 64])
+            sl = lambda t: None if t is None else t[c0:c0 + 64].contiguous()
+            parts.append(conv_k3_mfma(x, wsl, sl(scale), sl(shift), sl(skip), act=act, stride=stride, x2=x2))
+        return torch.cat(parts, 0)
     o = lambda n: (n - 1) // stride + 1
     out = torch.empty((Co, o(H), o(W)), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
