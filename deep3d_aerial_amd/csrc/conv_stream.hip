@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     // `grp` takes patch rows grp, grp+16, ...; its lanes run along x in 16-wide segments.  Item i = (row
     // iteration k, segment seg); the row table supplies the row's source / LDS offsets, so an item costs a
     // handful of integer instructions.
-    constexpr int PF = 48;  // items a thread can hold in flight (larger patches finish synchronously)
+    constexpr int PF = 32;  // items a thread can hold in flight (larger patches finish synchronously)
     float pv[PF];
     const int grp = tid >> 4, xs = tid & 15;
     const int nitems = (srows16 >> 4) * p.nseg;
