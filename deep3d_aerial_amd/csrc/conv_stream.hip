@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     const int gz_lo = blockIdx.z * p.zseg;
     const int gz_hi = min(p.Gz, gz_lo + p.zseg);
     const int iy0 = blockIdx.y * p.wyn * p.cy + p.ymin, ix0 = tx0 * p.cx + p.xmin;
-    const int bbase = g * CS + (wy * p.cy) * PX + (wx * (16 * NT) + j) * p.cx;
+    const int lcx = p.cx == 4 ? 2 : (p.cx == 2 ? 1 : 0), PXq = PX >> lcx;
+    const int bbase = g * CS + (wy * p.cy) * PX + (wx * (16 * NT) + j);
     const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
     const long out_plane = (long)p.Ho * p.Wo;
     const int zmax = p.zmin + p.zspan - 1;
@@ -125,7 +126,12 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             for (int u = 0; u < 4; ++u)
                 if (dsto[u] >= 0) *reinterpret_cast<float4*>(wl + dsto[u]) = v[u];
         }
-        if (tid < p.ntaps) tofft[tid] = (p.ty[tid] - p.ymin) * PX + (p.tx[tid] - p.xmin) + p.sh;
+        // Patch rows are stored de-interleaved by the column step cx: x -> (x % cx) * (PX / cx) + x / cx, so the 16
+        // columns of a B tile (x = j*cx + tap offset) are 16 consecutive LDS words whatever the fold / stride
+        if (tid < p.ntaps) {
+            const int o = (p.tx[tid] - p.xmin) + p.sh;
+            tofft[tid] = (p.ty[tid] - p.ymin) * PX + (o & (p.cx - 1)) * (PX >> lcx) + (o >> lcx);
+        }
         if (tid < 64) {
             ssl[tid] = (p.scale && tid < p.Co) ? p.scale[tid] : 1.0f;
             ssl[64 + tid] = (p.shift && tid < p.Co) ? p.shift[tid] : 0.0f;
@@ -267,13 +273,16 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
         return rowt[grpo + 16 * k];
     };
     const int ix0s = ix0 - p.sh;  // image column of patch column 0
+    int dk4[4];                   // LDS offsets of the four columns of an aligned float4 (de-interleaved rows)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dk4[k] = (k & (p.cx - 1)) * PXq + (k >> lcx);
     auto item_addr = [&](int2 e, int seg, int xso, int cmax, int& dst, unsigned& boff) {
         // scalar mode: 16 lanes x 1 float per segment; vec mode: 16 lanes x 4 floats (xso = 4 * lane-in-group)
         const int x = (p.vec ? seg * 64 : seg * 16) + xso;
         // (bitwise &, not &&: short-circuit evaluation turns each item into branches with its own LDS waits)
         const bool ok = (e.x != INT_MIN) & ((unsigned)(ix0s + x) < (unsigned)p.W) & ((e.y >> 20) < cmax);
         boff = ok ? (unsigned)(e.x + x) << 2 : 0x80000000u;  // beyond num_records (< 2 GiB): reads as zero
-        dst = ((e.y >= 0) & (x < PX)) ? (e.y & 0xfffff) + x : -1;
+        dst = ((e.y >= 0) & (x < PX)) ? (e.y & 0xfffff) + (x & (p.cx - 1)) * PXq + (x >> lcx) : -1;  // (vec: x % 4 == 0)
     };
     auto issue = [&](int zi, int c) {
         const auto rs = step_rsrc(zi, c);
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
                         item_addr(e[u], seg[u], xso, cmax, dst, boff);
                         if (dst >= 0) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) xin[dst + k] = pv[4 * (b4 + u) + k];
+                            for (int k = 0; k < 4; ++k) xin[dst + dk4[k]] = pv[4 * (b4 + u) + k];
                         }
                     }
                 }
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
                 for (int u = 0; u < 4; ++u)
                     if (dsto[u] >= 0) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) xin[dsto[u] + k] = v[u][k];
+                        for (int k = 0; k < 4; ++k) xin[dsto[u] + dk4[k]] = v[u][k];
                     }
             }
             return;
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
                 for (int kk = 0; kk < CK / 4; ++kk) {
                     float b[NT];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) b[n] = xb[kk * 4 * CS + n * 16 * p.cx];
+                    for (int n = 0; n < NT; ++n) b[n] = xb[kk * 4 * CS + n * 16];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const float av = wa[kk * 4 * WS + m * 16];
@@ -513,18 +522,16 @@ struct StreamCfg {
     int lds_bytes;
 };
 
-static int patch_stride(int PY, int PX, int cx) {
+static int patch_stride(int PY, int PX, int /*cx*/) {
     int cs = PY * PX;
-    if (cx == 1) cs += (16 - (cs & 31) + 32) & 31;  // CS = 16 mod 32
-    else if (cx == 2) cs |= 1;                       // odd
-    else if (cx == 4) cs += (2 - (cs & 3) + 4) & 3;  // CS = 2 mod 4
+    cs += (16 - (cs & 31) + 32) & 31;  // CS = 16 mod 32: the k-groups of a half-wave read disjoint bank halves
     return cs;
 }
 
 static int patch_rows(const ConvZParams& p) { return p.yspan + (p.wyn - 1) * p.cy; }
 static int patch_cols(const ConvZParams& p, int NT) {  // LDS row length (vec mode: origin shifted, whole float4s)
     const int px = p.xspan + (16 * NT * (4 / p.wyn) - 1) * p.cx;
-    return p.vec ? ((px + p.sh + 3) & ~3) : px;
+    return p.vec ? ((px + p.sh + 3) & ~3) : (px + p.cx - 1) / p.cx * p.cx;  // a multiple of cx (1, 2 or 4)
 }
 
 static int lds_bytes_for(const ConvZParams& p, int MT, int NT, int CK) {
@@ -624,7 +631,8 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
     p.fz = geom[12]; p.fy = geom[13]; p.fx = geom[14];
     p.act = act; p.skip_after_act = skip_after_act ? 1 : 0; p.ntaps = ntaps;
     D3D_REQUIRE(p.Gz > 0 && p.Gy > 0 && p.Gx > 0, "bad column grid %dx%dx%d", p.Gz, p.Gy, p.Gx);
-    D3D_REQUIRE(p.cz > 0 && p.cy > 0 && p.cx > 0 && p.sz > 0 && p.sy > 0 && p.sx > 0, "bad steps");
+    D3D_REQUIRE(p.cz > 0 && p.cy > 0 && (p.cx == 1 || p.cx == 2 || p.cx == 4) && p.sz > 0 && p.sy > 0 && p.sx > 0,
+                "bad steps (column step must be 1, 2 or 4)");
     D3D_REQUIRE(p.bz >= 0 && p.by >= 0 && p.bx >= 0, "bad output base");
     D3D_REQUIRE(p.fz > 0 && p.fy > 0 && p.fx > 0 && p.fz < 128 && p.fy < 256 && p.fx < 256, "bad fold");
     D3D_REQUIRE(Co > 0 && Co <= 64 && M == Co * p.fz * p.fy * p.fx && M <= 64, "bad rows: Co=%d fold=%dx%dx%d M=%d", Co,

@@ -567,7 +567,8 @@ def _conv_fold_choice(Co, Ci, three_d, stride):
     budget = int(_os.environ.get("D3D_CONV_FOLD_KB", "48")) * 1024
     ntaps = lambda f: (3 if three_d else 1) * ((f[0] - 1) * stride + 3) * ((f[1] - 1) * stride + 3)
     for f in [(4, 4), (2, 4), (2, 2), (1, 2)]:
-        if Co * f[0] * f[1] <= 16 and ntaps(f) <= 128 and ntaps(f) * Ci * 64 <= budget:
+        # (the kernel's column step f_x * stride must be 1, 2 or 4)
+        if Co * f[0] * f[1] <= 16 and f[1] * stride <= 4 and ntaps(f) <= 128 and ntaps(f) * Ci * 64 <= budget:
             return f
     return (1, 1)
 

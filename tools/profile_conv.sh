@@ -21,18 +21,18 @@ for f in glob.glob(out + "/SQ_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "conv_" in r["Kernel_Name"]:
             tot[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Kernel_Name"]][r["Counter_Name"]] += 1
-with open(out + "/summary.txt", "w") as fh:
-    for k in sorted(dur):
-        short = k.replace("void d3d::(anonymous namespace)::", "").split("(")[0]
-        d = sum(dur[k][1:]) / max(len(dur[k]) - 1, 1) if len(dur[k]) > 1 else dur[k][0]
-        line = "%-34s avg %9.1f us over %d launches" % (short, d, len(dur[k]))
-        c = {n: tot[k][n] / max(cnt[k][n], 1) for n in tot[k]}
-        if "SQ_INSTS_MFMA" in c:
-            # 32 cycles per v_mfma_f32_16x16x4_f32 on one of 1024 SIMDs
-            line += " | MFMA insts %.3e -> %.1f %% of MFMA issue slots at 2.4 GHz" % (c["SQ_INSTS_MFMA"], 100 * c["SQ_INSTS_MFMA"] * 32 / (d * 1e-6 * 2.4e9 * 1024))
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
-            line += " | MFMA_BUSY/BUSY %.3f" % (c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_BUSY_CYCLES"], 1))
-        fh.write(line + "\n")
-        fh.write("    " + "  ".join("%s=%.4g" % (n, c[n]) for n in sorted(c)) + "\n")
-print(open(out + "/summary.txt").read())
+lines = ["# rocprofv3 on tools/conv_prof_case.py (stage-3 CostRegNet layers at 2752x1856, fp32 MFMA 16x16x4), MI355X",
+         "# MFMA issue-slot share = SQ_INSTS_MFMA * 32 cycles / (kernel duration * 2.4 GHz * 1024 SIMDs); counters are per launch;",
+         "# launch order in the case file: conv0 8->8, prob 8->1, conv2 16->16, conv11 transposed 16->8"]
+for k in sorted(dur):
+    short = k.replace("void d3d::(anonymous namespace)::", "").split("(")[0]
+    d = sum(dur[k][1:]) / max(len(dur[k]) - 1, 1) if len(dur[k]) > 1 else dur[k][0]
+    c = {n: tot[k][n] / max(cnt[k][n], 1) for n in tot[k]}
+    line = "%-34s avg %8.1f us over %d launches" % (short, d, len(dur[k]))
+    if "SQ_INSTS_MFMA" in c:
+        line += " | SQ_INSTS_MFMA %.3e -> %.1f %% of MFMA issue slots" % (c["SQ_INSTS_MFMA"], 100 * c["SQ_INSTS_MFMA"] * 32 / (d * 1e-6 * 2.4e9 * 1024))
+    lines.append(line)
+    lines.append("    " + "  ".join("%s=%.4g" % (n, c[n]) for n in sorted(c)))
+open(out + "/summary.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
 PY
