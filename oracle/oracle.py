@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libplanesweep_oracle.so")
+# D3D_ORACLE_SO: use a pre-built variant instead (e.g. the -fsanitize=address,undefined build of `make asan`)
+_SO = os.environ.get("D3D_ORACLE_SO") or os.path.join(_HERE, "libplanesweep_oracle.so")
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 
@@ -17,6 +18,8 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 def build(force=False):
     """Compile the oracle with gcc (idempotent)."""
     src = os.path.join(_HERE, "planesweep_oracle.c")
+    if os.environ.get("D3D_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libplanesweep_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO
