@@ -204,6 +204,25 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
         unsigned mlo = (unsigned)colmask, mhi = (unsigned)(colmask >> 32);
         asm volatile("" : "+v"(mlo), "+v"(mhi));
         const unsigned long long cmask = ((unsigned long long)mhi << 32) | mlo;
+        // skip values first, all in flight together (clamped addresses, no branches), then the epilogue proper.
+        // (Not for the 32-row variants: the extra registers cost them an occupancy step on layers without a
+        // skip; they fetch the skip values tile by tile below.)
+        constexpr bool BATCH_SKIP = (MT != 2);
+        float sk[BATCH_SKIP ? MT : 1][4][NT];
+        if (BATCH_SKIP && skp) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int off = rowoff[mt][r];
+                    asm volatile("" : "+v"(off));
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const bool ok = (off >= 0) & (((cmask >> ((mt * 4 + r) * NT + n)) & 1ull) != 0);
+                        sk[mt][r][n] = skp[ok ? (unsigned)(off + coloff[n]) : 0u];
+                    }
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -218,15 +237,16 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
                         if ((cmask >> ((mt * 4 + r) * NT + n)) & 1ull) {
                             const unsigned e = (unsigned)(off + coloff[n]);
                             float y = acc[0][mt][n][r] * sc + sh;
-                            if (skp && !p.skip_after_act) y += skp[e];
+                            float skv = 0.0f;
+                            if (skp) skv = BATCH_SKIP ? sk[BATCH_SKIP ? mt : 0][r][n] : skp[e];
+                            if (skp && !p.skip_after_act) y += skv;
                             if (p.act == 1) y = fmaxf(y, 0.0f);
-                            if (skp && p.skip_after_act) y = skp[e] + y;
+                            if (skp && p.skip_after_act) y = skv + y;
                             outp[e] = y;
                         }
                     }
                 }
-                // four rows (one 16-row tile) at a time: their skip loads overlap, registers stay bounded
-                if (r == 3) __builtin_amdgcn_sched_barrier(0);
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);  // one 16-row tile at a time: bounded registers
             }
 #pragma unroll
         for (int s = 0; s + 1 < NS; ++s)

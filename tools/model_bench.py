@@ -31,4 +31,4 @@ with torch.no_grad():
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
         net(imgs, pm, dv); torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=70))
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=70))
