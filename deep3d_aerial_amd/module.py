@@ -4,11 +4,13 @@ Same public names, argument order and meaning, and the same state_dict keys, so 
 reference's Infer_* drivers and checkpoints carry over -- but the arithmetic of the hot
 path runs in the gfx950 C-ABI kernels (deep3d_aerial_amd.ops).  torch.nn modules are used
 as PARAMETER CONTAINERS (they define the checkpoint layout); their forward()s call the
-HIP kernels.  The image feature pyramids stay on PyTorch-ROCm /
-MIOpen by design: they are upstream of the plane-sweep path.
+HIP kernels.  The image feature pyramids are upstream of the plane-sweep path and
+stay PyTorch-ROCm / MIOpen modules, except that their 3x3 layers reuse the matrix-core convolution.
 
 Everything here requires GPU tensors: there is no CPU fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -209,6 +211,19 @@ class Conv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
+        c = self.conv
+        # 3x3 / pad 1 layers of the feature pyramid run on the matrix-core convolution too (eval-mode BN and
+        # ReLU in its epilogue); the 5x5 stride-2 and 1x1 layers stay on MIOpen.  D3D_FEATURE_CONV=miopen
+        # sends everything to MIOpen.
+        if (c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride in ((1, 1), (2, 2)) and c.dilation == (1, 1)
+                and c.groups == 1 and not self.training and x.is_cuda and x.dtype == torch.float32
+                and c.out_channels <= 64 and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+            if self.bn is not None:
+                s, t = folded_bn(self.bn)
+            else:
+                s, t = None, c.bias
+            return torch.stack([ops.conv2d_k3(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0,
+                                              stride=c.stride[0]) for b in range(x.shape[0])])
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)
