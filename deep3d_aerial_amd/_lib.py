@@ -42,6 +42,8 @@ SIGNATURES = {
                           _i, _i, _i, _i, _i, ctypes.c_char_p, _vp, _vp],
     "d3d_conv_fold_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                           ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
+    "d3d_conv_fold_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+                           ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
     "d3d_gru_gates": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "d3d_gru_update": [_vp, _vp, _vp, _i64, _vp, _vp],
     "d3d_groupnorm_stats": [_vp, _i64, _vp, _vp],

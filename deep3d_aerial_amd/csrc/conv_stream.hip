@@ -69,7 +69,13 @@ __device__ unsigned long long g_conv_stats[8];
 #define ZS_ADD(i, a, b)
 #endif
 
-template <int MT, int NT, int NS, int CK>
+typedef __bf16 bf4v __attribute__((ext_vector_type(4)));
+
+// BF16 = true: the same kernel with bf16 MFMA operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) -- the
+// precision BASELINE's config 3 names.  The patch stays fp32 in LDS and is rounded (RNE, v_cvt_pk_bf16_f32) when
+// the B operand is formed; the resident weights are stored as bf16.  One MFMA covers K = 16: one tap x 16 channels
+// (CK = 16) or two taps x 8 channels (CK = 8).
+template <int MT, int NT, int NS, int CK, bool BF16>
 __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int MP = 16 * MT;
@@ -84,7 +90,9 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     float* wl = lds;                                                     // [ntaps*CiP][WS] resident weights
-    int* tofft = reinterpret_cast<int*>(lds + p.ntaps * CiP * WS);       // [ntaps] patch offset of each tap
+    // bf16: [ntaps][chunks][4 k-slots][WS] entries of 4 bf16 (8 bytes) = 2 floats per entry
+    const int wl_floats = BF16 ? p.ntaps * (CiP / CK) * 4 * WS * 2 : p.ntaps * CiP * WS;
+    int* tofft = reinterpret_cast<int*>(lds + wl_floats);                // [ntaps] patch offset of each tap
     float* ssl = reinterpret_cast<float*>(tofft + ((p.ntaps + 3) & ~3)); // [2][64] per-channel scale, shift
     int2* rowt = reinterpret_cast<int2*>(ssl + 128);                     // [srows16] staging row table
     float* xin = reinterpret_cast<float*>(rowt + srows16);               // [CK][CS] one input plane chunk
@@ -105,7 +113,38 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
 
     // ---- one-time: resident weights (rows beyond Ci are zero), tap offsets, epilogue constants, row table
     {
-        const int rows = p.ntaps * CiP;
+        if constexpr (BF16) {
+            // entry (t, chunk c, k-slot g, row m): 4 consecutive k of row m.  CK = 16: channels c*16 + 4g.. of tap t;
+            // CK = 8: channels c*8 + 4(g&1).. of tap t + (g>>1) -- zero when that tap belongs to another z group
+            // (the sweep pairs taps inside a group) or does not exist.
+            const int nch = CiP / CK, nent = p.ntaps * nch * 4 * MP;
+            bf4v* wl16 = reinterpret_cast<bf4v*>(wl);
+            for (int e = tid; e < nent; e += 256) {
+                const int m = e % MP, r1 = e / MP;
+                const int gg = r1 & 3, r2 = r1 >> 2;
+                const int c = r2 % nch, t = r2 / nch;
+                int tt = t, cb = c * CK + 4 * gg;
+                bool live = true;
+                if (CK == 8) {
+                    tt = t + (gg >> 1);
+                    cb = c * CK + 4 * (gg & 1);
+                    int te = p.ntaps;
+                    for (int i = 0; i < p.zspan; ++i)
+                        if (t >= p.tzstart[i] && t < p.tzstart[i + 1]) te = p.tzstart[i + 1];
+                    live = tt < te;
+                }
+                bf4v v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ci = cb + q;
+                    const bool ok = live && ci < Ci;
+                    const float w = p.wpack[((long)(ok ? tt : 0) * Ci + (ok ? ci : 0)) * MP + m];
+                    v[q] = (__bf16)(ok ? w : 0.0f);
+                }
+                wl16[r1 * WS + m] = v;
+            }
+        }
+        const int rows = BF16 ? 0 : p.ntaps * CiP;
         const int n4 = rows * (MP / 4);
         for (int e0 = tid; e0 < n4; e0 += 256 * 4) {
             float4 v[4];
@@ -443,6 +482,33 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(ConvZParams p) {
             if (gzs >= gz_hi || tzv < p.zmin || tzv > zmax) continue;
             const int tb = p.tzstart[tzv - p.zmin], te = p.tzstart[tzv - p.zmin + 1];
             if (tb >= te) continue;
+            if constexpr (BF16) {
+                const bf4v* __restrict__ wl16 = reinterpret_cast<const bf4v*>(wl);
+                const int nch = CiP / CK;
+                const int bb = bbase - g * CS;  // patch offset of this lane's column, channel 0
+                constexpr int TSTEP = (CK == 8) ? 2 : 1;
+                for (int t = tb; t < te; t += TSTEP) {
+                    // this lane's k-slot: channels cb..cb+3 at tap t (CK = 16) or tap t + (g>>1) (CK = 8)
+                    const int tl = (CK == 8) ? min(t + (g >> 1), te - 1) : t;
+                    const int cb = (CK == 8) ? 4 * (g & 1) : 4 * g;
+                    const float* __restrict__ xb = xin + bb + tofft[tl] + cb * CS;
+                    const bf4v* __restrict__ wa = wl16 + ((t * nch + c) * 4 + g) * WS + j;
+                    bf4v b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const float x0 = xb[n * 16], x1 = xb[CS + n * 16], x2 = xb[2 * CS + n * 16], x3 = xb[3 * CS + n * 16];
+                        b[n] = (bf4v){(__bf16)x0, (__bf16)x1, (__bf16)x2, (__bf16)x3};
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const bf4v av = wa[m * 16];
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[s][m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, b[n], acc[s][m][n], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
             int toff = tofft[tb];
             for (int t = tb; t < te; ++t) {
                 const int toff_next = tofft[min(t + 1, p.ntaps - 1)];
@@ -554,15 +620,21 @@ static int patch_cols(const ConvZParams& p, int NT) {  // LDS row length (vec mo
     return p.vec ? ((px + p.sh + 3) & ~3) : (px + p.cx - 1) / p.cx * p.cx;  // a multiple of cx (1, 2 or 4)
 }
 
-static int lds_bytes_for(const ConvZParams& p, int MT, int NT, int CK) {
+static int lds_bytes_for(const ConvZParams& p, int MT, int NT, int CK, bool bf16 = false) {
     const int MP = 16 * MT, WS = (MP == 16) ? 16 : MP + 16;
     const int Ci = p.Ci0 + p.Ci1, CiP = (Ci + CK - 1) / CK * CK;
+    if (bf16) {
+        const int PYb = patch_rows(p), PXb = patch_cols(p, NT);
+        const int srows16b = (CK * PYb + 15) & ~15;
+        return 4 * (p.ntaps * (CiP / CK) * 4 * WS * 2 + ((p.ntaps + 3) & ~3) + 128 + 2 * srows16b +
+                    CK * patch_stride(PYb, PXb, p.cx));
+    }
     const int PY = patch_rows(p), PX = patch_cols(p, NT);
     const int srows16 = (CK * PY + 15) & ~15;
     return 4 * (p.ntaps * CiP * WS + ((p.ntaps + 3) & ~3) + 128 + 2 * srows16 + CK * patch_stride(PY, PX, p.cx));
 }
 
-template <int MT, int NT, int NS, int CK>
+template <int MT, int NT, int NS, int CK, bool BF16>
 static int launch_stream(ConvZParams& p, hipStream_t stream) {
     const int Ci = p.Ci0 + p.Ci1;
     p.CiP = (Ci + CK - 1) / CK * CK;
@@ -572,8 +644,8 @@ static int launch_stream(ConvZParams& p, hipStream_t stream) {
     p.nseg = p.vec ? (p.PX + 63) / 64 : (p.PX + 15) / 16;
     p.mg_nseg = 65536 / p.nseg + 1;
     p.mg_py = 65536 / p.PY + 1;
-    const int bytes = lds_bytes_for(p, MT, NT, CK);
-    auto kern = conv_stream_kernel<MT, NT, NS, CK>;
+    const int bytes = lds_bytes_for(p, MT, NT, CK, BF16);
+    auto kern = conv_stream_kernel<MT, NT, NS, CK, BF16>;
     static bool attr_set = false;
     if (!attr_set) {
         int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -599,16 +671,21 @@ static int launch_stream(ConvZParams& p, hipStream_t stream) {
 }
 
 template <int MT, int NT, int CK>
-static int launch_ns(ConvZParams& p, int NS, hipStream_t stream) {
-    if (NS == 1) return launch_stream<MT, NT, 1, CK>(p, stream);
-    if (NS == 2) return launch_stream<MT, NT, 2, CK>(p, stream);
-    return launch_stream<MT, NT, 3, CK>(p, stream);
+static int launch_ns(ConvZParams& p, int NS, bool bf16, hipStream_t stream) {
+    if (bf16) {
+        if (NS == 1) return launch_stream<MT, NT, 1, CK, true>(p, stream);
+        if (NS == 2) return launch_stream<MT, NT, 2, CK, true>(p, stream);
+        return launch_stream<MT, NT, 3, CK, true>(p, stream);
+    }
+    if (NS == 1) return launch_stream<MT, NT, 1, CK, false>(p, stream);
+    if (NS == 2) return launch_stream<MT, NT, 2, CK, false>(p, stream);
+    return launch_stream<MT, NT, 3, CK, false>(p, stream);
 }
 
 template <int MT, int NT>
-static int launch_ck(ConvZParams& p, int NS, int CK, hipStream_t stream) {
-    if (CK == 16) return launch_ns<MT, NT, 16>(p, NS, stream);
-    return launch_ns<MT, NT, 8>(p, NS, stream);
+static int launch_ck(ConvZParams& p, int NS, int CK, bool bf16, hipStream_t stream) {
+    if (CK == 16) return launch_ns<MT, NT, 16>(p, NS, bf16, stream);
+    return launch_ns<MT, NT, 8>(p, NS, bf16, stream);
 }
 
 }  // namespace
@@ -632,10 +709,12 @@ int d3d_conv_stream_stats(unsigned long long* out8, int reset) {
 }
 #endif
 
-int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
-                      const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
-                      int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
-                      const signed char* taps_zyx, float* out, d3d_stream_t stream) {
+}  // extern "C"
+
+static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad,
+                          int M, const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
+                          int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
+                          const signed char* taps_zyx, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in0 && wpack && out && taps_zyx && geom, "null pointer");
     D3D_REQUIRE(Ci0 > 0 && Ci1 >= 0 && (Ci1 == 0 || in1), "bad input channel split %d+%d", Ci0, Ci1);
     D3D_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "bad dims");
@@ -701,9 +780,9 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
     // tile / chunk choice: narrow tiles when the folded patch is wide; 16-channel chunks when they still leave
     // room for two workgroups per CU
     int NT = 4, CK = (Ci > 8) ? 16 : 8;
-    if (MT == 1 && lds_bytes_for(p, MT, 4, 8) > 72 * 1024) NT = 1;
+    if (MT == 1 && lds_bytes_for(p, MT, 4, 8, bf16) > 72 * 1024) NT = 1;
     if (MT == 1 && ((8 * patch_rows(p) + 15) / 16) * ((patch_cols(p, 4) + 15) / 16) > 48) NT = 1;  // register window
-    if (CK == 16 && lds_bytes_for(p, MT, NT, 16) > 72 * 1024) CK = 8;
+    if (CK == 16 && lds_bytes_for(p, MT, NT, 16, bf16) > 72 * 1024) CK = 8;
     const long in_plane = (long)H * W, in_vol = in_plane * D;
     // 32-bit element offsets inside one (chunk, plane) block and inside the output; a chunk must not straddle
     // the two concatenated inputs
@@ -712,7 +791,7 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
         set_error("conv_stream: tensor too large for 32-bit offsets, or input split %d+%d not chunk aligned", Ci0, Ci1);
         return D3D_ERR_UNSUPPORTED;
     }
-    const int bytes = lds_bytes_for(p, MT, NT, CK);
+    const int bytes = lds_bytes_for(p, MT, NT, CK, bf16);
     if (bytes > 156 * 1024) {
         set_error("conv_stream: resident weights + patch need %d B of LDS (ntaps=%d Ci=%d M=%d)", bytes, ntaps, Ci, M);
         return D3D_ERR_UNSUPPORTED;
@@ -725,12 +804,31 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
         D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 64 && PY <= 64, "patch %dx%d too large", PY, PX);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (NT == 1) return launch_ck<1, 1>(p, NS, CK, st);
+    if (NT == 1) return launch_ck<1, 1>(p, NS, CK, bf16, st);
     switch (MT) {
-        case 1: return launch_ck<1, 4>(p, NS, CK, st);
-        case 2: return launch_ck<2, 4>(p, NS, CK, st);
-        default: return launch_ck<4, 4>(p, NS, CK, st);
+        case 1: return launch_ck<1, 4>(p, NS, CK, bf16, st);
+        case 2: return launch_ck<2, 4>(p, NS, CK, bf16, st);
+        default: return launch_ck<4, 4>(p, NS, CK, bf16, st);
     }
 }
 
+extern "C" {
+
+int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
+                      const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
+                      int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
+                      const signed char* taps_zyx, float* out, d3d_stream_t stream) {
+    return conv_fold_impl(false, in0, Ci0, in1, Ci1, wpack, mpad, M, scale, shift, skip, skip_after_act, act, Co, D, H, W,
+                          Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
+}
+
+int d3d_conv_fold_bf16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
+                       const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
+                       int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
+                       const signed char* taps_zyx, float* out, d3d_stream_t stream) {
+    return conv_fold_impl(true, in0, Ci0, in1, Ci1, wpack, mpad, M, scale, shift, skip, skip_after_act, act, Co, D, H, W,
+                          Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
+}
+
 }  // extern "C"
+

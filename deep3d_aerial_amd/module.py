@@ -222,8 +222,9 @@ class Conv2d(nn.Module):
                 s, t = folded_bn(self.bn)
             else:
                 s, t = None, c.bias
-            return torch.stack([ops.conv2d_k3(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0,
-                                              stride=c.stride[0]) for b in range(x.shape[0])])
+            with ops.fp32_convs():  # the bf16 mode (BASELINE config 3) is for the cost regularisers only
+                return torch.stack([ops.conv2d_k3(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0,
+                                                  stride=c.stride[0]) for b in range(x.shape[0])])
         x = self.conv(x)
         if self.bn is not None:
             x = self.bn(x)

@@ -386,6 +386,33 @@ def _mpad(co):
     return 16 * (4 if mt == 3 else mt)
 
 
+_conv_precision = [None]
+
+
+def set_conv_precision(mode):
+    """"fp32" (default; exact fp32 MFMA) or "bf16" (bf16 MFMA operands, fp32 accumulate: BASELINE config 3) for
+    the convolutions that go through d3d_conv_fold_*.  None = follow the environment (D3D_CONV_PRECISION)."""
+    if mode not in (None, "fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    _conv_precision[0] = mode
+
+
+def conv_precision():
+    return _conv_precision[0] or _os.environ.get("D3D_CONV_PRECISION", "fp32")
+
+
+class fp32_convs:
+    """Context manager: exact fp32 convolutions inside, whatever the global precision (feature pyramids)."""
+
+    def __enter__(self):
+        self.saved = _conv_precision[0]
+        _conv_precision[0] = "fp32"
+
+    def __exit__(self, *exc):
+        _conv_precision[0] = self.saved
+        return False
+
+
 def _use_mfma():
     return _os.environ.get("D3D_CONV", "mfma") != "direct"
 
@@ -647,11 +674,12 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         else:
             G = tuple((od[i] + (fz, fy, fx)[i] - 1) // (fz, fy, fx)[i] for i in range(3))
         geom = (ctypes.c_int * 15)(G[0], G[1], G[2], cz, cy, cx, sz, sy, sx, bz, by, bx, fz, fy, fx)
-        rc = lib.d3d_conv_fold_f32(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
+        fold = lib.d3d_conv_fold_bf16 if conv_precision() == "bf16" else lib.d3d_conv_fold_f32
+        rc = fold(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
                                    _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
                                    int(skip_after_act), int(act), Co, D, H, W, od[0], od[1], od[2], geom, T, taps,
                                    _chk(out, "out"), _stream())
         if rc == _lib.ERR_UNSUPPORTED:
             return None
-        _lib.check(rc, "d3d_conv_fold_f32")
+        _lib.check(rc, "d3d_conv_fold")
     return out

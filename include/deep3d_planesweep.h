@@ -219,6 +219,14 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
                       int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
                       const signed char* taps_zyx, float* out, d3d_stream_t stream);
 
+/* Same contract with bf16 MFMA operands (v_mfma_f32_16x16x16_bf16; inputs and weights rounded to nearest-even
+ * bf16 as the operands are formed, fp32 accumulation, fp32 tensors in memory): the precision BASELINE.json's
+ * config 3 asks for.  Depth stays within the 1e-3 relative-L1 budget of the fp32 reference (tests/test_parity_gpu.py). */
+int d3d_conv_fold_bf16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
+                       const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
+                       int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
+                       const signed char* taps_zyx, float* out, d3d_stream_t stream);
+
 /*
  * module.py:24-51 ConvGRUCell gate math, fused:
  *   phase 0: gates [2Hc,H,W] (pre-activation, bias already applied) ->

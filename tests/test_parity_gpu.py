@@ -377,6 +377,65 @@ def test_conv_gemm_channel_counts_and_epilogue(ops, oracle, Ci, Co, mode, monkey
     assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
 
 
+def _bf16_round(a):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32, as v_cvt_pk_bf16_f32 does."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 16), (32, 8), (8, 1), (24, 16), (16, 32)])
+def test_conv_bf16_operands_match_rounded_oracle(ops, oracle, Ci, Co, monkeypatch):
+    """d3d_conv_fold_bf16: operands rounded to bf16 (RNE), fp32 accumulation -- so it must agree with the fp32
+    oracle run on pre-rounded inputs and weights to fp32 summation-order accuracy."""
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    rng = np.random.default_rng(Ci * 7 + Co)
+    x = rng.standard_normal((Ci, 4, 10, 40)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+    xr, wr = _bf16_round(x), _bf16_round(w)
+    ops.set_conv_precision("bf16")
+    try:
+        for stride in (1, 2):
+            got = host(ops.conv3d_k3(dev(x), dev(w), relu=False, stride=stride))
+            want = oracle.conv3d_k3(xr, wr, stride=stride)
+            assert np.abs(got - want).max() <= 3e-5 * max(1.0, np.abs(want).max()), stride
+            exact = oracle.conv3d_k3(x, w, stride=stride)
+            assert np.abs(got - exact).max() > 1e-4  # it really is the reduced-precision path
+        wt = (0.2 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
+        got = host(ops.convtranspose3d_k3s2(dev(x), dev(wt), relu=False))
+        want = oracle.convtranspose3d_k3s2(xr, _bf16_round(wt))
+        assert np.abs(got - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
+        x2 = x[:, 0]
+        w2 = (0.2 * rng.standard_normal((Co, Ci, 3, 3))).astype(np.float32)
+        got = host(ops.conv2d_k3(dev(x2), dev(w2)))
+        want = oracle.conv2d_k3(xr[:, 0], _bf16_round(w2))
+        assert np.abs(got - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
+    finally:
+        ops.set_conv_precision(None)
+
+
+@pytest.mark.parametrize("tag", ["model_casmvsnet_v5", "model_adamvs_v5", "model_msrednet_v5"])
+def test_model_forward_bf16_regulariser_within_depth_budget(ops, tag):
+    """BASELINE config 3 (bf16 MFMA regularisation): depth stays within the north-star 1e-3 relative L1 of the
+    fp32 reference; confidences within 2e-2."""
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+    from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
+
+    g = load_golden(tag)
+    ctor = {"casmvsnet": Infer_CascadeMVSNet, "adamvs": Infer_AdaMVSNet, "msrednet": Infer_CascadeREDNet}[tag.split("_")[1]]
+    net = _fill(ctor(num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    ops.set_conv_precision("bf16")
+    try:
+        with torch.no_grad():
+            out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    finally:
+        ops.set_conv_precision(None)
+    assert rel_l1(host(out["depth"][0]), g["depth"]) <= 1e-3
+    assert rel_l1(host(out["photometric_confidence"][0]), g["photometric_confidence"]) <= 2e-2
+
+
 def test_conv_gemm_weight_cache_follows_updates(ops, oracle):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((4, 8, 20)).astype(np.float32)
