@@ -49,10 +49,14 @@ struct ConvMParams {
     int act, skip_after_act;
     int ntaps;
     int zmin, zspan, ymin, yspan, xmin, xspan;  // tap offset ranges: patch = span + (tile-1)*istride
+    int vec, sh, PX, CS;       // 16-byte staging (W % 4 == 0, aligned tensors), origin shift, LDS row length, channel stride
+    int mg_row, mg_c, mg_y;    // reciprocal multipliers of the staging index arithmetic
     signed char tz[MAX_TAPS], ty[MAX_TAPS], tx[MAX_TAPS];
 };
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 template <int MT, int CK>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMParams p) {
@@ -60,13 +64,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, j = lane & 15;
     constexpr int MP = 16 * MT;
+    constexpr int WS = (MP == 16) ? 16 : MP + 16;  // weight row stride: k-groups g, g+1 on disjoint bank halves
 
-    // patch geometry (per channel): PZ x PY x PX floats, channel stride CS = 16 (mod 32)
-    const int PZ = p.zspan, PY = p.yspan + (CV_ROWS - 1) * p.istride, PX = p.xspan + (CV_COLS - 1) * p.istride;
-    int CS = PZ * PY * PX;
-    CS += (16 - (CS & 31) + 32) & 31;
-    float* xin = lds;                 // [CK][CS]
-    float* wl = lds + CK * CS;        // [ntaps*CK][MP]
+    // patch geometry (per channel): PZ x PY x PX floats, channel stride CS = 16 (mod 32).  vec: rows are staged
+    // with 16-byte loads from an origin moved left by sh columns to a multiple of 4 (PX includes sh, rounded to 4)
+    const int PZ = p.zspan, PY = p.yspan + (CV_ROWS - 1) * p.istride, PX = p.PX, CS = p.CS;
+    float* xin = lds;                                      // [CK][CS]
+    float* wl = lds + CK * CS;                             // [ntaps*CK][WS]
+    int* tofft = reinterpret_cast<int*>(wl + p.ntaps * CK * WS);  // [ntaps]
 
     const int gx0 = blockIdx.x * CV_COLS;
     const int gy0 = blockIdx.y * CV_ROWS;
@@ -81,44 +86,93 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMParams p) {
         for (int n = 0; n < 4; ++n) acc[m][n] = (f4v){0, 0, 0, 0};
 
     // input coordinates of patch origin
-    const int iz0 = gz * p.istride + p.zmin, iy0 = gy0 * p.istride + p.ymin, ix0 = gx0 * p.istride + p.xmin;
+    const int iz0 = gz * p.istride + p.zmin, iy0 = gy0 * p.istride + p.ymin;
+    const int ix0 = gx0 * p.istride + p.xmin - p.sh;
     // this lane's B base: channel g, row `wave`, column j (per N tile: + 16*istride)
     const int bbase = g * CS + (wave * p.istride) * PX + j * p.istride;
+    if (tid < p.ntaps)
+        tofft[tid] = ((p.tz[tid] - p.zmin) * PY + (p.ty[tid] - p.ymin)) * PX + (p.tx[tid] - p.xmin) + p.sh;
+
+    // staging items: one per (patch row, x segment); vec: a 16-byte load of 4 columns, else one float
+    const int rows_per_c = PZ * PY;
+    const int nrows = CK * rows_per_c;
+    const int per_row = p.vec ? (PX >> 2) : PX;
+    const int nitems = nrows * per_row;
 
     for (int c0 = 0; c0 < Ci; c0 += CK) {
         __syncthreads();  // previous chunk fully consumed
-        // ---- stage the input patch of channels c0..c0+CK-1 (zeros outside the image / beyond Ci):
-        // a wave takes patch rows (channel, z, y) round-robin, lanes run along x (coalesced)
-        const int nrows = CK * PZ * PY;
-        for (int rr = wave; rr < nrows; rr += 4) {
-            const int c = rr / (PZ * PY), zy = rr - c * (PZ * PY);
-            const int z = zy / PY, y = zy - z * PY;
-            const int ci = c0 + c;
-            const int sy = iy0 + y, sz = iz0 + z;
-            const bool rowok = (ci < Ci) && (unsigned)sy < (unsigned)p.H && (unsigned)sz < (unsigned)p.D;
-            // rows beyond Ci are read from a valid dummy location (channel 0 of in0) and zeroed
-            const float* __restrict__ src = (ci < p.Ci0 || ci >= Ci) ? p.in0 + (long)(ci < p.Ci0 ? ci : 0) * in_vol
-                                                                       : p.in1 + (long)(ci - p.Ci0) * in_vol;
-            const float* __restrict__ row = src + (long)(rowok ? sz : 0) * in_plane + (long)(rowok ? sy : 0) * p.W;
-            float* dst = xin + c * CS + (z * PY + y) * PX;
-            for (int x = lane; x < PX; x += 64) {
-                const int sx = ix0 + x;
-                const bool ok = rowok && (unsigned)sx < (unsigned)p.W;
-                const float v = row[ok ? sx : 0];
-                dst[x] = ok ? v : 0.0f;
+        // ---- stage the input patch of channels c0..c0+CK-1: raw buffer loads, zeros (range check) outside the
+        // image / beyond Ci; eight loads in flight per thread.  A chunk never straddles the two inputs.
+        {
+            const float* cb = (c0 < p.Ci0) ? p.in0 + (long)c0 * in_vol : p.in1 + (long)(c0 - p.Ci0) * in_vol;
+            const long span = (long)(CK - 1) * in_vol + in_vol;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cb), 0, (int)(span * 4), 0x00020000);
+            const int cmax = Ci - c0;
+            for (int e0 = tid; e0 < nitems; e0 += 256 * 8) {
+                unsigned boff[8];
+                int dst[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * 256, nitems - 1);  // (tail slots repeat the last item)
+                    const int row = (int)(((long)e * p.mg_row) >> 24), q = e - row * per_row;
+                    const int c = (row * p.mg_c) >> 16, zy = row - c * rows_per_c;
+                    const int z = (zy * p.mg_y) >> 16, y = zy - z * PY;
+                    const int x = p.vec ? 4 * q : q;
+                    const int sx = ix0 + x, sy = iy0 + y, sz = iz0 + z;
+                    const bool ok = (c < cmax) & ((unsigned)sx < (unsigned)p.W) & ((unsigned)sy < (unsigned)p.H) &
+                                    ((unsigned)sz < (unsigned)p.D);
+                    boff[u] = ok ? (unsigned)(((long)c * in_vol + (long)sz * in_plane + (long)sy * p.W + sx) << 2)
+                                 : 0x80000000u;
+                    dst[u] = c * CS + zy * PX + x;
+                }
+                if (p.vec) {
+                    f4v v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const u4v qv = __builtin_amdgcn_raw_buffer_load_b128(rs, boff[u], 0, 0);
+                        v[u] = __builtin_bit_cast(f4v, qv);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) *reinterpret_cast<f4v*>(xin + dst[u]) = v[u];
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, boff[u], 0, 0));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xin[dst[u]] = v[u];
+                }
             }
         }
-        // ---- stage the packed weights of this chunk: rows k = t*Ci + ci, ci in [c0, c0+CK)
-        const int nvalid = min(CK, Ci - c0) * MP;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const float* __restrict__ wsrc = p.wpack + ((long)t * Ci + c0) * MP;
-            for (int e = tid; e < CK * MP; e += 256) wl[t * CK * MP + e] = (e < nvalid) ? wsrc[e] : 0.0f;
+        // ---- stage the packed weights of this chunk: rows k = t*Ci + ci, ci in [c0, c0+CK); 16-byte loads,
+        // four in flight per thread
+        {
+            constexpr int R4 = CK * MP / 4;  // float4s per tap
+            const int n4 = p.ntaps * R4;
+            const int nvalid4 = min(CK, Ci - c0) * (MP / 4);
+            for (int e0 = tid; e0 < n4; e0 += 256 * 4) {
+                float4 v[4];
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = min(e0 + u * 256, n4 - 1);
+                    const int t = e / R4, r = e - t * R4;
+                    const bool ok = r < nvalid4;
+                    v[u] = *(reinterpret_cast<const float4*>(p.wpack + ((long)t * Ci + c0) * MP) + (ok ? r : 0));
+                    if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int k = r / (MP / 4), q = r - k * (MP / 4);
+                    dst[u] = (t * CK + k) * WS + 4 * q;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(wl + dst[u]) = v[u];
+            }
         }
         __syncthreads();
 
         // ---- sweep the taps: K steps of 4 channels
+        int toff = tofft[0];
         for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = ((p.tz[t] - p.zmin) * PY + (p.ty[t] - p.ymin)) * PX + (p.tx[t] - p.xmin);
+            const int toff_next = tofft[min(t + 1, p.ntaps - 1)];
             const float* __restrict__ xb = xin + bbase + toff;
 #pragma unroll
             for (int kk = 0; kk < CK / 4; ++kk) {
@@ -127,13 +181,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMParams p) {
                 for (int n = 0; n < 4; ++n) b[n] = xb[kk * 4 * CS + n * 16 * p.istride];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    // A[i = lane&15][k = lane>>4] = wl[(t*CK + kk*4 + g) * MP + m*16 + (lane&15)]
-                    const float av = wl[(t * CK + kk * 4 + g) * MP + m * 16 + j];
+                    // A[i = lane&15][k = lane>>4] = wl[(t*CK + kk*4 + g) * WS + m*16 + (lane&15)]
+                    const float av = wl[(t * CK + kk * 4 + g) * WS + m * 16 + j];
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n], acc[m][n], 0, 0, 0);
                 }
             }
+            toff = toff_next;
         }
     }
 
@@ -166,17 +221,52 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMParams p) {
         }
 }
 
-static int lds_floats(const ConvMParams& p, int MT, int CK) {
-    const int PZ = p.zspan, PY = p.yspan + (CV_ROWS - 1) * p.istride, PX = p.xspan + (CV_COLS - 1) * p.istride;
-    int CS = PZ * PY * PX;
+static int patch_px(const ConvMParams& p) {
+    const int px = p.xspan + (CV_COLS - 1) * p.istride;
+    return p.vec ? ((px + p.sh + 3) & ~3) : px;
+}
+
+static int patch_cs(const ConvMParams& p) {
+    const int PZ = p.zspan, PY = p.yspan + (CV_ROWS - 1) * p.istride;
+    int CS = PZ * PY * patch_px(p);
     CS += (16 - (CS & 31) + 32) & 31;
-    return CK * CS + p.ntaps * CK * 16 * MT;
+    return CS;
+}
+
+static int lds_floats(const ConvMParams& p, int MT, int CK) {
+    const int MP = 16 * MT, WS = (MP == 16) ? 16 : MP + 16;
+    return CK * patch_cs(p) + p.ntaps * CK * WS + ((p.ntaps + 3) & ~3);
 }
 
 template <int MT, int CK>
-static int launch_cfg(const ConvMParams& p, hipStream_t stream) {
+static int launch_cfg(const ConvMParams& pin, hipStream_t stream) {
+    ConvMParams p = pin;
     const int bytes = lds_floats(p, MT, CK) * 4;
     if (bytes > 160 * 1024) return D3D_ERR_UNSUPPORTED;
+    const int Ci = p.Ci0 + p.Ci1;
+    if (p.Ci1 > 0 && p.Ci0 % CK != 0) {
+        set_error("conv_mfma: input split %d+%d is not aligned to the %d-channel chunk", p.Ci0, p.Ci1, CK);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    (void)Ci;
+    const int PZ = p.zspan, PY = p.yspan + (CV_ROWS - 1) * p.istride;
+    p.PX = patch_px(p);
+    p.CS = patch_cs(p);
+    const int per_row = p.vec ? p.PX / 4 : p.PX;
+    const long nitems = (long)CK * PZ * PY * per_row;
+    p.mg_row = (int)((1L << 24) / per_row + 1);
+    p.mg_c = 65536 / (PZ * PY) + 1;
+    p.mg_y = 65536 / PY + 1;
+    // exactness of the reciprocal arithmetic (e * mg >> 24 with e < nitems, row * mg >> 16 with row < CK*PZ*PY)
+    if (nitems >= (1L << 24) / (per_row + 1) || (long)CK * PZ * PY >= 65536 / (PZ * PY + 1) + 1) {
+        set_error("conv_mfma: patch too large for the staging index arithmetic");
+        return D3D_ERR_UNSUPPORTED;
+    }
+    const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
+    if ((long)CK * in_vol >= (1L << 29)) {
+        set_error("conv_mfma: %d-channel block exceeds 32-bit buffer offsets", CK);
+        return D3D_ERR_UNSUPPORTED;
+    }
     auto kern = conv_mfma_kernel<MT, CK>;
     static int attr_bytes = 0;
     if (bytes > attr_bytes) {
@@ -195,13 +285,16 @@ static int launch_cfg(const ConvMParams& p, hipStream_t stream) {
 
 template <int MT>
 static int launch_mt(const ConvMParams& p, hipStream_t stream) {
-    // largest channel chunk (no larger than the channel count needs) whose patch + weights leave room for
-    // two workgroups per CU: one stages while the other feeds the matrix cores
+    // largest channel chunk (no larger than the channel count needs, and dividing the first input when two are
+    // concatenated) whose patch + weights leave room for two workgroups per CU
     const int Ci = p.Ci0 + p.Ci1;
-    if (Ci > 8 && lds_floats(p, MT, 16) * 4 <= 80 * 1024) return launch_cfg<MT, 16>(p, stream);
-    if (Ci > 4 && lds_floats(p, MT, 8) * 4 <= 80 * 1024) return launch_cfg<MT, 8>(p, stream);
-    if (Ci > 8 && lds_floats(p, MT, 16) * 4 <= 150 * 1024 && lds_floats(p, MT, 4) * 4 > 80 * 1024) return launch_cfg<MT, 16>(p, stream);
-    if (Ci > 4 && lds_floats(p, MT, 8) * 4 <= 150 * 1024 && lds_floats(p, MT, 4) * 4 > 80 * 1024) return launch_cfg<MT, 8>(p, stream);
+    auto fits = [&](int ck) { return p.Ci1 == 0 || p.Ci0 % ck == 0; };
+    if (Ci > 8 && fits(16) && lds_floats(p, MT, 16) * 4 <= 80 * 1024) return launch_cfg<MT, 16>(p, stream);
+    if (Ci > 4 && fits(8) && lds_floats(p, MT, 8) * 4 <= 80 * 1024) return launch_cfg<MT, 8>(p, stream);
+    if (Ci > 8 && fits(16) && lds_floats(p, MT, 16) * 4 <= 150 * 1024 && lds_floats(p, MT, 4) * 4 > 80 * 1024)
+        return launch_cfg<MT, 16>(p, stream);
+    if (Ci > 4 && fits(8) && lds_floats(p, MT, 8) * 4 <= 150 * 1024 && lds_floats(p, MT, 4) * 4 > 80 * 1024)
+        return launch_cfg<MT, 8>(p, stream);
     return launch_cfg<MT, 4>(p, stream);
 }
 
@@ -255,6 +348,8 @@ int d3d_conv_gemm_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
         xlo = p.tx[t] < xlo ? p.tx[t] : xlo; xhi = p.tx[t] > xhi ? p.tx[t] : xhi;
     }
     p.zmin = zlo; p.zspan = zhi - zlo + 1; p.ymin = ylo; p.yspan = yhi - ylo + 1; p.xmin = xlo; p.xspan = xhi - xlo + 1;
+    p.vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1)) & 15) == 0;
+    p.sh = p.vec ? (p.xmin & 3) : 0;
     return launch_conv_mfma(p, (hipStream_t)stream);
 }
 

@@ -209,7 +209,9 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
     if tuple(weight.shape) != (Co, Ci, 3, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     if _use_mfma() and Co <= 64:
-        return conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)
+        y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)
+        if y is not None:
+            return y
     o = lambda n: (n - 1) // stride + 1
     out = torch.empty((Co, o(D), o(H), o(W)), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
@@ -228,7 +230,9 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     if _use_mfma() and Co <= 64:
-        return convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=1 if relu else 0)
+        y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=1 if relu else 0)
+        if y is not None:
+            return y
     out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
@@ -249,15 +253,18 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
     if _use_mfma() and Co <= 64:
-        return conv_k3_mfma(x, weight, scale, shift, skip, act=act, stride=stride, x2=x2)
-    if _use_mfma() and Co % 64 == 0:
+        y = conv_k3_mfma(x, weight, scale, shift, skip, act=act, stride=stride, x2=x2)
+        if y is not None:
+            return y
+    if _use_mfma() and Co > 64 and Co % 64 == 0:
         # wide layers (RED-Net's 128-channel gate convolution): 64 output channels per matrix-core launch
         parts = []
         for c0 in range(0, Co, 64):
             wsl = derived_weight(weight, "rows%d" % c0, lambda w, c0=c0: w[c0:c0 + 64])
             sl = lambda t: None if t is None else t[c0:c0 + 64].contiguous()
             parts.append(conv_k3_mfma(x, wsl, sl(scale), sl(shift), sl(skip), act=act, stride=stride, x2=x2))
-        return torch.cat(parts, 0)
+        if all(q is not None for q in parts):
+            return torch.cat(parts, 0)
     o = lambda n: (n - 1) // stride + 1
     out = torch.empty((Co, o(H), o(W)), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
@@ -276,7 +283,9 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     if _use_mfma() and Co <= 64:
-        return convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
+        y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
+        if y is not None:
+            return y
     out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape mismatch")
@@ -486,7 +495,10 @@ def _gemm(x, x2, wpack, taps, ntaps, Co, scale, shift, skip, skip_after_act, act
                                        _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
                                        int(skip_after_act), int(act), Co, D, H, W, Dg, Hg, Wg, Do, Ho, Wo, istride,
                                        ostride, ooff[0], ooff[1], ooff[2], ntaps, taps, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
     _lib.check(rc, "d3d_conv_gemm_f32")
+    return True
 
 
 def conv_k3_mfma(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None, skip_after_act=True):
@@ -504,7 +516,9 @@ def conv_k3_mfma(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, 
     out = torch.empty((Co,) + (od if three_d else od[1:]), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
-    _gemm(x, x2, wpack, taps, nt, Co, scale, shift, skip, skip_after_act, act, dims, od, out, stride, 1, (0, 0, 0))
+    if not _gemm(x, x2, wpack, taps, nt, Co, scale, shift, skip, skip_after_act, act, dims, od, out, stride, 1,
+                 (0, 0, 0)):
+        return None  # shape outside the matrix-core kernels: the caller takes the direct kernel
     return out
 
 
@@ -522,7 +536,8 @@ def convtranspose_k3s2_mfma(x, weight, scale=None, shift=None, skip=None, act=0,
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
     for (par, wpack, taps, nt) in _packed(weight, True):
-        _gemm(x, None, wpack, taps, nt, Co, scale, shift, skip, skip_after_act, act, dims, dims, out, 1, 2, par)
+        if not _gemm(x, None, wpack, taps, nt, Co, scale, shift, skip, skip_after_act, act, dims, dims, out, 1, 2, par):
+            return None
     return out
 
 
