@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, folded_bn,
+from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, feature_conv, folded_bn,
                      plane_depths)
 
 
@@ -48,7 +48,7 @@ class FeatureNet(nn.Module):
     def _context(feat, br_a, br_b, head):
         size = feat.shape[2:]
         up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=False)
-        return head(torch.cat((up(br_a(feat)), up(br_b(feat)), feat), 1))
+        return feature_conv(head, torch.cat((up(br_a(feat)), up(br_b(feat)), feat), 1))
 
     def forward(self, x):
         c0 = self.conv0(x)

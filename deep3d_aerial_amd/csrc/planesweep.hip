@@ -229,9 +229,6 @@ static int check_dims(int C, int D, int h, int w) {
 static int sweep_dispatch(int mode, const SweepParams& p, hipStream_t stream) {
     const char* force = getenv("D3D_FORCE_PATH");  // "direct" | "tiled" (testing / profiling only)
     bool want_direct = force && !strcmp(force, "direct");
-    // A handful of planes cannot amortise the ring kernel's per-workgroup planning prologue (stage 3 of the
-    // cascade, 8 planes x 8 channels at 2752x1856: 2.4 ms tiled, 1.8 ms direct).
-    if (!force && p.D <= 8) want_direct = true;
     if (!want_direct) {
         int rc = launch_tiled(mode, p, stream);
         if (rc != D3D_ERR_UNSUPPORTED) return rc;

@@ -202,6 +202,46 @@ class ConvGRUCell2(nn.Module):
 # Image feature pyramids -- PyTorch-ROCm/MIOpen, checkpoint-compatible
 # with module.py:157-245,495-513,653-755.
 # ----------------------------------------------------------------------------------------
+def feature_conv(conv, x, bn=None, relu=False, skip=None, x2=None):
+    """nn.Conv2d `conv` (+ eval-mode BatchNorm `bn`, + ReLU, + `skip` added last) on a batch [B,C,H,W]; `x2`
+    [B,C2,H,W] is a second input concatenated after x along the channels without materialising the concat.  Odd square kernels with
+    padding K // 2 and stride 1 | 2 (the 3x3, 5x5 stride-2 and 1x1 layers of the feature pyramids) run on the
+    matrix-core convolution in exact fp32; anything else, or D3D_FEATURE_CONV=miopen, goes to MIOpen."""
+    K = conv.kernel_size[0]
+    if (conv.kernel_size == (K, K) and K % 2 == 1 and conv.padding == (K // 2, K // 2) and conv.stride in ((1, 1), (2, 2))
+            and conv.dilation == (1, 1) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
+            and conv.out_channels <= 64 and (bn is None or not bn.training)
+            and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+        if bn is not None:
+            s, t = folded_bn(bn)
+        else:
+            s, t = None, conv.bias
+        with ops.fp32_convs():  # the bf16 mode (BASELINE config 3) is for the cost regularisers only
+            outs = []
+            for b in range(x.shape[0]):
+                xb = x[b].contiguous()
+                sk = None if skip is None else skip[b].contiguous()
+                if K == 3:
+                    y = ops.conv2d_k3(xb, conv.weight, s, t, sk, act=1 if relu else 0, stride=conv.stride[0],
+                                      x2=None if x2 is None else x2[b].contiguous())
+                elif x2 is None:
+                    y = ops.conv2d_same(xb, conv.weight, s, t, sk, act=1 if relu else 0, stride=conv.stride[0])
+                else:
+                    y = None
+                if y is None:
+                    break
+                outs.append(y)
+            else:
+                return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+    if x2 is not None:
+        x = torch.cat((x, x2), dim=1)
+    y = conv(x)
+    if bn is not None:
+        y = bn(y)
+    y = F.relu(y, inplace=True) if relu else y
+    return y if skip is None else y + skip
+
+
 class Conv2d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
                  **kwargs):
@@ -210,25 +250,8 @@ class Conv2d(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum) if bn else None
         self.relu = relu
 
-    def forward(self, x):
-        c = self.conv
-        # 3x3 / pad 1 layers of the feature pyramid run on the matrix-core convolution too (eval-mode BN and
-        # ReLU in its epilogue); the 5x5 stride-2 and 1x1 layers stay on MIOpen.  D3D_FEATURE_CONV=miopen
-        # sends everything to MIOpen.
-        if (c.kernel_size == (3, 3) and c.padding == (1, 1) and c.stride in ((1, 1), (2, 2)) and c.dilation == (1, 1)
-                and c.groups == 1 and not self.training and x.is_cuda and x.dtype == torch.float32
-                and c.out_channels <= 64 and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
-            if self.bn is not None:
-                s, t = folded_bn(self.bn)
-            else:
-                s, t = None, c.bias
-            with ops.fp32_convs():  # the bf16 mode (BASELINE config 3) is for the cost regularisers only
-                return torch.stack([ops.conv2d_k3(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0,
-                                                  stride=c.stride[0]) for b in range(x.shape[0])])
-        x = self.conv(x)
-        if self.bn is not None:
-            x = self.bn(x)
-        return F.relu(x, inplace=True) if self.relu else x
+    def forward(self, x, x2=None):
+        return feature_conv(self.conv, x, self.bn, self.relu, x2=x2)
 
 
 class Deconv2d(nn.Module):
@@ -243,6 +266,15 @@ class Deconv2d(nn.Module):
         self.relu = relu
 
     def forward(self, x):
+        c = self.conv
+        if (self.stride == 2 and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.output_padding == (1, 1)
+                and c.out_channels <= 64 and x.is_cuda and (self.bn is None or not self.bn.training)
+                and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+            s, t = folded_bn(self.bn) if self.bn is not None else (None, c.bias)
+            with ops.fp32_convs():
+                outs = [ops.convtranspose2d_k3s2(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0)
+                        for b in range(x.shape[0])]
+            return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
         y = self.conv(x)
         if self.stride == 2:
             y = y[:, :, :2 * x.shape[2], :2 * x.shape[3]].contiguous()
@@ -260,7 +292,7 @@ class DeConv2dFuse(nn.Module):
                            bn_momentum=bn_momentum)
 
     def forward(self, x_pre, x):
-        return self.conv(torch.cat((self.deconv(x), x_pre), dim=1))
+        return self.conv(self.deconv(x), x2=x_pre)  # conv over cat((deconv(x), x_pre), 1) without the concat
 
 
 def _trunk(base):
@@ -299,15 +331,15 @@ class FeatureNet_mvsnet(nn.Module):
         c0 = self.conv0(x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
-        out = {"stage1": self.out1(c2)}
+        out = {"stage1": feature_conv(self.out1, c2)}
         if self.arch_mode == "unet":
             f = self.deconv1(c1, c2)
-            out["stage2"] = self.out2(f)
+            out["stage2"] = feature_conv(self.out2, f)
             f = self.deconv2(c0, f)
-            out["stage3"] = self.out3(f)
+            out["stage3"] = feature_conv(self.out3, f)
         else:
-            f = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
-            out["stage2"] = self.out2(f)
-            f = F.interpolate(f, scale_factor=2, mode="nearest") + self.inner2(c0)
-            out["stage3"] = self.out3(f)
+            f = feature_conv(self.inner1, c1, skip=F.interpolate(c2, scale_factor=2, mode="nearest"))
+            out["stage2"] = feature_conv(self.out2, f)
+            f = feature_conv(self.inner2, c0, skip=F.interpolate(f, scale_factor=2, mode="nearest"))
+            out["stage3"] = feature_conv(self.out3, f)
         return out

@@ -545,19 +545,21 @@ def convtranspose_k3s2_mfma(x, weight, scale=None, shift=None, skip=None, act=0,
 # z-streaming folded implicit GEMM (d3d_conv_fold_f32): tap lists / packed weights per layer
 # ----------------------------------------------------------------------------------------
 def _dim_conv(K, stride, fold):
-    """One dimension of an ordinary k=3 (or k=1) convolution folded over `fold` neighbouring outputs:
-    (tap offsets, fold positions, k(tap, fold) -> kernel index or -1, input step, output step, base)."""
-    if K == 1:
+    """One dimension of an ordinary convolution (odd kernel size K, padding K // 2) folded over `fold`
+    neighbouring outputs: (tap offsets, fold positions, k(tap, fold) -> kernel index or -1, input step, output
+    step, base).  K = 0 marks the degenerate row dimension of an image (a single tap, a single position)."""
+    if K == 0:
         return [0], [0], (lambda t, f: 0), 1, 1, 0
-    taps = list(range(-1, (fold - 1) * stride + 2))
-    k = lambda t, f: (t - f * stride + 1) if 0 <= t - f * stride + 1 <= 2 else -1
+    pad = K // 2
+    taps = list(range(-pad, (fold - 1) * stride + pad + 1))
+    k = lambda t, f: (t - f * stride + pad) if 0 <= t - f * stride + pad < K else -1
     return taps, list(range(fold)), k, fold * stride, fold, 0
 
 
 def _dim_convT(K, parities):
     """One dimension of a k=3 stride-2 pad-1 output_pad-1 transposed convolution: output 2g+p reads input
     g+o with kernel index k(o,p): p even -> (o=0: 1); p odd -> (o=0: 2, o=1: 0)."""
-    if K == 1:
+    if K == 0:
         return [0], [0], (lambda t, f: 0), 1, 1, 0
     table = {(0, 0): 1, (0, 1): 2, (1, 1): 0}
     k = lambda o, f: table.get((o, parities[f]), -1)
@@ -600,14 +602,14 @@ def _fold_pack(wk, dims, Co, ksizes):
     return wpack.contiguous(), _np.array(taps, _np.int8).tobytes(), T, M, mpad, tail
 
 
-def _conv_fold_choice(Co, Ci, three_d, stride):
+def _conv_fold_choice(Co, Ci, three_d, stride, K=3):
     """Fold (f_y, f_x) that fills the 16 GEMM rows of a narrow layer.  Limits: the kernel's 128 taps, and resident
     weights (ntaps * Ci * 16 floats) small enough that two workgroups still share a CU's LDS -- a wide-C_in layer
     is faster unfolded at twice the occupancy (stage-1 conv0 32->8: 9.4 ms folded, 5.3 ms unfolded)."""
     if _os.environ.get("D3D_CONV_NOFOLD"):
         return (1, 1)
     budget = int(_os.environ.get("D3D_CONV_FOLD_KB", "48")) * 1024
-    ntaps = lambda f: (3 if three_d else 1) * ((f[0] - 1) * stride + 3) * ((f[1] - 1) * stride + 3)
+    ntaps = lambda f: (K if three_d else 1) * ((f[0] - 1) * stride + K) * ((f[1] - 1) * stride + K)
     for f in [(4, 4), (2, 4), (2, 2), (1, 2)]:
         # (the kernel's column step f_x * stride must be 1, 2 or 4)
         if Co * f[0] * f[1] <= 16 and f[1] * stride <= 4 and ntaps(f) <= 128 and ntaps(f) * Ci * 64 <= budget:
@@ -632,18 +634,22 @@ def _packed_fold(weight, transposed, stride):
             w = w.transpose(0, 1)
         Co, Ci = w.shape[0], w.shape[1]
         wk = w.reshape(Co, Ci, -1).contiguous()
-        ks = (3, 3, 3) if three_d else (3, 1, 3)
+        K = w.shape[-1]  # cubic / square kernels, odd size, padding K // 2 (1, 3 and 5 occur in the reference)
+        if K % 2 == 0 or any(d != K for d in w.shape[2:]) or (transposed and K != 3):
+            raise ValueError("unsupported kernel shape %s" % (tuple(w.shape[2:]),))
+        ks = (K, K, K) if three_d else (K, 1, K)
         launches = []
         if not transposed:
-            fy, fx = _conv_fold_choice(Co, Ci, three_d, stride)
+            fy, fx = _conv_fold_choice(Co, Ci, three_d, stride, K)
             if three_d:
-                dims = (_dim_conv(3, stride, 1), _dim_conv(3, stride, fy), _dim_conv(3, stride, fx))
+                dims = (_dim_conv(K, stride, 1), _dim_conv(K, stride, fy), _dim_conv(K, stride, fx))
             else:
-                dims = (_dim_conv(3, stride, fy), _dim_conv(1, stride, 1), _dim_conv(3, stride, fx))
+                dims = (_dim_conv(K, stride, fy), _dim_conv(0, 1, 1), _dim_conv(K, stride, fx))
             launches.append(_fold_pack(wk, dims, Co, ks))
         else:
             # all output parities as GEMM rows while they fit 64 rows; otherwise one launch per parity of the
             # leading dimensions
+            ks0 = [k if k == 3 else 0 for k in ks]
             sets = [[[0, 1]] if k == 3 else [None] for k in ks]
             rows = lambda: Co * int(_np.prod([len(ss[0]) if ss[0] else 1 for ss in sets]))
             for d in range(3):
@@ -652,7 +658,7 @@ def _packed_fold(weight, transposed, stride):
             for p0 in sets[0]:
                 for p1 in sets[1]:
                     for p2 in sets[2]:
-                        dims = tuple(_dim_convT(ks[d], pp) for d, pp in enumerate((p0, p1, p2)))
+                        dims = tuple(_dim_convT(ks0[d], pp) for d, pp in enumerate((p0, p1, p2)))
                         launches.append(_fold_pack(wk, dims, Co, ks))
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
@@ -698,3 +704,13 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
             return None
         _lib.check(rc, "d3d_conv_fold")
     return out
+
+
+def conv2d_same(x, weight, scale=None, shift=None, skip=None, act=0, stride=1):
+    """Conv2d with an odd square kernel (1, 3, 5, ...) and padding K // 2, stride 1 | 2, on the matrix-core stream
+    kernel (feature pyramids: module.py:657-679 5x5 stride-2 and 1x1 layers).  Returns None when the layer does
+    not fit that kernel (the caller then uses MIOpen)."""
+    Co, Ci = weight.shape[0], weight.shape[1]
+    if x.shape[0] != Ci or Co > 64 or not _use_mfma():
+        return None
+    return conv_fold(x, weight, scale, shift, skip, act, stride, None, True, transposed=False)
