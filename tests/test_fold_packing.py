@@ -82,3 +82,18 @@ def test_convtranspose_fold_packing(oracle, Co):
     got = emulate(x[:, 0][:, :, None, :], ops._packed_fold(torch.from_numpy(wt2), True, 2),
                   (want.shape[1], 1, want.shape[2]), True)
     assert np.abs(got[:, :, 0] - want).max() <= 1e-5
+
+
+@pytest.mark.parametrize("Ci,Co,K,stride", [(3, 8, 3, 1), (8, 16, 5, 2), (16, 32, 5, 2), (32, 32, 1, 1), (8, 1, 1, 1)])
+def test_odd_kernel_packing_matches_torch_conv2d(Ci, Co, K, stride):
+    """1x1 and 5x5 stride-2 layers of the feature pyramids (module.py:657-679) through the same packer; the
+    checker is torch's CPU convolution (the oracle only restates the 3x3 family)."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(Ci + Co + K)
+    x = rng.standard_normal((Ci, 9, 14)).astype(np.float32)
+    w = (0.3 * rng.standard_normal((Co, Ci, K, K))).astype(np.float32)
+    want = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), stride=stride, padding=K // 2)[0].numpy()
+    got = emulate(x[:, :, None, :], ops._packed_fold(torch.from_numpy(w), False, stride),
+                  (want.shape[1], 1, want.shape[2]), False)
+    assert np.abs(got[:, :, 0] - want).max() <= 3e-5

@@ -437,6 +437,38 @@ def test_model_forward_bf16_regulariser_within_depth_budget(ops, tag):
     assert rel_l1(host(out["photometric_confidence"][0]), g["photometric_confidence"]) <= 2e-2
 
 
+@pytest.mark.parametrize("Ci,Co,K,stride", [(3, 8, 3, 1), (8, 16, 5, 2), (16, 32, 5, 2), (32, 32, 1, 1), (16, 8, 1, 1)])
+def test_feature_pyramid_convs_vs_torch(ops, Ci, Co, K, stride):
+    """module.feature_conv (1x1 / 3x3 / 5x5 stride-2 layers with folded BatchNorm, ReLU, fused add, two-input
+    concat) against torch's own convolution of the same parameters."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from deep3d_aerial_amd.module import feature_conv
+
+    torch.manual_seed(Ci * 100 + Co + K)
+    conv = nn.Conv2d(Ci, Co, K, stride=stride, padding=K // 2, bias=False).cuda()
+    bn = nn.BatchNorm2d(Co).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.1)
+    x = torch.randn(2, Ci, 20, 36, device="cuda")
+    with torch.no_grad():
+        want = F.relu(bn(conv(x)))
+        got = feature_conv(conv, x, bn, True)
+        assert (got - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+        skip = torch.randn_like(want)
+        got = feature_conv(conv, x, None, False, skip=skip)
+        assert (got - (conv(x) + skip)).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+        if K == 3:
+            a, b = x[:, : Ci // 2 or 1], x[:, Ci // 2 or 1:]
+            if a.shape[1] % 4 == 0 and b.shape[1] > 0:
+                got = feature_conv(conv, a.contiguous(), None, False, x2=b.contiguous())
+                assert (got - conv(x)).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_conv_gemm_weight_cache_follows_updates(ops, oracle):
     rng = np.random.default_rng(5)
     x = rng.standard_normal((4, 8, 20)).astype(np.float32)
