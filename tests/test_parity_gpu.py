@@ -593,6 +593,31 @@ def test_model_forward_matches_reference(ops, tag):
         assert rel_l1(host(vw), g["stage1_view_weights"]) <= REL_MODEL
 
 
+@pytest.mark.parametrize("model", ["casmvsnet", "adamvs"])
+def test_full_size_cascade_mfma_equals_direct_kernels(ops, model, monkeypatch):
+    """BASELINE image size (2752x1856, 5 views): the matrix-core convolution path (z-streaming, folds, z segments,
+    32-bit offset limits, 16-byte staging) against the independent direct VALU kernels on the same weights."""
+    from deep3d_aerial_amd import predict
+
+    net = _fill(predict.build_model(model, 384), 21)
+    s = predict.SyntheticBlock(1, 5, 2752, 1856, 384, seed=9)[0]
+    imgs = dev(s["imgs"])[None]
+    pm = {k: dev(v)[None] for k, v in s["proj_matrices"].items()}
+    dv = dev(s["depth_values"])[None]
+    outs = {}
+    for path in ("mfma", "direct"):
+        monkeypatch.setenv("D3D_CONV", path)
+        monkeypatch.setenv("D3D_FEATURE_CONV", "mfma" if path == "mfma" else "miopen")
+        with torch.no_grad():
+            o = net(imgs, pm, dv)
+        outs[path] = (host(o["depth"][0]), host(o["photometric_confidence"][0]))
+        del o
+        torch.cuda.empty_cache()
+    assert np.isfinite(outs["mfma"][0]).all()
+    assert rel_l1(outs["mfma"][0], outs["direct"][0]) <= 1e-4
+    assert rel_l1(outs["mfma"][1], outs["direct"][1]) <= 1e-3
+
+
 def test_predict_views_writes_reference_products(ops, tmp_path):
     """predict.py boundary: per view {name}_init.pfm, {name}_prob.pfm, {name}.txt; sharding by rank."""
     from deep3d_aerial_amd import predict
