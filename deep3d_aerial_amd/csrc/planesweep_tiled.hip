@@ -132,6 +132,10 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 #ifndef D3D_DECOUPLE
 #define D3D_DECOUPLE 0
 #endif
+#ifndef STAGE0_ALL
+#define STAGE0_ALL 0  // experiment: compute waves help to stage the initial window -- measured neutral (239k cycles per workgroup either way)
+#endif
+#define STAGE0_ALL_EFF (STAGE0_ALL && !D3D_DECOUPLE)
 __device__ __forceinline__ void step_signal(int* ctr, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -613,7 +617,10 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     // Loader waves: bring window(k) minus window(k-1) into the rings.
     const bool ltiming = a.tstats != nullptr && lw == 0;
     long long lt_desc = 0, lt_issue = 0, lt_write = 0, lt_bar = 0;
-    auto stage = [&](int k) {
+    // (sw, snw): this wave's index among the snw waves sharing the step's items -- the loaders for the deltas;
+    // ALL waves for the initial window, which nothing can overlap (one workgroup per CU): the compute waves
+    // would only wait for it.
+    auto stage = [&](int k, int sw, int snw) {
         const int rb = rfl(ldsi[L::SST + k]), re = rfl(ldsi[L::SST + k + 1]);
         const int T = rfl(ldsi[L::STOT + k]);
         const int nitems = (T + 63) >> 6;
@@ -622,12 +629,12 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         int pst16[16];
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) pst16[rr] = __builtin_amdgcn_readlane(psv, rr);
-        for (int it0 = lw; it0 < nitems; it0 += NLOADW * PFD) {
+        for (int it0 = sw; it0 < nitems; it0 += snw * PFD) {
             long long tq1 = 0, tq2 = 0;
             if (ltiming) tq1 = clock64();
 #pragma unroll
             for (int j = 0; j < PFD; ++j) {
-                const int it = it0 + NLOADW * j;
+                const int it = it0 + snw * j;
                 Item I = item(it < nitems ? it * 64 + lane : T, T, rb, pst16);
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         // (Raising the loaders' issue priority with s_setprio was measured: their decode time halves,
         // but the compute waves lose the same slots and the kernel gets 5 % slower -- left at default.)
         if (ring) {
-            stage(0);
+            stage(0, STAGE0_ALL_EFF ? wave : lw, STAGE0_ALL_EFF ? NCOMP + NLOADW : NLOADW);
 #if D3D_DECOUPLE
             step_signal(ldsi + L::CNT + 0, lane);
             for (int k = 0; k + 1 < nsteps; ++k) {
@@ -660,7 +667,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 if (ltiming) tb = clock64();
                 if (k > 0) step_wait(ldsi + L::CNT + MAXSTEPS + (k - 1), NCOMP);  // every compute wave has left step k-1
                 if (ltiming) lt_bar += clock64() - tb;
-                stage(k + 1);
+                stage(k + 1, lw, NLOADW);
                 step_signal(ldsi + L::CNT + (k + 1), lane);
             }
 #else
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 if (ltiming) tb = clock64();
                 __syncthreads();
                 if (ltiming) lt_bar += clock64() - tb;
-                if (k + 1 < nsteps) stage(k + 1);
+                if (k + 1 < nsteps) stage(k + 1, lw, NLOADW);
             }
 #endif
         }
@@ -753,6 +760,9 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     };
 
     // ================================ main loop over steps ======================================
+#if STAGE0_ALL_EFF
+    if (ring) stage(0, wave, NCOMP + NLOADW);  // initial window: every wave of the workgroup stages
+#endif
     const bool timing = a.tstats != nullptr && wave == 0;
     long long t_w = 0, t_c = 0, t_mark = 0;
     if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
