@@ -936,10 +936,11 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
-static int group_channels(int C) {
-    // channels per workgroup pass; D3D_TILED_CG overrides for experiments (must divide C)
+static int group_channels(int C, int n_src) {
+    // channels per workgroup pass; D3D_TILED_CG overrides for experiments (must divide C).  Six rings only fit
+    // LDS with 8-channel positions (config 5, 7 views x 512 planes: 76 ms with 8, 134 ms with 16 channels).
     const char* e = getenv("D3D_TILED_CG");
-    int cg = e ? atoi(e) : (C >= 16 ? 16 : C);
+    int cg = e ? atoi(e) : (n_src > 4 ? 8 : (C >= 16 ? 16 : C));
     if (cg != 8 && cg != 16 && cg != 32) cg = 8;
     while (C % cg) cg >>= 1;
     return cg;
@@ -947,7 +948,7 @@ static int group_channels(int C) {
 
 template <int MODE, int NSRC>
 static int launch_ch(const SweepParams& p, hipStream_t stream) {
-    const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C);
+    const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src);
     switch (cg) {
         case 32: return launch_one<MODE, NSRC, 32>(p, stream);
         case 16: return launch_one<MODE, NSRC, 16>(p, stream);
@@ -961,14 +962,16 @@ int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
         set_error("tiled kernel unsupported: C=%d", p.C);
         return D3D_ERR_UNSUPPORTED;
     }
-    if (p.n_src > 4) {
-        set_error("tiled kernel unsupported: %d source views (max 4)", p.n_src);
+    if (p.n_src > 6) {
+        set_error("tiled kernel unsupported: %d source views (max 6)", p.n_src);
         return D3D_ERR_UNSUPPORTED;
     }
     switch (mode) {
         case MODE_VARIANCE:
+            if (p.n_src > 4) return launch_ch<MODE_VARIANCE, 6>(p, stream);  // BASELINE config 5: 7 views
             return p.n_src <= 2 ? launch_ch<MODE_VARIANCE, 2>(p, stream) : launch_ch<MODE_VARIANCE, 4>(p, stream);
         case MODE_WEIGHTED:
+            if (p.n_src > 4) return launch_ch<MODE_WEIGHTED, 6>(p, stream);
             return p.n_src <= 2 ? launch_ch<MODE_WEIGHTED, 2>(p, stream) : launch_ch<MODE_WEIGHTED, 4>(p, stream);
         case MODE_PAIR: return launch_ch<MODE_PAIR, 1>(p, stream);
         case MODE_WARP: return launch_ch<MODE_WARP, 1>(p, stream);
