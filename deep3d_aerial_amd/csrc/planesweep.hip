@@ -8,6 +8,8 @@
 //     any C, any V.  It is the general path and the reference point for the tiled one.
 //   * sweep_tiled_kernel   -- (planesweep_tiled.hip) LDS-staged source footprints for
 //     the HBM-write-bound cost-volume shapes.
+#include <hip/hip_fp16.h>
+
 #include "common.h"
 
 #include <cstring>
@@ -121,17 +123,26 @@ __device__ __forceinline__ TapD make_tap_direct(float u, float v, int h, int w) 
     return t;
 }
 
-__device__ __forceinline__ float gather4(const float* __restrict__ f, const TapD& t) {
-    const float* q = f + t.off;
+// element access of the two storage types: fp32, or fp16 storage with fp32 arithmetic (BASELINE config 5)
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(__half* p, float v) { *p = __float2half_rn(v); }
+
+template <typename T>
+__device__ __forceinline__ float gather4(const T* __restrict__ f, const TapD& t) {
+    const T* q = f + t.off;
     // same summation order as grid_sample: nw, ne, sw, se
-    float acc = q[0] * t.nw;
-    acc = fmaf(q[t.dx], t.ne, acc);
-    acc = fmaf(q[t.dyw], t.sw, acc);
-    acc = fmaf(q[t.dyw + t.dx], t.se, acc);
+    float acc = ldf(q) * t.nw;
+    acc = fmaf(ldf(q + t.dx), t.ne, acc);
+    acc = fmaf(ldf(q + t.dyw), t.sw, acc);
+    acc = fmaf(ldf(q + t.dyw + t.dx), t.se, acc);
     return acc;
 }
 
-template <int MODE, int CC>
+// T = float: tensors as declared in SweepParams.  T = __half: feats[] and out point to fp16 tensors of the same
+// shapes (depth, weights and projections stay fp32); every product and sum is fp32, the result is rounded once.
+template <int MODE, int CC, typename T = float>
 __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
             float s[CC], q[CC], r[CC];
 #pragma unroll
             for (int c = 0; c < CC; ++c) {
-                r[c] = (MODE == MODE_WARP) ? 0.0f : p.feats[0][(size_t)(c0 + c) * plane + pix];
+                r[c] = (MODE == MODE_WARP) ? 0.0f : ldf(reinterpret_cast<const T*>(p.feats[0]) + (size_t)(c0 + c) * plane + pix);
                 s[c] = (MODE == MODE_VARIANCE) ? r[c] : 0.0f;
                 q[c] = r[c] * r[c];
             }
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
                 float u, v;
                 project(ray, P[3], P[7], P[11], dv, h, w, u, v);
                 TapD t = make_tap_direct(u, v, h, w);
-                const float* __restrict__ f = p.feats[i + 1] + (size_t)c0 * plane;
+                const T* __restrict__ f = reinterpret_cast<const T*>(p.feats[i + 1]) + (size_t)c0 * plane;
                 float vw = (MODE == MODE_WEIGHTED) ? p.weights[(size_t)i * plane + pix] : 0.0f;
 #pragma unroll
                 for (int c = 0; c < CC; ++c) {
@@ -193,28 +204,28 @@ __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
                     } else {
                         o = s[c];
                     }
-                    p.out[((size_t)(c0 + c) * D + d) * plane + pix] = o;
+                    stf(reinterpret_cast<T*>(p.out) + ((size_t)(c0 + c) * D + d) * plane + pix, o);
                 }
             }
         }
-        if (MODE == MODE_PAIR) p.out[(size_t)d * plane + pix] = pair_acc / (float)C;
+        if (MODE == MODE_PAIR) stf(reinterpret_cast<T*>(p.out) + (size_t)d * plane + pix, pair_acc / (float)C);
     }
 }
 
-template <int MODE>
+template <int MODE, typename T = float>
 static int launch_direct(const SweepParams& p, hipStream_t stream) {
     SweepParams q = p;
     q.d_chunk = 8;
     dim3 grid(ceil_div(p.w, 64), ceil_div(p.h, 4), ceil_div(p.D, q.d_chunk));
     dim3 block(256);
     if (p.C % 16 == 0)
-        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 16>), grid, block, 0, stream, q);
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 16, T>), grid, block, 0, stream, q);
     else if (p.C % 8 == 0)
-        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 8>), grid, block, 0, stream, q);
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 8, T>), grid, block, 0, stream, q);
     else if (p.C % 4 == 0)
-        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 4>), grid, block, 0, stream, q);
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 4, T>), grid, block, 0, stream, q);
     else
-        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 1>), grid, block, 0, stream, q);
+        hipLaunchKernelGGL((sweep_direct_kernel<MODE, 1, T>), grid, block, 0, stream, q);
     D3D_LAUNCH_CHECK("sweep_direct_kernel launch");
     return D3D_OK;
 }
@@ -306,6 +317,16 @@ int d3d_variance_volume(const float* const* feats, const float* proj34, const fl
     int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out);
     if (rc) return rc;
     return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
+}
+
+int d3d_variance_volume_f16(const void* const* feats, const float* proj34, const float* depth, int depth_mode,
+                            int n_views, int C, int D, int h, int w, void* out, d3d_stream_t stream) {
+    SweepParams p = {};
+    // same argument checks; the pointers are carried in the fp32-typed slots and reinterpreted by the kernel
+    int rc = fill_multi(p, reinterpret_cast<const float* const*>(feats), proj34, depth, depth_mode, n_views, C, D, h, w,
+                        reinterpret_cast<float*>(out));
+    if (rc) return rc;
+    return launch_direct<MODE_VARIANCE, __half>(p, (hipStream_t)stream);
 }
 
 int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,

@@ -88,9 +88,25 @@ def _check_feats(feats, proj34):
     return shape
 
 
+def _chk16(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous CUDA float16 tensor" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def variance_volume(feats, proj34, depth, out=None):
-    """feats: list of V tensors [C,h,w] (feats[0] = reference); -> [C,D,h,w] (cas_mvsnet.py:45-60)."""
+    """feats: list of V tensors [C,h,w] (feats[0] = reference); -> [C,D,h,w] (cas_mvsnet.py:45-60).
+    float16 feature maps give a float16 volume (fp32 arithmetic, BASELINE config 5)."""
     C, h, w = _check_feats(feats, proj34)
+    if feats[0].dtype == torch.float16:
+        dp, mode, D = _depth(depth, h, w)
+        if out is None:
+            out = torch.empty((C, D, h, w), dtype=torch.float16, device=feats[0].device)
+        arr = (ctypes.c_void_p * len(feats))(*[_chk16(f, "feats[%d]" % i).value for i, f in enumerate(feats)])
+        rc = _lib.load().d3d_variance_volume_f16(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
+                                                 _chk16(out, "out"), _stream())
+        _lib.check(rc, "d3d_variance_volume_f16")
+        return out
     dp, mode, D = _depth(depth, h, w)
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=feats[0].device)

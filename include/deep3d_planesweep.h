@@ -83,6 +83,12 @@ int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int
 int d3d_variance_volume(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                         int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream);
 
+/* The same volume with fp16 STORAGE (BASELINE config 5): feats[i] and out are IEEE half tensors of the shapes
+ * above; projections, depth and every product / sum stay fp32, the result is rounded once (RNE).  Served by the
+ * direct-gather kernel this round (the ring kernel is fp32-only). */
+int d3d_variance_volume_f16(const void* const* feats, const float* proj34, const float* depth, int depth_mode,
+                            int n_views, int C, int D, int h, int w, void* out, d3d_stream_t stream);
+
 /*
  * adamvs.py:469-474 -- per-pair channel-mean correlation for the visibility net:
  *     out[d] = mean_c( ref[c] * warp_d(src)[c] )          ref, src [C,h,w] -> out [D,h,w]

@@ -188,6 +188,24 @@ def test_aggregation_vs_oracle(ops, oracle, path, case):
     assert np.abs(wp - want).max() <= ABS_GATHER
 
 
+def test_variance_volume_fp16_storage_7_views(ops, oracle):
+    """BASELINE config 5's storage type and view count (7 views, fp16 features and cost volume, fp32 arithmetic):
+    equals the fp32 oracle on the same fp16-valued inputs, rounded once to fp16."""
+    V, C, h, w, D = 7, 32, 48, 80, 12
+    proj, dv = S.make_scene(V, h, w, D, sweep_px=6.0, seed=77, yaw_deg=4.0)
+    feats = [f.astype(np.float16) for f in S.make_features(V, C, h, w, seed=7)]
+    depth = S.uniform_depths(dv, D)
+    p34 = ops.compose_projections(dev(proj))
+    got = ops.variance_volume([torch.from_numpy(f).cuda() for f in feats], p34, dev(depth))
+    assert got.dtype == torch.float16 and tuple(got.shape) == (C, D, h, w)
+    f32 = [f.astype(np.float32) for f in feats]
+    want = oracle.variance_volume(f32[0], f32[1:], host(p34).reshape(-1, 3, 4), depth)
+    g = got.float().cpu().numpy()
+    # one fp16 rounding of a value that the fp32 kernel reproduces to ~1e-6: half an ulp of fp16 plus slack
+    assert np.abs(g - want).max() <= 2.0 ** -10 * np.abs(want).max() + 1e-6
+    assert np.abs(g - want.astype(np.float16).astype(np.float32)).mean() <= 1e-4 * np.abs(want).mean()
+
+
 def test_variance_of_identical_views_is_zero(ops, path):
     f = S.make_features(1, 16, 48, 64, seed=9)[0]
     eye = np.tile(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(1, 12), (3, 1))
