@@ -41,9 +41,9 @@ SIGNATURES = {
     "d3d_convtranspose2d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv_gemm_f32": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                           _i, _i, _i, _i, _i, ctypes.c_char_p, _vp, _vp],
-    "d3d_conv_fold_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "d3d_conv_fold_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                           ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
-    "d3d_conv_fold_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i,
+    "d3d_conv_fold_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                            ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
     "d3d_gru_gates": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "d3d_gru_update": [_vp, _vp, _vp, _i64, _vp, _vp],

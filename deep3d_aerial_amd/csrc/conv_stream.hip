@@ -36,6 +36,7 @@ struct ConvZParams {
     const float* scale;
     const float* shift;
     const float* skip;
+    const float* aux1;   // act == 3: the update gate u
     float* out;
     int Ci0, Ci1, Co, M;
     int D, H, W;
@@ -45,7 +46,7 @@ struct ConvZParams {
     int sz, sy, sx;
     int bz, by, bx;
     int fz, fy, fx;
-    int act, skip_after_act;
+    int act, skip_after_act, ep_split;  // act: 0 none, 1 ReLU, 2 GRU gates, 3 GRU state update (see the header)
     int ntaps, zmin, zspan, ymin, yspan, xmin, xspan;
     int PY, PX, CS, CiP;
     int nseg, mg_nseg, mg_py;  // staging: 16-lane segments per patch row, 16-bit reciprocal multipliers
@@ -254,7 +255,13 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         // (Not for the 32-row variants: the extra registers cost them an occupancy step on layers without a
         // skip; they fetch the skip values tile by tile below.)
         constexpr bool BATCH_SKIP = (MT != 2);
+        // GRU epilogues (module.py:24-51 fused into the gate / candidate convolutions): act 2: y = sigmoid(y), rows
+        // c_out < ep_split (the reset gate) multiplied by h = skip; act 3 (image kernels only): h' = u*h + (1-u)*tanh(y)
+        // with h = skip, u = aux1.
+        const bool gru_gate = p.act == 2, gru_upd = SPLIT && MT == 1 && p.act == 3;
+        const float* __restrict__ a1p = gru_upd ? p.aux1 + ubase : nullptr;
         float sk[BATCH_SKIP ? MT : 1][4][NT];
+        float sk2[(SPLIT && MT == 1) ? 4 : 1][NT];
         if (BATCH_SKIP && skp) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -262,10 +269,13 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                 for (int r = 0; r < 4; ++r) {
                     int off = rowoff[mt][r];
                     asm volatile("" : "+v"(off));
+                    const bool rowok = !gru_gate || ((rowco[mt] >> (8 * r)) & 255) < p.ep_split;  // h has ep_split channels
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        const bool ok = (off >= 0) & (((cmask >> ((mt * 4 + r) * NT + n)) & 1ull) != 0);
+                        const bool ok = (off >= 0) & rowok & (((cmask >> ((mt * 4 + r) * NT + n)) & 1ull) != 0);
                         sk[mt][r][n] = skp[ok ? (unsigned)(off + coloff[n]) : 0u];
+                        if constexpr (SPLIT && MT == 1)
+                            if (gru_upd) sk2[r][n] = a1p[ok ? (unsigned)(off + coloff[n]) : 0u];
                     }
                 }
         }
@@ -284,10 +294,18 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                             const unsigned e = (unsigned)(off + coloff[n]);
                             float y = acc[0][mt][n][r] * sc + sh;
                             float skv = 0.0f;
-                            if (skp) skv = BATCH_SKIP ? sk[BATCH_SKIP ? mt : 0][r][n] : skp[e];
-                            if (skp && !p.skip_after_act) y += skv;
-                            if (p.act == 1) y = fmaxf(y, 0.0f);
-                            if (skp && p.skip_after_act) y = skv + y;
+                            if (skp && (!gru_gate || co < p.ep_split)) skv = BATCH_SKIP ? sk[BATCH_SKIP ? mt : 0][r][n] : skp[e];
+                            if (gru_gate) {
+                                y = 1.0f / (1.0f + __expf(-y));
+                                if (co < p.ep_split) y *= skv;
+                            } else if (gru_upd) {
+                                const float u = sk2[(SPLIT && MT == 1) ? r : 0][n];
+                                y = u * skv + (1.0f - u) * tanhf(y);
+                            } else {
+                                if (skp && !p.skip_after_act) y += skv;
+                                if (p.act == 1) y = fmaxf(y, 0.0f);
+                                if (skp && p.skip_after_act) y = skv + y;
+                            }
                             outp[e] = y;
                         }
                     }
@@ -776,13 +794,16 @@ int d3d_conv_stream_stats(unsigned long long* out8, int reset) {
 
 static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad,
                           int M, const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
-                          int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
+                          const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
                           const signed char* taps_zyx, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in0 && wpack && out && taps_zyx && geom, "null pointer");
     D3D_REQUIRE(Ci0 > 0 && Ci1 >= 0 && (Ci1 == 0 || in1), "bad input channel split %d+%d", Ci0, Ci1);
     D3D_REQUIRE(D > 0 && H > 0 && W > 0 && Do > 0 && Ho > 0 && Wo > 0, "bad dims");
     D3D_REQUIRE(ntaps > 0 && ntaps <= ZS_MAXTAPS, "bad ntaps %d", ntaps);
-    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    D3D_REQUIRE(act >= 0 && act <= 3, "bad act %d", act);
+    D3D_REQUIRE(act < 2 || skip, "GRU epilogue (act %d) needs the state h in `skip`", act);
+    D3D_REQUIRE(act != 2 || (ep_split > 0 && ep_split <= Co), "GRU gate epilogue: bad ep_split %d", ep_split);
+    D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
     ConvZParams p = {};
     p.in0 = in0; p.in1 = in1; p.wpack = wpack; p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.Ci0 = Ci0; p.Ci1 = Ci1; p.Co = Co; p.M = M; p.D = D; p.H = H; p.W = W; p.Do = Do; p.Ho = Ho; p.Wo = Wo;
@@ -792,6 +813,7 @@ static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1
     p.bz = geom[9]; p.by = geom[10]; p.bx = geom[11];
     p.fz = geom[12]; p.fy = geom[13]; p.fx = geom[14];
     p.act = act; p.skip_after_act = skip_after_act ? 1 : 0; p.ntaps = ntaps;
+    p.aux1 = aux1; p.ep_split = ep_split;
     D3D_REQUIRE(p.Gz > 0 && p.Gy > 0 && p.Gx > 0, "bad column grid %dx%dx%d", p.Gz, p.Gy, p.Gx);
     D3D_REQUIRE(p.cz > 0 && p.cy > 0 && (p.cx == 1 || p.cx == 2 || p.cx == 4) && p.sz > 0 && p.sy > 0 && p.sx > 0,
                 "bad steps (column step must be 1, 2 or 4)");
@@ -872,6 +894,10 @@ static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1
     bool split = p.wyn == 1;
     if (const char* e = getenv("D3D_CONV_SPLIT")) split = atoi(e) != 0;
     split = split && lds_bytes_for(p, MT, NT, CK, bf16, true) <= 156 * 1024 && !(MT == 4 && NS == 3);
+    if (act == 3 && !(split && MT == 1)) {
+        set_error("conv_stream: the GRU update epilogue exists in the image (split) kernels with <= 16 GEMM rows only");
+        return D3D_ERR_UNSUPPORTED;
+    }
     if (NT == 1) return launch_ck<1, 1>(p, NS, CK, bf16, split, st);
     switch (MT) {
         case 1: return launch_ck<1, 4>(p, NS, CK, bf16, split, st);
@@ -884,18 +910,18 @@ extern "C" {
 
 int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                       const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
-                      int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
-                      const signed char* taps_zyx, float* out, d3d_stream_t stream) {
-    return conv_fold_impl(false, in0, Ci0, in1, Ci1, wpack, mpad, M, scale, shift, skip, skip_after_act, act, Co, D, H, W,
-                          Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
+                      const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo,
+                      const int* geom, int ntaps, const signed char* taps_zyx, float* out, d3d_stream_t stream) {
+    return conv_fold_impl(false, in0, Ci0, in1, Ci1, wpack, mpad, M, scale, shift, skip, skip_after_act, act, aux1, ep_split,
+                          Co, D, H, W, Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
 }
 
 int d3d_conv_fold_bf16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                        const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
-                       int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
-                       const signed char* taps_zyx, float* out, d3d_stream_t stream) {
-    return conv_fold_impl(true, in0, Ci0, in1, Ci1, wpack, mpad, M, scale, shift, skip, skip_after_act, act, Co, D, H, W,
-                          Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
+                       const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo,
+                       const int* geom, int ntaps, const signed char* taps_zyx, float* out, d3d_stream_t stream) {
+    return conv_fold_impl(true, in0, Ci0, in1, Ci1, wpack, mpad, M, scale, shift, skip, skip_after_act, act, aux1, ep_split,
+                          Co, D, H, W, Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
 }
 
 }  // extern "C"

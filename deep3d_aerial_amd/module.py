@@ -143,6 +143,9 @@ class ConvGRUCell(nn.Module):
         if h is None:
             h = torch.zeros((self.hidden_channels,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
         g = self.conv_gates[0]
+        fused = ops.gru_cell_fused(x, h, g.weight, g.bias, self.convc[0].weight, self.convc[0].bias)
+        if fused is not None:
+            return fused, fused
         gates = ops.conv2d_k3(x, g.weight, None, g.bias, None, act=0, stride=1, x2=h)
         rh, u = ops.gru_gates(gates, h)
         c = self.convc[0]

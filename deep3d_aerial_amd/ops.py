@@ -683,7 +683,7 @@ def _packed_fold(weight, transposed, stride):
 
 
 def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None, skip_after_act=True,
-              transposed=False):
+              transposed=False, aux1=None, ep_split=0):
     """k=3 convolution (2D [C,H,W] or 3D [C,D,H,W]; ordinary stride 1|2 over cat(x,x2), or transposed
     stride 2) through the z-streaming folded GEMM.  Returns None when the layer's resident weights do not fit
     LDS (D3D_ERR_UNSUPPORTED): the caller then takes the per-slice MFMA path."""
@@ -697,7 +697,7 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         o = lambda n: (n - 1) // stride + 1
         od = (o(D), o(H) if three_d else 1, o(W))
     out = torch.empty((Co,) + (od if three_d else (od[0], od[2])), dtype=torch.float32, device=x.device)
-    if skip is not None and skip.shape != out.shape:
+    if skip is not None and skip.shape != out.shape and act < 2:
         raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
     lib = _lib.load()
     Ci0 = x.shape[0]
@@ -714,8 +714,8 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         fold = lib.d3d_conv_fold_bf16 if conv_precision() == "bf16" else lib.d3d_conv_fold_f32
         rc = fold(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
                                    _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
-                                   int(skip_after_act), int(act), Co, D, H, W, od[0], od[1], od[2], geom, T, taps,
-                                   _chk(out, "out"), _stream())
+                                   int(skip_after_act), int(act), _opt(aux1, "aux1"), int(ep_split), Co, D, H, W,
+                                   od[0], od[1], od[2], geom, T, taps, _chk(out, "out"), _stream())
         if rc == _lib.ERR_UNSUPPORTED:
             return None
         _lib.check(rc, "d3d_conv_fold")
@@ -730,3 +730,17 @@ def conv2d_same(x, weight, scale=None, shift=None, skip=None, act=0, stride=1):
     if x.shape[0] != Ci or Co > 64 or not _use_mfma():
         return None
     return conv_fold(x, weight, scale, shift, skip, act, stride, None, True, transposed=False)
+
+
+def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
+    """ConvGRUCell.forward (module.py:24-51) as two convolutions with fused epilogues: gates conv -> [r*h | u], then
+    the candidate conv over cat(x, r*h) -> h' = u*h + (1-u)*tanh(c).  Returns None when the layer does not fit the
+    image stream kernel (the caller then runs the four-kernel form)."""
+    Hc = h.shape[0]
+    if not _use_mfma() or _os.environ.get("D3D_CONV", "mfma") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
+        return None
+    g = conv_fold(x, w_gates, None, b_gates, h, act=2, stride=1, x2=h, ep_split=Hc)
+    if g is None:
+        return None
+    rh, u = g[:Hc], g[Hc:]
+    return conv_fold(x, w_cand, None, b_cand, h, act=3, stride=1, x2=rh, aux1=u)

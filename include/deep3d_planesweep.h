@@ -217,21 +217,25 @@ int d3d_conv_gemm_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
  *   geom (HOST int[15]) = {Gz,Gy,Gx, cz,cy,cx, sz,sy,sx, bz,by,bx, fz,fy,fx}: column grid; per dimension
  *        input index = g*c + tap offset, output index = g*s + b + fold position (clipped to Do/Ho/Wo).
  *   M = Co*fz*fy*fx <= 64 GEMM rows, row m = ((fz_i*fy + fy_i)*fx + fx_i)*Co + co;  mpad = 16 | 32 | 64.
+ *   act: 0 none, 1 ReLU, 2 = ConvGRUCell gates fused (module.py:24-38): y = sigmoid(y), and the reset-gate rows
+ *        c_out < ep_split are multiplied by the state h passed in `skip` (out = [r*h | u]); 3 = ConvGRUCell state
+ *        update fused (module.py:41-51): out = u*h + (1-u)*tanh(y) with h in `skip`, u in `aux1` (image kernels,
+ *        <= 16 GEMM rows; otherwise D3D_ERR_UNSUPPORTED).  aux1 / ep_split are ignored for act 0 | 1.
  *   wpack [ntaps][Ci0+Ci1][mpad] (zero where a fold position does not use a tap);
  *   taps_zyx (HOST signed char[ntaps][3]) sorted by z offset, ntaps <= 128.
  */
 int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                       const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
-                      int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
-                      const signed char* taps_zyx, float* out, d3d_stream_t stream);
+                      const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo,
+                      const int* geom, int ntaps, const signed char* taps_zyx, float* out, d3d_stream_t stream);
 
 /* Same contract with bf16 MFMA operands (v_mfma_f32_16x16x16_bf16; inputs and weights rounded to nearest-even
  * bf16 as the operands are formed, fp32 accumulation, fp32 tensors in memory): the precision BASELINE.json's
  * config 3 asks for.  Depth stays within the 1e-3 relative-L1 budget of the fp32 reference (tests/test_parity_gpu.py). */
 int d3d_conv_fold_bf16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                        const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
-                       int Co, int D, int H, int W, int Do, int Ho, int Wo, const int* geom, int ntaps,
-                       const signed char* taps_zyx, float* out, d3d_stream_t stream);
+                       const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo,
+                       const int* geom, int ntaps, const signed char* taps_zyx, float* out, d3d_stream_t stream);
 
 /*
  * module.py:24-51 ConvGRUCell gate math, fused:
