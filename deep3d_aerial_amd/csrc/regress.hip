@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void gru_update_kernel(const float* __restrict
 // affine.  Stage 1 reduces sum and sum of squares (fp64 partials, one atomic pair per workgroup); the
 // elementwise stages read the two sums, so nothing synchronises with the host.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ stats) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ xall, long n, double* __restrict__ stats_all) {
+    // blockIdx.y = group: x = n consecutive elements, its own (sum, sum of squares) pair
+    const float* __restrict__ x = xall + (long)blockIdx.y * n;
+    double* __restrict__ stats = stats_all + 2 * blockIdx.y;
     double s = 0.0, q = 0.0;
     const long stride = (long)gridDim.x * blockDim.x * 4;
     for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -353,15 +356,18 @@ int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n
     return D3D_OK;
 }
 
-int d3d_groupnorm_stats(const float* x, int64_t n, double* stats2, d3d_stream_t stream) {
-    D3D_REQUIRE(x && stats2, "null pointer");
-    D3D_REQUIRE(n > 0, "bad n");
-    D3D_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
-    int rc = hip_status(hipMemsetAsync(stats2, 0, 2 * sizeof(double), (hipStream_t)stream), "hipMemsetAsync(stats)");
+int d3d_groupnorm_stats(const float* x, int64_t n, int ngroups, double* stats, d3d_stream_t stream) {
+    D3D_REQUIRE(x && stats, "null pointer");
+    D3D_REQUIRE(n > 0 && ngroups > 0 && ngroups <= 65535, "bad n / ngroups");
+    D3D_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ngroups == 1 || n % 4 == 0),
+                "x must be 16-byte aligned (every group)");
+    int rc = hip_status(hipMemsetAsync(stats, 0, 2 * ngroups * sizeof(double), (hipStream_t)stream),
+                        "hipMemsetAsync(stats)");
     if (rc != D3D_OK) return rc;
     long blocks = ceil_div(n, 256 * 4 * 8);
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, stats2);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)blocks, (unsigned)ngroups), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)n, stats);
     D3D_LAUNCH_CHECK("gn_stats_kernel launch");
     return D3D_OK;
 }

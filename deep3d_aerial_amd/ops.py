@@ -334,12 +334,14 @@ def gru_update(u, h, convc):
     return out
 
 
-def groupnorm_stats(x):
-    """sum and sum of squares of x (any shape) as a device fp64 pair, for GroupNorm(1, C) (module.py:62-67)."""
-    st = torch.empty(2, dtype=torch.float64, device=x.device)
-    rc = _lib.load().d3d_groupnorm_stats(_chk(x, "x"), x.numel(), ctypes.c_void_p(st.data_ptr()), _stream())
+def groupnorm_stats(x, ngroups=1):
+    """(sum, sum of squares) of each of `ngroups` equal consecutive parts of x as device fp64 pairs [ngroups,2],
+    for GroupNorm(1, C) (module.py:62-67); ngroups = 1 returns the single pair [2]."""
+    st = torch.empty((ngroups, 2), dtype=torch.float64, device=x.device)
+    rc = _lib.load().d3d_groupnorm_stats(_chk(x, "x"), x.numel() // ngroups, ngroups, ctypes.c_void_p(st.data_ptr()),
+                                         _stream())
     _lib.check(rc, "d3d_groupnorm_stats")
-    return st
+    return st[0] if ngroups == 1 else st
 
 
 def _dptr(t):
@@ -354,8 +356,8 @@ def gru_gates_gn(gates, h, gamma_r, beta_r, gamma_u, beta_u, eps=1e-5):
     plane = h[0].numel()
     if gates.shape[0] != 2 * Hc or gates[0].numel() != plane:
         raise ValueError("gates must be [2*Hc,H,W]")
-    st_r = groupnorm_stats(gates[:Hc])
-    st_u = groupnorm_stats(gates[Hc:])
+    st = groupnorm_stats(gates, 2)  # reset-gate half, update-gate half: one launch
+    st_r, st_u = st[0], st[1]
     rh = torch.empty_like(h)
     u = torch.empty_like(h)
     rc = _lib.load().d3d_gru_gates_gn(_chk(gates, "gates"), _dptr(st_r), _dptr(st_u), _chk(gamma_r, "gamma_r"),

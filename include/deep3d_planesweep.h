@@ -251,12 +251,13 @@ int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n
 /*
  * module.py:53-99 ConvGRUCell2 (msrednet.py:337-371): like ConvGRUCell, but every convolution output passes
  * nn.GroupNorm(1, C) (one group: statistics over all C*H*W elements; per-channel gamma/beta) first.
- *   d3d_groupnorm_stats: stats2[0] = sum(x), stats2[1] = sum(x^2) over n elements (device doubles; zeroed by
- *     the call, stream-ordered).  Call once per normalised tensor (the r and u halves of the gates separately).
+ *   d3d_groupnorm_stats: x holds ngroups consecutive segments of n elements; stats[2g] = sum, stats[2g+1] = sum of
+ *     squares of segment g (device doubles; zeroed by the call, stream-ordered).  The r and u halves of the gate
+ *     tensor are two segments of one call.
  *   d3d_gru_gates_gn:  r = sigmoid(gn_r(gates[:Hc])); u = sigmoid(gn_u(gates[Hc:])); rh = r*h.
  *   d3d_gru_update_gn: h' = u*h + (1-u)*tanh(gn_o(o)).
  */
-int d3d_groupnorm_stats(const float* x, int64_t n, double* stats2, d3d_stream_t stream);
+int d3d_groupnorm_stats(const float* x, int64_t n, int ngroups, double* stats, d3d_stream_t stream);
 int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* stats_u, const float* gamma_r,
                      const float* beta_r, const float* gamma_u, const float* beta_u, const float* h, int Hc,
                      int64_t plane, float eps, float* rh, float* u, d3d_stream_t stream);
