@@ -50,6 +50,7 @@ struct ConvZParams {
     int ntaps, zmin, zspan, ymin, yspan, xmin, xspan;
     int PY, PX, CS, CiP;
     int nseg, mg_nseg, mg_py;  // staging: 16-lane segments per patch row, 16-bit reciprocal multipliers
+    float inv_nseg;            // 1 / nseg for the unit -> (row, segment) split
     int zseg;                  // output columns in z per workgroup
     int vec, sh;               // vec: staging by 16-byte loads (W % 4 == 0); patch origin moved left by sh columns to a multiple of 4
     int wyn;                   // waves along y: 4 (tile 4 rows x 16*NT columns) or 1 (1 row x 64*NT columns)
@@ -73,9 +74,11 @@ __device__ unsigned long long g_conv_stats[8];
 typedef __bf16 bf4v __attribute__((ext_vector_type(4)));
 
 // BF16 = true: the same kernel with bf16 MFMA operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) -- the
-// precision BASELINE's config 3 names.  The patch stays fp32 in LDS and is rounded (RNE, v_cvt_pk_bf16_f32) when
-// the B operand is formed; the resident weights are stored as bf16.  One MFMA covers K = 16: one tap x 16 channels
-// (CK = 16) or two taps x 8 channels (CK = 8).
+// precision BASELINE's config 3 names.  Activations are rounded (RNE, v_cvt_pk_bf16_f32) as they are staged: the
+// LDS patch holds, per channel quad and position, the four bf16 channels as one 8-byte entry, so a B operand is
+// one ds_read_b64 (the first bf16 version kept the patch fp32 and paid four ds_read_b32 + two conversions per
+// operand: LDS-read bound).  The resident weights are stored as bf16.  One MFMA covers K = 16: one tap x 16 channels
+// (CK = 16) or two taps x 8 channels (CK = 8).  Needs the 16-byte staging mode (W % 4 == 0).
 //
 // SPLIT = true: the workgroup has eight waves -- waves 0-3 sweep and flush (the MFMA side), waves 4-7 stage the
 // NEXT step's patch into the other half of a double-buffered LDS patch, one barrier per step.  Staging (loads,
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
     const bool loader = SPLIT && (tid >> 8) != 0;    // waves 4-7 of a split workgroup
     const int g = lane >> 4, j = lane & 15;
     const int Ci = p.Ci0 + p.Ci1, CiP = p.CiP, PX = p.PX, PY = p.PY, CS = p.CS;
-    const int srows = CK * PY, srows16 = (srows + 15) & ~15;
+    // staging rows: (chunk channel, patch row) -- bf16: (channel quad, patch row), four channels per 8-byte entry
+    const int srows = (BF16 ? CK / 4 : CK) * PY, srows16 = (srows + 15) & ~15;
+    constexpr int QENT = 2;  // floats per bf16 quad entry
 
 #ifdef D3D_CONV_STATS
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -188,9 +193,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         for (int r = tid; r < srows16; r += THREADS) {
             int2 e = make_int2(INT_MIN, -1);
             if (r < srows) {
-                const int cc = r / PY, y = r - cc * PY;
+                const int cc = r / PY, y = r - cc * PY;  // bf16: cc = channel quad
                 const int sy = iy0 + y;
-                if ((unsigned)sy < (unsigned)p.H) e.x = (int)(cc * in_vol + (long)sy * p.W + ix0 - p.sh);
+                if ((unsigned)sy < (unsigned)p.H) e.x = (int)((BF16 ? 4 * cc : cc) * in_vol + (long)sy * p.W + ix0 - p.sh);
                 e.y = (cc * CS + y * PX) | (cc << 20);
             }
             rowt[r] = e;
@@ -333,12 +338,14 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
     // `grp` takes patch rows grp, grp+16, ...; its lanes run along x in 16-wide segments.  Item i = (row
     // iteration k, segment seg); the row table supplies the row's source / LDS offsets, so an item costs a
     // handful of integer instructions.
-    constexpr int PF = 32;  // items a thread can hold in flight (larger patches finish synchronously)
+    constexpr int PF = BF16 ? 48 : 32;  // floats a thread can hold in flight (larger patches finish synchronously)
     float pv[PF];
     const int grp = (tid & 255) >> 4, xs = tid & 15;
     float* xw = xin;        // patch buffer being written (split: alternates per step)
     const float* xr = xin;  // patch buffer being read
-    const int nitems = (srows16 >> 4) * p.nseg;
+    // staging units = (patch row, segment), dealt round-robin to the sixteen 16-lane groups of the staging waves
+    const int nunits = srows * p.nseg;
+    const int nitems = (nunits + 15) >> 4;
     // Staging loads are raw buffer loads: base (uniform, per step) + 32-bit byte offset, and the hardware range
     // check returns 0 for offset 0x80000000 -- out-of-image / beyond-C_in elements need no branch and no select.
     // Per item: a row-table read and about ten full-rate integer instructions (no 64-bit or multiply ops).
@@ -353,10 +360,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
     // item i -> LDS slot (or -1) and source byte offset (0x80000000 = reads as zero).  Slots beyond the last item
     // repeat it (same load, same LDS word), so batches of 8 carry no branches.
     auto item_row = [&](int i, int nit, int grpo, int& seg) -> int2 {
-        const int ic = min(i, nit - 1);                                    // uniform
-        const int k = (ic * p.mg_nseg) >> 16;                              // uniform
-        seg = ic - k * p.nseg;
-        return rowt[grpo + 16 * k];
+        const int ic = min(i, nit - 1);                  // uniform (batches are padded by repeating the last item)
+        const int u = min(grpo + 16 * ic, nunits - 1);   // this group's unit (tail groups repeat the last unit)
+        const int row = (int)(((float)u + 0.5f) * p.inv_nseg);
+        seg = u - row * p.nseg;
+        return rowt[row];
     };
     const int ix0s = ix0 - p.sh;  // image column of patch column 0
     int dk4[4];                   // LDS offsets of the four columns of an aligned float4 (de-interleaved rows)
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         // scalar mode: 16 lanes x 1 float per segment; vec mode: 16 lanes x 4 floats (xso = 4 * lane-in-group)
         const int x = (p.vec ? seg * 64 : seg * 16) + xso;
         // (bitwise &, not &&: short-circuit evaluation turns each item into branches with its own LDS waits)
-        const bool ok = (e.x != INT_MIN) & ((unsigned)(ix0s + x) < (unsigned)p.W) & ((e.y >> 20) < cmax);
+        const bool ok = (e.x != INT_MIN) & ((unsigned)(ix0s + x) < (unsigned)p.W) & ((BF16 ? 4 * (e.y >> 20) : (e.y >> 20)) < cmax);
         boff = ok ? (unsigned)(e.x + x) << 2 : 0x80000000u;  // beyond num_records (< 2 GiB): reads as zero
         dst = ((e.y >= 0) & (x < PX)) ? (e.y & 0xfffff) + (x & (p.cx - 1)) * PXq + (x >> lcx) : -1;  // (vec: x % 4 == 0)
     };
@@ -377,6 +385,28 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         // laundered: the item arithmetic is loop invariant; hoisted out of the plane loop it would pin hundreds
         // of registers (and the uniform parts would be spilled SGPRs read back with VALU instructions)
         asm volatile("" : "+v"(grpo), "+v"(xso), "+s"(nit));
+        if constexpr (BF16) {
+            // item = (channel quad, patch row, 4 columns): four 16-byte loads, one per channel (scalar offset)
+#pragma unroll
+            for (int b = 0; b < PF / 16; ++b) {
+                if (b < nit) {
+                    int seg, dst;
+                    unsigned boff;
+                    const int2 e = item_row(b, nit, grpo, seg);
+                    item_addr(e, seg, xso, cmax, dst, boff);
+                    const int cq = 4 * (e.y >> 20);
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const unsigned bo = (cq + ch < cmax) ? boff : 0x80000000u;
+                        const u4v q = __builtin_amdgcn_raw_buffer_load_b128(rs, bo, (unsigned)((long)ch * in_vol * 4), 0);
+                        const f4v f = __builtin_bit_cast(f4v, q);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pv[16 * b + 4 * ch + k] = f[k];
+                    }
+                }
+            }
+            return;
+        }
         if (p.vec) {  // 16-byte loads: a quarter of the instructions
 #pragma unroll
             for (int b4 = 0; b4 < PF / 4; b4 += 4) {
@@ -425,6 +455,43 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         const int cmax = Ci - c * CK;
         int grpo = grp, xso = p.vec ? 4 * xs : xs, nit = nitems;
         asm volatile("" : "+v"(grpo), "+v"(xso), "+s"(nit));
+        if constexpr (BF16) {
+            bf4v* xw8 = reinterpret_cast<bf4v*>(xw);
+            auto pack = [](float a0, float a1, float a2, float a3) { return (bf4v){(__bf16)a0, (__bf16)a1, (__bf16)a2, (__bf16)a3}; };
+#pragma unroll
+            for (int b = 0; b < PF / 16; ++b) {
+                if (b < nit) {
+                    int seg, dst;
+                    unsigned boff;
+                    const int2 e = item_row(b, nit, grpo, seg);
+                    item_addr(e, seg, xso, cmax, dst, boff);
+                    if (dst >= 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            xw8[dst + dk4[k]] = pack(pv[16 * b + k], pv[16 * b + 4 + k], pv[16 * b + 8 + k], pv[16 * b + 12 + k]);
+                    }
+                }
+            }
+            for (int i = PF / 16; i < nit; ++i) {  // beyond the register window
+                int seg, dst;
+                unsigned boff;
+                const int2 e = item_row(i, nit, grpo, seg);
+                item_addr(e, seg, xso, cmax, dst, boff);
+                const int cq = 4 * (e.y >> 20);
+                f4v v[4];
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const unsigned bo = (cq + ch < cmax) ? boff : 0x80000000u;
+                    const u4v q = __builtin_amdgcn_raw_buffer_load_b128(rs, bo, (unsigned)((long)ch * in_vol * 4), 0);
+                    v[ch] = __builtin_bit_cast(f4v, q);
+                }
+                if (dst >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xw8[dst + dk4[k]] = pack(v[0][k], v[1][k], v[2][k], v[3][k]);
+                }
+            }
+            return;
+        }
         if (p.vec) {
 #pragma unroll
             for (int b4 = 0; b4 < PF / 4; b4 += 4) {
@@ -512,20 +579,18 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
             if constexpr (BF16) {
                 const bf4v* __restrict__ wl16 = reinterpret_cast<const bf4v*>(wl);
                 const int nch = CiP / CK;
-                const int bb = bbase - g * CS;  // patch offset of this lane's column, channel 0
+                const bf4v* __restrict__ xr8 = reinterpret_cast<const bf4v*>(xr);
+                const int bb = bbase - g * CS;  // patch entry of this lane's column, quad 0
                 constexpr int TSTEP = (CK == 8) ? 2 : 1;
                 for (int t = tb; t < te; t += TSTEP) {
-                    // this lane's k-slot: channels cb..cb+3 at tap t (CK = 16) or tap t + (g>>1) (CK = 8)
+                    // this lane's k-slot: channel quad qd at tap t (CK = 16: qd = g) or at tap t + (g>>1) (CK = 8: qd = g&1)
                     const int tl = (CK == 8) ? min(t + (g >> 1), te - 1) : t;
-                    const int cb = (CK == 8) ? 4 * (g & 1) : 4 * g;
-                    const float* __restrict__ xb = xr + bb + tofft[tl] + cb * CS;
+                    const int qd = (CK == 8) ? (g & 1) : g;
+                    const bf4v* __restrict__ xb = xr8 + bb + tofft[tl] + qd * CS;
                     const bf4v* __restrict__ wa = wl16 + ((t * nch + c) * 4 + g) * WS + j;
                     bf4v b[NT];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const float x0 = xb[n * 16], x1 = xb[CS + n * 16], x2 = xb[2 * CS + n * 16], x3 = xb[3 * CS + n * 16];
-                        b[n] = (bf4v){(__bf16)x0, (__bf16)x1, (__bf16)x2, (__bf16)x3};
-                    }
+                    for (int n = 0; n < NT; ++n) b[n] = xb[n * 16];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const bf4v av = wa[m * 16];
@@ -577,7 +642,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         if (zi <= zend) {
             if (loader) {
                 for (int sidx = 0;; ++sidx) {
-                    xw = xin + (sidx & 1) * (CK * CS);
+                    xw = xin + (sidx & 1) * (BF16 ? (CK / 4) * CS * QENT : CK * CS);
                     issue(zi, c);
                     land(zi, c);
                     __syncthreads();  // step sidx staged; the MFMA waves are done with step sidx - 1
@@ -596,7 +661,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                         ZS_T(f1);
                         ZS_ADD(3, f0, f1);
                     }
-                    xr = xin + (sidx & 1) * (CK * CS);
+                    xr = xin + (sidx & 1) * (BF16 ? (CK / 4) * CS * QENT : CK * CS);
                     ZS_T(c0);
                     sweep(zi, c);
                     ZS_T(c1);
@@ -699,9 +764,9 @@ static int lds_bytes_for(const ConvZParams& p, int MT, int NT, int CK, bool bf16
     const int Ci = p.Ci0 + p.Ci1, CiP = (Ci + CK - 1) / CK * CK;
     if (bf16) {
         const int PYb = patch_rows(p), PXb = patch_cols(p, NT);
-        const int srows16b = (CK * PYb + 15) & ~15;
+        const int srows16b = ((CK / 4) * PYb + 15) & ~15;
         return 4 * (p.ntaps * (CiP / CK) * 4 * WS * 2 + ((p.ntaps + 3) & ~3) + 128 + 2 * srows16b +
-                    (split ? 2 : 1) * CK * patch_stride(PYb, PXb, p.cx));
+                    (split ? 2 : 1) * (CK / 4) * patch_stride(PYb, PXb, p.cx) * 2);
     }
     const int PY = patch_rows(p), PX = patch_cols(p, NT);
     const int srows16 = (CK * PY + 15) & ~15;
@@ -718,6 +783,7 @@ static int launch_stream(ConvZParams& p, hipStream_t stream) {
     p.CS = patch_stride(p.PY, p.PX, p.cx);
     p.nseg = p.vec ? (p.PX + 63) / 64 : (p.PX + 15) / 16;
     p.mg_nseg = 65536 / p.nseg + 1;
+    p.inv_nseg = 1.0f / (float)p.nseg;
     p.mg_py = 65536 / p.PY + 1;
     const int bytes = lds_bytes_for(p, MT, NT, CK, BF16, SPLIT);
     auto kern = conv_stream_kernel<MT, NT, NS, CK, BF16, SPLIT>;
@@ -876,6 +942,10 @@ static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1
         set_error("conv_stream: tensor too large for 32-bit offsets, or input split %d+%d not chunk aligned", Ci0, Ci1);
         return D3D_ERR_UNSUPPORTED;
     }
+    if (bf16 && !p.vec) {
+        set_error("conv_stream: the bf16 kernels need 16-byte staging (W %% 4 == 0 and 16-byte aligned inputs)");
+        return D3D_ERR_UNSUPPORTED;
+    }
     const int bytes = lds_bytes_for(p, MT, NT, CK, bf16);
     if (bytes > 156 * 1024) {
         set_error("conv_stream: resident weights + patch need %d B of LDS (ntaps=%d Ci=%d M=%d)", bytes, ntaps, Ci, M);
@@ -886,7 +956,8 @@ static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1
         const int PY = patch_rows(p), PX = patch_cols(p, NT);
         const int nseg = p.vec ? (PX + 63) / 64 : (PX + 15) / 16, rows = CK * PY;
         const int items = ((rows + 15) / 16) * nseg + 8;
-        D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 64 && PY <= 64, "patch %dx%d too large", PY, PX);
+        D3D_REQUIRE(items < 1024 && rows + 16 < 1024 && nseg <= 64 && PY <= 64 && rows * nseg < 8192, "patch %dx%d too large",
+                    PY, PX);
     }
     hipStream_t st = (hipStream_t)stream;
     // Loader / MFMA wave split (double-buffered patch): measured 8-11 % faster on row-streamed images (short

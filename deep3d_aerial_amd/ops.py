@@ -718,6 +718,12 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
                                    _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
                                    int(skip_after_act), int(act), _opt(aux1, "aux1"), int(ep_split), Co, D, H, W,
                                    od[0], od[1], od[2], geom, T, taps, _chk(out, "out"), _stream())
+        if rc == _lib.ERR_UNSUPPORTED and fold is lib.d3d_conv_fold_bf16:
+            # shape outside the bf16 kernels (e.g. image width not a multiple of 4): the exact fp32 kernel instead
+            rc = lib.d3d_conv_fold_f32(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
+                                       _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
+                                       int(skip_after_act), int(act), _opt(aux1, "aux1"), int(ep_split), Co, D, H, W,
+                                       od[0], od[1], od[2], geom, T, taps, _chk(out, "out"), _stream())
         if rc == _lib.ERR_UNSUPPORTED:
             return None
         _lib.check(rc, "d3d_conv_fold")
