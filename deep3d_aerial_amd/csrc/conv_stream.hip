@@ -257,8 +257,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         asm volatile("" : "+v"(mlo), "+v"(mhi));
         const unsigned long long cmask = ((unsigned long long)mhi << 32) | mlo;
         // skip values first, all in flight together (clamped addresses, no branches), then the epilogue proper.
-        // (Not for the 32-row variants: the extra registers cost them an occupancy step on layers without a
-        // skip; they fetch the skip values tile by tile below.)
+        // (The 32-row variants batch per 16-row tile instead: the full batch costs them an occupancy step.)
         constexpr bool BATCH_SKIP = (MT != 2);
         // GRU epilogues (module.py:24-51 fused into the gate / candidate convolutions): act 2: y = sigmoid(y), rows
         // c_out < ep_split (the reset gate) multiplied by h = skip; act 3 (image kernels only): h' = u*h + (1-u)*tanh(y)
@@ -285,7 +284,20 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                 }
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+            if (!BATCH_SKIP && skp) {  // this tile's skip values, all in flight together
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int off = rowoff[mt][r];
+                    asm volatile("" : "+v"(off));
+                    const bool rowok = !gru_gate || ((rowco[mt] >> (8 * r)) & 255) < p.ep_split;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const bool ok = (off >= 0) & rowok & (((cmask >> ((mt * 4 + r) * NT + n)) & 1ull) != 0);
+                        sk[0][r][n] = skp[ok ? (unsigned)(off + coloff[n]) : 0u];
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int off = rowoff[mt][r];
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                             const unsigned e = (unsigned)(off + coloff[n]);
                             float y = acc[0][mt][n][r] * sc + sh;
                             float skv = 0.0f;
-                            if (skp && (!gru_gate || co < p.ep_split)) skv = BATCH_SKIP ? sk[BATCH_SKIP ? mt : 0][r][n] : skp[e];
+                            if (skp && (!gru_gate || co < p.ep_split)) skv = sk[BATCH_SKIP ? mt : 0][r][n];
                             if (gru_gate) {
                                 y = 1.0f / (1.0f + __expf(-y));
                                 if (co < p.ep_split) y *= skv;
@@ -317,6 +329,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                 }
                 if (r == 3) __builtin_amdgcn_sched_barrier(0);  // one 16-row tile at a time: bounded registers
             }
+        }
 #pragma unroll
         for (int s = 0; s + 1 < NS; ++s)
 #pragma unroll
