@@ -51,6 +51,12 @@ SIGNATURES = {
     "d3d_gru_gates_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _vp, _vp, _vp],
     "d3d_gru_update_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _vp, _vp],
     "d3d_pair_softmax_max": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "d3d_consistency_check": [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double), _i, _i, _i, _i, ctypes.c_double,
+                              _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "d3d_fusion_ref_init": [_vp, _vp, ctypes.POINTER(ctypes.c_double), _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "d3d_fusion_accumulate": [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double), _i, _i, _i, _i,
+                              ctypes.c_double, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "d3d_fusion_finalize": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
 }
 
 

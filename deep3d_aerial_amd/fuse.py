@@ -1,0 +1,167 @@
+"""Geometric consistency check and per-view fusion accumulators on the GPU.
+
+Host-side mirror of the reference interface for this step:
+
+* `ConsistencyChecker(position_threshold, depth_threshold, normal_threshold, confidence_threshold)` with
+  `.check(depth_ref, normal_ref, intrinsics_ref, extrinsics_ref, depth_src, normal_src, intrinsics_src,
+  extrinsics_src, prob_map_ref)` -> `(mask, depth_reprojected, depth_src, xyz_world_src, angle_confidence)` --
+  fuse/consistency_check_n.py:17-27, 141-147.  The reference's CuPy path uploads nine arrays and downloads five
+  per (ref, src) pair; here the maps are device tensors (the depth / confidence maps the plane-sweep path has just
+  produced stay resident) and a pair is one kernel launch (`d3d_consistency_check`).
+* `ViewFusion` is the body of `Fuse_Depth_Map.fuse_depths` for one reference view (fuse/fusion_3d_normal.py:
+  452-474 reference init, :476-518 per-source accumulation, :522-527 average / final mask) on resident
+  accumulators; `add_source` is the check fused with the accumulation (`d3d_fusion_accumulate`), so the pair
+  outputs never reach memory.
+
+The 3x3 / 4x4 camera algebra (inverses, E_src @ inv(E_ref)) happens on the host in float32 with NumPy, exactly where
+and how the reference forms those matrices (np.fromstring(dtype=float32) cameras, linalg.inv keeps float32).
+All per-pixel arithmetic runs in libdeep3d_planesweep.so; there is no CPU path.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _chk, _stream
+
+_CAM_DOUBLES = 94  # D3D_FUSION_CAM_DOUBLES
+
+
+def camera_block(intrinsics_ref, extrinsics_ref, intrinsics_src, extrinsics_src):
+    """The `cam` argument of d3d_consistency_check (include/deep3d_planesweep.h): nine float32 matrices, widened."""
+    def f32(a):
+        a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        return np.ascontiguousarray(a, dtype=np.float32)
+
+    Kr, Er, Ks, Es = f32(intrinsics_ref), f32(extrinsics_ref), f32(intrinsics_src), f32(extrinsics_src)
+    if Kr.shape != (3, 3) or Ks.shape != (3, 3) or Er.shape != (4, 4) or Es.shape != (4, 4):
+        raise ValueError("intrinsics must be [3,3] and extrinsics [4,4]")
+    inv = np.linalg.inv
+    parts = [inv(Kr), np.matmul(Es, inv(Er))[:3, :4], Ks, inv(Ks), inv(Es), Er[:3, :4], Kr, inv(Es[:3, :3]),
+             inv(Er[:3, :3])]
+    cam = np.concatenate([p.reshape(-1).astype(np.float64) for p in parts])
+    assert cam.size == _CAM_DOUBLES
+    return (ctypes.c_double * _CAM_DOUBLES)(*cam.tolist())
+
+
+def _map(t, name, shape=None, last=None):
+    p = _chk(t, name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must be %s (got %s)" % (name, tuple(shape), tuple(t.shape)))
+    if last is not None and (t.dim() != 3 or t.shape[2] != last):
+        raise ValueError("%s must be [H,W,%d] (got %s)" % (name, last, tuple(t.shape)))
+    return p
+
+
+class ConsistencyChecker(object):
+    """fuse/consistency_check_n.py:17-27: thresholds in pixels, relative depth, degrees, confidence."""
+
+    def __init__(self, position_threshold, depth_threshold, normal_threshold, confidence_threshold, implement="hip"):
+        self.position_threshold = float(position_threshold)
+        self.depth_threshold = float(depth_threshold)
+        self.normal_threshold = math.cos(math.radians(normal_threshold))
+        self.confidence_threshold = float(confidence_threshold)
+        self.implement = implement.lower()
+        if self.implement != "hip":
+            raise ValueError("this build has one implementation, 'hip' (got %r)" % implement)
+
+    def _thresholds(self):
+        return (ctypes.c_double(self.position_threshold), ctypes.c_float(self.depth_threshold),
+                ctypes.c_float(self.normal_threshold), ctypes.c_float(self.confidence_threshold))
+
+    def check(self, depth_ref, normal_ref, intrinsics_ref, extrinsics_ref, depth_src, normal_src, intrinsics_src,
+              extrinsics_src, prob_map_ref):
+        """Device tensors: depth_ref, prob_map_ref [H,W]; normal_ref [H,W,3]; depth_src [Hs,Ws]; normal_src [Hs,Ws,3].
+        Returns (mask bool [H,W], depth_reprojected [H,W], depth_src with the consistent samples zeroed [Hs,Ws],
+        xyz_world_src [3,H,W], angle_confidence [3,H,W])."""
+        if depth_ref.dim() != 2 or depth_src.dim() != 2:
+            raise ValueError("depth maps must be [H,W]")
+        H, W = depth_ref.shape
+        Hs, Ws = depth_src.shape
+        dev = depth_ref.device
+        cam = camera_block(intrinsics_ref, extrinsics_ref, intrinsics_src, extrinsics_src)
+        args = [_map(depth_ref, "depth_ref"), _map(normal_ref, "normal_ref", (H, W, 3)),
+                _map(prob_map_ref, "prob_map_ref", (H, W)), _map(depth_src, "depth_src"),
+                _map(normal_src, "normal_src", (Hs, Ws, 3))]
+        mask = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        depth_reprojected = torch.empty((H, W), dtype=torch.float32, device=dev)
+        depth_src_out = depth_src.clone()
+        xyz_world_src = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        angle = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        rc = _lib.load().d3d_consistency_check(
+            *args, cam, H, W, Hs, Ws, *self._thresholds(), ctypes.c_void_p(mask.data_ptr()),
+            _chk(depth_reprojected, "depth_reprojected"), _chk(depth_src_out, "depth_src_out"),
+            _chk(xyz_world_src, "xyz_world_src"), _chk(angle, "angle_confidence"), _stream())
+        _lib.check(rc, "d3d_consistency_check")
+        return mask.bool(), depth_reprojected, depth_src_out, xyz_world_src, angle
+
+
+class ViewFusion(object):
+    """Accumulators of one reference view (fuse/fusion_3d_normal.py:446-527).
+
+        vf = ViewFusion(checker, depth_ref, normal_ref, K_ref, E_ref, confidence, ref_idx)
+        for each source view:  src_depth_filtered = vf.add_source(depth_src, normal_src, K_src, E_src, src_idx)
+        avg_xyz_world, final_mask = vf.finalize(min_geo_consist_num)
+
+    State (device): all_xyz_world [3,H,W], xyz_confidence [H,W] (the reference's three identical planes, kept once),
+    geo_mask_sum [H,W] int32, vis_infos: list of [H,W] int32 planes (index 0 = the reference view's own id),
+    normal_world [H,W,3] unit world normals of the reference view."""
+
+    def __init__(self, checker, depth_ref, normal_ref, intrinsics_ref, extrinsics_ref, confidence, ref_idx):
+        if depth_ref.dim() != 2:
+            raise ValueError("depth_ref must be [H,W]")
+        self.checker = checker
+        self.H, self.W = depth_ref.shape
+        H, W = self.H, self.W
+        dev = depth_ref.device
+        self.depth_ref, self.normal_ref, self.confidence = depth_ref, normal_ref, confidence
+        self.K_ref, self.E_ref = intrinsics_ref, extrinsics_ref
+        _map(confidence, "confidence", (H, W))
+        self.all_xyz_world = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        self.xyz_confidence = torch.empty((H, W), dtype=torch.float32, device=dev)
+        self.geo_mask_sum = torch.empty((H, W), dtype=torch.int32, device=dev)
+        self.normal_world = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        cam = camera_block(intrinsics_ref, extrinsics_ref, intrinsics_ref, extrinsics_ref)  # inv(E_src) slot = inv(E_ref)
+        rc = _lib.load().d3d_fusion_ref_init(
+            _map(depth_ref, "depth_ref"), _map(normal_ref, "normal_ref", (H, W, 3)), cam, H, W,
+            _chk(self.all_xyz_world, "all_xyz_world"), _chk(self.xyz_confidence, "xyz_confidence"),
+            ctypes.c_void_p(self.geo_mask_sum.data_ptr()), _chk(self.normal_world, "normal_world"), _stream())
+        _lib.check(rc, "d3d_fusion_ref_init")
+        self.vis_infos = [torch.full((H, W), int(ref_idx), dtype=torch.int32, device=dev)]  # :473
+
+    def add_source(self, depth_src, normal_src, intrinsics_src, extrinsics_src, src_idx, filter_source=True):
+        """:476-518 for one source view.  Returns the source depth map with the samples this reference view
+        confirmed set to 0 (what the reference writes back as the source's `_init.pfm` when save_temp is on), or
+        None with filter_source=False."""
+        if depth_src.dim() != 2:
+            raise ValueError("depth_src must be [Hs,Ws]")
+        H, W = self.H, self.W
+        Hs, Ws = depth_src.shape
+        dev = self.depth_ref.device
+        cam = camera_block(self.K_ref, self.E_ref, intrinsics_src, extrinsics_src)
+        vis = torch.empty((H, W), dtype=torch.int32, device=dev)
+        out = depth_src.clone() if filter_source else None
+        rc = _lib.load().d3d_fusion_accumulate(
+            _map(self.depth_ref, "depth_ref"), _map(self.normal_ref, "normal_ref"), _map(self.confidence, "confidence"),
+            _map(depth_src, "depth_src"), _map(normal_src, "normal_src", (Hs, Ws, 3)), cam, H, W, Hs, Ws,
+            *self.checker._thresholds(), int(src_idx), ctypes.c_void_p(self.geo_mask_sum.data_ptr()),
+            _chk(self.all_xyz_world, "all_xyz_world"), _chk(self.xyz_confidence, "xyz_confidence"),
+            ctypes.c_void_p(vis.data_ptr()), None if out is None else _chk(out, "depth_src_out"), _stream())
+        _lib.check(rc, "d3d_fusion_accumulate")
+        self.vis_infos.append(vis)
+        return out
+
+    def finalize(self, min_geo_consist_num):
+        """:522-527 -> (avg_xyz_world [3,H,W] float32, final_mask [H,W] bool)."""
+        H, W = self.H, self.W
+        dev = self.depth_ref.device
+        avg = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        fm = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        rc = _lib.load().d3d_fusion_finalize(
+            _chk(self.all_xyz_world, "all_xyz_world"), _chk(self.xyz_confidence, "xyz_confidence"),
+            ctypes.c_void_p(self.geo_mask_sum.data_ptr()), H, W, int(min_geo_consist_num), _chk(avg, "avg_xyz_world"),
+            ctypes.c_void_p(fm.data_ptr()), _stream())
+        _lib.check(rc, "d3d_fusion_finalize")
+        return avg, fm.bool()

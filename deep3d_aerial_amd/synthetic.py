@@ -123,3 +123,46 @@ def fill_state_dict_(state_dict, seed):
                 a = rng.standard_normal(shape) * np.sqrt(2.0 / max(fan_in, 1))
             t.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(shape))
     return state_dict
+
+
+def make_fusion_scene(h, w, n_src=3, seed=0, noise=0.004, src_scale=1.0):
+    """A reference view and n_src source views of one tilted ground plane, as the fusion step reads them
+    (fuse/fusion_3d_normal.py:425-505): per view a depth map [h,w], a camera-space normal map [h,w,3], K [3,3] and
+    E = Tcw [4,4] (float32), plus the reference confidence map.  Source depths carry relative noise of `noise`
+    (about half the default 1 % depth threshold), normals a few degrees of noise, parts of the maps are holes
+    (depth 0) and low confidence, and the source cameras are offset sideways so part of every reprojection leaves
+    the source image.  Source maps are [round(h*src_scale), round(w*src_scale)].
+    Returns (ref, [src...]) with ref/src dicts: depth, normal, K, E (+ ref["confidence"])."""
+    rng = np.random.default_rng(seed)
+    n_w = np.array([0.06, -0.04, -1.0])
+    n_w /= np.linalg.norm(n_w)
+    c_w = n_w @ np.array([0.0, 0.0, 600.0])
+
+    def view(hh, ww, f, R, C, rel_noise):
+        K = np.array([[f, 0, (ww - 1) / 2.0], [0, f, (hh - 1) / 2.0], [0, 0, 1]], np.float64)
+        t = -R @ C
+        ys, xs = np.mgrid[0:hh, 0:ww]
+        rays = np.linalg.inv(K) @ np.stack([xs.ravel(), ys.ravel(), np.ones(hh * ww)])
+        nr = n_w @ R.T
+        d = ((c_w + nr @ t) / (nr @ rays)).reshape(hh, ww)
+        d = d * (1.0 + rel_noise * rng.standard_normal((hh, ww)))
+        n_cam = R @ n_w
+        normal = n_cam[None, None, :] + 0.03 * rng.standard_normal((hh, ww, 3))
+        E = np.eye(4)
+        E[:3, :3] = R
+        E[:3, 3] = t
+        return dict(depth=d.astype(np.float32), normal=normal.astype(np.float32), K=K.astype(np.float32),
+                    E=E.astype(np.float32))
+
+    ref = view(h, w, 1.4 * w, _rot(0.01, -0.02, 0.015), np.zeros(3), 0.0)
+    ref["confidence"] = rng.uniform(0.0, 1.0, (h, w)).astype(np.float32)
+    ref["depth"][rng.uniform(size=(h, w)) < 0.02] = 0.0  # holes
+    hs, ws = int(round(h * src_scale)), int(round(w * src_scale))
+    srcs = []
+    for i in range(n_src):
+        a = 2.0 * np.pi * i / max(n_src, 1)
+        C = np.array([90.0 * np.cos(a), 60.0 * np.sin(a), 10.0 * (i - 1)])
+        s = view(hs, ws, 1.4 * ws, _rot(0.02 * np.sin(a), -0.03 * np.cos(a), 0.02 * (i - 1)), C, noise)
+        s["depth"][rng.uniform(size=(hs, ws)) < 0.02] = 0.0
+        srcs.append(s)
+    return ref, srcs

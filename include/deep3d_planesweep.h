@@ -271,6 +271,50 @@ int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma,
 int d3d_pair_softmax_max(const float* score, const float* depth, int depth_mode, int D, int h, int w,
                          float* view_weight, float* pair_depth, d3d_stream_t stream);
 
+/*
+ * SURVEY.md §8f row N1 -- the consumer of the depth / confidence maps: geometric consistency between a reference
+ * and a source view, and the fusion accumulators of one reference view.
+ *
+ * d3d_consistency_check replaces ConsistencyChecker.check (fuse/consistency_check_n.py:141-147 -> check_cupy
+ * :29-138): reference pixel -> source pixel (nearest, "+0.5 truncate"; out-of-range indices wrap around as CuPy's
+ * integer-array indexing does), sampled source depth -> world -> reference pixel; a pixel is consistent when the
+ * reprojection distance < position_threshold, |d_reproj - d_ref| / d_ref < depth_threshold, the reference
+ * confidence > confidence_threshold, the cosine between the world normals > normal_cos_threshold
+ * (= cos(radians(normal_threshold)), :22) and d_ref > 0.
+ *   depth_ref, prob_ref [H,W]; normal_ref [H,W,3]; depth_src [Hs,Ws]; normal_src [Hs,Ws,3]   (device, fp32)
+ *   cam: HOST array of D3D_FUSION_CAM_DOUBLES doubles, every matrix row-major and computed in float32 as the
+ *        reference does (linalg.inv / matmul of float32 arrays), then widened:
+ *          inv(K_ref)[9], (E_src @ inv(E_ref))[:3,:4][12], K_src[9], inv(K_src)[9], inv(E_src)[16],
+ *          E_ref[:3,:4][12], K_ref[9], inv(E_src[:3,:3])[9], inv(E_ref[:3,:3])[9]
+ *   outputs (device; any may be NULL): mask [H,W] u8; depth_reprojected [H,W] (0 where inconsistent);
+ *        depth_src_out [Hs,Ws]: a COPY of depth_src made by the caller, in which the samples of consistent pixels
+ *        are set to 0 (:123-126); xyz_world_src [3,H,W] and angle_conf [3,H,W] (cosine, clamped at 0; 0 where
+ *        inconsistent).
+ *
+ * d3d_fusion_ref_init / _accumulate / _finalize are the body of Fuse_Depth_Map.fuse_depths for one reference view
+ * (fuse/fusion_3d_normal.py:452-474, :476-518, :522-527) on resident accumulators: all_xyz_world [3,H,W],
+ * conf_sum [H,W] (the reference's three identical planes kept once), geo_mask_sum [H,W] i32, vis [H,W] i32
+ * (= mask * src_idx, :518).  _accumulate is the consistency check fused with :513-518 -- the pair outputs never
+ * reach memory.  For _ref_init the cam slots inv(K_ref), inv(E_src) (holding inv(E_ref)) and inv(E_ref[:3,:3])
+ * are read; normal_world [H,W,3] (unit world normals, :466-469) may be NULL.
+ */
+#define D3D_FUSION_CAM_DOUBLES 94
+int d3d_consistency_check(const float* depth_ref, const float* normal_ref, const float* prob_ref,
+                          const float* depth_src, const float* normal_src, const double* cam, int H, int W, int Hs,
+                          int Ws, double position_threshold, float depth_threshold, float normal_cos_threshold,
+                          float confidence_threshold, unsigned char* mask, float* depth_reprojected,
+                          float* depth_src_out, float* xyz_world_src, float* angle_conf, d3d_stream_t stream);
+int d3d_fusion_ref_init(const float* depth_ref, const float* normal_ref, const double* cam, int H, int W,
+                        float* all_xyz_world, float* conf_sum, int* geo_mask_sum, float* normal_world,
+                        d3d_stream_t stream);
+int d3d_fusion_accumulate(const float* depth_ref, const float* normal_ref, const float* prob_ref,
+                          const float* depth_src, const float* normal_src, const double* cam, int H, int W, int Hs,
+                          int Ws, double position_threshold, float depth_threshold, float normal_cos_threshold,
+                          float confidence_threshold, int src_idx, int* geo_mask_sum, float* all_xyz_world,
+                          float* conf_sum, int* vis, float* depth_src_out, d3d_stream_t stream);
+int d3d_fusion_finalize(const float* all_xyz_world, const float* conf_sum, const int* geo_mask_sum, int H, int W,
+                        int min_geo_consist_num, float* avg_xyz_world, unsigned char* final_mask, d3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

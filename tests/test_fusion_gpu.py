@@ -1,0 +1,123 @@
+"""Row N1, GPU side: csrc/fusion.hip through the C-ABI (deep3d_aerial_amd.fuse -> ctypes) against the
+reference's own outputs (tests/golden/fusion_pair_*.npz), against the CPU oracle on seeded scenes, and at the full
+2752x1856 map size through properties.
+
+The kernel and the oracle perform the same float64 / float32 operations in the same order with contraction off,
+and fp64/fp32 divide and square root are correctly rounded on gfx950, so the comparison is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from deep3d_aerial_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fuse():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from deep3d_aerial_amd import _lib, fuse as _fuse
+
+    _lib.load()
+    return _fuse
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("tag", ["lateral", "forward"])
+def test_check_matches_reference_outputs(fuse, tag):
+    g = load_golden("fusion_pair_" + tag)
+    t = g["thresholds"]
+    chk = fuse.ConsistencyChecker(t[0], t[1], t[2], t[3])
+    mask, drep, dsrc, xyz, ang = chk.check(dev(g["depth_ref"]), dev(g["normal_ref"]), g["K_ref"], g["E_ref"],
+                                           dev(g["depth_src"]), dev(g["normal_src"]), g["K_src"], g["E_src"],
+                                           dev(g["prob_ref"]))
+    assert np.array_equal(host(mask), g["out_mask"])
+    assert np.array_equal(host(drep), g["out_depth_reprojected"])
+    assert np.array_equal(host(dsrc), g["out_depth_src"])
+    assert np.array_equal(host(xyz), g["out_xyz_world_src"])
+    assert np.abs(host(ang) - g["out_angle_conf"]).max() <= 3e-7  # float32 BLAS summation order of the reference
+
+
+@pytest.mark.parametrize("h,w,scale,seed", [(120, 160, 1.0, 1), (97, 131, 1.25, 2), (256, 384, 0.5, 3)])
+def test_check_bit_exact_vs_oracle(fuse, oracle, h, w, scale, seed):
+    ref, srcs = S.make_fusion_scene(h, w, 2, seed=seed, src_scale=scale)
+    chk = fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2)
+    for s in srcs:
+        want = oracle.fusion.consistency_check(ref["depth"], ref["normal"], ref["K"], ref["E"], s["depth"], s["normal"],
+                                               s["K"], s["E"], ref["confidence"], 1.0, 0.01, 10.0, 0.2)
+        got = chk.check(dev(ref["depth"]), dev(ref["normal"]), ref["K"], ref["E"], dev(s["depth"]), dev(s["normal"]),
+                        s["K"], s["E"], dev(ref["confidence"]))
+        assert 0.1 < want[0].mean() < 0.9
+        for name, a, b in zip(("mask", "depth_reprojected", "depth_src", "xyz_world_src", "angle"), got, want):
+            assert np.array_equal(host(a), b), name
+
+
+def test_view_fusion_matches_oracle_chain(fuse, oracle):
+    ref, srcs = S.make_fusion_scene(150, 200, 4, seed=11)
+    chk = fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2)
+    vf = fuse.ViewFusion(chk, dev(ref["depth"]), dev(ref["normal"]), ref["K"], ref["E"], dev(ref["confidence"]), 5)
+    xyz, conf, cnt, nw = oracle.fusion.fusion_ref_init(ref["depth"], ref["normal"], ref["K"], ref["E"])
+    assert np.array_equal(host(vf.all_xyz_world), xyz) and np.array_equal(host(vf.normal_world), nw)
+    for i, s in enumerate(srcs):
+        m, _, dso, pts, ang = oracle.fusion.consistency_check(ref["depth"], ref["normal"], ref["K"], ref["E"], s["depth"],
+                                                              s["normal"], s["K"], s["E"], ref["confidence"], 1.0, 0.01,
+                                                              10.0, 0.2)
+        vis = oracle.fusion.fusion_accumulate(m, pts, ang, 20 + i, cnt, xyz, conf)
+        filtered = vf.add_source(dev(s["depth"]), dev(s["normal"]), s["K"], s["E"], 20 + i)
+        assert np.array_equal(host(filtered), dso)
+        assert np.array_equal(host(vf.vis_infos[-1]), vis)
+    assert np.array_equal(host(vf.geo_mask_sum), cnt)
+    assert np.array_equal(host(vf.all_xyz_world), xyz)
+    assert np.array_equal(host(vf.xyz_confidence), conf)
+    avg, fm = vf.finalize(3)
+    want_avg, want_fm = oracle.fusion.fusion_finalize(xyz, conf, cnt, 3)
+    assert np.array_equal(host(avg), want_avg) and np.array_equal(host(fm), want_fm)
+    assert 0.05 < want_fm.mean() < 0.95
+    assert (host(vf.vis_infos[0]) == 5).all()
+
+
+def test_full_size_identity_pair(fuse):
+    """2752x1856 (BASELINE config 2 map size): a view checked against itself reprojects every pixel onto itself, so
+    the mask is exactly (confidence > threshold) & (depth > 0), the reprojected depth equals the depth to float32
+    rounding of the round trip, the world points equal the reference-view initialisation, and the filtered source
+    map is zero exactly on the mask."""
+    H, W = 1856, 2752
+    ref, _ = S.make_fusion_scene(H, W, 0, seed=21)
+    d, n, c = dev(ref["depth"]), dev(ref["normal"]), dev(ref["confidence"])
+    chk = fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2)
+    mask, drep, dsrc, xyz, ang = chk.check(d, n, ref["K"], ref["E"], d, n, ref["K"], ref["E"], c)
+    want = (c > 0.2) & (d > 0)
+    assert torch.equal(mask, want)
+    assert float((drep[want] / d[want] - 1).abs().max()) < 1e-5
+    assert torch.equal(dsrc == 0, want | (d == 0))
+    vf = fuse.ViewFusion(chk, d, n, ref["K"], ref["E"], c, 1)
+    rel = (xyz - vf.all_xyz_world * want).abs().max() / vf.all_xyz_world.abs().max()
+    assert float(rel) < 1e-5
+    assert float((ang[0][want] - 1).abs().max()) < 1e-5 and float(ang[0][~want].abs().max()) == 0
+    # fused accumulation of the same pair: count 2 on the mask, confidence 1 + cos, average unchanged
+    vf.add_source(d, n, ref["K"], ref["E"], 2, filter_source=False)
+    avg, fm = vf.finalize(2)
+    assert torch.equal(fm, want)
+    assert float((avg - xyz)[:, want].abs().max() / xyz.abs().max()) < 1e-5
+
+
+def test_arguments_are_checked(fuse):
+    chk = fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2)
+    ref, srcs = S.make_fusion_scene(16, 24, 1, seed=1)
+    s = srcs[0]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        chk.check(torch.from_numpy(ref["depth"]), dev(ref["normal"]), ref["K"], ref["E"], dev(s["depth"]),
+                  dev(s["normal"]), s["K"], s["E"], dev(ref["confidence"]))
+    with pytest.raises(ValueError):
+        chk.check(dev(ref["depth"]), dev(ref["normal"][:, :, :2]), ref["K"], ref["E"], dev(s["depth"]),
+                  dev(s["normal"]), s["K"], s["E"], dev(ref["confidence"]))
+    with pytest.raises(ValueError):
+        fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2, implement="cupy")
