@@ -57,6 +57,7 @@ SIGNATURES = {
     "d3d_fusion_accumulate": [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double), _i, _i, _i, _i,
                               ctypes.c_double, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "d3d_fusion_finalize": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "d3d_flip_rows": [ctypes.POINTER(_vp), _i, _i, _i, _vp, _vp],
 }
 
 

@@ -59,6 +59,126 @@ def load_pfm(filename):
     return np.flipud(data.reshape(shape)).astype(np.float32), abs(scale)
 
 
+def _pfm_header(h, w, color=False, scale=1):
+    # little-endian float32 payload => negative scale (data_io.py:215-219)
+    return (b"PF\n" if color else b"Pf\n") + ("%d %d\n" % (w, h)).encode("utf-8") + ("%f\n" % -scale).encode("utf-8")
+
+
+class PfmWriter(object):
+    """Asynchronous writer of the per-view products (predict.py:176-180: {name}_init.pfm, {name}_prob.pfm) --
+    SURVEY.md 8f row N2.  The reference pulls each map to the host synchronously, flips it with NumPy and writes it
+    before the next view starts.  Here `submit` (stream-ordered, returns at once) flips the maps on the device
+    into a staging buffer in file order (`d3d_flip_rows`), a copy stream moves the buffer to pinned host memory with
+    ONE asynchronous D2H transfer, and a writer thread puts header + payload on disk while the GPU runs the next
+    view.  `depth` slots bound the memory in flight.  Files are byte-identical to save_pfm's."""
+
+    def __init__(self, h, w, n_maps=2, depth=2, device="cuda"):
+        import queue
+        import threading
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("PfmWriter stages through the GPU (no CPU fallback); use save_pfm for host arrays")
+        self.h, self.w, self.n = int(h), int(w), int(n_maps)
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = [dict(dev=torch.empty((self.n, self.h, self.w), dtype=torch.float32, device=self.device),
+                           host=torch.empty((self.n, self.h, self.w), dtype=torch.float32).pin_memory(),
+                           free=threading.Event()) for _ in range(depth)]
+        for sl in self.slots:
+            sl["free"].set()
+        self._next = 0
+        self._q = queue.Queue()
+        self._err = None
+        self._thread = threading.Thread(target=self._run, name="pfm-writer", daemon=True)
+        self._thread.start()
+
+    def submit(self, maps, paths):
+        """maps: n device tensors of h*w fp32 elements each; paths: n file names."""
+        import ctypes
+
+        from . import _lib
+        from .ops import _chk, _stream
+
+        if self._err is not None:
+            raise self._err
+        if len(maps) != self.n or len(paths) != self.n:
+            raise ValueError("expected %d maps and paths" % self.n)
+        maps = [m.reshape(self.h, self.w) for m in maps]
+        sl = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        sl["free"].wait()
+        sl["free"].clear()
+        ptrs = (ctypes.c_void_p * self.n)(*[_chk(m, "map").value for m in maps])
+        _lib.check(_lib.load().d3d_flip_rows(ptrs, self.n, self.h, self.w, _chk(sl["dev"], "staging"), _stream()),
+                   "d3d_flip_rows")
+        cur = torch.cuda.current_stream(self.device)
+        self.copy_stream.wait_stream(cur)
+        with torch.cuda.stream(self.copy_stream):
+            sl["host"].copy_(sl["dev"], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        self._q.put((sl, done, list(paths)))
+
+    def _run(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            sl, done, paths = item
+            try:
+                done.synchronize()
+                payload = sl["host"].numpy()
+                for k, path in enumerate(paths):
+                    with open(path, "wb") as f:
+                        f.write(_pfm_header(self.h, self.w))
+                        payload[k].tofile(f)
+            except Exception as e:  # surfaced by the next submit() / close()
+                self._err = e
+            finally:
+                sl["free"].set()
+
+    def close(self):
+        """Waits until every submitted file is on disk."""
+        self._q.put(None)
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def load_pfm_device(filename, device="cuda"):
+    """Read side for the fusion step (fusion_3d_normal.py:444,488: read_pfm(path)[0]): the payload goes to the
+    device as it lies in the file (pinned host buffer, one H2D copy) and is un-flipped there.  Greyscale
+    little-endian files (what the writer produces); anything else takes load_pfm + upload."""
+    import ctypes
+
+    from . import _lib
+    from .ops import _chk, _stream
+
+    with open(filename, "rb") as f:
+        header = f.readline().decode("utf-8").rstrip()
+        w, h = (int(t) for t in f.readline().decode("utf-8").split())
+        scale = float(f.readline().decode("utf-8").rstrip())
+        if header != "Pf" or scale >= 0 or sys.byteorder != "little":
+            return torch.from_numpy(np.ascontiguousarray(load_pfm(filename)[0])).to(device)
+        host = torch.empty((h, w), dtype=torch.float32).pin_memory()
+        n = f.readinto(memoryview(host.numpy()).cast("B"))
+        if n != h * w * 4:
+            raise Exception("truncated PFM payload in %s" % filename)
+    raw = host.to(device, non_blocking=True)
+    out = torch.empty_like(raw)
+    ptrs = (ctypes.c_void_p * 1)(_chk(raw, "payload").value)
+    _lib.check(_lib.load().d3d_flip_rows(ptrs, 1, h, w, _chk(out, "out"), _stream()), "d3d_flip_rows")
+    torch.cuda.current_stream().synchronize()  # the pinned buffer is released on return
+    return out
+
+
 def write_red_cam(file, cam, location, ref_path):
     """data_io.py:291-314: extrinsic 4x4, intrinsic 3x3, 'dmin interval D dmax', location + ref path."""
     with open(file, "w") as f:
@@ -146,25 +266,41 @@ class SyntheticBlock:
 # ----------------------------------------------------------------------------------------
 # the per-view loop of predict.py:126-183, sharded over ranks
 # ----------------------------------------------------------------------------------------
-def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda"):
+def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda", keep_maps=False):
+    """Returns the names of the views this rank produced; with keep_maps=True a dict name -> (depth, confidence)
+    of device tensors instead, so the fusion step (fuse.ViewFusion) can start without re-reading the PFM files."""
     os.makedirs(output_folder, exist_ok=True)
     model.eval()
-    done = []
-    with torch.no_grad():
-        for idx in sharding.shard_views(len(dataset), rank, world_size):
-            s = dataset[idx]
-            imgs = torch.from_numpy(np.ascontiguousarray(s["imgs"]))[None].to(device)
-            pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(device) for k, v in s["proj_matrices"].items()}
-            dv = torch.from_numpy(np.ascontiguousarray(s["depth_values"]))[None].to(device)
-            out = model(imgs, pm, dv)
-            depth = np.float32(np.squeeze(out["depth"].cpu().numpy()))
-            prob = np.float32(np.squeeze(out["photometric_confidence"].cpu().numpy()))
-            name = os.path.splitext(s["outlocation"][3])[0]
-            save_pfm(os.path.join(output_folder, "%s_init.pfm" % name), depth)
-            save_pfm(os.path.join(output_folder, "%s_prob.pfm" % name), prob)
-            write_red_cam(os.path.join(output_folder, "%s.txt" % name), s["outcam"], s["outlocation"],
-                          s["ref_image_path"])
-            done.append(name)
+    done = {} if keep_maps else []
+    writer = None
+    try:
+        with torch.no_grad():
+            for idx in sharding.shard_views(len(dataset), rank, world_size):
+                s = dataset[idx]
+                imgs = torch.from_numpy(np.ascontiguousarray(s["imgs"]))[None].to(device)
+                pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(device)
+                      for k, v in s["proj_matrices"].items()}
+                dv = torch.from_numpy(np.ascontiguousarray(s["depth_values"]))[None].to(device)
+                out = model(imgs, pm, dv)
+                depth = out["depth"].squeeze().float().contiguous()
+                prob = out["photometric_confidence"].squeeze().float().contiguous()
+                name = os.path.splitext(s["outlocation"][3])[0]
+                paths = [os.path.join(output_folder, "%s_init.pfm" % name),
+                         os.path.join(output_folder, "%s_prob.pfm" % name)]
+                if writer is None or (writer.h, writer.w) != tuple(depth.shape):
+                    if writer is not None:
+                        writer.close()
+                    writer = PfmWriter(depth.shape[0], depth.shape[1], 2, device=depth.device)
+                writer.submit([depth, prob], paths)  # the files land while the next view is computed
+                write_red_cam(os.path.join(output_folder, "%s.txt" % name), s["outcam"], s["outlocation"],
+                              s["ref_image_path"])
+                if keep_maps:
+                    done[name] = (depth, prob)
+                else:
+                    done.append(name)
+    finally:
+        if writer is not None:
+            writer.close()
     return done
 
 

@@ -315,6 +315,15 @@ int d3d_fusion_accumulate(const float* depth_ref, const float* normal_ref, const
 int d3d_fusion_finalize(const float* all_xyz_world, const float* conf_sum, const int* geo_mask_sum, int H, int W,
                         int min_geo_consist_num, float* avg_xyz_world, unsigned char* final_mask, d3d_stream_t stream);
 
+/*
+ * SURVEY.md §8f row N2 -- PFM payload order.  save_pfm_utf8 (mvs/mvs_cas/datasets/data_io.py:196-223) writes rows
+ * bottom-up (np.flipud) and read_pfm / load_pfm (data_io.py:150-193, IO/pfm.py:19-60) flips them back.
+ * d3d_flip_rows: out[k][H-1-y][x] = maps[k][y][x] for n <= 8 maps [H,W] (maps: HOST array of device pointers; out
+ * [n,H,W] device, must not alias an input): one staging buffer in file order for a single D2H copy, or the
+ * inverse after an upload.
+ */
+int d3d_flip_rows(const float* const* maps, int n, int H, int W, float* out, d3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

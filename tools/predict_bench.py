@@ -1,0 +1,61 @@
+"""End-to-end per-view time of the predict.py loop at 2752x1856, 5 views: model only, model +
+asynchronous PFM products (PfmWriter: device flip, pinned D2H on a copy stream, writer thread), and model + the
+reference's synchronous order (D2H, np.flipud, tofile before the next view starts; predict.py:146-183).
+Usage: python tools/predict_bench.py [--model casmvsnet --views 6 --out /tmp/d3d_out]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deep3d_aerial_amd import predict as P, synthetic as S  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="casmvsnet")
+    ap.add_argument("--views", type=int, default=6)
+    ap.add_argument("--h", type=int, default=1856)
+    ap.add_argument("--w", type=int, default=2752)
+    ap.add_argument("--out", default="/tmp/d3d_out")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    model = P.build_model(a.model, 384)
+    S.fill_state_dict_(model.state_dict(), 1)
+    model = model.cuda().eval()
+    s = P.SyntheticBlock(1, 5, a.w, a.h, 384, seed=9)[0]
+    imgs = torch.from_numpy(np.ascontiguousarray(s["imgs"]))[None].cuda()
+    pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].cuda() for k, v in s["proj_matrices"].items()}
+    dv = torch.from_numpy(np.ascontiguousarray(s["depth_values"]))[None].cuda()
+
+    def run(mode):
+        writer = None
+        with torch.no_grad():
+            model(imgs, pm, dv)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for i in range(a.views):
+                out = model(imgs, pm, dv)
+                depth, prob = out["depth"].squeeze().contiguous(), out["photometric_confidence"].squeeze().contiguous()
+                paths = [os.path.join(a.out, "v%d_init.pfm" % i), os.path.join(a.out, "v%d_prob.pfm" % i)]
+                if mode == "async":
+                    if writer is None:
+                        writer = P.PfmWriter(depth.shape[0], depth.shape[1], 2)
+                    writer.submit([depth, prob], paths)
+                elif mode == "sync":
+                    P.save_pfm(paths[0], np.float32(np.squeeze(depth.cpu().numpy())))
+                    P.save_pfm(paths[1], np.float32(np.squeeze(prob.cpu().numpy())))
+            if writer is not None:
+                writer.close()
+            torch.cuda.synchronize()
+            return (time.time() - t0) / a.views * 1e3
+
+    for mode in ("none", "async", "sync", "async", "sync"):
+        print("%-6s products: %7.1f ms per view" % (mode, run(mode)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
