@@ -58,6 +58,7 @@ SIGNATURES = {
                               ctypes.c_double, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "d3d_fusion_finalize": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "d3d_flip_rows": [ctypes.POINTER(_vp), _i, _i, _i, _vp, _vp],
+    "d3d_center_image_u8": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
 }
 
 

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .dataset import extract_features
 from . import ops
 from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, feature_conv, folded_bn,
                      plane_depths)
@@ -225,11 +226,16 @@ class Infer_AdaMVSNet(nn.Module):
                                        InferDepthNet(in_depths=self.ndepths[0], in_channels=oc[1]),
                                        InferDepthNet(in_depths=self.ndepths[0], in_up=False, in_channels=oc[2])])
 
-    def forward(self, imgs, proj_matrices, depth_values):
-        B, V, _, img_h, img_w = imgs.shape
+    feature_cache = None  # dataset.FeatureCache shared across reference views (set by the harness); see image_keys
+
+    def forward(self, imgs, proj_matrices, depth_values, image_keys=None):
+        """image_keys (optional, with self.feature_cache set): one hashable key per view; the feature pyramid of a
+        key seen before is reused instead of recomputed, and imgs may then be a list whose cached entries are None."""
         dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())
         depth_interval = (dmax - dmin) / self.num_depth
-        features = [self.feature(imgs[:, v]) for v in range(V)]
+        features = extract_features(self.feature, imgs, image_keys, self.feature_cache)
+        V = len(features)
+        B, _, img_h, img_w = features[0]["stage3"].shape  # the finest level has the image's size
         outputs = {}
         depth, pair_confidence = None, None
         for s in range(self.num_stage):

@@ -12,6 +12,7 @@ arguments, forward() contract, state_dict keys).  Hot path per stage:
 import torch
 import torch.nn as nn
 
+from .dataset import extract_features
 from . import ops
 from .module import ConvBnReLU3D, FeatureNet_mvsnet, folded_bn, plane_depths, _no_train
 
@@ -107,13 +108,18 @@ class Infer_CascadeMVSNet(nn.Module):
                  for i in range(self.num_stage)])
         self.DepthNet = DepthNet()
 
-    def forward(self, imgs, proj_matrices, depth_values):
-        B, V, _, img_h, img_w = imgs.shape
+    feature_cache = None  # dataset.FeatureCache shared across reference views (set by the harness); see image_keys
+
+    def forward(self, imgs, proj_matrices, depth_values, image_keys=None):
+        """image_keys (optional, with self.feature_cache set): one hashable key per view; the feature pyramid of a
+        key seen before is reused instead of recomputed, and imgs may then be a list whose cached entries are None."""
         # one device sync, like the reference's depth_values[0,0].cpu() (cas_mvsnet.py:184-185)
         dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())
         depth_interval = (dmax - dmin) / self.num_depth
 
-        features = [self.feature(imgs[:, v]) for v in range(V)]
+        features = extract_features(self.feature, imgs, image_keys, self.feature_cache)
+        V = len(features)
+        B, _, img_h, img_w = features[0]["stage3"].shape  # the finest level has the image's size
         outputs = {}
         depth = None
         for s in range(self.num_stage):

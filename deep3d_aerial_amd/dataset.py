@@ -1,0 +1,192 @@
+"""Input side of a reference view on the GPU.
+
+The reference builds every dataset item on the host (mvs/mvs_cas/datasets/cas_normal_eval.py:94-182): each of the V
+images of an item is decoded, cropped, converted to float32 and normalised with NumPy (preprocess.py:60-117), although
+neighbouring reference views share most of their images, and then every image goes through the feature network again
+(adamvs.py:571-574, cas_mvsnet.py:189-192).  Here
+
+* `crop_window` / `crop_camera` / `stage_projections` are the host-side camera arithmetic of that item builder
+  (a few 4x4 matrices: NumPy, as in the reference);
+* `center_image` crops and normalises a decoded 8-bit image on the device (`d3d_center_image_u8`: exact integer
+  statistics, one upload of h*w*3 bytes instead of h*w*12);
+* `FeatureCache` keeps the feature pyramids of recently used images resident in HBM (a 2752x1856 image's three-stage
+  pyramid is 286 MB; 288 GB hold hundreds), so an image shared by several reference views is normalised and
+  featurised once per block.  The inference drivers take `image_keys=` and consult the cache attached to them.
+"""
+import collections
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _chk, _stream
+
+
+# ----------------------------------------------------------------------------------------
+# camera arithmetic of the item builder (host, NumPy)
+# ----------------------------------------------------------------------------------------
+def crop_window(h, w, max_h, max_w, resize_scale=1, base_image_size=32):
+    """preprocess.py:60-77: (start_h, start_w, new_h, new_w) of the centre crop that fits the network (see
+    slice_window for the pixels it selects)."""
+    max_h = int(max_h * resize_scale)
+    max_w = int(max_w * resize_scale)
+    new_h = max_h if h > max_h else int(math.ceil(h / base_image_size) * base_image_size)
+    new_w = max_w if w > max_w else int(math.ceil(w / base_image_size) * base_image_size)
+    start_h = int(math.ceil((h - new_h) / 2))
+    start_w = int(math.ceil((w - new_w) / 2))
+    return start_h, start_w, new_h, new_w
+
+
+def slice_window(h, w, window):
+    """The pixels `image[start_h:start_h+new_h, start_w:start_w+new_w]` (preprocess.py:78-80) really selects, as
+    (y0, x0, H, W): for an image smaller than its rounded-up size the start is negative and Python's slice counts it
+    from the end -- kept, because the camera shift of crop_camera uses the same start."""
+    start_h, start_w, new_h, new_w = window
+    ys = range(h)[slice(start_h, start_h + new_h)]
+    xs = range(w)[slice(start_w, start_w + new_w)]
+    return (ys.start if len(ys) else 0), (xs.start if len(xs) else 0), len(ys), len(xs)
+
+
+def crop_camera(cam, start_h, start_w):
+    """preprocess.py:81-82: the principal point moves with the crop origin.  cam [2,4,4] (extrinsic; intrinsic +
+    depth row), modified in place like the reference and returned."""
+    cam[1][0][2] = cam[1][0][2] - start_w
+    cam[1][1][2] = cam[1][1][2] - start_h
+    return cam
+
+
+def scale_camera(cam, scale=1):
+    """preprocess.py:19-30: focal lengths and principal point times `scale`."""
+    new_cam = np.copy(cam)
+    rows, cols = [0, 1, 0, 1], [0, 1, 2, 2]  # fx, fy, x0, y0 of the intrinsic block
+    new_cam[1, rows, cols] = cam[1, rows, cols] * scale
+    return new_cam
+
+
+def stage_projections(cams, sample_scale=1):
+    """cas_normal_eval.py:134-173: per view proj = E with its top 3x4 replaced by K @ E[:3,:4]; the stage-2 / stage-1
+    matrices have the first two rows divided by 2 / 4.  cams: list of [2,4,4].  Returns (proj_matrices_ms,
+    intri_matrices_ms) with keys stage1..stage3 as the reference's sample dict."""
+    projs, intris = [], []
+    for cam in cams:
+        sc = scale_camera(cam, scale=sample_scale)
+        extrinsics = sc[0, :, :]
+        intrinsics = sc[1, 0:3, 0:3]
+        proj = extrinsics.copy()
+        proj[:3, :4] = np.matmul(intrinsics, proj[:3, :4])
+        projs.append(proj)
+        intris.append(intrinsics)
+    projs, intris = np.stack(projs), np.stack(intris)
+
+    def pyramid(m):
+        half, quarter = m.copy(), m.copy()
+        half[:, :2, :] = m[:, :2, :] / 2
+        quarter[:, :2, :] = m[:, :2, :] / 4
+        return {"stage1": quarter, "stage2": half, "stage3": m}
+
+    return pyramid(projs), pyramid(intris)
+
+
+# ----------------------------------------------------------------------------------------
+# crop + normalise on the device
+# ----------------------------------------------------------------------------------------
+_MODES = {"standard": 0, "mean": 1}
+
+
+def center_image(img_u8, mode="mean", window=None, out=None):
+    """preprocess.py:92-117 center_image over the crop window of preprocess.py:76-80.
+    img_u8: device uint8 tensor [h,w,C] (a decoded image, interleaved); window = (y0, x0, H, W) from slice_window, or
+    None for the whole image.  Returns float32 [C,new_h,new_w] -- already in the layout the reference reaches with
+    np.stack(...).transpose([0,3,1,2]) (cas_normal_eval.py:147)."""
+    if mode not in _MODES:
+        raise Exception("{}? Not implemented yet!".format(mode))
+    if not (isinstance(img_u8, torch.Tensor) and img_u8.is_cuda):
+        raise RuntimeError("img_u8 must be on the GPU (no CPU fallback)")
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or not img_u8.is_contiguous():
+        raise TypeError("img_u8 must be a contiguous uint8 [h,w,C] tensor")
+    h, w, C = img_u8.shape
+    y0, x0, H, W = window if window is not None else (0, 0, h, w)
+    if out is None:
+        out = torch.empty((C, H, W), dtype=torch.float32, device=img_u8.device)
+    sums = torch.empty(8, dtype=torch.int64, device=img_u8.device)
+    rc = _lib.load().d3d_center_image_u8(ctypes.c_void_p(img_u8.data_ptr()), h, w, C, int(y0), int(x0), int(H), int(W),
+                                         _MODES[mode], ctypes.c_void_p(sums.data_ptr()), _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_center_image_u8")
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# feature pyramids kept resident across reference views
+# ----------------------------------------------------------------------------------------
+class FeatureCache(object):
+    """LRU cache image key -> feature pyramid (dict stage -> [1,C,h,w] device tensor) bounded by `max_bytes` of HBM.
+
+    A key must identify the image AND its preprocessing (path, crop window, normalisation mode); the cache belongs to
+    one set of feature-network weights: call clear() after loading a checkpoint."""
+
+    def __init__(self, max_bytes=64 << 30):
+        self.max_bytes = int(max_bytes)
+        self.bytes = 0
+        self.hits = 0
+        self.misses = 0
+        self._d = collections.OrderedDict()
+
+    @staticmethod
+    def _size(pyr):
+        return sum(t.numel() * t.element_size() for t in pyr.values())
+
+    def get(self, key):
+        pyr = self._d.get(key)
+        if pyr is None:
+            self.misses += 1
+            return None
+        self._d.move_to_end(key)
+        self.hits += 1
+        return pyr
+
+    def put(self, key, pyr):
+        size = self._size(pyr)
+        if size > self.max_bytes:
+            return
+        if key in self._d:
+            self.bytes -= self._size(self._d.pop(key))
+        while self._d and self.bytes + size > self.max_bytes:
+            _, old = self._d.popitem(last=False)
+            self.bytes -= self._size(old)
+        self._d[key] = pyr
+        self.bytes += size
+
+    def clear(self):
+        self._d.clear()
+        self.bytes = 0
+
+    def __len__(self):
+        return len(self._d)
+
+    def __contains__(self, key):
+        return key in self._d
+
+
+def extract_features(feature_net, imgs, image_keys=None, cache=None):
+    """`[self.feature(imgs[:, v]) for v in range(V)]` (cas_mvsnet.py:189-192, adamvs.py:571-574, msrednet.py:
+    482-485) with the pyramids of known images taken from `cache`.  imgs: [B,V,3,H,W] tensor, or a list of V entries
+    each either a [B,3,H,W] tensor or None (None = "not uploaded because its key is cached")."""
+    V = imgs.shape[1] if isinstance(imgs, torch.Tensor) else len(imgs)
+    view = (lambda v: imgs[:, v]) if isinstance(imgs, torch.Tensor) else (lambda v: imgs[v])
+    if cache is None or image_keys is None:
+        return [feature_net(view(v)) for v in range(V)]
+    if len(image_keys) != V:
+        raise ValueError("image_keys must name the %d views" % V)
+    feats = []
+    for v in range(V):
+        pyr = cache.get(image_keys[v])
+        if pyr is None:
+            x = view(v)
+            if x is None:
+                raise KeyError("image %r is neither cached nor supplied" % (image_keys[v],))
+            pyr = feature_net(x)
+            cache.put(image_keys[v], pyr)
+        feats.append(pyr)
+    return feats

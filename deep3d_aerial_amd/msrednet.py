@@ -7,6 +7,7 @@ in a 2D encoder-decoder, on the matrix-core convolutions) -> online exp-sum regr
 import torch
 import torch.nn as nn
 
+from .dataset import extract_features
 from . import ops
 from .module import ConvGRUCell2, ConvReLU, ConvTransReLU, FeatureNet_mvsnet, plane_depths
 
@@ -109,13 +110,18 @@ class Infer_CascadeREDNet(nn.Module):
                  for i in range(self.num_stage)])
         self.DepthNet = InferDepthNet()
 
-    def forward(self, imgs, proj_matrices, depth_values):
+    feature_cache = None  # dataset.FeatureCache shared across reference views (set by the harness); see image_keys
+
+    def forward(self, imgs, proj_matrices, depth_values, image_keys=None):
+        """image_keys (optional, with self.feature_cache set): one hashable key per view; the feature pyramid of a
+        key seen before is reused instead of recomputed, and imgs may then be a list whose cached entries are None."""
         if self.training:
             raise RuntimeError("inference only: call .eval()")
-        B, V, _, img_h, img_w = imgs.shape
         dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())   # msrednet.py:477-478 (one host sync)
         depth_interval = (dmax - dmin) / self.num_depth
-        features = [self.feature(imgs[:, v]) for v in range(V)]
+        features = extract_features(self.feature, imgs, image_keys, self.feature_cache)
+        V = len(features)
+        B, _, img_h, img_w = features[0]["stage3"].shape  # the finest level has the image's size
         outputs = {}
         depth = None
         for s in range(self.num_stage):

@@ -263,25 +263,102 @@ class SyntheticBlock:
                 "outlocation": [str(self.w), str(self.h), str(idx), name + ".png"], "ref_image_path": name + ".png"}
 
 
+class SyntheticStrip:
+    """A flight strip of `n_images` overlapping 8-bit images; reference view i uses images i, i+1, ... (ring), as
+    neighbouring reference views of a real block share most of their sources (viewpair.txt).  Items carry what the
+    reference's item builder starts from -- decoded images and [2,4,4] cameras (cas_normal_eval.py:112-127) -- so the
+    crop / normalise / projection steps run through dataset.py on the GPU, and `image_keys` name the shared images
+    for the feature cache.  Images are a little larger than (max_h, max_w): the centre crop is exercised."""
+
+    def __init__(self, n_images, view_num, max_h, max_w, numdepth, seed=0, border=(6, 10), normalize="mean"):
+        self.n, self.v, self.h, self.w, self.nd, self.seed = n_images, view_num, max_h, max_w, numdepth, seed
+        self.h0, self.w0 = max_h + border[0], max_w + border[1]
+        self.normalize = normalize
+        self.depth = (400.0, 800.0)
+
+    def __len__(self):
+        return self.n
+
+    def image(self, j):
+        rng = np.random.default_rng(self.seed * 1000 + j)
+        base = rng.integers(0, 256, (self.h0 // 4 + 2, self.w0 // 4 + 2, 3), dtype=np.uint8)
+        img = np.repeat(np.repeat(base, 4, axis=0), 4, axis=1)[:self.h0, :self.w0]
+        return np.ascontiguousarray(img ^ rng.integers(0, 16, img.shape, dtype=np.uint8))
+
+    def camera(self, j):
+        from . import dataset
+
+        f = 1.2 * max(self.h0, self.w0)
+        cam = np.zeros((2, 4, 4), np.float32)
+        R = synthetic._rot(0.004 * np.sin(j), 0.006 * np.cos(1.3 * j), 0.003 * j)
+        C = np.array([0.02 * self.depth[0] * j, 0.004 * self.depth[0] * np.sin(j), 0.0])
+        cam[0] = np.eye(4)
+        cam[0, :3, :3] = R
+        cam[0, :3, 3] = -R @ C
+        cam[1, :3, :3] = [[f, 0, (self.w0 - 1) / 2], [0, f, (self.h0 - 1) / 2], [0, 0, 1]]
+        cam[1, 3] = [self.depth[0], (self.depth[1] - self.depth[0]) / self.nd, self.nd, self.depth[1]]
+        win = dataset.crop_window(self.h0, self.w0, self.h, self.w)
+        return dataset.crop_camera(cam, win[0], win[1]), dataset.slice_window(self.h0, self.w0, win)
+
+    def __getitem__(self, idx):
+        from . import dataset
+
+        ids = [(idx + k) % self.n for k in range(self.v)]
+        cams, wins = zip(*[self.camera(j) for j in ids])
+        pm, _ = dataset.stage_projections(list(cams))
+        name = "view_%04d" % idx
+        return {"images_u8": [self.image(j) for j in ids], "image_keys": [(self.seed, j, w, self.normalize) for j, w in zip(ids, wins)],
+                "crop_windows": list(wins), "normalize": self.normalize, "proj_matrices": pm,
+                "depth_values": np.array(self.depth, np.float32), "outcam": cams[0],
+                "outlocation": [str(self.w), str(self.h), str(idx), name + ".png"], "ref_image_path": name + ".png"}
+
+
+def _item_views(s, model, device):
+    """The views of one dataset item on the device.  Items with decoded 8-bit images ("images_u8", "crop_windows",
+    "image_keys") are cropped and normalised on the GPU (dataset.center_image), and an image whose feature pyramid is
+    cached is not even uploaded; items with host-normalised float images ("imgs", the reference's layout) are uploaded
+    as they are."""
+    from . import dataset
+
+    if "images_u8" not in s:
+        return torch.from_numpy(np.ascontiguousarray(s["imgs"]))[None].to(device), s.get("image_keys")
+    cache = getattr(model, "feature_cache", None)
+    views = []
+    for v, im in enumerate(s["images_u8"]):
+        if cache is not None and s["image_keys"][v] in cache:
+            views.append(None)
+            continue
+        u8 = torch.from_numpy(np.ascontiguousarray(im)).to(device, non_blocking=True)
+        views.append(dataset.center_image(u8, s.get("normalize", "mean"), s["crop_windows"][v])[None])
+    return views, s["image_keys"]
+
+
 # ----------------------------------------------------------------------------------------
 # the per-view loop of predict.py:126-183, sharded over ranks
 # ----------------------------------------------------------------------------------------
-def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda", keep_maps=False):
+def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda", keep_maps=False,
+                  feature_cache_bytes=0):
     """Returns the names of the views this rank produced; with keep_maps=True a dict name -> (depth, confidence)
-    of device tensors instead, so the fusion step (fuse.ViewFusion) can start without re-reading the PFM files."""
+    of device tensors instead, so the fusion step (fuse.ViewFusion) can start without re-reading the PFM files.
+    feature_cache_bytes > 0 keeps the feature pyramids of that many bytes of images resident across views (items must
+    carry "image_keys"); results do not change."""
+    from .dataset import FeatureCache
+
     os.makedirs(output_folder, exist_ok=True)
     model.eval()
+    if feature_cache_bytes > 0:
+        model.feature_cache = FeatureCache(feature_cache_bytes)
     done = {} if keep_maps else []
     writer = None
     try:
         with torch.no_grad():
             for idx in sharding.shard_views(len(dataset), rank, world_size):
                 s = dataset[idx]
-                imgs = torch.from_numpy(np.ascontiguousarray(s["imgs"]))[None].to(device)
+                imgs, keys = _item_views(s, model, device)
                 pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(device)
                       for k, v in s["proj_matrices"].items()}
                 dv = torch.from_numpy(np.ascontiguousarray(s["depth_values"]))[None].to(device)
-                out = model(imgs, pm, dv)
+                out = model(imgs, pm, dv, image_keys=keys)
                 depth = out["depth"].squeeze().float().contiguous()
                 prob = out["photometric_confidence"].squeeze().float().contiguous()
                 name = os.path.splitext(s["outlocation"][3])[0]
@@ -301,6 +378,8 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
     finally:
         if writer is not None:
             writer.close()
+        if feature_cache_bytes > 0:
+            model.feature_cache = None
     return done
 
 

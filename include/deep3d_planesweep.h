@@ -324,6 +324,18 @@ int d3d_fusion_finalize(const float* all_xyz_world, const float* conf_sum, const
  */
 int d3d_flip_rows(const float* const* maps, int n, int H, int W, float* out, d3d_stream_t stream);
 
+/*
+ * SURVEY.md §8f row N3 -- input side of a view: crop window + per-image normalisation of a decoded 8-bit image, as
+ * the dataset item builder does for every view (mvs/mvs_cas/datasets/preprocess.py:60-88 crop_input, :92-117
+ * center_image; cas_normal_eval.py:112-147).
+ *   img [h,w,channels] u8 interleaved (device); window rows y0..y0+H, columns x0..x0+W; out [channels,H,W] fp32.
+ *   mode 0 'standard': x / 255;  mode 1 'mean': (x - mean_c) / (sqrt(var_c) + 1e-8) with the population mean and
+ *   variance of channel c over the window (exact integer sums, evaluated in double, applied in float32).
+ *   sums: device workspace of 8 uint64 (zeroed by the call, stream-ordered).
+ */
+int d3d_center_image_u8(const unsigned char* img, int h, int w, int channels, int y0, int x0, int H, int W, int mode,
+                        unsigned long long* sums, float* out, d3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,80 @@
+"""Row N3, CPU side: the host camera arithmetic of the item builder against the outputs of the
+reference's own preprocess functions (tests/golden/dataset_preprocess.npz, made by tests/golden/make_golden_dataset.py),
+the matrix statements of cas_normal_eval.py:134-173 by construction, and the feature cache's bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from deep3d_aerial_amd import dataset as DS
+
+
+def test_crop_and_camera_match_reference():
+    g = load_golden("dataset_preprocess")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        img, cam = g[k + "img"], g[k + "cam"]
+        max_h, max_w = (int(v) for v in g[k + "max_hw"])
+        win = DS.crop_window(img.shape[0], img.shape[1], max_h, max_w)
+        y0, x0, H, W = DS.slice_window(img.shape[0], img.shape[1], win)
+        assert np.array_equal(img[y0:y0 + H, x0:x0 + W], g[k + "cropped"]), i
+        ccam = DS.crop_camera(cam.copy(), win[0], win[1])
+        assert np.array_equal(ccam, g[k + "crop_cam"]), i
+        assert np.array_equal(DS.scale_camera(ccam, 0.5), g[k + "scaled_cam"]), i
+    # the fixture holds the small-image case whose slice start is negative
+    assert any(g["c%d_cropped" % i].shape[0] < 32 for i in range(int(g["n_cases"])))
+
+
+def test_stage_projections_by_construction():
+    rng = np.random.default_rng(1)
+    cams = []
+    for _ in range(3):
+        cam = np.zeros((2, 4, 4), np.float32)
+        cam[0] = np.eye(4)
+        cam[0, :3, :] = rng.standard_normal((3, 4))
+        cam[1, :3, :3] = [[500, 0, 320], [0, 510, 240], [0, 0, 1]]
+        cams.append(cam)
+    pm, im = DS.stage_projections(cams)
+    for v, cam in enumerate(cams):
+        want = cam[0].copy()
+        want[:3, :4] = cam[1, :3, :3] @ cam[0, :3, :4]
+        assert np.array_equal(pm["stage3"][v], want)
+        assert np.array_equal(pm["stage2"][v][:2], want[:2] / 2) and np.array_equal(pm["stage2"][v][2:], want[2:])
+        assert np.array_equal(pm["stage1"][v][:2], want[:2] / 4) and np.array_equal(pm["stage1"][v][2:], want[2:])
+        assert np.array_equal(im["stage1"][v][:2], cam[1, :2, :3] / 4)
+    assert pm["stage1"].dtype == np.float32 and pm["stage1"].shape == (3, 4, 4)
+
+
+def test_feature_cache_is_lru_and_bounded():
+    def pyr(n):
+        return {"stage1": torch.zeros(n, dtype=torch.float32)}
+
+    c = DS.FeatureCache(max_bytes=100 * 4)
+    c.put("a", pyr(40))
+    c.put("b", pyr(40))
+    assert c.get("a") is not None  # a is now the most recent
+    c.put("c", pyr(40))            # evicts b
+    assert "b" not in c and "a" in c and "c" in c and c.bytes == 320
+    c.put("huge", pyr(1000))       # larger than the budget: not kept
+    assert "huge" not in c and len(c) == 2
+    assert c.get("zzz") is None and (c.hits, c.misses) == (1, 1)
+    c.clear()
+    assert len(c) == 0 and c.bytes == 0
+
+
+def test_extract_features_uses_the_cache():
+    calls = []
+
+    def net(x):
+        calls.append(float(x.sum()))
+        return {"stage3": x * 2}
+
+    imgs = torch.arange(2 * 3 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 3, 4, 4)
+    cache = DS.FeatureCache(1 << 20)
+    a = DS.extract_features(net, imgs, ["i0", "i1", "i2"], cache)
+    assert len(calls) == 3
+    b = DS.extract_features(net, [None, imgs[:, 1], None], ["i0", "i1", "i2"], cache)
+    assert len(calls) == 3 and all(torch.equal(x["stage3"], y["stage3"]) for x, y in zip(a, b))
+    with pytest.raises(KeyError):
+        DS.extract_features(net, [None, None, None], ["i0", "i1", "new"], cache)
+    assert len(DS.extract_features(net, imgs)) == 3 and len(calls) == 6  # no keys: every view recomputed

@@ -1,0 +1,75 @@
+"""Row N3, GPU side: crop + normalise of 8-bit images on the device against the reference's own
+center_image outputs, and the feature cache (results must not change, shared images must be featurised once)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from deep3d_aerial_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+# The reference normalises with NumPy in float32: np.var over axis (0,1) of an [h,w,3] array accumulates in float32 in
+# memory order and is off by up to 5e-6 relative on these images (measured against float64; the error depends on
+# NumPy's reduction order, not on the data alone).  The kernel's statistics are exact integer sums evaluated in
+# double, so the comparison carries the REFERENCE's rounding: values are O(1), 2e-5 absolute.
+ABS_CENTER = 2e-5
+
+
+def test_center_image_matches_reference():
+    from deep3d_aerial_amd import dataset as DS
+
+    g = load_golden("dataset_preprocess")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        img = g[k + "img"]
+        max_h, max_w = (int(v) for v in g[k + "max_hw"])
+        win = DS.slice_window(img.shape[0], img.shape[1], DS.crop_window(img.shape[0], img.shape[1], max_h, max_w))
+        got = DS.center_image(torch.from_numpy(img).cuda(), str(g[k + "mode"]), win).cpu().numpy()
+        want = g[k + "centered"].transpose(2, 0, 1)
+        assert got.shape == want.shape, i
+        assert np.abs(got - want).max() <= ABS_CENTER * max(1.0, np.abs(want).max()), (i, np.abs(got - want).max())
+
+
+def test_center_image_full_size_statistics():
+    """2752x1856x3: per-channel mean 0 and variance 1 after normalisation; 'standard' is exactly x/255."""
+    from deep3d_aerial_amd import dataset as DS
+
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (1862, 2762, 3), dtype=np.uint8)
+    win = DS.slice_window(1862, 2762, DS.crop_window(1862, 2762, 1856, 2752))
+    assert win == (3, 5, 1856, 2752)
+    d = torch.from_numpy(img).cuda()
+    out = DS.center_image(d, "mean", win)
+    assert out.shape == (3, 1856, 2752)
+    m = out.double().mean(dim=(1, 2)).cpu().numpy()
+    v = out.double().var(dim=(1, 2), unbiased=False).cpu().numpy()
+    assert np.abs(m).max() < 1e-6 and np.abs(v - 1).max() < 1e-6
+    std = DS.center_image(d, "standard", win)
+    want = (np.array(img[3:3 + 1856, 5:5 + 2752], dtype=np.float32) / 255.).transpose(2, 0, 1)  # preprocess.py:96
+    assert np.array_equal(std.cpu().numpy(), want)
+    with pytest.raises(Exception, match="Not implemented yet"):
+        DS.center_image(d, "vit", win)
+
+
+@pytest.mark.parametrize("name", ["casmvsnet", "adamvs", "msrednet"])
+def test_feature_cache_does_not_change_results(name, tmp_path):
+    """A strip whose reference views share images: with the cache every image is featurised once, and depth /
+    confidence files are byte-identical to the run without it."""
+    from deep3d_aerial_amd import predict as P
+
+    model = P.build_model(name, 64)
+    S.fill_state_dict_(model.state_dict(), 5)
+    model = model.cuda().eval()
+    ds = P.SyntheticStrip(5, 3, 64, 96, 64, seed=7)
+    calls = []
+    hook = model.feature.register_forward_hook(lambda *a: calls.append(1))
+    a = P.predict_views(model, ds, str(tmp_path / "plain"))
+    n_plain = len(calls)
+    b = P.predict_views(model, ds, str(tmp_path / "cached"), feature_cache_bytes=1 << 30)
+    hook.remove()
+    assert a == b and n_plain == 15 and len(calls) - n_plain == 5  # 5 views x 3 images vs 5 distinct images
+    assert model.feature_cache is None
+    for n in a:
+        for suffix in ("_init.pfm", "_prob.pfm", ".txt"):
+            assert (tmp_path / "plain" / (n + suffix)).read_bytes() == (tmp_path / "cached" / (n + suffix)).read_bytes()
