@@ -56,6 +56,27 @@ def main():
     for mode in ("none", "async", "sync", "async", "sync"):
         print("%-6s products: %7.1f ms per view" % (mode, run(mode)), flush=True)
 
+    # row N3: a strip whose reference views share images, items pre-built (decoded 8-bit images + cameras), whole loop
+    # = upload, crop + normalise on the device, forward, asynchronous products
+    strip = P.SyntheticStrip(a.views + 4, 5, a.w, a.h, 384, seed=3)
+    items = [strip[i] for i in range(a.views)]
+    for cache in (0, 64 << 30, 0, 64 << 30):
+        P.predict_views(model, items[:1], a.out)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        P.predict_views(model, items, a.out, feature_cache_bytes=cache)
+        torch.cuda.synchronize()
+        print("strip loop, feature cache %2d GiB: %7.1f ms per view" % (cache >> 30, (time.time() - t0) / a.views * 1e3),
+              flush=True)
+    # the reference's host-side normalisation of the same five images (preprocess.py:98-103), for scale
+    t0 = time.time()
+    for im in items[0]["images_u8"]:
+        x = im[3:3 + a.w, 5:5 + a.h].astype(np.float32)  # (the strip's images are [max_h + 6, max_w + 10])
+        var = np.var(x, axis=(0, 1), keepdims=True)
+        mean = np.mean(x, axis=(0, 1), keepdims=True)
+        _ = (x - mean) / (np.sqrt(var) + 0.00000001)
+    print("host NumPy normalisation of one item's 5 images: %.1f ms" % ((time.time() - t0) * 1e3))
+
 
 if __name__ == "__main__":
     main()
