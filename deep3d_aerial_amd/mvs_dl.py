@@ -1,0 +1,105 @@
+"""Launch of the depth-inference step and set-up of the fusion step.
+
+`MVS_Inference` keeps the reference's constructor and `run(data_folder, mvs_path)` (mvs/mvs_dl.py:27-65), but
+instead of formatting a shell command for os.system (whose exit status the reference drops, mvs_dl.py:61-65)
+
+* one GPU: the harness is imported and called in this process (`predict.main(argv)`), so an exception is an exception;
+* N GPUs: one worker process per GPU (`python -m torch.distributed.run --nproc-per-node N`, rendezvous on 127.0.0.1;
+  the reference views are sharded by rank inside predict.main), and a non-zero exit status raises.
+
+`fusion_checker(config)` / `fusion_settings(config)` build the consistency checker from ALL the FUSION thresholds of
+config.yaml: the reference reads position / depth / normal thresholds (run.py:101-108) but passes only fusion_num,
+geo_consist_num and the confidence threshold on (run.py:176), so Fuse_Depth_Map silently uses its defaults.
+"""
+import os
+import subprocess
+import sys
+
+MODELS = ("casmvsnet", "ucsnet", "msrednet", "adamvs")  # mvs_dl.py:45
+
+
+class MVS_Inference:
+    def __init__(self, max_w, max_h, view_num=5, num_depth=384, min_interval=0.1, model_type="adamvs",
+                 pretrain_weight=None, display_depth=False, n_gpus=1, extra_args=()):
+        self.max_w = max_w
+        self.max_h = max_h
+        self.view_num = view_num
+        self.num_depth = num_depth
+        self.min_interval = min_interval
+        self.pretrain_weight = pretrain_weight
+        self.display_depth = display_depth
+        self.model_type = model_type.lower()
+        self.n_gpus = int(n_gpus)
+        self.extra_args = list(extra_args)
+
+    def default_weight(self):
+        """mvs_dl.py:46-58: the last *.ckpt under mvs/mvs_cas/checkpoints/<model>/whu_omvs, if that folder exists."""
+        path = "mvs/mvs_cas/checkpoints/{}/whu_omvs".format(self.model_type)
+        found = None
+        if os.path.isdir(path):
+            for fname in os.listdir(path):
+                if os.path.splitext(fname)[-1] == ".ckpt":
+                    found = os.path.join(path, fname)
+        return found
+
+    def argv(self, data_folder, mvs_path):
+        """The flags mvs_dl.py:61-63 formats, as an argument vector."""
+        weight = self.pretrain_weight if self.pretrain_weight is not None else self.default_weight()
+        args = ["--data_folder=%s" % data_folder, "--output_folder=%s" % mvs_path, "--model=%s" % self.model_type,
+                "--view_num=%d" % self.view_num, "--numdepth=%d" % self.num_depth, "--max_w=%d" % self.max_w,
+                "--max_h=%d" % self.max_h, "--min_interval=%s" % self.min_interval, "--display=%s" % self.display_depth]
+        if weight is not None:
+            args.append("--loadckpt=%s" % weight)
+        return args + self.extra_args
+
+    def run(self, data_folder, mvs_path):
+        if self.model_type not in MODELS:
+            raise Exception("{}? Not implemented yet!".format(self.model_type))
+        parent = os.path.dirname(mvs_path)
+        if parent and not os.path.exists(parent):
+            os.mkdir(parent)
+        argv = self.argv(data_folder, mvs_path)
+        if self.n_gpus <= 1:
+            from . import predict
+
+            predict.main(argv)  # errors propagate as exceptions
+            return 0
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % self.n_gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-m", "deep3d_aerial_amd.predict"] + argv
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        res = subprocess.run(cmd, env=env)
+        if res.returncode != 0:
+            raise RuntimeError("depth inference failed on %d GPUs (exit status %d)" % (self.n_gpus, res.returncode))
+        return 0
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def fusion_settings(config):
+    """The FUSION block of config.yaml (run.py:98-108) as keyword arguments, every threshold included."""
+    f = config["FUSION"] if "FUSION" in config else config
+    return {"run_depth_fusion": bool(f.get("run_depth_fusion", True)), "fusion_num": int(f.get("fusion_num", 10)),
+            "min_geo_consist_num": int(f.get("geo_consist_num", 4)),
+            "photometric_threshold": float(f.get("photomatric_threshold", 0.2)),
+            "position_threshold": float(f.get("position_threshold", 1)),
+            "depth_threshold": float(f.get("depth_threshold", 0.01)),
+            "normal_threshold": float(f.get("normal_threshold", 90.0)), "pc_format": f.get("pc_format", "ply")}
+
+
+def fusion_checker(config):
+    """fuse.ConsistencyChecker with the thresholds of config.yaml (fusion_3d_normal.py:89-91 argument order:
+    position, depth, normal [degrees], confidence = photometric threshold)."""
+    from . import fuse
+
+    s = fusion_settings(config)
+    return fuse.ConsistencyChecker(s["position_threshold"], s["depth_threshold"], s["normal_threshold"],
+                                   s["photometric_threshold"])

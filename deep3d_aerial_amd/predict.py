@@ -383,7 +383,8 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
     return done
 
 
-def main(argv=None):
+def parse_args(argv=None):
+    """The flags mvs/mvs_dl.py:61-63 formats (predict.py:30-58), plus --synthetic_items."""
     ap = argparse.ArgumentParser(description="plane-sweep depth inference (predict.py-compatible flags)")
     ap.add_argument("--model", default="adamvs")
     ap.add_argument("--data_folder", default=None)
@@ -398,7 +399,11 @@ def main(argv=None):
     ap.add_argument("--depth_inter_r", type=str, default="4,2,1")
     ap.add_argument("--display", default="False")
     ap.add_argument("--synthetic_items", type=int, default=0, help="run on a synthetic block of this many views")
-    a = ap.parse_args(argv)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    a = parse_args(argv)
     rank, world = sharding.init_from_env()
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     model = build_model(a.model, a.numdepth, [int(x) for x in a.ndepths.split(",")],

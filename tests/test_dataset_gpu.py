@@ -73,3 +73,18 @@ def test_feature_cache_does_not_change_results(name, tmp_path):
     for n in a:
         for suffix in ("_init.pfm", "_prob.pfm", ".txt"):
             assert (tmp_path / "plain" / (n + suffix)).read_bytes() == (tmp_path / "cached" / (n + suffix)).read_bytes()
+
+
+def test_in_process_launch_writes_products(tmp_path):
+    """Row N4: MVS_Inference.run (mvs/mvs_dl.py:39-65) calls the harness in this process; products land in mvs_path."""
+    from deep3d_aerial_amd import mvs_dl
+
+    out = tmp_path / "block" / "mvs"
+    (tmp_path / "block").mkdir()
+    inf = mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet",
+                               extra_args=["--synthetic_items=2"])
+    assert inf.run("/unused", str(out)) == 0
+    assert sorted(p.name for p in out.iterdir()) == ["view_0000.txt", "view_0000_init.pfm", "view_0000_prob.pfm",
+                                                     "view_0001.txt", "view_0001_init.pfm", "view_0001_prob.pfm"]
+    with pytest.raises(SystemExit):  # no dataset reader for real blocks in this image: reported, not swallowed
+        mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet").run("/unused", str(out))

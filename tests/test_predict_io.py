@@ -49,3 +49,48 @@ def test_synthetic_block_item_layout():
     assert s["imgs"].shape == (3, 3, 64, 96) and s["depth_values"].shape == (2,)
     p1, p3 = s["proj_matrices"]["stage1"], s["proj_matrices"]["stage3"]
     assert np.allclose(p1[:, :2], p3[:, :2] / 4) and np.array_equal(p1[:, 2:], p3[:, 2:])
+
+
+# ---- row N4: launch of the inference step and fusion set-up (mvs/mvs_dl.py:27-65, run.py:98-108,176) ----------------
+def test_mvs_inference_arguments_and_errors(tmp_path):
+    from deep3d_aerial_amd import mvs_dl
+
+    inf = mvs_dl.MVS_Inference(768, 384, view_num=3, num_depth=64, model_type="CasMVSNet", pretrain_weight="w.ckpt")
+    argv = inf.argv("/data/block", str(tmp_path / "mvs"))
+    assert argv[:3] == ["--data_folder=/data/block", "--output_folder=%s" % (tmp_path / "mvs"), "--model=casmvsnet"]
+    assert "--view_num=3" in argv and "--numdepth=64" in argv and "--max_w=768" in argv and "--max_h=384" in argv
+    assert "--min_interval=0.1" in argv and "--display=False" in argv and "--loadckpt=w.ckpt" in argv
+    a = predict.parse_args(argv)  # the harness accepts exactly what the launcher formats
+    assert (a.model, a.view_num, a.numdepth, a.max_w, a.max_h, a.loadckpt) == ("casmvsnet", 3, 64, 768, 384, "w.ckpt")
+    with pytest.raises(Exception, match="Not implemented yet"):
+        mvs_dl.MVS_Inference(768, 384, model_type="rednet").run("/data/block", str(tmp_path / "x" / "mvs"))
+
+
+def test_multi_rank_launch_propagates_failure(tmp_path):
+    """N > 1: one worker per rank through torch.distributed.run; a failing worker raises here instead of being
+    dropped like os.system's status (mvs_dl.py:65).  The workers fail by design: no GPU / no dataset reader."""
+    from deep3d_aerial_amd import mvs_dl
+
+    inf = mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet", n_gpus=2)
+    with pytest.raises(RuntimeError, match="exit status"):
+        inf.run("/nonexistent", str(tmp_path / "mvs"))
+
+
+def test_fusion_settings_honour_every_threshold():
+    import yaml
+    from deep3d_aerial_amd import mvs_dl
+
+    cfg = yaml.safe_load("""
+FUSION:
+  run_depth_fusion: true
+  fusion_num: 7
+  geo_consist_num: 3
+  photomatric_threshold: 0.35
+  position_threshold: 0.5
+  depth_threshold: 0.02
+  normal_threshold: 30.0
+  pc_format: "ply"
+""")
+    s = mvs_dl.fusion_settings(cfg)
+    assert (s["fusion_num"], s["min_geo_consist_num"], s["photometric_threshold"]) == (7, 3, 0.35)
+    assert (s["position_threshold"], s["depth_threshold"], s["normal_threshold"]) == (0.5, 0.02, 30.0)
