@@ -33,6 +33,10 @@
 // Nothing is reshaped into a GEMM: this is HBM-write-bound streaming work with an LDS-fed
 // gather, not MFMA work.
 #include "common.h"
+
+#include <map>
+#include <mutex>
+#include <utility>
 #include "sweep_params.h"
 
 #include <cstdlib>
@@ -71,6 +75,7 @@ struct TiledArgs {
     int cap_floats;  // floats available for the rings
     int nseg;        // segments along depth
     int tiles_x, tiles_y;
+    const float* cl;  // channel-last copy of the source maps [view][group][h*w][CH] (pack_channel_last_kernel), or null
     unsigned long long* tstats;  // debug timing (cycles, wave 0): [0] prologue [1] barrierA+write+barrierB [2] issue [3] compute [4] total
     unsigned* stats;  // debug (D3D_TILED_STATS): [0] ring wgs [1] fallback wgs [2] sum m [3] sum nsteps [4] sum ring floats [5] overflow items
 };
@@ -583,8 +588,11 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         long long dsel = 0;
 #pragma unroll
         for (int i = 1; i < NSRC; ++i) dsel = (vi == i) ? fdelta[i] : dsel;
-        I.g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.feats[1]) + dsel) + (size_t)c0 * plane +
-              (ok ? sy * w + sx : 0);
+        if (a.cl)  // one position's CH channels are contiguous: 16-byte loads
+            I.g = a.cl + ((size_t)(vi * a.ngroups + grp) * plane + (size_t)(ok ? sy * w + sx : 0)) * CH;
+        else
+            I.g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.feats[1]) + dsel) + (size_t)c0 * plane +
+                  (ok ? sy * w + sx : 0);
         unsigned c = (unsigned)((e6 & 0xffff) + cx), r = (unsigned)((e6 >> 16) + cy);
         c = min(c, c - (unsigned)RWv);
         r = min(r, r - (unsigned)RHv);
@@ -636,13 +644,18 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             for (int j = 0; j < PFD; ++j) {
                 const int it = it0 + snw * j;
                 Item I = item(it < nitems ? it * 64 + lane : T, T, rb, pst16);
+                if (a.cl) {
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
-                    pf[j][q][0] = g[0];
-                    pf[j][q][1] = g[plane];
-                    pf[j][q][2] = g[2 * plane];
-                    pf[j][q][3] = g[3 * plane];
+                    for (int q = 0; q < Q; ++q) pf[j][q] = reinterpret_cast<const f4*>(I.g)[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
+                        pf[j][q][0] = g[0];
+                        pf[j][q][1] = g[plane];
+                        pf[j][q][2] = g[2 * plane];
+                        pf[j][q][3] = g[3 * plane];
+                    }
                 }
                 pmeta[j] = I.meta;
                 pgeo[j] = I.geo;
@@ -682,7 +695,6 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         }
         if (ltiming && lane == 0) {
             atomicAdd(a.tstats + 2, (unsigned long long)lt_bar);
-            atomicAdd(a.tstats + 5, (unsigned long long)lt_desc);
             atomicAdd(a.tstats + 6, (unsigned long long)lt_issue);
             atomicAdd(a.tstats + 7, (unsigned long long)lt_write);
         }
@@ -764,7 +776,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     if (ring) stage(0, wave, NCOMP + NLOADW);  // initial window: every wave of the workgroup stages
 #endif
     const bool timing = a.tstats != nullptr && wave == 0;
-    long long t_w = 0, t_c = 0, t_mark = 0;
+    long long t_w = 0, t_w0 = 0, t_c = 0, t_mark = 0;
     if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
     for (int k = 0; k < nsteps; ++k) {
         if (ring) {
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #else
             __syncthreads();  // barrier k: rings hold window(k)
 #endif
-            if (timing) { t_mark = clock64(); t_w += t_mark - ta; }
+            if (timing) { t_mark = clock64(); t_w += t_mark - ta; if (k == 0) t_w0 = t_mark - ta; }
         }
         Win W[NSRC];
 #pragma unroll
@@ -875,12 +887,59 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     }
     if (timing && lane == 0) {
         atomicAdd(a.tstats + 1, (unsigned long long)t_w);
+        atomicAdd(a.tstats + 5, (unsigned long long)t_w0);  // wait for the initial window (first barrier)
         atomicAdd(a.tstats + 3, (unsigned long long)t_c);
         atomicAdd(a.tstats + 4, (unsigned long long)(clock64() - t_start));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
+// Channel-last copy of the source maps for the loaders: [view][group][position][CH].  A loader lane then fetches the
+// CH channels of a ring position with CH/4 16-byte loads instead of CH 4-byte loads from CH different planes (the
+// staging waves are bound by the number of VMEM instructions they issue, not by bytes).  One extra read + write of
+// the source maps per launch (0.33 GB next to 15.7 GB of output at config 2).
+struct PackArgs {
+    const float* src[D3D_MAX_VIEWS];
+};
+template <int CH>
+__global__ __launch_bounds__(256) void pack_channel_last_kernel(PackArgs pa, int ngroups, long plane, float* __restrict__ out) {
+    // thread = (position, quad): lanes 4k..4k+3 write the CH*4 contiguous bytes of one position (CH = 16);
+    // for a fixed channel, every CH/4-th lane reads consecutive positions
+    constexpr int Q = CH / 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pos = t / Q;
+    const int q = (int)(t - pos * Q);
+    if (pos >= plane) return;
+    const int vg = blockIdx.y;  // view * ngroups + group
+    const int v = vg / ngroups, g = vg - v * ngroups;
+    const float* __restrict__ s = pa.src[v] + ((size_t)g * CH + 4 * q) * plane + pos;
+    f4 x;
+    x[0] = s[0]; x[1] = s[plane]; x[2] = s[2 * plane]; x[3] = s[3 * plane];
+    reinterpret_cast<f4*>(out + ((size_t)vg * plane + pos) * CH)[q] = x;
+}
+
+// Grow-only workspace per (device, stream): calls on one stream are ordered, so they can share it.
+static float* cl_workspace(hipStream_t stream, size_t bytes) {
+    struct Buf { float* p; size_t n; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = pool[{dev, stream}];
+    if (b.n < bytes) {
+        if (b.p) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;  // earlier launches still read it
+            (void)hipFree(b.p);
+            b.p = nullptr;
+            b.n = 0;
+        }
+        if (hipMalloc(&b.p, bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.n = bytes;
+    }
+    return b.p;
+}
+
 template <int MODE, int NSRC, int CH>
 static int launch_one(const SweepParams& p, hipStream_t stream) {
     using L = Lds<CH, NSRC>;
@@ -913,6 +972,25 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     if (nblk > 0x7fffffffL) return D3D_ERR_UNSUPPORTED;
     a.stats = nullptr;
     a.tstats = nullptr;
+    a.cl = nullptr;
+    {
+        // worth it when the sweep is deep: the copy costs 2 x (n_src*C*h*w*4) bytes of traffic
+        int use_cl = p.D >= 96;
+        if (const char* e = getenv("D3D_TILED_CL")) use_cl = atoi(e);
+        if (use_cl) {
+            const size_t bytes = (size_t)p.n_src * p.C * p.h * p.w * sizeof(float);
+            float* ws = cl_workspace(stream, bytes);
+            if (ws) {
+                PackArgs pa = {};
+                for (int i = 0; i < p.n_src; ++i) pa.src[i] = p.feats[i + 1];
+                const long plane = (long)p.h * p.w;
+                hipLaunchKernelGGL(pack_channel_last_kernel<CH>, dim3((unsigned)ceil_div(plane * (CH / 4), 256), p.n_src * a.ngroups),
+                                   dim3(256), 0, stream, pa, a.ngroups, plane, ws);
+                D3D_LAUNCH_CHECK("pack_channel_last_kernel launch");
+                a.cl = ws;
+            }
+        }
+    }
     if (getenv("D3D_TILED_STATS")) {  // debug only: synchronous, allocates
         hipMalloc(&a.stats, 8 * sizeof(unsigned) + 8 * sizeof(unsigned long long));
         hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 8 * sizeof(unsigned long long));
@@ -925,9 +1003,9 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         unsigned long long ht[8];
         hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
         hipMemcpy(ht, a.tstats, sizeof(ht), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f | compute %.0f | total %.0f || loader 0: barrier wait %.0f | descriptors %.0f | decode+issue %.0f | wait+write %.0f\n",
-                ht[0] / (double)nblk, ht[1] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk, ht[2] / (double)nblk,
-                ht[5] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
+        fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f (initial window %.0f) | compute %.0f | total %.0f || loader 0: barrier wait %.0f | decode+issue %.0f | wait+write %.0f\n",
+                ht[0] / (double)nblk, ht[1] / (double)nblk, ht[5] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk,
+                ht[2] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
         fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
                 CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
                 a.cap_floats / L::STRIDE, hs[5], a.dseg);

@@ -1,0 +1,108 @@
+// Microbenchmark: do ds_read_b128 traffic and VALU work of the SAME waves overlap on gfx950?
+// Models the hot loop of sweep_tiled_kernel: 8 waves per CU (2 per SIMD), per "unit" a wave requests 4 x
+// ds_read_b128 (the four bilinear taps of 4 channels, 80-byte position stride) one unit ahead and then runs NV
+// dependent-free FMAs on the unit that has landed.  Prints cycles per unit for LDS only, VALU only and both:
+// max(...) means the two pipes overlap, the sum means they serialise.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int NV, bool USE_LDS, int DEPTH, int MM = 0>
+__global__ __launch_bounds__(512) void k(float* out, int iters, int stride_f) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < 32 * 1024; i += 512) lds[i] = (float)(i & 255) * 0.001f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int RW = 40;
+    f4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    f4 t[DEPTH + 1][4];
+    const f4* lds4 = reinterpret_cast<const f4*>(lds);  // indices in 16-byte units: ds_read_b128 needs provable alignment
+    const int s4 = stride_f >> 2;
+    auto addr = [&](int it) { return ((lane + it * 5 + wave * 97) & 255) * s4 + (it & 3); };
+    auto request = [&](int it, f4 (&d)[4]) {
+        if (USE_LDS) {
+            const int a = addr(it);
+            d[0] = lds4[a];
+            d[2] = lds4[a + RW * s4];
+            if (MM == 0) {
+                d[1] = lds4[a + s4];
+                d[3] = lds4[a + RW * s4 + s4];
+            } else {
+                d[1] = d[0];
+                d[3] = d[2];
+                if (MM >= 2 && (lane & (MM == 2 ? 15 : 3)) == 0) {  // "broken" lanes fetch their own east taps
+                    d[1] = lds4[a + s4];
+                    d[3] = lds4[a + RW * s4 + s4];
+                }
+            }
+        } else {
+            const float v = (float)(it + lane);
+            d[0] = (f4){v, v, v, v}; d[1] = d[0] + 1.0f; d[2] = d[0] + 2.0f; d[3] = d[0] + 3.0f;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) request(j, t[j]);
+    const float w0 = 0.25f + lane * 1e-4f, w1 = 0.26f, w2 = 0.24f, w3 = 0.25f;
+    for (int it = 0; it < iters; it += DEPTH + 1) {
+#pragma unroll
+        for (int j = 0; j <= DEPTH; ++j) {
+            request(it + j + DEPTH, t[(j + DEPTH) % (DEPTH + 1)]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the blend (the scheduler sinks it otherwise)
+            f4 (&c)[4] = t[j];
+            asm volatile("" : "+v"(c[3]));      // LDS returns in order: one wait per unit
+            // NV wave-instructions: blend (4 per channel) + accumulate, repeated
+            f4 v = c[0] * w0;
+#pragma unroll
+            for (int r = 0; r < NV / 4; ++r) {
+                const int s = r & 3;
+                if (s == 0) v = c[1] * w1 + v;
+                else if (s == 1) v = c[2] * w2 + v;
+                else if (s == 2) { v = c[3] * w3 + v; acc0 += v; }
+                else { acc1 = v * v + acc1; v = c[0] * w0; }
+            }
+            acc0 += v;
+        }
+    }
+    f4 s = acc0 + acc1;
+    out[blockIdx.x * 512 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <int NV, bool USE_LDS, int DEPTH, int MM = 0>
+static double run(float* out, int iters, int stride_f) {
+    auto kern = k<NV, USE_LDS, DEPTH, MM>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 128 * 1024, 0, out, iters, stride_f);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    return ms * 1e-3 * 2.4e9 / iters;  // cycles (at 2.4 GHz) per unit per wave, all 8 waves of a CU concurrent
+}
+
+template <int NV>
+static void row(float* out, int iters, int stride_f) {
+    const double both1 = run<NV, true, 1>(out, iters, stride_f), both2 = run<NV, true, 2>(out, iters, stride_f);
+    const double valu = run<NV, false, 1>(out, iters, stride_f);
+    const double h2 = run<NV, true, 1, 1>(out, iters, stride_f), m16 = run<NV, true, 1, 2>(out, iters, stride_f),
+                 m4 = run<NV, true, 1, 3>(out, iters, stride_f);
+    printf("NV=%2d  VALU only %6.1f | 4 reads depth1 %6.1f depth2 %6.1f | 2 reads %6.1f | 2 + 2 by 1/16 lanes %6.1f | 2 + 2 by 1/4 lanes %6.1f cycles/unit\n",
+           NV, valu, both1, both2, h2, m16, m4);
+}
+
+int main() {
+    float* out; hipMalloc(&out, 256 * 512 * sizeof(float));
+    const int iters = 60000;
+    for (int stride_f : {20, 16}) {
+        printf("position stride %d floats (%s)\n", stride_f, stride_f == 20 ? "padded: conflict-free b128" : "unpadded");
+        row<0>(out, iters, stride_f);
+        row<16>(out, iters, stride_f);
+        row<32>(out, iters, stride_f);
+        row<48>(out, iters, stride_f);
+        row<64>(out, iters, stride_f);
+        row<96>(out, iters, stride_f);
+    }
+    return 0;
+}
