@@ -776,6 +776,8 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     if (ring) stage(0, wave, NCOMP + NLOADW);  // initial window: every wave of the workgroup stages
 #endif
     const bool timing = a.tstats != nullptr && wave == 0;
+    const bool wtiming = a.tstats != nullptr;  // every compute wave: its own barrier wait
+    long long t_ww = 0;
     long long t_w = 0, t_w0 = 0, t_c = 0, t_mark = 0;
     if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
     for (int k = 0; k < nsteps; ++k) {
@@ -785,7 +787,10 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #if D3D_DECOUPLE
             step_wait(ldsi + L::CNT + k, NLOADW);  // rings hold window(k)
 #else
+            long long tw0 = 0;
+            if (wtiming) tw0 = clock64();
             __syncthreads();  // barrier k: rings hold window(k)
+            if (wtiming && k > 0) t_ww += clock64() - tw0;
 #endif
             if (timing) { t_mark = clock64(); t_w += t_mark - ta; if (k == 0) t_w0 = t_mark - ta; }
         }
@@ -885,6 +890,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         if (ring) step_signal(ldsi + L::CNT + MAXSTEPS + k, lane);  // this wave has left step k
 #endif
     }
+    if (wtiming && lane == 0) atomicAdd(a.tstats + 8 + wave, (unsigned long long)t_ww);
     if (timing && lane == 0) {
         atomicAdd(a.tstats + 1, (unsigned long long)t_w);
         atomicAdd(a.tstats + 5, (unsigned long long)t_w0);  // wait for the initial window (first barrier)
@@ -992,20 +998,23 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         }
     }
     if (getenv("D3D_TILED_STATS")) {  // debug only: synchronous, allocates
-        hipMalloc(&a.stats, 8 * sizeof(unsigned) + 8 * sizeof(unsigned long long));
-        hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 8 * sizeof(unsigned long long));
+        hipMalloc(&a.stats, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
+        hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
         a.tstats = reinterpret_cast<unsigned long long*>(a.stats + 8);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(THREADS), LDS_BYTES, stream, p, a);
     D3D_LAUNCH_CHECK("sweep_tiled_kernel launch");
     if (a.stats) {
         unsigned hs[8];
-        unsigned long long ht[8];
+        unsigned long long ht[24];
         hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
         hipMemcpy(ht, a.tstats, sizeof(ht), hipMemcpyDeviceToHost);
         fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f (initial window %.0f) | compute %.0f | total %.0f || loader 0: barrier wait %.0f | decode+issue %.0f | wait+write %.0f\n",
                 ht[0] / (double)nblk, ht[1] / (double)nblk, ht[5] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk,
                 ht[2] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
+        fprintf(stderr, "[d3d tiled timing] barrier wait after the first, per compute wave (pixel rows, depth sub-range):");
+        for (int wv = 0; wv < NCOMP; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
                 CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
                 a.cap_floats / L::STRIDE, hs[5], a.dseg);

@@ -27,6 +27,8 @@ for f in glob.glob(out+"/trace/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if 'sweep_tiled' in r['Name']:
             res['kernel_stats']={k:r[k] for k in r}
+        if 'pack_channel_last' in r['Name']:
+            res['pack_kernel_stats']={k:r[k] for k in r}
 json.dump(res, open(out+"/summary.json","w"), indent=1)
 print(json.dumps(res)[:1500])
 PY
