@@ -10,12 +10,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libfusion_oracle.so")
+# D3D_FUSION_ORACLE_SO: a pre-built variant (the -fsanitize=address,undefined build of `make -C oracle asan`)
+_SO = os.environ.get("D3D_FUSION_ORACLE_SO") or os.path.join(_HERE, "libfusion_oracle.so")
 _lib = None
 
 
 def build(force=False):
     src = os.path.join(_HERE, "fusion_oracle.c")
+    if os.environ.get("D3D_FUSION_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libfusion_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO

@@ -162,3 +162,26 @@ def test_predict_views_products_feed_fusion(tmp_path, fuse):
         assert torch.equal(on_disk, depth)
         assert np.array_equal(P.load_pfm(str(tmp_path / (name + "_prob.pfm")))[0], host(prob))
         assert (tmp_path / (name + ".txt")).exists()
+
+
+def test_check_poisoned_inputs_match_oracle(fuse, oracle):
+    """Non-finite and absurd depths (NaN, inf, 1e30, negative, denormal) in either map: no fault, the same index
+    arithmetic as the oracle (float -> int64 of a non-finite value gives INT64_MIN, indices wrap), identical outputs."""
+    ref, srcs = S.make_fusion_scene(64, 80, 1, seed=31)
+    s = srcs[0]
+    rng = np.random.default_rng(7)
+    poison = np.array([np.nan, np.inf, -np.inf, 1e30, -5.0, 1e-40, 0.0, 3e9], np.float32)
+    for arr in (ref["depth"], s["depth"]):
+        idx = rng.integers(0, arr.size, 400)
+        arr.reshape(-1)[idx] = poison[rng.integers(0, len(poison), 400)]
+    s["normal"].reshape(-1, 3)[rng.integers(0, s["normal"].shape[0] * s["normal"].shape[1], 50)] = 0.0  # zero normals: 0/0
+    with np.errstate(all="ignore"):
+        want = oracle.fusion.consistency_check(ref["depth"], ref["normal"], ref["K"], ref["E"], s["depth"], s["normal"],
+                                               s["K"], s["E"], ref["confidence"], 1.0, 0.01, 10.0, 0.2)
+    got = fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2).check(dev(ref["depth"]), dev(ref["normal"]), ref["K"], ref["E"],
+                                                               dev(s["depth"]), dev(s["normal"]), s["K"], s["E"],
+                                                               dev(ref["confidence"]))
+    torch.cuda.synchronize()
+    for name, a, b in zip(("mask", "depth_reprojected", "depth_src", "xyz_world_src", "angle"), got, want):
+        assert np.array_equal(host(a), b, equal_nan=(name != "mask")), name
+    assert want[0].any()
