@@ -335,6 +335,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         }
     }
     __syncthreads();
+    const long long t_range = clock64();
 
     // --- plan every step of the segment ---------------------------------------------------------
     // P1: wave (candidate, view) computes, one lane per step, that view's windows for the candidate
@@ -345,8 +346,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     // candidate c steps by NSUB*4, NSUB*2, NSUB, NSUB/2 planes (the last leaves half the sub-waves idle,
     // which is still far better than gathering from global memory)
     auto cand_planes = [](int c) { return c < 3 ? NSUB * (4 >> c) : max(NSUB / 2, 1); };
-    for (int wk = wave; wk < NCAND * NSRC; wk += NWAVES) {
-        const int cand = wk / NSRC, vsel = wk % NSRC;
+    auto candidate_windows = [&](int cand, int vsel) {
         {
             const int SPc = cand_planes(cand);
             const int nstepc = (nplanes + SPc - 1) / SPc;
@@ -405,11 +405,16 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 hd[0] = RWc; hd[1] = RHc; hd[2] = badc; hd[3] = nstepc;
             }
         }
-    }
+    };
+    // the three regular candidates first (one round: NWAVES = 3 * 4 waves); the half-step candidate only when none
+    // of them fits (rare: very wide plane spacing)
+    constexpr int NCAND1 = NCAND - 1;
+    for (int wk = wave; wk < NCAND1 * NSRC; wk += NWAVES) candidate_windows(wk / NSRC, wk % NSRC);
     __syncthreads();
-    if (wave == 0) {
+    const long long t_p1 = clock64();
+    auto plan_tables = [&](int cbeg, int cend) {  // wave 0: first candidate in [cbeg, cend) whose rings fit
         int mode = 0, sp_sel = NSUB, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
-        for (int cand = 0; cand < NCAND && !mode; ++cand) {
+        for (int cand = cbeg; cand < cend && !mode; ++cand) {
             const int nsteps = ldsi[CHD + (cand * NSRC) * 4 + 3];
             const bool act = lane < nsteps;
             int wx0[NSRC], wy0[NSRC], ww[NSRC], wh[NSRC], RW[NSRC], RH[NSRC];
@@ -525,8 +530,22 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             ldsi[L::HDR + 2] = nsteps_sel;
         }
         for (int i = lane; i < 2 * MAXSTEPS; i += 64) ldsi[L::CNT + i] = 0;
-    }
+    };
+    if (wave == 0) plan_tables(0, NCAND1);
     __syncthreads();
+    if (rfl(ldsi[L::HDR + 0]) == 0) {  // (workgroup-uniform)
+        __syncthreads();  // everyone has read the header before wave 0 rewrites it
+        for (int wk = wave; wk < NSRC; wk += NWAVES) candidate_windows(NCAND1, wk);
+        __syncthreads();
+        if (wave == 0) plan_tables(NCAND1, NCAND);
+        __syncthreads();
+    }
+    if (a.tstats && tid == 0) {  // prologue phases: depth range | windows of every candidate | plan + rectangle tables
+        const long long t_p2 = clock64();
+        atomicAdd(a.tstats + 16, (unsigned long long)(t_range - t_start));
+        atomicAdd(a.tstats + 17, (unsigned long long)(t_p1 - t_range));
+        atomicAdd(a.tstats + 18, (unsigned long long)(t_p2 - t_p1));
+    }
     const int ring = rfl(ldsi[L::HDR + 0]);
     const int SP = rfl(ldsi[L::HDR + 1]);  // planes per step
     const int nsteps = rfl(ldsi[L::HDR + 2]);
@@ -1012,6 +1031,8 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f (initial window %.0f) | compute %.0f | total %.0f || loader 0: barrier wait %.0f | decode+issue %.0f | wait+write %.0f\n",
                 ht[0] / (double)nblk, ht[1] / (double)nblk, ht[5] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk,
                 ht[2] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
+        fprintf(stderr, "[d3d tiled timing] prologue phases: depth range %.0f | candidate windows %.0f | plan tables %.0f (rest: per-lane constants)\n",
+                ht[16] / (double)nblk, ht[17] / (double)nblk, ht[18] / (double)nblk);
         fprintf(stderr, "[d3d tiled timing] barrier wait after the first, per compute wave (pixel rows, depth sub-range):");
         for (int wv = 0; wv < NCOMP; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
         fprintf(stderr, "\n");
