@@ -283,9 +283,10 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     // concurrently overlap in its L2 instead of each being fetched from HBM.
     const int ty = b % a.tiles_y;
     const int seg = (b / a.tiles_y) % a.nseg;
-    const int grp = (b / (a.tiles_y * a.nseg)) % a.ngroups;
-    const int tx = b / (a.tiles_y * a.nseg * a.ngroups);
-    const int c0 = grp * CH;
+    const int tx = b / (a.tiles_y * a.nseg);
+    // The workgroup sweeps ALL channel groups of its (patch, depth segment), one after the other: the plan (windows,
+    // step size, staging rectangles) does not depend on the channels, so the prologue is paid once.
+    int grp = 0, c0 = 0;  // current channel group / its first channel
     const int x0 = tx * TW, y0 = ty * TH;
     const int ds = seg * a.dseg;
     const int de = min(ds + a.dseg, D);
@@ -687,9 +688,15 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 
     // Barrier k separates {compute step k-1, stage delta k} from {compute step k, stage delta k+1}.
     // Both roles execute exactly nsteps barriers in ring mode and none in gather mode.
+#if D3D_DECOUPLE
+#error "the counter hand-off experiment predates the channel-group loop (its counters are per step, not per pass)"
+#endif
     if (loader) {
         // (Raising the loaders' issue priority with s_setprio was measured: their decode time halves,
         // but the compute waves lose the same slots and the kernel gets 5 % slower -- left at default.)
+        for (int gi = 0; gi < a.ngroups; ++gi) {
+        grp = gi;
+        c0 = gi * CH;
         if (ring) {
             stage(0, STAGE0_ALL_EFF ? wave : lw, STAGE0_ALL_EFF ? NCOMP + NLOADW : NLOADW);
 #if D3D_DECOUPLE
@@ -711,6 +718,8 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 if (k + 1 < nsteps) stage(k + 1, lw, NLOADW);
             }
 #endif
+        }
+        __syncthreads();  // end of the pass: the rings may be overwritten with the next group's first window
         }
         if (ltiming && lane == 0) {
             atomicAdd(a.tstats + 2, (unsigned long long)lt_bar);
@@ -734,15 +743,17 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         rbase[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 2]) : L::DATA;
     }
     f4 r[Q];
-    if (MODE != MODE_WARP) {
+    auto load_reference = [&]() {
+        if (MODE != MODE_WARP) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
+            for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
-                r[q][k] = valid ? t : 0.0f;
-            }
-    }
+                for (int k = 0; k < 4; ++k) {
+                    float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
+                    r[q][k] = valid ? t : 0.0f;
+                }
+        }
+    };
     float vw[NSRC];
     float rden = 0.0f;
     if (MODE == MODE_WEIGHTED) {
@@ -799,18 +810,18 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     long long t_ww = 0;
     long long t_w = 0, t_w0 = 0, t_c = 0, t_mark = 0;
     if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+    grp = gi;
+    c0 = gi * CH;
+    load_reference();
     for (int k = 0; k < nsteps; ++k) {
         if (ring) {
             long long ta = 0;
             if (timing) ta = clock64();
-#if D3D_DECOUPLE
-            step_wait(ldsi + L::CNT + k, NLOADW);  // rings hold window(k)
-#else
             long long tw0 = 0;
             if (wtiming) tw0 = clock64();
             __syncthreads();  // barrier k: rings hold window(k)
             if (wtiming && k > 0) t_ww += clock64() - tw0;
-#endif
             if (timing) { t_mark = clock64(); t_w += t_mark - ta; if (k == 0) t_w0 = t_mark - ta; }
         }
         Win W[NSRC];
@@ -905,9 +916,9 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                 store_sbase(uniform64(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
         }
         if (timing) t_c += clock64() - t_mark;
-#if D3D_DECOUPLE
-        if (ring) step_signal(ldsi + L::CNT + MAXSTEPS + k, lane);  // this wave has left step k
-#endif
+    }
+    __syncthreads();  // end of the pass (matches the loaders')
+    if (timing) t_mark = clock64();
     }
     if (wtiming && lane == 0) atomicAdd(a.tstats + 8 + wave, (unsigned long long)t_ww);
     if (timing && lane == 0) {
@@ -993,7 +1004,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     while (tiles * nseg < 4096 && nseg * 2 <= ceil_div(p.D, 32)) nseg *= 2;
     a.dseg = ceil_div(p.D, nseg);
     a.nseg = ceil_div(p.D, a.dseg);
-    const long nblk = tiles * a.nseg;
+    const long nblk = (long)a.tiles_x * a.tiles_y * a.nseg;  // a workgroup sweeps every channel group of its patch
     if (nblk > 0x7fffffffL) return D3D_ERR_UNSUPPORTED;
     a.stats = nullptr;
     a.tstats = nullptr;
