@@ -6,11 +6,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ int g_scale_q8 = 256;  // source positions per pixel, 8.8 fixed point (skips when > 256, repeats when < 256)
 
-template <int NV, bool USE_LDS, int DEPTH, int MM = 0>
-__global__ __launch_bounds__(512) void k(float* out, int iters, int stride_f) {
+template <int NV, bool USE_LDS, int DEPTH, int MM = 0, int NT = 512>
+__global__ __launch_bounds__(NT) void k(float* out, int iters, int stride_f) {
     extern __shared__ float lds[];
-    for (int i = threadIdx.x; i < 32 * 1024; i += 512) lds[i] = (float)(i & 255) * 0.001f;
+    for (int i = threadIdx.x; i < 32 * 1024; i += NT) lds[i] = (float)(i & 255) * 0.001f;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int RW = 40;
@@ -18,7 +19,8 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int stride_f) {
     f4 t[DEPTH + 1][4];
     const f4* lds4 = reinterpret_cast<const f4*>(lds);  // indices in 16-byte units: ds_read_b128 needs provable alignment
     const int s4 = stride_f >> 2;
-    auto addr = [&](int it) { return ((lane + it * 5 + wave * 97) & 255) * s4 + (it & 3); };
+    const int lpos = (lane * g_scale_q8) >> 8;
+    auto addr = [&](int it) { return ((lpos + it * 5 + wave * 97) & 255) * s4 + (it & 3); };
     auto request = [&](int it, f4 (&d)[4]) {
         if (USE_LDS) {
             const int a = addr(it);
@@ -27,6 +29,16 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int stride_f) {
             if (MM == 0) {
                 d[1] = lds4[a + s4];
                 d[3] = lds4[a + RW * s4 + s4];
+            } else if (MM == 4) {
+                // east taps fetched only by 1 lane in 16, EXEC narrowed without a branch: are masked-off lanes free?
+                const unsigned ab = (unsigned)(a + s4) * 16u, ab2 = (unsigned)(a + RW * s4 + s4) * 16u;
+                f4 e1 = d[0], e3 = d[2];
+                asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b32 exec_lo, 0x00010001\n\ts_mov_b32 exec_hi, 0x00010001\n\t"
+                             "ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_mov_b64 exec, s[20:21]"
+                             : "+v"(e1), "+v"(e3) : "v"(ab), "v"(ab2) : "s20", "s21", "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                d[1] = e1;
+                d[3] = e3;
             } else {
                 d[1] = d[0];
                 d[3] = d[2];
@@ -64,18 +76,18 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int stride_f) {
         }
     }
     f4 s = acc0 + acc1;
-    out[blockIdx.x * 512 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+    out[blockIdx.x * NT + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-template <int NV, bool USE_LDS, int DEPTH, int MM = 0>
+template <int NV, bool USE_LDS, int DEPTH, int MM = 0, int NT = 512>
 static double run(float* out, int iters, int stride_f) {
-    auto kern = k<NV, USE_LDS, DEPTH, MM>;
+    auto kern = k<NV, USE_LDS, DEPTH, MM, NT>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 128 * 1024, 0, out, iters, stride_f);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(NT), 128 * 1024, 0, out, iters, stride_f);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     }
@@ -93,7 +105,7 @@ static void row(float* out, int iters, int stride_f) {
 }
 
 int main() {
-    float* out; hipMalloc(&out, 256 * 512 * sizeof(float));
+    float* out; hipMalloc(&out, 256 * 1024 * sizeof(float));
     const int iters = 60000;
     for (int stride_f : {20, 16}) {
         printf("position stride %d floats (%s)\n", stride_f, stride_f == 20 ? "padded: conflict-free b128" : "unpadded");
@@ -103,6 +115,19 @@ int main() {
         row<48>(out, iters, stride_f);
         row<64>(out, iters, stride_f);
         row<96>(out, iters, stride_f);
+    }
+    // occupancy: the same loop with 8 / 12 / 16 waves per CU; SIMD throughput = waves per SIMD / cycles per unit
+    printf("waves per CU (padded stride, NV=48, 4 reads): cycles per unit and units per 1000 SIMD-cycles\n");
+    const double c8 = run<48, true, 1, 0, 512>(out, iters, 20), c12 = run<48, true, 1, 0, 768>(out, iters, 20),
+                 c16 = run<48, true, 1, 0, 1024>(out, iters, 20);
+    printf("  8 waves %6.1f (%.2f)  12 waves %6.1f (%.2f)  16 waves %6.1f (%.2f)\n", c8, 2000.0 / c8, c12, 3000.0 / c12, c16,
+           4000.0 / c16);
+    printf("2 full + 2 EXEC-masked reads (1 lane in 16, no branch; waits for them at once), NV=48: %6.1f vs 2 reads %6.1f vs 4 reads %6.1f\n",
+           run<48, true, 1, 4, 512>(out, iters, 20), run<48, true, 1, 1, 512>(out, iters, 20), run<48, true, 1, 0, 512>(out, iters, 20));
+    printf("source scale (positions per pixel), padded stride, NV=48, 4 reads, 8 waves: cycles per unit\n");
+    for (int sc : {256, 243, 230, 269, 282, 320}) {
+        hipMemcpyToSymbol(HIP_SYMBOL(g_scale_q8), &sc, sizeof(int));
+        printf("  scale %.3f: %6.1f\n", sc / 256.0, run<48, true, 1, 0, 512>(out, iters, 20));
     }
     return 0;
 }
