@@ -29,6 +29,25 @@ __global__ __launch_bounds__(NT) void k(float* out, int iters, int stride_f) {
             if (MM == 0) {
                 d[1] = lds4[a + s4];
                 d[3] = lds4[a + RW * s4 + s4];
+            } else if (MM >= 5) {
+                // all reads through inline asm (the consumer waits with s_waitcnt lgkmcnt(n) by hand):
+                // 5: four full reads; 6: west full + east by 1 lane in 16 (EXEC narrowed, no branch); 7: west only
+                const unsigned b0 = (unsigned)a * 16u, b2 = (unsigned)(a + RW * s4) * 16u;
+                const unsigned b1 = (unsigned)(a + s4) * 16u, b3 = (unsigned)(a + RW * s4 + s4) * 16u;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=v"(d[0]), "=v"(d[2]) : "v"(b0), "v"(b2) : "memory");
+                if (MM == 5) {
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=v"(d[1]), "=v"(d[3]) : "v"(b1), "v"(b3) : "memory");
+                } else if (MM == 6) {
+                    f4 e1 = {0, 0, 0, 0}, e3 = {0, 0, 0, 0};
+                    asm volatile("s_mov_b64 s[20:21], exec\n\ts_mov_b32 exec_lo, 0x00010001\n\ts_mov_b32 exec_hi, 0x00010001\n\t"
+                                 "ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_mov_b64 exec, s[20:21]"
+                                 : "+v"(e1), "+v"(e3) : "v"(b1), "v"(b3) : "s20", "s21", "memory");
+                    d[1] = e1;
+                    d[3] = e3;
+                } else {
+                    d[1] = (f4){1, 1, 1, 1};
+                    d[3] = (f4){2, 2, 2, 2};
+                }
             } else if (MM == 4) {
                 // east taps fetched only by 1 lane in 16, EXEC narrowed without a branch: are masked-off lanes free?
                 const unsigned ab = (unsigned)(a + s4) * 16u, ab2 = (unsigned)(a + RW * s4 + s4) * 16u;
@@ -61,7 +80,11 @@ __global__ __launch_bounds__(NT) void k(float* out, int iters, int stride_f) {
             request(it + j + DEPTH, t[(j + DEPTH) % (DEPTH + 1)]);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the blend (the scheduler sinks it otherwise)
             f4 (&c)[4] = t[j];
-            asm volatile("" : "+v"(c[3]));      // LDS returns in order: one wait per unit
+            if (USE_LDS && MM >= 5) {  // reads of DEPTH later units may stay in flight (LDS returns in order)
+                if (MM == 7) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * DEPTH) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 * DEPTH) : "memory");
+            }
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));      // LDS returns in order: one wait per unit
             // NV wave-instructions: blend (4 per channel) + accumulate, repeated
             f4 v = c[0] * w0;
 #pragma unroll
@@ -124,6 +147,9 @@ int main() {
            4000.0 / c16);
     printf("2 full + 2 EXEC-masked reads (1 lane in 16, no branch; waits for them at once), NV=48: %6.1f vs 2 reads %6.1f vs 4 reads %6.1f\n",
            run<48, true, 1, 4, 512>(out, iters, 20), run<48, true, 1, 1, 512>(out, iters, 20), run<48, true, 1, 0, 512>(out, iters, 20));
+    printf("hand-scheduled reads, NV=24 / 48: four full %6.1f %6.1f | west full + east by 1 lane in 16 (EXEC) %6.1f %6.1f | west only %6.1f %6.1f\n",
+           run<24, true, 1, 5, 512>(out, iters, 20), run<48, true, 1, 5, 512>(out, iters, 20), run<24, true, 1, 6, 512>(out, iters, 20),
+           run<48, true, 1, 6, 512>(out, iters, 20), run<24, true, 1, 7, 512>(out, iters, 20), run<48, true, 1, 7, 512>(out, iters, 20));
     printf("source scale (positions per pixel), padded stride, NV=48, 4 reads, 8 waves: cycles per unit\n");
     for (int sc : {256, 243, 230, 269, 282, 320}) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_scale_q8), &sc, sizeof(int));
