@@ -649,6 +649,9 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     // ALL waves for the initial window, which nothing can overlap (one workgroup per CU): the compute waves
     // would only wait for it.
     auto stage = [&](int k, int sw, int snw) {
+#ifdef D3D_NOSTAGE  // timing experiment build: only the first window is staged (results are wrong)
+        if (k > 0) return;
+#endif
         const int rb = rfl(ldsi[L::SST + k]), re = rfl(ldsi[L::SST + k + 1]);
         const int T = rfl(ldsi[L::STOT + k]);
         const int nitems = (T + 63) >> 6;
