@@ -56,7 +56,10 @@ constexpr int THREADS = 64 * NWAVES;
 constexpr int DSEG_MAX = 384;   // planes per workgroup segment upper bound
 constexpr int MAXSTEPS = 64;    // >= DSEG_MAX / NSUB, <= 64 (one lane per step)
 constexpr int PFD = 2;          // delta staging items (64 positions x CH channels) a loader wave keeps in flight
-constexpr int LDS_PIPE = 1;     // (quad, view) units whose taps are requested ahead of the one being blended
+#ifndef D3D_LDS_PIPE
+#define D3D_LDS_PIPE 1
+#endif
+constexpr int LDS_PIPE = D3D_LDS_PIPE;     // (quad, view) units whose taps are requested ahead of the one being blended
 constexpr int NCAND = 4;        // candidate step sizes: 4, 2, 1, 1/2 times NSUB planes
 constexpr int MAXRECTS = 256;
 #ifndef RING_ALIGN
