@@ -165,3 +165,53 @@ class ViewFusion(object):
             ctypes.c_void_p(fm.data_ptr()), _stream())
         _lib.check(rc, "d3d_fusion_finalize")
         return avg, fm.bool()
+
+
+def default_normals(h, w, device="cuda"):
+    """fuse/fusion_3d_normal.py:441-443, 497-498: views without a normal map get (0, 0, -1) everywhere."""
+    n = torch.zeros((h, w, 3), dtype=torch.float32, device=device)
+    n[:, :, 2] = -1.0
+    return n
+
+
+def fuse_block(views, pairs, checker, fusion_num=10, min_geo_consist_num=4, filter_sources=True):
+    """The view loop of Fuse_Depth_Map.fuse_depths (fuse/fusion_3d_normal.py:404-533) over maps that are already on
+    the device (predict.predict_views(keep_maps=True), or sharding.all_gather_maps across ranks) -- no PFM round trip.
+
+    views: dict name -> {"depth" [H,W], "confidence" [H,W] (optional: ones), "normal" [H,W,3] (optional: default),
+           "K" [3,3], "E" [4,4] (numpy float32, Tcw), "id" (int written into the visibility planes)}
+    pairs: list of {"ref": name, "src": [names...]} (viewpair.txt order).
+    With filter_sources=True a source's depth map is replaced by its filtered copy after every check, as the reference
+    does through its tmp/ folder when save_temp is on (:417-418, 479-480, 504-510): samples a reference view has confirmed
+    are not offered to later reference views again.
+    Returns a list of {"ref", "avg_xyz_world" [3,H,W], "final_mask" [H,W] bool, "vis_infos" list of [H,W] int32,
+    "normal_world" [H,W,3]} in pair order."""
+    depth = {k: v["depth"] for k, v in views.items()}
+    out = []
+    for pair in pairs:
+        r = views[pair["ref"]]
+        H, W = depth[pair["ref"]].shape
+        dev = depth[pair["ref"]].device
+        conf = r.get("confidence")
+        if conf is None:
+            conf = torch.ones((H, W), dtype=torch.float32, device=dev)
+        normal = r.get("normal")
+        if normal is None:
+            normal = default_normals(H, W, dev)
+        vf = ViewFusion(checker, depth[pair["ref"]], normal, r["K"], r["E"], conf, r["id"])
+        for name in pair["src"][:fusion_num]:
+            if name not in views:
+                continue  # the reference warns and skips missing maps (:482-485)
+            s = views[name]
+            sn = s.get("normal")
+            if sn is None:
+                sn = default_normals(depth[name].shape[0], depth[name].shape[1], dev)
+            filtered = vf.add_source(depth[name], sn, s["K"], s["E"], s["id"], filter_source=filter_sources)
+            if filter_sources:
+                depth[name] = filtered
+        avg, fm = vf.finalize(min_geo_consist_num)
+        if filter_sources:  # :529-533: the reference view's own map keeps only its confirmed points
+            depth[pair["ref"]] = torch.where(fm, depth[pair["ref"]], torch.zeros_like(depth[pair["ref"]]))
+        out.append({"ref": pair["ref"], "avg_xyz_world": avg, "final_mask": fm, "vis_infos": vf.vis_infos,
+                    "normal_world": vf.normal_world})
+    return out

@@ -185,3 +185,39 @@ def test_check_poisoned_inputs_match_oracle(fuse, oracle):
     for name, a, b in zip(("mask", "depth_reprojected", "depth_src", "xyz_world_src", "angle"), got, want):
         assert np.array_equal(host(a), b, equal_nan=(name != "mask")), name
     assert want[0].any()
+
+
+def test_fuse_block_chains_filtered_maps(fuse, oracle):
+    """fuse_block = the view loop of fuse_depths on resident maps: every reference view is fused against the maps as
+    the EARLIER reference views left them (sources filtered by each check, a reference's own map cut to its final mask).
+    Checked against the same chain built from the CPU oracle."""
+    ref, srcs = S.make_fusion_scene(72, 96, 3, seed=41)
+    cams = [ref] + srcs
+    names = ["v%d" % i for i in range(4)]
+    views = {n: {"depth": dev(c["depth"]), "normal": dev(c["normal"]), "K": c["K"], "E": c["E"], "id": 10 + i,
+                 "confidence": dev(ref["confidence"]) if i == 0 else None}
+             for i, (n, c) in enumerate(zip(names, cams))}
+    pairs = [{"ref": "v0", "src": ["v1", "v2", "v3", "missing"]}, {"ref": "v1", "src": ["v0", "v2"]}]
+    chk = fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2)
+    got = fuse.fuse_block(views, pairs, chk, fusion_num=10, min_geo_consist_num=2)
+    # the same chain on the CPU
+    depth = {n: c["depth"].copy() for n, c in zip(names, cams)}
+    conf = {"v0": ref["confidence"], "v1": np.ones_like(srcs[0]["depth"])}
+    cam = dict(zip(names, cams))
+    for pair, g in zip(pairs, got):
+        r = cam[pair["ref"]]
+        xyz, cs, cnt, nw = oracle.fusion.fusion_ref_init(depth[pair["ref"]], r["normal"], r["K"], r["E"])
+        for sn in pair["src"]:
+            if sn not in cam:
+                continue
+            s = cam[sn]
+            m, _, dso, pts, ang = oracle.fusion.consistency_check(depth[pair["ref"]], r["normal"], r["K"], r["E"], depth[sn],
+                                                                  s["normal"], s["K"], s["E"], conf[pair["ref"]], 1.0, 0.01,
+                                                                  10.0, 0.2)
+            oracle.fusion.fusion_accumulate(m, pts, ang, 10 + names.index(sn), cnt, xyz, cs)
+            depth[sn] = dso
+        avg, fm = oracle.fusion.fusion_finalize(xyz, cs, cnt, 2)
+        depth[pair["ref"]] = np.where(fm, depth[pair["ref"]], np.float32(0))
+        assert np.array_equal(host(g["final_mask"]), fm) and 0.02 < fm.mean() < 0.98
+        assert np.array_equal(host(g["avg_xyz_world"]), avg, equal_nan=True)
+        assert len(g["vis_infos"]) == 1 + sum(sn in cam for sn in pair["src"])
