@@ -141,7 +141,8 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 #define D3D_DECOUPLE 0
 #endif
 #ifndef STAGE0_ALL
-#define STAGE0_ALL 0  // experiment: compute waves help to stage the initial window -- measured neutral (239k cycles per workgroup either way)
+#define STAGE0_ALL 1  // compute waves help to stage the first window of a pass: neutral on deep sweeps (239k cycles per workgroup
+                     // either way), -7 % on the cascade's 8-plane stage where that window is the only staging there is
 #endif
 #define STAGE0_ALL_EFF (STAGE0_ALL && !D3D_DECOUPLE)
 __device__ __forceinline__ void step_signal(int* ctr, int lane) {
@@ -808,9 +809,6 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     };
 
     // ================================ main loop over steps ======================================
-#if STAGE0_ALL_EFF
-    if (ring) stage(0, wave, NCOMP + NLOADW);  // initial window: every wave of the workgroup stages
-#endif
     const bool timing = a.tstats != nullptr && wave == 0;
     const bool wtiming = a.tstats != nullptr;  // every compute wave: its own barrier wait
     long long t_ww = 0;
@@ -821,6 +819,9 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     grp = gi;
     c0 = gi * CH;
     load_reference();
+#if STAGE0_ALL_EFF
+    if (ring) stage(0, wave, NCOMP + NLOADW);  // first window of the pass: every wave of the workgroup stages
+#endif
     for (int k = 0; k < nsteps; ++k) {
         if (ring) {
             long long ta = 0;
