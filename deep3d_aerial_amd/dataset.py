@@ -126,7 +126,11 @@ class FeatureCache(object):
     A key must identify the image AND its preprocessing (path, crop window, normalisation mode); the cache belongs to
     one set of feature-network weights: call clear() after loading a checkpoint."""
 
-    def __init__(self, max_bytes=64 << 30):
+    def __init__(self, max_bytes=64 << 30, by_content=False):
+        """by_content=True: views that arrive WITHOUT keys (the reference's own item layout, `forward(imgs, ...)`
+        unchanged) are recognised by their pixels -- a cheap device fingerprint selects a candidate and an exact
+        comparison with the stored image confirms it, so a reused pyramid always belongs to a bit-identical input."""
+        self.by_content = bool(by_content)
         self.max_bytes = int(max_bytes)
         self.bytes = 0
         self.hits = 0
@@ -169,12 +173,34 @@ class FeatureCache(object):
         return key in self._d
 
 
+def _by_content(feature_net, x, cache):
+    """Pyramid of image tensor x [B,3,H,W], reused when a bit-identical tensor has been featurised before.  The
+    fingerprint (two float64 reductions, one host read) only selects the candidate; torch.equal on the stored copy of
+    the image decides.  The stored image counts against the cache budget (it rides in the entry as "_image")."""
+    flat = x.reshape(-1)
+    ramp = torch.arange(flat.numel() % 8191 + 1, dtype=torch.float64, device=x.device)  # short ramp, tiled by viewing
+    d = flat.double()
+    n = (flat.numel() // ramp.numel()) * ramp.numel()
+    fp = torch.stack([d.sum(), (d[:n].view(-1, ramp.numel()) * ramp).sum()]).tolist()
+    key = ("content", tuple(x.shape), fp[0], fp[1])
+    entry = cache.get(key)
+    if entry is not None and torch.equal(entry["_image"], x):
+        return {k: v for k, v in entry.items() if k != "_image"}
+    pyr = feature_net(x)
+    stored = dict(pyr)
+    stored["_image"] = x.clone()
+    cache.put(key, stored)
+    return pyr
+
+
 def extract_features(feature_net, imgs, image_keys=None, cache=None):
     """`[self.feature(imgs[:, v]) for v in range(V)]` (cas_mvsnet.py:189-192, adamvs.py:571-574, msrednet.py:
     482-485) with the pyramids of known images taken from `cache`.  imgs: [B,V,3,H,W] tensor, or a list of V entries
     each either a [B,3,H,W] tensor or None (None = "not uploaded because its key is cached")."""
     V = imgs.shape[1] if isinstance(imgs, torch.Tensor) else len(imgs)
     view = (lambda v: imgs[:, v]) if isinstance(imgs, torch.Tensor) else (lambda v: imgs[v])
+    if cache is not None and image_keys is None and cache.by_content:
+        return [_by_content(feature_net, view(v), cache) for v in range(V)]
     if cache is None or image_keys is None:
         return [feature_net(view(v)) for v in range(V)]
     if len(image_keys) != V:

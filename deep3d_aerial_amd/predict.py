@@ -347,7 +347,8 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
     os.makedirs(output_folder, exist_ok=True)
     model.eval()
     if feature_cache_bytes > 0:
-        model.feature_cache = FeatureCache(feature_cache_bytes)
+        # items without "image_keys" (the reference's layout) are matched by content: exact comparison, same results
+        model.feature_cache = FeatureCache(feature_cache_bytes, by_content=True)
     done = {} if keep_maps else []
     writer = None
     try:

@@ -78,3 +78,25 @@ def test_extract_features_uses_the_cache():
     with pytest.raises(KeyError):
         DS.extract_features(net, [None, None, None], ["i0", "i1", "new"], cache)
     assert len(DS.extract_features(net, imgs)) == 3 and len(calls) == 6  # no keys: every view recomputed
+
+
+def test_content_matching_reuses_only_identical_images():
+    calls = []
+
+    def net(x):
+        calls.append(1)
+        return {"stage3": x + 1}
+
+    torch.manual_seed(0)
+    a, b = torch.randn(1, 3, 16, 24), torch.randn(1, 3, 16, 24)
+    c = a.clone()
+    c[0, 1, 5, 7] += 1e-6  # one pixel differs: must not be taken for `a`
+    cache = DS.FeatureCache(1 << 24, by_content=True)
+    f1 = DS.extract_features(net, torch.stack([a, b, a.clone()], dim=1)[0:1].reshape(1, 3, 3, 16, 24), None, cache)
+    assert len(calls) == 2 and torch.equal(f1[0]["stage3"], f1[2]["stage3"]) and "_image" not in f1[2]
+    f2 = DS.extract_features(net, torch.stack([c, b], dim=1).reshape(1, 2, 3, 16, 24), None, cache)
+    assert len(calls) == 3 and torch.equal(f2[0]["stage3"], c + 1) and torch.equal(f2[1]["stage3"], b + 1)
+    # without by_content nothing is reused
+    plain = DS.FeatureCache(1 << 24)
+    DS.extract_features(net, torch.stack([a, a], dim=1).reshape(1, 2, 3, 16, 24), None, plain)
+    assert len(calls) == 5

@@ -88,3 +88,37 @@ def test_in_process_launch_writes_products(tmp_path):
                                                      "view_0001.txt", "view_0001_init.pfm", "view_0001_prob.pfm"]
     with pytest.raises(SystemExit):  # no dataset reader for real blocks in this image: reported, not swallowed
         mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet").run("/unused", str(out))
+
+
+def test_content_matched_cache_on_reference_item_layout(tmp_path):
+    """Items in the reference's own layout ("imgs": host-normalised float arrays, no keys): with the cache on, shared
+    images are recognised by their pixels (exact comparison) and featurised once; files are byte-identical."""
+    from deep3d_aerial_amd import dataset as DS, predict as P
+
+    strip = P.SyntheticStrip(5, 3, 64, 96, 64, seed=9)
+
+    class ReferenceLayout:
+        def __len__(self):
+            return len(strip)
+
+        def __getitem__(self, i):
+            s = dict(strip[i])
+            imgs = [DS.center_image(torch.from_numpy(im).cuda(), s["normalize"], w).cpu().numpy()
+                    for im, w in zip(s.pop("images_u8"), s.pop("crop_windows"))]
+            s.pop("image_keys")
+            s["imgs"] = np.stack(imgs)
+            return s
+
+    model = P.build_model("casmvsnet", 64)
+    S.fill_state_dict_(model.state_dict(), 5)
+    model = model.cuda().eval()
+    calls = []
+    hook = model.feature.register_forward_hook(lambda *a: calls.append(1))
+    a = P.predict_views(model, ReferenceLayout(), str(tmp_path / "plain"))
+    n_plain = len(calls)
+    b = P.predict_views(model, ReferenceLayout(), str(tmp_path / "cached"), feature_cache_bytes=1 << 30)
+    hook.remove()
+    assert a == b and n_plain == 15 and len(calls) - n_plain == 5
+    for n in a:
+        for suffix in ("_init.pfm", "_prob.pfm"):
+            assert (tmp_path / "plain" / (n + suffix)).read_bytes() == (tmp_path / "cached" / (n + suffix)).read_bytes()

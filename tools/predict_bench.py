@@ -68,6 +68,25 @@ def main():
         torch.cuda.synchronize()
         print("strip loop, feature cache %2d GiB: %7.1f ms per view" % (cache >> 30, (time.time() - t0) / a.views * 1e3),
               flush=True)
+    # the same strip in the reference's own item layout (host-normalised float "imgs", no keys): shared images are
+    # recognised by content (fingerprint + exact comparison)
+    from deep3d_aerial_amd import dataset as DS
+    ref_items = []
+    for it in items:
+        it = dict(it)
+        imgs = [DS.center_image(torch.from_numpy(im).cuda(), it["normalize"], w).cpu().numpy()
+                for im, w in zip(it.pop("images_u8"), it.pop("crop_windows"))]
+        it.pop("image_keys")
+        it["imgs"] = np.stack(imgs)
+        ref_items.append(it)
+    for cache in (0, 64 << 30, 0, 64 << 30):
+        P.predict_views(model, ref_items[:1], a.out)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        P.predict_views(model, ref_items, a.out, feature_cache_bytes=cache)
+        torch.cuda.synchronize()
+        print("reference item layout, content-matched cache %2d GiB: %7.1f ms per view" % (cache >> 30, (time.time() - t0) / a.views * 1e3),
+              flush=True)
     # the reference's host-side normalisation of the same five images (preprocess.py:98-103), for scale
     t0 = time.time()
     for im in items[0]["images_u8"]:
