@@ -112,6 +112,10 @@ __global__ __launch_bounds__(256) void image_center_kernel(const unsigned char* 
         float r;
         if (mode == 0) {  // 'standard': /255 (preprocess.py:95-96)
             r = v / 255.0f;
+        } else if (mode == 2) {  // 'vit': fixed per-channel mean / std (preprocess.py:105-110), float32 arithmetic
+            const float pm = c == 0 ? 123.675f : c == 1 ? 116.28f : 103.53f;
+            const float ps = c == 0 ? 58.395f : c == 1 ? 57.12f : 57.375f;
+            r = (v - pm) / (ps + 0.00000001f);
         } else {  // 'mean': (x - mean) / (sqrt(var) + 1e-8) (preprocess.py:98-103)
             const double sm = (double)sums[2 * c], sq = (double)sums[2 * c + 1];
             const double mean = sm / N;
@@ -132,7 +136,7 @@ extern "C" int d3d_center_image_u8(const unsigned char* img, int h, int w, int c
     D3D_REQUIRE(h > 0 && w > 0 && H > 0 && W > 0 && H <= 65535, "bad dims %dx%d -> %dx%d", h, w, H, W);
     D3D_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + H <= h && x0 + W <= w, "crop window (%d,%d)+%dx%d outside %dx%d", y0, x0, H,
                 W, h, w);
-    D3D_REQUIRE(mode == 0 || mode == 1, "mode %d (0 standard, 1 mean)", mode);
+    D3D_REQUIRE(mode == 0 || mode == 1 || (mode == 2 && channels == 3), "mode %d (0 standard, 1 mean, 2 vit: 3 channels)", mode);
     hipStream_t st = (hipStream_t)stream;
     if (mode == 1) {
         int rc = hip_status(hipMemsetAsync(sums, 0, 8 * sizeof(unsigned long long), st), "hipMemsetAsync(sums)");

@@ -92,7 +92,7 @@ def stage_projections(cams, sample_scale=1):
 # ----------------------------------------------------------------------------------------
 # crop + normalise on the device
 # ----------------------------------------------------------------------------------------
-_MODES = {"standard": 0, "mean": 1}
+_MODES = {"standard": 0, "mean": 1, "vit": 2}
 
 
 def center_image(img_u8, mode="mean", window=None, out=None):

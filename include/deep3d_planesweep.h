@@ -330,7 +330,8 @@ int d3d_flip_rows(const float* const* maps, int n, int H, int W, float* out, d3d
  * center_image; cas_normal_eval.py:112-147).
  *   img [h,w,channels] u8 interleaved (device); window rows y0..y0+H, columns x0..x0+W; out [channels,H,W] fp32.
  *   mode 0 'standard': x / 255;  mode 1 'mean': (x - mean_c) / (sqrt(var_c) + 1e-8) with the population mean and
- *   variance of channel c over the window (exact integer sums, evaluated in double, applied in float32).
+ *   variance of channel c over the window (exact integer sums, evaluated in double, applied in float32);
+ *   mode 2 'vit' (3 channels): (x - {123.675, 116.28, 103.53}_c) / ({58.395, 57.12, 57.375}_c + 1e-8).
  *   sums: device workspace of 8 uint64 (zeroed by the call, stream-ordered).
  */
 int d3d_center_image_u8(const unsigned char* img, int h, int w, int channels, int y0, int x0, int H, int W, int mode,

@@ -29,7 +29,7 @@ def main():
     rng = np.random.default_rng(8101)
     out = {}
     cases = [(70, 106, 64, 96, "mean"), (64, 96, 64, 96, "mean"), (50, 75, 128, 160, "mean"), (90, 70, 64, 64, "standard"),
-             (200, 333, 96, 128, "mean")]
+             (200, 333, 96, 128, "mean"), (40, 50, 32, 32, "vit")]
     for i, (h, w, max_h, max_w, mode) in enumerate(cases):
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         img[:, :, 1] = (img[:, :, 1] // 3) + 40       # channels with different statistics

@@ -49,7 +49,7 @@ def test_center_image_full_size_statistics():
     want = (np.array(img[3:3 + 1856, 5:5 + 2752], dtype=np.float32) / 255.).transpose(2, 0, 1)  # preprocess.py:96
     assert np.array_equal(std.cpu().numpy(), want)
     with pytest.raises(Exception, match="Not implemented yet"):
-        DS.center_image(d, "vit", win)
+        DS.center_image(d, "zscore", win)
 
 
 @pytest.mark.parametrize("name", ["casmvsnet", "adamvs", "msrednet"])
