@@ -89,6 +89,19 @@ def stage_projections(cams, sample_scale=1):
     return pyramid(projs), pyramid(intris)
 
 
+def read_image_u8(filename):
+    """cas_normal_eval.py:38-40, 114-115: `Image.open(filename)` -> `np.array(image)`; decoding stays on the host (PIL).
+    Returns a contiguous uint8 [h,w,C] array, ready for `torch.from_numpy(...).cuda()` and center_image."""
+    from PIL import Image
+
+    img = np.array(Image.open(filename))
+    if img.ndim == 2:
+        img = img[:, :, None]
+    if img.dtype != np.uint8:
+        raise TypeError("%s decodes to %s; the device item builder takes 8-bit images" % (filename, img.dtype))
+    return np.ascontiguousarray(img)
+
+
 # ----------------------------------------------------------------------------------------
 # crop + normalise on the device
 # ----------------------------------------------------------------------------------------

@@ -100,3 +100,15 @@ def test_content_matching_reuses_only_identical_images():
     plain = DS.FeatureCache(1 << 24)
     DS.extract_features(net, torch.stack([a, a], dim=1).reshape(1, 2, 3, 16, 24), None, plain)
     assert len(calls) == 5
+
+
+def test_read_image_u8_roundtrip(tmp_path):
+    from PIL import Image
+
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    got = DS.read_image_u8(str(tmp_path / "a.png"))
+    assert got.dtype == np.uint8 and got.flags["C_CONTIGUOUS"] and np.array_equal(got, rgb)
+    Image.fromarray(rgb[:, :, 0]).save(tmp_path / "g.png")
+    assert DS.read_image_u8(str(tmp_path / "g.png")).shape == (20, 30, 1)
