@@ -8,6 +8,8 @@
 // Reference citations: include/deep3d_planesweep.h.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace d3d {
 
 struct ConvParams {
@@ -162,6 +164,116 @@ static int launch_conv(const ConvParams& p, bool transposed, hipStream_t stream)
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// C_out = 1, stride 1 (the probability layer of CostRegNet, cas_mvsnet.py:110: nn.Conv3d(8, 1, 3, padding=1)): a single
+// output channel wastes 15 of the 16 rows of a matrix-core tile (the 4x4-patch fold reaches 25 % useful work), and
+// the layer is pure streaming: 8 input planes per output plane.  This kernel streams the input volume through LDS one
+// z-plane at a time (each input element is fetched from memory once per 64x4 tile); a lane owns one (x, y) column and
+// keeps the three output planes a staged input plane contributes to in registers.  Per lane and plane: 9*Ci LDS
+// reads, 27*Ci FMAs with wave-uniform (scalar-loaded) weights; the next plane's loads are in flight during the FMAs.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int C1_TX = 64, C1_TY = 4, C1_PW = C1_TX + 2, C1_PH = C1_TY + 2, C1_PS = C1_PW + 1;  // patch row stride (pad)
+
+template <int CI>
+__global__ __launch_bounds__(256) void conv3d_co1_kernel(ConvParams p, int zseg) {
+    constexpr int PLANE = C1_PH * C1_PS;      // floats per channel in a patch
+    constexpr int NLD = (CI * C1_PH * C1_PW + 255) / 256;  // staging loads per lane and plane
+    __shared__ float patch[2][CI * PLANE + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * C1_TX, y0 = blockIdx.y * C1_TY;
+    const int z_lo = blockIdx.z * zseg, z_hi = min(z_lo + zseg, p.D);  // output planes [z_lo, z_hi)
+    const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool valid = (x < p.W) && (y < p.H);
+
+    // staging element e (0 .. CI*PH*PW): channel, patch row, patch col -> 32-bit byte offset from the plane's base
+    // (raw buffer loads: out-of-image elements get an out-of-range offset and read as the zero padding) and LDS slot
+    unsigned voff[NLD];
+    int lslot[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (C1_PH * C1_PW), r = e - c * (C1_PH * C1_PW);
+        const int py = r / C1_PW, px = r - py * C1_PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool live = e < CI * C1_PH * C1_PW;
+        const bool ok = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        voff[i] = ok ? (unsigned)(((long)c * in_vol + (long)gy * p.W + gx) * 4) : 0x80000000u;
+        lslot[i] = live ? c * PLANE + py * C1_PS + px : CI * PLANE;  // dead elements land in a spare word
+    }
+    const int span_bytes = (int)((((long)CI - 1) * in_vol + in_plane) * 4);  // (host: < 2^31)
+    float pv[NLD];
+    auto issue = [&](int zi) {
+        const bool zin = zi >= 0 && zi < p.D;
+        const float* base = p.in0 + (long)(zin ? zi : 0) * in_plane;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, zin ? span_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[i], 0, 0));
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) patch[buf][lslot[i]] = pv[i];
+    };
+
+    float a_prev = 0.0f, a_cur = 0.0f, a_next = 0.0f;  // output planes zi-1, zi, zi+1 while input plane zi is swept
+    // weights [1][CI][3][3][3] through the constant address space: wave-uniform addresses become scalar loads, and the
+    // per-plane laundering below keeps them from being hoisted out of the plane loop into 27*CI registers
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* wt = (cfloat*)p.weight;
+    issue(z_lo - 1);
+    land(0);
+    __syncthreads();
+    for (int zi = z_lo - 1, it = 0; zi <= z_hi; ++zi, ++it) {
+        const int buf = it & 1;
+        if (zi + 1 <= z_hi) issue(zi + 1);  // next plane's loads fly during the FMAs
+        const float* __restrict__ pl = patch[buf] + ty * C1_PS + tx;
+#pragma unroll 1  // (a rolled channel loop bounds the live weights to 27 scalar registers)
+        for (int c = 0; c < CI; ++c) {
+            cfloat* wc = wt + c * 27;
+            asm volatile("" : "+s"(wc));
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = pl[c * PLANE + dy * C1_PS + dx];
+                    cfloat* w = wc + dy * 3 + dx;
+                    a_next = fmaf(v, w[0], a_next);   // kz = 0: this plane is the z-1 neighbour of output zi+1
+                    a_cur = fmaf(v, w[9], a_cur);     // kz = 1
+                    a_prev = fmaf(v, w[18], a_prev);  // kz = 2: ... the z+1 neighbour of output zi-1
+                }
+        }
+        // output plane zi-1 is complete (it has seen input planes zi-2, zi-1, zi)
+        const int zo = zi - 1;
+        if (valid && zo >= z_lo && zo < z_hi) {
+            const long oidx = (long)zo * in_plane + (long)y * p.W + x;
+            p.out[oidx] = epilogue(a_prev, 0, oidx, p);
+        }
+        a_prev = a_cur;
+        a_cur = a_next;
+        a_next = 0.0f;
+        if (zi + 1 <= z_hi) land(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+static int launch_conv3d_co1(const ConvParams& p, hipStream_t stream) {
+    const int gx = ceil_div(p.W, C1_TX), gy = ceil_div(p.H, C1_TY);
+    // depth segments: enough workgroups to fill the chip, at least 8 planes each (two halo planes per segment)
+    int nz = 1;
+    while ((long)gx * gy * nz < 2048 && p.D / (nz * 2) >= 8) nz *= 2;
+    const int zseg = ceil_div(p.D, nz);
+    nz = ceil_div(p.D, zseg);
+    if (gy > 65535 || nz > 65535) return D3D_ERR_UNSUPPORTED;
+    dim3 grid(gx, gy, nz);
+    const long in_plane = (long)p.H * p.W;
+    if (p.Ci0 != 8 || ((long)7 * in_plane * p.D + in_plane) * 4 >= (1L << 31)) return D3D_ERR_UNSUPPORTED;  // 32-bit offsets
+    hipLaunchKernelGGL(conv3d_co1_kernel<8>, grid, dim3(256), 0, stream, p, zseg);
+    D3D_LAUNCH_CHECK("conv3d_co1_kernel launch");
+    return D3D_OK;
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -178,6 +290,13 @@ int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, cons
     p.Ci0 = Ci; p.Co = Co; p.D = D; p.H = H; p.W = W;
     p.Do = (D - 1) / stride + 1; p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
     p.stride = stride; p.act = relu ? 1 : 0; p.skip_after_act = 1;
+    if (Co == 1 && stride == 1 && Ci == 8) {  // streaming single-channel form (D3D_CONV_CO1=0: generic kernel)
+        const char* e = getenv("D3D_CONV_CO1");
+        if (!e || atoi(e) != 0) {
+            int rc = launch_conv3d_co1(p, (hipStream_t)stream);
+            if (rc != D3D_ERR_UNSUPPORTED) return rc;
+        }
+    }
     return launch_conv<3>(p, false, (hipStream_t)stream);
 }
 

@@ -224,7 +224,10 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
     Co = weight.shape[0]
     if tuple(weight.shape) != (Co, Ci, 3, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    if _use_mfma() and Co <= 64:
+    # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
+    # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
+    co1 = Co == 1 and stride == 1 and Ci == 8 and _os.environ.get("D3D_CONV_CO1", "1") != "0"
+    if _use_mfma() and Co <= 64 and not co1:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)
         if y is not None:
             return y

@@ -408,6 +408,7 @@ def test_conv_bf16_operands_match_rounded_oracle(ops, oracle, Ci, Co, monkeypatc
     """d3d_conv_fold_bf16: operands rounded to bf16 (RNE), fp32 accumulation -- so it must agree with the fp32
     oracle run on pre-rounded inputs and weights to fp32 summation-order accuracy."""
     monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.setenv("D3D_CONV_CO1", "0")  # (the C_out = 1 streaming kernel is exact fp32 in either precision mode)
     rng = np.random.default_rng(Ci * 7 + Co)
     x = rng.standard_normal((Ci, 4, 10, 40)).astype(np.float32)
     w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
@@ -653,3 +654,25 @@ def test_predict_views_writes_reference_products(ops, tmp_path):
     prob, _ = predict.load_pfm(str(tmp_path / "view_0001_prob.pfm"))
     assert np.array_equal(depth, host(out["depth"][0])) and np.array_equal(prob, host(out["photometric_confidence"][0]))
     assert (tmp_path / "view_0001.txt").read_text().startswith("extrinsic: XrightYdown, [Rcw|tcw]")
+
+
+@pytest.mark.parametrize("D,H,W", [(1, 3, 5), (2, 4, 64), (5, 9, 70), (8, 37, 130), (11, 64, 65), (19, 6, 300)])
+def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, W):
+    """C_out = 1 layers (CostRegNet.prob, cas_mvsnet.py:110) run on the z-streaming VALU kernel behind d3d_conv3d_k3:
+    against the oracle with bias / ReLU / skip, and against the folded matrix-core form of the same layer."""
+    rng = np.random.default_rng(D * 1000 + W)
+    x = rng.standard_normal((8, D, H, W)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((1, 8, 3, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(1).astype(np.float32)
+    sk = rng.standard_normal((1, D, H, W)).astype(np.float32)
+    monkeypatch.delenv("D3D_CONV_CO1", raising=False)
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    got = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
+    want = oracle.conv3d_k3(x, w, b)
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
+    got2 = host(ops.conv3d_k3(dev(x), dev(w), dev(np.full(1, 0.5, np.float32)), dev(b), dev(sk), relu=True))
+    want2 = np.maximum(0.5 * oracle.conv3d_k3(x, w, None) + b[0], 0.0) + sk
+    assert np.abs(got2 - want2).max() <= 2e-6 * max(1.0, np.abs(want2).max()) * 8
+    monkeypatch.setenv("D3D_CONV_CO1", "0")
+    folded = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
+    assert np.abs(got - folded).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
