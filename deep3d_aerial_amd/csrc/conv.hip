@@ -274,11 +274,148 @@ static int launch_conv3d_co1(const ConvParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// C_out = 8, stride 1 (conv0 of every CostRegNet, cas_mvsnet.py:84: ConvBnReLU3D(C_in, 8)): the fp32 vector units of
+// this chip have the same peak as its fp32 matrix cores (157 TFLOP/s), and an 8-row GEMM fills half an MFMA tile at
+// best, so these three layers -- 14 ms of a 53 ms CasMVSNet view on the matrix-core kernel -- go through the same
+// z-streaming form as the single-channel kernel above: a lane owns one (x, y) column, eight output channels and the
+// three open output planes (24 accumulators); the input arrives in chunks of 8 channels per LDS stage; weights are
+// pre-packed [C_in][ky][kx][kz][8] so that the 72 weights of a (channel, row) are contiguous scalar loads feeding
+// v_pk_fma_f32 (two output channels per instruction).  Per tap value: 1 LDS read, 24 FMAs.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg) {
+    constexpr int CK = 8, CO = 8;
+    constexpr int PLANE = C1_PH * C1_PS;
+    constexpr int NLD = (CK * C1_PH * C1_PW + 255) / 256;
+    __shared__ float patch[2][CK * PLANE + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * C1_TX, y0 = blockIdx.y * C1_TY;
+    const int z_lo = blockIdx.z * zseg, z_hi = min(z_lo + zseg, p.D);
+    const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool valid = (x < p.W) && (y < p.H);
+    const int nchunk = p.Ci0 / CK;
+
+    unsigned voff[NLD];
+    int lslot[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (C1_PH * C1_PW), r = e - c * (C1_PH * C1_PW);
+        const int py = r / C1_PW, px = r - py * C1_PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool live = e < CK * C1_PH * C1_PW;
+        const bool ok = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        voff[i] = ok ? (unsigned)(((long)c * in_vol + (long)gy * p.W + gx) * 4) : 0x80000000u;
+        lslot[i] = live ? c * PLANE + py * C1_PS + px : CK * PLANE;
+    }
+    const int span_bytes = (int)((((long)CK - 1) * in_vol + in_plane) * 4);  // (host: < 2^31)
+    float pv[NLD];
+    // step s = (input plane, channel chunk)
+    auto issue = [&](int zi, int ch) {
+        const bool zin = zi >= 0 && zi < p.D;
+        const float* base = p.in0 + (long)ch * CK * in_vol + (long)(zin ? zi : 0) * in_plane;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, zin ? span_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[i], 0, 0));
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) patch[buf][lslot[i]] = pv[i];
+    };
+
+    float acc[3][CO];  // [0] output plane zi-1, [1] zi, [2] zi+1 while input plane zi is swept
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[k][o] = 0.0f;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* wt = (cfloat*)p.weight;  // packed [C_in][3 ky][3 kx][3 kz][8]
+
+    issue(z_lo - 1, 0);
+    land(0);
+    __syncthreads();
+    int it = 0;
+    for (int zi = z_lo - 1; zi <= z_hi; ++zi) {
+        for (int ch = 0; ch < nchunk; ++ch, ++it) {
+            const int buf = it & 1;
+            // next step: next chunk of this plane, or the first chunk of the next plane
+            const bool more = (ch + 1 < nchunk) || (zi + 1 <= z_hi);
+            if (more) issue(ch + 1 < nchunk ? zi : zi + 1, ch + 1 < nchunk ? ch + 1 : 0);
+            const float* __restrict__ pl = patch[buf] + ty * C1_PS + tx;
+#pragma unroll 1
+            for (int c = 0; c < CK; ++c) {
+#pragma unroll 1
+                for (int dy = 0; dy < 3; ++dy) {
+                    cfloat* w = wt + ((ch * CK + c) * 3 + dy) * 72;
+                    asm volatile("" : "+s"(w));  // (reloaded per row: 72 live scalars, not 216 * C_in)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = pl[c * PLANE + dy * C1_PS + dx];
+#pragma unroll
+                        for (int o = 0; o < CO; ++o) {
+                            acc[2][o] = fmaf(v, w[dx * 24 + 0 * 8 + o], acc[2][o]);  // kz = 0 -> output plane zi+1
+                            acc[1][o] = fmaf(v, w[dx * 24 + 1 * 8 + o], acc[1][o]);
+                            acc[0][o] = fmaf(v, w[dx * 24 + 2 * 8 + o], acc[0][o]);  // kz = 2 -> output plane zi-1
+                        }
+                    }
+                }
+            }
+            if (more) land(buf ^ 1);
+            __syncthreads();
+        }
+        const int zo = zi - 1;
+        if (valid && zo >= z_lo && zo < z_hi) {
+            const long obase = (long)zo * in_plane + (long)y * p.W + x;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const long oidx = (long)o * in_vol + obase;
+                p.out[oidx] = epilogue(acc[0][o], o, oidx, p);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            acc[0][o] = acc[1][o];
+            acc[1][o] = acc[2][o];
+            acc[2][o] = 0.0f;
+        }
+    }
+}
+
+static int launch_conv3d_co8(const ConvParams& p, hipStream_t stream) {
+    const int gx = ceil_div(p.W, C1_TX), gy = ceil_div(p.H, C1_TY);
+    int nz = 1;
+    while ((long)gx * gy * nz < 2048 && p.D / (nz * 2) >= 8) nz *= 2;
+    const int zseg = ceil_div(p.D, nz);
+    nz = ceil_div(p.D, zseg);
+    const long in_plane = (long)p.H * p.W;
+    if (gy > 65535 || nz > 65535 || p.Ci0 % 8 != 0 || ((long)7 * in_plane * p.D + in_plane) * 4 >= (1L << 31))
+        return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv3d_co8_kernel, dim3(gx, gy, nz), dim3(256), 0, stream, p, zseg);
+    D3D_LAUNCH_CHECK("conv3d_co8_kernel launch");
+    return D3D_OK;
+}
+
 }  // namespace d3d
 
 using namespace d3d;
 
 extern "C" {
+
+int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale, const float* shift, const float* skip,
+                      int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(Ci > 0 && D > 0 && H > 0 && W > 0, "bad dims");
+    ConvParams p = {};
+    p.in0 = in; p.weight = wpacked; p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.Ci0 = Ci; p.Co = 8; p.D = D; p.H = H; p.W = W; p.Do = D; p.Ho = H; p.Wo = W;
+    p.stride = 1; p.act = relu ? 1 : 0; p.skip_after_act = 1;
+    int rc = launch_conv3d_co8(p, (hipStream_t)stream);
+    if (rc == D3D_ERR_UNSUPPORTED) set_error("d3d_conv3d_k3_co8: unsupported shape Ci=%d %dx%dx%d", Ci, D, H, W);
+    return rc;
+}
 
 int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, const float* shift, const float* skip,
                   int relu, int Ci, int Co, int D, int H, int W, int stride, float* out, d3d_stream_t stream) {

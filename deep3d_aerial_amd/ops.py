@@ -226,6 +226,18 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
     # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
+    if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and _os.environ.get("D3D_CONV_CO8", "1") != "0" \
+            and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
+        # C_out = 8 (conv0 of every CostRegNet): z-streaming kernel on the fp32 vector units (same peak as the fp32 matrix
+        # cores, which an 8-row GEMM half fills); weights re-laid out [Ci][ky][kx][kz][8] once per parameter version
+        wp = derived_weight(weight, "co8", lambda w: w.permute(1, 3, 4, 2, 0))
+        out = torch.empty((8, D, H, W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_conv3d_k3_co8(_chk(x, "x", 4), _chk(wp, "wpacked"), _opt(scale, "scale"), _opt(shift, "shift"),
+                                           _opt(skip, "skip"), int(relu), Ci, D, H, W, _chk(out, "out"), _stream())
+        _lib.check(rc, "d3d_conv3d_k3_co8")
+        return out
     co1 = Co == 1 and stride == 1 and Ci == 8 and _os.environ.get("D3D_CONV_CO1", "1") != "0"
     if _use_mfma() and Co <= 64 and not co1:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)

@@ -159,6 +159,13 @@ int d3d_resize_bilinear(const float* in, int n, int h, int w, int H, int W, floa
 int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, const float* shift, const float* skip,
                   int relu, int Ci, int Co, int D, int H, int W, int stride, float* out, d3d_stream_t stream);
 
+/* The same convolution for C_out = 8, stride 1 (conv0 of every CostRegNet, cas_mvsnet.py:84) on the fp32 vector units,
+ * streaming the input volume through LDS plane by plane.  wpacked: the nn.Conv3d weight [8,Ci,3,3,3] re-laid out as
+ * [Ci][ky][kx][kz][8] (host-side permutation, ops.conv3d_k3).  Ci % 8 == 0; returns D3D_ERR_UNSUPPORTED when
+ * 7*D*H*W*4 bytes exceeds the 32-bit offsets of its staging loads. */
+int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale, const float* shift, const float* skip,
+                      int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
+
 /*
  * cas_mvsnet.py:94-108 -- ConvTranspose3d k=3, stride 2, padding 1, output_padding 1
  * (output exactly 2x per axis) + folded BatchNorm + ReLU + skip add.

@@ -676,3 +676,27 @@ def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, 
     monkeypatch.setenv("D3D_CONV_CO1", "0")
     folded = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
     assert np.abs(got - folded).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
+
+
+@pytest.mark.parametrize("Ci,D,H,W", [(8, 1, 3, 5), (8, 5, 9, 70), (16, 8, 37, 130), (32, 3, 4, 64), (24, 11, 20, 65),
+                                      (16, 19, 6, 300)])
+def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D, H, W):
+    """C_out = 8, stride 1 (conv0 of CostRegNet, cas_mvsnet.py:84) on the z-streaming vector-unit kernel
+    (d3d_conv3d_k3_co8): against the oracle with folded-BN affine, ReLU and skip, and against the matrix-core form."""
+    rng = np.random.default_rng(Ci * 100 + W)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((8, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    sh = rng.standard_normal(8).astype(np.float32)
+    sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.delenv("D3D_CONV_CO8", raising=False)
+    want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
+    tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
+    assert np.abs(got - want).max() <= tol
+    plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
+    monkeypatch.setenv("D3D_CONV_CO8", "0")
+    folded = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
+    assert np.abs(plain - folded).max() <= tol
+    assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() <= tol
