@@ -283,18 +283,19 @@ static int launch_conv3d_co1(const ConvParams& p, hipStream_t stream) {
 // pre-packed [C_in][ky][kx][kz][8] so that the 72 weights of a (channel, row) are contiguous scalar loads feeding
 // v_pk_fma_f32 (two output channels per instruction).  Per tap value: 1 LDS read, 24 FMAs.
 // ---------------------------------------------------------------------------------------------------------------
+template <int XP>  // output pixels per lane along x (tile = 64*XP x 4): XP = 2 halves the scalar weight loads per FMA
 __global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg) {
     constexpr int CK = 8, CO = 8;
-    constexpr int PLANE = C1_PH * C1_PS;
-    constexpr int NLD = (CK * C1_PH * C1_PW + 255) / 256;
+    constexpr int TX = 64 * XP, PW = TX + 2, PS = PW + 1, PH = C1_TY + 2;
+    constexpr int PLANE = PH * PS;
+    constexpr int NLD = (CK * PH * PW + 255) / 256;
     __shared__ float patch[2][CK * PLANE + 1];
     const int tid = threadIdx.x;
     const int tx = tid & 63, ty = tid >> 6;
-    const int x0 = blockIdx.x * C1_TX, y0 = blockIdx.y * C1_TY;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * C1_TY;
     const int z_lo = blockIdx.z * zseg, z_hi = min(z_lo + zseg, p.D);
     const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
-    const int x = x0 + tx, y = y0 + ty;
-    const bool valid = (x < p.W) && (y < p.H);
+    const int y = y0 + ty;
     const int nchunk = p.Ci0 / CK;
 
     unsigned voff[NLD];
@@ -302,13 +303,13 @@ __global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int e = tid + 256 * i;
-        const int c = e / (C1_PH * C1_PW), r = e - c * (C1_PH * C1_PW);
-        const int py = r / C1_PW, px = r - py * C1_PW;
+        const int c = e / (PH * PW), r = e - c * (PH * PW);
+        const int py = r / PW, px = r - py * PW;
         const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-        const bool live = e < CK * C1_PH * C1_PW;
+        const bool live = e < CK * PH * PW;
         const bool ok = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         voff[i] = ok ? (unsigned)(((long)c * in_vol + (long)gy * p.W + gx) * 4) : 0x80000000u;
-        lslot[i] = live ? c * PLANE + py * C1_PS + px : CK * PLANE;
+        lslot[i] = live ? c * PLANE + py * PS + px : CK * PLANE;
     }
     const int span_bytes = (int)((((long)CK - 1) * in_vol + in_plane) * 4);  // (host: < 2^31)
     float pv[NLD];
@@ -326,11 +327,13 @@ __global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg)
         for (int i = 0; i < NLD; ++i) patch[buf][lslot[i]] = pv[i];
     };
 
-    float acc[3][CO];  // [0] output plane zi-1, [1] zi, [2] zi+1 while input plane zi is swept
+    float acc[XP][3][CO];  // [.][0] output plane zi-1, [1] zi, [2] zi+1 while input plane zi is swept
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int q = 0; q < XP; ++q)
 #pragma unroll
-        for (int o = 0; o < CO; ++o) acc[k][o] = 0.0f;
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[q][k][o] = 0.0f;
     typedef const float __attribute__((address_space(4))) cfloat;
     cfloat* wt = (cfloat*)p.weight;  // packed [C_in][3 ky][3 kx][3 kz][8]
 
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg)
             // next step: next chunk of this plane, or the first chunk of the next plane
             const bool more = (ch + 1 < nchunk) || (zi + 1 <= z_hi);
             if (more) issue(ch + 1 < nchunk ? zi : zi + 1, ch + 1 < nchunk ? ch + 1 : 0);
-            const float* __restrict__ pl = patch[buf] + ty * C1_PS + tx;
+            const float* __restrict__ pl = patch[buf] + ty * PS + tx;
 #pragma unroll 1
             for (int c = 0; c < CK; ++c) {
 #pragma unroll 1
@@ -353,12 +356,15 @@ __global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg)
                     asm volatile("" : "+s"(w));  // (reloaded per row: 72 live scalars, not 216 * C_in)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
-                        const float v = pl[c * PLANE + dy * C1_PS + dx];
 #pragma unroll
-                        for (int o = 0; o < CO; ++o) {
-                            acc[2][o] = fmaf(v, w[dx * 24 + 0 * 8 + o], acc[2][o]);  // kz = 0 -> output plane zi+1
-                            acc[1][o] = fmaf(v, w[dx * 24 + 1 * 8 + o], acc[1][o]);
-                            acc[0][o] = fmaf(v, w[dx * 24 + 2 * 8 + o], acc[0][o]);  // kz = 2 -> output plane zi-1
+                        for (int q = 0; q < XP; ++q) {
+                            const float v = pl[c * PLANE + dy * PS + dx + 64 * q];
+#pragma unroll
+                            for (int o = 0; o < CO; ++o) {
+                                acc[q][2][o] = fmaf(v, w[dx * 24 + 0 * 8 + o], acc[q][2][o]);  // kz = 0 -> output plane zi+1
+                                acc[q][1][o] = fmaf(v, w[dx * 24 + 1 * 8 + o], acc[q][1][o]);
+                                acc[q][0][o] = fmaf(v, w[dx * 24 + 2 * 8 + o], acc[q][0][o]);  // kz = 2 -> output plane zi-1
+                            }
                         }
                     }
                 }
@@ -367,25 +373,34 @@ __global__ __launch_bounds__(256) void conv3d_co8_kernel(ConvParams p, int zseg)
             __syncthreads();
         }
         const int zo = zi - 1;
-        if (valid && zo >= z_lo && zo < z_hi) {
-            const long obase = (long)zo * in_plane + (long)y * p.W + x;
+#pragma unroll
+        for (int q = 0; q < XP; ++q) {
+            const int x = x0 + tx + 64 * q;
+            if (x < p.W && y < p.H && zo >= z_lo && zo < z_hi) {
+                const long obase = (long)zo * in_plane + (long)y * p.W + x;
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const long oidx = (long)o * in_vol + obase;
+                    p.out[oidx] = epilogue(acc[q][0][o], o, oidx, p);
+                }
+            }
 #pragma unroll
             for (int o = 0; o < CO; ++o) {
-                const long oidx = (long)o * in_vol + obase;
-                p.out[oidx] = epilogue(acc[0][o], o, oidx, p);
+                acc[q][0][o] = acc[q][1][o];
+                acc[q][1][o] = acc[q][2][o];
+                acc[q][2][o] = 0.0f;
             }
-        }
-#pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            acc[0][o] = acc[1][o];
-            acc[1][o] = acc[2][o];
-            acc[2][o] = 0.0f;
         }
     }
 }
 
 static int launch_conv3d_co8(const ConvParams& p, hipStream_t stream) {
-    const int gx = ceil_div(p.W, C1_TX), gy = ceil_div(p.H, C1_TY);
+    // two pixels per lane (128-wide tiles) unless the wider tiles pad the rows by over 4 % more (measured: 2752 and
+    // 1376 wide +13 % / +8 % faster with two, 688 wide 10 % slower)
+    const double pad1 = ceil_div(p.W, 64) * 64.0 / p.W, pad2 = ceil_div(p.W, 128) * 128.0 / p.W;
+    int xp = (pad2 - pad1 <= 0.04) ? 2 : 1;
+    if (const char* e = getenv("D3D_CONV_CO8_XP")) xp = atoi(e) == 1 ? 1 : 2;  // experiments
+    const int gx = ceil_div(p.W, 64 * xp), gy = ceil_div(p.H, C1_TY);
     int nz = 1;
     while ((long)gx * gy * nz < 2048 && p.D / (nz * 2) >= 8) nz *= 2;
     const int zseg = ceil_div(p.D, nz);
@@ -393,7 +408,10 @@ static int launch_conv3d_co8(const ConvParams& p, hipStream_t stream) {
     const long in_plane = (long)p.H * p.W;
     if (gy > 65535 || nz > 65535 || p.Ci0 % 8 != 0 || ((long)7 * in_plane * p.D + in_plane) * 4 >= (1L << 31))
         return D3D_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv3d_co8_kernel, dim3(gx, gy, nz), dim3(256), 0, stream, p, zseg);
+    if (xp == 2)
+        hipLaunchKernelGGL(conv3d_co8_kernel<2>, dim3(gx, gy, nz), dim3(256), 0, stream, p, zseg);
+    else
+        hipLaunchKernelGGL(conv3d_co8_kernel<1>, dim3(gx, gy, nz), dim3(256), 0, stream, p, zseg);
     D3D_LAUNCH_CHECK("conv3d_co8_kernel launch");
     return D3D_OK;
 }

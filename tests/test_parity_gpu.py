@@ -680,7 +680,8 @@ def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, 
 
 @pytest.mark.parametrize("Ci,D,H,W", [(8, 1, 3, 5), (8, 5, 9, 70), (16, 8, 37, 130), (32, 3, 4, 64), (24, 11, 20, 65),
                                       (16, 19, 6, 300)])
-def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D, H, W):
+@pytest.mark.parametrize("xp", ["1", "2"])
+def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D, H, W, xp):
     """C_out = 8, stride 1 (conv0 of CostRegNet, cas_mvsnet.py:84) on the z-streaming vector-unit kernel
     (d3d_conv3d_k3_co8): against the oracle with folded-BN affine, ReLU and skip, and against the matrix-core form."""
     rng = np.random.default_rng(Ci * 100 + W)
@@ -691,6 +692,7 @@ def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D,
     sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
     monkeypatch.setenv("D3D_CONV", "mfma")
     monkeypatch.delenv("D3D_CONV_CO8", raising=False)
+    monkeypatch.setenv("D3D_CONV_CO8_XP", xp)  # one / two output pixels per lane (64- / 128-wide tiles)
     want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
     got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
