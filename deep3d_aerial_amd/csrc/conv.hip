@@ -416,11 +416,176 @@ static int launch_conv3d_co8(const ConvParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed convolution k = 3, stride 2, pad 1, output_pad 1 with C_out = 8 (conv11 of every CostRegNet,
+// cas_mvsnet.py:103: Deconv3d(16, 8) + BN + ReLU, then the skip add of :118): 35 GFLOP but 2.9 GB of output / skip
+// traffic per stage -- a streaming layer.  Same z-streaming vector-unit form as above, seen from the INPUT: a lane owns
+// one input (x, y) column = a 2x2 block of output columns; input plane z feeds output planes 2z-1 (k_z = 0), 2z
+// (k_z = 1) and 2z+1 (k_z = 2), every kernel tap exactly once:
+//   out(2y+py, 2x+px): py = 0 takes k_y = 1 from row y; py = 1 takes k_y = 2 from row y and k_y = 0 from row y+1
+// (same along x).  96 accumulators (3 planes x 4 parities x 8 channels); the two x parities of a row leave as one
+// 8-byte store per lane (512 contiguous bytes per wave).  Weights packed [C_in][kz][ky][kx][8].
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convT3d_co8_kernel(ConvParams p, int zseg) {
+    constexpr int CK = 8, CO = 8;
+    constexpr int PW = C1_TX + 1, PS = PW + 2, PH = C1_TY + 1;  // +1 halo on the high side
+    constexpr int PLANE = PH * PS;
+    constexpr int NLD = (CK * PH * PW + 255) / 256;
+    __shared__ float patch[2][CK * PLANE + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * C1_TX, y0 = blockIdx.y * C1_TY;
+    const int z_lo = blockIdx.z * zseg, z_hi = min(z_lo + zseg, p.D);  // input planes [z_lo, z_hi) -> output planes [2 z_lo, 2 z_hi)
+    const long in_plane = (long)p.H * p.W, in_vol = in_plane * p.D;
+    const long out_plane = (long)p.Ho * p.Wo, out_vol = out_plane * p.Do;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool valid = (x < p.W) && (y < p.H);
+    const int nchunk = p.Ci0 / CK;
+
+    unsigned voff[NLD];
+    int lslot[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (PH * PW), r = e - c * (PH * PW);
+        const int py = r / PW, px = r - py * PW;
+        const int gy = y0 + py, gx = x0 + px;
+        const bool live = e < CK * PH * PW;
+        const bool ok = live && gy < p.H && gx < p.W;
+        voff[i] = ok ? (unsigned)(((long)c * in_vol + (long)gy * p.W + gx) * 4) : 0x80000000u;
+        lslot[i] = live ? c * PLANE + py * PS + px : CK * PLANE;
+    }
+    const int span_bytes = (int)((((long)CK - 1) * in_vol + in_plane) * 4);  // (host: < 2^31)
+    float pv[NLD];
+    auto issue = [&](int zi, int ch) {
+        const bool zin = zi >= 0 && zi < p.D;
+        const float* base = p.in0 + (long)ch * CK * in_vol + (long)(zin ? zi : 0) * in_plane;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, zin ? span_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[i], 0, 0));
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) patch[buf][lslot[i]] = pv[i];
+    };
+
+    // acc[kz]: [0] output plane 2zi-1 (opened by the previous input plane), [1] 2zi, [2] 2zi+1; [parity py*2+px][co]
+    float acc[3][4][CO];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[k][q][o] = 0.0f;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* wt = (cfloat*)p.weight;  // packed [C_in][3 kz][3 ky][3 kx][8]
+
+    auto store_plane = [&](int oz, float (&a)[4][CO]) {  // output plane oz of this lane's 2x2 columns
+        if (!valid) return;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const long rowbase = (long)oz * out_plane + (long)(2 * y + py) * p.Wo + 2 * x;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const long oidx = (long)o * out_vol + rowbase;
+                float2 r;
+                r.x = a[py * 2 + 0][o];
+                r.y = a[py * 2 + 1][o];
+                if (p.scale) { r.x *= p.scale[o]; r.y *= p.scale[o]; }
+                if (p.shift) { r.x += p.shift[o]; r.y += p.shift[o]; }
+                float2 sk = {0.0f, 0.0f};
+                if (p.skip) sk = *reinterpret_cast<const float2*>(p.skip + oidx);
+                if (p.skip && !p.skip_after_act) { r.x += sk.x; r.y += sk.y; }
+                if (p.act == 1) { r.x = fmaxf(r.x, 0.0f); r.y = fmaxf(r.y, 0.0f); }
+                if (p.skip && p.skip_after_act) { r.x = sk.x + r.x; r.y = sk.y + r.y; }
+                *reinterpret_cast<float2*>(p.out + oidx) = r;
+            }
+        }
+    };
+
+    issue(z_lo, 0);
+    land(0);
+    __syncthreads();
+    int it = 0;
+    for (int zi = z_lo; zi <= z_hi; ++zi) {  // the plane at z_hi only closes output plane 2 z_hi - 1 (zeros beyond the volume)
+        for (int ch = 0; ch < nchunk; ++ch, ++it) {
+            const int buf = it & 1;
+            const bool more = (ch + 1 < nchunk) || (zi + 1 <= z_hi);
+            if (more) issue(ch + 1 < nchunk ? zi : zi + 1, ch + 1 < nchunk ? ch + 1 : 0);
+            const float* __restrict__ pl = patch[buf] + ty * PS + tx;
+#pragma unroll 1
+            for (int c = 0; c < CK; ++c) {
+                const float v00 = pl[c * PLANE], v01 = pl[c * PLANE + 1], v10 = pl[c * PLANE + PS], v11 = pl[c * PLANE + PS + 1];
+#pragma unroll
+                for (int kz = 0; kz < 3; ++kz) {
+                    cfloat* w = wt + ((ch * CK + c) * 3 + kz) * 72;  // [ky][kx][co]
+                    asm volatile("" : "+s"(w));
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        float (&a)[4][CO] = acc[kz];
+                        a[0][o] = fmaf(v00, w[(1 * 3 + 1) * 8 + o], a[0][o]);
+                        a[1][o] = fmaf(v00, w[(1 * 3 + 2) * 8 + o], a[1][o]);
+                        a[1][o] = fmaf(v01, w[(1 * 3 + 0) * 8 + o], a[1][o]);
+                        a[2][o] = fmaf(v00, w[(2 * 3 + 1) * 8 + o], a[2][o]);
+                        a[2][o] = fmaf(v10, w[(0 * 3 + 1) * 8 + o], a[2][o]);
+                        a[3][o] = fmaf(v00, w[(2 * 3 + 2) * 8 + o], a[3][o]);
+                        a[3][o] = fmaf(v01, w[(2 * 3 + 0) * 8 + o], a[3][o]);
+                        a[3][o] = fmaf(v10, w[(0 * 3 + 2) * 8 + o], a[3][o]);
+                        a[3][o] = fmaf(v11, w[(0 * 3 + 0) * 8 + o], a[3][o]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one k_z group of 72 scalar weights live at a time
+                }
+            }
+            if (more) land(buf ^ 1);
+            __syncthreads();
+        }
+        if (zi > z_lo) store_plane(2 * zi - 1, acc[0]);
+        if (zi < z_hi) store_plane(2 * zi, acc[1]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                acc[0][q][o] = acc[2][q][o];
+                acc[1][q][o] = 0.0f;
+                acc[2][q][o] = 0.0f;
+            }
+    }
+}
+
+static int launch_convT3d_co8(const ConvParams& p, hipStream_t stream) {
+    const int gx = ceil_div(p.W, C1_TX), gy = ceil_div(p.H, C1_TY);
+    int nz = 1;
+    while ((long)gx * gy * nz < 2048 && p.D / (nz * 2) >= 4) nz *= 2;
+    const int zseg = ceil_div(p.D, nz);
+    nz = ceil_div(p.D, zseg);
+    const long in_plane = (long)p.H * p.W;
+    if (gy > 65535 || nz > 65535 || p.Ci0 % 8 != 0 || ((long)7 * in_plane * p.D + in_plane) * 4 >= (1L << 31))
+        return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(convT3d_co8_kernel, dim3(gx, gy, nz), dim3(256), 0, stream, p, zseg);
+    D3D_LAUNCH_CHECK("convT3d_co8_kernel launch");
+    return D3D_OK;
+}
+
 }  // namespace d3d
 
 using namespace d3d;
 
 extern "C" {
+
+int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const float* scale, const float* shift,
+                                 const float* skip, int relu, int Ci, int D, int H, int W, float* out,
+                                 d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(Ci > 0 && D > 0 && H > 0 && W > 0, "bad dims");
+    ConvParams p = {};
+    p.in0 = in; p.weight = wpacked; p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.Ci0 = Ci; p.Co = 8; p.D = D; p.H = H; p.W = W; p.Do = 2 * D; p.Ho = 2 * H; p.Wo = 2 * W;
+    p.stride = 2; p.act = relu ? 1 : 0; p.skip_after_act = 1;
+    int rc = launch_convT3d_co8(p, (hipStream_t)stream);
+    if (rc == D3D_ERR_UNSUPPORTED) set_error("d3d_convtranspose3d_k3s2_co8: unsupported shape Ci=%d %dx%dx%d", Ci, D, H, W);
+    return rc;
+}
 
 int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale, const float* shift, const float* skip,
                       int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream) {

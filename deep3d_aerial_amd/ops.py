@@ -260,6 +260,18 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    if Co == 8 and Ci % 8 == 0 and _use_mfma() and _os.environ.get("D3D_CONV_CO8", "1") != "0" \
+            and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
+        # C_out = 8 (conv11 of every CostRegNet): z-streaming kernel on the fp32 vector units, weights [Ci][kz][ky][kx][8]
+        wp = derived_weight(weight, "coT8", lambda w: w.permute(0, 2, 3, 4, 1))
+        out = torch.empty((8, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_convtranspose3d_k3s2_co8(_chk(x, "x", 4), _chk(wp, "wpacked"), _opt(scale, "scale"),
+                                                      _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, D, H, W,
+                                                      _chk(out, "out"), _stream())
+        _lib.check(rc, "d3d_convtranspose3d_k3s2_co8")
+        return out
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=1 if relu else 0)
         if y is not None:

@@ -166,6 +166,14 @@ int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, cons
 int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale, const float* shift, const float* skip,
                       int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
 
+/* module.py:307-314 Deconv3d (+BN+ReLU) / cas_mvsnet.py:103,118 for C_out = 8 (conv11 of CostRegNet: 16 -> 8, then the
+ * skip add) on the fp32 vector units, streaming the INPUT volume through LDS: k = 3, stride 2, pad 1, output_pad 1;
+ * in [Ci,D,H,W] -> out [8,2D,2H,2W]; skip (same shape as out, may be NULL) added after the activation.
+ * wpacked: the nn.ConvTranspose3d weight [Ci,8,3,3,3] re-laid out as [Ci][kz][ky][kx][8].  Ci % 8 == 0. */
+int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const float* scale, const float* shift,
+                                 const float* skip, int relu, int Ci, int D, int H, int W, float* out,
+                                 d3d_stream_t stream);
+
 /*
  * cas_mvsnet.py:94-108 -- ConvTranspose3d k=3, stride 2, padding 1, output_padding 1
  * (output exactly 2x per axis) + folded BatchNorm + ReLU + skip add.

@@ -702,3 +702,25 @@ def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D,
     folded = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
     assert np.abs(plain - folded).max() <= tol
     assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() <= tol
+
+
+@pytest.mark.parametrize("Ci,D,H,W", [(8, 1, 1, 1), (8, 2, 3, 5), (16, 4, 9, 70), (16, 3, 5, 64), (24, 5, 20, 65), (16, 9, 4, 130)])
+def test_convtranspose3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D, H, W):
+    """Deconv3d(C, 8) + BN + ReLU + skip (conv11 of CostRegNet, cas_mvsnet.py:103,118) on the z-streaming vector-unit
+    kernel (d3d_convtranspose3d_k3s2_co8): against the oracle and against the matrix-core form."""
+    rng = np.random.default_rng(Ci * 100 + W)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Ci, 8, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    sh = rng.standard_normal(8).astype(np.float32)
+    sk = rng.standard_normal((8, 2 * D, 2 * H, 2 * W)).astype(np.float32)
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.delenv("D3D_CONV_CO8", raising=False)
+    want = np.maximum(oracle.convtranspose3d_k3s2(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
+    tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
+    assert got.shape == want.shape and np.abs(got - want).max() <= tol
+    plain = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
+    monkeypatch.setenv("D3D_CONV_CO8", "0")
+    folded = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
+    assert np.abs(plain - folded).max() <= tol
