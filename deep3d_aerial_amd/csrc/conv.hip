@@ -567,11 +567,139 @@ static int launch_convT3d_co8(const ConvParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 2D 3x3 stride-1 convolution with C_out = 8 | 16 on the vector units (the full- and half-resolution layers of the
+// feature pyramids, module.py:653-755: 3 -> 8, 8 -> 8, 32 -> 8, 16 -> 16, 32 -> 16): these are streaming layers (a few
+// GFLOP over hundreds of MB) that a 16-row matrix-core tile half fills.  A workgroup takes a 64 x 8 tile, a lane two
+// pixels four rows apart; the input arrives in chunks of 8 channels (patch 10 x 66 per channel, the next chunk's
+// loads in flight during the FMAs); weights packed [C_in padded to 8][ky][kx][C_out] feed v_pk_fma_f32 from scalar
+// registers.  Channels beyond C_in (the 3-channel image layer) are staged as zeros.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
+    constexpr int CK = 8, YP = 2, TY = 4 * YP;
+    constexpr int PW = C1_TX + 2, PS = PW + 1, PH = TY + 2;
+    constexpr int PLANE = PH * PS;
+    constexpr int NLD = (CK * PH * PW + 255) / 256;
+    __shared__ float patch[2][CK * PLANE + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int x0 = blockIdx.x * C1_TX, y0 = blockIdx.y * TY;
+    const long in_plane = (long)p.H * p.W;
+    const int x = x0 + tx;
+    const int nchunk = (p.Ci0 + CK - 1) / CK;
+
+    unsigned voff[NLD];
+    int lslot[NLD], lch[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i;
+        const int c = e / (PH * PW), r = e - c * (PH * PW);
+        const int py = r / PW, px = r - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool live = e < CK * PH * PW;
+        const bool ok = live && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        voff[i] = ok ? (unsigned)(((long)c * in_plane + (long)gy * p.W + gx) * 4) : 0x80000000u;
+        lslot[i] = live ? c * PLANE + py * PS + px : CK * PLANE;
+        lch[i] = c;
+    }
+    float pv[NLD];
+    auto issue = [&](int ch) {
+        const int c0 = ch * CK;
+        const int nc = min(CK, p.Ci0 - c0);  // channels of this chunk that exist
+        const float* base = p.in0 + (long)c0 * in_plane;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((long)nc * in_plane * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            pv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[i], 0, 0));
+    };
+    auto land = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) patch[buf][lslot[i]] = pv[i];
+    };
+
+    float acc[YP][CO];
+#pragma unroll
+    for (int q = 0; q < YP; ++q)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[q][o] = 0.0f;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* wt = (cfloat*)p.weight;  // packed [C_in padded][3 ky][3 kx][CO]
+
+    issue(0);
+    land(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) issue(ch + 1);
+        const float* __restrict__ pl = patch[buf] + ty * PS + tx;
+#pragma unroll 1
+        for (int c = 0; c < CK; ++c) {
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                cfloat* w = wt + ((ch * CK + c) * 3 + dy) * (3 * CO);
+                asm volatile("" : "+s"(w));
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                    for (int q = 0; q < YP; ++q) {
+                        const float v = pl[c * PLANE + (dy + 4 * q) * PS + dx];
+#pragma unroll
+                        for (int o = 0; o < CO; ++o) acc[q][o] = fmaf(v, w[dx * CO + o], acc[q][o]);
+                    }
+                }
+            }
+        }
+        if (ch + 1 < nchunk) land(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < YP; ++q) {
+        const int y = y0 + ty + 4 * q;
+        if (x < p.W && y < p.H) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                const long oidx = (long)o * in_plane + (long)y * p.W + x;
+                p.out[oidx] = epilogue(acc[q][o], o, oidx, p);
+            }
+        }
+    }
+    (void)lch;
+}
+
+static int launch_conv2d_stream(const ConvParams& p, hipStream_t stream) {
+    const int gx = ceil_div(p.W, C1_TX), gy = ceil_div(p.H, 8);
+    const long in_plane = (long)p.H * p.W;
+    if (gy > 65535 || (long)8 * in_plane * 4 >= (1L << 31)) return D3D_ERR_UNSUPPORTED;
+    if (p.Co == 8)
+        hipLaunchKernelGGL(conv2d_stream_kernel<8>, dim3(gx, gy), dim3(256), 0, stream, p);
+    else if (p.Co == 16)
+        hipLaunchKernelGGL(conv2d_stream_kernel<16>, dim3(gx, gy), dim3(256), 0, stream, p);
+    else
+        return D3D_ERR_UNSUPPORTED;
+    D3D_LAUNCH_CHECK("conv2d_stream_kernel launch");
+    return D3D_OK;
+}
+
 }  // namespace d3d
 
 using namespace d3d;
 
 extern "C" {
+
+int d3d_conv2d_k3_stream(const float* in, int Ci, const float* wpacked, const float* scale, const float* shift,
+                         const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(Ci > 0 && H > 0 && W > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    ConvParams p = {};
+    p.in0 = in; p.weight = wpacked; p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.Ci0 = Ci; p.Co = Co; p.D = 1; p.H = H; p.W = W; p.Do = 1; p.Ho = H; p.Wo = W;
+    p.stride = 1; p.act = act; p.skip_after_act = 1;
+    int rc = launch_conv2d_stream(p, (hipStream_t)stream);
+    if (rc == D3D_ERR_UNSUPPORTED) set_error("d3d_conv2d_k3_stream: unsupported shape Ci=%d Co=%d %dx%d", Ci, Co, H, W);
+    return rc;
+}
 
 int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const float* scale, const float* shift,
                                  const float* skip, int relu, int Ci, int D, int H, int W, float* out,

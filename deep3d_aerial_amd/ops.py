@@ -286,6 +286,9 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     return out
 
 
+_CONV2D_STREAM_MIN = 256 * 256  # pixels from which the vector-unit streaming form of conv2d_k3 is used
+
+
 def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None):
     """3x3 conv over cat(x, x2) channels. x [Ci0,H,W], x2 [Ci1,H,W]|None, weight [Co,Ci0+Ci1,3,3]."""
     Ci0, H, W = x.shape
@@ -295,6 +298,23 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
+    if (x2 is None and stride == 1 and Co in (8, 16) and act in (0, 1) and _use_mfma() and conv_precision() != "bf16"
+            and H * W >= _CONV2D_STREAM_MIN and 8 * H * W * 4 < 2 ** 31 and _os.environ.get("D3D_CONV2D_STREAM", "1") != "0"):
+        # large single-input layers with 8 | 16 output channels (feature pyramids): vector-unit streaming kernel
+        def pack(w):
+            cip = (Ci0 + 7) // 8 * 8
+            wp = w.new_zeros((cip, 3, 3, Co))
+            wp[:Ci0] = w.permute(1, 2, 3, 0)
+            return wp
+        wp = derived_weight(weight, "c2s", pack)
+        out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape mismatch")
+        rc = _lib.load().d3d_conv2d_k3_stream(_chk(x, "x", 3), Ci0, _chk(wp, "wpacked"), _opt(scale, "scale"),
+                                              _opt(shift, "shift"), _opt(skip, "skip"), int(act), Co, H, W,
+                                              _chk(out, "out"), _stream())
+        _lib.check(rc, "d3d_conv2d_k3_stream")
+        return out
     if _use_mfma() and Co <= 64:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=act, stride=stride, x2=x2)
         if y is not None:

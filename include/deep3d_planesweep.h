@@ -174,6 +174,13 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
                                  const float* skip, int relu, int Ci, int D, int H, int W, float* out,
                                  d3d_stream_t stream);
 
+/* 3x3 stride-1 nn.Conv2d with C_out = 8 | 16 and one input tensor (the full- / half-resolution layers of the feature
+ * pyramids, module.py:653-755) on the fp32 vector units; same epilogue as d3d_conv2d_k3 (affine, act 0 | 1, skip added
+ * after the activation).  wpacked: weight [Co,Ci,3,3] re-laid out as [Ci rounded up to 8][ky][kx][Co], zero rows for
+ * the padding channels. */
+int d3d_conv2d_k3_stream(const float* in, int Ci, const float* wpacked, const float* scale, const float* shift,
+                         const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /*
  * cas_mvsnet.py:94-108 -- ConvTranspose3d k=3, stride 2, padding 1, output_padding 1
  * (output exactly 2x per axis) + folded BatchNorm + ReLU + skip add.

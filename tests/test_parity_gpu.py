@@ -724,3 +724,27 @@ def test_convtranspose3d_eight_output_channels_streaming(ops, oracle, monkeypatc
     monkeypatch.setenv("D3D_CONV_CO8", "0")
     folded = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
     assert np.abs(plain - folded).max() <= tol
+
+
+@pytest.mark.parametrize("Ci,Co,H,W", [(3, 8, 5, 7), (8, 8, 9, 70), (32, 8, 37, 130), (16, 16, 8, 64), (32, 16, 21, 65),
+                                       (5, 16, 1, 1), (12, 8, 17, 200), (8, 16, 300, 270)])
+def test_conv2d_streaming_vector_unit_kernel(ops, oracle, monkeypatch, Ci, Co, H, W):
+    """d3d_conv2d_k3_stream (3x3, stride 1, C_out 8 | 16, any C_in incl. the 3-channel image layer): against the oracle
+    with affine / ReLU / skip and against the matrix-core form of the same layer."""
+    rng = np.random.default_rng(Ci * 100 + Co + W)
+    x = rng.standard_normal((Ci, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Co, Ci, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    sk = rng.standard_normal((Co, H, W)).astype(np.float32)
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.delenv("D3D_CONV2D_STREAM", raising=False)
+    monkeypatch.setattr(ops, "_CONV2D_STREAM_MIN", 1)
+    want = np.maximum(oracle.conv2d_k3(x, w, None) * sc[:, None, None] + sh[:, None, None], 0) + sk
+    got = host(ops.conv2d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), act=1))
+    tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
+    assert np.abs(got - want).max() <= tol
+    plain = host(ops.conv2d_k3(dev(x), dev(w)))
+    monkeypatch.setenv("D3D_CONV2D_STREAM", "0")
+    folded = host(ops.conv2d_k3(dev(x), dev(w)))
+    assert np.abs(plain - folded).max() <= tol
