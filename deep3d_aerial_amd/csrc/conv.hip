@@ -681,11 +681,65 @@ static int launch_conv2d_stream(const ConvParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lateral connection of the feature pyramid (module.py:736-747, FeatureNet_mvsnet "fpn"): out = conv1x1(x) + bias +
+// nearest-x2 upsampling of the coarser level -- `F.interpolate(f, scale_factor=2, mode="nearest") + self.inner(x)`.
+// The reference materialises the upsampled tensor (32 channels at full resolution: 653 MB written and read again); here
+// the coarse level is read in place at (y/2, x/2).  Pure streaming: C_in + C_out/4 + C_out floats per pixel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void conv1x1_upskip_kernel(const float* __restrict__ in, const float* wpacked,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ coarse, int H, int W,
+                                                             float* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const long plane = (long)H * W, idx = (long)y * W + x;
+    const int hw = W >> 1;
+    const long cplane = (long)(H >> 1) * hw, cidx = (long)(y >> 1) * hw + (x >> 1);
+    float v[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) v[c] = in[c * plane + idx];
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = bias ? bias[o] : 0.0f;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat* wt = (cfloat*)wpacked;  // [CI][CO]
+#pragma unroll
+    for (int c = 0; c < CI; ++c) {
+        cfloat* w = wt + c * CO;
+        asm volatile("" : "+s"(w));
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = fmaf(v[c], w[o], acc[o]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) out[o * plane + idx] = acc[o] + coarse[o * cplane + cidx];
+}
+
 }  // namespace d3d
 
 using namespace d3d;
 
 extern "C" {
+
+int d3d_conv1x1_upskip(const float* in, int Ci, const float* wpacked, const float* bias, const float* coarse, int Co, int H,
+                       int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && coarse && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && H <= 65535, "bad dims %dx%d (even sizes)", H, W);
+    dim3 grid(ceil_div(W, 256), H);
+    hipStream_t st = (hipStream_t)stream;
+    if (Ci == 8 && Co == 32)
+        hipLaunchKernelGGL((conv1x1_upskip_kernel<8, 32>), grid, dim3(256), 0, st, in, wpacked, bias, coarse, H, W, out);
+    else if (Ci == 16 && Co == 32)
+        hipLaunchKernelGGL((conv1x1_upskip_kernel<16, 32>), grid, dim3(256), 0, st, in, wpacked, bias, coarse, H, W, out);
+    else {
+        set_error("d3d_conv1x1_upskip: unsupported channels %d -> %d", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    D3D_LAUNCH_CHECK("conv1x1_upskip_kernel launch");
+    return D3D_OK;
+}
 
 int d3d_conv2d_k3_stream(const float* in, int Ci, const float* wpacked, const float* scale, const float* shift,
                          const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream) {

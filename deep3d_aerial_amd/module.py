@@ -245,6 +245,22 @@ def feature_conv(conv, x, bn=None, relu=False, skip=None, x2=None):
     return y if skip is None else y + skip
 
 
+def lateral_upsample_add(conv, x, coarse):
+    """`F.interpolate(coarse, scale_factor=2, mode="nearest") + conv(x)` (module.py:744-747 of the reference) with the
+    upsampling folded into the 1x1 convolution's epilogue where the fused kernel takes the shape."""
+    if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
+            and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+        outs = []
+        for b in range(x.shape[0]):
+            y = ops.conv1x1_upskip(x[b].contiguous(), conv.weight, conv.bias, coarse[b].contiguous())
+            if y is None:
+                break
+            outs.append(y)
+        else:
+            return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+    return feature_conv(conv, x, skip=F.interpolate(coarse, scale_factor=2, mode="nearest"))
+
+
 class Conv2d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
                  **kwargs):
@@ -341,8 +357,8 @@ class FeatureNet_mvsnet(nn.Module):
             f = self.deconv2(c0, f)
             out["stage3"] = feature_conv(self.out3, f)
         else:
-            f = feature_conv(self.inner1, c1, skip=F.interpolate(c2, scale_factor=2, mode="nearest"))
+            f = lateral_upsample_add(self.inner1, c1, c2)
             out["stage2"] = feature_conv(self.out2, f)
-            f = feature_conv(self.inner2, c0, skip=F.interpolate(f, scale_factor=2, mode="nearest"))
+            f = lateral_upsample_add(self.inner2, c0, f)
             out["stage3"] = feature_conv(self.out3, f)
         return out

@@ -286,6 +286,22 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     return out
 
 
+def conv1x1_upskip(x, weight, bias, coarse):
+    """conv1x1(x) + bias + nearest-x2 upsampling of `coarse` (FPN lateral, module.py:736-747) in one pass.
+    x [Ci,H,W], weight [Co,Ci,1,1], coarse [Co,H/2,W/2].  Returns None for shapes the kernel does not take."""
+    Ci, H, W = x.shape
+    Co = weight.shape[0]
+    if (Ci, Co) not in ((8, 32), (16, 32)) or H % 2 or W % 2 or tuple(coarse.shape) != (Co, H // 2, W // 2) \
+            or tuple(weight.shape) != (Co, Ci, 1, 1) or _os.environ.get("D3D_CONV1X1_UPSKIP", "1") == "0":
+        return None
+    wp = derived_weight(weight, "c11", lambda w: w.reshape(Co, Ci).t())
+    out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_conv1x1_upskip(_chk(x, "x", 3), Ci, _chk(wp, "wpacked"), _opt(bias, "bias"), _chk(coarse, "coarse", 3),
+                                        Co, H, W, _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_conv1x1_upskip")
+    return out
+
+
 _CONV2D_STREAM_MIN = 256 * 256  # pixels from which the vector-unit streaming form of conv2d_k3 is used
 
 

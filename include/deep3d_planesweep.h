@@ -181,6 +181,13 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
 int d3d_conv2d_k3_stream(const float* in, int Ci, const float* wpacked, const float* scale, const float* shift,
                          const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
+/* module.py:736-747 (FeatureNet_mvsnet, "fpn"): out = conv1x1(in) + bias + nearest-x2 upsampling of `coarse`
+ * (F.interpolate(..., scale_factor=2, mode="nearest") + self.inner(x)) without materialising the upsampled tensor.
+ * in [Ci,H,W]; coarse [Co,H/2,W/2]; wpacked = weight [Co,Ci,1,1] transposed to [Ci][Co]; out [Co,H,W]; H, W even;
+ * (Ci, Co) in {(8,32), (16,32)}, else D3D_ERR_UNSUPPORTED. */
+int d3d_conv1x1_upskip(const float* in, int Ci, const float* wpacked, const float* bias, const float* coarse, int Co, int H,
+                       int W, float* out, d3d_stream_t stream);
+
 /*
  * cas_mvsnet.py:94-108 -- ConvTranspose3d k=3, stride 2, padding 1, output_padding 1
  * (output exactly 2x per axis) + folded BatchNorm + ReLU + skip add.

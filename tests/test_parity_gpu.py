@@ -748,3 +748,20 @@ def test_conv2d_streaming_vector_unit_kernel(ops, oracle, monkeypatch, Ci, Co, H
     monkeypatch.setenv("D3D_CONV2D_STREAM", "0")
     folded = host(ops.conv2d_k3(dev(x), dev(w)))
     assert np.abs(plain - folded).max() <= tol
+
+
+@pytest.mark.parametrize("Ci,H,W", [(8, 2, 2), (8, 6, 10), (16, 14, 260), (8, 64, 514), (16, 2, 600)])
+def test_fpn_lateral_upsample_add(ops, Ci, H, W):
+    """d3d_conv1x1_upskip = F.interpolate(coarse, scale_factor=2, mode='nearest') + conv1x1(x) (module.py:744-747), against
+    the same expression in PyTorch fp32 on the GPU."""
+    import torch.nn.functional as F
+
+    g = torch.Generator(device="cpu").manual_seed(Ci + H + W)
+    x = torch.randn(Ci, H, W, generator=g).cuda()
+    w = (0.2 * torch.randn(32, Ci, 1, 1, generator=g)).cuda()
+    b = torch.randn(32, generator=g).cuda()
+    coarse = torch.randn(32, H // 2, W // 2, generator=g).cuda()
+    got = ops.conv1x1_upskip(x, w, b, coarse)
+    want = F.interpolate(coarse[None], scale_factor=2, mode="nearest")[0] + F.conv2d(x[None].double(), w.double(), b.double())[0].float()
+    assert got is not None and float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert ops.conv1x1_upskip(x[:, :, : W - 1].contiguous(), w, b, coarse) is None  # odd width: the caller falls back
