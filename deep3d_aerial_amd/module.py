@@ -246,7 +246,7 @@ def feature_conv(conv, x, bn=None, relu=False, skip=None, x2=None):
 
 
 def lateral_upsample_add(conv, x, coarse):
-    """`F.interpolate(coarse, scale_factor=2, mode="nearest") + conv(x)` (module.py:744-747 of the reference) with the
+    """`F.interpolate(coarse, scale_factor=2, mode="nearest") + conv(x)` (module.py:742,746 of the reference) with the
     upsampling folded into the 1x1 convolution's epilogue where the fused kernel takes the shape."""
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
             and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):

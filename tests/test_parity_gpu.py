@@ -752,7 +752,7 @@ def test_conv2d_streaming_vector_unit_kernel(ops, oracle, monkeypatch, Ci, Co, H
 
 @pytest.mark.parametrize("Ci,H,W", [(8, 2, 2), (8, 6, 10), (16, 14, 260), (8, 64, 514), (16, 2, 600)])
 def test_fpn_lateral_upsample_add(ops, Ci, H, W):
-    """d3d_conv1x1_upskip = F.interpolate(coarse, scale_factor=2, mode='nearest') + conv1x1(x) (module.py:744-747), against
+    """d3d_conv1x1_upskip = F.interpolate(coarse, scale_factor=2, mode='nearest') + conv1x1(x) (module.py:742,746), against
     the same expression in PyTorch fp32 on the GPU."""
     import torch.nn.functional as F
 
