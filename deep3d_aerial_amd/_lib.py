@@ -40,7 +40,7 @@ SIGNATURES = {
     "d3d_convtranspose3d_k3s2_co8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv1x1_upskip": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "d3d_conv2d_k3_stream": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3_stream": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv_gemm_f32": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,

@@ -24,8 +24,10 @@ struct ConvParams {
     int D, H, W;     // input dims
     int Do, Ho, Wo;  // output dims
     int stride;
-    int act;             // 0 none, 1 relu
+    int act;             // 0 none, 1 relu; conv2d_stream_kernel also 2 | 3 = ConvGRUCell gates / state update (see there)
     int skip_after_act;  // 1: out = skip + act(y) ; 0: out = act(y + skip)
+    const float* aux1;   // act 3: the update gate u
+    int ep_split;        // act 2: channels < ep_split are the reset gate (multiplied by h = skip)
 };
 
 __device__ __forceinline__ float epilogue(float acc, int co, long oidx, const ConvParams& p) {
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
     const int x0 = blockIdx.x * C1_TX, y0 = blockIdx.y * TY;
     const long in_plane = (long)p.H * p.W;
     const int x = x0 + tx;
-    const int nchunk = (p.Ci0 + CK - 1) / CK;
+    const int nchunk = (p.Ci0 + p.Ci1 + CK - 1) / CK;
 
     unsigned voff[NLD];
     int lslot[NLD], lch[NLD];
@@ -606,8 +608,10 @@ __global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
     float pv[NLD];
     auto issue = [&](int ch) {
         const int c0 = ch * CK;
-        const int nc = min(CK, p.Ci0 - c0);  // channels of this chunk that exist
-        const float* base = p.in0 + (long)c0 * in_plane;
+        // a chunk comes from one tensor: the first input, or (two-input form, C_in0 % 8 == 0) the second
+        const bool second = c0 >= p.Ci0;
+        const int nc = second ? min(CK, p.Ci0 + p.Ci1 - c0) : min(CK, p.Ci0 - c0);  // channels of this chunk that exist
+        const float* base = second ? p.in1 + (long)(c0 - p.Ci0) * in_plane : p.in0 + (long)c0 * in_plane;
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((long)nc * in_plane * 4), 0x00020000);
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
@@ -660,7 +664,23 @@ __global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
 #pragma unroll
             for (int o = 0; o < CO; ++o) {
                 const long oidx = (long)o * in_plane + (long)y * p.W + x;
-                p.out[oidx] = epilogue(acc[q][o], o, oidx, p);
+                if (p.act <= 1) {
+                    p.out[oidx] = epilogue(acc[q][o], o, oidx, p);
+                } else {
+                    // ConvGRUCell (module.py:24-51) fused as in conv_stream.hip: act 2: y = sigmoid(y), reset-gate channels
+                    // (< ep_split) times the state h = skip -> out = [r*h | u]; act 3: h' = u*h + (1-u)*tanh(y)
+                    float yv = acc[q][o];
+                    if (p.scale) yv *= p.scale[o];
+                    if (p.shift) yv += p.shift[o];
+                    if (p.act == 2) {
+                        yv = 1.0f / (1.0f + __expf(-yv));
+                        if (o < p.ep_split) yv *= p.skip[oidx];
+                    } else {
+                        const float u = p.aux1[oidx], hv = p.skip[oidx];
+                        yv = u * hv + (1.0f - u) * tanhf(yv);
+                    }
+                    p.out[oidx] = yv;
+                }
             }
         }
     }
@@ -741,17 +761,22 @@ int d3d_conv1x1_upskip(const float* in, int Ci, const float* wpacked, const floa
     return D3D_OK;
 }
 
-int d3d_conv2d_k3_stream(const float* in, int Ci, const float* wpacked, const float* scale, const float* shift,
-                         const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream) {
-    D3D_REQUIRE(in && wpacked && out, "null pointer");
-    D3D_REQUIRE(Ci > 0 && H > 0 && W > 0, "bad dims");
-    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+int d3d_conv2d_k3_stream(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpacked, const float* scale,
+                         const float* shift, const float* skip, const float* aux1, int ep_split, int act, int Co, int H,
+                         int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in0 && wpacked && out, "null pointer");
+    D3D_REQUIRE(Ci0 > 0 && Ci1 >= 0 && (Ci1 == 0 || (in1 && Ci0 % 8 == 0)), "bad input channel split %d+%d", Ci0, Ci1);
+    D3D_REQUIRE(H > 0 && W > 0, "bad dims");
+    D3D_REQUIRE(act >= 0 && act <= 3, "bad act %d", act);
+    D3D_REQUIRE(act < 2 || skip, "act %d needs the state h in `skip`", act);
+    D3D_REQUIRE(act != 3 || aux1, "act 3 needs the update gate in `aux1`");
     ConvParams p = {};
-    p.in0 = in; p.weight = wpacked; p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
-    p.Ci0 = Ci; p.Co = Co; p.D = 1; p.H = H; p.W = W; p.Do = 1; p.Ho = H; p.Wo = W;
+    p.in0 = in0; p.in1 = in1; p.weight = wpacked; p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.aux1 = aux1; p.ep_split = ep_split;
+    p.Ci0 = Ci0; p.Ci1 = Ci1; p.Co = Co; p.D = 1; p.H = H; p.W = W; p.Do = 1; p.Ho = H; p.Wo = W;
     p.stride = 1; p.act = act; p.skip_after_act = 1;
     int rc = launch_conv2d_stream(p, (hipStream_t)stream);
-    if (rc == D3D_ERR_UNSUPPORTED) set_error("d3d_conv2d_k3_stream: unsupported shape Ci=%d Co=%d %dx%d", Ci, Co, H, W);
+    if (rc == D3D_ERR_UNSUPPORTED) set_error("d3d_conv2d_k3_stream: unsupported shape Ci=%d+%d Co=%d %dx%d", Ci0, Ci1, Co, H, W);
     return rc;
 }
 

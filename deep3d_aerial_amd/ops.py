@@ -302,7 +302,35 @@ def conv1x1_upskip(x, weight, bias, coarse):
     return out
 
 
-_CONV2D_STREAM_MIN = 256 * 256  # pixels from which the vector-unit streaming form of conv2d_k3 is used
+_CONV2D_STREAM_MIN = 256 * 256
+
+
+def conv2d_stream(x, weight, scale, shift, skip, act, x2=None, aux1=None, ep_split=0):
+    """3x3 stride-1 convolution over cat(x, x2) with 8 | 16 output channels on the vector-unit streaming kernel
+    (d3d_conv2d_k3_stream): large feature-pyramid layers (act 0 | 1) and conv-GRU cells (act 2 | 3, see
+    gru_cell_fused).  Returns None when the layer is not one of those."""
+    Ci0, H, W = x.shape
+    Ci1 = 0 if x2 is None else x2.shape[0]
+    Co = weight.shape[0]
+    if (Co not in (8, 16) or not _use_mfma() or conv_precision() == "bf16" or H * W < _CONV2D_STREAM_MIN
+            or 8 * H * W * 4 >= 2 ** 31 or _os.environ.get("D3D_CONV2D_STREAM", "1") == "0"
+            or (x2 is not None and Ci0 % 8 != 0) or tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3)):
+        return None
+
+    def pack(w):
+        ci = Ci0 + Ci1
+        wp = w.new_zeros(((ci + 7) // 8 * 8, 3, 3, Co))
+        wp[:ci] = w.permute(1, 2, 3, 0)
+        return wp
+    wp = derived_weight(weight, "c2s", pack)
+    out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+    if act <= 1 and skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape mismatch")
+    rc = _lib.load().d3d_conv2d_k3_stream(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, _chk(wp, "wpacked"),
+                                          _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), _opt(aux1, "aux1"),
+                                          int(ep_split), int(act), Co, H, W, _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_conv2d_k3_stream")
+    return out  # pixels from which the vector-unit streaming form of conv2d_k3 is used
 
 
 def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None):
@@ -314,23 +342,10 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
-    if (x2 is None and stride == 1 and Co in (8, 16) and act in (0, 1) and _use_mfma() and conv_precision() != "bf16"
-            and H * W >= _CONV2D_STREAM_MIN and 8 * H * W * 4 < 2 ** 31 and _os.environ.get("D3D_CONV2D_STREAM", "1") != "0"):
-        # large single-input layers with 8 | 16 output channels (feature pyramids): vector-unit streaming kernel
-        def pack(w):
-            cip = (Ci0 + 7) // 8 * 8
-            wp = w.new_zeros((cip, 3, 3, Co))
-            wp[:Ci0] = w.permute(1, 2, 3, 0)
-            return wp
-        wp = derived_weight(weight, "c2s", pack)
-        out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
-        if skip is not None and skip.shape != out.shape:
-            raise ValueError("skip shape mismatch")
-        rc = _lib.load().d3d_conv2d_k3_stream(_chk(x, "x", 3), Ci0, _chk(wp, "wpacked"), _opt(scale, "scale"),
-                                              _opt(shift, "shift"), _opt(skip, "skip"), int(act), Co, H, W,
-                                              _chk(out, "out"), _stream())
-        _lib.check(rc, "d3d_conv2d_k3_stream")
-        return out
+    if stride == 1 and act in (0, 1):
+        y = conv2d_stream(x, weight, scale, shift, skip, act, x2=x2)
+        if y is not None:
+            return y
     if _use_mfma() and Co <= 64:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=act, stride=stride, x2=x2)
         if y is not None:
@@ -810,8 +825,19 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
     Hc = h.shape[0]
     if not _use_mfma() or _os.environ.get("D3D_CONV", "mfma") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
         return None
-    g = conv_fold(x, w_gates, None, b_gates, h, act=2, stride=1, x2=h, ep_split=Hc)
+    # both convolutions of a large cell run on the vector-unit kernel (AdaMVS view, same device: 87.9 ms, with the
+    # gates on the matrix cores 89.3 ms; D3D_GRU_GATES=mfma selects that)
+    g = None
+    if _os.environ.get("D3D_GRU_GATES", "stream") == "stream":
+        g = conv2d_stream(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
+    if g is None:
+        g = conv_fold(x, w_gates, None, b_gates, h, act=2, stride=1, x2=h, ep_split=Hc)
+    if g is None:
+        g = conv2d_stream(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
     if g is None:
         return None
     rh, u = g[:Hc], g[Hc:]
-    return conv_fold(x, w_cand, None, b_cand, h, act=3, stride=1, x2=rh, aux1=u)
+    hn = conv2d_stream(x, w_cand, None, b_cand, h, 3, x2=rh, aux1=u)
+    if hn is None:
+        hn = conv_fold(x, w_cand, None, b_cand, h, act=3, stride=1, x2=rh, aux1=u)
+    return hn

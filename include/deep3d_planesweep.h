@@ -174,12 +174,15 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
                                  const float* skip, int relu, int Ci, int D, int H, int W, float* out,
                                  d3d_stream_t stream);
 
-/* 3x3 stride-1 nn.Conv2d with C_out = 8 | 16 and one input tensor (the full- / half-resolution layers of the feature
- * pyramids, module.py:653-755) on the fp32 vector units; same epilogue as d3d_conv2d_k3 (affine, act 0 | 1, skip added
- * after the activation).  wpacked: weight [Co,Ci,3,3] re-laid out as [Ci rounded up to 8][ky][kx][Co], zero rows for
- * the padding channels. */
-int d3d_conv2d_k3_stream(const float* in, int Ci, const float* wpacked, const float* scale, const float* shift,
-                         const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream);
+/* 3x3 stride-1 nn.Conv2d with C_out = 8 | 16 (the full- / half-resolution layers of the feature pyramids,
+ * module.py:653-755, and the conv-GRU cells of the slice regularisers, module.py:5-51) on the fp32 vector units.
+ * Input = cat(in0 [Ci0], in1 [Ci1]) along the channels (in1 may be NULL with Ci1 = 0; with two inputs Ci0 % 8 == 0).
+ * act 0 | 1: same epilogue as d3d_conv2d_k3 (affine, ReLU, skip added after the activation); act 2 | 3: the ConvGRUCell
+ * epilogues of d3d_conv_fold_f32 (2: sigmoid, channels < ep_split times h = skip; 3: u*h + (1-u)*tanh(y), u = aux1).
+ * wpacked: weight [Co,Ci0+Ci1,3,3] re-laid out as [C_in rounded up to 8][ky][kx][Co], zero rows for the padding. */
+int d3d_conv2d_k3_stream(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpacked, const float* scale,
+                         const float* shift, const float* skip, const float* aux1, int ep_split, int act, int Co, int H,
+                         int W, float* out, d3d_stream_t stream);
 
 /* module.py:736-747 (FeatureNet_mvsnet, "fpn"): out = conv1x1(in) + bias + nearest-x2 upsampling of `coarse`
  * (F.interpolate(..., scale_factor=2, mode="nearest") + self.inner(x)) without materialising the upsampled tensor.

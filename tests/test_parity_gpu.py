@@ -765,3 +765,27 @@ def test_fpn_lateral_upsample_add(ops, Ci, H, W):
     want = F.interpolate(coarse[None], scale_factor=2, mode="nearest")[0] + F.conv2d(x[None].double(), w.double(), b.double())[0].float()
     assert got is not None and float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     assert ops.conv1x1_upskip(x[:, :, : W - 1].contiguous(), w, b, coarse) is None  # odd width: the caller falls back
+
+
+@pytest.mark.parametrize("Cx,Hc,H,W", [(8, 8, 6, 10), (8, 8, 37, 130), (16, 8, 9, 70), (8, 4, 20, 65), (16, 16, 12, 64)])
+def test_gru_cell_on_streaming_kernel(ops, oracle, monkeypatch, Cx, Hc, H, W):
+    """ConvGRUCell (module.py:24-51) with both convolutions on the two-input vector-unit kernel and its fused epilogues
+    (d3d_conv2d_k3_stream act 2 | 3): against the oracle and against the matrix-core form."""
+    rng = np.random.default_rng(Cx * 10 + Hc + W)
+    x = rng.standard_normal((Cx, H, W)).astype(np.float32)
+    h = rng.standard_normal((Hc, H, W)).astype(np.float32)
+    p = {"g.conv_gates.0.weight": (0.15 * rng.standard_normal((2 * Hc, Cx + Hc, 3, 3))).astype(np.float32),
+         "g.conv_gates.0.bias": rng.standard_normal(2 * Hc).astype(np.float32),
+         "g.convc.0.weight": (0.15 * rng.standard_normal((Hc, Cx + Hc, 3, 3))).astype(np.float32),
+         "g.convc.0.bias": rng.standard_normal(Hc).astype(np.float32)}
+    want = oracle.conv_gru_cell(x, h, p, "g.")
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.delenv("D3D_CONV2D_STREAM", raising=False)
+    monkeypatch.setattr(ops, "_CONV2D_STREAM_MIN", 1)
+    args = (dev(x), dev(h), dev(p["g.conv_gates.0.weight"]), dev(p["g.conv_gates.0.bias"]), dev(p["g.convc.0.weight"]),
+            dev(p["g.convc.0.bias"]))
+    got = host(ops.gru_cell_fused(*args))
+    assert np.abs(got - want).max() <= 2e-5
+    monkeypatch.setenv("D3D_CONV2D_STREAM", "0")
+    folded = host(ops.gru_cell_fused(*args))
+    assert np.abs(got - folded).max() <= 2e-5
