@@ -53,7 +53,7 @@ constexpr int NCOMP = NPIXW * NSUB;  // compute waves
 constexpr int NLOADW = 4;       // loader waves: stage the next step's window delta into the rings
 constexpr int NWAVES = NCOMP + NLOADW;  // 12 waves: 3 per SIMD, 168-VGPR budget
 constexpr int THREADS = 64 * NWAVES;
-constexpr int DSEG_MAX = 384;   // planes per workgroup segment upper bound
+constexpr int DSEG_MAX = 128;   // planes per workgroup segment upper bound (launch_one never asks for more)
 constexpr int MAXSTEPS = 64;    // >= DSEG_MAX / NSUB, <= 64 (one lane per step)
 constexpr int PFD = 2;          // delta staging items (64 positions x CH channels) a loader wave keeps in flight
 #ifndef D3D_LDS_PIPE
@@ -62,15 +62,21 @@ constexpr int PFD = 2;          // delta staging items (64 positions x CH channe
 constexpr int LDS_PIPE = D3D_LDS_PIPE;     // (quad, view) units whose taps are requested ahead of the one being blended
 constexpr int NCAND = 4;        // candidate step sizes: 4, 2, 1, 1/2 times NSUB planes
 constexpr int MAXRECTS = 256;
-#ifndef RING_ALIGN
-#define RING_ALIGN 0
-#endif
-// Floats between ring rows.  Padded to a multiple of the 64 LDS banks: a sample row change inside a 16-lane
-// ds_read_b128 group then keeps every column's bank, so only column skips / repeats can conflict.
+// LDS bank layout of the rings (tools/bank_sim.py models it on config 2; PMC: SQ_LDS_BANK_CONFLICT).  A ds_read_b128 is
+// serviced in four 16-lane groups, one 16-byte slot (4 banks) per lane, 16 slots per LDS cycle.  A lane group holds an
+// 8 x 2 block of reference pixels (lane -> pixel map below), whose taps span < 8 columns and 2 (rarely 3) rows of a
+// source view for scales up to 1.14.  With a position stride of an ODD number of slots (STRIDE = CH + 4 floats) and a
+// row pitch of 8 slots mod 16 (32 floats mod 64), two positions share a slot only if they lie (16,0), (8,1) or (0,2)
+// apart -- outside such a block.  The torus wrap keeps that property when RW is a multiple of 8 and RH is even.
+// Round 1 (16 x 1 pixels per group, unpadded pitch): 6.2 LDS cycles per tap read on config 2; this layout: 4.3.
+constexpr int RING_RW_QUANT = 8;
+constexpr int RING_RH_QUANT = 2;
 template <int STRIDE>
 __host__ __device__ __forceinline__ int ring_row_floats(int RW) {
-    return RING_ALIGN ? (((RW + 1) * STRIDE + 63) & ~63) : (RW + 1) * STRIDE;
-}   // non-empty delta rectangles per workgroup segment
+    const int n = (RW + 1) * STRIDE;
+    return ((n - 32 + 63) & ~63) + 32;   // smallest pitch >= n that is 32 mod 64
+}
+// non-empty delta rectangles per workgroup segment: MAXRECTS
 
 struct TiledArgs {
     int ngroups;     // channel groups (C / CH), one workgroup pass each
@@ -225,12 +231,22 @@ __device__ __forceinline__ f4 lds_read4(const float* lds, int byte_addr) {
     return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(lds) + byte_addr);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+// Two channels per VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32): each half is the IEEE operation,
+// so results are bit-identical to the one-channel forms.  Why: beside the ds_read_b128 tap stream a SIMD's time goes
+// with the NUMBER of VALU instructions it issues, not with their FLOPs (tools/issue_model.hip: 24 plain vs 12 packed
+// instructions per unit = 302 vs 235 cycles per unit at 8 waves per CU).
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 lo2(const f4& v) { return (f2){v[0], v[1]}; }
+__device__ __forceinline__ f2 hi2(const f4& v) { return (f2){v[2], v[3]}; }
+__device__ __forceinline__ f4 cat2(f2 a, f2 b) { return (f4){a[0], a[1], b[0], b[1]}; }
+
 // same summation order as grid_sample: nw, ne, sw, se
 __device__ __forceinline__ f4 blend(f4 t00, f4 t01, f4 t10, f4 t11, float nw, float ne, float sw, float se) {
-    f4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = fmaf(t11[k], se, fmaf(t10[k], sw, fmaf(t01[k], ne, t00[k] * nw)));
-    return r;
+    const f2 wnw = {nw, nw}, wne = {ne, ne}, wsw = {sw, sw}, wse = {se, se};
+    f2 a = pk_fma(lo2(t11), wse, pk_fma(lo2(t10), wsw, pk_fma(lo2(t01), wne, lo2(t00) * wnw)));
+    f2 b = pk_fma(hi2(t11), wse, pk_fma(hi2(t10), wsw, pk_fma(hi2(t01), wne, hi2(t00) * wnw)));
+    return cat2(a, b);
 }
 
 // Store with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit
@@ -298,13 +314,13 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     const int x1c = min(x0 + TW - 1, w - 1), y1c = min(y0 + TH - 1, h - 1);
 
     // Lane -> pixel.  ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and
-    // {4-11,16-19,28-31} (+32): map each group to 16 consecutive pixels so that a unit-scale sweep
-    // puts its 16 lanes on 16 distinct 16-byte bank slots.  Quads of lanes stay on 4 consecutive
-    // pixels, so global stores still coalesce into the same 128-byte row segments.
+    // {4-11,16-19,28-31} (+32; confirmed with tools/lds_groups.hip): each group takes an 8 x 2 block of
+    // pixels (bank layout: see ring_row_floats).  Lanes 0-15 / 16-31 / 32-47 / 48-63 each hold 16
+    // consecutive pixels of one row, so a store instruction still writes whole 64-byte row segments.
     const int l5 = lane & 31;
-    const int pxl = (l5 < 4) ? l5 : (l5 < 12) ? l5 + 12 : (l5 < 16) ? l5 - 8 : (l5 < 20) ? l5 + 8 : (l5 < 28) ? l5 - 12 : l5;
-    const int px = x0 + pxl;
-    const int py = y0 + pw * 2 + (lane >> 5);
+    const int pxl = (l5 < 4) ? l5 : (l5 < 12) ? l5 + 4 : (l5 < 20) ? l5 - 8 : (l5 < 28) ? l5 - 20 : l5 - 16;
+    const int px = x0 + pxl + 16 * (lane >> 5);
+    const int py = y0 + pw * 2 + (l5 >> 4);
     const bool valid = (px < w) && (py < h);
     const int pix = valid ? py * w + px : 0;
     const unsigned pixb = (unsigned)pix * 4u;  // per-lane byte offset (h*w < 2^30)
@@ -423,12 +439,21 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             const int nsteps = ldsi[CHD + (cand * NSRC) * 4 + 3];
             const bool act = lane < nsteps;
             int wx0[NSRC], wy0[NSRC], ww[NSRC], wh[NSRC], RW[NSRC], RH[NSRC];
-            int bad = 0, total = 0;
+            int bad = 0, total = 0, totalq = 0;
+            int RWq[NSRC], RHq[NSRC];   // rounded up for the bank layout (any size >= the union span is valid)
 #pragma unroll
             for (int i = 0; i < NSRC; ++i) {
                 const int* hd = ldsi + CHD + (cand * NSRC + i) * 4;
                 RW[i] = hd[0]; RH[i] = hd[1]; bad |= hd[2];
+                RWq[i] = (RW[i] + RING_RW_QUANT - 1) / RING_RW_QUANT * RING_RW_QUANT;
+                RHq[i] = (RH[i] + RING_RH_QUANT - 1) / RING_RH_QUANT * RING_RH_QUANT;
                 total += ring_row_floats<STRIDE>(RW[i]) * (RH[i] + 1);
+                totalq += ring_row_floats<STRIDE>(RWq[i]) * (RHq[i] + 1);
+            }
+            if (totalq <= a.cap_floats) {   // the conflict-free ring sizes fit: use them
+                total = totalq;
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) { RW[i] = RWq[i]; RH[i] = RHq[i]; }
             }
             if (bad || total > a.cap_floats) continue;
 #pragma unroll
@@ -795,8 +820,9 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     };
     auto accumulate = [&](f4& s, f4& qq, float& pair_acc, const f4& val, int q, int i) {
         if (MODE == MODE_VARIANCE) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { s[k] += val[k]; qq[k] = fmaf(val[k], val[k], qq[k]); }
+            const f2 vl = lo2(val), vh = hi2(val);
+            s = cat2(lo2(s) + vl, hi2(s) + vh);
+            qq = cat2(pk_fma(vl, vl, lo2(qq)), pk_fma(vh, vh, hi2(qq)));
         } else if (MODE == MODE_WEIGHTED) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[k] = fmaf(val[k] * r[q][k], vw[i], s[k]);
@@ -814,7 +840,13 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     long long t_ww = 0;
     long long t_w = 0, t_w0 = 0, t_c = 0, t_mark = 0;
     if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
-    // (s_setprio 2 / 3 on the compute waves: no effect, 6.49 / 6.46 ms next to 6.51 / 6.47 ms without)
+    // (s_setprio 2 / 3 on ALL compute waves: no effect, 6.49 / 6.46 ms next to 6.51 / 6.47 ms without)
+#ifdef D3D_YOUNG_PRIO
+    // Issue arbitration is priority, then age: of the two compute waves of a SIMD the older one (waves 0-3) wins every
+    // contested slot, finishes its planes of a step early and idles at the step barrier (~95k of 427k cycles per workgroup)
+    // while the younger one runs alone.  Static priority for the younger half evens the two out.
+    if (wave >= NCOMP / 2) __builtin_amdgcn_s_setprio(D3D_YOUNG_PRIO);
+#endif
     for (int gi = 0; gi < a.ngroups; ++gi) {
     grp = gi;
     c0 = gi * CH;
@@ -835,6 +867,9 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         Win W[NSRC];
 #pragma unroll
         for (int i = 0; i < NSRC; ++i) W[i] = load_win(ring ? k : 0, i);
+#ifdef D3D_X_GEO
+        TapL tkeep[NSRC];
+#endif
 
         for (int j = 0; sub + NSUB * j < SP; ++j) {
             const int dl_ = k * SP + sub + NSUB * j;
@@ -852,6 +887,20 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             if (!valid) continue;  // one EXEC region per plane instead of one branch per store
 
             if (ring) {
+#ifdef D3D_X_GEO   // timing experiment (results wrong): geometry once per step instead of once per plane
+                static_assert(true, "");
+                TapL t[NSRC];
+                if (j == 0) {
+#pragma unroll
+                    for (int i = 0; i < NSRC; ++i) {
+                        float u, v;
+                        project(ray[i], T0[i], T1[i], T2[i], dv, h, w, u, v);
+                        tkeep[i] = make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) t[i] = tkeep[i];
+#else
                 TapL t[NSRC];
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
@@ -859,6 +908,14 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                     project(ray[i], T0[i], T1[i], T2[i], dv, h, w, u, v);
                     t[i] = make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
                 }
+#endif
+#ifdef D3D_X_ADDR  // timing experiment (results wrong): conflict-free tap addresses (16 consecutive ring positions per lane group)
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    t[i].a0 = rbase[i] * 4 + ((lane & 31) + (lane >> 5) * (RW[i] + 1)) * (STRIDE * 4);
+                    t[i].a1 = t[i].a0 + (RW[i] + 1) * (STRIDE * 4);
+                }
+#endif
                 // Units u = (quad q, view i) in q-major order; the four taps of unit u+1 are requested
                 // before unit u is blended, so LDS latency overlaps the 24 VALU ops of a unit.
                 constexpr int NU = Q * NSRC;
@@ -1005,7 +1062,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     // segments: enough workgroups to fill 256 CUs a few times over, each at most DSEG_MAX planes
     // 128-plane segments measured best on config 2 (rings sized per segment follow the depth-dependent
     // window size; shorter segments pay the planning prologue more often)
-    int dseg_cap = 128;
+    int dseg_cap = DSEG_MAX;
     if (const char* e = getenv("D3D_TILED_DSEG")) dseg_cap = max(NSUB, min(atoi(e), DSEG_MAX));  // experiments
     int nseg = ceil_div(p.D, dseg_cap);
     const long tiles = (long)a.tiles_x * a.tiles_y * a.ngroups;
@@ -1036,8 +1093,8 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         }
     }
     if (getenv("D3D_TILED_STATS")) {  // debug only: synchronous, allocates
-        hipMalloc(&a.stats, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
-        hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
+        (void)hipMalloc(&a.stats, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
+        (void)hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
         a.tstats = reinterpret_cast<unsigned long long*>(a.stats + 8);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(THREADS), LDS_BYTES, stream, p, a);
@@ -1045,8 +1102,8 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     if (a.stats) {
         unsigned hs[8];
         unsigned long long ht[24];
-        hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
-        hipMemcpy(ht, a.tstats, sizeof(ht), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ht, a.tstats, sizeof(ht), hipMemcpyDeviceToHost);
         fprintf(stderr, "[d3d tiled timing] per-WG mean cycles: compute wave 0: prologue %.0f | barrier wait %.0f (initial window %.0f) | compute %.0f | total %.0f || loader 0: barrier wait %.0f | decode+issue %.0f | wait+write %.0f\n",
                 ht[0] / (double)nblk, ht[1] / (double)nblk, ht[5] / (double)nblk, ht[3] / (double)nblk, ht[4] / (double)nblk,
                 ht[2] / (double)nblk, ht[6] / (double)nblk, ht[7] / (double)nblk);
@@ -1058,7 +1115,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
                 CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
                 a.cap_floats / L::STRIDE, hs[5], a.dseg);
-        hipFree(a.stats);
+        (void)hipFree(a.stats);
     }
     return D3D_OK;
 }
