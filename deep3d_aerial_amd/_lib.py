@@ -13,23 +13,26 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libdeep3d_planesweep.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _i64 = ctypes.c_int64
 _f = ctypes.c_float
+_sz = ctypes.c_size_t
 
 # name -> argtypes; restype is int except where noted.  Mirrors include/deep3d_planesweep.h.
 SIGNATURES = {
     "d3d_version": [],
     "d3d_last_error": [],
     "d3d_compose_projections": [_vp, _i, _vp, _vp],
-    "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_variance_volume_f16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_pair_corr_mean": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_debug_force_path": [_i],
+    "d3d_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],  # returns size_t
+    "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_variance_volume_f16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_pair_corr_mean": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_softargmin_conf4": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "d3d_online_regress_update": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_online_regress_finalize": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
@@ -100,7 +103,8 @@ def load():
         except AttributeError as e:
             raise LibraryMissing("symbol %s missing from %s" % (name, SO_PATH)) from e
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "d3d_last_error" else ctypes.c_int
+        fn.restype = (ctypes.c_char_p if name == "d3d_last_error" else
+                      ctypes.c_size_t if name == "d3d_sweep_workspace_bytes" else ctypes.c_int)
     if lib.d3d_version() != ABI_VERSION:
         raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))
     _lib = lib

@@ -401,7 +401,9 @@ static int launch_conv3d_co8(const ConvParams& p, hipStream_t stream) {
     // 1376 wide +13 % / +8 % faster with two, 688 wide 10 % slower)
     const double pad1 = ceil_div(p.W, 64) * 64.0 / p.W, pad2 = ceil_div(p.W, 128) * 128.0 / p.W;
     int xp = (pad2 - pad1 <= 0.04) ? 2 : 1;
-    if (const char* e = getenv("D3D_CONV_CO8_XP")) xp = atoi(e) == 1 ? 1 : 2;  // experiments
+#ifdef D3D_EXPERIMENTS
+    if (const char* e = getenv("D3D_CONV_CO8_XP")) xp = atoi(e) == 1 ? 1 : 2;
+#endif
     const int gx = ceil_div(p.W, 64 * xp), gy = ceil_div(p.H, C1_TY);
     int nz = 1;
     while ((long)gx * gy * nz < 2048 && p.D / (nz * 2) >= 8) nz *= 2;
@@ -817,9 +819,12 @@ int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, cons
     p.Ci0 = Ci; p.Co = Co; p.D = D; p.H = H; p.W = W;
     p.Do = (D - 1) / stride + 1; p.Ho = (H - 1) / stride + 1; p.Wo = (W - 1) / stride + 1;
     p.stride = stride; p.act = relu ? 1 : 0; p.skip_after_act = 1;
-    if (Co == 1 && stride == 1 && Ci == 8) {  // streaming single-channel form (D3D_CONV_CO1=0: generic kernel)
-        const char* e = getenv("D3D_CONV_CO1");
-        if (!e || atoi(e) != 0) {
+    if (Co == 1 && stride == 1 && Ci == 8) {  // streaming single-channel form
+        bool co1 = true;
+#ifdef D3D_EXPERIMENTS
+        if (const char* e = getenv("D3D_CONV_CO1")) co1 = atoi(e) != 0;   // 0: generic kernel
+#endif
+        if (co1) {
             int rc = launch_conv3d_co1(p, (hipStream_t)stream);
             if (rc != D3D_ERR_UNSUPPORTED) return rc;
         }

@@ -932,8 +932,10 @@ static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1
     }
     // 16-byte staging loads when every patch row starts on a 16-byte boundary: W % 4 == 0, aligned tensors, and the
     // patch origin moved left to a multiple of 4 columns (tile origins are multiples of 16 columns)
-    p.vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1)) & 15) == 0 &&
-            !getenv("D3D_CONV_SCALAR_STAGING");
+    p.vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1)) & 15) == 0;
+#ifdef D3D_EXPERIMENTS
+    if (getenv("D3D_CONV_SCALAR_STAGING")) p.vec = false;
+#endif
     p.sh = p.vec ? (p.xmin & 3) : 0;
     // single-row planes (a 2D image handed over as [C, rows, 1, W]): the four waves sit side by side
     p.wyn = (H == 1 && Ho == 1 && p.yspan == 1 && p.fy == 1 && p.Gy == 1) ? 1 : 4;
@@ -976,7 +978,9 @@ static int conv_fold_impl(bool bf16, const float* in0, int Ci0, const float* in1
     // Loader / MFMA wave split (double-buffered patch): measured 8-11 % faster on row-streamed images (short
     // steps), 5-10 % slower on volumes (fewer MFMA waves per CU) -- so images only.  D3D_CONV_SPLIT=0|1 overrides.
     bool split = p.wyn == 1;
+#ifdef D3D_EXPERIMENTS
     if (const char* e = getenv("D3D_CONV_SPLIT")) split = atoi(e) != 0;
+#endif
     split = split && lds_bytes_for(p, MT, NT, CK, bf16, true) <= 156 * 1024 && !(MT == 4 && NS == 3);
     if (act == 3 && !(split && MT == 1)) {
         set_error("conv_stream: the GRU update epilogue exists in the image (split) kernels with <= 16 GEMM rows only");

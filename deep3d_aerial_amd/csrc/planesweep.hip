@@ -12,6 +12,7 @@
 
 #include "common.h"
 
+#include <atomic>
 #include <cstring>
 
 namespace d3d {
@@ -34,6 +35,7 @@ int hip_status(hipError_t e, const char* what) {
 // defined in planesweep_tiled.hip: returns D3D_ERR_UNSUPPORTED when the shape is outside
 // what the tiled kernel handles, in which case the caller uses the direct kernel.
 int launch_tiled(int mode, const struct SweepParams& p, hipStream_t stream);
+size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes);
 
 }  // namespace d3d
 
@@ -237,14 +239,19 @@ static int check_dims(int C, int D, int h, int w) {
     return D3D_OK;
 }
 
+// Test hook (d3d_debug_force_path): pins the kernel family so that the parity suite can run both on the same inputs.
+// Every other experiment switch needs a -DD3D_EXPERIMENTS build; nothing here reads the environment.
+static std::atomic<int> g_force_path{0};   // 0 dispatcher's choice | 1 direct-gather kernel | 2 LDS-ring kernel
+static int forced_path() { return g_force_path.load(std::memory_order_relaxed); }
+
 static int sweep_dispatch(int mode, const SweepParams& p, hipStream_t stream) {
-    const char* force = getenv("D3D_FORCE_PATH");  // "direct" | "tiled" (testing / profiling only)
-    bool want_direct = force && !strcmp(force, "direct");
-    if (!want_direct) {
+    const int force = forced_path();
+    if (force != 1) {
         int rc = launch_tiled(mode, p, stream);
         if (rc != D3D_ERR_UNSUPPORTED) return rc;
-        if (force && !strcmp(force, "tiled")) return rc;
+        if (force == 2) return rc;
     }
+    if (p.elem_bytes == 2) return launch_direct<MODE_VARIANCE, __half>(p, stream);
     switch (mode) {
         case MODE_WARP: return launch_direct<MODE_WARP>(p, stream);
         case MODE_VARIANCE: return launch_direct<MODE_VARIANCE>(p, stream);
@@ -273,8 +280,19 @@ int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_
     return D3D_OK;
 }
 
+int d3d_debug_force_path(int path) {
+    D3D_REQUIRE(path >= 0 && path <= 2, "path must be 0 (auto), 1 (direct) or 2 (tiled)");
+    g_force_path.store(path, std::memory_order_relaxed);
+    return D3D_OK;
+}
+
+size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes) {
+    if (n_views < 2 || C <= 0 || D <= 0 || h <= 1 || w <= 1 || (elem_bytes != 4 && elem_bytes != 2)) return 0;
+    return tiled_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes);
+}
+
 int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int depth_mode, int C, int D, int h,
-                  int w, float* out, d3d_stream_t stream) {
+                  int w, float* out, void* workspace, size_t workspace_bytes, d3d_stream_t stream) {
     D3D_REQUIRE(src && proj34 && depth && out, "null pointer");
     D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
     int rc = check_dims(C, D, h, w);
@@ -288,11 +306,15 @@ int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int
     p.n_src = 1;
     p.C = C; p.D = D; p.h = h; p.w = w;
     p.depth_mode = depth_mode;
+    p.elem_bytes = 4;
+    p.workspace = workspace;
+    p.workspace_bytes = workspace ? workspace_bytes : 0;
     return sweep_dispatch(MODE_WARP, p, (hipStream_t)stream);
 }
 
 static int fill_multi(SweepParams& p, const float* const* feats, const float* proj34, const float* depth,
-                      int depth_mode, int n_views, int C, int D, int h, int w, float* out) {
+                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, void* workspace,
+                      size_t workspace_bytes, int elem_bytes = 4) {
     D3D_REQUIRE(feats && proj34 && depth && out, "null pointer");
     D3D_REQUIRE(n_views >= 2 && n_views <= D3D_MAX_VIEWS, "n_views=%d out of range [2,%d]", n_views, D3D_MAX_VIEWS);
     D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
@@ -308,42 +330,49 @@ static int fill_multi(SweepParams& p, const float* const* feats, const float* pr
     p.n_src = n_views - 1;
     p.C = C; p.D = D; p.h = h; p.w = w;
     p.depth_mode = depth_mode;
+    p.elem_bytes = elem_bytes;
+    p.workspace = workspace;
+    p.workspace_bytes = workspace ? workspace_bytes : 0;
     return D3D_OK;
 }
 
 int d3d_variance_volume(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
-                        int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream) {
+                        int n_views, int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
+                        d3d_stream_t stream) {
     SweepParams p = {};
-    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out);
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes);
     if (rc) return rc;
     return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
 }
 
 int d3d_variance_volume_f16(const void* const* feats, const float* proj34, const float* depth, int depth_mode,
-                            int n_views, int C, int D, int h, int w, void* out, d3d_stream_t stream) {
+                            int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
+                            d3d_stream_t stream) {
     SweepParams p = {};
-    // same argument checks; the pointers are carried in the fp32-typed slots and reinterpreted by the kernel
+    // same argument checks; the pointers are carried in the fp32-typed slots and reinterpreted by the kernels
     int rc = fill_multi(p, reinterpret_cast<const float* const*>(feats), proj34, depth, depth_mode, n_views, C, D, h, w,
-                        reinterpret_cast<float*>(out));
+                        reinterpret_cast<float*>(out), workspace, workspace_bytes, 2);
     if (rc) return rc;
-    return launch_direct<MODE_VARIANCE, __half>(p, (hipStream_t)stream);
+    return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
 }
 
 int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
-                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream) {
+                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, void* workspace,
+                      size_t workspace_bytes, d3d_stream_t stream) {
     SweepParams p = {};
     D3D_REQUIRE(weights, "null weights");
-    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out);
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes);
     if (rc) return rc;
     p.weights = weights;
     return sweep_dispatch(MODE_WEIGHTED, p, (hipStream_t)stream);
 }
 
 int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, const float* depth, int depth_mode,
-                       int C, int D, int h, int w, float* out, d3d_stream_t stream) {
+                       int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
+                       d3d_stream_t stream) {
     const float* feats[2] = {ref, src};
     SweepParams p = {};
-    int rc = fill_multi(p, feats, proj34, depth, depth_mode, 2, C, D, h, w, out);
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, 2, C, D, h, w, out, workspace, workspace_bytes);
     if (rc) return rc;
     return sweep_dispatch(MODE_PAIR, p, (hipStream_t)stream);
 }

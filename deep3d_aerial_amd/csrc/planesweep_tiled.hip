@@ -34,9 +34,8 @@
 // gather, not MFMA work.
 #include "common.h"
 
-#include <map>
-#include <mutex>
-#include <utility>
+#include <hip/hip_fp16.h>
+
 #include "sweep_params.h"
 
 #include <cstdlib>
@@ -61,7 +60,7 @@ constexpr int PFD = 2;          // delta staging items (64 positions x CH channe
 #endif
 constexpr int LDS_PIPE = D3D_LDS_PIPE;     // (quad, view) units whose taps are requested ahead of the one being blended
 constexpr int NCAND = 4;        // candidate step sizes: 4, 2, 1, 1/2 times NSUB planes
-constexpr int MAXRECTS = 256;
+constexpr int MAXRECTS = 512;   // non-empty delta rectangles per workgroup segment (4 words each)
 // LDS bank layout of the rings (tools/bank_sim.py models it on config 2; PMC: SQ_LDS_BANK_CONFLICT).  A ds_read_b128 is
 // serviced in four 16-lane groups, one 16-byte slot (4 banks) per lane, 16 slots per LDS cycle.  A lane group holds an
 // 8 x 2 block of reference pixels (lane -> pixel map below), whose taps span < 8 columns and 2 (rarely 3) rows of a
@@ -92,14 +91,14 @@ struct TiledArgs {
 // LDS map (ints/floats):
 //   [zero cell 2*STRIDE][pmin DSEG_MAX][pmax DSEG_MAX][header 32][plan table MAXSTEPS*NSRC*8]
 //   [rect starts MAXSTEPS+4][rect descriptors MAXRECTS*8][rings ...]
-// header: 0 mode (1 rings, 0 global gather) | 1 planes per step | 2 nsteps | 4+4i.. RW, RH, base, - per view
+// header: 0 mode (1 rings, 0 global gather) | 1 planes per step | 2 nsteps | 4+4i.. RW, RH, base, RW | RH << 8 | (base/4) << 16 per view
 // plan entry (per step, view): wx0, wy0, ww, wh, ox, oy, -, -
-// rect descriptor (non-empty delta rectangles, grouped by step): rx, ry, rw | view<<16, positions,
-//   first position (cumulative within the step), -,
-//   ring col | row << 16 of the rect origin (unwrapped), ring base | RW << 18 | RH << 25 ... see item()
-template <int CH, int NSRC>
+// rect descriptor (non-empty delta rectangles, grouped by step), 4 words:
+//   (rx + 1) | (ry + 1) << 16,  width | view << 12 | first position (cumulative within the step) << 16,
+//   positions,  ring col | row << 16 of the rect origin (unwrapped)
+template <int CW, int NSRC>   // CW = 4-byte words per ring position (CH fp32 channels, or CH/2 words of fp16 pairs)
 struct Lds {
-    static constexpr int STRIDE = CH + 4;
+    static constexpr int STRIDE = CW + 4;
     static constexpr int ZERO = 0;
     static constexpr int PMIN = 2 * STRIDE;
     static constexpr int PMAX = PMIN + DSEG_MAX;
@@ -109,7 +108,7 @@ struct Lds {
     static constexpr int SST = PLAN + MAXSTEPS * NSRC * 8;
     static constexpr int STOT = SST + MAXSTEPS + 4;   // positions to stage per step
     static constexpr int RECTS = ((STOT + MAXSTEPS + 3) / 4) * 4;
-    static constexpr int DATA = RECTS + (MAXRECTS + 1) * 8;  // 16-byte aligned
+    static constexpr int DATA = RECTS + (MAXRECTS + 1) * 4;  // 16-byte aligned
 };
 
 struct Win {  // wave-uniform window of one view at one step
@@ -269,13 +268,50 @@ __device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte
 #endif
 }
 
+// fp16 storage: one 2-byte store per lane (a wave writes two 64-byte row segments per channel and plane)
+__device__ __forceinline__ void store_sbase_h(unsigned long long sb, unsigned byte_off, float v) {
+    const _Float16 hv = (_Float16)v;   // RNE
+    const unsigned bits = __builtin_bit_cast(unsigned short, hv);
+#ifdef D3D_NOSTORE
+    asm volatile("" : : "v"(byte_off), "v"(bits), "s"(sb));
+#else
+    asm volatile("global_store_short %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
+#endif
+}
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+// fp32 fma whose first factor is the LOW / HIGH fp16 half of a 32-bit word (v_fma_mix_f32): the fp16 tap is widened
+// inside the instruction -- exact -- so no conversion instruction and no fp32 copy of the tap exist (hipcc prefers
+// v_cvt_f32_f16 + packed fp32 fma here: 32 more instructions and 32 more live registers per 8-channel unit).
+__device__ __forceinline__ float fma_mix_lo(float pair, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(float pair, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float ldf(const float* q) { return *q; }
+__device__ __forceinline__ float ldf(const __half* q) { return __half2float(*q); }
+
 }  // namespace
 
-template <int MODE, int NSRC, int CH>
+// T = float: tensors as declared in SweepParams.  T = __half (MODE_VARIANCE only; BASELINE config 5): feats[] and out
+// are fp16 tensors of the same shapes, the rings hold fp16 cells (half the LDS bytes per tap), every product and sum
+// is fp32 (v_fma_mix_f32 reads the fp16 tap directly), the result is rounded once (RNE) at the store.
+template <int MODE, int NSRC, int CH, typename T = float>
 __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {
-    using L = Lds<CH, NSRC>;
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int CW = CH * (int)sizeof(T) / 4;   // words per ring position
+    constexpr int CPC = 16 / (int)sizeof(T);      // channels per 16-byte chunk (one ds_read_b128): 4 | 8
+    using L = Lds<CW, NSRC>;
     constexpr int STRIDE = L::STRIDE;
-    constexpr int Q = CH / 4;
+    constexpr int Q = CW / 4;                     // 16-byte chunks per position
+    static_assert(!F16 || MODE == MODE_VARIANCE, "fp16 storage is built for the variance volume only");
+    constexpr bool VIEW_MAJOR = F16;             // unit order of the compute loop (see there)
+    constexpr int MAXRS = 4 * NSRC;               // delta rectangles a step can have (left | right | top | bottom per view)
+    static_assert(NSRC <= 15, "rect descriptors keep the view in 4 bits");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsi = reinterpret_cast<int*>(lds);
 
@@ -323,7 +359,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     const int py = y0 + pw * 2 + (l5 >> 4);
     const bool valid = (px < w) && (py < h);
     const int pix = valid ? py * w + px : 0;
-    const unsigned pixb = (unsigned)pix * 4u;  // per-lane byte offset (h*w < 2^30)
+    const unsigned pixb = (unsigned)pix * (unsigned)sizeof(T);  // per-lane byte offset (h*w < 2^30)
     const float xf = (float)px, yf = (float)py;
 
     // --- zero cell and per-plane depth range of this patch -------------------------------------
@@ -486,13 +522,14 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                         ldsi[L::HDR + 4 + 4 * i + 0] = RW[i];
                         ldsi[L::HDR + 4 + 4 * i + 1] = RH[i];
                         ldsi[L::HDR + 4 + 4 * i + 2] = base;
+                        ldsi[L::HDR + 4 + 4 * i + 3] = RW[i] | (RH[i] << 8) | ((base >> 2) << 16);
                     }
                     base += ring_row_floats<STRIDE>(RW[i]) * (RH[i] + 1);
                 }
                 // ---- staging items of every step: window(k) minus window(k-1) as <= 4 rectangles per
                 // view, cut into items of 64 positions (all CH channels of the group).
                 int cnt[NSRC][4], rx[NSRC][4], ry[NSRC][4], rwid[NSRC][4], nel[NSRC][4];
-                int T = 0;
+                int npos = 0;   // positions this step stages
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
                     const int xa = wx0[i], xb = wx0[i] + ww[i] - 1, ya = wy0[i], yb = wy0[i] + wh[i] - 1;
@@ -511,7 +548,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                     for (int r = 0; r < 4; ++r) {
                         nel[i][r] = act ? max(rwid[i][r], 0) * max(rh_[r], 0) : 0;
                         cnt[i][r] = (nel[i][r] + 63) >> 6;
-                        T += cnt[i][r];
+                        npos += nel[i][r];
                     }
                 }
                 int nrect = 0;
@@ -526,7 +563,8 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                     if (lane >= sft) incl += o;
                 }
                 const int total_rects = __shfl(incl, 63);
-                if (total_rects > MAXRECTS || !dims_ok) {
+                // (field widths of the descriptors: a step stages < 65536 positions, windows are < 4096 wide)
+                if (total_rects > MAXRECTS || !dims_ok || __any(npos > 0xffff) || w > 0xfff0 || h > 0xfff0) {
                     mode = 0;  // cannot describe the staging work: gather from global memory instead
                 } else {
                     int idx = incl - nrect;
@@ -538,15 +576,12 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (cnt[i][r] > 0) {
-                                int* e = ldsi + L::RECTS + 8 * idx;
-                                e[0] = rx[i][r];
-                                e[1] = ry[i][r];
-                                e[2] = rwid[i][r] | (i << 16);
-                                e[3] = nel[i][r];
-                                e[4] = pstart;
-                                // ring coordinates of the rect origin (unwrapped: < 2*RW, 2*RH) and ring geometry
-                                e[6] = (rx[i][r] - wx0[i] + oxv[i]) | ((ry[i][r] - wy0[i] + oyv[i]) << 16);
-                                e[7] = RW[i] | (RH[i] << 8) | ((basev[i] >> 2) << 16);
+                                int* e = ldsi + L::RECTS + 4 * idx;
+                                e[0] = (rx[i][r] + 1) | ((ry[i][r] + 1) << 16);   // windows start at >= -1
+                                e[1] = rwid[i][r] | (i << 12) | (pstart << 16);
+                                e[2] = nel[i][r];
+                                // ring coordinates of the rect origin (unwrapped: < 2*RW, 2*RH)
+                                e[3] = (rx[i][r] - wx0[i] + oxv[i]) | ((ry[i][r] - wy0[i] + oyv[i]) << 16);
                                 pstart += nel[i][r];
                                 ++idx;
                             }
@@ -614,17 +649,19 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     }
     // Element `el` (0..T-1) of step k's flattened delta -> source address and ring slot of this lane.
     // Each lane finds its own rectangle (<= 16 per step), so items are densely packed.
-    auto item = [&](int el, int T, int rb, const int (&pst16)[16]) -> Item {
+    auto item = [&](int el, int Tn, int rb, const int (&pst16)[MAXRS]) -> Item {
         Item I;
-        const bool live = el < T;
+        const bool live = el < Tn;
         // rect holding element el: count the rect starts <= el (starts beyond the step's rects are INT_MAX)
         int ridx = rb - 1;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) ridx += (pst16[rr] <= el) ? 1 : 0;
+        for (int rr = 0; rr < MAXRS; ++rr) ridx += (pst16[rr] <= el) ? 1 : 0;
         ridx = max(ridx, rb);
-        const int* e = ldsi + L::RECTS + 8 * ridx;
-        const int rx = e[0], ry = e[1], e2 = e[2], pst = e[4], e6 = e[6], e7 = e[7];
-        const int rwid = e2 & 0xffff, vi = e2 >> 16;
+        const int* e = ldsi + L::RECTS + 4 * ridx;
+        const int e0 = e[0], e1 = e[1], e6 = e[3];
+        const int rx = (e0 & 0xffff) - 1, ry = (e0 >> 16) - 1;
+        const int rwid = e1 & 0xfff, vi = (e1 >> 12) & 0xf, pst = (unsigned)e1 >> 16;
+        const int e7 = ldsi[L::HDR + 4 + 4 * vi + 3];   // ring geometry of the rect's view
         const int RWv = e7 & 0xff, RHv = (e7 >> 8) & 0xff, bs = (e7 >> 16) << 2;
         const int pos = el - pst;
         const int cy = (int)(((float)pos + 0.5f) * __builtin_amdgcn_rcpf((float)max(rwid, 1)));
@@ -638,7 +675,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #pragma unroll
         for (int i = 1; i < NSRC; ++i) dsel = (vi == i) ? fdelta[i] : dsel;
         if (a.cl)  // one position's CH channels are contiguous: 16-byte loads
-            I.g = a.cl + ((size_t)(vi * a.ngroups + grp) * plane + (size_t)(ok ? sy * w + sx : 0)) * CH;
+            I.g = a.cl + ((size_t)(vi * a.ngroups + grp) * plane + (size_t)(ok ? sy * w + sx : 0)) * CW;
         else
             I.g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.feats[1]) + dsel) + (size_t)c0 * plane +
                   (ok ? sy * w + sx : 0);
@@ -682,24 +719,24 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         if (k > 0) return;
 #endif
         const int rb = rfl(ldsi[L::SST + k]), re = rfl(ldsi[L::SST + k + 1]);
-        const int T = rfl(ldsi[L::STOT + k]);
-        const int nitems = (T + 63) >> 6;
-        // first positions of the step's (<= 16) rects: one LDS read by 16 lanes, then wave-uniform copies
-        const int psv = (lane < re - rb) ? ldsi[L::RECTS + 8 * (rb + min(lane, 15)) + 4] : 0x7fffffff;
-        int pst16[16];
+        const int Tn = rfl(ldsi[L::STOT + k]);
+        const int nitems = (Tn + 63) >> 6;
+        // first positions of the step's (<= 4 per view) rects: one LDS read by MAXRS lanes, then wave-uniform copies
+        const int psv = (lane < re - rb) ? (int)((unsigned)ldsi[L::RECTS + 4 * (rb + min(lane, MAXRS - 1)) + 1] >> 16) : 0x7fffffff;
+        int pst16[MAXRS];
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) pst16[rr] = __builtin_amdgcn_readlane(psv, rr);
+        for (int rr = 0; rr < MAXRS; ++rr) pst16[rr] = __builtin_amdgcn_readlane(psv, rr);
         for (int it0 = sw; it0 < nitems; it0 += snw * PFD) {
             long long tq1 = 0, tq2 = 0;
             if (ltiming) tq1 = clock64();
 #pragma unroll
             for (int j = 0; j < PFD; ++j) {
                 const int it = it0 + snw * j;
-                Item I = item(it < nitems ? it * 64 + lane : T, T, rb, pst16);
+                Item I = item(it < nitems ? it * 64 + lane : Tn, Tn, rb, pst16);
                 if (a.cl) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) pf[j][q] = reinterpret_cast<const f4*>(I.g)[q];
-                } else {
+                } else if (!F16) {   // planar fp32 maps (no workspace given); fp16 rings are only launched with the channel-last copy
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const float* __restrict__ g = I.g + (size_t)(4 * q) * plane;
@@ -774,15 +811,24 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         RH[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 1]) : 1;
         rbase[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 2]) : L::DATA;
     }
-    f4 r[Q];
+    f4 r[F16 ? 1 : Q];
+    float rh[F16 ? Q : 1][8];   // fp16 storage: reference features of the group, 8 channels per chunk
     auto load_reference = [&]() {
-        if (MODE != MODE_WARP) {
+        if (F16) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float t = ldf(reinterpret_cast<const T*>(p.feats[0]) + (size_t)(c0 + 8 * q + k) * plane + pix);
+                    rh[F16 ? q : 0][k] = valid ? t : 0.0f;
+                }
+        } else if (MODE != MODE_WARP) {
 #pragma unroll
             for (int q = 0; q < Q; ++q)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
-                    r[q][k] = valid ? t : 0.0f;
+                    r[F16 ? 0 : q][k] = valid ? t : 0.0f;
                 }
         }
     };
@@ -799,22 +845,23 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         rden = 1.0f / den;
     }
     const float invV = 1.0f / (float)(p.n_src + 1);
-    const size_t cstride_b = (size_t)D * plane * 4;
+    const size_t cstride_b = (size_t)D * plane * sizeof(T);
 
     // all CH/4.. channels of one quad: accumulators -> output values -> stores
     auto finalize_store = [&](const f4& s, const f4& qq, unsigned long long& ob) {
+        f4 o;
+        if (MODE == MODE_VARIANCE) {   // two channels per instruction; each half is the scalar sequence m = s/V, fma(qq, 1/V, -(m*m))
+            const f2 iv = {invV, invV};
+            const f2 ml = lo2(s) * iv, mh = hi2(s) * iv;
+            o = cat2(pk_fma(lo2(qq), iv, -(ml * ml)), pk_fma(hi2(qq), iv, -(mh * mh)));
+        } else if (MODE == MODE_WEIGHTED) {
+            o = s * rden;
+        } else {
+            o = s;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float o;
-            if (MODE == MODE_VARIANCE) {
-                float m = s[k] * invV;
-                o = fmaf(qq[k], invV, -(m * m));
-            } else if (MODE == MODE_WEIGHTED) {
-                o = s[k] * rden;
-            } else {
-                o = s[k];
-            }
-            store_sbase(ob, pixb, o);
+            store_sbase(ob, pixb, o[k]);
             ob += cstride_b;
         }
     };
@@ -825,10 +872,10 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             qq = cat2(pk_fma(vl, vl, lo2(qq)), pk_fma(vh, vh, hi2(qq)));
         } else if (MODE == MODE_WEIGHTED) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] = fmaf(val[k] * r[q][k], vw[i], s[k]);
+            for (int k = 0; k < 4; ++k) s[k] = fmaf(val[k] * r[F16 ? 0 : q][k], vw[i], s[k]);
         } else if (MODE == MODE_PAIR) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pair_acc = fmaf(r[q][k], val[k], pair_acc);
+            for (int k = 0; k < 4; ++k) pair_acc = fmaf(r[F16 ? 0 : q][k], val[k], pair_acc);
         } else {
             s = val;
         }
@@ -882,9 +929,125 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             } else {
                 dv = lds[L::PMIN + dl_];
             }
-            unsigned long long ob = uniform64(p.out + ((size_t)c0 * D + d) * plane);  // scalar base, once per plane
+            unsigned long long ob = uniform64(reinterpret_cast<T*>(p.out) + ((size_t)c0 * D + d) * plane);  // scalar base, once per plane
             float pair_acc = 0.0f;
             if (!valid) continue;  // one EXEC region per plane instead of one branch per store
+
+            if constexpr (VIEW_MAJOR) {
+                // ---- view-major order (fp16 storage, or more than four source views) -----------------------------
+                // The geometry of ONE view is live at a time (the next view's is computed while this view's taps are
+                // in flight) and the accumulators of all Q chunks stay in registers until the last view: with six
+                // views the chunk-major order of the fp32 / four-view path keeps 6 x (2 addresses + 4 weights) alive
+                // and spills, and a scratch reload inside the plane loop waits (vmcnt) for every store in flight.
+                float sa[Q][CPC], qa[Q][CPC];
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int k = 0; k < CPC; ++k) {
+                        const float rv = F16 ? rh[F16 ? q : 0][F16 ? k : 0] : r[F16 ? 0 : q][F16 ? 0 : k];
+                        sa[q][k] = (MODE == MODE_VARIANCE) ? rv : 0.0f;
+                        qa[q][k] = rv * rv;
+                    }
+                auto accumulate_vm = [&](const float (&val)[CPC], int q, int i) {
+#pragma unroll
+                    for (int k = 0; k < CPC; k += 2) {
+                        const f2 v = {val[k], val[k + 1]};
+                        if (MODE == MODE_VARIANCE) {
+                            const f2 sn = (f2){sa[q][k], sa[q][k + 1]} + v;
+                            const f2 qn = pk_fma(v, v, (f2){qa[q][k], qa[q][k + 1]});
+                            sa[q][k] = sn[0]; sa[q][k + 1] = sn[1];
+                            qa[q][k] = qn[0]; qa[q][k + 1] = qn[1];
+                        } else {   // MODE_WEIGHTED (fp32 only)
+                            sa[q][k] = fmaf(v[0] * r[F16 ? 0 : q][F16 ? 0 : k], vw[i], sa[q][k]);
+                            sa[q][k + 1] = fmaf(v[1] * r[F16 ? 0 : q][F16 ? 0 : k + 1], vw[i], sa[q][k + 1]);
+                        }
+                    }
+                };
+                if (ring) {
+                    auto geometry = [&](int i) -> TapL {
+                        const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
+                        const Ray rr = make_ray(M, xf, yf);
+                        float u, v;
+                        project(rr, M[3], M[7], M[11], dv, h, w, u, v);
+                        return make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
+                    };
+                    auto fetch = [&](const TapL& g, int q, f4 (&dst)[4]) {
+                        dst[0] = lds_read4(lds, g.a0 + q * 16);
+                        dst[1] = lds_read4(lds, g.a0 + q * 16 + STRIDE * 4);
+                        dst[2] = lds_read4(lds, g.a1 + q * 16);
+                        dst[3] = lds_read4(lds, g.a1 + q * 16 + STRIDE * 4);
+                    };
+                    f4 tp[2][4];
+                    TapL gc = geometry(0);
+                    fetch(gc, 0, tp[0]);
+#pragma unroll
+                    for (int i = 0; i < NSRC; ++i) {
+                        // keep the scheduler from hoisting every view's geometry to the top of the plane (it would: the
+                        // views are independent), which is exactly the register pressure this order avoids
+                        __builtin_amdgcn_sched_barrier(0);
+                        TapL gn = gc;
+                        if (i + 1 < NSRC) gn = geometry(i + 1);
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            const int u = i * Q + q;
+                            if (q + 1 < Q) fetch(gc, q + 1, tp[(u + 1) & 1]);
+                            else if (i + 1 < NSRC) fetch(gn, 0, tp[(u + 1) & 1]);
+                            f4 (&c)[4] = tp[u & 1];
+                            asm volatile("" : "+v"(c[3]));
+                            float val[CPC];
+                            if constexpr (F16) {
+#pragma unroll
+                                for (int k = 0; k < CPC; k += 2) {   // same summation order as grid_sample: nw, ne, sw, se
+                                    const int wi = k >> 1;           // word wi of a tap holds channels k (low half) and k + 1
+                                    val[k] = fma_mix_lo(c[3][wi], gc.se, fma_mix_lo(c[2][wi], gc.sw, fma_mix_lo(c[1][wi], gc.ne, fma_mix_lo(c[0][wi], gc.nw, 0.0f))));
+                                    val[k + 1] = fma_mix_hi(c[3][wi], gc.se, fma_mix_hi(c[2][wi], gc.sw, fma_mix_hi(c[1][wi], gc.ne, fma_mix_hi(c[0][wi], gc.nw, 0.0f))));
+                                }
+                            } else {
+                                const f4 v4 = blend(c[0], c[1], c[2], c[3], gc.nw, gc.ne, gc.sw, gc.se);
+#pragma unroll
+                                for (int k = 0; k < CPC; ++k) val[k] = v4[k];
+                            }
+                            accumulate_vm(val, q, i);
+                        }
+                        gc = gn;
+                    }
+                } else {   // fallback workgroups: taps from the planar maps in global memory, one channel at a time
+                    for (int i = 0; i < p.n_src; ++i) {
+                        const float* __restrict__ M = p.proj34 + 12 * i;
+                        const Ray rr = make_ray(M, xf, yf);
+                        float u, v;
+                        project(rr, M[3], M[7], M[11], dv, h, w, u, v);
+                        const TapG t = make_tap_glb(u, v, h, w);
+                        const T* __restrict__ gp = reinterpret_cast<const T*>(p.feats[i + 1]) + (size_t)c0 * plane + t.off;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            float val[CPC];
+#pragma unroll
+                            for (int k = 0; k < CPC; ++k) {
+                                const T* __restrict__ gk = gp + (size_t)(CPC * q + k) * plane;
+                                val[k] = fmaf(ldf(gk + t.dyw + t.dx), t.se, fmaf(ldf(gk + t.dyw), t.sw, fmaf(ldf(gk + t.dx), t.ne, ldf(gk) * t.nw)));
+                            }
+                            accumulate_vm(val, q, i);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int k = 0; k < CPC; ++k) {
+                        float o;
+                        if (MODE == MODE_VARIANCE) {
+                            const float m = sa[q][k] * invV;
+                            o = fmaf(qa[q][k], invV, -(m * m));
+                        } else {
+                            o = sa[q][k] * rden;
+                        }
+                        if constexpr (F16) store_sbase_h(ob, pixb, o);
+                        else store_sbase(ob, pixb, o);
+                        ob += cstride_b;
+                    }
+                continue;
+            }
 
             if (ring) {
 #ifdef D3D_X_GEO   // timing experiment (results wrong): geometry once per step instead of once per plane
@@ -937,7 +1100,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
                     const int q = u / NSRC, i = u % NSRC;
                     if (PD > 0 ? (u + PD < NU) : (u > 0)) request(u + PD, tp[(u + PD) % (PD + 1)]);
                     if (i == 0) {
-                        if (MODE == MODE_VARIANCE) { s = r[q]; qq = r[q] * r[q]; }
+                        if (MODE == MODE_VARIANCE) { s = r[F16 ? 0 : q]; qq = s * s; }
                         else { s = (f4){0, 0, 0, 0}; qq = s; }
                     }
                     f4 (&c)[4] = tp[u % (PD + 1)];
@@ -960,7 +1123,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     f4 s, qq;
-                    if (MODE == MODE_VARIANCE) { s = r[q]; qq = r[q] * r[q]; }
+                    if (MODE == MODE_VARIANCE) { s = r[F16 ? 0 : q]; qq = s * s; }
                     else { s = (f4){0, 0, 0, 0}; qq = s; }
 #pragma unroll
                     for (int i = 0; i < NSRC; ++i) {
@@ -996,109 +1159,112 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 
 // ---------------------------------------------------------------------------------------------
 // Channel-last copy of the source maps for the loaders: [view][group][position][CH].  A loader lane then fetches the
-// CH channels of a ring position with CH/4 16-byte loads instead of CH 4-byte loads from CH different planes (the
+// CH channels of a ring position with 16-byte loads instead of CH element loads from CH different planes (the
 // staging waves are bound by the number of VMEM instructions they issue, not by bytes).  One extra read + write of
-// the source maps per launch (0.33 GB next to 15.7 GB of output at config 2).
+// the source maps per launch (0.33 GB next to 15.7 GB of output at config 2).  The copy lives in the CALLER's
+// workspace (d3d_sweep_workspace_bytes); without one the fp32 loaders read the planar maps directly.
 struct PackArgs {
-    const float* src[D3D_MAX_VIEWS];
+    const void* src[D3D_MAX_VIEWS];
 };
-template <int CH>
+template <int CH, typename T>
 __global__ __launch_bounds__(256) void pack_channel_last_kernel(PackArgs pa, int ngroups, long plane, float* __restrict__ out) {
-    // thread = (position, quad): lanes 4k..4k+3 write the CH*4 contiguous bytes of one position (CH = 16);
-    // for a fixed channel, every CH/4-th lane reads consecutive positions
-    constexpr int Q = CH / 4;
+    // thread = (position, 16-byte chunk): consecutive lanes write the contiguous bytes of one position;
+    // for a fixed channel, every Q-th lane reads consecutive positions
+    constexpr int CW = CH * (int)sizeof(T) / 4, Q = CW / 4, CPC = 16 / (int)sizeof(T);
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     const long pos = t / Q;
     const int q = (int)(t - pos * Q);
     if (pos >= plane) return;
     const int vg = blockIdx.y;  // view * ngroups + group
     const int v = vg / ngroups, g = vg - v * ngroups;
-    const float* __restrict__ s = pa.src[v] + ((size_t)g * CH + 4 * q) * plane + pos;
+    const T* __restrict__ s = reinterpret_cast<const T*>(pa.src[v]) + ((size_t)g * CH + CPC * q) * plane + pos;
     f4 x;
-    x[0] = s[0]; x[1] = s[plane]; x[2] = s[2 * plane]; x[3] = s[3 * plane];
-    reinterpret_cast<f4*>(out + ((size_t)vg * plane + pos) * CH)[q] = x;
-}
-
-// Grow-only workspace per (device, stream): calls on one stream are ordered, so they can share it.
-static float* cl_workspace(hipStream_t stream, size_t bytes) {
-    struct Buf { float* p; size_t n; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Buf> pool;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    Buf& b = pool[{dev, stream}];
-    if (b.n < bytes) {
-        if (b.p) {
-            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;  // earlier launches still read it
-            (void)hipFree(b.p);
-            b.p = nullptr;
-            b.n = 0;
-        }
-        if (hipMalloc(&b.p, bytes) != hipSuccess) { b.p = nullptr; return nullptr; }
-        b.n = bytes;
+    if (sizeof(T) == 4) {
+        const float* __restrict__ sf = reinterpret_cast<const float*>(s);
+        x[0] = sf[0]; x[1] = sf[plane]; x[2] = sf[2 * plane]; x[3] = sf[3 * plane];
+    } else {
+        const unsigned short* __restrict__ sh = reinterpret_cast<const unsigned short*>(s);
+        unsigned wd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wd[k] = (unsigned)sh[(2 * k) * plane] | ((unsigned)sh[(2 * k + 1) * plane] << 16);
+        x = __builtin_bit_cast(f4, (uint4){wd[0], wd[1], wd[2], wd[3]});
     }
-    return b.p;
+    reinterpret_cast<f4*>(out + ((size_t)vg * plane + pos) * CW)[q] = x;
 }
 
-template <int MODE, int NSRC, int CH>
+static int group_channels(int C, int n_src, int elem_bytes);
+
+// depth planes per workgroup segment and the number of segments (shared by the launcher and the workspace query)
+static void segments(int D, long tiles, int& dseg, int& nseg) {
+    int dseg_cap = DSEG_MAX;
+#ifdef D3D_EXPERIMENTS
+    if (const char* e = getenv("D3D_TILED_DSEG")) dseg_cap = max(NSUB, min(atoi(e), DSEG_MAX));
+#endif
+    nseg = ceil_div(D, dseg_cap);
+    // enough workgroups to fill 256 CUs a few times over; 128-plane segments measured best on config 2 (rings sized
+    // per segment follow the depth-dependent window size; shorter segments pay the planning prologue more often)
+    while (tiles * nseg < 4096 && nseg * 2 <= ceil_div(D, 32)) nseg *= 2;
+    dseg = ceil_div(D, nseg);
+    nseg = ceil_div(D, dseg);
+}
+
+// The channel-last copy pays off when the sweep is deep: it costs 2 x (n_src*C*h*w) elements of traffic.
+static bool wants_channel_last(int D, int elem_bytes) { return elem_bytes == 2 || D >= 96; }
+
+size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes) {
+    if (C % 8 != 0 || n_src > 6 || n_src < 1 || !wants_channel_last(D, elem_bytes)) return 0;
+    return (size_t)n_src * C * h * w * elem_bytes;
+}
+
+template <int MODE, int NSRC, int CH, typename T>
 static int launch_one(const SweepParams& p, hipStream_t stream) {
-    using L = Lds<CH, NSRC>;
+    constexpr int CW = CH * (int)sizeof(T) / 4;
+    using L = Lds<CW, NSRC>;
     constexpr int LDS_BYTES = 160 * 1024;
-    auto kern = sweep_tiled_kernel<MODE, NSRC, CH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-        if (rc != D3D_OK) return rc;
-        attr_done = true;
-    }
+    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T>;
+    // per device and idempotent: set on every launch (no process-global "done" flag that a second GPU would miss)
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
     TiledArgs a;
     a.ngroups = p.C / CH;
     a.tiles_x = ceil_div(p.w, TW);
     a.tiles_y = ceil_div(p.h, TH);
     a.cap_floats = LDS_BYTES / 4 - L::DATA;
-    // segments: enough workgroups to fill 256 CUs a few times over, each at most DSEG_MAX planes
-    // 128-plane segments measured best on config 2 (rings sized per segment follow the depth-dependent
-    // window size; shorter segments pay the planning prologue more often)
-    int dseg_cap = DSEG_MAX;
-    if (const char* e = getenv("D3D_TILED_DSEG")) dseg_cap = max(NSUB, min(atoi(e), DSEG_MAX));  // experiments
-    int nseg = ceil_div(p.D, dseg_cap);
-    const long tiles = (long)a.tiles_x * a.tiles_y * a.ngroups;
-    while (tiles * nseg < 4096 && nseg * 2 <= ceil_div(p.D, 32)) nseg *= 2;
-    a.dseg = ceil_div(p.D, nseg);
-    a.nseg = ceil_div(p.D, a.dseg);
+    segments(p.D, (long)a.tiles_x * a.tiles_y * a.ngroups, a.dseg, a.nseg);
     const long nblk = (long)a.tiles_x * a.tiles_y * a.nseg;  // a workgroup sweeps every channel group of its patch
     if (nblk > 0x7fffffffL) return D3D_ERR_UNSUPPORTED;
     a.stats = nullptr;
     a.tstats = nullptr;
     a.cl = nullptr;
     {
-        // worth it when the sweep is deep: the copy costs 2 x (n_src*C*h*w*4) bytes of traffic
-        int use_cl = p.D >= 96;
-        if (const char* e = getenv("D3D_TILED_CL")) use_cl = atoi(e);
-        if (use_cl) {
-            const size_t bytes = (size_t)p.n_src * p.C * p.h * p.w * sizeof(float);
-            float* ws = cl_workspace(stream, bytes);
-            if (ws) {
-                PackArgs pa = {};
-                for (int i = 0; i < p.n_src; ++i) pa.src[i] = p.feats[i + 1];
-                const long plane = (long)p.h * p.w;
-                hipLaunchKernelGGL(pack_channel_last_kernel<CH>, dim3((unsigned)ceil_div(plane * (CH / 4), 256), p.n_src * a.ngroups),
-                                   dim3(256), 0, stream, pa, a.ngroups, plane, ws);
-                D3D_LAUNCH_CHECK("pack_channel_last_kernel launch");
-                a.cl = ws;
-            }
+        bool use_cl = wants_channel_last(p.D, (int)sizeof(T));
+#ifdef D3D_EXPERIMENTS
+        if (const char* e = getenv("D3D_TILED_CL")) use_cl = atoi(e) != 0;
+#endif
+        const size_t bytes = (size_t)p.n_src * p.C * p.h * p.w * sizeof(T);
+        if (use_cl && p.workspace && p.workspace_bytes >= bytes) {
+            PackArgs pa = {};
+            for (int i = 0; i < p.n_src; ++i) pa.src[i] = p.feats[i + 1];
+            const long plane = (long)p.h * p.w;
+            hipLaunchKernelGGL((pack_channel_last_kernel<CH, T>), dim3((unsigned)ceil_div(plane * (CW / 4), 256), p.n_src * a.ngroups),
+                               dim3(256), 0, stream, pa, a.ngroups, plane, reinterpret_cast<float*>(p.workspace));
+            D3D_LAUNCH_CHECK("pack_channel_last_kernel launch");
+            a.cl = reinterpret_cast<const float*>(p.workspace);
         }
+        // the fp16 loaders only read the channel-last copy (2-byte planar gathers would be VMEM-issue bound)
+        if (sizeof(T) == 2 && !a.cl) return D3D_ERR_UNSUPPORTED;
     }
+#ifdef D3D_EXPERIMENTS
     if (getenv("D3D_TILED_STATS")) {  // debug only: synchronous, allocates
         (void)hipMalloc(&a.stats, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
         (void)hipMemset(a.stats, 0, 8 * sizeof(unsigned) + 24 * sizeof(unsigned long long));
         a.tstats = reinterpret_cast<unsigned long long*>(a.stats + 8);
     }
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(THREADS), LDS_BYTES, stream, p, a);
     D3D_LAUNCH_CHECK("sweep_tiled_kernel launch");
+#ifdef D3D_EXPERIMENTS
     if (a.stats) {
         unsigned hs[8];
         unsigned long long ht[24];
@@ -1112,19 +1278,21 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         fprintf(stderr, "[d3d tiled timing] barrier wait after the first, per compute wave (pixel rows, depth sub-range):");
         for (int wv = 0; wv < NCOMP; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
         fprintf(stderr, "\n");
-        fprintf(stderr, "[d3d tiled stats] CH=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) overflow_items=%u dseg=%d\n",
-                CH, nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
-                a.cap_floats / L::STRIDE, hs[5], a.dseg);
+        fprintf(stderr, "[d3d tiled stats] CH=%d elem=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) dseg=%d\n",
+                CH, (int)sizeof(T), nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
+                a.cap_floats / L::STRIDE, a.dseg);
         (void)hipFree(a.stats);
     }
+#endif
     return D3D_OK;
 }
 
-static int group_channels(int C, int n_src) {
-    // channels per workgroup pass; D3D_TILED_CG overrides for experiments (must divide C).  Six rings only fit
-    // LDS with 8-channel positions (config 5, 7 views x 512 planes: 76 ms with 8, 134 ms with 16 channels).
-    const char* e = getenv("D3D_TILED_CG");
-    int cg = e ? atoi(e) : (n_src > 4 ? 8 : (C >= 16 ? 16 : C));
+static int group_channels(int C, int n_src, int elem_bytes) {
+    // channels per workgroup pass.  Six fp32 rings only fit LDS with 8-channel positions; fp16 cells take 16.
+    int cg = (n_src > 4 && elem_bytes == 4) ? 8 : (C >= 16 ? 16 : C);
+#ifdef D3D_EXPERIMENTS
+    if (const char* e = getenv("D3D_TILED_CG")) cg = atoi(e);   // must divide C
+#endif
     if (cg != 8 && cg != 16 && cg != 32) cg = 8;
     while (C % cg) cg >>= 1;
     return cg;
@@ -1132,13 +1300,20 @@ static int group_channels(int C, int n_src) {
 
 template <int MODE, int NSRC>
 static int launch_ch(const SweepParams& p, hipStream_t stream) {
-    const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src);
+    const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src, 4);
     switch (cg) {
-        case 32: return launch_one<MODE, NSRC, 32>(p, stream);
-        case 16: return launch_one<MODE, NSRC, 16>(p, stream);
-        case 8: return launch_one<MODE, NSRC, 8>(p, stream);
+        case 32: return launch_one<MODE, NSRC, 32, float>(p, stream);
+        case 16: return launch_one<MODE, NSRC, 16, float>(p, stream);
+        case 8: return launch_one<MODE, NSRC, 8, float>(p, stream);
     }
     return D3D_ERR_UNSUPPORTED;
+}
+
+// fp16 storage (BASELINE config 5): 16-channel groups of 32-byte cells
+template <int NSRC>
+static int launch_f16(const SweepParams& p, hipStream_t stream) {
+    if (p.C % 16 != 0) return D3D_ERR_UNSUPPORTED;
+    return launch_one<MODE_VARIANCE, NSRC, 16, __half>(p, stream);
 }
 
 int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
@@ -1149,6 +1324,11 @@ int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
     if (p.n_src > 6) {
         set_error("tiled kernel unsupported: %d source views (max 6)", p.n_src);
         return D3D_ERR_UNSUPPORTED;
+    }
+    if (p.elem_bytes == 2) {
+        if (mode != MODE_VARIANCE) return D3D_ERR_UNSUPPORTED;
+        if (p.n_src > 4) return launch_f16<6>(p, stream);
+        return p.n_src <= 2 ? launch_f16<2>(p, stream) : launch_f16<4>(p, stream);
     }
     switch (mode) {
         case MODE_VARIANCE:

@@ -5,6 +5,7 @@ happens in libdeep3d_planesweep.so.  Tensors must be fp32, contiguous and on the
 anything else raises (no CPU path exists).  Shapes are unbatched, as in the header.
 """
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +31,31 @@ def _chk(t, name, ndim=None):
     if ndim is not None and t.dim() != ndim:
         raise ValueError("%s must have %d dims (got shape %s)" % (name, ndim, tuple(t.shape)))
     return ctypes.c_void_p(t.data_ptr())
+
+
+_forced = [None]
+
+
+def _sync_force_path():
+    """D3D_FORCE_PATH = direct | tiled (tests, profiling): forwarded to the library's test hook when it changes."""
+    want = os.environ.get("D3D_FORCE_PATH", "")
+    if want != _forced[0]:
+        code = {"": 0, "auto": 0, "direct": 1, "tiled": 2}.get(want)
+        if code is None:
+            raise ValueError("D3D_FORCE_PATH must be direct, tiled or unset (got %r)" % want)
+        _lib.check(_lib.load().d3d_debug_force_path(code), "d3d_debug_force_path")
+        _forced[0] = want
+
+
+def _workspace(n_views, C, D, h, w, elem_bytes, device):
+    """Scratch for one sweep call, sized by the library and owned by torch's caching allocator: the allocator hands the
+    block back only after the work queued on the current stream (this call) has been ordered, so calls never share it."""
+    _sync_force_path()
+    n = int(_lib.load().d3d_sweep_workspace_bytes(n_views, C, D, h, w, elem_bytes))
+    if n == 0:
+        return None, ctypes.c_void_p(0), 0
+    buf = torch.empty((n,), dtype=torch.uint8, device=device)
+    return buf, ctypes.c_void_p(buf.data_ptr()), n
 
 
 def _opt(t, name):
@@ -70,8 +96,9 @@ def homo_warp(src, proj34, depth, out=None):
     dp, mode, D = _depth(depth, h, w)
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=src.device)
+    ws, wp, wn = _workspace(2, C, D, h, w, 4, src.device)
     rc = _lib.load().d3d_homo_warp(_chk(src, "src", 3), _chk(proj34, "proj34"), dp, mode, C, D, h, w,
-                                   _chk(out, "out", 4), _stream())
+                                   _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_homo_warp")
     return out
 
@@ -103,16 +130,18 @@ def variance_volume(feats, proj34, depth, out=None):
         if out is None:
             out = torch.empty((C, D, h, w), dtype=torch.float16, device=feats[0].device)
         arr = (ctypes.c_void_p * len(feats))(*[_chk16(f, "feats[%d]" % i).value for i, f in enumerate(feats)])
+        ws, wp, wn = _workspace(len(feats), C, D, h, w, 2, feats[0].device)
         rc = _lib.load().d3d_variance_volume_f16(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
-                                                 _chk16(out, "out"), _stream())
+                                                 _chk16(out, "out"), wp, wn, _stream())
         _lib.check(rc, "d3d_variance_volume_f16")
         return out
     dp, mode, D = _depth(depth, h, w)
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=feats[0].device)
     arr = _ptr_array(feats, "feats")
+    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
     rc = _lib.load().d3d_variance_volume(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
-                                         _chk(out, "out", 4), _stream())
+                                         _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_variance_volume")
     return out
 
@@ -126,8 +155,9 @@ def weighted_corr(feats, proj34, weights, depth, out=None):
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=feats[0].device)
     arr = _ptr_array(feats, "feats")
+    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
     rc = _lib.load().d3d_weighted_corr(arr, _chk(proj34, "proj34"), _chk(weights, "weights", 3), dp, mode,
-                                       len(feats), C, D, h, w, _chk(out, "out", 4), _stream())
+                                       len(feats), C, D, h, w, _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_weighted_corr")
     return out
 
@@ -138,8 +168,9 @@ def pair_corr_mean(ref, src, proj34, depth, out=None):
     dp, mode, D = _depth(depth, h, w)
     if out is None:
         out = torch.empty((D, h, w), dtype=torch.float32, device=ref.device)
+    ws, wp, wn = _workspace(2, C, D, h, w, 4, ref.device)
     rc = _lib.load().d3d_pair_corr_mean(_chk(ref, "ref", 3), _chk(src, "src", 3), _chk(proj34, "proj34"), dp, mode,
-                                        C, D, h, w, _chk(out, "out", 3), _stream())
+                                        C, D, h, w, _chk(out, "out", 3), wp, wn, _stream())
     _lib.check(rc, "d3d_pair_corr_mean")
     return out
 

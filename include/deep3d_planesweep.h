@@ -12,7 +12,9 @@
  * Conventions
  *   - Plain C: raw DEVICE pointers owned by the caller, explicit sizes, a HIP stream,
  *     int status.  No torch types, no exceptions across the boundary, no hidden
- *     synchronisation, no allocation: every call is stream-ordered and reentrant.
+ *     synchronisation, no allocation: every call is stream-ordered and reentrant.  Scratch
+ *     memory is the caller's: d3d_sweep_workspace_bytes() says how much a sweep can use and
+ *     the sweep entry points take the buffer as (workspace, workspace_bytes).
  *   - All tensors are contiguous fp32, batch handled by the caller (the reference runs
  *     inference at batch 1, predict.py:49):
  *         features  [C,h,w]      cost volume [C,D,h,w]      maps [h,w] / [D,h,w]
@@ -31,13 +33,14 @@
 #ifndef DEEP3D_PLANESWEEP_H
 #define DEEP3D_PLANESWEEP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 1
+#define D3D_ABI_VERSION 2
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -66,11 +69,29 @@ const char* d3d_last_error(void);
 int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_stream_t stream);
 
 /*
+ * Test hook, process-wide: 0 = the dispatcher chooses (default), 1 = direct-gather kernel, 2 = LDS-ring kernel
+ * (D3D_ERR_UNSUPPORTED where that kernel does not take the shape).  The parity suite runs every sweep case on
+ * all three.  Not for production callers.
+ */
+int d3d_debug_force_path(int path);
+
+/*
+ * Scratch bytes the plane-sweep entry points below (d3d_homo_warp, d3d_variance_volume[_f16],
+ * d3d_weighted_corr, d3d_pair_corr_mean) can use for a problem of n_views views (reference included) of
+ * [C,h,w] elements of elem_bytes (4 = fp32, 2 = fp16) swept over D planes: room for a channel-last staging
+ * copy of the source maps.  0 = the shape takes none.  The buffer is the caller's (device memory, 16-byte
+ * aligned, private to the call until it completes on its stream); passing NULL / fewer bytes is valid and
+ * selects a slower staging form (fp32) or the direct-gather kernel (fp16).
+ * Replaces nothing in the reference: torch's caching allocator plays this role there.
+ */
+size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes);
+
+/*
  * module.py:516-557 homo_warping_float -- warp ONE source feature map onto D planes.
  * src [C,h,w] -> out [C,D,h,w].
  */
 int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int depth_mode, int C, int D, int h,
-                  int w, float* out, d3d_stream_t stream);
+                  int w, float* out, void* workspace, size_t workspace_bytes, d3d_stream_t stream);
 
 /*
  * cas_mvsnet.py:45-60 (same arithmetic ucsnet.py:119-134, msrednet.py:217-230 and,
@@ -81,20 +102,24 @@ int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int
  * Never materialises the warped volumes, sum or sq.
  */
 int d3d_variance_volume(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
-                        int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream);
+                        int n_views, int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
+                        d3d_stream_t stream);
 
 /* The same volume with fp16 STORAGE (BASELINE config 5): feats[i] and out are IEEE half tensors of the shapes
- * above; projections, depth and every product / sum stay fp32, the result is rounded once (RNE).  Served by the
- * direct-gather kernel this round (the ring kernel is fp32-only). */
+ * above; projections, depth and every product / sum stay fp32, the result is rounded once (RNE).  With a
+ * workspace of d3d_sweep_workspace_bytes(..., 2) bytes and C % 16 == 0, up to 6 source views run on the LDS-ring
+ * kernel with fp16 ring cells; otherwise on the direct-gather kernel. */
 int d3d_variance_volume_f16(const void* const* feats, const float* proj34, const float* depth, int depth_mode,
-                            int n_views, int C, int D, int h, int w, void* out, d3d_stream_t stream);
+                            int n_views, int C, int D, int h, int w, void* out, void* workspace,
+                            size_t workspace_bytes, d3d_stream_t stream);
 
 /*
  * adamvs.py:469-474 -- per-pair channel-mean correlation for the visibility net:
  *     out[d] = mean_c( ref[c] * warp_d(src)[c] )          ref, src [C,h,w] -> out [D,h,w]
  */
 int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, const float* depth, int depth_mode,
-                       int C, int D, int h, int w, float* out, d3d_stream_t stream);
+                       int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
+                       d3d_stream_t stream);
 
 /*
  * adamvs.py:492-509 -- visibility-weighted correlation:
@@ -102,7 +127,8 @@ int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, 
  * weights: device [V-1,h,w] at this stage's resolution.  out [C,D,h,w].
  */
 int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
-                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, d3d_stream_t stream);
+                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, void* workspace,
+                      size_t workspace_bytes, d3d_stream_t stream);
 
 /*
  * cas_mvsnet.py:69-76 + module.py:605-613 -- softmax over D, soft-argmin depth and the

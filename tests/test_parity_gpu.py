@@ -246,6 +246,45 @@ def test_full_size_properties(ops):
     assert out.min().item() >= -1e-4
 
 
+def test_full_size_config5_fp16_ring(ops):
+    """BASELINE config 5 on its own terms: 7 views x 512 planes, features 32 x 928 x 688, fp16 storage, through the
+    LDS-ring kernel (fp16 ring cells, fp32 arithmetic).  Size-independent properties, as above."""
+    V, C, h, w, D = 7, 32, 928, 688, 512
+    proj, dv = S.make_scene(V, h, w, D, seed=5)
+    feats = [torch.from_numpy(f).cuda().half() for f in S.make_features(V, C, h, w, seed=5)]
+    p34 = ops.compose_projections(dev(proj))
+    depth = dev(S.uniform_depths(dv, D))
+    os.environ["D3D_FORCE_PATH"] = "tiled"   # fail instead of silently taking the direct kernel
+    try:
+        out = ops.variance_volume(feats, p34, depth)
+        torch.cuda.synchronize()
+        assert out.dtype == torch.float16 and out.shape == (C, D, h, w)
+        assert bool(torch.isfinite(out[:, ::37]).all())
+        # (1) a depth sub-range computed alone is bit-identical to the same planes of the full sweep
+        sub = ops.variance_volume(feats, p34, depth[300:316].contiguous())
+        assert bool((sub == out[:, 300:316]).all())
+        del sub
+    finally:
+        os.environ.pop("D3D_FORCE_PATH", None)
+    # (2) planes from the start, the middle and the end against the direct-gather kernel (other code path, same
+    #     fp32 arithmetic, one RNE rounding): identical up to the last fp16 bit of a cancelling variance
+    os.environ["D3D_FORCE_PATH"] = "direct"
+    try:
+        for d0 in (0, 254, 508):
+            ref = ops.variance_volume(feats, p34, depth[d0:d0 + 4].contiguous())
+            got = out[:, d0:d0 + 4]
+            diff = (ref.float() - got.float()).abs()
+            assert diff.max().item() <= 2.0 ** -10 * ref.float().abs().max().item() + 1e-6
+            assert (diff > 0).float().mean().item() < 1e-3    # almost every voxel bit-identical
+    finally:
+        os.environ.pop("D3D_FORCE_PATH", None)
+    # (3) exact homogeneity: every view x 2 -> variance x 4 (powers of two commute with every rounding, fp16 included,
+    #     away from the fp16 overflow / subnormal ranges: N(0,1) features keep the variance in [1e-3, 60])
+    out2 = ops.variance_volume([f * 2 for f in feats], p34, depth[128:136].contiguous())
+    assert bool((out2 == out[:, 128:136] * 4).all())
+    assert out[:, ::29].float().min().item() >= -1e-2
+
+
 # ----------------------------------------------------------------------------------------
 # regression family
 # ----------------------------------------------------------------------------------------
@@ -678,10 +717,11 @@ def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, 
     assert np.abs(got - folded).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
 
 
+# widths chosen so that the launcher's padding rule takes both tilings: one pixel per lane (64-wide tiles: W = 64, 130,
+# 300) and two pixels per lane (128-wide tiles: W = 5, 70, 65, 128, 250)
 @pytest.mark.parametrize("Ci,D,H,W", [(8, 1, 3, 5), (8, 5, 9, 70), (16, 8, 37, 130), (32, 3, 4, 64), (24, 11, 20, 65),
-                                      (16, 19, 6, 300)])
-@pytest.mark.parametrize("xp", ["1", "2"])
-def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D, H, W, xp):
+                                      (16, 19, 6, 300), (8, 4, 5, 128), (16, 3, 7, 250)])
+def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D, H, W):
     """C_out = 8, stride 1 (conv0 of CostRegNet, cas_mvsnet.py:84) on the z-streaming vector-unit kernel
     (d3d_conv3d_k3_co8): against the oracle with folded-BN affine, ReLU and skip, and against the matrix-core form."""
     rng = np.random.default_rng(Ci * 100 + W)
@@ -692,7 +732,6 @@ def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D,
     sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
     monkeypatch.setenv("D3D_CONV", "mfma")
     monkeypatch.delenv("D3D_CONV_CO8", raising=False)
-    monkeypatch.setenv("D3D_CONV_CO8_XP", xp)  # one / two output pixels per lane (64- / 128-wide tiles)
     want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
     got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8

@@ -144,6 +144,63 @@ static double beside(float* out, int iters, int stride_b) {
     return ms * 1e-3 * 2.4e9 / iters * 4.0 / (NT / 64);  // cycles per iteration per SIMD
 }
 
+
+// part D: the same 4 KB of taps + 24 independent FMAs per iteration, with the reads issued (0) in one burst of four
+// ds_read_b128, (1) one ds_read_b128 every 6 FMAs, (2) as eight ds_read_b64, one every 3 FMAs.  Hand-placed (asm):
+// does spreading the returns let the VALU stream run beside them?
+template <int PAT, int NT>
+__global__ __launch_bounds__(NT) void lds_interleave(float* out, int iters, int stride_b) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < 32 * 1024; i += NT) lds[i] = (float)(i & 255) * 0.001f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = lane * 0.001f + i;
+    const float w = 1.0001f, c = 0.001f;
+    f4 x0 = {0,0,0,0}, x1 = x0, x2 = x0, x3 = x0;
+    float sink = 0.f;
+    unsigned a = ((lane + wave * 7) & 255) * stride_b;
+#define FMA6(k) _Pragma("unroll") for (int i = 0; i < 6; ++i) acc[(k * 6 + i) & 7] = fmaf(acc[(k * 6 + i) & 7], w, c);
+#define FMA3(k) _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[(k * 3 + i) & 7] = fmaf(acc[(k * 3 + i) & 7], w, c);
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        sink += x0[0] + x1[1] + x2[2] + x3[3];
+        if (PAT == 0) {
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:3200\n\tds_read_b128 %3, %4 offset:3216"
+                         : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "v"(a) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            FMA6(0) FMA6(1) FMA6(2) FMA6(3)
+        } else if (PAT == 1) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(x0) : "v"(a) : "memory"); __builtin_amdgcn_sched_barrier(0); FMA6(0) __builtin_amdgcn_sched_barrier(0);
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(x1) : "v"(a) : "memory"); __builtin_amdgcn_sched_barrier(0); FMA6(1) __builtin_amdgcn_sched_barrier(0);
+            asm volatile("ds_read_b128 %0, %1 offset:3200" : "=v"(x2) : "v"(a) : "memory"); __builtin_amdgcn_sched_barrier(0); FMA6(2) __builtin_amdgcn_sched_barrier(0);
+            asm volatile("ds_read_b128 %0, %1 offset:3216" : "=v"(x3) : "v"(a) : "memory"); __builtin_amdgcn_sched_barrier(0); FMA6(3)
+        } else {
+            f2 y[8];
+#define RD64(k, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(y[k]) : "v"(a) : "memory"); __builtin_amdgcn_sched_barrier(0); FMA3(k) __builtin_amdgcn_sched_barrier(0);
+            RD64(0, 0) RD64(1, 8) RD64(2, 16) RD64(3, 24) RD64(4, 3200) RD64(5, 3208) RD64(6, 3216) RD64(7, 3224)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            x0 = (f4){y[0][0], y[1][1], y[2][0], y[3][1]};
+            x1 = (f4){y[4][0], y[5][1], y[6][0], y[7][1]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a = (a + 5 * stride_b) & 0x7ff0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s = sink + x0[0] + x1[0] + x2[0] + x3[0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+}
+template <int PAT, int NT>
+static double interleave(float* out, int iters, int stride_b) {
+    auto kern = lds_interleave<PAT, NT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(256), dim3(NT), 128 * 1024, 0, out, iters, stride_b); });
+    return ms * 1e-3 * 2.4e9 / iters * 4.0 / (NT / 64);
+}
+
 int main() {
     float* out; (void)hipMalloc(&out, 256 * 1024 * sizeof(float));
     const int iters = 40000;
@@ -165,5 +222,9 @@ int main() {
            beside<24, 1, 512>(out, iters, 80), beside<24, 0, 1024>(out, iters, 80), beside<0, 1, 1024>(out, iters, 80), beside<24, 1, 1024>(out, iters, 80));
     printf("  NV=48:  8 waves: %6.1f | %6.1f | %6.1f    16 waves: %6.1f | %6.1f | %6.1f\n", beside<48, 0, 512>(out, iters, 80), beside<0, 1, 512>(out, iters, 80),
            beside<48, 1, 512>(out, iters, 80), beside<48, 0, 1024>(out, iters, 80), beside<0, 1, 1024>(out, iters, 80), beside<48, 1, 1024>(out, iters, 80));
+    printf("part D: cycles per iteration per SIMD, 4 KB of taps + 24 independent FMAs: burst of 4 x b128 | one b128 per 6 FMAs | 8 x b64, one per 3 FMAs\n");
+    printf("   8 waves: %6.1f | %6.1f | %6.1f    12 waves: %6.1f | %6.1f | %6.1f    16 waves: %6.1f | %6.1f | %6.1f\n", interleave<0, 512>(out, iters, 80), interleave<1, 512>(out, iters, 80),
+           interleave<2, 512>(out, iters, 80), interleave<0, 768>(out, iters, 80), interleave<1, 768>(out, iters, 80), interleave<2, 768>(out, iters, 80),
+           interleave<0, 1024>(out, iters, 80), interleave<1, 1024>(out, iters, 80), interleave<2, 1024>(out, iters, 80));
     return 0;
 }
