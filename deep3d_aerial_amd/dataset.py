@@ -218,14 +218,258 @@ def extract_features(feature_net, imgs, image_keys=None, cache=None):
         return [feature_net(view(v)) for v in range(V)]
     if len(image_keys) != V:
         raise ValueError("image_keys must name the %d views" % V)
-    feats = []
+    # two passes: take (and so hold a reference to) every cached pyramid of the item FIRST; a put() for an uncached view
+    # may evict any key, including one of this item's that the caller did not upload because it was cached
+    feats = [cache.get(k) for k in image_keys]
     for v in range(V):
-        pyr = cache.get(image_keys[v])
-        if pyr is None:
+        if feats[v] is None:
+            dup = next((u for u in range(v) if image_keys[u] == image_keys[v]), None)
+            if dup is not None:            # the same image twice in one item (padded source lists)
+                feats[v] = feats[dup]
+                continue
             x = view(v)
             if x is None:
                 raise KeyError("image %r is neither cached nor supplied" % (image_keys[v],))
-            pyr = feature_net(x)
-            cache.put(image_keys[v], pyr)
-        feats.append(pyr)
+            feats[v] = feature_net(x)
+            cache.put(image_keys[v], feats[v])
     return feats
+
+
+# ----------------------------------------------------------------------------------------
+# the block on disk: viewpair.txt / images.txt / cameras.txt / image_path.txt
+# (mvs/mvs_cas/datasets/data_io.py:18-126 define the records and the four text formats;
+#  mvs/mvs_cas/datasets/cas_normal_eval.py:10-182 is the dataset built on them)
+# ----------------------------------------------------------------------------------------
+class Camera(object):
+    """One line of cameras.txt (data_io.py:18-29, 48-67): id  width height  pixelsize  fx fy x0 y0  [distortion...]."""
+
+    def __init__(self, camera_id=None, size=None, pixelsize=None, focallength=None, x0y0=None, distortion=None):
+        self.camera_id, self.size, self.pixelsize = camera_id, size, pixelsize
+        self.focallength, self.x0y0, self.distortion = focallength, x0y0, distortion
+
+
+class Photo(object):
+    """One line of images.txt (data_io.py:32-45, 70-91): id camera_id  R (9, row-major, Rwc XrightYup)  C (3, twc)
+    depth_min depth_max  name."""
+
+    def __init__(self, image_id=None, camera_id=None, rotation_matrix=None, project_center=None, depth=None, name=None):
+        self.image_id, self.camera_id, self.name = image_id, camera_id, name
+        self.rotation_matrix, self.project_center, self.depth = rotation_matrix, project_center, depth
+
+
+def _records(path):
+    with open(path, "r") as f:
+        for line in f:
+            line = line.strip()
+            if line and not line.startswith("#"):
+                yield line.split()
+
+
+def read_cameras_text(path):
+    """data_io.py:48-67 -> {camera_id: Camera}."""
+    cams = {}
+    for e in _records(path):
+        p = np.array(tuple(map(float, e[4:8])))
+        cams[int(e[0])] = Camera(camera_id=int(e[0]), size=[int(e[1]), int(e[2])], pixelsize=float(e[3]),
+                                 focallength=[p[0], p[1]], x0y0=[p[2], p[3]],
+                                 distortion=np.array(tuple(map(float, e[8:]))))
+    return cams
+
+
+def read_images_text(path):
+    """data_io.py:70-91 -> {image_id: Photo}."""
+    images = {}
+    for e in _records(path):
+        images[int(e[0])] = Photo(image_id=int(e[0]), camera_id=int(e[1]),
+                                  rotation_matrix=np.array(tuple(map(float, e[2:11]))).reshape(3, 3),
+                                  project_center=np.array(tuple(map(float, e[11:14]))),
+                                  depth=np.array(tuple(map(float, e[14:16]))), name=e[16])
+    return images
+
+
+def read_images_path_text(path):
+    """data_io.py:94-108: `N` then N triples `index name path` (whitespace separated) -> ({index: path}, {index: name})."""
+    tok = open(path).read().split()
+    paths, names = {}, {}
+    for i in range(int(tok[0])):
+        idx = int(tok[3 * i + 1])
+        names[idx], paths[idx] = tok[3 * i + 2], tok[3 * i + 3]
+    return paths, names
+
+
+def read_view_pair_text(pair_path, view_num):
+    """data_io.py:111-126: per viewpoint a line with the reference id and a line `n id score id score ...`; views with no
+    source are dropped, short source lists are padded with their first source.  -> [[ref, src...], ...] (every source
+    listed is kept; an item uses the first view_num entries, cas_normal_eval.py:105-107)."""
+    metas = []
+    with open(pair_path) as f:
+        for _ in range(int(f.readline())):
+            ref = [int(f.readline().rstrip())]
+            src = [int(x) for x in f.readline().rstrip().split()[1::2]]
+            if src:
+                if len(src) < view_num:
+                    print("{}< num_views:{}".format(len(src), view_num))
+                    src += [src[0]] * (view_num - len(src))
+                metas.append(ref + src)
+    return metas
+
+
+def scale_image(image, scale=1.0):
+    """preprocess.py:41-46 scale_image -> cv2.resize(image, None, fx=scale, fy=scale, INTER_LINEAR).
+    scale == 1 (the pipeline's setting: mvs_dl.py never passes --resize_scale) returns the image as cv2 does.  Other
+    scales follow OpenCV's documented INTER_LINEAR rule (output size round(n*scale); source coordinate
+    (dst + 0.5)/scale - 0.5, clamped; round half up for 8-bit) in float64 -- OpenCV itself is absent from the build
+    image, so this branch is NOT pinned against it (its 8-bit path uses 11-bit fixed-point weights and may differ by
+    one grey level)."""
+    if scale == 1 or scale == 1.0:
+        return np.ascontiguousarray(image)
+    img = np.asarray(image)
+    h, w = img.shape[:2]
+    nh, nw = int(round(h * scale)), int(round(w * scale))
+
+    def taps(n_out, n_in, s):
+        x = (np.arange(n_out) + 0.5) / s - 0.5
+        x0 = np.floor(x).astype(np.int64)
+        f = x - x0
+        a = np.clip(x0, 0, n_in - 1)
+        b = np.clip(x0 + 1, 0, n_in - 1)
+        return a, b, f
+
+    ya, yb, fy = taps(nh, h, nh / float(h))
+    xa, xb, fx = taps(nw, w, nw / float(w))
+    src = img.astype(np.float64)
+    if src.ndim == 2:
+        src = src[:, :, None]
+    top = src[ya][:, xa] * (1 - fx)[None, :, None] + src[ya][:, xb] * fx[None, :, None]
+    bot = src[yb][:, xa] * (1 - fx)[None, :, None] + src[yb][:, xb] * fx[None, :, None]
+    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    if img.dtype == np.uint8:
+        out = np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+    else:
+        out = out.astype(img.dtype)
+    return out.reshape((nh, nw) + img.shape[2:])
+
+
+def create_cams(image_params, cam_params_dict, num_depth=384, min_interval=0.1):
+    """cas_normal_eval.py:53-91: images.txt holds [Rwc | twc] with the camera looking along -z, y up; the network wants
+    Tcw with x right, y down.  cam[0] = inverse([Rwc @ diag(1,-1,-1) | twc]) (inverted in float32, as the reference does),
+    cam[1][:3,:3] = K, cam[1][3] = (depth_min, (depth_max - depth_min) / num_depth, num_depth, depth_max).
+    `min_interval` is accepted and unused, as in the reference."""
+    cam = np.zeros((2, 4, 4), dtype=np.float32)
+    extrinsics = np.zeros((4, 4), dtype=np.float32)
+    flip_yz = np.array([[1, 0, 0], [0, -1, 0], [0, 0, -1]], dtype=float)
+    extrinsics[0:3, 0:3] = np.matmul(image_params.rotation_matrix, flip_yz)
+    extrinsics[0:3, 3] = image_params.project_center
+    extrinsics[3, 3] = 1.0
+    cam[0, :, :] = np.linalg.inv(extrinsics)
+    cp = cam_params_dict[image_params.camera_id]
+    cam[1][0][0], cam[1][1][1] = cp.focallength[0], cp.focallength[1]
+    cam[1][0][2], cam[1][1][2] = cp.x0y0[0], cp.x0y0[1]
+    cam[1][2][2] = 1
+    cam[1][3][0] = image_params.depth[0]
+    cam[1][3][1] = (image_params.depth[1] - image_params.depth[0]) / num_depth
+    cam[1][3][3] = image_params.depth[1]
+    cam[1][3][2] = num_depth
+    return cam
+
+
+def _host_center_image(img, mode="mean"):
+    """preprocess.py:92-115 on the host (the reference's item layout carries normalised float images)."""
+    if mode == "standard":
+        return np.array(img, dtype=np.float32) / 255.
+    if mode == "mean":
+        x = np.array(img).astype(np.float32)
+        var = np.var(x, axis=(0, 1), keepdims=True)
+        mean = np.mean(x, axis=(0, 1), keepdims=True)
+        return (x - mean) / (np.sqrt(var) + 0.00000001)
+    if mode == "vit":
+        x = np.array(img).astype(np.float32)
+        return (x - np.array([123.675, 116.28, 103.53], np.float32)) / (np.array([58.395, 57.12, 57.375], np.float32) + 0.00000001)
+    raise Exception("{}? Not implemented yet!".format(mode))
+
+
+class MVSDataset(object):
+    """The inference dataset of the reference (cas_normal_eval.py:10-182) over a block folder holding viewpair.txt,
+    images.txt, cameras.txt and image_path.txt.  Same constructor, same `len`, and `dataset[i]` returns the same item
+    dict (imgs [V,3,H,W] float32 normalised on the host, proj_matrices / intri_matrices {stage1..3}, depth_values
+    [min, max], outimage, outcam, ref_image_path, outlocation).
+
+    `device_item(i)` is the form the predict loop of this package uses: decoded 8-bit images with their crop windows and
+    cache keys ("images_u8", "crop_windows", "image_keys") -- cropping and normalisation then run on the GPU
+    (center_image) and an image shared by several reference views is featurised once (FeatureCache); the matrices and
+    the output records are the same objects as in `dataset[i]`.
+
+    args needs: min_interval, interval_scale, numdepth, resize_scale, sample_scale, max_h, max_w (predict.py:38-48)."""
+
+    def __init__(self, data_folder, mode, view_num, normalize, args, **kwargs):
+        assert mode in ["train", "val", "test"]
+        self.data_folder, self.mode, self.args = data_folder, mode, args
+        self.view_num, self.normalize = view_num, normalize
+        self.min_interval, self.interval_scale, self.num_depth = args.min_interval, args.interval_scale, args.numdepth
+        self.cam_params_dict = read_cameras_text(data_folder + "/cameras.txt")
+        self.image_params_dict = read_images_text(data_folder + "/images.txt")
+        self.image_paths, _ = read_images_path_text(data_folder + "/image_path.txt")
+        self.sample_list = read_view_pair_text(data_folder + "/viewpair.txt", view_num)
+        self.sample_num = len(self.sample_list)
+
+    def __len__(self):
+        return len(self.sample_list)
+
+    def _view(self, image_idx):
+        """Decoded image, its (scaled, cropped) camera and crop window: cas_normal_eval.py:112-127."""
+        image = read_image_u8(self.image_paths[image_idx])
+        ip = self.image_params_dict[image_idx]
+        cam = create_cams(ip, self.cam_params_dict, self.num_depth, self.min_interval * self.interval_scale)
+        rs = self.args.resize_scale
+        image = scale_image(image, rs)
+        cam = scale_camera(cam, scale=rs)
+        win = crop_window(image.shape[0], image.shape[1], self.args.max_h, self.args.max_w, resize_scale=rs)
+        cam = crop_camera(cam, win[0], win[1])
+        return image, cam, win, ip
+
+    def _records_of(self, views):
+        cams = [v[1] for v in views]
+        image0, cam0, win0, ip0 = views[0]
+        y0, x0, H, W = slice_window(image0.shape[0], image0.shape[1], win0)
+        pm, im = stage_projections(cams, sample_scale=self.args.sample_scale)
+        depth_values = np.array([cam0[1][3][0], cam0[1][3][3]], dtype=np.float32)
+        return {"proj_matrices": pm, "intri_matrices": im, "depth_values": depth_values, "outcam": cam0,
+                "outlocation": [str(W), str(H), str(ip0.image_id), str(ip0.name)]}
+
+    def __getitem__(self, idx):
+        ids = self.sample_list[idx][:self.view_num]
+        views = [self._view(i) for i in ids]
+        item = self._records_of(views)
+        crops = []
+        for image, _, win, _ in views:
+            y0, x0, H, W = slice_window(image.shape[0], image.shape[1], win)
+            crops.append(image[y0:y0 + H, x0:x0 + W])
+        item["imgs"] = np.stack([_host_center_image(c, self.normalize) for c in crops]).transpose([0, 3, 1, 2])
+        item["outimage"] = crops[0]
+        item["ref_image_path"] = self.image_paths[ids[0]]
+        return item
+
+    def device_item(self, idx):
+        ids = self.sample_list[idx][:self.view_num]
+        views = [self._view(i) for i in ids]
+        item = self._records_of(views)
+        wins = [slice_window(v[0].shape[0], v[0].shape[1], v[2]) for v in views]
+        item["images_u8"] = [v[0] for v in views]
+        item["crop_windows"] = wins
+        item["normalize"] = self.normalize
+        item["image_keys"] = [(self.image_paths[i], self.args.resize_scale, w, self.normalize) for i, w in zip(ids, wins)]
+        item["ref_image_path"] = self.image_paths[ids[0]]
+        return item
+
+
+class DeviceItems(object):
+    """`dataset[i]` -> `dataset.device_item(i)` view of an MVSDataset, for predict_views."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        return self.dataset.device_item(idx)

@@ -43,13 +43,18 @@ class MVS_Inference:
         return found
 
     def argv(self, data_folder, mvs_path):
-        """The flags mvs_dl.py:61-63 formats, as an argument vector."""
+        """The flags mvs_dl.py:61-63 formats, as an argument vector.  No checkpoint -- neither `pretrain_weight` nor a
+        *.ckpt in the default folder -- raises, as the reference does at os.listdir / torch.load: products of an
+        untrained network must never reach the fusion step unnoticed ("--random_weights" in extra_args opts out)."""
         weight = self.pretrain_weight if self.pretrain_weight is not None else self.default_weight()
         args = ["--data_folder=%s" % data_folder, "--output_folder=%s" % mvs_path, "--model=%s" % self.model_type,
                 "--view_num=%d" % self.view_num, "--numdepth=%d" % self.num_depth, "--max_w=%d" % self.max_w,
                 "--max_h=%d" % self.max_h, "--min_interval=%s" % self.min_interval, "--display=%s" % self.display_depth]
         if weight is not None:
             args.append("--loadckpt=%s" % weight)
+        elif not any(x == "--random_weights" or x.startswith("--synthetic_items") for x in self.extra_args):
+            raise FileNotFoundError("no checkpoint: pretrain_weight is None and mvs/mvs_cas/checkpoints/%s/whu_omvs holds "
+                                    "no *.ckpt" % self.model_type)
         return args + self.extra_args
 
     def run(self, data_folder, mvs_path):

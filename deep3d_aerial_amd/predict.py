@@ -8,9 +8,9 @@ What is kept identical for the rest of the pipeline (mvs_dl.py upstream, fuse/ d
     (predict.py:146-183; PFM layout data_io.py:196-223; camera text data_io.py:291-314).
 What is new: reference views are sharded over ranks (one process per GPU, sharding.py).
 
-The reference's dataset class needs cv2/GDAL (datasets/cas_normal_eval.py:7, data_io.py:11-12),
-which this image does not have; any iterable yielding the same sample dicts can be passed to
-predict_views(), and SyntheticBlock provides one for plumbing tests (BASELINE.json config 1).
+The block folder (viewpair.txt, images.txt, cameras.txt, image_path.txt) is read by dataset.MVSDataset, the
+counterpart of datasets/cas_normal_eval.py; any iterable yielding the same sample dicts can be passed to
+predict_views(), and SyntheticBlock provides one for plumbing tests.
 """
 import argparse
 import os
@@ -337,7 +337,7 @@ def _item_views(s, model, device):
 # the per-view loop of predict.py:126-183, sharded over ranks
 # ----------------------------------------------------------------------------------------
 def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda", keep_maps=False,
-                  feature_cache_bytes=0):
+                  feature_cache_bytes=0, display=False):
     """Returns the names of the views this rank produced; with keep_maps=True a dict name -> (depth, confidence)
     of device tensors instead, so the fusion step (fuse.ViewFusion) can start without re-reading the PFM files.
     feature_cache_bytes > 0 keeps the feature pyramids of that many bytes of images resident across views (items must
@@ -372,6 +372,8 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
                 writer.submit([depth, prob], paths)  # the files land while the next view is computed
                 write_red_cam(os.path.join(output_folder, "%s.txt" % name), s["outcam"], s["outlocation"],
                               s["ref_image_path"])
+                if display:
+                    write_display_maps(output_folder, name, depth.cpu().numpy(), prob.cpu().numpy())
                 if keep_maps:
                     done[name] = (depth, prob)
                 else:
@@ -384,39 +386,96 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
     return done
 
 
+def _truthy(text):
+    """--display arrives as the STRING "True" / "False" (mvs_dl.py:61-63 formats the bool; predict.py:50 declares no
+    type), which the reference then tests for truth -- so its "False" displays too.  Here the
+    text is read for what it says."""
+    return str(text).strip().lower() not in ("", "0", "false", "no", "none")
+
+
 def parse_args(argv=None):
-    """The flags mvs/mvs_dl.py:61-63 formats (predict.py:30-58), plus --synthetic_items."""
+    """Every flag of the reference's harness (predict.py:30-58) with its default, plus --synthetic_items /
+    --random_weights / --feature_cache_gb of this package."""
     ap = argparse.ArgumentParser(description="plane-sweep depth inference (predict.py-compatible flags)")
-    ap.add_argument("--model", default="adamvs")
-    ap.add_argument("--data_folder", default=None)
+    ap.add_argument("--model", default="adamvs", help="casmvsnet | msrednet | adamvs (ucsnet: broken in the reference, SURVEY F7)")
+    ap.add_argument("--dataset", default="cas_normal_eval", help="dataset class (only the inference dataset exists here)")
+    ap.add_argument("--data_folder", default=None, help="block folder: viewpair.txt images.txt cameras.txt image_path.txt")
     ap.add_argument("--output_folder", required=True)
     ap.add_argument("--loadckpt", default=None)
     ap.add_argument("--view_num", type=int, default=5)
-    ap.add_argument("--numdepth", type=int, default=384)
-    ap.add_argument("--max_w", type=int, default=768)
-    ap.add_argument("--max_h", type=int, default=384)
+    ap.add_argument("--numdepth", type=int, default=192)
+    ap.add_argument("--max_w", type=int, default=3584)
+    ap.add_argument("--max_h", type=int, default=4096)
     ap.add_argument("--min_interval", type=float, default=0.1)
+    ap.add_argument("--fext", type=str, default=".jpg", help="accepted and unused, as in the reference's inference dataset")
+    ap.add_argument("--normalize", type=str, default="mean")
+    ap.add_argument("--resize_scale", type=float, default=1.0)
+    ap.add_argument("--sample_scale", type=float, default=1)
+    ap.add_argument("--interval_scale", type=float, default=1)
+    ap.add_argument("--batch_size", type=int, default=1)
+    ap.add_argument("--display", default=True)
+    ap.add_argument("--share_cr", action="store_true")
     ap.add_argument("--ndepths", type=str, default="48,32,8")
     ap.add_argument("--depth_inter_r", type=str, default="4,2,1")
-    ap.add_argument("--display", default="False")
-    ap.add_argument("--synthetic_items", type=int, default=0, help="run on a synthetic block of this many views")
+    ap.add_argument("--cr_base_chs", type=str, default="8,8,8")
+    ap.add_argument("--synthetic_items", type=int, default=0, help="run on a synthetic block of this many views instead of --data_folder")
+    ap.add_argument("--random_weights", action="store_true", help="run without --loadckpt (seeded random weights; plumbing tests only)")
+    ap.add_argument("--feature_cache_gb", type=float, default=8.0, help="HBM kept for feature pyramids of shared images (0 = off)")
     return ap.parse_args(argv)
+
+
+def write_display_maps(output_folder, name, depth, prob):
+    """predict.py:155-176: colour renderings of the depth (36000 - depth, non-finite columns patched) and confidence
+    maps under <output>/color/.  Needs matplotlib, like the reference."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    os.makedirs(os.path.join(output_folder, "color"), exist_ok=True)
+    img = (np.float32(36000) - depth).astype(np.float32)
+    img[np.isinf(img)] = np.nan
+    colmin = np.nanmin(np.where(np.isnan(img), np.inf, img), axis=0)     # per column, as the reference's loop
+    bad = np.isnan(img)
+    img[bad] = np.broadcast_to(colmin - 1, img.shape)[bad]
+    plt.imsave(os.path.join(output_folder, "color", "%s_init.png" % name), img, format="png")
+    plt.imsave(os.path.join(output_folder, "color", "%s_prob.png" % name), np.nan_to_num(prob).clip(0, 1), format="png")
 
 
 def main(argv=None):
     a = parse_args(argv)
+    if a.dataset != "cas_normal_eval":
+        raise Exception("{}? Not implemented yet!".format(a.dataset))   # the other dataset classes are training sets
+    if a.batch_size != 1:
+        raise ValueError("--batch_size must be 1 (reference views are sharded over GPUs instead; predict.py:49)")
+    if a.synthetic_items <= 0 and not a.data_folder:
+        raise ValueError("--data_folder is required (or --synthetic_items N)")
+    if not a.loadckpt and not (a.random_weights or a.synthetic_items > 0):
+        # the reference fails at torch.load here (predict.py:105); never write products of an untrained net silently
+        raise FileNotFoundError("--loadckpt is required (pass --random_weights to run on seeded random weights)")
     rank, world = sharding.init_from_env()
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # one process per GPU; more ranks than devices (tests on a one-GPU box) share the devices round-robin
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    # the dataset first: a bad folder fails before the model is built
+    if a.synthetic_items > 0:
+        ds = SyntheticBlock(a.synthetic_items, a.view_num, a.max_h, a.max_w, a.numdepth)
+    else:
+        from . import dataset
+
+        ds = dataset.DeviceItems(dataset.MVSDataset(a.data_folder, "val", a.view_num, a.normalize, a))
     model = build_model(a.model, a.numdepth, [int(x) for x in a.ndepths.split(",")],
-                        [float(x) for x in a.depth_inter_r.split(",")]).cuda()
+                        [float(x) for x in a.depth_inter_r.split(",")], share_cr=a.share_cr,
+                        cr_base_chs=[int(x) for x in a.cr_base_chs.split(",")])
     if a.loadckpt:
+        print("loading model {}".format(a.loadckpt))
         load_checkpoint(model, a.loadckpt)
-    if a.synthetic_items <= 0:
-        raise SystemExit("reading WHU-OMVS blocks needs cv2/GDAL (absent here): pass --synthetic_items N, or call "
-                         "predict_views() with your own dataset object")
-    ds = SyntheticBlock(a.synthetic_items, a.view_num, a.max_h, a.max_w, a.numdepth)
-    names = predict_views(model, ds, a.output_folder, rank, world)
+    else:
+        synthetic.fill_state_dict_(model.state_dict(), 0)
+    model = model.cuda()
+    names = predict_views(model, ds, a.output_folder, rank, world, display=_truthy(a.display),
+                          feature_cache_bytes=int(a.feature_cache_gb * (1 << 30)) if a.synthetic_items <= 0 else 0)
     print("rank %d/%d wrote %d views" % (rank, world, len(names)))
+    return names
 
 
 if __name__ == "__main__":

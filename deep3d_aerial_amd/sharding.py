@@ -35,7 +35,9 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RCCL needs one device per rank; ranks sharing a device (tests) and CPU runs rendezvous over gloo
+            local = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= local else "gloo"
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world
 

@@ -1,9 +1,14 @@
 """Row N3, CPU side: the host camera arithmetic of the item builder against the outputs of the
 reference's own preprocess functions (tests/golden/dataset_preprocess.npz, made by tests/golden/make_golden_dataset.py),
 the matrix statements of cas_normal_eval.py:134-173 by construction, and the feature cache's bookkeeping."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from conftest import load_golden
 from deep3d_aerial_amd import dataset as DS
@@ -112,3 +117,84 @@ def test_read_image_u8_roundtrip(tmp_path):
     assert got.dtype == np.uint8 and got.flags["C_CONTIGUOUS"] and np.array_equal(got, rgb)
     Image.fromarray(rgb[:, :, 0]).save(tmp_path / "g.png")
     assert DS.read_image_u8(str(tmp_path / "g.png")).shape == (20, 30, 1)
+
+
+# ----------------------------------------------------------------------------------------
+# the block reader against the REFERENCE's dataset class (tests/golden/make_golden_block.py)
+# ----------------------------------------------------------------------------------------
+def _block(tmp_path):
+    import block_fixture as BF
+
+    return BF, BF.write_block(str(tmp_path / "block"))
+
+
+@pytest.mark.parametrize("normalize", ["mean", "standard"])
+def test_block_reader_equals_reference_items(tmp_path, normalize):
+    """viewpair.txt / images.txt / cameras.txt / image_path.txt + PNGs -> the item dict of cas_normal_eval.py:94-182:
+    cameras, projection pyramids, crops and records EXACTLY as the reference produced them; host-normalised images too
+    (same NumPy statements)."""
+    from deep3d_aerial_amd import dataset as D
+
+    BF, folder = _block(tmp_path)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "block_items.npz"))
+    ds = D.MVSDataset(folder, "val", BF.VIEW_NUM, normalize, BF.Args())
+    assert len(ds) == int(g["n_%s" % normalize]) == 4          # the view without sources is dropped
+    assert ds.sample_list[3] == [3, 4, 4, 4]                   # short source lists are padded with their first entry
+    for i in range(len(ds)):
+        it, k = ds[i], "%s_%d_" % (normalize, i)
+        for st in ("stage1", "stage2", "stage3"):
+            assert it["proj_matrices"][st].dtype == g[k + "proj_" + st].dtype
+            assert np.array_equal(it["proj_matrices"][st], g[k + "proj_" + st])
+            assert np.array_equal(it["intri_matrices"][st], g[k + "intri_" + st])
+        assert np.array_equal(it["depth_values"], g[k + "depth_values"])
+        assert np.array_equal(it["outcam"], g[k + "outcam"])
+        assert np.array_equal(it["outimage"], g[k + "outimage"])
+        assert list(it["outlocation"]) == list(g[k + "outlocation"])
+        assert os.path.basename(it["ref_image_path"]) == str(g[k + "ref_name"])
+        assert it["imgs"].dtype == np.float32 and it["imgs"].shape == g[k + "imgs"].shape
+        assert np.abs(it["imgs"] - g[k + "imgs"]).max() <= 2e-5
+
+
+def test_block_reader_device_items_describe_the_same_views(tmp_path):
+    """device_item(i): the decoded images + crop windows + cache keys select exactly the pixels of dataset[i]."""
+    from deep3d_aerial_amd import dataset as D
+
+    BF, folder = _block(tmp_path)
+    ds = D.MVSDataset(folder, "val", BF.VIEW_NUM, "mean", BF.Args())
+    for i in range(len(ds)):
+        host, dev = ds[i], D.DeviceItems(ds)[i]
+        assert len(dev["images_u8"]) == BF.VIEW_NUM and len(set(dev["image_keys"])) == len(set(ds.sample_list[i][:BF.VIEW_NUM]))
+        y0, x0, H, W = dev["crop_windows"][0]
+        assert np.array_equal(dev["images_u8"][0][y0:y0 + H, x0:x0 + W], host["outimage"])
+        for st in ("stage1", "stage2", "stage3"):
+            assert np.array_equal(dev["proj_matrices"][st], host["proj_matrices"][st])
+        assert np.array_equal(dev["outcam"], host["outcam"]) and dev["outlocation"] == host["outlocation"]
+
+
+def test_scale_image_unit_scale_is_identity_and_half_scale_averages():
+    from deep3d_aerial_amd import dataset as D
+
+    img = np.arange(4 * 6 * 3, dtype=np.uint8).reshape(4, 6, 3)
+    assert np.array_equal(D.scale_image(img, 1.0), img)
+    half = D.scale_image(img, 0.5)      # INTER_LINEAR at 1/2: each output pixel is the mean of a 2 x 2 block
+    want = np.floor(img.reshape(2, 2, 3, 2, 3).astype(np.float64).mean(axis=(1, 3)) + 0.5).astype(np.uint8)
+    assert half.shape == (2, 3, 3) and np.array_equal(half, want)
+
+
+def test_feature_cache_hit_survives_eviction_by_an_earlier_miss():
+    """An item whose cached view sits BEHIND an uncached one, with room for about one pyramid: the put() for the miss
+    evicts the cached key; the pyramid taken in the first pass must still be used (advisor finding, round 1)."""
+    calls = []
+
+    def net(x):
+        calls.append(float(x.flatten()[0]))
+        return {"stage1": x * 2.0}
+
+    cache = DS.FeatureCache(max_bytes=4 * 16 + 8)           # one 16-float pyramid
+    a, b = torch.full((1, 1, 4, 4), 1.0), torch.full((1, 1, 4, 4), 2.0)
+    DS.extract_features(net, [a], ["A"], cache)             # A cached
+    feats = DS.extract_features(net, [b, None], ["B", "A"], cache)   # B uncached and first; A not uploaded (it was cached)
+    assert float(feats[0]["stage1"][0, 0, 0, 0]) == 4.0 and float(feats[1]["stage1"][0, 0, 0, 0]) == 2.0
+    assert calls == [1.0, 2.0]
+    feats = DS.extract_features(net, [b, None, None], ["B", "B", "B"], cache)   # padded source lists repeat an image
+    assert len(calls) == 2 and all(float(f["stage1"][0, 0, 0, 0]) == 4.0 for f in feats)

@@ -1,8 +1,13 @@
 """Row N3, GPU side: crop + normalise of 8-bit images on the device against the reference's own
 center_image outputs, and the feature cache (results must not change, shared images must be featurised once)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from conftest import load_golden
 from deep3d_aerial_amd import synthetic as S
@@ -86,7 +91,7 @@ def test_in_process_launch_writes_products(tmp_path):
     assert inf.run("/unused", str(out)) == 0
     assert sorted(p.name for p in out.iterdir()) == ["view_0000.txt", "view_0000_init.pfm", "view_0000_prob.pfm",
                                                      "view_0001.txt", "view_0001_init.pfm", "view_0001_prob.pfm"]
-    with pytest.raises(SystemExit):  # no dataset reader for real blocks in this image: reported, not swallowed
+    with pytest.raises(FileNotFoundError):  # a real block needs a checkpoint: reported as an ordinary exception
         mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet").run("/unused", str(out))
 
 
@@ -122,3 +127,70 @@ def test_content_matched_cache_on_reference_item_layout(tmp_path):
     for n in a:
         for suffix in ("_init.pfm", "_prob.pfm"):
             assert (tmp_path / "plain" / (n + suffix)).read_bytes() == (tmp_path / "cached" / (n + suffix)).read_bytes()
+
+
+# ----------------------------------------------------------------------------------------
+# the CLI boundary on a block folder (BASELINE config 1's plumbing: V = 3, num_depth = 64)
+# ----------------------------------------------------------------------------------------
+def _block_and_checkpoint(tmp_path, model_type):
+    import block_fixture as BF
+    from deep3d_aerial_amd import predict as P
+
+    folder = BF.write_block(str(tmp_path / "block"))
+    model = P.build_model(model_type, BF.NUM_DEPTH)
+    S.fill_state_dict_(model.state_dict(), 31)
+    ckpt = str(tmp_path / "model_000001_0.1000.ckpt")
+    # the reference's checkpoint layout: {'epoch', 'model', 'optimizer'} with DataParallel's "module." prefix
+    torch.save({"epoch": 1, "model": {"module." + k: v for k, v in model.state_dict().items()}, "optimizer": {}}, ckpt)
+    return BF, folder, ckpt, model
+
+
+@pytest.mark.parametrize("model_type", ["casmvsnet", "adamvs"])
+def test_mvs_inference_runs_on_a_block_folder(tmp_path, model_type):
+    """MVS_Inference(...).run(data_folder, mvs_path) -- the call run.py:160-165 makes -- on a block in the reference's
+    on-disk layout: reads viewpair / images / cameras / image_path + PNGs, loads the checkpoint, writes the three
+    products per reference view.  The depth maps equal a forward on the item tensors the REFERENCE's dataset class
+    produced for the same block (tests/golden/block_items.npz)."""
+    from deep3d_aerial_amd import mvs_dl, predict as P
+
+    BF, folder, ckpt, model = _block_and_checkpoint(tmp_path, model_type)
+    out = tmp_path / "dense" / "MVS"
+    inf = mvs_dl.MVS_Inference(BF.MAX_W, BF.MAX_H, view_num=BF.VIEW_NUM, num_depth=BF.NUM_DEPTH, model_type=model_type,
+                               pretrain_weight=ckpt, display_depth=False)
+    assert inf.run(folder, str(out)) == 0
+    names = ["img_%02d" % i for i in range(4)]
+    assert sorted(p.name for p in out.iterdir()) == sorted(n + e for n in names for e in (".txt", "_init.pfm", "_prob.pfm"))
+    g = load_golden("block_items")
+    model = model.cuda().eval()
+    for i, n in enumerate(names):
+        depth, _ = P.load_pfm(str(out / (n + "_init.pfm")))
+        prob, _ = P.load_pfm(str(out / (n + "_prob.pfm")))
+        assert depth.shape == (BF.MAX_H, BF.MAX_W) and np.isfinite(depth).all() and np.isfinite(prob).all()
+        k = "mean_%d_" % i
+        with torch.no_grad():
+            ref = model(torch.from_numpy(g[k + "imgs"])[None].cuda(),
+                        {st: torch.from_numpy(g[k + "proj_" + st])[None].cuda() for st in ("stage1", "stage2", "stage3")},
+                        torch.from_numpy(g[k + "depth_values"])[None].cuda())
+        want = ref["depth"].squeeze().cpu().numpy()
+        assert np.abs(depth - want).mean() / np.abs(want).mean() <= 1e-3   # images normalised on the GPU vs on the host
+        txt = (out / (n + ".txt")).read_text().split()
+        assert txt[0] == "extrinsic:" and txt[-5:-1] == [str(BF.MAX_W), str(BF.MAX_H), str(i), n + ".png"]
+        assert os.path.basename(txt[-1]) == n + ".png"
+        nums = [float(v) for v in txt[3:19]]
+        assert np.allclose(np.array(nums).reshape(4, 4), g[k + "outcam"][0], rtol=1e-6, atol=1e-6)
+
+
+def test_two_ranks_write_the_same_products_as_one(tmp_path):
+    """predict.main under torch.distributed.run with two ranks (both on this box's GPU): every view is written by exactly
+    one rank and the union of the files equals the single-rank run byte for byte (mvs_dl.py:61-65, predict.py:126-183)."""
+    from deep3d_aerial_amd import mvs_dl
+
+    BF, folder, ckpt, _ = _block_and_checkpoint(tmp_path, "casmvsnet")
+    kw = dict(view_num=BF.VIEW_NUM, num_depth=BF.NUM_DEPTH, model_type="casmvsnet", pretrain_weight=ckpt)
+    one, two = tmp_path / "one" / "MVS", tmp_path / "two" / "MVS"
+    mvs_dl.MVS_Inference(BF.MAX_W, BF.MAX_H, **kw).run(folder, str(one))
+    mvs_dl.MVS_Inference(BF.MAX_W, BF.MAX_H, n_gpus=2, **kw).run(folder, str(two))
+    files = sorted(p.name for p in one.iterdir())
+    assert len(files) == 12 and files == sorted(p.name for p in two.iterdir())
+    for f in files:
+        assert (one / f).read_bytes() == (two / f).read_bytes(), f

@@ -71,9 +71,39 @@ def test_multi_rank_launch_propagates_failure(tmp_path):
     dropped like os.system's status (mvs_dl.py:65).  The workers fail by design: no GPU / no dataset reader."""
     from deep3d_aerial_amd import mvs_dl
 
-    inf = mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet", n_gpus=2)
+    inf = mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet", n_gpus=2,
+                               extra_args=["--random_weights"])
     with pytest.raises(RuntimeError, match="exit status"):
         inf.run("/nonexistent", str(tmp_path / "mvs"))
+
+
+def test_missing_checkpoint_is_an_error_not_random_weights(tmp_path):
+    """mvs_dl.py:52-58 / predict.py:105: the reference fails when no checkpoint exists; products of an untrained network
+    must not be written silently."""
+    from deep3d_aerial_amd import mvs_dl
+
+    inf = mvs_dl.MVS_Inference(96, 64, view_num=3, num_depth=32, model_type="casmvsnet")
+    with pytest.raises(FileNotFoundError, match="no checkpoint"):
+        inf.run(str(tmp_path), str(tmp_path / "mvs"))
+    with pytest.raises(FileNotFoundError, match="--loadckpt is required"):
+        predict.main(["--data_folder", str(tmp_path), "--output_folder", str(tmp_path / "o")])
+    with pytest.raises(ValueError, match="--data_folder is required"):
+        predict.main(["--output_folder", str(tmp_path / "o"), "--random_weights"])
+
+
+def test_harness_accepts_every_reference_flag():
+    """predict.py:31-56: all 21 flags parse, with the reference's defaults."""
+    a = predict.parse_args(["--output_folder", "o"])
+    assert (a.model, a.dataset, a.view_num, a.numdepth, a.max_w, a.max_h) == ("adamvs", "cas_normal_eval", 5, 192, 3584, 4096)
+    assert (a.fext, a.normalize, a.resize_scale, a.sample_scale, a.interval_scale, a.batch_size) == (".jpg", "mean", 1.0, 1, 1, 1)
+    assert (a.share_cr, a.ndepths, a.depth_inter_r, a.cr_base_chs, a.min_interval) == (False, "48,32,8", "4,2,1", "8,8,8", 0.1)
+    b = predict.parse_args(["--model", "casmvsnet", "--dataset", "cas_normal_eval", "--data_folder", "d", "--output_folder", "o",
+                            "--loadckpt", "w", "--view_num", "3", "--numdepth", "64", "--max_w", "96", "--max_h", "64",
+                            "--min_interval", "0.2", "--fext", ".png", "--normalize", "standard", "--resize_scale", "0.5",
+                            "--sample_scale", "1", "--interval_scale", "2", "--batch_size", "1", "--display", "False",
+                            "--share_cr", "--ndepths", "8,8,4", "--depth_inter_r", "2,1,1", "--cr_base_chs", "8,8,8"])
+    assert b.share_cr and b.normalize == "standard" and b.resize_scale == 0.5 and b.interval_scale == 2
+    assert predict._truthy(b.display) is False and predict._truthy("True") and predict._truthy(True)
 
 
 def test_fusion_settings_honour_every_threshold():

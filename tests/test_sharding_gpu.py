@@ -1,0 +1,47 @@
+"""The optional all-gather of per-view (depth, confidence) maps on DEVICE tensors over RCCL (backend "nccl"), one process
+per GPU -- SURVEY.md 8e, BASELINE config 5's exchange step.  Needs two GPUs in the box: skipped on the one-GPU test
+boxes (no 1 -> 8 scaling curve has been measured by the build; DESIGN.md section 6 says so)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _view(i, h=37, w=53):
+    g = torch.Generator().manual_seed(4000 + i)
+    return torch.rand((2, h, w), generator=g) + i
+
+
+def _worker(rank, world, port, n_views, out_dir):
+    sys.path.insert(0, ROOT)
+    from deep3d_aerial_amd import sharding
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    sharding.init_from_env("nccl")
+    full = sharding.run_sharded(lambda i: _view(i).cuda(), n_views, gather=True)
+    assert full.is_cuda
+    torch.save(full.cpu(), os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_views", [5, 8])
+def test_all_gather_maps_on_devices(tmp_path, n_views):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL needs one device per rank)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, n_views, str(tmp_path)), nprocs=2, join=True)
+    want = torch.stack([_view(i) for i in range(n_views)])
+    for rank in range(2):
+        assert torch.equal(torch.load(os.path.join(str(tmp_path), "rank%d.pt" % rank)), want)
