@@ -53,6 +53,61 @@ def host_threads():
     return max(1, n)
 
 
+def torch_cpu_leg(proj_host, feats_host, depth_host, threads, budget_s=6.0):
+    """The reference's own op sequence (module.py:516-557 + cas_mvsnet.py:46-60) written in this harness with plain
+    PyTorch CPU operators -- inverse/matmul, the pixel grid, F.grid_sample(bilinear, zeros, align_corners=True), sum and
+    sum of squares -- in chunks of 8 planes (the full 384-plane call needs ~50 GB of host memory), on a
+    bounded number of chunks.  Nothing of the reference is imported: this is the baseline a user of the reference's
+    CPU path would see on this box's host cores."""
+    import torch.nn.functional as F
+
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        feats = [torch.from_numpy(f)[None] for f in feats_host]             # [1,C,h,w]
+        projs = [torch.from_numpy(p)[None] for p in proj_host]              # [1,4,4]
+        ref, ref_proj = feats[0], projs[0]
+        h, w = H_FEAT, W_FEAT
+        V = len(feats)
+
+        def warp(src_fea, src_proj, dvals):
+            nd = dvals.shape[1]
+            proj = torch.matmul(src_proj, torch.inverse(ref_proj))
+            rot, trans = proj[:, :3, :3], proj[:, :3, 3:4]
+            y, x = torch.meshgrid([torch.arange(0, h, dtype=torch.float32), torch.arange(0, w, dtype=torch.float32)], indexing="ij")
+            xyz = torch.stack((x.reshape(-1), y.reshape(-1), torch.ones(h * w)))[None]
+            rot_depth_xyz = torch.matmul(rot, xyz).unsqueeze(2).repeat(1, 1, nd, 1) * dvals.view(1, 1, nd, -1)
+            pxyz = rot_depth_xyz + trans.view(1, 3, 1, 1)
+            pxy = pxyz[:, :2] / pxyz[:, 2:3]
+            grid = torch.stack((pxy[:, 0] / ((w - 1) / 2) - 1, pxy[:, 1] / ((h - 1) / 2) - 1), dim=3)
+            out = F.grid_sample(src_fea, grid.view(1, nd * h, w, 2), mode="bilinear", padding_mode="zeros", align_corners=True)
+            return out.view(1, C, nd, h, w)
+
+        def chunk(d0):
+            dvals = torch.from_numpy(depth_host[d0:d0 + 8])[None]
+            vol = ref.unsqueeze(2).repeat(1, 1, 8, 1, 1)
+            vsum, vsq = vol, vol ** 2
+            for i in range(1, V):
+                wv = warp(feats[i], projs[i], dvals)
+                vsum = vsum + wv
+                vsq = vsq + wv ** 2
+            return vsq.div_(V).sub_(vsum.div_(V).pow_(2))
+
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            chunk(D // 2)
+            first = time.perf_counter() - t0
+            n = int(max(1, min(6, budget_s / max(first, 1e-3))))
+            t0 = time.perf_counter()
+            for k in range(n):
+                chunk((D // 2 + 8 * (k + 1)) % (D - 8))
+            dt = time.perf_counter() - t0
+        return {"value": round(n * 8 * h * w / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": threads, "kind": "torch-ops",
+                "sample": "%d chunks of 8 planes of the same 5-view 32x688x464 workload, %.1f s" % (n, dt)}
+    finally:
+        torch.set_num_threads(old)
+
+
 def cpu_baseline(proj34_host, feats_host, depth_host):
     """Times the CPU oracle on a depth sub-range of the same workload (bounded to ~10-20 s)."""
     import oracle
@@ -75,12 +130,68 @@ def cpu_baseline(proj34_host, feats_host, depth_host):
                       % (planes, D, start, start + planes - 1, dt)}
 
 
+def profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC profile (profiles/pmc_latest.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950).  Counters cannot be collected inside this process, so
+    the number is only reported while the profile was taken from the SAME kernel source: the profile records the
+    SHA-256 of csrc/planesweep_tiled.hip, compared here; after any kernel edit `traffic` is null until
+    tools/profile_round.sh has been re-run."""
+    import hashlib
+
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    src = os.path.join(ROOT, "deep3d_aerial_amd", "csrc", "planesweep_tiled.hip")
+    try:
+        prof = json.load(open(pmc))
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    except Exception:
+        return None, None
+    info = {"file": "profiles/pmc_latest.json", "kernel": prof.get("kernel"), "round": prof.get("round"),
+            "kernel_source_sha256": prof.get("kernel_source_sha256"), "matches_current_source": prof.get("kernel_source_sha256") == sha}
+    return (prof.get("hbm_bytes_per_launch") if info["matches_current_source"] else None), info
+
+
+def secondary_models(reps=2):
+    """BASELINE config 3 (not the headline metric): one reference view of the full cascades at 2752x1856, 5 views, bf16
+    regulariser operands, seeded random weights -- ms per view and cost-volume Mvoxels/s (97.05 M voxels per view)."""
+    from deep3d_aerial_amd import predict
+
+    res = {}
+    old = ops.conv_precision()
+    ops.set_conv_precision("bf16")
+    try:
+        for name in ("casmvsnet", "adamvs"):
+            net = predict.build_model(name, 384)
+            S.fill_state_dict_(net.state_dict(), 1)
+            net = net.cuda().eval()
+            s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
+            imgs = torch.from_numpy(s["imgs"])[None].cuda()
+            pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}
+            dv = torch.from_numpy(s["depth_values"])[None].cuda()
+            with torch.no_grad():
+                net(imgs, pm, dv)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    net(imgs, pm, dv)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / reps * 1e3
+            res[name] = {"ms_per_view": round(ms, 2), "mvoxels_per_s": round(97.05e6 / ms / 1e3, 1)}
+            del net, imgs, pm, dv
+            torch.cuda.empty_cache()
+    finally:
+        ops.set_conv_precision(old)
+    res["config"] = "config 3: full cascade forward, 5 views, 2752x1856, ndepths 48/32/8, bf16 regulariser operands (fp32 accumulate), synthetic"
+    res["casmvsnet"]["regulariser_flop"] = 1.264e12   # SURVEY.md 8d: 632.2 GMAC of 3D convolution per view
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 model timings appended after the headline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,13 +248,7 @@ def main():
     achieved = algorithmic_bytes() / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_info = profiled_traffic()
         line = {
             "metric": "cost-volume Mvoxels/s (5v x 384D)",
             "value": round(value, 1),
@@ -162,12 +267,24 @@ def main():
                                    "step per GPU", "voxels_per_step_per_gpu": voxels,
                        "in_frame_fraction": round(in_frame, 4), "path": os.environ.get("D3D_FORCE_PATH", "auto")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profile": traffic_info,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": algorithmic_bytes()},
         }
         if world == 1 and not args.no_cpu_baseline:
             p34_host = p34.cpu().numpy().reshape(-1, 3, 4)
-            line["cpu_baseline"] = cpu_baseline(p34_host, feats_host, depth_host)
+            cb = cpu_baseline(p34_host, feats_host, depth_host)
+            # second baseline of SURVEY.md 8(d): the reference's op sequence in plain PyTorch CPU, all cores and 8 threads
+            allc = host_threads()
+            cb["torch_ops_all_cores"] = torch_cpu_leg(proj, feats_host, depth_host, allc)
+            cb["torch_ops_8_threads"] = torch_cpu_leg(proj, feats_host, depth_host, min(8, allc))
+            line["cpu_baseline"] = cb
+        if world == 1 and not args.no_secondary:
+            del out
+            torch.cuda.empty_cache()
+            try:
+                line["secondary"] = secondary_models()
+            except Exception as e:   # the headline line must survive a failure of the add-on
+                line["secondary"] = {"error": repr(e)[:200]}
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -27,6 +27,8 @@ SIGNATURES = {
     "d3d_last_error": [],
     "d3d_compose_projections": [_vp, _i, _vp, _vp],
     "d3d_debug_force_path": [_i],
+    "d3d_compose_projections_f64": [_vp, _i, _vp, _vp],
+    "d3d_homo_warp_f64coord": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],  # returns size_t
     "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],

@@ -214,6 +214,68 @@ __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// module.py:560-601 homo_warping_double: the same warp with the coordinate chain in fp64 -- rot @ [x,y,1], times
+// depth, plus trans, the perspective divide and the normalisation to [-1,1] are double; the grid is rounded to fp32
+// (`.float()`, module.py:590) and F.grid_sample un-normalises it in fp32.  Unused by the reference's models (it needs
+// fp64 projection matrices, which its datasets never produce); built because SURVEY.md 8(a) lists it.  One lane per
+// (pixel, plane), channels in a loop: a direct-gather kernel, not a tuned one.
+// ---------------------------------------------------------------------------------------
+__global__ void compose_f64_kernel(const double* __restrict__ proj44, int n_views, double* __restrict__ out34) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i >= n_views) return;
+    // Gauss-Jordan with partial pivoting on the reference view's 4x4 (fp64)
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { a[r][c] = proj44[r * 4 + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+        const double inv = 1.0 / a[col][col];
+        for (int c = 0; c < 8; ++c) a[col][c] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+        }
+    }
+    const double* s = proj44 + 16 * i;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += s[r * 4 + k] * a[k][4 + c];
+            out34[(i - 1) * 12 + r * 4 + c] = acc;
+        }
+}
+
+__global__ __launch_bounds__(256) void warp_f64coord_kernel(const float* __restrict__ src, const double* __restrict__ P,
+                                                            const float* __restrict__ depth, int depth_mode, int C, int D,
+                                                            int h, int w, float* __restrict__ out) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int d = blockIdx.z;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)h * w, pix = (size_t)y * w + x;
+    const double dv = (double)(depth_mode == D3D_DEPTH_PER_PIXEL ? depth[(size_t)d * plane + pix] : depth[d]);
+    const double xd = (double)x, yd = (double)y;
+    // torch.matmul(rot, xyz): a 3-term dot product per row, accumulated left to right
+    const double rx = P[0] * xd + P[1] * yd + P[2];
+    const double ry = P[4] * xd + P[5] * yd + P[6];
+    const double rz = P[8] * xd + P[9] * yd + P[10];
+    const double px = rx * dv + P[3], py = ry * dv + P[7], pz = rz * dv + P[11];
+    const float gx = (float)((px / pz) / ((double)(w - 1) / 2.0) - 1.0);
+    const float gy = (float)((py / pz) / ((double)(h - 1) / 2.0) - 1.0);
+    // grid_sampler_unnormalize, align_corners=True: ((coord + 1) / 2) * (size - 1), in fp32
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(w - 1);
+    const float iy = ((gy + 1.0f) / 2.0f) * (float)(h - 1);
+    const bool ok = (ix > -2.0f) && (ix < (float)w + 1.0f) && (iy > -2.0f) && (iy < (float)h + 1.0f);  // also rejects NaN
+    const TapD t = make_tap_direct(ok ? ix : -2.0f, ok ? iy : -2.0f, h, w);
+    for (int c = 0; c < C; ++c)
+        out[((size_t)c * D + d) * plane + pix] = gather4(src + (size_t)c * plane, t);
+}
+
 template <int MODE, typename T = float>
 static int launch_direct(const SweepParams& p, hipStream_t stream) {
     SweepParams q = p;
@@ -310,6 +372,27 @@ int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int
     p.workspace = workspace;
     p.workspace_bytes = workspace ? workspace_bytes : 0;
     return sweep_dispatch(MODE_WARP, p, (hipStream_t)stream);
+}
+
+int d3d_compose_projections_f64(const double* proj44, int n_views, double* out34, d3d_stream_t stream) {
+    D3D_REQUIRE(proj44 && out34, "null pointer");
+    D3D_REQUIRE(n_views >= 2 && n_views <= D3D_MAX_VIEWS, "n_views=%d out of range [2,%d]", n_views, D3D_MAX_VIEWS);
+    hipLaunchKernelGGL(compose_f64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, proj44, n_views, out34);
+    D3D_LAUNCH_CHECK("compose_f64_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_homo_warp_f64coord(const float* src, const double* proj34, const float* depth, int depth_mode, int C, int D,
+                           int h, int w, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(src && proj34 && depth && out, "null pointer");
+    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    int rc = check_dims(C, D, h, w);
+    if (rc) return rc;
+    D3D_REQUIRE(D <= 65535, "D=%d too large for one launch", D);
+    hipLaunchKernelGGL(warp_f64coord_kernel, dim3(ceil_div(w, 64), ceil_div(h, 4), D), dim3(256), 0, (hipStream_t)stream, src,
+                       proj34, depth, depth_mode, C, D, h, w, out);
+    D3D_LAUNCH_CHECK("warp_f64coord_kernel launch");
+    return D3D_OK;
 }
 
 static int fill_multi(SweepParams& p, const float* const* feats, const float* proj34, const float* depth,

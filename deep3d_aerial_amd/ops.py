@@ -103,6 +103,26 @@ def homo_warp(src, proj34, depth, out=None):
     return out
 
 
+def homo_warp_double(src, src_proj, ref_proj, depth):
+    """module.py:560-601 homo_warping_double: src [C,h,w] fp32, src_proj / ref_proj [4,4] FLOAT64 (the reference function
+    only accepts double matrices), depth [D]|[D,h,w] fp32 -> [C,D,h,w] fp32 sampled at fp64-computed coordinates."""
+    for name, t in (("src_proj", src_proj), ("ref_proj", ref_proj)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and tuple(t.shape) == (4, 4)):
+            raise TypeError("%s must be a CUDA float64 [4,4] tensor" % name)
+    C, h, w = src.shape
+    dp, mode, D = _depth(depth, h, w)
+    p44 = torch.stack([ref_proj, src_proj]).contiguous()
+    p34 = torch.empty((1, 12), dtype=torch.float64, device=src.device)
+    lib = _lib.load()
+    _lib.check(lib.d3d_compose_projections_f64(ctypes.c_void_p(p44.data_ptr()), 2, ctypes.c_void_p(p34.data_ptr()),
+                                               _stream()), "d3d_compose_projections_f64")
+    out = torch.empty((C, D, h, w), dtype=torch.float32, device=src.device)
+    rc = lib.d3d_homo_warp_f64coord(_chk(src, "src", 3), ctypes.c_void_p(p34.data_ptr()), dp, mode, C, D, h, w,
+                                    _chk(out, "out", 4), _stream())
+    _lib.check(rc, "d3d_homo_warp_f64coord")
+    return out
+
+
 def _check_feats(feats, proj34):
     if len(feats) < 2:
         raise ValueError("need a reference and at least one source view")

@@ -94,6 +94,18 @@ int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int
                   int w, float* out, void* workspace, size_t workspace_bytes, d3d_stream_t stream);
 
 /*
+ * module.py:560-601 homo_warping_double -- the warp with an fp64 coordinate chain: proj = src_proj @ inverse(ref_proj),
+ * rot @ [x,y,1], * depth, + trans, the divide and the [-1,1] normalisation in double; the grid is rounded to fp32 and
+ * un-normalised / sampled in fp32 as F.grid_sample does.  (The reference function only runs when handed fp64
+ * projection matrices; no model of the reference calls it.)
+ * d3d_compose_projections_f64: proj44 device double [V,4,4] -> out34 device double [V-1,12].
+ * d3d_homo_warp_f64coord: src [C,h,w] fp32, proj34 device double [12], depth fp32 -> out [C,D,h,w] fp32.
+ */
+int d3d_compose_projections_f64(const double* proj44, int n_views, double* out34, d3d_stream_t stream);
+int d3d_homo_warp_f64coord(const float* src, const double* proj34, const float* depth, int depth_mode, int C, int D,
+                           int h, int w, float* out, d3d_stream_t stream);
+
+/*
  * cas_mvsnet.py:45-60 (same arithmetic ucsnet.py:119-134, msrednet.py:217-230 and,
  * with D = 1 per call, msrednet.py:400-414) -- fused warp + variance cost volume:
  *     sum = ref + SUM_i warp_i ; sq = ref^2 + SUM_i warp_i^2 ; var = sq/V - (sum/V)^2

@@ -82,6 +82,23 @@ def homo_warp(src, proj34, depth):
     return out
 
 
+def homo_warp_double(src, src_proj44, ref_proj44, depth):
+    """module.py:560-601: projection matrices in float64 [4,4]."""
+    import ctypes
+
+    src = _c(src)
+    C, h, w = src.shape
+    depth, is_map, D = _depth_args(depth, h, w)
+    out = np.empty((C, D, h, w), np.float32)
+    r = np.ascontiguousarray(ref_proj44, np.float64)
+    s_ = np.ascontiguousarray(src_proj44, np.float64)
+    pd = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    rc = lib().d3d_oracle_homo_warp_f64(_p(src), pd(r), pd(s_), _p(depth), is_map, C, D, h, w, _p(out))
+    if rc != 0:
+        raise ValueError("singular reference projection")
+    return out
+
+
 def variance_volume(ref, srcs, projs, depth):
     """ref [C,h,w]; srcs [V-1,C,h,w]; projs [V-1,3,4]; depth [D] or [D,h,w] -> [C,D,h,w]."""
     ref, srcs, projs = _c(ref), _c(srcs), _c(projs)

@@ -165,6 +165,68 @@ API void d3d_oracle_homo_warp(const float* src, const float* proj34, const float
             }
 }
 
+/* module.py:560-601 homo_warping_double.  src [C,h,w] fp32; ref44 / src44 row-major 4x4 DOUBLE; depth fp32.
+ * proj = src44 @ inverse(ref44) in fp64 (:571), rot @ [x,y,1] (:581), * depth (:582-583), + trans (:584), the divide
+ * (:585) and the normalisation x/((W-1)/2) - 1 (:586-587) in fp64; grid = .float() (:590); F.grid_sample
+ * (bilinear, zeros, align_corners=True) then un-normalises in fp32 with ((g+1)/2)*(size-1). */
+API int d3d_oracle_homo_warp_f64(const float* src, const double* ref44, const double* src44, const float* depth,
+                                 int depth_is_map, int C, int D, int h, int w, float* out) {
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = ref44[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) return -1;
+        for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+        double inv = 1.0 / a[col][col];
+        for (int j = 0; j < 8; ++j) a[col][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            double f = a[r][col];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
+        }
+    }
+    double P[12];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += src44[i * 4 + k] * a[k][4 + j];
+            P[i * 4 + j] = s;
+        }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int d = 0; d < D; ++d)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                double dv = (double)depth_at(depth, depth_is_map, d, y, x, h, w);
+                double rx = P[0] * x + P[1] * y + P[2], ry = P[4] * x + P[5] * y + P[6], rz = P[8] * x + P[9] * y + P[10];
+                double px = rx * dv + P[3], py = ry * dv + P[7], pz = rz * dv + P[11];
+                float gx = (float)((px / pz) / ((double)(w - 1) / 2.0) - 1.0);
+                float gy = (float)((py / pz) / ((double)(h - 1) / 2.0) - 1.0);
+                float ix = ((gx + 1.0f) / 2.0f) * (float)(w - 1);
+                float iy = ((gy + 1.0f) / 2.0f) * (float)(h - 1);
+                tap_t t;
+                t.ok_nw = t.ok_ne = t.ok_sw = t.ok_se = 0;
+                t.nw = t.ne = t.sw = t.se = 0.0f;
+                t.x0 = t.y0 = 0;
+                if (ix > -2.0f && ix < (float)w + 1.0f && iy > -2.0f && iy < (float)h + 1.0f) {
+                    float fx = floorf(ix), fy = floorf(iy);
+                    int x0 = (int)fx, y0 = (int)fy;
+                    float x1f = fx + 1.0f, y1f = fy + 1.0f;
+                    t.x0 = x0; t.y0 = y0;
+                    t.nw = (x1f - ix) * (y1f - iy); t.ne = (ix - fx) * (y1f - iy);
+                    t.sw = (x1f - ix) * (iy - fy); t.se = (ix - fx) * (iy - fy);
+                    t.ok_nw = (x0 >= 0 && x0 < w && y0 >= 0 && y0 < h);
+                    t.ok_ne = (x0 + 1 >= 0 && x0 + 1 < w && y0 >= 0 && y0 < h);
+                    t.ok_sw = (x0 >= 0 && x0 < w && y0 + 1 >= 0 && y0 + 1 < h);
+                    t.ok_se = (x0 + 1 >= 0 && x0 + 1 < w && y0 + 1 >= 0 && y0 + 1 < h);
+                }
+                for (int c = 0; c < C; ++c)
+                    out[(((size_t)c * D + d) * h + y) * w + x] = sample_tap(src + (size_t)c * h * w, w, &t);
+            }
+    return 0;
+}
+
 /* cas_mvsnet.py:45-60 (same arithmetic: ucsnet.py:119-134, msrednet.py:217-230,400-414)
  * variance cost volume.  ref [C,h,w]; srcs [V-1,C,h,w]; projs [V-1,12]; out [C,D,h,w].
  *   sum = ref + sum_i warp_i ; sq = ref^2 + sum_i warp_i^2 ; var = sq/V - (sum/V)^2 */

@@ -157,3 +157,17 @@ def test_costregnet_3d(oracle):
         assert y.shape == want.shape
         assert rel_l1(y, want) <= 1e-5, i
         assert np.abs(y - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), i
+
+
+def test_homo_warp_double_oracle_matches_reference(oracle):
+    """Row a2: module.py:560-601 with float64 projection matrices (tests/golden/make_golden_warp_double.py)."""
+    g = load_golden("ops_warp_double")
+    worst = 0.0
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        got = oracle.homo_warp_double(g[k + "src"], g[k + "src_proj"], g[k + "ref_proj"], g[k + "depth"])
+        worst = max(worst, float(np.abs(got - g[k + "out"]).max()))
+    # same fp64 chain, same fp32 un-normalisation: only the 4x4 inverse (LU vs Gauss-Jordan, 1e-16 relative) differs
+    assert worst <= 2e-6, worst
+    # and the fp64 chain is not the fp32 chain: far from the origin they differ by whole grey levels
+    assert float(g["c9_float_chain_maxdiff"]) > 1e-2

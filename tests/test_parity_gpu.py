@@ -828,3 +828,21 @@ def test_gru_cell_on_streaming_kernel(ops, oracle, monkeypatch, Cx, Hc, H, W):
     monkeypatch.setenv("D3D_CONV2D_STREAM", "0")
     folded = host(ops.gru_cell_fused(*args))
     assert np.abs(got - folded).max() <= 2e-5
+
+
+# ----------------------------------------------------------------------------------------
+# row a2: homo_warping_double (module.py:560-601)
+# ----------------------------------------------------------------------------------------
+def test_homo_warp_double_golden_and_oracle(ops, oracle):
+    g = load_golden("ops_warp_double")
+    for i in range(int(g["n_cases"])):
+        k = "c%d_" % i
+        src, depth = g[k + "src"], g[k + "depth"]
+        got = host(ops.homo_warp_double(dev(src), torch.from_numpy(g[k + "src_proj"]).cuda(),
+                                        torch.from_numpy(g[k + "ref_proj"]).cuda(), dev(depth)))
+        assert got.shape == g[k + "out"].shape
+        assert np.abs(got - g[k + "out"]).max() <= 2e-6, i                 # the reference itself
+        want = oracle.homo_warp_double(src, g[k + "src_proj"], g[k + "ref_proj"], depth)
+        assert np.abs(got - want).max() <= 2e-6, i
+    with pytest.raises(TypeError):                                           # fp32 matrices: the reference raises too
+        ops.homo_warp_double(dev(src), dev(np.eye(4)), dev(np.eye(4)), dev(depth))
