@@ -66,6 +66,9 @@ SIGNATURES = {
     "d3d_fusion_accumulate": [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_double), _i, _i, _i, _i,
                               ctypes.c_double, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "d3d_fusion_finalize": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "d3d_fusion_points_scratch_bytes": [_i, _i],  # returns size_t
+    "d3d_fusion_mark_points": [_vp, _vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp, _vp],
+    "d3d_fusion_gather_points": [_vp, _vp, ctypes.POINTER(_vp), _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "d3d_flip_rows": [ctypes.POINTER(_vp), _i, _i, _i, _vp, _vp],
     "d3d_center_image_u8": [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
 }
@@ -106,7 +109,7 @@ def load():
             raise LibraryMissing("symbol %s missing from %s" % (name, SO_PATH)) from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "d3d_last_error" else
-                      ctypes.c_size_t if name == "d3d_sweep_workspace_bytes" else ctypes.c_int)
+                      ctypes.c_size_t if name in ("d3d_sweep_workspace_bytes", "d3d_fusion_points_scratch_bytes") else ctypes.c_int)
     if lib.d3d_version() != ABI_VERSION:
         raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))
     _lib = lib

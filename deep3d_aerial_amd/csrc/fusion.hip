@@ -222,6 +222,128 @@ static void fill_cams(FusionCams& c, const double* cam) {
     for (int i = 0; i < 9; ++i) c.Rri[i] = (float)*p++;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tail of a reference view (fuse/fusion_3d_normal.py:545-570): the confirmed pixels become point-cloud vertices.
+// The reference compacts with boolean indexing (row-major order of final_mask), then walks every skip_line-th valid
+// point in a Python loop, keeps those inside the scene block in x and y, and lists the views that see the point.
+// Here: two flag scans (valid pixels -> ordinal among the valid ones; kept points -> output slot) and one gather.
+// Order and content of the output equal the reference's lists.
+// ---------------------------------------------------------------------------------------------------------------
+struct VisPlanes { const int* p[64]; };     // the visibility planes of a reference view, by value (<= 1 + fusion_num)
+constexpr int SCAN_ITEMS = 16;              // flags per thread
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
+
+// block totals of a byte-flag array
+__global__ __launch_bounds__(256) void flag_count_kernel(const unsigned char* __restrict__ flags, long n, unsigned* __restrict__ block_sums) {
+    __shared__ unsigned wsum[4];
+    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) c += (base + k < n && flags[base + k]) ? 1u : 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the block totals in place (one workgroup; a 2752 x 1856 map has 1247 blocks); total -> *total
+__global__ __launch_bounds__(256) void block_scan_kernel(unsigned* __restrict__ block_sums, int nblocks, unsigned* __restrict__ total) {
+    __shared__ unsigned part[256];
+    const int per = (nblocks + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, nblocks);
+    unsigned s = 0;
+    for (int b = b0; b < b1; ++b) s += block_sums[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < 256; ++i) { const unsigned t = part[i]; part[i] = run; run += t; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned run = part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) { const unsigned t = block_sums[b]; block_sums[b] = run; run += t; }
+}
+
+// exclusive prefix of this thread's first flag within the grid (block offset + in-block scan)
+__device__ __forceinline__ unsigned thread_prefix(const unsigned char* __restrict__ flags, long n, const unsigned* __restrict__ block_offs,
+                                                  unsigned (&mine)[SCAN_ITEMS]) {
+    __shared__ unsigned wsum[4];
+    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) { mine[k] = (base + k < n && flags[base + k]) ? 1u : 0u; c += mine[k]; }
+    unsigned incl = c;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { const unsigned o = __shfl_up(incl, sft); if ((int)(threadIdx.x & 63) >= sft) incl += o; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) woff += wsum[wv];
+    return block_offs[blockIdx.x] + woff + incl - c;
+}
+
+// valid pixel with ordinal i (among the valid ones) is kept iff i % skip == 0 and it lies inside the block in x and y
+__global__ __launch_bounds__(256) void points_mark_kernel(const unsigned char* __restrict__ final_mask, const float* __restrict__ avg_xyz,
+                                                          long plane, const unsigned* __restrict__ block_offs, int skip, double x0,
+                                                          double x1, double y0, double y1, unsigned char* __restrict__ keep) {
+    unsigned mine[SCAN_ITEMS];
+    unsigned ord = thread_prefix(final_mask, plane, block_offs, mine);
+    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const long i = base + k;
+        if (i >= plane) break;
+        unsigned char kp = 0;
+        if (mine[k]) {
+            const double x = (double)avg_xyz[i], y = (double)avg_xyz[plane + i];
+            kp = (ord % (unsigned)skip == 0u) && (x0 < x) && (x < x1) && (y0 < y) && (y < y1);   // NaN fails, as in Python
+            ++ord;
+        }
+        keep[i] = kp;
+    }
+}
+
+__global__ __launch_bounds__(256) void points_gather_kernel(const unsigned char* __restrict__ keep, long plane,
+                                                            const unsigned* __restrict__ block_offs, const float* __restrict__ avg_xyz,
+                                                            const float* __restrict__ color, const float* __restrict__ normal,
+                                                            VisPlanes vis, int n_vis, float* __restrict__ out_xyz,
+                                                            int* __restrict__ out_color, float* __restrict__ out_normal,
+                                                            int* __restrict__ out_views, int* __restrict__ out_nviews) {
+    unsigned mine[SCAN_ITEMS];
+    unsigned slot = thread_prefix(keep, plane, block_offs, mine);
+    const long base = (long)blockIdx.x * SCAN_BLOCK + (long)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const long i = base + k;
+        if (i >= plane || !mine[k]) continue;
+        const size_t o = slot++;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out_xyz[o * 3 + c] = avg_xyz[(size_t)c * plane + i];
+        if (color)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out_color[o * 3 + c] = (int)(color[(size_t)i * 3 + c] * 255.0f);   // (color * 255).astype(int)
+        if (normal)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out_normal[o * 3 + c] = normal[(size_t)i * 3 + c];
+        // views = sorted(vis[vis > 0] - 1): insertion into the output row (n_vis <= 1 + fusion_num, ~11)
+        int nv = 0;
+        int* row = out_views + o * n_vis;
+        for (int v = 0; v < n_vis; ++v) {
+            const int id = vis.p[v][i];
+            if (id > 0) {
+                int j = nv++;
+                while (j > 0 && row[j - 1] > id - 1) { row[j] = row[j - 1]; --j; }
+                row[j] = id - 1;
+            }
+        }
+        for (int v = nv; v < n_vis; ++v) row[v] = -1;
+        out_nviews[o] = nv;
+    }
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -300,6 +422,54 @@ int d3d_fusion_finalize(const float* all_xyz_world, const float* conf_sum, const
     hipLaunchKernelGGL(fusion_finalize_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream,
                        all_xyz_world, conf_sum, geo_mask_sum, plane, min_geo_consist_num, avg_xyz_world, final_mask);
     D3D_LAUNCH_CHECK("fusion_finalize_kernel launch");
+    return D3D_OK;
+}
+
+size_t d3d_fusion_points_scratch_bytes(int H, int W) {
+    if (H <= 0 || W <= 0) return 0;
+    const long blocks = ((long)H * W + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    return (size_t)(2 * blocks + 4) * sizeof(unsigned);
+}
+
+int d3d_fusion_mark_points(const float* avg_xyz_world, const unsigned char* final_mask, int H, int W, int skip_line,
+                           const double* scene_range_xy, void* scratch, unsigned char* keep, unsigned* counts,
+                           d3d_stream_t stream) {
+    D3D_REQUIRE(avg_xyz_world && final_mask && scene_range_xy && scratch && keep && counts, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && skip_line >= 1, "bad dims %dx%d / skip_line %d", H, W, skip_line);
+    const long plane = (long)H * W;
+    const int blocks = (int)((plane + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    unsigned* offs_valid = reinterpret_cast<unsigned*>(scratch);
+    unsigned* offs_keep = offs_valid + blocks;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(flag_count_kernel, dim3(blocks), dim3(256), 0, st, final_mask, plane, offs_valid);
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, offs_valid, blocks, counts);
+    hipLaunchKernelGGL(points_mark_kernel, dim3(blocks), dim3(256), 0, st, final_mask, avg_xyz_world, plane, offs_valid, skip_line,
+                       scene_range_xy[0], scene_range_xy[1], scene_range_xy[2], scene_range_xy[3], keep);
+    hipLaunchKernelGGL(flag_count_kernel, dim3(blocks), dim3(256), 0, st, keep, plane, offs_keep);
+    hipLaunchKernelGGL(block_scan_kernel, dim3(1), dim3(256), 0, st, offs_keep, blocks, counts + 1);
+    D3D_LAUNCH_CHECK("fusion point marking launch");
+    return D3D_OK;
+}
+
+int d3d_fusion_gather_points(const float* avg_xyz_world, const unsigned char* keep, const int* const* vis, int n_vis,
+                             const float* color, const float* normal_world, int H, int W, void* scratch, float* out_xyz,
+                             int* out_color, float* out_normal, int* out_views, int* out_nviews, d3d_stream_t stream) {
+    D3D_REQUIRE(avg_xyz_world && keep && vis && scratch && out_xyz && out_views && out_nviews, "null pointer");
+    D3D_REQUIRE(!color || out_color, "colour input without output");
+    D3D_REQUIRE(!normal_world || out_normal, "normal input without output");
+    D3D_REQUIRE(H > 0 && W > 0 && n_vis >= 1 && n_vis <= 64, "bad dims %dx%d / %d visibility planes (max 64)", H, W, n_vis);
+    const long plane = (long)H * W;
+    const int blocks = (int)((plane + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    unsigned* offs_keep = reinterpret_cast<unsigned*>(scratch) + blocks;     // left by d3d_fusion_mark_points
+    VisPlanes vp = {};
+    for (int v = 0; v < n_vis; ++v) {
+        D3D_REQUIRE(vis[v], "vis[%d] is null", v);
+        vp.p[v] = vis[v];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(points_gather_kernel, dim3(blocks), dim3(256), 0, st, keep, plane, offs_keep, avg_xyz_world, color, normal_world,
+                       vp, n_vis, out_xyz, out_color, out_normal, out_views, out_nviews);
+    D3D_LAUNCH_CHECK("points_gather_kernel launch");
     return D3D_OK;
 }
 

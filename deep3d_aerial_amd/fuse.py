@@ -167,6 +167,60 @@ class ViewFusion(object):
         return avg, fm.bool()
 
 
+def extract_points(avg_xyz_world, final_mask, vis_infos, ref_img, normal_world, scene_range, skip_line=2):
+    """fuse/fusion_3d_normal.py:545-570 on the device: the vertices of one reference view.
+
+    avg_xyz_world [3,H,W] and final_mask [H,W] from ViewFusion.finalize; vis_infos: ViewFusion.vis_infos (list of [H,W]
+    int32 planes holding 1-based image indices, 0 = not visible); ref_img [H,W,3] float32 in 0..1 (read_img, :174-186) or
+    None; normal_world [H,W,3] or None; scene_range = [min_x, max_x, min_y, max_y, ...] of the block (:598).
+    Returns a dict of device tensors: "xyz" [n,3], "color" [n,3] int32 (or None), "normal" [n,3] (or None), "views"
+    [n,n_vis] int32 = the sorted 0-based view indices of every vertex, -1 padded, "nviews" [n] -- the content of the
+    reference's total_vertices / total_verticesColor / total_verticesNormal for this view, in the same order.  A view with
+    fewer than 10 confirmed pixels yields no vertices (:541-543)."""
+    if avg_xyz_world.dim() != 3 or avg_xyz_world.shape[0] != 3:
+        raise ValueError("avg_xyz_world must be [3,H,W]")
+    _, H, W = avg_xyz_world.shape
+    dev = avg_xyz_world.device
+    lib = _lib.load()
+    fm = final_mask.to(torch.uint8).contiguous()
+    if tuple(fm.shape) != (H, W):
+        raise ValueError("final_mask must be [H,W]")
+    n_vis = len(vis_infos)
+    if not 1 <= n_vis <= 64:
+        raise ValueError("1..64 visibility planes (got %d)" % n_vis)
+    for v in vis_infos:
+        if v.dtype != torch.int32 or tuple(v.shape) != (H, W) or not v.is_cuda or not v.is_contiguous():
+            raise TypeError("vis_infos must be contiguous CUDA int32 [H,W] tensors")
+    scratch = torch.empty((int(lib.d3d_fusion_points_scratch_bytes(H, W)),), dtype=torch.uint8, device=dev)
+    keep = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+    sr = (ctypes.c_double * 4)(*[float(x) for x in list(scene_range)[:4]])
+    rc = lib.d3d_fusion_mark_points(_chk(avg_xyz_world, "avg_xyz_world"), ctypes.c_void_p(fm.data_ptr()), H, W, int(skip_line), sr,
+                                    ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(keep.data_ptr()),
+                                    ctypes.c_void_p(counts.data_ptr()), _stream())
+    _lib.check(rc, "d3d_fusion_mark_points")
+    n_valid, n = (int(x) for x in counts.tolist())   # the one host read: the caller sizes the outputs
+    if n_valid < 10 or n_valid <= 1:                 # :541-543 ("no points left"), :555
+        n = 0
+    out = {"xyz": torch.empty((n, 3), dtype=torch.float32, device=dev),
+           "color": None if ref_img is None else torch.empty((n, 3), dtype=torch.int32, device=dev),
+           "normal": None if normal_world is None else torch.empty((n, 3), dtype=torch.float32, device=dev),
+           "views": torch.empty((n, n_vis), dtype=torch.int32, device=dev),
+           "nviews": torch.empty((n,), dtype=torch.int32, device=dev), "n_valid": n_valid}
+    if n == 0:
+        return out
+    vp = (ctypes.c_void_p * n_vis)(*[v.data_ptr() for v in vis_infos])
+    opt = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    rc = lib.d3d_fusion_gather_points(_chk(avg_xyz_world, "avg_xyz_world"), ctypes.c_void_p(keep.data_ptr()), vp, n_vis,
+                                      None if ref_img is None else _map(ref_img, "ref_img", (H, W, 3)),
+                                      None if normal_world is None else _map(normal_world, "normal_world", (H, W, 3)), H, W,
+                                      ctypes.c_void_p(scratch.data_ptr()), _chk(out["xyz"], "xyz"), opt(out["color"]),
+                                      opt(out["normal"]), ctypes.c_void_p(out["views"].data_ptr()),
+                                      ctypes.c_void_p(out["nviews"].data_ptr()), _stream())
+    _lib.check(rc, "d3d_fusion_gather_points")
+    return out
+
+
 def default_normals(h, w, device="cuda"):
     """fuse/fusion_3d_normal.py:441-443, 497-498: views without a normal map get (0, 0, -1) everywhere."""
     n = torch.zeros((h, w, 3), dtype=torch.float32, device=device)

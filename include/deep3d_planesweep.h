@@ -386,6 +386,26 @@ int d3d_fusion_finalize(const float* all_xyz_world, const float* conf_sum, const
                         int min_geo_consist_num, float* avg_xyz_world, unsigned char* final_mask, d3d_stream_t stream);
 
 /*
+ * fuse/fusion_3d_normal.py:545-570 -- the confirmed pixels of a reference view as point-cloud vertices, replacing the
+ * boolean-index compaction and the Python loop over points.  Two calls, because the caller sizes the outputs:
+ *   d3d_fusion_mark_points: pixel i is KEPT iff final_mask[i], its ordinal among the valid pixels (row-major) is a
+ *     multiple of skip_line, and scene_range_xy[0] < x < [1] and [2] < y < [3] (host array of 4 doubles; strict, NaN fails).
+ *     keep [H*W] bytes; counts[0] = valid pixels, counts[1] = kept points (device, read them after the stream).
+ *   d3d_fusion_gather_points: out_xyz [n,3], out_color [n,3] = trunc(color * 255) of color [H,W,3] in 0..1 (NULL: skipped),
+ *     out_normal [n,3] of normal_world [H,W,3] (NULL: skipped), out_views [n,n_vis] = sorted(vis[vis > 0] - 1) padded
+ *     with -1, out_nviews [n]; rows in the order of the reference's lists.  vis: HOST array of n_vis device pointers.
+ *   scratch: d3d_fusion_points_scratch_bytes(H, W) bytes of device memory shared by both calls (caller-owned).
+ */
+size_t d3d_fusion_points_scratch_bytes(int H, int W);
+int d3d_fusion_mark_points(const float* avg_xyz_world, const unsigned char* final_mask, int H, int W, int skip_line,
+                           const double* scene_range_xy, void* scratch, unsigned char* keep, unsigned* counts,
+                           d3d_stream_t stream);
+int d3d_fusion_gather_points(const float* avg_xyz_world, const unsigned char* keep, const int* const* vis, int n_vis,
+                             const float* color, const float* normal_world, int H, int W, void* scratch, float* out_xyz,
+                             int* out_color, float* out_normal, int* out_views, int* out_nviews, d3d_stream_t stream);
+
+
+/*
  * SURVEY.md §8f row N2 -- PFM payload order.  save_pfm_utf8 (mvs/mvs_cas/datasets/data_io.py:196-223) writes rows
  * bottom-up (np.flipud) and read_pfm / load_pfm (data_io.py:150-193, IO/pfm.py:19-60) flips them back.
  * d3d_flip_rows: out[k][H-1-y][x] = maps[k][y][x] for n <= 8 maps [H,W] (maps: HOST array of device pointers; out

@@ -112,3 +112,30 @@ def fusion_finalize(all_xyz_world, conf_sum, geo_mask_sum, min_geo_consist_num):
     lib().d3d_oracle_fusion_finalize(_ptr(all_xyz_world, fp), _ptr(conf_sum, fp), _ptr(geo_mask_sum, ctypes.c_int32), H, W,
                                      int(min_geo_consist_num), _ptr(avg, fp), _ptr(fm, ctypes.c_ubyte))
     return avg, fm.astype(bool)
+
+
+def fusion_points(avg_xyz_world, final_mask, vis_infos, color, normal_world, skip_line, scene_range):
+    """fusion_3d_normal.py:545-570 -> (xyz [n,3], color [n,3] int32, normal [n,3], views [n,n_vis] int32 (-1 padded), nviews [n])."""
+    avg = _f(avg_xyz_world)
+    _, H, W = avg.shape
+    m8 = np.ascontiguousarray(np.asarray(final_mask).astype(np.uint8))
+    vis = [np.ascontiguousarray(v, dtype=np.int32) for v in vis_infos]
+    vp = (ctypes.POINTER(ctypes.c_int32) * len(vis))(*[v.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) for v in vis])
+    col = None if color is None else _f(color)
+    nrm = None if normal_world is None else _f(normal_world)
+    sr = (ctypes.c_double * 4)(*[float(x) for x in scene_range[:4]])
+    fp, ip = ctypes.c_float, ctypes.c_int32
+    f = lib().d3d_oracle_fusion_points
+    f.restype = ctypes.c_int64
+    null = lambda t: ctypes.cast(None, ctypes.POINTER(t))
+    args = [_ptr(avg, fp), _ptr(m8, ctypes.c_ubyte), vp, len(vis), null(fp) if col is None else _ptr(col, fp),
+            null(fp) if nrm is None else _ptr(nrm, fp), H, W, int(skip_line), sr]
+    n = int(f(*args, null(fp), null(ip), null(fp), null(ip), null(ip)))
+    xyz = np.empty((n, 3), np.float32)
+    oc = np.empty((n, 3), np.int32)
+    on = np.empty((n, 3), np.float32)
+    ov = np.empty((n, len(vis)), np.int32)
+    onv = np.empty((n,), np.int32)
+    if n:
+        f(*args, _ptr(xyz, fp), _ptr(oc, ip), _ptr(on, fp), _ptr(ov, ip), _ptr(onv, ip))
+    return xyz, (oc if col is not None else None), (on if nrm is not None else None), ov, onv

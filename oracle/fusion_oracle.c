@@ -161,3 +161,46 @@ API void d3d_oracle_fusion_finalize(const float* all_xyz_world, const float* con
         final_mask[i] = geo_mask_sum[i] >= min_num;
     }
 }
+
+
+/* fuse/fusion_3d_normal.py:545-570: vertices of one reference view.  valid = final_mask (row-major order, as boolean
+ * indexing yields them, :546-552); every skip_line-th VALID point (:554) that lies strictly inside the block in x and y
+ * (:558) becomes a vertex with views = sorted(vis[vis > 0] - 1) (:559-562), colour = (ref_img * 255).astype(int) (:551),
+ * normal = ref_normal_est_world (:552).  `len(all_vis_infos[0]) > 1` (:555): a view with a single valid point emits nothing.
+ * Returns the number of vertices; outputs must hold that many rows (call with NULL outputs to count). */
+API int64_t d3d_oracle_fusion_points(const float* avg_xyz_world, const unsigned char* final_mask, const int32_t* const* vis,
+                                     int n_vis, const float* color, const float* normal_world, int H, int W, int skip_line,
+                                     const double* scene_range, float* out_xyz, int32_t* out_color, float* out_normal,
+                                     int32_t* out_views, int32_t* out_nviews) {
+    const int64_t plane = (int64_t)H * W;
+    int64_t n_valid = 0;
+    for (int64_t i = 0; i < plane; ++i) n_valid += final_mask[i] ? 1 : 0;
+    if (n_valid <= 1) return 0;
+    int64_t ord = 0, n = 0;
+    for (int64_t i = 0; i < plane; ++i) {
+        if (!final_mask[i]) continue;
+        const int64_t k = ord++;
+        if (k % skip_line != 0) continue;
+        const double x = (double)avg_xyz_world[i], y = (double)avg_xyz_world[plane + i];
+        if (!(scene_range[0] < x && x < scene_range[1] && scene_range[2] < y && y < scene_range[3])) continue;
+        if (out_xyz) {
+            for (int c = 0; c < 3; ++c) out_xyz[n * 3 + c] = avg_xyz_world[(int64_t)c * plane + i];
+            if (color) for (int c = 0; c < 3; ++c) out_color[n * 3 + c] = (int32_t)(color[i * 3 + c] * 255.0f);
+            if (normal_world) for (int c = 0; c < 3; ++c) out_normal[n * 3 + c] = normal_world[i * 3 + c];
+            int nv = 0;
+            int32_t* row = out_views + n * n_vis;
+            for (int v = 0; v < n_vis; ++v) {
+                const int32_t id = vis[v][i];
+                if (id > 0) {
+                    int j = nv++;
+                    while (j > 0 && row[j - 1] > id - 1) { row[j] = row[j - 1]; --j; }
+                    row[j] = id - 1;
+                }
+            }
+            for (int v = nv; v < n_vis; ++v) row[v] = -1;
+            out_nviews[n] = nv;
+        }
+        ++n;
+    }
+    return n;
+}

@@ -221,3 +221,37 @@ def test_fuse_block_chains_filtered_maps(fuse, oracle):
         assert np.array_equal(host(g["final_mask"]), fm) and 0.02 < fm.mean() < 0.98
         assert np.array_equal(host(g["avg_xyz_world"]), avg, equal_nan=True)
         assert len(g["vis_infos"]) == 1 + sum(sn in cam for sn in pair["src"])
+
+
+# ---- row N1 tail: vertices of a reference view (fuse/fusion_3d_normal.py:545-570) ------------------------------------
+@pytest.mark.parametrize("h,w,n_vis,skip_line", [(37, 53, 5, 2), (64, 96, 3, 1), (301, 517, 11, 3), (2752, 1856, 11, 2)])
+def test_extract_points_bit_exact_vs_oracle(fuse, oracle, h, w, n_vis, skip_line):
+    from oracle import fusion as F
+    from test_fusion_oracle import _points_scene
+
+    avg, mask, vis, color, normal, sr = _points_scene(h, w, n_vis, 100 + h)
+    got = fuse.extract_points(torch.from_numpy(avg).cuda(), torch.from_numpy(mask).cuda(), [torch.from_numpy(v).cuda() for v in vis],
+                              torch.from_numpy(color).cuda(), torch.from_numpy(normal).cuda(), sr, skip_line=skip_line)
+    xyz, oc, on, ov, onv = F.fusion_points(avg, mask, vis, color, normal, skip_line, sr)
+    assert got["n_valid"] == int(mask.sum()) and got["xyz"].shape[0] == xyz.shape[0] > 50
+    assert np.array_equal(got["xyz"].cpu().numpy(), xyz) and np.array_equal(got["color"].cpu().numpy(), oc)
+    assert np.array_equal(got["normal"].cpu().numpy(), on)
+    assert np.array_equal(got["views"].cpu().numpy(), ov) and np.array_equal(got["nviews"].cpu().numpy(), onv)
+
+
+def test_extract_points_after_view_fusion(fuse):
+    """End of the chain: ViewFusion.finalize -> extract_points; few confirmed pixels give no vertices (:541-543)."""
+    ref, srcs = S.make_fusion_scene(48, 64, n_src=3, seed=5)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    vf = fuse.ViewFusion(fuse.ConsistencyChecker(1.0, 0.01, 90.0, 0.0), d(ref["depth"]), d(ref["normal"]), ref["K"], ref["E"],
+                         d(ref["confidence"]), 1)
+    for i, s in enumerate(srcs):
+        vf.add_source(d(s["depth"]), d(s["normal"]), s["K"], s["E"], i + 2)
+    avg, fm = vf.finalize(2)
+    pts = fuse.extract_points(avg, fm, vf.vis_infos, None, vf.normal_world, [-1e9, 1e9, -1e9, 1e9], skip_line=2)
+    n_valid = int(fm.sum().item())
+    assert pts["n_valid"] == n_valid and pts["xyz"].shape[0] == (n_valid + 1) // 2 and pts["color"] is None
+    assert int(pts["nviews"].min().item()) >= 2                       # the reference view + >= 1 confirming source (geo_mask_sum starts at 1)
+    assert bool((pts["views"][:, 0] == 0).all())                      # view ids are 0-based in the vertices
+    none = fuse.extract_points(avg, torch.zeros_like(fm), vf.vis_infos, None, None, [-1e9, 1e9, -1e9, 1e9])
+    assert none["xyz"].shape[0] == 0

@@ -93,3 +93,47 @@ def test_accumulators_by_construction(oracle):
     avg, fm = oracle.fusion.fusion_finalize(xyz, conf, cnt, 3)
     assert np.array_equal(avg, (e_xyz / e_conf).astype(np.float32))
     assert np.array_equal(fm, e_cnt >= 3) and 0 < fm.mean() < 1
+
+
+def _points_scene(h, w, n_vis, seed):
+    rng = np.random.default_rng(seed)
+    avg = (rng.standard_normal((3, h, w)) * 40 + np.array([500.0, -200.0, 30.0])[:, None, None]).astype(np.float32)
+    avg[0, rng.random((h, w)) < 0.01] = np.nan                       # a failed average (0/0) must drop out at the range test
+    mask = rng.random((h, w)) < 0.35
+    vis = [np.full((h, w), 3, np.int32)] + [(rng.random((h, w)) < 0.6).astype(np.int32) * int(v) for v in rng.permutation(np.arange(4, 4 + n_vis - 1))]
+    color = (rng.integers(0, 256, (h, w, 3)).astype(np.float32) / 255.).astype(np.float32)
+    normal = rng.standard_normal((h, w, 3)).astype(np.float32)
+    return avg, mask, vis, color, normal, [470.0, 545.0, -250.0, -160.0, 0.0, 100.0]
+
+
+def _points_reference_loop(avg, mask, vis, color, normal, skip_line, scene_range):
+    """The statements of fuse/fusion_3d_normal.py:545-570, with NumPy, as the construction check of the oracle."""
+    all_vis = np.array([v[mask] for v in vis])
+    xyz = avg[np.repeat(mask[None], 3, axis=0)].reshape(3, -1)
+    col = (color[mask] * 255).astype(int)
+    nrm = normal[mask]
+    V, C, N, VW = [], [], [], []
+    for i in range(0, xyz.shape[1], skip_line):
+        if len(all_vis[0]) > 1:
+            p, va = xyz[:, i], all_vis[:, i]
+            if scene_range[0] < p[0] < scene_range[1] and scene_range[2] < p[1] < scene_range[3]:
+                V.append(p); C.append(col[i]); N.append(nrm[i]); VW.append(sorted((va[va > 0] - 1).tolist()))
+    return V, C, N, VW
+
+
+@pytest.mark.parametrize("skip_line", [1, 2, 3])
+def test_fusion_points_by_construction(oracle, skip_line):
+    """Row N1 tail: the oracle's vertex extraction equals the reference's boolean-index compaction + per-point loop."""
+    from oracle import fusion as F
+
+    avg, mask, vis, color, normal, sr = _points_scene(37, 53, 5, 11 + skip_line)
+    xyz, oc, on, ov, onv = F.fusion_points(avg, mask, vis, color, normal, skip_line, sr)
+    V, C, N, VW = _points_reference_loop(avg, mask, vis, color, normal, skip_line, sr)
+    assert len(V) == xyz.shape[0] and len(V) > 20
+    assert np.array_equal(xyz, np.array(V, np.float32)) and np.array_equal(oc, np.array(C, np.int32))
+    assert np.array_equal(on, np.array(N, np.float32))
+    for i, want in enumerate(VW):
+        assert ov[i, :onv[i]].tolist() == want and (ov[i, onv[i]:] == -1).all()
+    # a single valid pixel emits nothing (:555)
+    one = np.zeros_like(mask); one[3, 4] = True
+    assert F.fusion_points(avg, one, vis, color, normal, 1, [-1e9, 1e9, -1e9, 1e9])[0].shape[0] == 0
