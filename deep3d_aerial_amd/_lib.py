@@ -34,7 +34,7 @@ SIGNATURES = {
     "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_f16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_pair_corr_mean": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
-    "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_softargmin_conf4": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "d3d_online_regress_update": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_online_regress_finalize": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
@@ -42,6 +42,7 @@ SIGNATURES = {
     "d3d_resize_bilinear": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3_co8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv3d_k3_c8_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2_co8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv1x1_upskip": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],

@@ -169,7 +169,7 @@ class InferDepthNet(nn.Module):
         else:  # adamvs.py:502, once per stage instead of once per plane
             weights = ops.resize_bilinear(conf_in, h, w)
 
-        sim = ops.weighted_corr(feats, p34, weights, dv)  # [C,D,h,w]
+        sim = ops.weighted_corr(feats, p34, weights, dv, plane_major=True)  # [D,C,h,w]: plane d is one contiguous block
         H, W = (2 * h, 2 * w) if self.in_up else (h, w)
         s1 = torch.zeros((8, h, w), dtype=torch.float32, device=dev)
         s2 = torch.zeros((16, h // 2, w // 2), dtype=torch.float32, device=dev)
@@ -177,9 +177,9 @@ class InferDepthNet(nn.Module):
         sum_d = torch.zeros_like(max_p)
         sum_p = torch.zeros_like(max_p)
         for d in range(D):
-            reg, s1, s2 = self.reg_fuse(sim[:, d].contiguous(), s1, s2)
+            reg, s1, s2 = self.reg_fuse(sim[d], s1, s2)
             dplane = dv[d].reshape(1, 1) if dv.dim() == 1 else dv[d]
-            ops.online_regress_update(reg[0], dplane.contiguous(), max_p, sum_d, sum_p)
+            ops.online_regress_update(reg[0], dplane, max_p, sum_d, sum_p)
         depth, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
         return depth, conf, weights, pair_results
 

@@ -1,0 +1,247 @@
+// 3x3x3 stride-1 convolution with EIGHT output channels on the bf16 matrix cores of gfx950 (v_mfma_f32_16x16x32_bf16):
+// conv0 of every CostRegNet (cas_mvsnet.py:84 ConvBnReLU3D(C_in, 8), module.py:297-304) on the full stage volumes --
+// 32 -> 8 at [48,688,464], 16 -> 8 at [32,1376,928], 8 -> 8 at [8,2752,1856] -- the layers that carry most of a
+// CasMVSNet view's activation traffic.  BASELINE config 3 asks for bf16 operands with fp32 accumulation.
+//
+// Why its own kernel: with 8 output channels the GEMM is [pixels] x [27 * C_in] x [8] -- the matrix cores finish it in a
+// fraction of the time HBM needs to stream the volume once (8 -> 8 at stage 3: 141 GFLOP, 2.6 GB), so everything is
+// arranged around reading each input plane ONCE and writing each output plane ONCE:
+//   * A workgroup (8 waves) owns a 64 x 8 tile of (x, y) and walks z.  Input plane z is staged once (fp32 planar
+//     [C_in][z][y][x] -> bf16 channel-last cells, RNE) and feeds the three output planes z-1, z, z+1 through the k_z
+//     slices of the weights; three accumulator sets rotate, a plane is finished after its third input plane.
+//   * GEMM orientation: M = 16 consecutive pixels of a row, N = 16 = the 8 output channels (upper half zero),
+//     K = (k_y, k_x, c_in) in blocks of 32.  An A operand is ONE ds_read_b128 per lane: 8 consecutive channels of the
+//     pixel (m + k_x, y + k_y) -- the im2col matrix is never materialised.  The B operands (weights, packed by the host in
+//     exactly the lane order of the instruction) stay in registers (C_in <= 16) or LDS (C_in = 32).
+//   * One wave = one row of the tile = four 16-pixel groups; D[m][n] leaves as 16-byte stores of 4 consecutive pixels
+//     per (lane, channel) after the folded-BN affine, ReLU and skip.
+//   * The next plane's global loads are issued before the MFMA sweep of the current one and written to the other LDS
+//     buffer after it: one barrier per plane.
+#include "common.h"
+
+namespace d3d {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int TX = 64, TY = 8;             // output tile (x, y) of a workgroup
+constexpr int PX = TX + 2, PY = TY + 2;    // staged patch with the 1-pixel halo
+constexpr int NT = 64 * TY;                // one wave per tile row
+
+struct C8Params {
+    const float* in;      // [CI, D, H, W]
+    const u4* wpk;        // [3 (kz)][NKB][64 lanes] 16-byte B fragments (bf16 pairs), host-packed
+    const float* scale;   // [8] or null
+    const float* shift;   // [8] or null
+    const float* skip;    // [8, D, H, W] or null (added after the activation)
+    float* out;           // [8, D, H, W]
+    int D, H, W;
+    int relu;
+    int zper;             // output planes per workgroup along z
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+// waves per SIMD the register budget is sized for: two workgroups per CU (the second one's loads and stores fly while the
+// first one sweeps) where the staging registers allow it
+template <int CI>
+__global__ __launch_bounds__(NT, CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+    constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5)
+    constexpr int G = CI / 8;                          // 8-channel groups per pixel
+    constexpr int PATCH = PX * PY * CS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const int z0 = blockIdx.z * p.zper, z1 = min(z0 + p.zper, p.D);
+    const int D = p.D, H = p.H, W = p.W;
+    const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
+
+    // ---- weights: resident in LDS (a K block's three k_z fragments are read once per wave and plane and reused by the
+    //      four pixel groups; keeping all 3 * NKB fragments in registers would cost the second workgroup per CU) -------
+    for (int i = tid; i < 3 * NKB * 64; i += NT) wlds[i] = p.wpk[i];
+
+    // ---- per-lane A offsets: K index k = 32 kb + 8 (lane >> 4) + j  ->  tap t = k / CI, channel k % CI ----------
+    // (recomputed per use from an opaque copy of the lane's K group: NKB loop-invariant registers would cost the second
+    //  workgroup per CU at C_in = 16)
+    auto a_offset = [&](int kb, int kgroup) {
+        const int k0 = 32 * kb + 8 * kgroup;
+        const int t = k0 / CI, c = k0 % CI;
+        const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
+        return (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
+    };
+    const int abase = (wave * PX + (lane & 15)) * CS;   // pixel (m, row) of the patch: + mg * 16 * CS per pixel group
+
+    // ---- staging: task = (patch pixel, 8-channel group) ------------------------------------------------------
+    // The loads of the next plane are issued in two halves around the two halves of the MFMA sweep, so that only half of
+    // them sit in registers at a time (C_in = 32: 6 rounds of 8 floats per thread).
+    constexpr int NTASK = PX * PY * G;
+    constexpr int ROUNDS = (NTASK + NT - 1) / NT;
+    // (measured at the cascade shapes: C_in = 32 1.18 ms split vs 2.37 ms unsplit; C_in = 16 1.52 ms unsplit at one workgroup
+    //  per CU vs 2.1-2.5 ms split or at two workgroups per CU; C_in = 8 0.76 ms at two workgroups per CU vs 1.54 ms at one)
+    constexpr int RH = CI > 16 ? (ROUNDS + 1) / 2 : ROUNDS;   // rounds in the first half
+    float stg[RH][8];
+    auto issue = [&](int zi, int r0, int r1) {   // global loads of input plane zi, rounds [r0, r1), into registers (zeros outside the volume)
+        const bool zin = zi >= 0 && zi < D;
+#pragma unroll
+        for (int rr = 0; rr < RH; ++rr) {
+            const int r = r0 + rr;
+            if (r >= r1) break;
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PX, px = pix - py * PX;
+            const int gx = x0 + px - 1, gy = y0 + py - 1;
+            const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const float* __restrict__ src = p.in + (size_t)(8 * g) * vol + (size_t)(ok ? zi : 0) * plane + (ok ? (size_t)gy * W + gx : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * vol];
+                stg[rr][k] = ok ? v : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](unsigned char* dst, int r0, int r1) {   // registers -> bf16 cells
+#pragma unroll
+        for (int rr = 0; rr < RH; ++rr) {
+            const int r = r0 + rr;
+            if (r >= r1) break;
+            const int task = tid + r * NT;
+            if (task < NTASK) {
+                const int pix = task / G, g = task - pix * G;
+                u4 v = {pack_bf16(stg[rr][0], stg[rr][1]), pack_bf16(stg[rr][2], stg[rr][3]), pack_bf16(stg[rr][4], stg[rr][5]),
+                        pack_bf16(stg[rr][6], stg[rr][7])};
+                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+            }
+        }
+    };
+
+    f4 acc[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mg = 0; mg < 4; ++mg) acc[s][mg] = (f4){0, 0, 0, 0};
+
+    const int co = lane & 15;
+    const float sc = (co < 8 && p.scale) ? p.scale[co] : 1.0f;
+    const float sh = (co < 8 && p.shift) ? p.shift[co] : 0.0f;
+    const int oy = y0 + wave;
+
+    auto store_plane = [&](int zo, f4 (&a)[4]) {   // epilogue of a finished output plane
+        if (co < 8 && oy < H && zo >= z0 && zo < z1) {
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+                const int ox = x0 + mg * 16 + (lane >> 4) * 4;   // D layout: row (pixel) = (lane >> 4) * 4 + register
+                if (ox < W) {                                     // W % 4 == 0: a quad is inside or outside as a whole
+                    const size_t o = (size_t)co * vol + (size_t)zo * plane + (size_t)oy * W + ox;
+                    f4 v = a[mg] * sc + sh;
+                    if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                    if (p.skip) v += *reinterpret_cast<const f4*>(p.skip + o);
+                    *reinterpret_cast<f4*>(p.out + o) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int mg = 0; mg < 4; ++mg) a[mg] = (f4){0, 0, 0, 0};
+    };
+
+    // input plane zi feeds output planes zi+1 (k_z = 0), zi (k_z = 1), zi-1 (k_z = 2); slot of output plane zo = phase of zo
+    auto sweep = [&](const unsigned char* buf, f4 (&up)[4], f4 (&mid)[4], f4 (&down)[4], int kb0, int kb1) {
+        int kgroup = lane >> 4;
+        asm volatile("" : "+v"(kgroup));   // keeps the offsets out of long-lived registers
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb < kb0 || kb >= kb1) continue;
+            const int aoffk = a_offset(kb, kgroup);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, wlds[(0 * NKB + kb) * 64 + lane]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, wlds[(1 * NKB + kb) * 64 + lane]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, wlds[(2 * NKB + kb) * 64 + lane]);
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                up[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, up[mg], 0, 0, 0);
+                mid[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, mid[mg], 0, 0, 0);
+                down[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, down[mg], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- z walk: input planes z0-1 .. z1 ----------------------------------------------------------------------
+    issue(z0 - 1, 0, RH);
+    commit(smem, 0, RH);
+    if (ROUNDS > RH) {
+        issue(z0 - 1, RH, ROUNDS);
+        commit(smem, RH, ROUNDS);
+    }
+    __syncthreads();
+    int cur = 0;
+    auto step = [&](int zi, f4 (&up)[4], f4 (&mid)[4], f4 (&down)[4]) {   // up: zi+1, mid: zi, down: zi-1
+        const bool more = zi + 1 <= z1, live = zi >= 0 && zi < D;
+        constexpr int KH = (NKB + 1) / 2;
+        if (more) issue(zi + 1, 0, RH);                // the next plane's loads fly during the MFMA sweep
+        if (live) sweep(smem + cur * PATCH, up, mid, down, 0, KH);
+        if (more) commit(smem + (cur ^ 1) * PATCH, 0, RH);
+        if (more && ROUNDS > RH) issue(zi + 1, RH, ROUNDS);
+        if (live) sweep(smem + cur * PATCH, up, mid, down, KH, NKB);
+        store_plane(zi - 1, down);                     // complete: it has seen input planes zi-2, zi-1, zi
+        if (more && ROUNDS > RH) commit(smem + (cur ^ 1) * PATCH, RH, ROUNDS);
+        __syncthreads();
+        cur ^= 1;
+    };
+    for (int zi = z0 - 1; zi <= z1; zi += 3) {
+        step(zi, acc[1], acc[0], acc[2]);
+        if (zi + 1 <= z1) step(zi + 1, acc[2], acc[1], acc[0]);
+        if (zi + 2 <= z1) step(zi + 2, acc[0], acc[2], acc[1]);
+    }
+}
+
+template <int CI>
+static int launch(const C8Params& p, hipStream_t stream) {
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * PX * PY * CS + 3 * NKB * 64 * 16;
+    auto kern = conv3d_c8_bf16_kernel<CI>;
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
+    C8Params q = p;
+    const int gx = ceil_div(p.W, TX), gy = ceil_div(p.H, TY);
+    int nz = 1;   // enough workgroups for 256 CUs; every z segment re-reads two halo planes
+    while ((long)gx * gy * nz < 1024 && p.D / (nz * 2) >= 4) nz *= 2;
+    q.zper = ceil_div(p.D, nz);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(p.D, q.zper)), dim3(NT), lds, stream, q);
+    D3D_LAUNCH_CHECK("conv3d_c8_bf16_kernel launch");
+    return D3D_OK;
+}
+
+}  // namespace
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int D, int H, int W, float* out,
+                                     d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    if ((Ci != 8 && Ci != 16 && Ci != 32) || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_c8_bf16: C_in = %d (8 | 16 | 32), W = %d (multiple of 4) not taken", Ci, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    C8Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.relu = relu;
+    switch (Ci) {
+        case 8: return launch<8>(p, (hipStream_t)stream);
+        case 16: return launch<16>(p, (hipStream_t)stream);
+        default: return launch<32>(p, (hipStream_t)stream);
+    }
+}

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
                     } else {
                         o = s[c];
                     }
-                    stf(reinterpret_cast<T*>(p.out) + ((size_t)(c0 + c) * D + d) * plane + pix, o);
+                    stf(reinterpret_cast<T*>(p.out) + (p.plane_major ? (size_t)d * C + (c0 + c) : (size_t)(c0 + c) * D + d) * plane + pix, o);
                 }
             }
         }
@@ -440,13 +440,15 @@ int d3d_variance_volume_f16(const void* const* feats, const float* proj34, const
 }
 
 int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
-                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, void* workspace,
+                      int depth_mode, int n_views, int C, int D, int h, int w, int plane_major, float* out, void* workspace,
                       size_t workspace_bytes, d3d_stream_t stream) {
     SweepParams p = {};
     D3D_REQUIRE(weights, "null weights");
+    D3D_REQUIRE(plane_major == 0 || plane_major == 1, "bad plane_major %d", plane_major);
     int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes);
     if (rc) return rc;
     p.weights = weights;
+    p.plane_major = plane_major;
     return sweep_dispatch(MODE_WEIGHTED, p, (hipStream_t)stream);
 }
 

@@ -47,9 +47,15 @@ namespace {
 constexpr int TW = 32;          // patch width  (one 128-byte output row segment per lane-row)
 constexpr int TH = 4;           // patch height
 constexpr int NPIXW = 2;        // pixel waves (2 patch rows each)
-constexpr int NSUB = 4;         // depth sub-ranges
+#ifndef D3D_NSUB
+#define D3D_NSUB 4
+#endif
+#ifndef D3D_NLOADW
+#define D3D_NLOADW 4
+#endif
+constexpr int NSUB = D3D_NSUB;  // depth sub-ranges
 constexpr int NCOMP = NPIXW * NSUB;  // compute waves
-constexpr int NLOADW = 4;       // loader waves: stage the next step's window delta into the rings
+constexpr int NLOADW = D3D_NLOADW;  // loader waves: stage the next step's window delta into the rings
 constexpr int NWAVES = NCOMP + NLOADW;  // 12 waves: 3 per SIMD, 168-VGPR budget
 constexpr int THREADS = 64 * NWAVES;
 constexpr int DSEG_MAX = 128;   // planes per workgroup segment upper bound (launch_one never asks for more)
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         rden = 1.0f / den;
     }
     const float invV = 1.0f / (float)(p.n_src + 1);
-    const size_t cstride_b = (size_t)D * plane * sizeof(T);
+    const size_t cstride_b = (p.plane_major ? plane : (size_t)D * plane) * sizeof(T);   // bytes between channels
 
     // all CH/4.. channels of one quad: accumulators -> output values -> stores
     auto finalize_store = [&](const f4& s, const f4& qq, unsigned long long& ob) {
@@ -929,7 +935,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             } else {
                 dv = lds[L::PMIN + dl_];
             }
-            unsigned long long ob = uniform64(reinterpret_cast<T*>(p.out) + ((size_t)c0 * D + d) * plane);  // scalar base, once per plane
+            unsigned long long ob = uniform64(reinterpret_cast<T*>(p.out) + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);  // scalar base, once per plane
             float pair_acc = 0.0f;
             if (!valid) continue;  // one EXEC region per plane instead of one branch per store
 
@@ -1075,6 +1081,12 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
 #ifdef D3D_X_ADDR  // timing experiment (results wrong): conflict-free tap addresses (16 consecutive ring positions per lane group)
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
+#if D3D_X_ADDR == 2   // keep the real address computation alive (same VALU work), then discard it
+                    asm volatile("" : : "v"(t[i].a0), "v"(t[i].a1));
+#endif
+#if D3D_X_ADDR == 3   // real addresses, but all lanes forced inside the ring (no zero-cell reads): add 0 through an opaque register
+                    { int z = 0; asm volatile("" : "+v"(z)); t[i].a0 += z; t[i].a1 += z; continue; }
+#endif
                     t[i].a0 = rbase[i] * 4 + ((lane & 31) + (lane >> 5) * (RW[i] + 1)) * (STRIDE * 4);
                     t[i].a1 = t[i].a0 + (RW[i] + 1) * (STRIDE * 4);
                 }

@@ -20,6 +20,7 @@ struct SweepParams {
     int depth_mode;
     int d_chunk;
     int elem_bytes;                     // 4 (fp32 tensors) | 2 (fp16 storage, fp32 arithmetic)
+    int plane_major;                    // 0: out [C,D,h,w] | 1: out [D,C,h,w] (one contiguous [C,h,w] slice per plane)
 };
 
 }  // namespace d3d

@@ -166,18 +166,18 @@ def variance_volume(feats, proj34, depth, out=None):
     return out
 
 
-def weighted_corr(feats, proj34, weights, depth, out=None):
-    """adamvs.py:492-509. weights [V-1,h,w] -> [C,D,h,w]."""
+def weighted_corr(feats, proj34, weights, depth, out=None, plane_major=False):
+    """adamvs.py:492-509. weights [V-1,h,w] -> [C,D,h,w], or [D,C,h,w] with plane_major=True (plane d contiguous)."""
     C, h, w = _check_feats(feats, proj34)
     if tuple(weights.shape) != (len(feats) - 1, h, w):
         raise ValueError("weights must be [%d,%d,%d]" % (len(feats) - 1, h, w))
     dp, mode, D = _depth(depth, h, w)
     if out is None:
-        out = torch.empty((C, D, h, w), dtype=torch.float32, device=feats[0].device)
+        out = torch.empty((D, C, h, w) if plane_major else (C, D, h, w), dtype=torch.float32, device=feats[0].device)
     arr = _ptr_array(feats, "feats")
     ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
     rc = _lib.load().d3d_weighted_corr(arr, _chk(proj34, "proj34"), _chk(weights, "weights", 3), dp, mode,
-                                       len(feats), C, D, h, w, _chk(out, "out", 4), wp, wn, _stream())
+                                       len(feats), C, D, h, w, int(bool(plane_major)), _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_weighted_corr")
     return out
 
@@ -269,6 +269,20 @@ def resize_bilinear(x, H, W):
     return out
 
 
+def _pack_c8_bf16(w):
+    """[8,Ci,3,3,3] -> the B operands of v_mfma_f32_16x16x32_bf16 for d3d_conv3d_k3_c8_bf16: [kz][K block][lane][8] bf16
+    with K = (ky, kx, ci) padded to a multiple of 32 and the 8 output channels in columns 0..7 of 16 (rest zero);
+    lane l holds column l & 15, rows 8 * (l >> 4) .. + 7 of its block.  Returned as int16 bits."""
+    Co, Ci = w.shape[0], w.shape[1]
+    K = 9 * Ci
+    nkb = (K + 31) // 32
+    b = torch.zeros((3, nkb * 32, 16), dtype=torch.float32, device=w.device)
+    # w[n, ci, kz, ky, kx] -> b[kz, (ky*3+kx)*Ci + ci, n]
+    b[:, :K, :Co] = w.permute(2, 3, 4, 1, 0).reshape(3, K, Co)
+    b = b.reshape(3, nkb, 4, 8, 16).permute(0, 1, 2, 4, 3)      # [kz][kb][kgroup][n][j]
+    return b.reshape(3, nkb, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
 def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1):
     """x [Ci,D,H,W], weight [Co,Ci,3,3,3] -> [Co,Do,Ho,Wo] with folded-BN affine, ReLU, skip (after ReLU)."""
     Ci, D, H, W = x.shape
@@ -289,6 +303,19 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
                                            _opt(skip, "skip"), int(relu), Ci, D, H, W, _chk(out, "out"), _stream())
         _lib.check(rc, "d3d_conv3d_k3_co8")
         return out
+    if Co == 8 and stride == 1 and Ci in (8, 16, 32) and W % 4 == 0 and _use_mfma() and conv_precision() == "bf16" \
+            and _os.environ.get("D3D_CONV_C8", "1") != "0":
+        # conv0 of every CostRegNet with bf16 operands: z-streaming matrix-core kernel (each plane read once)
+        wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
+        out = torch.empty((8, D, H, W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_conv3d_k3_c8_bf16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                               _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, D, H, W,
+                                               _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_conv3d_k3_c8_bf16")
+            return out
     co1 = Co == 1 and stride == 1 and Ci == 8 and _os.environ.get("D3D_CONV_CO1", "1") != "0"
     if _use_mfma() and Co <= 64 and not co1:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)

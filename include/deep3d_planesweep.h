@@ -136,10 +136,12 @@ int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, 
 /*
  * adamvs.py:492-509 -- visibility-weighted correlation:
  *     sim[c,d] = SUM_i (warp_i[c,d] * ref[c]) * vw_i / (1e-5 + SUM_i vw_i)
- * weights: device [V-1,h,w] at this stage's resolution.  out [C,D,h,w].
+ * weights: device [V-1,h,w] at this stage's resolution.  out [C,D,h,w] (plane_major = 0, the reference's training-time
+ * layout adamvs.py:292-301) or [D,C,h,w] (plane_major = 1: the slice loop of adamvs.py:492-512 then reads plane d as one
+ * contiguous [C,h,w] block -- the reference never materialises the volume at inference).
  */
 int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
-                      int depth_mode, int n_views, int C, int D, int h, int w, float* out, void* workspace,
+                      int depth_mode, int n_views, int C, int D, int h, int w, int plane_major, float* out, void* workspace,
                       size_t workspace_bytes, d3d_stream_t stream);
 
 /*
@@ -203,6 +205,15 @@ int d3d_conv3d_k3(const float* in, const float* weight, const float* scale, cons
  * 7*D*H*W*4 bytes exceeds the 32-bit offsets of its staging loads. */
 int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale, const float* shift, const float* skip,
                       int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
+
+/* The same layer (3x3x3, stride 1, pad 1, C_out = 8; C_in = 8 | 16 | 32; W % 4 == 0) with bf16 OPERANDS on the matrix
+ * cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation; BASELINE config 3): tensors stay fp32 in memory, the input is
+ * rounded to bf16 (RNE) while it is staged, each input plane is read once and feeds three output planes.
+ * wpacked: the weight [8,Ci,3,3,3] rounded to bf16 and laid out in the instruction's B-operand order,
+ * [k_z][K block of 32][lane 0..63][8 values], K = (k_y, k_x, c_in) (ops.conv3d_k3 packs it once per parameter version). */
+int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                          int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
+
 
 /* module.py:307-314 Deconv3d (+BN+ReLU) / cas_mvsnet.py:103,118 for C_out = 8 (conv11 of CostRegNet: 16 -> 8, then the
  * skip add) on the fp32 vector units, streaming the INPUT volume through LDS: k = 3, stride 2, pad 1, output_pad 1;

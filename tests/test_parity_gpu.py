@@ -176,6 +176,9 @@ def test_aggregation_vs_oracle(ops, oracle, path, case):
 
     vw = rng.uniform(0.02, 1.0, (V - 1, h, w)).astype(np.float32)
     wc = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(fd, p34, dev(vw), dd)), path)
+    # plane-major output [D,C,h,w] (what the slice loop of the AdaMVS driver reads): the same values, transposed
+    wc_pm = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(fd, p34, dev(vw), dd, plane_major=True)), path)
+    assert np.array_equal(wc_pm.transpose(1, 0, 2, 3), wc)
     want = oracle.weighted_corr(feats[0], feats[1:], p34_host, vw, depth)
     assert rel_l1(wc, want) <= REL_VOLUME
 
@@ -846,3 +849,34 @@ def test_homo_warp_double_golden_and_oracle(ops, oracle):
         assert np.abs(got - want).max() <= 2e-6, i
     with pytest.raises(TypeError):                                           # fp32 matrices: the reference raises too
         ops.homo_warp_double(dev(src), dev(np.eye(4)), dev(np.eye(4)), dev(depth))
+
+
+@pytest.mark.parametrize("Ci,D,H,W", [(8, 1, 3, 4), (8, 5, 9, 68), (16, 8, 37, 132), (32, 3, 4, 64), (16, 11, 20, 60), (8, 19, 6, 300),
+                                      (32, 13, 21, 128), (8, 40, 16, 64)])
+def test_conv3d_c8_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, D, H, W):
+    """conv0 of CostRegNet (cas_mvsnet.py:84) with bf16 operands on d3d_conv3d_k3_c8_bf16 (v_mfma_f32_16x16x32_bf16,
+    z-streaming): equals the fp32 oracle on operands pre-rounded to bf16 (RNE) to fp32 summation-order accuracy, with
+    the folded-BN affine, ReLU and skip; shapes cover ragged tiles, single planes and the z segmentation."""
+    rng = np.random.default_rng(Ci * 1000 + W + D)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((8, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    sh = rng.standard_normal(8).astype(np.float32)
+    sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.delenv("D3D_CONV_C8", raising=False)
+    ops.set_conv_precision("bf16")
+    try:
+        got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
+        plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
+        monkeypatch.setenv("D3D_CONV_C8", "0")                       # the round-1 bf16 stream kernel, same operands
+        other = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
+    finally:
+        ops.set_conv_precision(None)
+    ref = oracle.conv3d_k3(_bf16_round(x), _bf16_round(w), None)
+    want = np.maximum(ref * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(plain - ref).max() <= tol
+    assert np.abs(got - want).max() <= 2 * tol
+    assert np.abs(plain - other).max() <= 2 * tol
+    assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() > 1e-4  # it really is the reduced-precision path
