@@ -1,0 +1,250 @@
+// nn.ConvTranspose3d(k = 3, stride 2, pad 1, output_pad 1) + folded BN + ReLU + skip -- the three decoder layers of every
+// CostRegNet (cas_mvsnet.py:97-103,116-118: 64 -> 32, 32 -> 16, 16 -> 8; module.py:307-314 Deconv3d) -- on the bf16 matrix
+// cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation), z-streaming like conv_c8.hip.  BASELINE config 3 (bf16 operands).
+//
+// Output voxel o = 2 i + p per dimension (p = parity): an even coordinate takes kernel tap k = 1 of input i; an odd one
+// takes k = 2 of input i and k = 0 of input i + 1.  So the layer is eight small dense convolutions (one per output
+// parity, 1 .. 8 taps) over the SAME input, and nothing is multiplied by an inserted zero:
+//   * a workgroup (8 waves) owns a 32 x 8 tile of INPUT pixels (= 64 x 16 outputs per plane) and walks the OUTPUT planes;
+//     an even plane needs input plane z/2, an odd one planes (z-1)/2 and (z+1)/2: two staged planes are resident in LDS
+//     (fp32 planar -> bf16 channel-last cells, RNE), the next one is loaded while an even plane is computed;
+//   * per output plane and wave (= input row): for each row parity both column parities are accumulated (M = 16 input
+//     pixels, N = 16 output channels, K = taps x C_in in blocks of 32: an A operand is one ds_read_b128 of 8 channels of
+//     the cell (x + dx, y + dy) of plane z + dz), then interleaved in registers so that a lane stores 8 consecutive
+//     output pixels (two 16-byte stores; the skip tensor is read the same way);
+//   * the weights of all 27 taps sit in LDS, packed by the host per parity class in the B-operand lane order.
+#include "common.h"
+
+#include <type_traits>
+
+namespace d3d {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int TYI = 8;   // input rows per workgroup = waves
+
+struct T2Params {
+    const float* in;     // [CI, D, H, W]
+    const u4* wpk;       // per parity class (pz, py, px): [K blocks][N tiles][64 lanes] 16-byte B fragments
+    const float* scale;  // [CO] or null
+    const float* shift;  // [CO] or null
+    const float* skip;   // [CO, 2D, 2H, 2W] or null (added after the activation)
+    float* out;          // [CO, 2D, 2H, 2W]
+    int D, H, W, CO;
+    int relu;
+    int ozper;           // output planes per workgroup (even)
+};
+
+__device__ __forceinline__ unsigned pack_bf16_t2(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+constexpr int ntaps(int pz, int py, int px) { return (1 + pz) * (1 + py) * (1 + px); }
+constexpr int nkb(int CI, int pz, int py, int px) { return (ntaps(pz, py, px) * CI + 31) / 32; }
+// first fragment (in units of NTN * 64 lanes) of parity class p = pz * 4 + py * 2 + px
+constexpr int frag_base(int CI, int p) {
+    int s = 0;
+    for (int q = 0; q < p; ++q) s += nkb(CI, q >> 2, (q >> 1) & 1, q & 1);
+    return s;
+}
+
+template <int CI, int NTN, int MG>   // NTN: 16-channel output tiles; MG: 16-pixel groups per wave (input tile width = 16 * MG)
+__global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
+    constexpr int NT = 64 * TYI;
+    constexpr int TXI = 16 * MG;
+    constexpr int PXI = TXI + 1, PYI = TYI + 1;         // input patch: one more column / row for the d = 1 taps
+    constexpr int CS = CI * 2 + 16;                     // bytes per cell: 3 | 5 | 9 sixteen-byte slots (odd)
+    constexpr int G = CI / 8;
+    constexpr int PATCH = PXI * PYI * CS;
+    constexpr int NFRAG = frag_base(CI, 8);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ix0 = blockIdx.x * TXI, iy0 = blockIdx.y * TYI;
+    const int D = p.D, H = p.H, W = p.W;
+    const int oz0 = blockIdx.z * p.ozper, oz1 = min(oz0 + p.ozper, 2 * D);
+    const size_t iplane = (size_t)H * W, ivol = (size_t)D * iplane;
+    const size_t oplane = 4 * iplane, ovol = (size_t)(2 * D) * oplane;
+    const int OW = 2 * W;
+
+    for (int i = tid; i < NFRAG * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+
+    constexpr int NTASK = PXI * PYI * G;
+    constexpr int ROUNDS = (NTASK + NT - 1) / NT;
+    float stg[ROUNDS][8];
+    auto issue = [&](int zi) {
+        const bool zin = zi >= 0 && zi < D;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PXI, px = pix - py * PXI;
+            const int gx = ix0 + px, gy = iy0 + py;
+            const bool ok = zin && task < NTASK && gx < W && gy < H;
+            const float* __restrict__ src = p.in + (size_t)(8 * g) * ivol + (size_t)(ok ? zi : 0) * iplane + (ok ? (size_t)gy * W + gx : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * ivol];
+                stg[r][k] = ok ? v : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            if (task < NTASK) {
+                const int pix = task / G, g = task - pix * G;
+                u4 v = {pack_bf16_t2(stg[r][0], stg[r][1]), pack_bf16_t2(stg[r][2], stg[r][3]), pack_bf16_t2(stg[r][4], stg[r][5]),
+                        pack_bf16_t2(stg[r][6], stg[r][7])};
+                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+            }
+        }
+    };
+
+    const int n = lane & 15;                       // output channel within a 16-channel tile
+    const int iy = iy0 + wave;                     // this wave's input row
+    const int abase = (wave * PXI + (lane & 15)) * CS;
+
+    // one (pz, py) row of outputs: both column parities, all pixel groups and channel tiles
+    auto row = [&](auto pzc, auto pyc, int oz, const unsigned char* b0, const unsigned char* b1) {
+        constexpr int PZ = decltype(pzc)::value, PY = decltype(pyc)::value;
+        f4 acc[2][MG][NTN];
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) acc[px][mg][nt] = (f4){0, 0, 0, 0};
+        int kgroup = lane >> 4;
+        asm volatile("" : "+v"(kgroup));
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int NKB = nkb(CI, PZ, PY, px);
+            const int FB = frag_base(CI, PZ * 4 + PY * 2 + px);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                // K index k = 32 kb + 8 kgroup + j  ->  tap t = k / CI over (dz, dy, dx), channel k % CI
+                const int k0 = 32 * kb + 8 * kgroup;
+                const int t = k0 / CI, c = k0 % CI;
+                const bool real = t < ntaps(PZ, PY, px);
+                const int dx = real ? t % (1 + px) : 0, dy = real ? (t / (1 + px)) % (1 + PY) : 0;
+                const int dz = real ? t / ((1 + px) * (1 + PY)) : 0;
+                const unsigned char* buf = dz ? b1 : b0;
+                const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
+                bf16x8 bfrag[NTN];
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) bfrag[nt] = __builtin_bit_cast(bf16x8, wlds[((FB + kb) * NTN + nt) * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt)
+                        acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[nt], acc[px][mg][nt], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: D row = input pixel (lane >> 4) * 4 + r, column = channel; outputs x = 2 ix + px interleaved
+        const int oy = 2 * iy + PY;
+        if (iy < H) {
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int co = nt * 16 + n;
+                if (co < p.CO) {
+                    const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) {
+                        const int ix = ix0 + mg * 16 + (lane >> 4) * 4;
+                        if (ix < W) {   // W need not be a multiple of 4: guard each pair below
+                            const size_t o = (size_t)co * ovol + (size_t)oz * oplane + (size_t)oy * OW + 2 * ix;
+                            f4 e = acc[0][mg][nt] * sc + sh, od = acc[1][mg][nt] * sc + sh;
+                            if (p.relu) { e = __builtin_elementwise_max(e, (f4){0, 0, 0, 0}); od = __builtin_elementwise_max(od, (f4){0, 0, 0, 0}); }
+                            f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
+                            if (ix + 3 < W && (W & 1) == 0) {   // 16-byte aligned rows
+                                if (p.skip) { lo += *reinterpret_cast<const f4*>(p.skip + o); hi += *reinterpret_cast<const f4*>(p.skip + o + 4); }
+                                *reinterpret_cast<f4*>(p.out + o) = lo;
+                                *reinterpret_cast<f4*>(p.out + o + 4) = hi;
+                            } else {   // ragged right edge
+                                const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                                for (int j = 0; j < 8; ++j)
+                                    if (ix + (j >> 1) < W) p.out[o + j] = v[j] + (p.skip ? p.skip[o + j] : 0.0f);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- walk the output planes: plane iz lives in buffer iz & 1 ------------------------------------------------
+    const int izf = oz0 >> 1;                     // oz0 is even
+    issue(izf);
+    commit(smem + (izf & 1) * PATCH);
+    __syncthreads();
+    for (int oz = oz0; oz < oz1; ++oz) {
+        const int iz = oz >> 1;
+        const unsigned char* b0 = smem + (iz & 1) * PATCH;
+        const unsigned char* b1 = smem + ((iz + 1) & 1) * PATCH;
+        if ((oz & 1) == 0) {
+            const bool more = oz + 1 < oz1;       // the odd plane that follows needs input plane iz + 1
+            if (more) issue(iz + 1);
+            row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, oz, b0, b1);
+            row(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, oz, b0, b1);
+            if (more) commit(smem + ((iz + 1) & 1) * PATCH);   // that buffer held plane iz - 1, last read by plane oz - 1
+        } else {
+            row(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, oz, b0, b1);
+            row(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, oz, b0, b1);
+        }
+        __syncthreads();
+    }
+}
+
+template <int CI, int NTN, int MG>
+static int launch(const T2Params& p, hipStream_t stream) {
+    constexpr int TXI = 16 * MG;
+    constexpr int CS = CI * 2 + 16;
+    const int lds = 2 * (TXI + 1) * (TYI + 1) * CS + frag_base(CI, 8) * NTN * 64 * 16;
+    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG>;
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
+    T2Params q = p;
+    const int gx = ceil_div(p.W, TXI), gy = ceil_div(p.H, TYI);
+    int nz = 1;
+    while ((long)gx * gy * nz < 1024 && p.D / (nz * 2) >= 2) nz *= 2;
+    q.ozper = 2 * ceil_div(p.D, nz);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(2 * p.D, q.ozper)), dim3(64 * TYI), lds, stream, q);
+    D3D_LAUNCH_CHECK("convt3d_zs_bf16_kernel launch");
+    return D3D_OK;
+}
+
+}  // namespace
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                                d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    const bool shape = (Ci == 16 && Co == 8) || (Ci == 16 && Co == 16) || (Ci == 32 && Co == 16) || (Ci == 64 && Co == 32);
+    if (!shape || ceil_div(H, TYI) > 65535 || 2 * D > 65535) {
+        set_error("d3d_convtranspose3d_k3s2_zs_bf16: %d -> %d channels not taken (16->8, 16->16, 32->16, 64->32)", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    T2Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.CO = Co; p.relu = relu;
+    hipStream_t st = (hipStream_t)stream;
+    if (Ci == 16) return launch<16, 1, 2>(p, st);
+    if (Ci == 32) return launch<32, 1, 2>(p, st);
+    return launch<64, 2, 1>(p, st);
+}

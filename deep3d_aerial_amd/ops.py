@@ -332,6 +332,30 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
     return out
 
 
+def _pack_t2_bf16(w):
+    """nn.ConvTranspose3d weight [Ci,Co,3,3,3] -> B operands of v_mfma_f32_16x16x32_bf16 for d3d_convtranspose3d_k3s2_zs_bf16.
+    Output parity class (pz,py,px), in the order pz*4 + py*2 + px: taps (dz,dy,dx), d <= p per dimension, enumerated dz-major;
+    an even output coordinate uses kernel index 1 (d = 0), an odd one index 2 (d = 0) and 0 (d = 1).  K = (tap, ci) padded to
+    a multiple of 32, output channels padded to a multiple of 16; per class [K block][N tile][lane][8] with lane l holding
+    column l & 15 and rows 8 * (l >> 4) .. + 7 of its block.  Returned as int16 bits (bf16)."""
+    Ci, Co = w.shape[0], w.shape[1]
+    ntn = (max(Co, 16) + 15) // 16
+    kmap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+    parts = []
+    for p in range(8):
+        pz, py, px = p >> 2, (p >> 1) & 1, p & 1
+        taps = [(dz, dy, dx) for dz in range(1 + pz) for dy in range(1 + py) for dx in range(1 + px)]
+        K = len(taps) * Ci
+        nkb = (K + 31) // 32
+        b = torch.zeros((nkb * 32, ntn * 16), dtype=torch.float32, device=w.device)
+        for t, (dz, dy, dx) in enumerate(taps):
+            b[t * Ci:(t + 1) * Ci, :Co] = w[:, :, kmap[(pz, dz)], kmap[(py, dy)], kmap[(px, dx)]]
+        # [kb][kgroup][j][nt][n] -> [kb][nt][kgroup][n][j]
+        b = b.reshape(nkb, 4, 8, ntn, 16).permute(0, 3, 1, 4, 2)
+        parts.append(b.reshape(nkb * ntn * 64, 8))
+    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
 def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True):
     """x [Ci,D,H,W], weight [Ci,Co,3,3,3] -> [Co,2D,2H,2W]."""
     Ci, D, H, W = x.shape
@@ -350,6 +374,19 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
                                                       _chk(out, "out"), _stream())
         _lib.check(rc, "d3d_convtranspose3d_k3s2_co8")
         return out
+    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() == "bf16" \
+            and _os.environ.get("D3D_CONV_T2", "1") != "0":
+        # decoder layers of CostRegNet with bf16 operands: eight per-parity dense convolutions on the matrix cores, z-streaming
+        wp = derived_weight(weight, "t2bf16", _pack_t2_bf16)
+        out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_convtranspose3d_k3s2_zs_bf16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                          _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
+                                                          _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_convtranspose3d_k3s2_zs_bf16")
+            return out
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=1 if relu else 0)
         if y is not None:

@@ -223,6 +223,18 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
                                  const float* skip, int relu, int Ci, int D, int H, int W, float* out,
                                  d3d_stream_t stream);
 
+/* module.py:307-314 Deconv3d (+BN+ReLU) / cas_mvsnet.py:97-103,116-118 with bf16 OPERANDS on the matrix cores
+ * (v_mfma_f32_16x16x32_bf16, fp32 accumulation; BASELINE config 3): k = 3, stride 2, pad 1, output_pad 1;
+ * in [Ci,D,H,W] fp32 -> out [Co,2D,2H,2W] fp32; skip (shape of out, may be NULL) added after the activation.  Taken channel
+ * pairs: 16->8, 16->16, 32->16, 64->32 (D3D_ERR_UNSUPPORTED otherwise).  The layer runs as eight dense per-parity
+ * convolutions over one staged input (no multiplications by inserted zeros), each input plane read once per tile.
+ * wpacked: the weight [Ci,Co,3,3,3] rounded to bf16, per output parity class in B-operand lane order
+ * (ops.convtranspose3d_k3s2 packs it once per parameter version). */
+int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                     d3d_stream_t stream);
+
+
 /* 3x3 stride-1 nn.Conv2d with C_out = 8 | 16 (the full- / half-resolution layers of the feature pyramids,
  * module.py:653-755, and the conv-GRU cells of the slice regularisers, module.py:5-51) on the fp32 vector units.
  * Input = cat(in0 [Ci0], in1 [Ci1]) along the channels (in1 may be NULL with Ci1 = 0; with two inputs Ci0 % 8 == 0).

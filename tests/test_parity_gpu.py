@@ -880,3 +880,31 @@ def test_conv3d_c8_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, D, H, W
     assert np.abs(got - want).max() <= 2 * tol
     assert np.abs(plain - other).max() <= 2 * tol
     assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() > 1e-4  # it really is the reduced-precision path
+
+
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 1, 1, 1), (16, 8, 2, 3, 5), (16, 8, 4, 9, 70), (32, 16, 3, 5, 64), (64, 32, 2, 9, 18),
+                                         (16, 16, 5, 20, 33), (32, 16, 9, 4, 130), (16, 8, 12, 17, 36)])
+def test_convtranspose3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, Co, D, H, W):
+    """Deconv3d + BN + ReLU + skip (conv7 / conv9 / conv11 of CostRegNet, cas_mvsnet.py:97-103,116-118) with bf16 operands on
+    d3d_convtranspose3d_k3s2_zs_bf16 (eight per-parity convolutions, z-streaming): equals the fp32 oracle on operands
+    pre-rounded to bf16; shapes cover ragged tiles, odd widths, single voxels and the z segmentation."""
+    rng = np.random.default_rng(Ci * 1000 + W + D)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    sk = rng.standard_normal((Co, 2 * D, 2 * H, 2 * W)).astype(np.float32)
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    monkeypatch.delenv("D3D_CONV_T2", raising=False)
+    ops.set_conv_precision("bf16")
+    try:
+        got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
+        plain = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
+    finally:
+        ops.set_conv_precision(None)
+    ref = oracle.convtranspose3d_k3s2(_bf16_round(x), _bf16_round(w), None)
+    want = np.maximum(ref * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    assert plain.shape == ref.shape
+    assert np.abs(plain - ref).max() <= tol
+    assert np.abs(got - want).max() <= 2 * tol
