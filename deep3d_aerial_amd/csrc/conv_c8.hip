@@ -41,6 +41,7 @@ struct C8Params {
     int D, H, W;
     int relu;
     int zper;             // output planes per workgroup along z
+    int CO;               // real output channels (<= 16 * NTN)
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -50,8 +51,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // waves per SIMD the register budget is sized for: two workgroups per CU (the second one's loads and stores fly while the
 // first one sweeps) where the staging registers allow it
-template <int CI>
-__global__ __launch_bounds__(NT, CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+template <int CI, int NTN>   // NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32)
+__global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5)
     constexpr int G = CI / 8;                          // 8-channel groups per pixel
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(NT, CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8P
 
     // ---- weights: resident in LDS (a K block's three k_z fragments are read once per wave and plane and reused by the
     //      four pixel groups; keeping all 3 * NKB fragments in registers would cost the second workgroup per CU) -------
-    for (int i = tid; i < 3 * NKB * 64; i += NT) wlds[i] = p.wpk[i];
+    for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
 
     // ---- per-lane A offsets: K index k = 32 kb + 8 (lane >> 4) + j  ->  tap t = k / CI, channel k % CI ----------
     // (recomputed per use from an opaque copy of the lane's K group: NKB loop-invariant registers would cost the second
@@ -123,52 +124,64 @@ __global__ __launch_bounds__(NT, CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8P
         }
     };
 
-    f4 acc[3][4];
+    constexpr int AW = 4 * NTN;   // accumulators per plane slot: [pixel group][channel tile]
+    f4 acc[3][AW];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int mg = 0; mg < 4; ++mg) acc[s][mg] = (f4){0, 0, 0, 0};
+        for (int i = 0; i < AW; ++i) acc[s][i] = (f4){0, 0, 0, 0};
 
-    const int co = lane & 15;
-    const float sc = (co < 8 && p.scale) ? p.scale[co] : 1.0f;
-    const float sh = (co < 8 && p.shift) ? p.shift[co] : 0.0f;
     const int oy = y0 + wave;
 
-    auto store_plane = [&](int zo, f4 (&a)[4]) {   // epilogue of a finished output plane
-        if (co < 8 && oy < H && zo >= z0 && zo < z1) {
+    auto store_plane = [&](int zo, f4 (&a)[AW]) {   // epilogue of a finished output plane
+        if (oy < H && zo >= z0 && zo < z1) {
 #pragma unroll
-            for (int mg = 0; mg < 4; ++mg) {
-                const int ox = x0 + mg * 16 + (lane >> 4) * 4;   // D layout: row (pixel) = (lane >> 4) * 4 + register
-                if (ox < W) {                                     // W % 4 == 0: a quad is inside or outside as a whole
-                    const size_t o = (size_t)co * vol + (size_t)zo * plane + (size_t)oy * W + ox;
-                    f4 v = a[mg] * sc + sh;
-                    if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                    if (p.skip) v += *reinterpret_cast<const f4*>(p.skip + o);
-                    *reinterpret_cast<f4*>(p.out + o) = v;
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int co = nt * 16 + (lane & 15);
+                if (co < p.CO) {
+                    const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+                    for (int mg = 0; mg < 4; ++mg) {
+                        const int ox = x0 + mg * 16 + (lane >> 4) * 4;   // D layout: row (pixel) = (lane >> 4) * 4 + register
+                        if (ox < W) {                                     // W % 4 == 0: a quad is inside or outside as a whole
+                            const size_t o = (size_t)co * vol + (size_t)zo * plane + (size_t)oy * W + ox;
+                            f4 v = a[mg * NTN + nt] * sc + sh;
+                            if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                            if (p.skip) v += *reinterpret_cast<const f4*>(p.skip + o);
+                            *reinterpret_cast<f4*>(p.out + o) = v;
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int mg = 0; mg < 4; ++mg) a[mg] = (f4){0, 0, 0, 0};
+        for (int i = 0; i < AW; ++i) a[i] = (f4){0, 0, 0, 0};
     };
 
     // input plane zi feeds output planes zi+1 (k_z = 0), zi (k_z = 1), zi-1 (k_z = 2); slot of output plane zo = phase of zo
-    auto sweep = [&](const unsigned char* buf, f4 (&up)[4], f4 (&mid)[4], f4 (&down)[4], int kb0, int kb1) {
+    auto sweep = [&](const unsigned char* buf, f4 (&up)[AW], f4 (&mid)[AW], f4 (&down)[AW], int kb0, int kb1) {
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));   // keeps the offsets out of long-lived registers
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb < kb0 || kb >= kb1) continue;
             const int aoffk = a_offset(kb, kgroup);
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, wlds[(0 * NKB + kb) * 64 + lane]);
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, wlds[(1 * NKB + kb) * 64 + lane]);
-            const bf16x8 b2 = __builtin_bit_cast(bf16x8, wlds[(2 * NKB + kb) * 64 + lane]);
+            bf16x8 b0[NTN], b1[NTN], b2[NTN];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                b0[nt] = __builtin_bit_cast(bf16x8, wlds[((0 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b1[nt] = __builtin_bit_cast(bf16x8, wlds[((1 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b2[nt] = __builtin_bit_cast(bf16x8, wlds[((2 * NKB + kb) * NTN + nt) * 64 + lane]);
+            }
 #pragma unroll
             for (int mg = 0; mg < 4; ++mg) {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
-                up[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, up[mg], 0, 0, 0);
-                mid[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, mid[mg], 0, 0, 0);
-                down[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, down[mg], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    up[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0[nt], up[mg * NTN + nt], 0, 0, 0);
+                    mid[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[nt], mid[mg * NTN + nt], 0, 0, 0);
+                    down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2[nt], down[mg * NTN + nt], 0, 0, 0);
+                }
             }
         }
     };
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(NT, CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8P
     }
     __syncthreads();
     int cur = 0;
-    auto step = [&](int zi, f4 (&up)[4], f4 (&mid)[4], f4 (&down)[4]) {   // up: zi+1, mid: zi, down: zi-1
+    auto step = [&](int zi, f4 (&up)[AW], f4 (&mid)[AW], f4 (&down)[AW]) {   // up: zi+1, mid: zi, down: zi-1
         const bool more = zi + 1 <= z1, live = zi >= 0 && zi < D;
         constexpr int KH = (NKB + 1) / 2;
         if (more) issue(zi + 1, 0, RH);                // the next plane's loads fly during the MFMA sweep
@@ -202,12 +215,12 @@ __global__ __launch_bounds__(NT, CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8P
     }
 }
 
-template <int CI>
+template <int CI, int NTN>
 static int launch(const C8Params& p, hipStream_t stream) {
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * PX * PY * CS + 3 * NKB * 64 * 16;
-    auto kern = conv3d_c8_bf16_kernel<CI>;
+    const int lds = 2 * PX * PY * CS + 3 * NKB * NTN * 64 * 16;
+    auto kern = conv3d_c8_bf16_kernel<CI, NTN>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -227,21 +240,30 @@ static int launch(const C8Params& p, hipStream_t stream) {
 
 using namespace d3d;
 
-extern "C" int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
-                                     const float* skip, int relu, int Ci, int D, int H, int W, float* out,
+extern "C" int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
-    if ((Ci != 8 && Ci != 16 && Ci != 32) || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
-        set_error("d3d_conv3d_k3_c8_bf16: C_in = %d (8 | 16 | 32), W = %d (multiple of 4) not taken", Ci, W);
+    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && Co >= 1 && (Co <= 16 || (Co == 32 && Ci == 32));
+    if (!shape || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_zs_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16, or 32 with C_in = 32), W = %d (multiple of 4) not taken", Ci, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
     C8Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
-    p.D = D; p.H = H; p.W = W; p.relu = relu;
+    p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
+    hipStream_t st = (hipStream_t)stream;
+    if (Co > 16) return launch<32, 2>(p, st);
     switch (Ci) {
-        case 8: return launch<8>(p, (hipStream_t)stream);
-        case 16: return launch<16>(p, (hipStream_t)stream);
-        default: return launch<32>(p, (hipStream_t)stream);
+        case 8: return launch<8, 1>(p, st);
+        case 16: return launch<16, 1>(p, st);
+        default: return launch<32, 1>(p, st);
     }
+}
+
+extern "C" int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int D, int H, int W, float* out,
+                                     d3d_stream_t stream) {
+    return d3d_conv3d_k3_zs_bf16(in, wpacked, scale, shift, skip, relu, Ci, 8, D, H, W, out, stream);
 }

@@ -276,11 +276,12 @@ def _pack_c8_bf16(w):
     Co, Ci = w.shape[0], w.shape[1]
     K = 9 * Ci
     nkb = (K + 31) // 32
-    b = torch.zeros((3, nkb * 32, 16), dtype=torch.float32, device=w.device)
+    ntn = (max(Co, 16) + 15) // 16
+    b = torch.zeros((3, nkb * 32, ntn * 16), dtype=torch.float32, device=w.device)
     # w[n, ci, kz, ky, kx] -> b[kz, (ky*3+kx)*Ci + ci, n]
     b[:, :K, :Co] = w.permute(2, 3, 4, 1, 0).reshape(3, K, Co)
-    b = b.reshape(3, nkb, 4, 8, 16).permute(0, 1, 2, 4, 3)      # [kz][kb][kgroup][n][j]
-    return b.reshape(3, nkb, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+    b = b.reshape(3, nkb, 4, 8, ntn, 16).permute(0, 1, 4, 2, 5, 3)      # [kz][kb][ntile][kgroup][n][j]
+    return b.reshape(3, nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
 def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1):
@@ -303,18 +304,18 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
                                            _opt(skip, "skip"), int(relu), Ci, D, H, W, _chk(out, "out"), _stream())
         _lib.check(rc, "d3d_conv3d_k3_co8")
         return out
-    if Co == 8 and stride == 1 and Ci in (8, 16, 32) and W % 4 == 0 and _use_mfma() and conv_precision() == "bf16" \
-            and _os.environ.get("D3D_CONV_C8", "1") != "0":
-        # conv0 of every CostRegNet with bf16 operands: z-streaming matrix-core kernel (each plane read once)
+    if stride == 1 and Ci in (8, 16, 32) and (Co in (8, 16) or (Co == 32 and Ci == 32)) and W % 4 == 0 and _use_mfma() \
+            and conv_precision() == "bf16" and _os.environ.get("D3D_CONV_C8", "1") != "0":
+        # conv0 / conv2 / conv4 of every CostRegNet with bf16 operands: z-streaming matrix-core kernel (each plane read once)
         wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
-        out = torch.empty((8, D, H, W), dtype=torch.float32, device=x.device)
+        out = torch.empty((Co, D, H, W), dtype=torch.float32, device=x.device)
         if skip is not None and skip.shape != out.shape:
             raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
-        rc = _lib.load().d3d_conv3d_k3_c8_bf16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
-                                               _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, D, H, W,
+        rc = _lib.load().d3d_conv3d_k3_zs_bf16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                               _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
                                                _chk(out, "out"), _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_conv3d_k3_c8_bf16")
+            _lib.check(rc, "d3d_conv3d_k3_zs_bf16")
             return out
     co1 = Co == 1 and stride == 1 and Ci == 8 and _os.environ.get("D3D_CONV_CO1", "1") != "0"
     if _use_mfma() and Co <= 64 and not co1:

@@ -213,6 +213,10 @@ int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale,
  * [k_z][K block of 32][lane 0..63][8 values], K = (k_y, k_x, c_in) (ops.conv3d_k3 packs it once per parameter version). */
 int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
+/* The same kernel for C_out <= 16 (C_in = 8 | 16 | 32) and 32 -> 32: conv2 / conv4 of CostRegNet (cas_mvsnet.py:87,90).
+ * wpacked: [k_z][K block][N tile of 16 channels][lane][8 values]. */
+int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                          int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
 
 
 /* module.py:307-314 Deconv3d (+BN+ReLU) / cas_mvsnet.py:103,118 for C_out = 8 (conv11 of CostRegNet: 16 -> 8, then the

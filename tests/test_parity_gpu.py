@@ -851,18 +851,20 @@ def test_homo_warp_double_golden_and_oracle(ops, oracle):
         ops.homo_warp_double(dev(src), dev(np.eye(4)), dev(np.eye(4)), dev(depth))
 
 
-@pytest.mark.parametrize("Ci,D,H,W", [(8, 1, 3, 4), (8, 5, 9, 68), (16, 8, 37, 132), (32, 3, 4, 64), (16, 11, 20, 60), (8, 19, 6, 300),
-                                      (32, 13, 21, 128), (8, 40, 16, 64)])
-def test_conv3d_c8_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, D, H, W):
-    """conv0 of CostRegNet (cas_mvsnet.py:84) with bf16 operands on d3d_conv3d_k3_c8_bf16 (v_mfma_f32_16x16x32_bf16,
-    z-streaming): equals the fp32 oracle on operands pre-rounded to bf16 (RNE) to fp32 summation-order accuracy, with
-    the folded-BN affine, ReLU and skip; shapes cover ragged tiles, single planes and the z segmentation."""
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 8, 1, 3, 4), (8, 8, 5, 9, 68), (16, 8, 8, 37, 132), (32, 8, 3, 4, 64), (16, 8, 11, 20, 60),
+                                         (8, 8, 19, 6, 300), (32, 8, 13, 21, 128), (8, 8, 40, 16, 64), (16, 16, 7, 19, 72),
+                                         (32, 32, 5, 11, 68), (16, 16, 1, 1, 4), (32, 32, 14, 8, 128), (8, 16, 3, 9, 20)])
+def test_conv3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, Co, D, H, W):
+    """conv0 / conv2 / conv4 of CostRegNet (cas_mvsnet.py:84,87,90) with bf16 operands on d3d_conv3d_k3_zs_bf16
+    (v_mfma_f32_16x16x32_bf16, z-streaming): equals the fp32 oracle on operands pre-rounded to bf16 (RNE) to fp32
+    summation-order accuracy, with the folded-BN affine, ReLU and skip; shapes cover ragged tiles, single planes, the z
+    segmentation and both output-tile counts."""
     rng = np.random.default_rng(Ci * 1000 + W + D)
     x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
-    w = (0.1 * rng.standard_normal((8, Ci, 3, 3, 3))).astype(np.float32)
-    sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
-    sh = rng.standard_normal(8).astype(np.float32)
-    sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    sk = rng.standard_normal((Co, D, H, W)).astype(np.float32)
     monkeypatch.setenv("D3D_CONV", "mfma")
     monkeypatch.delenv("D3D_CONV_C8", raising=False)
     ops.set_conv_precision("bf16")
@@ -878,7 +880,8 @@ def test_conv3d_c8_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, D, H, W
     tol = 3e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(plain - ref).max() <= tol
     assert np.abs(got - want).max() <= 2 * tol
-    assert np.abs(plain - other).max() <= 2 * tol
+    if Co <= 16:  # (the round-1 library has no bf16 kernel for 32 -> 32: it computes that layer in fp32)
+        assert np.abs(plain - other).max() <= 2 * tol
     assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() > 1e-4  # it really is the reduced-precision path
 
 
