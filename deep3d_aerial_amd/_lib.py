@@ -33,6 +33,7 @@ SIGNATURES = {
     "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_f16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_variance_volume_cl_bf16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_pair_corr_mean": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_softargmin_conf4": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
@@ -45,6 +46,11 @@ SIGNATURES = {
     "d3d_conv3d_k3_c8_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv3d_k3_cl_bf16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "d3d_conv3d_k3s2_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_convtranspose3d_k3s2_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "d3d_volume_planar_to_cl_bf16": [_vp, _i, _sz, _vp, _vp],
+    "d3d_volume_cl_bf16_to_planar": [_vp, _i, _sz, _vp, _vp],
     "d3d_convtranspose3d_k3s2_co8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv1x1_upskip": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],

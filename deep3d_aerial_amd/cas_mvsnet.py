@@ -30,6 +30,11 @@ class _Up3D(nn.Sequential):
         s, t = folded_bn(self[1])
         return ops.convtranspose3d_k3s2(x, self[0].weight, s, t, skip, relu=True)
 
+    def forward_cl(self, x, skip):  # channel-last bf16 volumes (ops.conv3d_k3_cl)
+        _no_train(self)
+        s, t = folded_bn(self[1])
+        return ops.convtranspose3d_k3s2_cl(x, self[0].weight, s, t, skip, relu=True)
+
 
 class CostRegNet(nn.Module):
     """cas_mvsnet.py:81-121.  forward(x [B,C,D,H,W]) -> [B,1,D,H,W]."""
@@ -48,10 +53,27 @@ class CostRegNet(nn.Module):
         self.conv11 = _Up3D(16, 8)
         self.prob = nn.Conv3d(8, 1, 3, stride=1, padding=1)
 
-    def forward_one(self, x):  # [C,D,H,W] -> [D,H,W]
-        D, H, W = x.shape[1:]
+    @staticmethod
+    def channel_last():
+        """bf16 mode with channel-last bf16 activations between the layers (ops.conv3d_k3_cl)."""
+        return ops.conv_precision() == "bf16" and ops.channel_last_enabled()
+
+    def forward_one(self, x):  # [C,D,H,W] fp32 (or channel-last bf16 [D,H,W,C] in bf16 mode) -> [D,H,W]
+        cl_in = x.dtype == torch.bfloat16
+        D, H, W = x.shape[:3] if cl_in else x.shape[1:]
         if D % 8 or H % 8 or W % 8:
-            raise ValueError("CostRegNet needs D,H,W divisible by 8 (got %s)" % (tuple(x.shape[1:]),))
+            raise ValueError("CostRegNet needs D,H,W divisible by 8 (got %s)" % ((D, H, W),))
+        if cl_in or (self.channel_last() and x.shape[0] % 8 == 0):
+            # bf16 mode (BASELINE config 3): every layer rounds its operands to bf16 anyway, so the activations travel
+            # between the layers as channel-last bf16 volumes (half the traffic, 16-byte staging loads)
+            c0 = self.conv0.forward_cl(x)
+            c2 = self.conv2.forward_cl(self.conv1.forward_cl(c0))
+            c4 = self.conv4.forward_cl(self.conv3.forward_cl(c2))
+            y = self.conv6.forward_cl(self.conv5.forward_cl(c4))
+            y = self.conv7.forward_cl(y, c4)
+            y = self.conv9.forward_cl(y, c2)
+            y = self.conv11.forward_cl(y, c0)
+            return ops.conv3d_k3_cl(y, self.prob.weight, None, self.prob.bias, None, relu=False, stride=1, out_cl=False)[0]
         c0 = self.conv0(x)
         c2 = self.conv2(self.conv1(c0))
         c4 = self.conv4(self.conv3(c2))
@@ -78,7 +100,11 @@ class DepthNet(nn.Module):
         for b in range(features[0].shape[0]):
             p34 = ops.compose_projections(proj_matrices[b].contiguous())
             dv = depth_values[b].contiguous()
-            var = ops.variance_volume([f[b].contiguous() for f in features], p34, dv)
+            fb = [f[b].contiguous() for f in features]
+            # bf16 mode: the volume leaves the sweep kernel in the form conv0 stages (same rounding, half the bytes)
+            cl = getattr(cost_regularization, "channel_last", None)
+            var = ops.variance_volume_cl(fb, p34, dv) if (cl is not None and cl() and fb[0].shape[0] % 8 == 0) \
+                else ops.variance_volume(fb, p34, dv)
             cost = cost_regularization.forward_one(var)
             d, c = ops.softargmin_conf4(cost, dv)
             depths.append(d)

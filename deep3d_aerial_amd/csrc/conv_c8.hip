@@ -31,13 +31,17 @@ constexpr int TX = 64, TY = 8;             // output tile (x, y) of a workgroup
 constexpr int PX = TX + 2, PY = TY + 2;    // staged patch with the 1-pixel halo
 constexpr int NT = 64 * TY;                // one wave per tile row
 
+// Activation formats.  PLANAR: fp32 [C][D][H][W] (what the cost-volume kernels write and the regression kernels read).
+// CL ("channel-last"): bf16 [D][H][W][C] -- the form the layers of a CostRegNet hand to each other in bf16 mode: the
+// operands are rounded to bf16 at staging anyway, so storing them rounded halves the activation traffic, and a staging
+// task becomes ONE 16-byte load of 8 channels instead of 8 loads from 8 planes plus four conversions.
 struct C8Params {
-    const float* in;      // [CI, D, H, W]
-    const u4* wpk;        // [3 (kz)][NKB][64 lanes] 16-byte B fragments (bf16 pairs), host-packed
-    const float* scale;   // [8] or null
-    const float* shift;   // [8] or null
-    const float* skip;    // [8, D, H, W] or null (added after the activation)
-    float* out;           // [8, D, H, W]
+    const void* in;       // PLANAR [CI, D, H, W] fp32 | CL [D, H, W, CI] bf16
+    const u4* wpk;        // [3 (kz)][NKB][N tiles][64 lanes] 16-byte B fragments (bf16 pairs), host-packed
+    const float* scale;   // [CO] or null
+    const float* shift;   // [CO] or null
+    const void* skip;     // in the OUTPUT's format, or null (added after the activation)
+    void* out;            // PLANAR [CO, D, H, W] fp32 | CL [D, H, W, CO] bf16
     int D, H, W;
     int relu;
     int zper;             // output planes per workgroup along z
@@ -51,7 +55,13 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 
 // waves per SIMD the register budget is sized for: two workgroups per CU (the second one's loads and stores fly while the
 // first one sweeps) where the staging registers allow it
-template <int CI, int NTN>   // NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32)
+__device__ __forceinline__ f4 unpack_bf16x4(uint2 u) {
+    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+
+// NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32); INCL / OUTCL: channel-last bf16 input / output
+template <int CI, int NTN, bool INCL, bool OUTCL>
 __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5)
@@ -88,8 +98,9 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
     // (measured at the cascade shapes: C_in = 32 1.18 ms split vs 2.37 ms unsplit; C_in = 16 1.52 ms unsplit at one workgroup
     //  per CU vs 2.1-2.5 ms split or at two workgroups per CU; C_in = 8 0.76 ms at two workgroups per CU vs 1.54 ms at one)
-    constexpr int RH = CI > 16 ? (ROUNDS + 1) / 2 : ROUNDS;   // rounds in the first half
-    float stg[RH][8];
+    constexpr int RH = (CI > 16 && !INCL) ? (ROUNDS + 1) / 2 : ROUNDS;   // rounds in the first half
+    float stg[INCL ? 1 : RH][8];
+    u4 stc[INCL ? RH : 1];
     auto issue = [&](int zi, int r0, int r1) {   // global loads of input plane zi, rounds [r0, r1), into registers (zeros outside the volume)
         const bool zin = zi >= 0 && zi < D;
 #pragma unroll
@@ -101,11 +112,19 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
             const int py = pix / PX, px = pix - py * PX;
             const int gx = x0 + px - 1, gy = y0 + py - 1;
             const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = p.in + (size_t)(8 * g) * vol + (size_t)(ok ? zi : 0) * plane + (ok ? (size_t)gy * W + gx : 0);
+            if constexpr (INCL) {
+                const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
+                    (ok ? (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16 : 0);
+                const u4 v = *reinterpret_cast<const u4*>(src);
+                stc[rr] = ok ? v : (u4){0, 0, 0, 0};
+            } else {
+                const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * vol + (size_t)(ok ? zi : 0) * plane +
+                    (ok ? (size_t)gy * W + gx : 0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * vol];
-                stg[rr][k] = ok ? v : 0.0f;
+                for (int k = 0; k < 8; ++k) {
+                    const float v = src[(size_t)k * vol];
+                    stg[rr][k] = ok ? v : 0.0f;
+                }
             }
         }
     };
@@ -117,8 +136,10 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
             const int task = tid + r * NT;
             if (task < NTASK) {
                 const int pix = task / G, g = task - pix * G;
-                u4 v = {pack_bf16(stg[rr][0], stg[rr][1]), pack_bf16(stg[rr][2], stg[rr][3]), pack_bf16(stg[rr][4], stg[rr][5]),
-                        pack_bf16(stg[rr][6], stg[rr][7])};
+                u4 v;
+                if constexpr (INCL) v = stc[rr];
+                else v = (u4){pack_bf16(stg[rr][0], stg[rr][1]), pack_bf16(stg[rr][2], stg[rr][3]), pack_bf16(stg[rr][4], stg[rr][5]),
+                              pack_bf16(stg[rr][6], stg[rr][7])};
                 *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
             }
         }
@@ -134,7 +155,34 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
     const int oy = y0 + wave;
 
     auto store_plane = [&](int zo, f4 (&a)[AW]) {   // epilogue of a finished output plane
-        if (oy < H && zo >= z0 && zo < z1) {
+        if constexpr (OUTCL) {
+            // operands swapped (weights as A): D row = channel (lane >> 4) * 4 + register, column = pixel lane & 15 -- a
+            // lane owns four consecutive channels of one pixel = one 8-byte store into the pixel's cell
+            if (oy < H && zo >= z0 && zo < z1) {
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    const int cb = nt * 16 + (lane >> 4) * 4;
+                    if (cb < p.CO) {   // C_out % 4 == 0
+                        const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+                        const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+                        for (int mg = 0; mg < 4; ++mg) {
+                            const int ox = x0 + mg * 16 + (lane & 15);
+                            if (ox < W) {
+                                const size_t o = (((size_t)zo * H + oy) * W + ox) * p.CO + cb;   // bf16 element index
+                                f4 v = a[mg * NTN + nt] * sc + sh;
+                                if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                                if (p.skip) v += unpack_bf16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                                const uint2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                                *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (oy < H && zo >= z0 && zo < z1) {
+            const float* __restrict__ skipf = static_cast<const float*>(p.skip);
+            float* __restrict__ outf = static_cast<float*>(p.out);
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
                 const int co = nt * 16 + (lane & 15);
@@ -147,8 +195,8 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
                             const size_t o = (size_t)co * vol + (size_t)zo * plane + (size_t)oy * W + ox;
                             f4 v = a[mg * NTN + nt] * sc + sh;
                             if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                            if (p.skip) v += *reinterpret_cast<const f4*>(p.skip + o);
-                            *reinterpret_cast<f4*>(p.out + o) = v;
+                            if (skipf) v += *reinterpret_cast<const f4*>(skipf + o);
+                            *reinterpret_cast<f4*>(outf + o) = v;
                         }
                     }
                 }
@@ -178,9 +226,16 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
                 const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) {
-                    up[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0[nt], up[mg * NTN + nt], 0, 0, 0);
-                    mid[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[nt], mid[mg * NTN + nt], 0, 0, 0);
-                    down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2[nt], down[mg * NTN + nt], 0, 0, 0);
+                    // (the A and B fragment layouts are the same, so D^T costs nothing: weights first = channel rows)
+                    if constexpr (OUTCL) {
+                        up[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[nt], a, up[mg * NTN + nt], 0, 0, 0);
+                        mid[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[nt], a, mid[mg * NTN + nt], 0, 0, 0);
+                        down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[nt], a, down[mg * NTN + nt], 0, 0, 0);
+                    } else {
+                        up[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0[nt], up[mg * NTN + nt], 0, 0, 0);
+                        mid[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[nt], mid[mg * NTN + nt], 0, 0, 0);
+                        down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2[nt], down[mg * NTN + nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -215,12 +270,12 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
     }
 }
 
-template <int CI, int NTN>
+template <int CI, int NTN, bool INCL, bool OUTCL>
 static int launch(const C8Params& p, hipStream_t stream) {
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
     const int lds = 2 * PX * PY * CS + 3 * NKB * NTN * 64 * 16;
-    auto kern = conv3d_c8_bf16_kernel<CI, NTN>;
+    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -240,30 +295,43 @@ static int launch(const C8Params& p, hipStream_t stream) {
 
 using namespace d3d;
 
-extern "C" int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
-                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+template <bool INCL, bool OUTCL>
+static int launch_fmt(const C8Params& p, int Ci, int Co, hipStream_t st) {
+    if (Co > 16) return launch<32, 2, INCL, OUTCL>(p, st);
+    switch (Ci) {
+        case 8: return launch<8, 1, INCL, OUTCL>(p, st);
+        case 16: return launch<16, 1, INCL, OUTCL>(p, st);
+        default: return launch<32, 1, INCL, OUTCL>(p, st);
+    }
+}
+
+extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+                                     const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out, int out_cl,
                                      d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && Co >= 1 && (Co <= 16 || (Co == 32 && Ci == 32));
-    if (!shape || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
-        set_error("d3d_conv3d_k3_zs_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16, or 32 with C_in = 32), W = %d (multiple of 4) not taken", Ci, Co, W);
+    if (!shape || (out_cl ? Co % 4 != 0 : W % 4 != 0) || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_cl_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16, or 32 with C_in = 32; a multiple of 4 for "
+                  "channel-last output), W = %d (a multiple of 4 for planar output) not taken", Ci, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
     C8Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
     hipStream_t st = (hipStream_t)stream;
-    if (Co > 16) return launch<32, 2>(p, st);
-    switch (Ci) {
-        case 8: return launch<8, 1>(p, st);
-        case 16: return launch<16, 1>(p, st);
-        default: return launch<32, 1>(p, st);
-    }
+    if (in_cl) return out_cl ? launch_fmt<true, true>(p, Ci, Co, st) : launch_fmt<true, false>(p, Ci, Co, st);
+    return out_cl ? launch_fmt<false, true>(p, Ci, Co, st) : launch_fmt<false, false>(p, Ci, Co, st);
+}
+
+extern "C" int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                     d3d_stream_t stream) {
+    return d3d_conv3d_k3_cl_bf16(in, 0, wpacked, scale, shift, skip, relu, Ci, Co, D, H, W, out, 0, stream);
 }
 
 extern "C" int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int D, int H, int W, float* out,
                                      d3d_stream_t stream) {
-    return d3d_conv3d_k3_zs_bf16(in, wpacked, scale, shift, skip, relu, Ci, 8, D, H, W, out, stream);
+    return d3d_conv3d_k3_cl_bf16(in, 0, wpacked, scale, shift, skip, relu, Ci, 8, D, H, W, out, 0, stream);
 }

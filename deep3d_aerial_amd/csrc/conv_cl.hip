@@ -1,0 +1,294 @@
+// Channel-last bf16 activations for the CostRegNet layers in bf16 mode (BASELINE config 3):
+//   * 3x3x3 STRIDE-2 convolution + folded BN + ReLU (conv1 / conv3 of CostRegNet, cas_mvsnet.py:86,89: 8 -> 16, 16 -> 32) on
+//     v_mfma_f32_16x16x32_bf16, z-streaming, channel-last bf16 in and out ([D][H][W][C], see conv_c8.hip);
+//   * the two format conversions (planar fp32 <-> channel-last bf16) for the layers that stay on the planar kernels
+//     (conv5 / conv6, 1/64 .. 1/512 of the voxels) and for tests.
+//
+// Stride-2 kernel.  Output (z, y, x) reads inputs (2z + k_z - 1, 2y + k_y - 1, 2x + k_x - 1):
+//   * a workgroup (8 waves) owns 32 x 8 OUTPUT pixels and walks the INPUT planes of its z segment, each staged once: an
+//     even plane 2a feeds output plane a through k_z = 1, an odd plane 2a + 1 feeds plane a (k_z = 2, which completes it)
+//     and plane a + 1 (k_z = 0): two accumulator sets alternate;
+//   * the staged patch (65 x 17 input pixels) keeps the even and the odd columns of a row in separate runs, so the 16
+//     pixels of an A operand (input columns 2m + k_x - 1) are 16 CONSECUTIVE cells: one ds_read_b128 per lane, cell pitch
+//     an odd number of 16-byte slots, no bank conflicts;
+//   * weights are the A operand (the fragment layouts of A and B are the same), so D row = channel, column = pixel: a lane
+//     leaves with four consecutive channels of one pixel = one 8-byte store into the pixel's cell.
+#include "common.h"
+
+namespace d3d {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int TXO = 32, TYO = 8;                      // output tile of a workgroup
+constexpr int MG = TXO / 16;                          // 16-pixel groups per wave (= output row)
+constexpr int PXI = 2 * TXO + 1, PYI = 2 * TYO + 1;   // staged input patch
+constexpr int NEVEN = TXO + 1;                        // even patch columns come first in a row, then the TXO odd ones
+constexpr int NT = 64 * TYO;
+
+struct S2Params {
+    const void* in;       // [D, H, W, CI] bf16
+    const u4* wpk;        // [3 (kz)][NKB][N tiles][64 lanes] fragments (ops._pack_c8_bf16)
+    const float* scale;   // [CO] or null
+    const float* shift;   // [CO] or null
+    const void* skip;     // [Do, Ho, Wo, CO] bf16 or null (added after the activation)
+    void* out;            // [Do, Ho, Wo, CO] bf16
+    int D, H, W;          // input dims
+    int Do, Ho, Wo, CO;
+    int relu;
+    int zper;             // output planes per workgroup
+};
+
+__device__ __forceinline__ unsigned pack_bf16_cl(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ f4 unpack_bf16x4_cl(uint2 u) {
+    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+
+template <int CI, int NTN>
+__global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);   // odd number of 16-byte slots
+    constexpr int G = CI / 8;
+    constexpr int PATCH = PXI * PYI * CS;
+    constexpr int AW = MG * NTN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xo0 = blockIdx.x * TXO, yo0 = blockIdx.y * TYO;
+    const int zo0 = blockIdx.z * p.zper, zo1 = min(zo0 + p.zper, p.Do);
+    const int D = p.D, H = p.H, W = p.W;
+
+    for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+
+    // ---- staging: task = (patch pixel, 8-channel group), one 16-byte load and one 16-byte LDS write ----------------
+    constexpr int NTASK = PXI * PYI * G;
+    constexpr int ROUNDS = (NTASK + NT - 1) / NT;
+    u4 stc[ROUNDS];
+    auto issue = [&](int zi) {
+        const bool zin = zi >= 0 && zi < D;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PXI, px = pix - py * PXI;
+            const int gx = 2 * xo0 - 1 + px, gy = 2 * yo0 - 1 + py;
+            const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
+                (ok ? (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16 : 0);
+            const u4 v = *reinterpret_cast<const u4*>(src);
+            stc[r] = ok ? v : (u4){0, 0, 0, 0};
+        }
+    };
+    auto commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            if (task < NTASK) {
+                const int pix = task / G, g = task - pix * G;
+                const int py = pix / PXI, px = pix - py * PXI;
+                const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
+                *reinterpret_cast<u4*>(dst + cell * CS + g * 16) = stc[r];
+            }
+        }
+    };
+
+    // K index k = 32 kb + 8 (lane >> 4) + j -> tap t = k / CI = (k_y, k_x), channel k % CI.  Output pixel m of the row reads
+    // patch row 2 wave + k_y, patch column 2 m + k_x: even run index m (k_x = 0) | m + 1 (k_x = 2), odd run index m (k_x = 1)
+    auto a_offset = [&](int kb, int kgroup) {
+        const int k0 = 32 * kb + 8 * kgroup;
+        const int t = k0 / CI, c = k0 % CI;
+        const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
+        const int col = kx == 1 ? NEVEN : (kx >> 1);
+        return (ky * PXI + col) * CS + (t < 9 ? c : 0) * 2;
+    };
+    const int abase = (2 * wave * PXI + (lane & 15)) * CS;
+
+    f4 acc[2][AW];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < AW; ++i) acc[s][i] = (f4){0, 0, 0, 0};
+
+    const int oy = yo0 + wave;
+    auto store_plane = [&](int zo, f4 (&a)[AW]) {
+        if (oy < p.Ho && zo >= zo0) {
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int cb = nt * 16 + (lane >> 4) * 4;
+                if (cb < p.CO) {
+                    const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+                    const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) {
+                        const int ox = xo0 + mg * 16 + (lane & 15);
+                        if (ox < p.Wo) {
+                            const size_t o = (((size_t)zo * p.Ho + oy) * p.Wo + ox) * p.CO + cb;   // bf16 element index
+                            f4 v = a[mg * NTN + nt] * sc + sh;
+                            if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                            if (p.skip) v += unpack_bf16x4_cl(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                            const uint2 pk = {pack_bf16_cl(v[0], v[1]), pack_bf16_cl(v[2], v[3])};
+                            *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AW; ++i) a[i] = (f4){0, 0, 0, 0};
+    };
+
+    // one k_z slice (KZ2 < 0) or two (k_z = KZ1 -> d1, k_z = KZ2 -> d2) of the weights over the staged plane
+    auto sweep = [&](const unsigned char* buf, int kz1, f4 (&d1)[AW], int kz2, f4 (&d2)[AW], bool two) {
+        int kgroup = lane >> 4;
+        asm volatile("" : "+v"(kgroup));
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int aoffk = a_offset(kb, kgroup);
+            bf16x8 w1[NTN], w2[NTN];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) {
+                w1[nt] = __builtin_bit_cast(bf16x8, wlds[((kz1 * NKB + kb) * NTN + nt) * 64 + lane]);
+                if (two) w2[nt] = __builtin_bit_cast(bf16x8, wlds[((kz2 * NKB + kb) * NTN + nt) * 64 + lane]);
+            }
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    d1[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[nt], a, d1[mg * NTN + nt], 0, 0, 0);
+                    if (two) d2[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt], a, d2[mg * NTN + nt], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- walk the input planes 2 zo0 - 1 .. 2 zo1 - 1 (the last one is odd) -----------------------------------------
+    const int zlast = 2 * zo1 - 1;
+    int zi = 2 * zo0 - 1, cur = 0;
+    issue(zi);
+    commit(smem);
+    __syncthreads();
+    auto odd_step = [&](f4 (&lo)[AW], f4 (&hi)[AW]) {   // zi = 2a + 1: completes output plane a (lo), opens plane a + 1 (hi)
+        const bool more = zi < zlast, live = zi >= 0 && zi < D;
+        if (more) issue(zi + 1);
+        if (live) sweep(smem + cur * PATCH, 2, lo, 0, hi, true);
+        store_plane((zi - 1) >> 1, lo);
+        if (more) commit(smem + (cur ^ 1) * PATCH);
+        __syncthreads();
+        cur ^= 1;
+    };
+    auto even_step = [&](f4 (&mid)[AW]) {               // zi = 2a: k_z = 1 of output plane a; never the last plane
+        const bool live = zi < D;
+        issue(zi + 1);
+        if (live) sweep(smem + cur * PATCH, 1, mid, 1, mid, false);
+        commit(smem + (cur ^ 1) * PATCH);
+        __syncthreads();
+        cur ^= 1;
+    };
+    while (true) {
+        odd_step(acc[1], acc[0]);
+        if (zi == zlast) break;
+        ++zi;
+        even_step(acc[0]);
+        ++zi;
+        odd_step(acc[0], acc[1]);
+        if (zi == zlast) break;
+        ++zi;
+        even_step(acc[1]);
+        ++zi;
+    }
+}
+
+template <int CI, int NTN>
+static int launch_s2(const S2Params& p, hipStream_t stream) {
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * PXI * PYI * CS + 3 * NKB * NTN * 64 * 16;
+    auto kern = conv3d_s2_cl_kernel<CI, NTN>;
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
+    S2Params q = p;
+    const int gx = ceil_div(p.Wo, TXO), gy = ceil_div(p.Ho, TYO);
+    int nz = 1;   // every z segment re-reads one halo plane
+    while ((long)gx * gy * nz < 1024 && p.Do / (nz * 2) >= 2) nz *= 2;
+    q.zper = ceil_div(p.Do, nz);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(p.Do, q.zper)), dim3(NT), lds, stream, q);
+    D3D_LAUNCH_CHECK("conv3d_s2_cl_kernel launch");
+    return D3D_OK;
+}
+
+// ---- format conversions: thread = (voxel, 8-channel group) ---------------------------------------------------------
+__global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restrict__ in, int C, size_t n, u4* __restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, G = C >> 3;
+    if (v >= n) return;
+    const float* src = in + (size_t)(8 * g) * n + v;
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = src[(size_t)k * n];
+    out[v * G + g] = (u4){pack_bf16_cl(f[0], f[1]), pack_bf16_cl(f[2], f[3]), pack_bf16_cl(f[4], f[5]), pack_bf16_cl(f[6], f[7])};
+}
+
+__global__ __launch_bounds__(256) void cl_to_planar_kernel(const u4* __restrict__ in, int C, size_t n, float* __restrict__ out) {
+    const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, G = C >> 3;
+    if (v >= n) return;
+    const u4 u = in[v * G + g];
+    float* dst = out + (size_t)(8 * g) * n + v;
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dst[(size_t)(2 * k) * n] = __builtin_bit_cast(float, w[k] << 16);
+        dst[(size_t)(2 * k + 1) * n] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+    }
+}
+
+}  // namespace
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
+                                       int relu, int Ci, int Co, int D, int H, int W, void* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    S2Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.Do = (D - 1) / 2 + 1; p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1; p.CO = Co; p.relu = relu;
+    const bool shape = (Ci == 8 && Co == 16) || (Ci == 16 && Co == 32) || (Ci == 8 && Co == 8) || (Ci == 16 && Co == 16);
+    if (!shape || ceil_div(p.Ho, TYO) > 65535 || p.Do > 65535) {
+        set_error("d3d_conv3d_k3s2_cl_bf16: %d -> %d channels not taken (8->8, 8->16, 16->16, 16->32)", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (Ci == 8) return launch_s2<8, 1>(p, st);
+    return Co > 16 ? launch_s2<16, 2>(p, st) : launch_s2<16, 1>(p, st);
+}
+
+extern "C" int d3d_volume_planar_to_cl_bf16(const float* in, int C, size_t n, void* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && out, "null pointer");
+    D3D_REQUIRE(C > 0 && C % 8 == 0 && C <= 8 * 65535 && n > 0 && n < ((size_t)1 << 39), "C = %d (multiple of 8), n = %zu", C, n);
+    hipLaunchKernelGGL(planar_to_cl_kernel, dim3((unsigned)((n + 255) / 256), C / 8), dim3(256), 0, (hipStream_t)stream, in, C, n,
+                       static_cast<u4*>(out));
+    D3D_LAUNCH_CHECK("planar_to_cl_kernel launch");
+    return D3D_OK;
+}
+
+extern "C" int d3d_volume_cl_bf16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && out, "null pointer");
+    D3D_REQUIRE(C > 0 && C % 8 == 0 && C <= 8 * 65535 && n > 0 && n < ((size_t)1 << 39), "C = %d (multiple of 8), n = %zu", C, n);
+    hipLaunchKernelGGL(cl_to_planar_kernel, dim3((unsigned)((n + 255) / 256), C / 8), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const u4*>(in), C, n, out);
+    D3D_LAUNCH_CHECK("cl_to_planar_kernel launch");
+    return D3D_OK;
+}

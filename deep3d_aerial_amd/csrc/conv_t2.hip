@@ -27,13 +27,14 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int TYI = 8;   // input rows per workgroup = waves
 
+// CL = true: input, skip and output are channel-last bf16 volumes ([D][H][W][C], see conv_c8.hip) instead of planar fp32.
 struct T2Params {
-    const float* in;     // [CI, D, H, W]
+    const void* in;      // [CI, D, H, W] fp32 | [D, H, W, CI] bf16
     const u4* wpk;       // per parity class (pz, py, px): [K blocks][N tiles][64 lanes] 16-byte B fragments
     const float* scale;  // [CO] or null
     const float* shift;  // [CO] or null
-    const float* skip;   // [CO, 2D, 2H, 2W] or null (added after the activation)
-    float* out;          // [CO, 2D, 2H, 2W]
+    const void* skip;    // [CO, 2D, 2H, 2W] fp32 | [2D, 2H, 2W, CO] bf16, or null (added after the activation)
+    void* out;           // [CO, 2D, 2H, 2W] fp32 | [2D, 2H, 2W, CO] bf16
     int D, H, W, CO;
     int relu;
     int ozper;           // output planes per workgroup (even)
@@ -53,7 +54,12 @@ constexpr int frag_base(int CI, int p) {
     return s;
 }
 
-template <int CI, int NTN, int MG>   // NTN: 16-channel output tiles; MG: 16-pixel groups per wave (input tile width = 16 * MG)
+__device__ __forceinline__ f4 unpack_bf16x4_t2(uint2 u) {
+    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+}
+
+template <int CI, int NTN, int MG, bool CL>   // NTN: 16-channel output tiles; MG: 16-pixel groups per wave (input tile width = 16 * MG)
 __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     constexpr int NT = 64 * TYI;
     constexpr int TXI = 16 * MG;
@@ -77,7 +83,8 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
 
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
-    float stg[ROUNDS][8];
+    float stg[CL ? 1 : ROUNDS][8];
+    u4 stc[CL ? ROUNDS : 1];
     auto issue = [&](int zi) {
         const bool zin = zi >= 0 && zi < D;
 #pragma unroll
@@ -87,11 +94,19 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             const int py = pix / PXI, px = pix - py * PXI;
             const int gx = ix0 + px, gy = iy0 + py;
             const bool ok = zin && task < NTASK && gx < W && gy < H;
-            const float* __restrict__ src = p.in + (size_t)(8 * g) * ivol + (size_t)(ok ? zi : 0) * iplane + (ok ? (size_t)gy * W + gx : 0);
+            if constexpr (CL) {
+                const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
+                    (ok ? (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16 : 0);
+                const u4 v = *reinterpret_cast<const u4*>(src);
+                stc[r] = ok ? v : (u4){0, 0, 0, 0};
+            } else {
+                const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * ivol + (size_t)(ok ? zi : 0) * iplane +
+                    (ok ? (size_t)gy * W + gx : 0);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * ivol];
-                stg[r][k] = ok ? v : 0.0f;
+                for (int k = 0; k < 8; ++k) {
+                    const float v = src[(size_t)k * ivol];
+                    stg[r][k] = ok ? v : 0.0f;
+                }
             }
         }
     };
@@ -101,8 +116,10 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             const int task = tid + r * NT;
             if (task < NTASK) {
                 const int pix = task / G, g = task - pix * G;
-                u4 v = {pack_bf16_t2(stg[r][0], stg[r][1]), pack_bf16_t2(stg[r][2], stg[r][3]), pack_bf16_t2(stg[r][4], stg[r][5]),
-                        pack_bf16_t2(stg[r][6], stg[r][7])};
+                u4 v;
+                if constexpr (CL) v = stc[r];
+                else v = (u4){pack_bf16_t2(stg[r][0], stg[r][1]), pack_bf16_t2(stg[r][2], stg[r][3]), pack_bf16_t2(stg[r][4], stg[r][5]),
+                              pack_bf16_t2(stg[r][6], stg[r][7])};
                 *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
             }
         }
@@ -145,14 +162,46 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                 for (int mg = 0; mg < MG; ++mg) {
                     const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
 #pragma unroll
-                    for (int nt = 0; nt < NTN; ++nt)
-                        acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[nt], acc[px][mg][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTN; ++nt) {
+                        if constexpr (CL) acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[nt], a, acc[px][mg][nt], 0, 0, 0);
+                        else acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[nt], acc[px][mg][nt], 0, 0, 0);
+                    }
                 }
             }
         }
         // epilogue: D row = input pixel (lane >> 4) * 4 + r, column = channel; outputs x = 2 ix + px interleaved
         const int oy = 2 * iy + PY;
-        if (iy < H) {
+        if constexpr (CL) {
+            // weights were the A operand: D row = channel (lane >> 4) * 4 + register, column = input pixel lane & 15; a lane
+            // stores four consecutive channels of the output pixels (2 ix, 2 ix + 1) = one 8-byte store each
+            if (iy < H) {
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    const int cb = nt * 16 + (lane >> 4) * 4;
+                    if (cb < p.CO) {
+                        const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+                        const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+                        for (int mg = 0; mg < MG; ++mg) {
+                            const int ix = ix0 + mg * 16 + (lane & 15);
+                            if (ix < W) {
+#pragma unroll
+                                for (int px = 0; px < 2; ++px) {
+                                    const size_t o = (((size_t)oz * (2 * H) + oy) * OW + 2 * ix + px) * p.CO + cb;   // bf16 element index
+                                    f4 v = acc[px][mg][nt] * sc + sh;
+                                    if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                                    if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                                    const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
+                                    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (iy < H) {
+            const float* __restrict__ skipf = static_cast<const float*>(p.skip);
+            float* __restrict__ outf = static_cast<float*>(p.out);
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
                 const int co = nt * 16 + n;
@@ -167,13 +216,13 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                             if (p.relu) { e = __builtin_elementwise_max(e, (f4){0, 0, 0, 0}); od = __builtin_elementwise_max(od, (f4){0, 0, 0, 0}); }
                             f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
                             if (ix + 3 < W && (W & 1) == 0) {   // 16-byte aligned rows
-                                if (p.skip) { lo += *reinterpret_cast<const f4*>(p.skip + o); hi += *reinterpret_cast<const f4*>(p.skip + o + 4); }
-                                *reinterpret_cast<f4*>(p.out + o) = lo;
-                                *reinterpret_cast<f4*>(p.out + o + 4) = hi;
+                                if (skipf) { lo += *reinterpret_cast<const f4*>(skipf + o); hi += *reinterpret_cast<const f4*>(skipf + o + 4); }
+                                *reinterpret_cast<f4*>(outf + o) = lo;
+                                *reinterpret_cast<f4*>(outf + o + 4) = hi;
                             } else {   // ragged right edge
                                 const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                                 for (int j = 0; j < 8; ++j)
-                                    if (ix + (j >> 1) < W) p.out[o + j] = v[j] + (p.skip ? p.skip[o + j] : 0.0f);
+                                    if (ix + (j >> 1) < W) outf[o + j] = v[j] + (skipf ? skipf[o + j] : 0.0f);
                             }
                         }
                     }
@@ -205,12 +254,12 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     }
 }
 
-template <int CI, int NTN, int MG>
+template <int CI, int NTN, int MG, bool CL>
 static int launch(const T2Params& p, hipStream_t stream) {
     constexpr int TXI = 16 * MG;
     constexpr int CS = CI * 2 + 16;
     const int lds = 2 * (TXI + 1) * (TYI + 1) * CS + frag_base(CI, 8) * NTN * 64 * 16;
-    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG>;
+    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -230,21 +279,32 @@ static int launch(const T2Params& p, hipStream_t stream) {
 
 using namespace d3d;
 
-extern "C" int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
-                                                const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
-                                                d3d_stream_t stream) {
+extern "C" int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift,
+                                                const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out,
+                                                int channel_last, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     const bool shape = (Ci == 16 && Co == 8) || (Ci == 16 && Co == 16) || (Ci == 32 && Co == 16) || (Ci == 64 && Co == 32);
     if (!shape || ceil_div(H, TYI) > 65535 || 2 * D > 65535) {
-        set_error("d3d_convtranspose3d_k3s2_zs_bf16: %d -> %d channels not taken (16->8, 16->16, 32->16, 64->32)", Ci, Co);
+        set_error("d3d_convtranspose3d_k3s2_cl_bf16: %d -> %d channels not taken (16->8, 16->16, 32->16, 64->32)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }
     T2Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.CO = Co; p.relu = relu;
     hipStream_t st = (hipStream_t)stream;
-    if (Ci == 16) return launch<16, 1, 2>(p, st);
-    if (Ci == 32) return launch<32, 1, 2>(p, st);
-    return launch<64, 2, 1>(p, st);
+    if (channel_last) {
+        if (Ci == 16) return launch<16, 1, 2, true>(p, st);
+        if (Ci == 32) return launch<32, 1, 2, true>(p, st);
+        return launch<64, 2, 1, true>(p, st);
+    }
+    if (Ci == 16) return launch<16, 1, 2, false>(p, st);
+    if (Ci == 32) return launch<32, 1, 2, false>(p, st);
+    return launch<64, 2, 1, false>(p, st);
+}
+
+extern "C" int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                                d3d_stream_t stream) {
+    return d3d_convtranspose3d_k3s2_cl_bf16(in, wpacked, scale, shift, skip, relu, Ci, Co, D, H, W, out, 0, stream);
 }

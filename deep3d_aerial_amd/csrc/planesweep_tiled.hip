@@ -274,6 +274,18 @@ __device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte
 #endif
 }
 
+// channel-last bf16 output: four consecutive channels of the lane's voxel, RNE, one 8-byte store
+__device__ __forceinline__ void store_sbase_bf16x4(unsigned long long sb, unsigned byte_off, const float __attribute__((ext_vector_type(4)))& v) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32
+    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(unsigned, a) | ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32);
+#ifdef D3D_NOSTORE
+    asm volatile("" : : "v"(byte_off), "v"(bits), "s"(sb));
+#else
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
+#endif
+}
+
 // fp16 storage: one 2-byte store per lane (a wave writes two 64-byte row segments per channel and plane)
 __device__ __forceinline__ void store_sbase_h(unsigned long long sb, unsigned byte_off, float v) {
     const _Float16 hv = (_Float16)v;   // RNE
@@ -306,9 +318,12 @@ __device__ __forceinline__ float ldf(const __half* q) { return __half2float(*q);
 // T = float: tensors as declared in SweepParams.  T = __half (MODE_VARIANCE only; BASELINE config 5): feats[] and out
 // are fp16 tensors of the same shapes, the rings hold fp16 cells (half the LDS bytes per tap), every product and sum
 // is fp32 (v_fma_mix_f32 reads the fp16 tap directly), the result is rounded once (RNE) at the store.
-template <int MODE, int NSRC, int CH, typename T = float>
+// OUTCL: the variance volume leaves as a channel-last bf16 volume [D][h][w][C] (RNE) -- the form conv0 of the 3-D
+// regulariser stages in bf16 mode (conv_c8.hip); four channels of a voxel = one 8-byte store instead of four 4-byte ones.
+template <int MODE, int NSRC, int CH, typename T = float, bool OUTCL = false>
 __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {
     constexpr bool F16 = sizeof(T) == 2;
+    static_assert(!OUTCL || (MODE == MODE_VARIANCE && !F16), "channel-last bf16 output is built for the fp32 variance volume");
     constexpr int CW = CH * (int)sizeof(T) / 4;   // words per ring position
     constexpr int CPC = 16 / (int)sizeof(T);      // channels per 16-byte chunk (one ds_read_b128): 4 | 8
     using L = Lds<CW, NSRC>;
@@ -366,6 +381,7 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
     const bool valid = (px < w) && (py < h);
     const int pix = valid ? py * w + px : 0;
     const unsigned pixb = (unsigned)pix * (unsigned)sizeof(T);  // per-lane byte offset (h*w < 2^30)
+    const unsigned pixo = OUTCL ? (unsigned)pix * (unsigned)p.C * 2u : pixb;   // channel-last cells: h*w*C*2 < 2^32 (checked at launch)
     const float xf = (float)px, yf = (float)py;
 
     // --- zero cell and per-plane depth range of this patch -------------------------------------
@@ -865,10 +881,15 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
         } else {
             o = s;
         }
+        if constexpr (OUTCL) {
+            store_sbase_bf16x4(ob, pixo, o);
+            ob += 8;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            store_sbase(ob, pixb, o[k]);
-            ob += cstride_b;
+            for (int k = 0; k < 4; ++k) {
+                store_sbase(ob, pixb, o[k]);
+                ob += cstride_b;
+            }
         }
     };
     auto accumulate = [&](f4& s, f4& qq, float& pair_acc, const f4& val, int q, int i) {
@@ -935,7 +956,8 @@ __global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, Til
             } else {
                 dv = lds[L::PMIN + dl_];
             }
-            unsigned long long ob = uniform64(reinterpret_cast<T*>(p.out) + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);  // scalar base, once per plane
+            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) + (size_t)d * plane * p.C + c0)
+                                          : uniform64(reinterpret_cast<T*>(p.out) + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);  // scalar base, once per plane
             float pair_acc = 0.0f;
             if (!valid) continue;  // one EXEC region per plane instead of one branch per store
 
@@ -1228,12 +1250,13 @@ size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_byt
     return (size_t)n_src * C * h * w * elem_bytes;
 }
 
-template <int MODE, int NSRC, int CH, typename T>
+template <int MODE, int NSRC, int CH, typename T, bool OUTCL = false>
 static int launch_one(const SweepParams& p, hipStream_t stream) {
     constexpr int CW = CH * (int)sizeof(T) / 4;
     using L = Lds<CW, NSRC>;
     constexpr int LDS_BYTES = 160 * 1024;
-    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T>;
+    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T, OUTCL>;
+    if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
     // per device and idempotent: set on every launch (no process-global "done" flag that a second GPU would miss)
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
@@ -1313,6 +1336,16 @@ static int group_channels(int C, int n_src, int elem_bytes) {
 template <int MODE, int NSRC>
 static int launch_ch(const SweepParams& p, hipStream_t stream) {
     const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src, 4);
+    if constexpr (MODE == MODE_VARIANCE) {
+        if (p.out_cl) {
+            switch (cg) {
+                case 16: return launch_one<MODE, NSRC, 16, float, true>(p, stream);
+                case 8: return launch_one<MODE, NSRC, 8, float, true>(p, stream);
+            }
+            return D3D_ERR_UNSUPPORTED;
+        }
+    }
+    if (p.out_cl) return D3D_ERR_UNSUPPORTED;
     switch (cg) {
         case 32: return launch_one<MODE, NSRC, 32, float>(p, stream);
         case 16: return launch_one<MODE, NSRC, 16, float>(p, stream);
@@ -1338,7 +1371,7 @@ int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
         return D3D_ERR_UNSUPPORTED;
     }
     if (p.elem_bytes == 2) {
-        if (mode != MODE_VARIANCE) return D3D_ERR_UNSUPPORTED;
+        if (mode != MODE_VARIANCE || p.out_cl) return D3D_ERR_UNSUPPORTED;
         if (p.n_src > 4) return launch_f16<6>(p, stream);
         return p.n_src <= 2 ? launch_f16<2>(p, stream) : launch_f16<4>(p, stream);
     }

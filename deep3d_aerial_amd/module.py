@@ -98,6 +98,11 @@ class ConvBnReLU3D(nn.Module):
         s, t = folded_bn(self.bn)
         return ops.conv3d_k3(x, self.conv.weight, s, t, skip, relu=True, stride=self.stride)
 
+    def forward_cl(self, x, skip=None):  # bf16 mode: x planar fp32 or channel-last bf16 -> channel-last bf16
+        _no_train(self)
+        s, t = folded_bn(self.bn)
+        return ops.conv3d_k3_cl(x, self.conv.weight, s, t, skip, relu=True, stride=self.stride)
+
 
 # ----------------------------------------------------------------------------------------
 # 2D blocks used by the regularisers (module.py:248-274, 5-51)

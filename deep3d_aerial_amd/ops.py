@@ -166,6 +166,24 @@ def variance_volume(feats, proj34, depth, out=None):
     return out
 
 
+def variance_volume_cl(feats, proj34, depth):
+    """variance_volume for the bf16 mode of the regulariser (BASELINE config 3): fp32 features and arithmetic, the volume
+    written once as a channel-last bf16 tensor [D,h,w,C] (the rounding conv0 would apply when it stages the planar volume).
+    Shapes the ring kernel does not take go through the planar kernel and the format conversion."""
+    C, h, w = _check_feats(feats, proj34)
+    dp, mode, D = _depth(depth, h, w)
+    if C % 8 == 0:
+        out = torch.empty((D, h, w, C), dtype=torch.bfloat16, device=feats[0].device)
+        arr = _ptr_array(feats, "feats")
+        ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
+        rc = _lib.load().d3d_variance_volume_cl_bf16(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
+                                                     ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_variance_volume_cl_bf16")
+            return out
+    return to_cl(variance_volume(feats, proj34, depth))
+
+
 def weighted_corr(feats, proj34, weights, depth, out=None, plane_major=False):
     """adamvs.py:492-509. weights [V-1,h,w] -> [C,D,h,w], or [D,C,h,w] with plane_major=True (plane d contiguous)."""
     C, h, w = _check_feats(feats, proj34)
@@ -400,6 +418,111 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
                                               _chk(out, "out"), _stream())
     _lib.check(rc, "d3d_convtranspose3d_k3s2")
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# Channel-last bf16 volumes: what the CostRegNet layers hand to each other in bf16 mode (BASELINE config 3).
+# A "CL" volume is a torch.bfloat16 tensor [D,H,W,C]; a planar one the usual float32 [C,D,H,W].
+# ----------------------------------------------------------------------------------------
+def channel_last_enabled():
+    return _os.environ.get("D3D_CONV_CL", "1") != "0"
+
+
+def _chk_cl(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 4):
+        raise TypeError("%s must be a contiguous CUDA bfloat16 tensor [D,H,W,C]" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def to_cl(x):
+    """planar fp32 [C,D,H,W] -> channel-last bf16 [D,H,W,C] (round to nearest even)."""
+    C, D, H, W = x.shape
+    if C % 8:
+        raise ValueError("channel-last volumes need C % 8 == 0 (got %d)" % C)
+    out = torch.empty((D, H, W, C), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().d3d_volume_planar_to_cl_bf16(_chk(x, "x", 4), C, D * H * W, _chk_cl(out, "out"), _stream()),
+               "d3d_volume_planar_to_cl_bf16")
+    return out
+
+
+def from_cl(x):
+    """channel-last bf16 [D,H,W,C] -> planar fp32 [C,D,H,W] (exact)."""
+    D, H, W, C = x.shape
+    if C % 8:
+        raise ValueError("channel-last volumes need C % 8 == 0 (got %d)" % C)
+    out = torch.empty((C, D, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().d3d_volume_cl_bf16_to_planar(_chk_cl(x, "x"), C, D * H * W, _chk(out, "out"), _stream()),
+               "d3d_volume_cl_bf16_to_planar")
+    return out
+
+
+def _planar(t):
+    return None if t is None else (from_cl(t) if t.dtype == torch.bfloat16 else t)
+
+
+def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1, out_cl=True):
+    """conv3d_k3 with bf16 operands on either activation format: x planar fp32 [Ci,D,H,W] or CL bf16 [D,H,W,Ci];
+    returns CL [Do,Ho,Wo,Co] (out_cl) or planar fp32 [Co,Do,Ho,Wo]; `skip` comes in the output's format.  Shapes the
+    channel-last kernels do not take go through the planar kernels and the two format conversions."""
+    in_cl = x.dtype == torch.bfloat16
+    (D, H, W, Ci) = x.shape if in_cl else (x.shape[1], x.shape[2], x.shape[3], x.shape[0])
+    Co = weight.shape[0]
+    if tuple(weight.shape) != (Co, Ci, 3, 3, 3):
+        raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    o = lambda n: (n - 1) // stride + 1
+    oshape = (o(D), o(H), o(W), Co) if out_cl else (Co, o(D), o(H), o(W))
+    if skip is not None and (tuple(skip.shape) != oshape or (skip.dtype == torch.bfloat16) != bool(out_cl)):
+        raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
+    xp = _chk_cl(x, "x") if in_cl else _chk(x, "x", 4)
+    sp = None if skip is None else (_chk_cl(skip, "skip") if out_cl else _chk(skip, "skip"))
+    wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
+    wptr = ctypes.c_void_p(wp.data_ptr())
+    out = torch.empty(oshape, dtype=torch.bfloat16 if out_cl else torch.float32, device=x.device)
+    optr = ctypes.c_void_p(out.data_ptr())
+    rc = _lib.ERR_UNSUPPORTED
+    if stride == 1:
+        rc = _lib.load().d3d_conv3d_k3_cl_bf16(xp, int(in_cl), wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
+                                               Ci, Co, D, H, W, optr, int(out_cl), _stream())
+    elif stride == 2 and in_cl and out_cl:
+        rc = _lib.load().d3d_conv3d_k3s2_cl_bf16(xp, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu), Ci, Co,
+                                                 D, H, W, optr, _stream())
+    if rc != _lib.ERR_UNSUPPORTED:
+        _lib.check(rc, "d3d_conv3d_k3_cl_bf16" if stride == 1 else "d3d_conv3d_k3s2_cl_bf16")
+        return out
+    saved = _conv_precision[0]
+    _conv_precision[0] = "bf16"
+    try:
+        y = conv3d_k3(_planar(x), weight, scale, shift, _planar(skip), relu=relu, stride=stride)
+    finally:
+        _conv_precision[0] = saved
+    return to_cl(y) if out_cl else y
+
+
+def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=True):
+    """convtranspose3d_k3s2 with bf16 operands on channel-last volumes: x [D,H,W,Ci] bf16, skip / result [2D,2H,2W,Co] bf16."""
+    D, H, W, Ci = x.shape
+    Co = weight.shape[1]
+    if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
+        raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    oshape = (2 * D, 2 * H, 2 * W, Co)
+    if skip is not None and (tuple(skip.shape) != oshape or skip.dtype != torch.bfloat16):
+        raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
+    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)):
+        wp = derived_weight(weight, "t2bf16", _pack_t2_bf16)
+        out = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
+        rc = _lib.load().d3d_convtranspose3d_k3s2_cl_bf16(_chk_cl(x, "x"), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                          _opt(shift, "shift"), None if skip is None else _chk_cl(skip, "skip"),
+                                                          int(relu), Ci, Co, D, H, W, ctypes.c_void_p(out.data_ptr()), 1, _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_convtranspose3d_k3s2_cl_bf16")
+            return out
+    saved = _conv_precision[0]
+    _conv_precision[0] = "bf16"
+    try:
+        y = convtranspose3d_k3s2(from_cl(x), weight, scale, shift, _planar(skip), relu=relu)
+    finally:
+        _conv_precision[0] = saved
+    return to_cl(y)
 
 
 def conv1x1_upskip(x, weight, bias, coarse):

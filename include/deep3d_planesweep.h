@@ -117,6 +117,15 @@ int d3d_variance_volume(const float* const* feats, const float* proj34, const fl
                         int n_views, int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
                         d3d_stream_t stream);
 
+/* d3d_variance_volume with the result as a channel-last bf16 volume [D,h,w,C] (RNE at the store; fp32 features and fp32
+ * arithmetic as above): the form conv0 of the 3-D regulariser takes in bf16 mode (d3d_conv3d_k3_cl_bf16, in_cl = 1), which
+ * rounds its input to bf16 anyway -- so the regularised result is bit-identical to the planar fp32 route, the volume is
+ * written once at half the bytes and read with 16-byte loads.  C % 8 == 0, h*w*C < 2^31, at most 6 source views;
+ * D3D_ERR_UNSUPPORTED otherwise (nothing is launched; callers use d3d_variance_volume + d3d_volume_planar_to_cl_bf16). */
+int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                                int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
+                                d3d_stream_t stream);
+
 /* The same volume with fp16 STORAGE (BASELINE config 5): feats[i] and out are IEEE half tensors of the shapes
  * above; projections, depth and every product / sum stay fp32, the result is rounded once (RNE).  With a
  * workspace of d3d_sweep_workspace_bytes(..., 2) bytes and C % 16 == 0, up to 6 source views run on the LDS-ring
@@ -237,6 +246,31 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
 int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream);
+
+/* ---- channel-last bf16 activations between the layers of a CostRegNet (bf16 mode, BASELINE config 3) ------------------
+ * "CL" volume: bf16 [D][H][W][C].  The matrix-core kernels round their operands to bf16 when they stage them, so a layer
+ * that hands its output on in this form loses nothing its consumer would have kept, the activation traffic halves, and a
+ * staging task is one 16-byte load.  Same layers and weight packings as the *_zs_bf16 entry points above
+ * (cas_mvsnet.py:84-118: conv0 planar -> CL, conv1 .. conv11 CL -> CL with CL skips, prob CL -> planar).
+ *
+ * d3d_conv3d_k3_cl_bf16: stride 1; in_cl / out_cl select the format of `in` and of `out` + `skip` (0: planar fp32
+ *   [C,D,H,W], 1: CL).  C_in = 8 | 16 | 32, C_out <= 16 or 32 -> 32; C_out % 4 == 0 for CL output, W % 4 == 0 for planar.
+ * d3d_conv3d_k3s2_cl_bf16: stride 2, pad 1; CL in [D,H,W,Ci] -> CL out [(D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Co];
+ *   8->8, 8->16, 16->16, 16->32.
+ * d3d_convtranspose3d_k3s2_cl_bf16: channel_last = 1: CL in / skip / out ([2D,2H,2W,Co]); 0: the planar form above.
+ * d3d_volume_planar_to_cl_bf16 / d3d_volume_cl_bf16_to_planar: format conversion of a volume of n voxels, C % 8 == 0 (RNE;
+ *   the way back is exact) -- for the layers that stay on the planar kernels (conv5 / conv6) and for tests.
+ * D3D_ERR_UNSUPPORTED for other shapes; nothing is launched then. */
+int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+                          const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out, int out_cl,
+                          d3d_stream_t stream);
+int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
+                            int relu, int Ci, int Co, int D, int H, int W, void* out, d3d_stream_t stream);
+int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift,
+                                     const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out,
+                                     int channel_last, d3d_stream_t stream);
+int d3d_volume_planar_to_cl_bf16(const float* in, int C, size_t n, void* out, d3d_stream_t stream);
+int d3d_volume_cl_bf16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream);
 
 
 /* 3x3 stride-1 nn.Conv2d with C_out = 8 | 16 (the full- / half-resolution layers of the feature pyramids,

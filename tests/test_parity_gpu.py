@@ -911,3 +911,165 @@ def test_convtranspose3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci
     assert plain.shape == ref.shape
     assert np.abs(plain - ref).max() <= tol
     assert np.abs(got - want).max() <= 2 * tol
+
+
+# ---- channel-last bf16 activations between the CostRegNet layers (bf16 mode, BASELINE config 3) ---------------------------
+def _cl_host(t):
+    """channel-last bf16 device tensor [D,H,W,C] -> planar fp32 numpy [C,D,H,W] (exact)."""
+    return t.float().permute(3, 0, 1, 2).contiguous().cpu().numpy()
+
+
+def _cl_dev(a):
+    """planar fp32 numpy [C,D,H,W] -> channel-last bf16 device tensor (torch's RNE)."""
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda().permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)
+
+
+def _assert_bf16_of(got, exact, tol):
+    """`got` holds bf16 values of a quantity the kernel computed in fp32 to within `tol` of `exact`."""
+    err = np.abs(got - exact)
+    assert (err <= 2 * tol + 2.0 ** -8 * np.abs(exact)).all(), float(err.max())
+
+
+def test_volume_format_conversions(ops):
+    rng = np.random.default_rng(5)
+    for C, D, H, W in [(8, 3, 5, 7), (64, 2, 4, 9), (16, 1, 1, 1), (32, 4, 6, 130)]:
+        x = (rng.standard_normal((C, D, H, W)) * 10.0 ** rng.integers(-3, 3, (C, 1, 1, 1))).astype(np.float32)
+        cl = ops.to_cl(dev(x))
+        assert cl.dtype == torch.bfloat16 and tuple(cl.shape) == (D, H, W, C)
+        assert np.array_equal(_cl_host(cl), _bf16_round(x))
+        assert np.array_equal(host(ops.from_cl(cl)), _bf16_round(x))
+    with pytest.raises(ValueError):
+        ops.to_cl(dev(np.zeros((4, 2, 2, 2), np.float32)))
+
+
+@pytest.mark.parametrize("Ci,Co,D,H,W,in_cl,out_cl", [
+    (8, 8, 5, 9, 68, False, True), (16, 8, 8, 21, 132, False, True), (32, 8, 3, 4, 64, False, True), (8, 8, 1, 3, 5, False, True),
+    (16, 16, 7, 19, 70, True, True), (32, 32, 5, 11, 66, True, True), (8, 16, 3, 9, 21, True, True), (32, 16, 14, 8, 128, True, True),
+    (8, 1, 6, 10, 72, True, False), (8, 1, 40, 16, 64, True, False), (16, 8, 4, 9, 36, True, False), (8, 8, 9, 17, 37, True, True)])
+def test_conv3d_channel_last_bf16(ops, oracle, Ci, Co, D, H, W, in_cl, out_cl):
+    """d3d_conv3d_k3_cl_bf16 on every format pair the CostRegNet uses (cas_mvsnet.py:84 conv0 planar -> CL, :87,90 conv2 /
+    conv4 CL -> CL, :110 prob CL -> planar): the fp32 oracle on bf16-rounded operands, with the folded-BN affine, ReLU and a
+    skip in the output's format; channel-last results are the bf16 rounding of that value."""
+    rng = np.random.default_rng(Ci * 1000 + Co * 100 + W + D)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    sk = _bf16_round(rng.standard_normal((Co, D, H, W)).astype(np.float32)) if out_cl else rng.standard_normal((Co, D, H, W)).astype(np.float32)
+    xin = _cl_dev(x) if in_cl else dev(x)
+    skin = _cl_dev(sk) if out_cl else dev(sk)
+    got = ops.conv3d_k3_cl(xin, dev(w), dev(sc), dev(sh), skin, relu=True, stride=1, out_cl=out_cl)
+    plain = ops.conv3d_k3_cl(xin, dev(w), relu=False, stride=1, out_cl=out_cl)
+    ref = oracle.conv3d_k3(_bf16_round(x), _bf16_round(w), None)
+    want = np.maximum(ref * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    if out_cl:
+        assert got.dtype == torch.bfloat16 and tuple(got.shape) == (D, H, W, Co)
+        _assert_bf16_of(_cl_host(plain), ref, tol)
+        _assert_bf16_of(_cl_host(got), want, tol)
+    else:
+        assert got.dtype == torch.float32 and tuple(got.shape) == (Co, D, H, W)
+        assert np.abs(host(plain) - ref).max() <= tol
+        assert np.abs(host(got) - want).max() <= 2 * tol
+
+
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 16, 4, 16, 64), (16, 32, 8, 10, 70), (8, 8, 5, 9, 33), (16, 16, 1, 1, 1), (8, 16, 2, 34, 130),
+                                         (16, 32, 13, 7, 19), (8, 16, 16, 8, 8)])
+def test_conv3d_stride2_channel_last_bf16(ops, oracle, Ci, Co, D, H, W):
+    """conv1 / conv3 of CostRegNet (cas_mvsnet.py:86,89: stride 2) on d3d_conv3d_k3s2_cl_bf16, channel-last bf16 in and
+    out; odd sizes, single voxels and the z segmentation included."""
+    rng = np.random.default_rng(Ci * 1000 + Co * 100 + W + D)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    ref = oracle.conv3d_k3(_bf16_round(x), _bf16_round(w), stride=2)
+    sk = _bf16_round(rng.standard_normal(ref.shape).astype(np.float32))
+    got = ops.conv3d_k3_cl(_cl_dev(x), dev(w), dev(sc), dev(sh), _cl_dev(sk), relu=True, stride=2)
+    plain = ops.conv3d_k3_cl(_cl_dev(x), dev(w), relu=False, stride=2)
+    assert tuple(plain.shape) == ref.shape[1:] + (Co,)
+    want = np.maximum(ref * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    _assert_bf16_of(_cl_host(plain), ref, tol)
+    _assert_bf16_of(_cl_host(got), want, tol)
+
+
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 2, 3, 5), (16, 8, 4, 9, 70), (32, 16, 3, 5, 64), (64, 32, 2, 9, 18), (16, 16, 5, 20, 33),
+                                         (16, 8, 1, 1, 1), (32, 16, 9, 4, 130)])
+def test_convtranspose3d_channel_last_bf16(ops, oracle, Ci, Co, D, H, W):
+    """conv7 / conv9 / conv11 of CostRegNet (cas_mvsnet.py:97-103,116-118) on d3d_convtranspose3d_k3s2_cl_bf16 with
+    channel-last bf16 input, skip and output."""
+    rng = np.random.default_rng(Ci * 1000 + W + D)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    sh = rng.standard_normal(Co).astype(np.float32)
+    sk = _bf16_round(rng.standard_normal((Co, 2 * D, 2 * H, 2 * W)).astype(np.float32))
+    got = ops.convtranspose3d_k3s2_cl(_cl_dev(x), dev(w), dev(sc), dev(sh), _cl_dev(sk), relu=True)
+    plain = ops.convtranspose3d_k3s2_cl(_cl_dev(x), dev(w), relu=False)
+    ref = oracle.convtranspose3d_k3s2(_bf16_round(x), _bf16_round(w), None)
+    want = np.maximum(ref * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    assert tuple(plain.shape) == (2 * D, 2 * H, 2 * W, Co)
+    _assert_bf16_of(_cl_host(plain), ref, tol)
+    _assert_bf16_of(_cl_host(got), want, tol)
+
+
+def test_channel_last_layers_fall_back_through_the_planar_kernels(ops, oracle):
+    """conv5 / conv6 of CostRegNet (32 -> 64 stride 2, 64 -> 64: cas_mvsnet.py:92-93) have no channel-last kernel: the
+    same entry points convert, run the planar bf16 kernels and convert back."""
+    rng = np.random.default_rng(77)
+    for Ci, Co, stride in [(32, 64, 2), (64, 64, 1)]:
+        x = rng.standard_normal((Ci, 4, 6, 8)).astype(np.float32)
+        w = (0.1 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+        got = ops.conv3d_k3_cl(_cl_dev(x), dev(w), relu=True, stride=stride)
+        assert got.dtype == torch.bfloat16
+        # (the planar library keeps the weights of these two shapes in fp32 -- more precise than asked; accept either)
+        errs = []
+        for wr in (_bf16_round(w), w):
+            ref = np.maximum(oracle.conv3d_k3(_bf16_round(x), wr, stride=stride), 0)
+            assert tuple(got.shape) == ref.shape[1:] + (Co,)
+            errs.append(float((np.abs(_cl_host(got) - ref) - 2.0 ** -8 * np.abs(ref)).max()))
+        assert min(errs) <= 6e-5 * max(1.0, np.abs(ref).max()), errs
+
+
+def test_costregnet_channel_last_path_matches_planar_bf16_path(ops, monkeypatch):
+    """The whole 3-D regulariser (cas_mvsnet.py:81-121) in bf16 mode: the channel-last path differs from the planar bf16
+    path only by the rounding of the skip operands and of the prob input, far inside the depth budget of config 3."""
+    from deep3d_aerial_amd.cas_mvsnet import CostRegNet
+    torch.manual_seed(3)
+    net = CostRegNet(16).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, (torch.nn.BatchNorm3d,)):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    x = torch.randn(16, 16, 24, 40, device="cuda")
+    ops.set_conv_precision("bf16")
+    try:
+        with torch.no_grad():
+            a = net.forward_one(x)
+            monkeypatch.setenv("D3D_CONV_CL", "0")
+            b = net.forward_one(x)
+            ops.set_conv_precision("fp32")
+            c = net.forward_one(x)
+    finally:
+        ops.set_conv_precision(None)
+    assert a.shape == b.shape == (16, 24, 40)
+    scale = c.abs().max().item()
+    assert (a - b).abs().max().item() <= 0.03 * scale          # a handful of bf16 roundings apart
+    assert (a - c).abs().max().item() <= 0.06 * scale          # both bf16 paths sit the same distance from fp32
+    assert (a - b).abs().max().item() > 0                      # (the channel-last path really ran)
+
+
+@pytest.mark.parametrize("V,C,D,h,w", [(3, 8, 8, 40, 56), (5, 16, 16, 64, 96), (5, 32, 24, 48, 80), (7, 16, 8, 36, 52), (2, 8, 4, 17, 23)])
+def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, C, D, h, w):
+    """d3d_variance_volume_cl_bf16 (cas_mvsnet.py:45-60 in bf16 mode): exactly the bf16 rounding (RNE) of what
+    d3d_variance_volume writes, laid out [D,h,w,C] -- so conv0 sees the same operands either way."""
+    proj, dr = S.make_scene(V, h, w, D, sweep_px=D / 2.0, seed=V * 100 + C, yaw_deg=3.0)
+    f = S.make_features(V, C, h, w, seed=C + D)
+    feats = [dev(f[i]) for i in range(V)]
+    p34 = ops.compose_projections(dev(proj))
+    dv = dev(S.uniform_depths(dr, D))
+    planar = host(ops.variance_volume(feats, p34, dv))
+    got = ops.variance_volume_cl(feats, p34, dv)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (D, h, w, C)
+    assert np.array_equal(_cl_host(got), _bf16_round(planar))

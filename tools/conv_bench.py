@@ -61,6 +61,48 @@ def layer2d(tag, Ci, Co, h, w, stride=1, transposed=False, Ci1=0):
     return ms
 
 
+def layer3d_cl(tag, Ci, Co, D, h, w, stride=1, transposed=False, in_cl=True, out_cl=True, skip=False):
+    """The same layer on channel-last bf16 activations (bf16 mode of CostRegNet); traffic = one read of the input (and of the
+    skip) and one write of the output in their formats."""
+    x = torch.randn(Ci, D, h, w, device="cuda")
+    if in_cl:
+        x = ops.to_cl(x)
+    if transposed:
+        wt = torch.randn(Ci, Co, 3, 3, 3, device="cuda") * 0.1
+        outv = 8 * D * h * w
+        sk = torch.randn(2 * D, 2 * h, 2 * w, Co, device="cuda").to(torch.bfloat16) if skip else None
+        fn = lambda: ops.convtranspose3d_k3s2_cl(x, wt, skip=sk, relu=True)
+        flop = 2 * 27 * Ci * Co * D * h * w
+    else:
+        wt = torch.randn(Co, Ci, 3, 3, 3, device="cuda") * 0.1
+        outv = D * h * w // stride ** 3
+        sk = None
+        fn = lambda: ops.conv3d_k3_cl(x, wt, relu=True, stride=stride, out_cl=out_cl)
+        flop = 2 * 27 * Ci * Co * outv
+    ms = timeit(fn)
+    gb = ((2 if in_cl else 4) * Ci * D * h * w + (2 if out_cl else 4) * Co * outv * (2 if skip else 1)) / 1e9
+    print("%-28s Ci=%2d Co=%2d %3dx%4dx%4d s%d%s  %8.3f ms  %7.2f TFLOP/s  %7.1f GB/s(min traffic, %s -> %s)" % (
+        tag, Ci, Co, D, h, w, stride, "T" if transposed else " ", ms, flop / ms / 1e9, gb / ms * 1e3,
+        "CL" if in_cl else "planar", "CL" if out_cl else "planar"), flush=True)
+    return ms
+
+
+def costreg3d_cl(tag, C, D, h, w):
+    t = 0
+    t += layer3d_cl(tag + " conv0", C, 8, D, h, w, in_cl=False)
+    t += layer3d_cl(tag + " conv1", 8, 16, D, h, w, 2)
+    t += layer3d_cl(tag + " conv2", 16, 16, D // 2, h // 2, w // 2)
+    t += layer3d_cl(tag + " conv3", 16, 32, D // 2, h // 2, w // 2, 2)
+    t += layer3d_cl(tag + " conv4", 32, 32, D // 4, h // 4, w // 4)
+    t += layer3d_cl(tag + " conv5", 32, 64, D // 4, h // 4, w // 4, 2)
+    t += layer3d_cl(tag + " conv6", 64, 64, D // 8, h // 8, w // 8)
+    t += layer3d_cl(tag + " conv7T", 64, 32, D // 8, h // 8, w // 8, transposed=True, skip=True)
+    t += layer3d_cl(tag + " conv9T", 32, 16, D // 4, h // 4, w // 4, transposed=True, skip=True)
+    t += layer3d_cl(tag + " conv11T", 16, 8, D // 2, h // 2, w // 2, transposed=True, skip=True)
+    t += layer3d_cl(tag + " prob", 8, 1, D, h, w, out_cl=False)
+    print("%s total %.2f ms (channel-last bf16 activations)" % (tag, t), flush=True)
+
+
 def costreg3d(tag, C, D, h, w):
     t = 0
     t += layer3d(tag + " conv0", C, 8, D, h, w)
@@ -83,6 +125,12 @@ if __name__ == "__main__":
         costreg3d("cas s3", 8, 8, H, W)
         costreg3d("cas s2", 16, 32, H // 2, W // 2)
         costreg3d("cas s1", 32, 48, H // 4, W // 4)
+    if which in ("all", "3dcl"):
+        ops.set_conv_precision("bf16")
+        costreg3d_cl("cas s3", 8, 8, H, W)
+        costreg3d_cl("cas s2", 16, 32, H // 2, W // 2)
+        costreg3d_cl("cas s1", 32, 48, H // 4, W // 4)
+        ops.set_conv_precision(None)
     if which in ("all", "2d"):
         # AdaMVS slice regulariser (per depth plane) at stage 3 resolution and the pair UNet at 1/4
         h, w = H, W
