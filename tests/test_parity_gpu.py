@@ -679,6 +679,38 @@ def test_full_size_cascade_mfma_equals_direct_kernels(ops, model, monkeypatch):
     assert rel_l1(outs["mfma"][1], outs["direct"][1]) <= 1e-3
 
 
+def test_full_size_cascade_bf16_regulariser_within_depth_budget(ops, monkeypatch):
+    """BASELINE config 3 at the BASELINE image size (2752x1856, 5 views, CasMVSNet): bf16 matrix-core regularisation on
+    channel-last bf16 activations (variance volume written channel-last by the sweep kernel) stays within the north-star
+    1e-3 relative L1 of the fp32 depth map, and equals the planar bf16 route (same roundings of the conv operands; only the
+    skip operands differ) far inside that budget."""
+    from deep3d_aerial_amd import predict
+
+    net = _fill(predict.build_model("casmvsnet", 384), 21)
+    s = predict.SyntheticBlock(1, 5, 2752, 1856, 384, seed=9)[0]
+    imgs = dev(s["imgs"])[None]
+    pm = {k: dev(v)[None] for k, v in s["proj_matrices"].items()}
+    dv = dev(s["depth_values"])[None]
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    outs = {}
+    for tag, prec, cl in (("fp32", "fp32", "1"), ("bf16_cl", "bf16", "1"), ("bf16_planar", "bf16", "0")):
+        monkeypatch.setenv("D3D_CONV_CL", cl)
+        ops.set_conv_precision(prec)
+        try:
+            with torch.no_grad():
+                o = net(imgs, pm, dv)
+        finally:
+            ops.set_conv_precision(None)
+        outs[tag] = (host(o["depth"][0]), host(o["photometric_confidence"][0]))
+        del o
+        torch.cuda.empty_cache()
+    assert np.isfinite(outs["bf16_cl"][0]).all() and np.isfinite(outs["bf16_cl"][1]).all()
+    assert rel_l1(outs["bf16_cl"][0], outs["fp32"][0]) <= 1e-3
+    assert rel_l1(outs["bf16_planar"][0], outs["fp32"][0]) <= 1e-3
+    assert rel_l1(outs["bf16_cl"][0], outs["bf16_planar"][0]) <= 5e-4
+    assert not np.array_equal(outs["bf16_cl"][0], outs["fp32"][0])
+
+
 def test_predict_views_writes_reference_products(ops, tmp_path):
     """predict.py boundary: per view {name}_init.pfm, {name}_prob.pfm, {name}.txt; sharding by rank."""
     from deep3d_aerial_amd import predict
