@@ -59,15 +59,27 @@ __device__ __forceinline__ f4 unpack_bf16x4_t2(uint2 u) {
                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
 }
 
-template <int CI, int NTN, int MG, bool CL>   // NTN: 16-channel output tiles; MG: 16-pixel groups per wave (input tile width = 16 * MG)
+// first fragment of the x-folded packing: class (pz, py) holds the K blocks of its px = 1 tap set
+constexpr int fold_base(int CI, int c) {
+    int s = 0;
+    for (int q = 0; q < c; ++q) s += nkb(CI, q >> 1, q & 1, 1);
+    return s;
+}
+
+// NTN: 16-channel output tiles; MG: 16-pixel groups per wave (input tile width = 16 * MG); CL: channel-last bf16 volumes.
+// FOLD (CL, C_out = 8): both column parities in ONE GEMM -- rows 0..7 of the weight operand are the 8 channels of the even
+// output column (taps with dx = 1 zeroed), rows 8..15 those of the odd one, so no half of the tile idles, the four lane
+// groups of a pixel leave with the 32 contiguous bytes of the output cells (2 ix, 2 ix + 1) and every lane stores.
+template <int CI, int NTN, int MG, bool CL, bool FOLD = false>
 __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
+    static_assert(!FOLD || (CL && NTN == 1), "x-folded form: channel-last, C_out = 8");
     constexpr int NT = 64 * TYI;
     constexpr int TXI = 16 * MG;
     constexpr int PXI = TXI + 1, PYI = TYI + 1;         // input patch: one more column / row for the d = 1 taps
     constexpr int CS = CI * 2 + 16;                     // bytes per cell: 3 | 5 | 9 sixteen-byte slots (odd)
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
-    constexpr int NFRAG = frag_base(CI, 8);
+    constexpr int NFRAG = FOLD ? fold_base(CI, 4) : frag_base(CI, 8);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
 
@@ -132,6 +144,50 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     // one (pz, py) row of outputs: both column parities, all pixel groups and channel tiles
     auto row = [&](auto pzc, auto pyc, int oz, const unsigned char* b0, const unsigned char* b1) {
         constexpr int PZ = decltype(pzc)::value, PY = decltype(pyc)::value;
+        if constexpr (FOLD) {
+            f4 accf[MG];
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) accf[mg] = (f4){0, 0, 0, 0};
+            int kgroup = lane >> 4;
+            asm volatile("" : "+v"(kgroup));
+            constexpr int NKB = nkb(CI, PZ, PY, 1);
+            constexpr int FB = fold_base(CI, PZ * 2 + PY);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int k0 = 32 * kb + 8 * kgroup;
+                const int t = k0 / CI, c = k0 % CI;            // taps (dz, dy, dx) of the odd column, dz-major
+                const bool real = t < ntaps(PZ, PY, 1);
+                const int dx = real ? (t & 1) : 0, dy = real ? (t >> 1) % (1 + PY) : 0, dz = real ? (t >> 1) / (1 + PY) : 0;
+                const unsigned char* buf = dz ? b1 : b0;
+                const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, wlds[(FB + kb) * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
+                    accf[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a, accf[mg], 0, 0, 0);
+                }
+            }
+            // D row (lane >> 4) * 4 + r = (column parity, channel), column = input pixel lane & 15
+            if (iy < H) {
+                const int g = lane >> 4, cb = (g & 1) * 4, px = g >> 1;
+                const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+                const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+                const int oyf = 2 * iy + PY;
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const int ix = ix0 + mg * 16 + (lane & 15);
+                    if (ix < W) {
+                        const size_t o = (((size_t)oz * (2 * H) + oyf) * OW + 2 * ix + px) * 8 + cb;   // bf16 element index
+                        f4 v = accf[mg] * sc + sh;
+                        if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                        if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                        const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
+                        *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
+                    }
+                }
+            }
+            return;
+        }
         f4 acc[2][MG][NTN];
 #pragma unroll
         for (int px = 0; px < 2; ++px)
@@ -254,12 +310,12 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     }
 }
 
-template <int CI, int NTN, int MG, bool CL>
+template <int CI, int NTN, int MG, bool CL, bool FOLD = false>
 static int launch(const T2Params& p, hipStream_t stream) {
     constexpr int TXI = 16 * MG;
     constexpr int CS = CI * 2 + 16;
-    const int lds = 2 * (TXI + 1) * (TYI + 1) * CS + frag_base(CI, 8) * NTN * 64 * 16;
-    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL>;
+    const int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16;
+    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -293,6 +349,11 @@ extern "C" int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpac
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.CO = Co; p.relu = relu;
     hipStream_t st = (hipStream_t)stream;
+    if (channel_last == 2) {   // x-folded weight packing
+        if (Ci == 16 && Co == 8) return launch<16, 1, 2, true, true>(p, st);
+        set_error("d3d_convtranspose3d_k3s2_cl_bf16: the x-folded form takes 16 -> 8 channels only");
+        return D3D_ERR_UNSUPPORTED;
+    }
     if (channel_last) {
         if (Ci == 16) return launch<16, 1, 2, true>(p, st);
         if (Ci == 32) return launch<32, 1, 2, true>(p, st);

@@ -375,6 +375,31 @@ def _pack_t2_bf16(w):
     return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_t2_fold_bf16(w):
+    """ConvTranspose3d weight [Ci,8,3,3,3] -> A operands of the x-folded form of d3d_convtranspose3d_k3s2_cl_bf16: per output
+    parity class (pz,py), K = (taps (dz,dy,dx) with dx in {0,1}, dz-major) x ci, GEMM row r = px * 8 + channel: the even
+    column (px = 0) uses kernel column 1 of the dx = 0 taps (its dx = 1 entries are zero), the odd one column 2 (dx = 0)
+    and 0 (dx = 1).  [class][K block][lane][8], lane l = row l & 15, K rows 8 * (l >> 4) .. + 7.  int16 bits (bf16)."""
+    Ci, Co = w.shape[0], w.shape[1]
+    assert Co == 8
+    kmap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+    parts = []
+    for c in range(4):
+        pz, py = c >> 1, c & 1
+        taps = [(dz, dy, dx) for dz in range(1 + pz) for dy in range(1 + py) for dx in range(2)]
+        K = len(taps) * Ci
+        nkb = (K + 31) // 32
+        b = torch.zeros((nkb * 32, 16), dtype=torch.float32, device=w.device)
+        for t, (dz, dy, dx) in enumerate(taps):
+            kz, ky = kmap[(pz, dz)], kmap[(py, dy)]
+            if dx == 0:
+                b[t * Ci:(t + 1) * Ci, 0:8] = w[:, :, kz, ky, 1]
+            b[t * Ci:(t + 1) * Ci, 8:16] = w[:, :, kz, ky, kmap[(1, dx)]]
+        b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)      # [kb][kgroup][row][j]
+        parts.append(b.reshape(nkb * 64, 8))
+    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
 def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True):
     """x [Ci,D,H,W], weight [Ci,Co,3,3,3] -> [Co,2D,2H,2W]."""
     Ci, D, H, W = x.shape
@@ -508,11 +533,13 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
     if skip is not None and (tuple(skip.shape) != oshape or skip.dtype != torch.bfloat16):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
     if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)):
-        wp = derived_weight(weight, "t2bf16", _pack_t2_bf16)
+        fold = (Ci, Co) == (16, 8) and _os.environ.get("D3D_CONV_T2_FOLD", "1") != "0"   # conv11: both column parities in one GEMM
+        wp = derived_weight(weight, "t2foldbf16", _pack_t2_fold_bf16) if fold else derived_weight(weight, "t2bf16", _pack_t2_bf16)
         out = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
         rc = _lib.load().d3d_convtranspose3d_k3s2_cl_bf16(_chk_cl(x, "x"), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
                                                           _opt(shift, "shift"), None if skip is None else _chk_cl(skip, "skip"),
-                                                          int(relu), Ci, Co, D, H, W, ctypes.c_void_p(out.data_ptr()), 1, _stream())
+                                                          int(relu), Ci, Co, D, H, W, ctypes.c_void_p(out.data_ptr()),
+                                                          2 if fold else 1, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_convtranspose3d_k3s2_cl_bf16")
             return out

@@ -257,7 +257,8 @@ int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const
  *   [C,D,H,W], 1: CL).  C_in = 8 | 16 | 32, C_out <= 16 or 32 -> 32; C_out % 4 == 0 for CL output, W % 4 == 0 for planar.
  * d3d_conv3d_k3s2_cl_bf16: stride 2, pad 1; CL in [D,H,W,Ci] -> CL out [(D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Co];
  *   8->8, 8->16, 16->16, 16->32.
- * d3d_convtranspose3d_k3s2_cl_bf16: channel_last = 1: CL in / skip / out ([2D,2H,2W,Co]); 0: the planar form above.
+ * d3d_convtranspose3d_k3s2_cl_bf16: channel_last = 1: CL in / skip / out ([2D,2H,2W,Co]); 0: the planar form above;
+ *   2: CL with the x-folded weight packing (16 -> 8 only: both output-column parities in one GEMM, ops._pack_t2_fold_bf16).
  * d3d_volume_planar_to_cl_bf16 / d3d_volume_cl_bf16_to_planar: format conversion of a volume of n voxels, C % 8 == 0 (RNE;
  *   the way back is exact) -- for the layers that stay on the planar kernels (conv5 / conv6) and for tests.
  * D3D_ERR_UNSUPPORTED for other shapes; nothing is launched then. */

@@ -1028,9 +1028,14 @@ def test_conv3d_stride2_channel_last_bf16(ops, oracle, Ci, Co, D, H, W):
 
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 2, 3, 5), (16, 8, 4, 9, 70), (32, 16, 3, 5, 64), (64, 32, 2, 9, 18), (16, 16, 5, 20, 33),
                                          (16, 8, 1, 1, 1), (32, 16, 9, 4, 130)])
-def test_convtranspose3d_channel_last_bf16(ops, oracle, Ci, Co, D, H, W):
+@pytest.mark.parametrize("fold", ["1", "0"])
+def test_convtranspose3d_channel_last_bf16(ops, oracle, monkeypatch, Ci, Co, D, H, W, fold):
     """conv7 / conv9 / conv11 of CostRegNet (cas_mvsnet.py:97-103,116-118) on d3d_convtranspose3d_k3s2_cl_bf16 with
-    channel-last bf16 input, skip and output."""
+    channel-last bf16 input, skip and output; 16 -> 8 both in the x-folded form (one GEMM for both column parities) and in
+    the per-parity form."""
+    if fold == "0" and (Ci, Co) != (16, 8):
+        pytest.skip("only 16 -> 8 has two forms")
+    monkeypatch.setenv("D3D_CONV_T2_FOLD", fold)
     rng = np.random.default_rng(Ci * 1000 + W + D)
     x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
     w = (0.1 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
