@@ -178,11 +178,49 @@ def secondary_models(reps=2):
             res[name] = {"ms_per_view": round(ms, 2), "mvoxels_per_s": round(97.05e6 / ms / 1e3, 1)}
             del net, imgs, pm, dv
             torch.cuda.empty_cache()
+        res["casmvsnet"]["regulariser"] = regulariser_leg()
     finally:
         ops.set_conv_precision(old)
     res["config"] = "config 3: full cascade forward, 5 views, 2752x1856, ndepths 48/32/8, bf16 regulariser operands (fp32 accumulate), synthetic"
-    res["casmvsnet"]["regulariser_flop"] = 1.264e12   # 632.2 GMAC of 3D convolution per view
     return res
+
+
+def regulariser_leg(reps=5):
+    """The three CostRegNets of a CasMVSNet view alone (bf16 mode, channel-last bf16 activations, the volume as the sweep
+    kernel leaves it): ms, algorithmic HBM bytes (every layer reads its input and skip once and writes its output once, in
+    the formats they travel in) against 8 TB/s, and the 3-D convolution FLOPs against the 2.5 PFLOP/s dense bf16 peak."""
+    from deep3d_aerial_amd.cas_mvsnet import CostRegNet
+
+    total_ms, total_bytes, total_flop = 0.0, 0.0, 0.0
+    for C, D, h, w in ((32, 48, 464, 688), (16, 32, 928, 1376), (8, 8, 1856, 2752)):
+        net = CostRegNet(C).cuda().eval()
+        S.fill_state_dict_(net.state_dict(), 3)
+        vol = torch.randn(D, h, w, C, device="cuda").to(torch.bfloat16)
+        with torch.no_grad():
+            net.forward_one(vol)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                net.forward_one(vol)
+            e1.record()
+            torch.cuda.synchronize()
+        total_ms += e0.elapsed_time(e1) / reps
+        v = D * h * w
+        # (C_in, C_out, input voxels, output voxels, skip): conv0..conv6, conv7/9/11 (transposed, with skip), prob
+        layers = [(C, 8, v, v, 0), (8, 16, v, v // 8, 0), (16, 16, v // 8, v // 8, 0), (16, 32, v // 8, v // 64, 0),
+                  (32, 32, v // 64, v // 64, 0), (32, 64, v // 64, v // 512, 0), (64, 64, v // 512, v // 512, 0),
+                  (64, 32, v // 512, v // 64, 1), (32, 16, v // 64, v // 8, 1), (16, 8, v // 8, v, 1)]
+        for ci, co, vi, vo, sk in layers:
+            total_bytes += 2.0 * ci * vi + 2.0 * co * vo * (1 + sk)
+            total_flop += 2.0 * 27 * ci * co * (vo if vo <= vi else vi)   # a transposed layer does 27 MACs per INPUT voxel and channel pair
+        total_bytes += 2.0 * 8 * v + 4.0 * v            # prob: channel-last in, fp32 plane out
+        total_flop += 2.0 * 27 * 8 * v
+        del net, vol
+        torch.cuda.empty_cache()
+    return {"ms": round(total_ms, 2), "algorithmic_bytes": int(total_bytes), "gbps": round(total_bytes / total_ms / 1e6, 1),
+            "hbm_frac": round(total_bytes / total_ms / 1e6 / 8000.0, 3), "flop": total_flop,
+            "tflops": round(total_flop / total_ms / 1e9, 1), "mfma_frac": round(total_flop / total_ms / 1e9 / 2500.0, 4),
+            "formats": "channel-last bf16 activations, fp32 probability volume out"}
 
 
 def main():

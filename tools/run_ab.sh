@@ -2,7 +2,7 @@
 # GPU box: bench the tiled sweep kernel built with each given set of -D flags, e.g.
 #   tools/run_ab.sh "-DRING_ALIGN=0" "-DRING_ALIGN=1"
 # Variants are built with -DD3D_EXPERIMENTS (the D3D_TILED_* switches and the cycle statistics exist only there).
-# C5=f16|f32 runs tools/config5_bench.py instead of bench.py.  PMC=1 adds one rocprofv3 counter pass (LDS conflicts / activity, VALU instructions) per variant.
+# C5=f16|f32 runs tools/config5_bench.py instead of bench.py; CMD="..." runs that command instead (statistics on).  PMC=1 adds one rocprofv3 counter pass (LDS conflicts / activity, VALU instructions) per variant.
 # The variant library is linked from the Makefile's object list and the clean library is restored on exit.
 CS=deep3d_aerial_amd/csrc
 cp $CS/libdeep3d_planesweep.so /tmp/keep.so
@@ -11,7 +11,9 @@ OBJS=$(make -s -C $CS print-objs)
 for flags in "$@"; do
   (cd $CS && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -w -DD3D_EXPERIMENTS $flags -c -o /tmp/v.o planesweep_tiled.hip \
     && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o libdeep3d_planesweep.so $(echo $OBJS | sed 's#planesweep_tiled.o#/tmp/v.o#')) || { echo "build failed: $flags"; continue; }
-  if [ -n "$C5" ]; then   # BASELINE config 5 shape instead of the bench (C5=f16|f32)
+  if [ -n "$CMD" ]; then   # any other command (e.g. CMD="python tools/stage_sweep_bench.py tiled"), with the cycle statistics on
+    D3D_TILED_STATS=1 $CMD 2>&1 | grep -av amdgpu.ids | cut -c1-400
+  elif [ -n "$C5" ]; then   # BASELINE config 5 shape instead of the bench (C5=f16|f32)
     D3D_TILED_STATS=1 D3D_FORCE_PATH=tiled python tools/config5_bench.py $C5 tiled 2>&1 | grep -a "per-WG\|tiled stats\|config 5" | tail -3 | cut -c1-330
   else
   D3D_TILED_STATS=1 python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep -a "per-WG\|tiled stats" | head -2 | cut -c1-330

@@ -24,7 +24,7 @@ for (tag, C, D, sc, perpix) in [("stage1", 32, 48, 4, False), ("stage2", 16, 32,
     else:
         depth = torch.from_numpy(S.uniform_depths(dv, D)).cuda()
     vw = torch.rand(4, h, w, device="cuda")
-    for path in ("tiled", "direct"):
+    for path in (sys.argv[1:] or ("tiled", "direct")):
         os.environ["D3D_FORCE_PATH"] = path
         try:
             t1 = timeit(lambda: ops.variance_volume(feats, p34, depth))
