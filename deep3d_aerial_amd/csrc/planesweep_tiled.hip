@@ -320,8 +320,13 @@ __device__ __forceinline__ float ldf(const __half* q) { return __half2float(*q);
 // is fp32 (v_fma_mix_f32 reads the fp16 tap directly), the result is rounded once (RNE) at the store.
 // OUTCL: the variance volume leaves as a channel-last bf16 volume [D][h][w][C] (RNE) -- the form conv0 of the 3-D
 // regulariser stages in bf16 mode (conv_c8.hip); four channels of a voxel = one 8-byte store instead of four 4-byte ones.
-template <int MODE, int NSRC, int CH, typename T = float, bool OUTCL = false>
-__global__ __launch_bounds__(THREADS) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {
+// NSUB_T / NLOAD_T: depth sub-ranges and loader waves of a workgroup.  The default (4 + 4: 12 waves, all of a CU's LDS) is
+// sized for deep sweeps; SHALLOW sweeps (the last cascade stage: 8 planes) run 2 + 2 = 6 waves on half the LDS, so TWO
+// workgroups share a CU and one's planning prologue and first-window latency (most of its life: 47 % + 40 % at 8 planes)
+// overlap the other's arithmetic.
+template <int MODE, int NSRC, int CH, typename T = float, bool OUTCL = false, int NSUB_T = D3D_NSUB, int NLOAD_T = D3D_NLOADW>
+__global__ __launch_bounds__(64 * (NPIXW * NSUB_T + NLOAD_T), 3) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {   // 3 waves per SIMD: the 168-register budget for either workgroup size
+    constexpr int NSUB = NSUB_T, NLOADW = NLOAD_T, NCOMP = NPIXW * NSUB, NWAVES = NCOMP + NLOADW, THREADS = 64 * NWAVES;   // (shadow the defaults)
     constexpr bool F16 = sizeof(T) == 2;
     static_assert(!OUTCL || (MODE == MODE_VARIANCE && !F16), "channel-last bf16 output is built for the fp32 variance volume");
     constexpr int CW = CH * (int)sizeof(T) / 4;   // words per ring position
@@ -1250,12 +1255,19 @@ size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_byt
     return (size_t)n_src * C * h * w * elem_bytes;
 }
 
-template <int MODE, int NSRC, int CH, typename T, bool OUTCL = false>
+#ifndef D3D_SHALLOW_PLANES
+#define D3D_SHALLOW_PLANES 16   // sweeps of at most this many planes take the 6-wave workgroups (0: never)
+#endif
+constexpr int SHALLOW_NSUB = 2, SHALLOW_NLOADW = 2, SHALLOW_PLANES = D3D_SHALLOW_PLANES;
+
+template <int MODE, int NSRC, int CH, typename T, bool OUTCL = false, bool SHALLOW = false>
 static int launch_one(const SweepParams& p, hipStream_t stream) {
     constexpr int CW = CH * (int)sizeof(T) / 4;
     using L = Lds<CW, NSRC>;
-    constexpr int LDS_BYTES = 160 * 1024;
-    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T, OUTCL>;
+    constexpr int LDS_BYTES = SHALLOW ? 80 * 1024 : 160 * 1024;
+    constexpr int NSUBK = SHALLOW ? SHALLOW_NSUB : NSUB, NLOADK = SHALLOW ? SHALLOW_NLOADW : NLOADW;
+    constexpr int THREADSK = 64 * (NPIXW * NSUBK + NLOADK);
+    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T, OUTCL, NSUBK, NLOADK>;
     if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
     // per device and idempotent: set on every launch (no process-global "done" flag that a second GPU would miss)
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
@@ -1297,7 +1309,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         a.tstats = reinterpret_cast<unsigned long long*>(a.stats + 8);
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(THREADS), LDS_BYTES, stream, p, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(THREADSK), LDS_BYTES, stream, p, a);
     D3D_LAUNCH_CHECK("sweep_tiled_kernel launch");
 #ifdef D3D_EXPERIMENTS
     if (a.stats) {
@@ -1311,7 +1323,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         fprintf(stderr, "[d3d tiled timing] prologue phases: depth range %.0f | candidate windows %.0f | plan tables %.0f (rest: per-lane constants)\n",
                 ht[16] / (double)nblk, ht[17] / (double)nblk, ht[18] / (double)nblk);
         fprintf(stderr, "[d3d tiled timing] barrier wait after the first, per compute wave (pixel rows, depth sub-range):");
-        for (int wv = 0; wv < NCOMP; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
+        for (int wv = 0; wv < NPIXW * NSUBK; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
         fprintf(stderr, "\n");
         fprintf(stderr, "[d3d tiled stats] CH=%d elem=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) dseg=%d\n",
                 CH, (int)sizeof(T), nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
@@ -1336,8 +1348,19 @@ static int group_channels(int C, int n_src, int elem_bytes) {
 template <int MODE, int NSRC>
 static int launch_ch(const SweepParams& p, hipStream_t stream) {
     const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src, 4);
+    // shallow sweeps of 8-channel groups (the full-resolution cascade stage): two half-size workgroups per CU.  Measured at
+    // 8 planes x 1856 x 2752, 5 views (tools/run_ab.sh NOEXP=1 "-DD3D_SHALLOW_PLANES=0|16"): weighted correlation 2.70 -> 2.25 ms,
+    // variance 2.41 -> 3.06 ms -- so only the weighted mode takes them (D3D_SHALLOW_VARIANCE=1 builds the other for A/B).
+#ifndef D3D_SHALLOW_VARIANCE
+#define D3D_SHALLOW_VARIANCE 0
+#endif
+    bool shallow = p.D <= SHALLOW_PLANES && cg == 8 && (MODE == MODE_WEIGHTED || D3D_SHALLOW_VARIANCE);
+#ifdef D3D_EXPERIMENTS
+    if (const char* e = getenv("D3D_TILED_SHALLOW")) shallow = shallow && atoi(e) != 0;
+#endif
     if constexpr (MODE == MODE_VARIANCE) {
         if (p.out_cl) {
+            if (shallow) return launch_one<MODE, NSRC, 8, float, true, true>(p, stream);
             switch (cg) {
                 case 16: return launch_one<MODE, NSRC, 16, float, true>(p, stream);
                 case 8: return launch_one<MODE, NSRC, 8, float, true>(p, stream);
@@ -1346,6 +1369,9 @@ static int launch_ch(const SweepParams& p, hipStream_t stream) {
         }
     }
     if (p.out_cl) return D3D_ERR_UNSUPPORTED;
+    if constexpr (MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED) {
+        if (shallow) return launch_one<MODE, NSRC, 8, float, false, true>(p, stream);
+    }
     switch (cg) {
         case 32: return launch_one<MODE, NSRC, 32, float>(p, stream);
         case 16: return launch_one<MODE, NSRC, 16, float>(p, stream);

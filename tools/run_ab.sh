@@ -8,11 +8,13 @@ CS=deep3d_aerial_amd/csrc
 cp $CS/libdeep3d_planesweep.so /tmp/keep.so
 trap 'cp /tmp/keep.so $GRAFT_REPO_ROOT/'$CS'/libdeep3d_planesweep.so' EXIT
 OBJS=$(make -s -C $CS print-objs)
+EXP=-DD3D_EXPERIMENTS
+[ -n "$NOEXP" ] && EXP=   # NOEXP=1: the production build of the variant (no cycle counters in the kernel)
 for flags in "$@"; do
-  (cd $CS && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -w -DD3D_EXPERIMENTS $flags -c -o /tmp/v.o planesweep_tiled.hip \
+  (cd $CS && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -w $EXP $flags -c -o /tmp/v.o planesweep_tiled.hip \
     && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o libdeep3d_planesweep.so $(echo $OBJS | sed 's#planesweep_tiled.o#/tmp/v.o#')) || { echo "build failed: $flags"; continue; }
   if [ -n "$CMD" ]; then   # any other command (e.g. CMD="python tools/stage_sweep_bench.py tiled"), with the cycle statistics on
-    D3D_TILED_STATS=1 $CMD 2>&1 | grep -av amdgpu.ids | cut -c1-400
+    echo "[$flags]"; D3D_TILED_STATS=1 $CMD 2>&1 | grep -av amdgpu.ids | cut -c1-400
   elif [ -n "$C5" ]; then   # BASELINE config 5 shape instead of the bench (C5=f16|f32)
     D3D_TILED_STATS=1 D3D_FORCE_PATH=tiled python tools/config5_bench.py $C5 tiled 2>&1 | grep -a "per-WG\|tiled stats\|config 5" | tail -3 | cut -c1-330
   else

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 S="$GRAFT_REPO_ROOT/$1"; shift
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $S "$@" > $out/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc1 -- python3 $S "$@" > $out/pmc1.log 2>&1
-rocprofv3 --pmc FETCH_SIZE WRITE_SIZE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY --output-format csv -d $out/pmc2 -- python3 $S "$@" > $out/pmc2.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY --output-format csv -d $out/pmc2 -- python3 $S "$@" > $out/pmc2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_INSTS_SMEM --output-format csv -d $out/pmc3 -- python3 $S "$@" > $out/pmc3.log 2>&1
 python3 - <<PY
 import csv, glob, collections
