@@ -1256,7 +1256,7 @@ size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_byt
 }
 
 #ifndef D3D_SHALLOW_PLANES
-#define D3D_SHALLOW_PLANES 16   // sweeps of at most this many planes take the 6-wave workgroups (0: never)
+#define D3D_SHALLOW_PLANES 0    // sweeps of at most this many planes take the 6-wave workgroups (0: never -- see launch_ch)
 #endif
 constexpr int SHALLOW_NSUB = 2, SHALLOW_NLOADW = 2, SHALLOW_PLANES = D3D_SHALLOW_PLANES;
 
@@ -1349,8 +1349,9 @@ template <int MODE, int NSRC>
 static int launch_ch(const SweepParams& p, hipStream_t stream) {
     const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src, 4);
     // shallow sweeps of 8-channel groups (the full-resolution cascade stage): two half-size workgroups per CU.  Measured at
-    // 8 planes x 1856 x 2752, 5 views (tools/run_ab.sh NOEXP=1 "-DD3D_SHALLOW_PLANES=0|16"): weighted correlation 2.70 -> 2.25 ms,
-    // variance 2.41 -> 3.06 ms -- so only the weighted mode takes them (D3D_SHALLOW_VARIANCE=1 builds the other for A/B).
+    // 8 planes x 1856 x 2752, 5 views (tools/run_ab.sh NOEXP=1 "-DD3D_SHALLOW_PLANES=0|16"): weighted correlation 2.70 -> 2.25 ms
+    // and variance 2.41 -> 3.06 ms on the bench scene, but 2.85 -> 5.4 ms inside an AdaMVS view, whose wider windows no longer
+    // fit half the LDS (gather fallback).  Off by default (D3D_SHALLOW_PLANES=0); kept as an A/B build.
 #ifndef D3D_SHALLOW_VARIANCE
 #define D3D_SHALLOW_VARIANCE 0
 #endif
@@ -1360,7 +1361,7 @@ static int launch_ch(const SweepParams& p, hipStream_t stream) {
 #endif
     if constexpr (MODE == MODE_VARIANCE) {
         if (p.out_cl) {
-            if (shallow) return launch_one<MODE, NSRC, 8, float, true, true>(p, stream);
+            if constexpr (SHALLOW_PLANES > 0) { if (shallow) return launch_one<MODE, NSRC, 8, float, true, true>(p, stream); }
             switch (cg) {
                 case 16: return launch_one<MODE, NSRC, 16, float, true>(p, stream);
                 case 8: return launch_one<MODE, NSRC, 8, float, true>(p, stream);
@@ -1369,9 +1370,10 @@ static int launch_ch(const SweepParams& p, hipStream_t stream) {
         }
     }
     if (p.out_cl) return D3D_ERR_UNSUPPORTED;
-    if constexpr (MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED) {
+    if constexpr (SHALLOW_PLANES > 0 && (MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED)) {
         if (shallow) return launch_one<MODE, NSRC, 8, float, false, true>(p, stream);
     }
+    (void)shallow;
     switch (cg) {
         case 32: return launch_one<MODE, NSRC, 32, float>(p, stream);
         case 16: return launch_one<MODE, NSRC, 16, float>(p, stream);

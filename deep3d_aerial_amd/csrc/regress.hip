@@ -38,6 +38,60 @@ __global__ __launch_bounds__(256) void softargmin_conf4_kernel(const float* __re
     conf_out[i] = conf * inv;
 }
 
+// ucsnet.py:137-151 (compute_depth of UCS-Net): the same soft-argmin and 4-plane confidence, plus the spread of the
+// distribution around the regressed depth, exp_variance = lamb * sqrt(sum_d p_d (dv_d - depth)^2) -- one more sweep over D.
+__global__ __launch_bounds__(256) void softargmin_conf4_var_kernel(const float* __restrict__ cost,
+                                                                    const float* __restrict__ depth, int depth_mode,
+                                                                    int D, long plane, float lamb,
+                                                                    float* __restrict__ depth_out,
+                                                                    float* __restrict__ conf_out,
+                                                                    float* __restrict__ var_out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, cost[d * plane + i]);
+    float den = 0.0f, dep = 0.0f, idx = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        float e = __expf(cost[d * plane + i] - mx);
+        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
+        den += e;
+        dep = fmaf(e, dv, dep);
+        idx = fmaf(e, (float)d, idx);
+    }
+    float inv = 1.0f / den;
+    int k = (int)(idx * inv);
+    k = min(max(k, 0), D - 1);
+    float conf = 0.0f;
+#pragma unroll
+    for (int j = -1; j <= 2; ++j) {
+        int kk = k + j;
+        if (kk >= 0 && kk < D) conf += __expf(cost[kk * plane + i] - mx);
+    }
+    const float depth_v = dep * inv;
+    float var = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        float e = __expf(cost[d * plane + i] - mx);
+        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
+        float t = dv - depth_v;
+        var = fmaf(t * t, e * inv, var);
+    }
+    depth_out[i] = depth_v;
+    conf_out[i] = conf * inv;
+    var_out[i] = lamb * sqrtf(var);
+}
+
+// ucsnet.py:42-51 (uncertainty_aware_samples, later stages): per pixel D hypotheses low + step * i + 1e-12 between
+// cur - var and cur + var, step = (high - low) / (D - 1).
+__global__ __launch_bounds__(256) void uncertainty_samples_kernel(const float* __restrict__ cur, const float* __restrict__ var,
+                                                                   int D, long plane, float* __restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const float c = cur[i], v = var[i];
+    const float low = c - v, high = c + v;
+    const float step = (high - low) / ((float)D - 1.0f);
+    for (int d = 0; d < D; ++d) out[d * plane + i] = low + step * (float)d + 1e-12f;
+}
+
 // adamvs.py:478-486: softmax over D, max prob, expected depth.
 __global__ __launch_bounds__(256) void pair_softmax_max_kernel(const float* __restrict__ score,
                                                                 const float* __restrict__ depth, int depth_mode,
@@ -268,6 +322,29 @@ int d3d_softargmin_conf4(const float* cost, const float* depth, int depth_mode, 
     hipLaunchKernelGGL(softargmin_conf4_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cost,
                        depth, depth_mode, D, plane, depth_out, conf_out);
     D3D_LAUNCH_CHECK("softargmin_conf4_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_softargmin_conf4_var(const float* cost, const float* depth, int depth_mode, int D, int h, int w, float lamb,
+                             float* depth_out, float* conf_out, float* var_out, d3d_stream_t stream) {
+    D3D_REQUIRE(cost && depth && depth_out && conf_out && var_out, "null pointer");
+    D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
+    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    long plane = (long)h * w;
+    hipLaunchKernelGGL(softargmin_conf4_var_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cost,
+                       depth, depth_mode, D, plane, lamb, depth_out, conf_out, var_out);
+    D3D_LAUNCH_CHECK("softargmin_conf4_var_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_uncertainty_samples(const float* cur_depth, const float* exp_var, int D, int h, int w, float* out,
+                            d3d_stream_t stream) {
+    D3D_REQUIRE(cur_depth && exp_var && out, "null pointer");
+    D3D_REQUIRE(D > 1 && h > 0 && w > 0, "need D > 1 and positive dims (D=%d h=%d w=%d)", D, h, w);
+    long plane = (long)h * w;
+    hipLaunchKernelGGL(uncertainty_samples_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cur_depth,
+                       exp_var, D, plane, out);
+    D3D_LAUNCH_CHECK("uncertainty_samples_kernel launch");
     return D3D_OK;
 }
 

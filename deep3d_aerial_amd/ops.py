@@ -227,6 +227,38 @@ def softargmin_conf4(cost, depth):
     return dep, conf
 
 
+def softargmin_conf4_var(cost, depth, lamb):
+    """cost [D,h,w] -> (depth, confidence, exp_variance) each [h,w] (ucsnet.py:137-151)."""
+    D, h, w = cost.shape
+    dp, mode, D2 = _depth(depth, h, w)
+    if D2 != D:
+        raise ValueError("depth has %d planes, cost has %d" % (D2, D))
+    dep = torch.empty((h, w), dtype=torch.float32, device=cost.device)
+    conf, var = torch.empty_like(dep), torch.empty_like(dep)
+    rc = _lib.load().d3d_softargmin_conf4_var(_chk(cost, "cost", 3), dp, mode, D, h, w, float(lamb), _chk(dep, "dep"),
+                                              _chk(conf, "conf"), _chk(var, "var"), _stream())
+    _lib.check(rc, "d3d_softargmin_conf4_var")
+    return dep, conf, var
+
+
+def uncertainty_aware_samples(cur_depth, exp_var, ndepth, shape=None):
+    """ucsnet.py:30-53.  First stage: cur_depth [2+] = (min, ..., max) -> uniform hypotheses [ndepth] (the reference tiles
+    them to [ndepth,h,w]; the sweep kernels take the per-plane form).  Later stages: cur_depth, exp_var [h,w] ->
+    [ndepth,h,w] hypotheses between cur - var and cur + var."""
+    if cur_depth.dim() == 1:
+        return depth_range_samples(cur_depth, ndepth, 0.0)
+    if ndepth <= 1:
+        raise ValueError("ndepth must be > 1")
+    h, w = cur_depth.shape
+    if exp_var is None or tuple(exp_var.shape) != (h, w):
+        raise ValueError("exp_var must be [%d,%d]" % (h, w))
+    out = torch.empty((ndepth, h, w), dtype=torch.float32, device=cur_depth.device)
+    rc = _lib.load().d3d_uncertainty_samples(_chk(cur_depth, "cur_depth", 2), _chk(exp_var, "exp_var", 2), ndepth, h, w,
+                                             _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_uncertainty_samples")
+    return out
+
+
 def pair_softmax_max(score, depth):
     """score [D,h,w] -> (view_weight [h,w], pair_depth [h,w]) (adamvs.py:478-486)."""
     D, h, w = score.shape

@@ -220,7 +220,11 @@ def build_model(name, numdepth, ndepths=(48, 32, 8), depth_inter_r=(4, 2, 1), sh
         return Infer_CascadeREDNet(num_depth=numdepth, ndepths=list(ndepths),
                                    depth_intervals_ratio=list(depth_inter_r), share_cr=share_cr,
                                    cr_base_chs=list(cr_base_chs))
-    # ucsnet cannot be constructed by the reference's own predict.py call
+    if name == "ucsnet":
+        # the reference's own call (predict.py:78-81) fails in the constructor (no `num_depth` argument, and
+        # forward reads self.num_depth); here the class takes it, so `--model ucsnet` runs
+        from .ucsnet import Infer_UCSNet
+        return Infer_UCSNet(lamb=1.5, num_depth=numdepth, ndepths=list(ndepths))
     raise Exception("{}? Not implemented yet!".format(name))
 
 
@@ -397,7 +401,7 @@ def parse_args(argv=None):
     """Every flag of the reference's harness (predict.py:30-58) with its default, plus --synthetic_items /
     --random_weights / --feature_cache_gb of this package."""
     ap = argparse.ArgumentParser(description="plane-sweep depth inference (predict.py-compatible flags)")
-    ap.add_argument("--model", default="adamvs", help="casmvsnet | msrednet | adamvs (ucsnet: broken in the reference, SURVEY F7)")
+    ap.add_argument("--model", default="adamvs", help="casmvsnet | msrednet | adamvs | ucsnet")
     ap.add_argument("--dataset", default="cas_normal_eval", help="dataset class (only the inference dataset exists here)")
     ap.add_argument("--data_folder", default=None, help="block folder: viewpair.txt images.txt cameras.txt image_path.txt")
     ap.add_argument("--output_folder", required=True)

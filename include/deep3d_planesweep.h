@@ -396,6 +396,17 @@ int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* st
 int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* u,
                       const float* h, int Hc, int64_t plane, float eps, float* h_out, d3d_stream_t stream);
 
+/* ucsnet.py:137-151 (compute_depth of UCS-Net): d3d_softargmin_conf4 plus the spread of the per-pixel distribution,
+ * var_out = lamb * sqrt(sum_d softmax(cost)_d * (depth_d - depth_out)^2)  [h,w]. */
+int d3d_softargmin_conf4_var(const float* cost, const float* depth, int depth_mode, int D, int h, int w, float lamb,
+                             float* depth_out, float* conf_out, float* var_out, d3d_stream_t stream);
+
+/* ucsnet.py:42-51 (uncertainty_aware_samples, stages after the first): out[d,y,x] = low + step * d + 1e-12 with
+ * low = cur - var, step = ((cur + var) - low) / (D - 1); cur_depth, exp_var [h,w] -> out [D,h,w].  (The first stage's
+ * uniform hypotheses, ucsnet.py:33-41, are d3d_depth_range_samples in per-plane mode: the same formula.) */
+int d3d_uncertainty_samples(const float* cur_depth, const float* exp_var, int D, int h, int w, float* out,
+                            d3d_stream_t stream);
+
 /*
  * adamvs.py:478-486 -- per-pair softmax over D, view weight = max_D prob,
  * pair depth = SUM_D prob*d.  score [D,h,w], depth [D] or [D,h,w].

@@ -142,6 +142,35 @@ def softargmin_conf4(cost, depth):
     return dep, conf
 
 
+def softargmin_conf4_var(cost, depth, lamb):
+    """ucsnet.py:137-151 (compute_depth): softmax over D, expected depth, 4-plane confidence at the expected index, and
+    exp_variance = lamb * sqrt(sum_d p_d (depth_d - depth)^2).  numpy restatement (fp32 arithmetic, in the reference's order)."""
+    cost = _c(cost)
+    D, h, w = cost.shape
+    depth, is_map, D2 = _depth_args(depth, h, w)
+    assert D2 == D
+    dv = depth.reshape(D, h, w) if is_map else np.broadcast_to(depth.reshape(D, 1, 1), (D, h, w))
+    dep, conf = softargmin_conf4(cost, depth)
+    e = np.exp(cost - cost.max(0, keepdims=True), dtype=np.float32)
+    prob = (e / e.sum(0, keepdims=True, dtype=np.float32)).astype(np.float32)
+    samp = ((dv - dep[None]) ** 2).astype(np.float32)
+    var = np.float32(lamb) * np.sqrt((samp * prob).sum(0, dtype=np.float32), dtype=np.float32)
+    return dep, conf, var.astype(np.float32)
+
+
+def uncertainty_aware_samples(cur_depth, exp_var, ndepth):
+    """ucsnet.py:30-53.  cur_depth [2+] (first stage): min + arange(ndepth) * (max - min) / (ndepth - 1) -> [ndepth];
+    cur_depth, exp_var [h,w]: low + step * i + 1e-12, low = cur - var, step = ((cur + var) - low) / (ndepth - 1)."""
+    cur = np.asarray(cur_depth, np.float32)
+    if cur.ndim == 1:
+        interval = np.float32((cur[-1] - cur[0]) / np.float32(ndepth - 1))
+        return (cur[0] + np.arange(ndepth, dtype=np.float32) * interval).astype(np.float32)
+    var = np.asarray(exp_var, np.float32)
+    low, high = cur - var, cur + var
+    step = ((high - low) / np.float32(float(ndepth) - 1)).astype(np.float32)
+    return np.stack([(low + step * np.float32(i) + np.float32(1e-12)).astype(np.float32) for i in range(int(ndepth))])
+
+
 def resize_bilinear(x, H, W):
     x = _c(x)
     h, w = x.shape

@@ -38,6 +38,7 @@ from models import module as RM  # noqa: E402
 from models import adamvs as RA  # noqa: E402
 from models import cas_mvsnet as RC  # noqa: E402
 from models import msrednet as RR  # noqa: E402
+from models import ucsnet as RU  # noqa: E402
 
 T = torch.from_numpy
 
@@ -406,8 +407,57 @@ def gen_models(only=None):
         save(tag, **out)
 
 
+def gen_ucsnet():
+    """UCS-Net (ucsnet.py): uncertainty_aware_samples both branches (30-53), the variance tail of compute_depth (137-151),
+    and Infer_UCSNet end to end.  The class is built with its own constructor arguments; `num_depth`, which forward reads
+    but nothing sets, is assigned as an attribute -- the reference's code is otherwise run as it is."""
+    out = {}
+    rng = np.random.default_rng(900)
+    dv2 = np.array([[400.0, 800.0]], np.float32)
+    s1 = RU.uncertainty_aware_samples(T(dv2), None, 48, torch.device("cpu"), torch.float32, [1, 6, 10])
+    out["s1_depth_values"], out["s1_samples"] = dv2[0], s1[0].numpy()
+    cur = (600 + 50 * rng.standard_normal((1, 1, 12, 20))).astype(np.float32)
+    var = np.abs(8 * rng.standard_normal((1, 1, 12, 20))).astype(np.float32)
+    s2 = RU.uncertainty_aware_samples(T(cur), T(var), 8, torch.device("cpu"), torch.float32, [1, 12, 20])
+    out["s2_cur"], out["s2_var"], out["s2_samples"] = cur[0, 0], var[0, 0], s2[0].numpy()
+    # tail of compute_depth on a given probability-volume pre-activation
+    D, h, w = 16, 10, 14
+    pre = (2.0 * rng.standard_normal((1, D, h, w))).astype(np.float32)
+    pre[0, :, 0, 0] = -30.0; pre[0, 3, 0, 0] = 30.0      # a peaked column
+    samps = np.sort(rng.uniform(400, 800, (1, D, h, w)).astype(np.float32), 1)
+    prob = F.softmax(T(pre), dim=1)
+    depth = RM.depth_regression(prob, depth_values=T(samps))
+    samp_variance = (T(samps) - depth.unsqueeze(1)) ** 2
+    exp_variance = 1.5 * torch.sum(samp_variance * prob, dim=1, keepdim=False) ** 0.5
+    out["cd_pre"], out["cd_samps"], out["cd_depth"], out["cd_variance"] = pre[0], samps[0], depth[0].numpy(), exp_variance[0].numpy()
+    save("ops_ucsnet", **out)
+
+    for tag, V, nd, seed in [("model_ucsnet_v3", 3, 64, 7011), ("model_ucsnet_v5", 5, 384, 7012)]:
+        H, W = 64, 96
+        net = RU.Infer_UCSNet().eval()
+        net.num_depth = nd
+        S.fill_state_dict_(net.state_dict(), seed)
+        imgs, pm, dv = model_inputs(V, H, W, nd, seed)
+        with torch.no_grad():
+            o = net(T(imgs), {k: T(v) for k, v in pm.items()}, T(dv))
+        res = {"imgs": imgs, "depth_values": dv, "seed": np.array(seed), "num_depth": np.array(nd),
+               "n_state_keys": np.array(len(net.state_dict())),
+               "state_keys": np.array(list(net.state_dict().keys())),
+               "state_shapes": np.array([",".join(map(str, v.shape)) for v in net.state_dict().values()])}
+        for k, v in pm.items():
+            res["proj_" + k] = v
+        res["depth"] = o["depth"][0].numpy()
+        res["photometric_confidence"] = o["photometric_confidence"][0].numpy()
+        res["variance"] = o["variance"][0].numpy()
+        for st in ("stage1", "stage2", "stage3"):
+            res[st + "_depth"] = o[st]["depth"][0].numpy()
+            res[st + "_conf"] = o[st]["photometric_confidence"][0].numpy()
+            res[st + "_variance"] = o[st]["variance"][0].numpy()
+        save(tag, **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models"]
+    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models", "ucsnet"]
     for wname in which:
         if wname.startswith("model_"):
             gen_models(only=[wname])

@@ -67,6 +67,20 @@ def test_softargmin_conf4(oracle):
         assert np.abs(conf - g[k + "conf"]).max() <= 2e-6, i
 
 
+def test_ucsnet_samples_and_variance(oracle):
+    """UCS-Net pieces of row a10 / a9 (ucsnet.py:30-53, 137-151) against the reference's own outputs."""
+    g = load_golden("ops_ucsnet")
+    s1 = oracle.uncertainty_aware_samples(g["s1_depth_values"], None, g["s1_samples"].shape[0])
+    assert np.array_equal(s1, g["s1_samples"][:, 0, 0])
+    assert (g["s1_samples"] == g["s1_samples"][:, :1, :1]).all()          # the reference tiles the same D values per pixel
+    s2 = oracle.uncertainty_aware_samples(g["s2_cur"], g["s2_var"], g["s2_samples"].shape[0])
+    assert np.array_equal(s2, g["s2_samples"])
+    dep, conf, var = oracle.softargmin_conf4_var(g["cd_pre"], g["cd_samps"], 1.5)
+    assert rel_l1(dep, g["cd_depth"]) <= REL
+    assert np.abs(var - g["cd_variance"]).max() <= 2e-4 * max(1.0, float(np.abs(g["cd_variance"]).max()))
+    assert var[0, 0] <= 1e-2 * float(g["cd_variance"].max())           # the peaked column has (almost) no spread
+
+
 def test_online_regression_and_upsample(oracle):
     g = load_golden("ops_regress")
     for i in range(int(g["n_online"])):

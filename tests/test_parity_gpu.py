@@ -630,6 +630,47 @@ def test_pairnet_golden(ops, convpath):
 # ----------------------------------------------------------------------------------------
 # full cascades behind the reference's forward() contract, vs the reference's own outputs
 # ----------------------------------------------------------------------------------------
+def test_ucsnet_samples_and_variance(ops, oracle):
+    """ucsnet.py:30-53 (uncertainty_aware_samples) and :137-151 (variance tail of compute_depth) on the device, against the
+    reference's outputs and the oracle."""
+    g = load_golden("ops_ucsnet")
+    D1 = g["s1_samples"].shape[0]
+    s1 = host(ops.uncertainty_aware_samples(dev(g["s1_depth_values"]), None, D1))
+    assert np.abs(s1 - g["s1_samples"][:, 0, 0]).max() <= 1e-4
+    s2 = host(ops.uncertainty_aware_samples(dev(g["s2_cur"]), dev(g["s2_var"]), g["s2_samples"].shape[0]))
+    assert np.abs(s2 - g["s2_samples"]).max() <= 1e-4 and s2.shape == g["s2_samples"].shape
+    dep, conf, var = [host(t) for t in ops.softargmin_conf4_var(dev(g["cd_pre"]), dev(g["cd_samps"]), 1.5)]
+    odep, oconf, ovar = oracle.softargmin_conf4_var(g["cd_pre"], g["cd_samps"], 1.5)
+    assert rel_l1(dep, g["cd_depth"]) <= 1e-5
+    assert np.abs(conf - oconf).max() <= 1e-5
+    assert np.abs(var - g["cd_variance"]).max() <= 2e-4 * float(np.abs(g["cd_variance"]).max())
+    assert np.abs(var - ovar).max() <= 2e-4 * float(np.abs(ovar).max())
+    with pytest.raises(ValueError):
+        ops.uncertainty_aware_samples(dev(g["s2_cur"]), dev(g["s2_var"][:3]), 8)
+
+
+@pytest.mark.parametrize("tag", ["model_ucsnet_v3", "model_ucsnet_v5"])
+def test_ucsnet_forward_matches_reference(ops, tag):
+    """Infer_UCSNet (ucsnet.py:234-311) behind the reference's forward() contract: per-stage depth, confidence and the
+    uncertainty that sizes the next stage's hypotheses, against the reference's own outputs; the state_dict keys are the
+    reference's."""
+    from deep3d_aerial_amd.ucsnet import Infer_UCSNet
+
+    g = load_golden(tag)
+    net = Infer_UCSNet(num_depth=int(g["num_depth"]))
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    net = _fill(net, int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    with torch.no_grad():
+        out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    for s in ("stage1", "stage2", "stage3"):
+        assert rel_l1(host(out[s]["depth"][0]), g[s + "_depth"]) <= REL_MODEL, s
+        assert rel_l1(host(out[s]["photometric_confidence"][0]), g[s + "_conf"]) <= 5 * REL_MODEL, s
+        assert rel_l1(host(out[s]["variance"][0]), g[s + "_variance"]) <= 20 * REL_MODEL, s
+    assert rel_l1(host(out["depth"][0]), g["depth"]) <= REL_MODEL
+    assert out["variance"].shape == (1,) + g["variance"].shape
+
+
 @pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "model_adamvs_v5",
                                  "model_msrednet_v3", "model_msrednet_v5"])
 def test_model_forward_matches_reference(ops, tag):
