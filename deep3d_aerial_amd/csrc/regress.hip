@@ -7,89 +7,188 @@
 
 namespace d3d {
 
-// cas_mvsnet.py:69-76.  Two sweeps over D (max, then exp-sums); the 4-plane window is
-// re-read from cache at the end.
+// VEC consecutive pixels per thread: 16-byte loads / stores when VEC = 4 (the streaming kernels below are bound by the
+// number of memory instructions in flight, not by arithmetic).  Per element the arithmetic is the same in either form.
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int VEC> __device__ __forceinline__ float vget(const typename VecT<VEC>::type& v, int k);
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float vget<4>(const VecT<4>::type& v, int k) { return v[k]; }
+template <int VEC> __device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int k, float x);
+template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
+template <> __device__ __forceinline__ void vset<4>(VecT<4>::type& v, int k, float x) { v[k] = x; }
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// cas_mvsnet.py:69-76 (and, WITH_VAR, ucsnet.py:137-151: the spread of the distribution around the regressed depth,
+// exp_variance = lamb * sqrt(sum_d p_d (dv_d - depth)^2) -- one more sweep over D).  Two sweeps over D (max, then
+// exp-sums); the 4-plane window is re-read from cache at the end.
+template <int VEC, bool WITH_VAR>
 __global__ __launch_bounds__(256) void softargmin_conf4_kernel(const float* __restrict__ cost,
                                                                 const float* __restrict__ depth, int depth_mode,
-                                                                int D, long plane, float* __restrict__ depth_out,
-                                                                float* __restrict__ conf_out) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                                                int D, long plane, float lamb, float* __restrict__ depth_out,
+                                                                float* __restrict__ conf_out, float* __restrict__ var_out) {
+    typedef typename VecT<VEC>::type V;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= plane) return;
-    float mx = -INFINITY;
-    for (int d = 0; d < D; ++d) mx = fmaxf(mx, cost[d * plane + i]);
-    float den = 0.0f, dep = 0.0f, idx = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        float e = __expf(cost[d * plane + i] - mx);
-        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
-        den += e;
-        dep = fmaf(e, dv, dep);
-        idx = fmaf(e, (float)d, idx);
-    }
-    float inv = 1.0f / den;
-    int k = (int)(idx * inv);  // .long() truncation (value >= 0)
-    k = min(max(k, 0), D - 1);
-    float conf = 0.0f;
+    float mx[VEC], den[VEC], dep[VEC], idx[VEC];
 #pragma unroll
-    for (int j = -1; j <= 2; ++j) {
-        int kk = k + j;
-        if (kk >= 0 && kk < D) conf += __expf(cost[kk * plane + i] - mx);
+    for (int k = 0; k < VEC; ++k) { mx[k] = -INFINITY; den[k] = 0.0f; dep[k] = 0.0f; idx[k] = 0.0f; }
+    for (int d = 0; d < D; ++d) {
+        const V c = *reinterpret_cast<const V*>(cost + d * plane + i);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) mx[k] = fmaxf(mx[k], vget<VEC>(c, k));
     }
-    depth_out[i] = dep * inv;
-    conf_out[i] = conf * inv;
+    for (int d = 0; d < D; ++d) {
+        const V c = *reinterpret_cast<const V*>(cost + d * plane + i);
+        V dv;
+        if (depth_mode == D3D_DEPTH_PER_PIXEL) dv = *reinterpret_cast<const V*>(depth + d * plane + i);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float e = __expf(vget<VEC>(c, k) - mx[k]);
+            const float dvk = depth_mode == D3D_DEPTH_PER_PIXEL ? vget<VEC>(dv, k) : depth[d];
+            den[k] += e;
+            dep[k] = fmaf(e, dvk, dep[k]);
+            idx[k] = fmaf(e, (float)d, idx[k]);
+        }
+    }
+    V dout, cout;
+    float inv[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        inv[k] = 1.0f / den[k];
+        int kk0 = (int)(idx[k] * inv[k]);  // .long() truncation (value >= 0)
+        kk0 = min(max(kk0, 0), D - 1);
+        float conf = 0.0f;
+#pragma unroll
+        for (int j = -1; j <= 2; ++j) {
+            const int kk = kk0 + j;
+            if (kk >= 0 && kk < D) conf += __expf(cost[kk * plane + i + k] - mx[k]);
+        }
+        vset<VEC>(dout, k, dep[k] * inv[k]);
+        vset<VEC>(cout, k, conf * inv[k]);
+    }
+    *reinterpret_cast<V*>(depth_out + i) = dout;
+    *reinterpret_cast<V*>(conf_out + i) = cout;
+    if constexpr (WITH_VAR) {
+        float var[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) var[k] = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const V c = *reinterpret_cast<const V*>(cost + d * plane + i);
+            V dv;
+            if (depth_mode == D3D_DEPTH_PER_PIXEL) dv = *reinterpret_cast<const V*>(depth + d * plane + i);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float e = __expf(vget<VEC>(c, k) - mx[k]);
+                const float dvk = depth_mode == D3D_DEPTH_PER_PIXEL ? vget<VEC>(dv, k) : depth[d];
+                const float t = dvk - vget<VEC>(dout, k);
+                var[k] = fmaf(t * t, e * inv[k], var[k]);
+            }
+        }
+        V vout;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) vset<VEC>(vout, k, lamb * sqrtf(var[k]));
+        *reinterpret_cast<V*>(var_out + i) = vout;
+    }
 }
 
-// ucsnet.py:137-151 (compute_depth of UCS-Net): the same soft-argmin and 4-plane confidence, plus the spread of the
-// distribution around the regressed depth, exp_variance = lamb * sqrt(sum_d p_d (dv_d - depth)^2) -- one more sweep over D.
-__global__ __launch_bounds__(256) void softargmin_conf4_var_kernel(const float* __restrict__ cost,
-                                                                    const float* __restrict__ depth, int depth_mode,
-                                                                    int D, long plane, float lamb,
-                                                                    float* __restrict__ depth_out,
-                                                                    float* __restrict__ conf_out,
-                                                                    float* __restrict__ var_out) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// The same for D <= DC with the cost column of the pixel held in registers: every plane is read ONCE, all D loads are in
+// flight together, and the arithmetic per element -- max, then exp-sums in plane order, window, variance -- is exactly
+// that of the streaming form above (the cascade depths 8 / 32 / 48 / 64 all take this path).
+template <int DC, bool WITH_VAR>
+__global__ __launch_bounds__(256) void softargmin_conf4_cached_kernel(const float* __restrict__ cost,
+                                                                       const float* __restrict__ depth, int depth_mode,
+                                                                       int D, long plane, float lamb,
+                                                                       float* __restrict__ depth_out,
+                                                                       float* __restrict__ conf_out,
+                                                                       float* __restrict__ var_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= plane) return;
-    float mx = -INFINITY;
-    for (int d = 0; d < D; ++d) mx = fmaxf(mx, cost[d * plane + i]);
-    float den = 0.0f, dep = 0.0f, idx = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        float e = __expf(cost[d * plane + i] - mx);
-        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
-        den += e;
-        dep = fmaf(e, dv, dep);
-        idx = fmaf(e, (float)d, idx);
+    float c[DC], dvv[DC];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        c[d] = d < D ? cost[d * plane + i] : -INFINITY;
+        dvv[d] = d < D ? (depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d]) : 0.0f;
     }
-    float inv = 1.0f / den;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < DC; ++d) mx = fmaxf(mx, c[d]);
+    float den = 0.0f, dep = 0.0f, idx = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        if (d < D) {
+            c[d] = __expf(c[d] - mx);
+            den += c[d];
+            dep = fmaf(c[d], dvv[d], dep);
+            idx = fmaf(c[d], (float)d, idx);
+        }
+    }
+    const float inv = 1.0f / den;
     int k = (int)(idx * inv);
     k = min(max(k, 0), D - 1);
     float conf = 0.0f;
 #pragma unroll
-    for (int j = -1; j <= 2; ++j) {
-        int kk = k + j;
-        if (kk >= 0 && kk < D) conf += __expf(cost[kk * plane + i] - mx);
-    }
+    for (int d = 0; d < DC; ++d)    // planes k-1 .. k+2, in plane order (as the streaming form adds them)
+        if (d < D && d >= k - 1 && d <= k + 2) conf += c[d];
     const float depth_v = dep * inv;
-    float var = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        float e = __expf(cost[d * plane + i] - mx);
-        float dv = depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d];
-        float t = dv - depth_v;
-        var = fmaf(t * t, e * inv, var);
-    }
     depth_out[i] = depth_v;
     conf_out[i] = conf * inv;
-    var_out[i] = lamb * sqrtf(var);
+    if constexpr (WITH_VAR) {
+        float var = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DC; ++d) {
+            if (d < D) {
+                const float t = dvv[d] - depth_v;
+                var = fmaf(t * t, c[d] * inv, var);
+            }
+        }
+        var_out[i] = lamb * sqrtf(var);
+    }
+}
+
+template <bool WITH_VAR>
+static bool launch_softargmin_cached(const float* cost, const float* depth, int depth_mode, int D, long plane, float lamb,
+                                     float* depth_out, float* conf_out, float* var_out, hipStream_t stream) {
+    const dim3 grid(ceil_div(plane, 256)), block(256);
+#define D3D_SA_CASE(DC)                                                                                                      \
+    if (D <= DC) {                                                                                                           \
+        hipLaunchKernelGGL((softargmin_conf4_cached_kernel<DC, WITH_VAR>), grid, block, 0, stream, cost, depth, depth_mode, D, \
+                           plane, lamb, depth_out, conf_out, var_out);                                                       \
+        return true;                                                                                                         \
+    }
+    D3D_SA_CASE(8)
+    D3D_SA_CASE(16)
+    D3D_SA_CASE(32)
+    D3D_SA_CASE(48)
+    D3D_SA_CASE(64)
+#undef D3D_SA_CASE
+    return false;
 }
 
 // ucsnet.py:42-51 (uncertainty_aware_samples, later stages): per pixel D hypotheses low + step * i + 1e-12 between
 // cur - var and cur + var, step = (high - low) / (D - 1).
+template <int VEC>
 __global__ __launch_bounds__(256) void uncertainty_samples_kernel(const float* __restrict__ cur, const float* __restrict__ var,
                                                                    int D, long plane, float* __restrict__ out) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef typename VecT<VEC>::type V;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= plane) return;
-    const float c = cur[i], v = var[i];
-    const float low = c - v, high = c + v;
-    const float step = (high - low) / ((float)D - 1.0f);
-    for (int d = 0; d < D; ++d) out[d * plane + i] = low + step * (float)d + 1e-12f;
+    const V c = *reinterpret_cast<const V*>(cur + i), v = *reinterpret_cast<const V*>(var + i);
+    float low[VEC], step[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        low[k] = vget<VEC>(c, k) - vget<VEC>(v, k);
+        const float high = vget<VEC>(c, k) + vget<VEC>(v, k);
+        step[k] = (high - low[k]) / ((float)D - 1.0f);
+    }
+    for (int d = 0; d < D; ++d) {
+        V o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) vset<VEC>(o, k, __fadd_rn(__fadd_rn(low[k], __fmul_rn(step[k], (float)d)), 1e-12f));
+        *reinterpret_cast<V*>(out + d * plane + i) = o;
+    }
 }
 
 // adamvs.py:478-486: softmax over D, max prob, expected depth.
@@ -130,17 +229,24 @@ __device__ __forceinline__ float bilerp(const float* __restrict__ in, int w, int
            ly * (hx * in[(long)y1 * w + x0] + lx * in[(long)y1 * w + x1]);
 }
 
+template <int VEC>   // VEC consecutive output columns per thread (one 16-byte store when VEC = 4)
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, int n, int h, int w,
                                                                int H, int W, float* __restrict__ out) {
-    int X = blockIdx.x * 64 + (threadIdx.x & 63);
-    int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    typedef typename VecT<VEC>::type V;
+    const int X = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC;
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (X >= W || Y >= H) return;
-    int y0, y1, x0, x1;
-    float ly, lx;
+    int y0, y1, x0[VEC], x1[VEC];
+    float ly, lx[VEC];
     lin_coord(Y, (float)h / (float)H, h, y0, y1, ly);
-    lin_coord(X, (float)w / (float)W, w, x0, x1, lx);
-    for (int k = blockIdx.z; k < n; k += gridDim.z)
-        out[((long)k * H + Y) * W + X] = bilerp(in + (long)k * h * w, w, y0, y1, x0, x1, ly, lx);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) lin_coord(X + k, (float)w / (float)W, w, x0[k], x1[k], lx[k]);
+    for (int z = blockIdx.z; z < n; z += gridDim.z) {
+        V o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) vset<VEC>(o, k, bilerp(in + (long)z * h * w, w, y0, y1, x0[k], x1[k], ly, lx[k]));
+        *reinterpret_cast<V*>(out + ((long)z * H + Y) * W + X) = o;
+    }
 }
 
 // adamvs.py:514-525 with the optional depth-plane resample of adamvs.py:519-520 fused in.
@@ -182,16 +288,28 @@ __global__ __launch_bounds__(256) void online_regress_finalize_kernel(const floa
 }
 
 // module.py:616-650.
+template <int VEC>
 __global__ __launch_bounds__(256) void depth_samples_pixel_kernel(const float* __restrict__ cur, int D,
                                                                    float interval, long plane,
                                                                    float* __restrict__ out) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef typename VecT<VEC>::type V;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= plane) return;
-    float c = cur[i];
-    float half = (float)D / 2.0f * interval;
-    float lo = c - half, hi = c + half;
-    float step = (hi - lo) / (float)(D - 1);
-    for (int d = 0; d < D; ++d) out[d * plane + i] = __fadd_rn(lo, __fmul_rn((float)d, step));
+    const V c = *reinterpret_cast<const V*>(cur + i);
+    const float half = (float)D / 2.0f * interval;
+    float lo[VEC], step[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        lo[k] = vget<VEC>(c, k) - half;
+        const float hi = vget<VEC>(c, k) + half;
+        step[k] = (hi - lo[k]) / (float)(D - 1);
+    }
+    for (int d = 0; d < D; ++d) {
+        V o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) vset<VEC>(o, k, __fadd_rn(lo[k], __fmul_rn((float)d, step[k])));
+        *reinterpret_cast<V*>(out + d * plane + i) = o;
+    }
 }
 
 __global__ void depth_samples_plane_kernel(const float* __restrict__ minmax, int D, float* __restrict__ out) {
@@ -319,8 +437,13 @@ int d3d_softargmin_conf4(const float* cost, const float* depth, int depth_mode, 
     D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
     D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
     long plane = (long)h * w;
-    hipLaunchKernelGGL(softargmin_conf4_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cost,
-                       depth, depth_mode, D, plane, depth_out, conf_out);
+    if (launch_softargmin_cached<false>(cost, depth, depth_mode, D, plane, 0.0f, depth_out, conf_out, nullptr, (hipStream_t)stream)) {
+    } else if (plane % 4 == 0 && aligned16(cost) && aligned16(depth) && aligned16(depth_out) && aligned16(conf_out))
+        hipLaunchKernelGGL((softargmin_conf4_kernel<4, false>), dim3(ceil_div(plane / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cost, depth, depth_mode, D, plane, 0.0f, depth_out, conf_out, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((softargmin_conf4_kernel<1, false>), dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cost, depth, depth_mode, D, plane, 0.0f, depth_out, conf_out, (float*)nullptr);
     D3D_LAUNCH_CHECK("softargmin_conf4_kernel launch");
     return D3D_OK;
 }
@@ -331,9 +454,14 @@ int d3d_softargmin_conf4_var(const float* cost, const float* depth, int depth_mo
     D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
     D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
     long plane = (long)h * w;
-    hipLaunchKernelGGL(softargmin_conf4_var_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cost,
-                       depth, depth_mode, D, plane, lamb, depth_out, conf_out, var_out);
-    D3D_LAUNCH_CHECK("softargmin_conf4_var_kernel launch");
+    if (launch_softargmin_cached<true>(cost, depth, depth_mode, D, plane, lamb, depth_out, conf_out, var_out, (hipStream_t)stream)) {
+    } else if (plane % 4 == 0 && aligned16(cost) && aligned16(depth) && aligned16(depth_out) && aligned16(conf_out) && aligned16(var_out))
+        hipLaunchKernelGGL((softargmin_conf4_kernel<4, true>), dim3(ceil_div(plane / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cost, depth, depth_mode, D, plane, lamb, depth_out, conf_out, var_out);
+    else
+        hipLaunchKernelGGL((softargmin_conf4_kernel<1, true>), dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cost, depth, depth_mode, D, plane, lamb, depth_out, conf_out, var_out);
+    D3D_LAUNCH_CHECK("softargmin_conf4_kernel (variance) launch");
     return D3D_OK;
 }
 
@@ -342,8 +470,12 @@ int d3d_uncertainty_samples(const float* cur_depth, const float* exp_var, int D,
     D3D_REQUIRE(cur_depth && exp_var && out, "null pointer");
     D3D_REQUIRE(D > 1 && h > 0 && w > 0, "need D > 1 and positive dims (D=%d h=%d w=%d)", D, h, w);
     long plane = (long)h * w;
-    hipLaunchKernelGGL(uncertainty_samples_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cur_depth,
-                       exp_var, D, plane, out);
+    if (plane % 4 == 0 && aligned16(cur_depth) && aligned16(exp_var) && aligned16(out))
+        hipLaunchKernelGGL(uncertainty_samples_kernel<4>, dim3(ceil_div(plane / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cur_depth, exp_var, D, plane, out);
+    else
+        hipLaunchKernelGGL(uncertainty_samples_kernel<1>, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream,
+                           cur_depth, exp_var, D, plane, out);
     D3D_LAUNCH_CHECK("uncertainty_samples_kernel launch");
     return D3D_OK;
 }
@@ -363,9 +495,11 @@ int d3d_pair_softmax_max(const float* score, const float* depth, int depth_mode,
 int d3d_resize_bilinear(const float* in, int n, int h, int w, int H, int W, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && out, "null pointer");
     D3D_REQUIRE(n > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bad dims n=%d %dx%d -> %dx%d", n, h, w, H, W);
-    dim3 grid(ceil_div(W, 64), ceil_div(H, 4), n < 64 ? n : 64);
+    const bool vec = W % 4 == 0 && aligned16(out);
+    dim3 grid(ceil_div(vec ? W / 4 : W, 64), ceil_div(H, 4), n < 64 ? n : 64);
     D3D_REQUIRE(grid.y <= 65535, "H=%d too large", H);
-    hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, n, h, w, H, W, out);
+    if (vec) hipLaunchKernelGGL(resize_bilinear_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, in, n, h, w, H, W, out);
+    else hipLaunchKernelGGL(resize_bilinear_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, in, n, h, w, H, W, out);
     D3D_LAUNCH_CHECK("resize_bilinear_kernel launch");
     return D3D_OK;
 }
@@ -402,8 +536,12 @@ int d3d_depth_range_samples(const float* cur_depth, int mode, int D, float inter
     } else if (mode == D3D_DEPTH_PER_PIXEL) {
         D3D_REQUIRE(h > 0 && w > 0, "bad dims h=%d w=%d", h, w);
         long plane = (long)h * w;
-        hipLaunchKernelGGL(depth_samples_pixel_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0,
-                           (hipStream_t)stream, cur_depth, D, interval, plane, out);
+        if (plane % 4 == 0 && aligned16(cur_depth) && aligned16(out))
+            hipLaunchKernelGGL(depth_samples_pixel_kernel<4>, dim3(ceil_div(plane / 4, 256)), dim3(256), 0,
+                               (hipStream_t)stream, cur_depth, D, interval, plane, out);
+        else
+            hipLaunchKernelGGL(depth_samples_pixel_kernel<1>, dim3(ceil_div(plane, 256)), dim3(256), 0,
+                               (hipStream_t)stream, cur_depth, D, interval, plane, out);
     } else {
         set_error("bad mode %d", mode);
         return D3D_ERR_INVALID_ARG;
