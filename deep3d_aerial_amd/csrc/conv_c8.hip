@@ -28,7 +28,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int TX = 64, TY = 8;             // output tile (x, y) of a workgroup
-constexpr int PX = TX + 2, PY = TY + 2;    // staged patch with the 1-pixel halo
+constexpr int PY = TY + 2;                 // staged patch rows with the 1-pixel halo (columns: 16 * MGN + 2)
 constexpr int NT = 64 * TY;                // one wave per tile row
 
 // Activation formats.  PLANAR: fp32 [C][D][H][W] (what the cost-volume kernels write and the regression kernels read).
@@ -60,9 +60,12 @@ __device__ __forceinline__ f4 unpack_bf16x4(uint2 u) {
                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
 }
 
-// NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32); INCL / OUTCL: channel-last bf16 input / output
-template <int CI, int NTN, bool INCL, bool OUTCL>
+// NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32, 4: C_out = 64); INCL / OUTCL: channel-last bf16 input / output;
+// MGN: 16-pixel groups per wave (tile width 16 * MGN); WG: the weight fragments are read from global memory (L2) per use
+// instead of living in LDS -- the 64 -> 64 layer's 221 KB of weights do not fit beside a patch, its volumes are tiny.
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false>
 __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+    constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5)
     constexpr int G = CI / 8;                          // 8-channel groups per pixel
@@ -78,7 +81,9 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
 
     // ---- weights: resident in LDS (a K block's three k_z fragments are read once per wave and plane and reused by the
     //      four pixel groups; keeping all 3 * NKB fragments in registers would cost the second workgroup per CU) -------
-    for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+    if constexpr (!WG)
+        for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+    const u4* __restrict__ wsrc = WG ? p.wpk : wlds;
 
     // ---- per-lane A offsets: K index k = 32 kb + 8 (lane >> 4) + j  ->  tap t = k / CI, channel k % CI ----------
     // (recomputed per use from an opaque copy of the lane's K group: NKB loop-invariant registers would cost the second
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
         }
     };
 
-    constexpr int AW = 4 * NTN;   // accumulators per plane slot: [pixel group][channel tile]
+    constexpr int AW = MGN * NTN;   // accumulators per plane slot: [pixel group][channel tile]
     f4 acc[3][AW];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
                         const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
                         const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
 #pragma unroll
-                        for (int mg = 0; mg < 4; ++mg) {
+                        for (int mg = 0; mg < MGN; ++mg) {
                             const int ox = x0 + mg * 16 + (lane & 15);
                             if (ox < W) {
                                 const size_t o = (((size_t)zo * H + oy) * W + ox) * p.CO + cb;   // bf16 element index
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
                 if (co < p.CO) {
                     const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
 #pragma unroll
-                    for (int mg = 0; mg < 4; ++mg) {
+                    for (int mg = 0; mg < MGN; ++mg) {
                         const int ox = x0 + mg * 16 + (lane >> 4) * 4;   // D layout: row (pixel) = (lane >> 4) * 4 + register
                         if (ox < W) {                                     // W % 4 == 0: a quad is inside or outside as a whole
                             const size_t o = (size_t)co * vol + (size_t)zo * plane + (size_t)oy * W + ox;
@@ -210,19 +215,17 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
     auto sweep = [&](const unsigned char* buf, f4 (&up)[AW], f4 (&mid)[AW], f4 (&down)[AW], int kb0, int kb1) {
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));   // keeps the offsets out of long-lived registers
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            if (kb < kb0 || kb >= kb1) continue;
+        auto kb_body = [&](int kb) {
             const int aoffk = a_offset(kb, kgroup);
             bf16x8 b0[NTN], b1[NTN], b2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                b0[nt] = __builtin_bit_cast(bf16x8, wlds[((0 * NKB + kb) * NTN + nt) * 64 + lane]);
-                b1[nt] = __builtin_bit_cast(bf16x8, wlds[((1 * NKB + kb) * NTN + nt) * 64 + lane]);
-                b2[nt] = __builtin_bit_cast(bf16x8, wlds[((2 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b0[nt] = __builtin_bit_cast(bf16x8, wsrc[((0 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b1[nt] = __builtin_bit_cast(bf16x8, wsrc[((1 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b2[nt] = __builtin_bit_cast(bf16x8, wsrc[((2 * NKB + kb) * NTN + nt) * 64 + lane]);
             }
 #pragma unroll
-            for (int mg = 0; mg < 4; ++mg) {
+            for (int mg = 0; mg < MGN; ++mg) {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) {
@@ -237,6 +240,16 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
                         down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2[nt], down[mg * NTN + nt], 0, 0, 0);
                     }
                 }
+            }
+        };
+        if constexpr (WG) {   // fragments come from L2: keep ONE K block's loads in flight, not all of them (registers)
+#pragma unroll 1
+            for (int kb = kb0; kb < kb1; ++kb) kb_body(kb);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb < kb0 || kb >= kb1) continue;
+                kb_body(kb);
             }
         }
     };
@@ -270,17 +283,18 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
     }
 }
 
-template <int CI, int NTN, bool INCL, bool OUTCL>
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false>
 static int launch(const C8Params& p, hipStream_t stream) {
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * PX * PY * CS + 3 * NKB * NTN * 64 * 16;
-    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL>;
+    constexpr int TXk = 16 * MGN, PXk = TXk + 2;
+    const int lds = 2 * PXk * PY * CS + (WG ? 0 : 3 * NKB * NTN * 64 * 16);
+    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
     C8Params q = p;
-    const int gx = ceil_div(p.W, TX), gy = ceil_div(p.H, TY);
+    const int gx = ceil_div(p.W, TXk), gy = ceil_div(p.H, TY);
     int nz = 1;   // enough workgroups for 256 CUs; every z segment re-reads two halo planes
     while ((long)gx * gy * nz < 1024 && p.D / (nz * 2) >= 4) nz *= 2;
     q.zper = ceil_div(p.D, nz);
@@ -310,16 +324,18 @@ extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpac
                                      d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
-    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && Co >= 1 && (Co <= 16 || (Co == 32 && Ci == 32));
+    const bool wide = Ci == 64 && Co == 64 && in_cl && out_cl;   // conv6: channel-last only, weights streamed from L2
+    const bool shape = ((Ci == 8 || Ci == 16 || Ci == 32) && Co >= 1 && (Co <= 16 || (Co == 32 && Ci == 32))) || wide;
     if (!shape || (out_cl ? Co % 4 != 0 : W % 4 != 0) || ceil_div(H, TY) > 65535 || D > 65535) {
         set_error("d3d_conv3d_k3_cl_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16, or 32 with C_in = 32; a multiple of 4 for "
-                  "channel-last output), W = %d (a multiple of 4 for planar output) not taken", Ci, Co, W);
+                  "channel-last output; 64 -> 64 channel-last), W = %d (a multiple of 4 for planar output) not taken", Ci, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
     C8Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
     hipStream_t st = (hipStream_t)stream;
+    if (wide) return launch<64, 4, true, true, 2, true>(p, st);
     if (in_cl) return out_cl ? launch_fmt<true, true>(p, Ci, Co, st) : launch_fmt<true, false>(p, Ci, Co, st);
     return out_cl ? launch_fmt<false, true>(p, Ci, Co, st) : launch_fmt<false, false>(p, Ci, Co, st);
 }

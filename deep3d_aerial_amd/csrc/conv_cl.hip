@@ -23,10 +23,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-constexpr int TXO = 32, TYO = 8;                      // output tile of a workgroup
-constexpr int MG = TXO / 16;                          // 16-pixel groups per wave (= output row)
-constexpr int PXI = 2 * TXO + 1, PYI = 2 * TYO + 1;   // staged input patch
-constexpr int NEVEN = TXO + 1;                        // even patch columns come first in a row, then the TXO odd ones
+constexpr int TYO = 8;                 // output rows of a workgroup = waves (output columns: 16 * MGK)
+constexpr int PYI = 2 * TYO + 1;       // staged input patch rows
 constexpr int NT = 64 * TYO;
 
 struct S2Params {
@@ -51,8 +49,12 @@ __device__ __forceinline__ f4 unpack_bf16x4_cl(uint2 u) {
                 __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
 }
 
-template <int CI, int NTN>
+// MGK: 16-pixel groups per wave (output tile width 16 * MGK); WG: weight fragments read from global memory (L2) per use
+// (32 -> 64: 110 KB of weights do not fit beside the double-buffered patch)
+template <int CI, int NTN, int MGK = 2, bool WG = false>
 __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
+    constexpr int TXO = 16 * MGK, MG = MGK;          // output tile width, 16-pixel groups per wave (= output row)
+    constexpr int PXI = 2 * TXO + 1, NEVEN = TXO + 1;   // staged patch columns; the even ones come first in a row, then the TXO odd ones
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);   // odd number of 16-byte slots
     constexpr int G = CI / 8;
@@ -66,7 +68,9 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     const int zo0 = blockIdx.z * p.zper, zo1 = min(zo0 + p.zper, p.Do);
     const int D = p.D, H = p.H, W = p.W;
 
-    for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+    if constexpr (!WG)
+        for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+    const u4* __restrict__ wsrc = WG ? p.wpk : wlds;
 
     // ---- staging: task = (patch pixel, 8-channel group), one 16-byte load and one 16-byte LDS write ----------------
     constexpr int NTASK = PXI * PYI * G;
@@ -149,14 +153,13 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     auto sweep = [&](const unsigned char* buf, int kz1, f4 (&d1)[AW], int kz2, f4 (&d2)[AW], bool two) {
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+auto kb_body = [&](int kb) {
             const int aoffk = a_offset(kb, kgroup);
             bf16x8 w1[NTN], w2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                w1[nt] = __builtin_bit_cast(bf16x8, wlds[((kz1 * NKB + kb) * NTN + nt) * 64 + lane]);
-                if (two) w2[nt] = __builtin_bit_cast(bf16x8, wlds[((kz2 * NKB + kb) * NTN + nt) * 64 + lane]);
+                w1[nt] = __builtin_bit_cast(bf16x8, wsrc[((kz1 * NKB + kb) * NTN + nt) * 64 + lane]);
+                if (two) w2[nt] = __builtin_bit_cast(bf16x8, wsrc[((kz2 * NKB + kb) * NTN + nt) * 64 + lane]);
             }
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) {
@@ -167,6 +170,13 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
                     if (two) d2[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt], a, d2[mg * NTN + nt], 0, 0, 0);
                 }
             }
+        };
+        if constexpr (WG) {   // fragments come from L2: one K block's loads in flight at a time (registers)
+#pragma unroll 1
+            for (int kb = 0; kb < NKB; ++kb) kb_body(kb);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) kb_body(kb);
         }
     };
 
@@ -207,17 +217,18 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     }
 }
 
-template <int CI, int NTN>
+template <int CI, int NTN, int MGK = 2, bool WG = false>
 static int launch_s2(const S2Params& p, hipStream_t stream) {
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * PXI * PYI * CS + 3 * NKB * NTN * 64 * 16;
-    auto kern = conv3d_s2_cl_kernel<CI, NTN>;
+    constexpr int TXOk = 16 * MGK, PXIk = 2 * TXOk + 1;
+    const int lds = 2 * PXIk * PYI * CS + (WG ? 0 : 3 * NKB * NTN * 64 * 16);
+    auto kern = conv3d_s2_cl_kernel<CI, NTN, MGK, WG>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
     S2Params q = p;
-    const int gx = ceil_div(p.Wo, TXO), gy = ceil_div(p.Ho, TYO);
+    const int gx = ceil_div(p.Wo, TXOk), gy = ceil_div(p.Ho, TYO);
     int nz = 1;   // every z segment re-reads one halo plane
     while ((long)gx * gy * nz < 1024 && p.Do / (nz * 2) >= 2) nz *= 2;
     q.zper = ceil_div(p.Do, nz);
@@ -265,12 +276,14 @@ extern "C" int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, cons
     S2Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.Do = (D - 1) / 2 + 1; p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1; p.CO = Co; p.relu = relu;
-    const bool shape = (Ci == 8 && Co == 16) || (Ci == 16 && Co == 32) || (Ci == 8 && Co == 8) || (Ci == 16 && Co == 16);
+    const bool shape = (Ci == 8 && Co == 16) || (Ci == 16 && Co == 32) || (Ci == 8 && Co == 8) || (Ci == 16 && Co == 16) ||
+                       (Ci == 32 && Co == 64);
     if (!shape || ceil_div(p.Ho, TYO) > 65535 || p.Do > 65535) {
-        set_error("d3d_conv3d_k3s2_cl_bf16: %d -> %d channels not taken (8->8, 8->16, 16->16, 16->32)", Ci, Co);
+        set_error("d3d_conv3d_k3s2_cl_bf16: %d -> %d channels not taken (8->8, 8->16, 16->16, 16->32, 32->64)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (Ci == 32) return launch_s2<32, 4, 1, true>(p, st);   // conv5: 16-wide tiles, weights streamed from L2
     if (Ci == 8) return launch_s2<8, 1>(p, st);
     return Co > 16 ? launch_s2<16, 2>(p, st) : launch_s2<16, 1>(p, st);
 }

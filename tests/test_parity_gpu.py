@@ -1018,7 +1018,8 @@ def test_volume_format_conversions(ops):
 @pytest.mark.parametrize("Ci,Co,D,H,W,in_cl,out_cl", [
     (8, 8, 5, 9, 68, False, True), (16, 8, 8, 21, 132, False, True), (32, 8, 3, 4, 64, False, True), (8, 8, 1, 3, 5, False, True),
     (16, 16, 7, 19, 70, True, True), (32, 32, 5, 11, 66, True, True), (8, 16, 3, 9, 21, True, True), (32, 16, 14, 8, 128, True, True),
-    (8, 1, 6, 10, 72, True, False), (8, 1, 40, 16, 64, True, False), (16, 8, 4, 9, 36, True, False), (8, 8, 9, 17, 37, True, True)])
+    (8, 1, 6, 10, 72, True, False), (8, 1, 40, 16, 64, True, False), (16, 8, 4, 9, 36, True, False), (8, 8, 9, 17, 37, True, True),
+    (64, 64, 1, 8, 16, True, True), (64, 64, 6, 29, 43, True, True), (64, 64, 3, 7, 70, True, True)])
 def test_conv3d_channel_last_bf16(ops, oracle, Ci, Co, D, H, W, in_cl, out_cl):
     """d3d_conv3d_k3_cl_bf16 on every format pair the CostRegNet uses (cas_mvsnet.py:84 conv0 planar -> CL, :87,90 conv2 /
     conv4 CL -> CL, :110 prob CL -> planar): the fp32 oracle on bf16-rounded operands, with the folded-BN affine, ReLU and a
@@ -1047,10 +1048,11 @@ def test_conv3d_channel_last_bf16(ops, oracle, Ci, Co, D, H, W, in_cl, out_cl):
 
 
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 16, 4, 16, 64), (16, 32, 8, 10, 70), (8, 8, 5, 9, 33), (16, 16, 1, 1, 1), (8, 16, 2, 34, 130),
-                                         (16, 32, 13, 7, 19), (8, 16, 16, 8, 8)])
+                                         (16, 32, 13, 7, 19), (8, 16, 16, 8, 8), (32, 64, 2, 16, 32), (32, 64, 12, 29, 43),
+                                         (32, 64, 5, 6, 70)])
 def test_conv3d_stride2_channel_last_bf16(ops, oracle, Ci, Co, D, H, W):
-    """conv1 / conv3 of CostRegNet (cas_mvsnet.py:86,89: stride 2) on d3d_conv3d_k3s2_cl_bf16, channel-last bf16 in and
-    out; odd sizes, single voxels and the z segmentation included."""
+    """conv1 / conv3 / conv5 of CostRegNet (cas_mvsnet.py:86,89,92: stride 2) on d3d_conv3d_k3s2_cl_bf16, channel-last bf16
+    in and out (32 -> 64 with the weights streamed from L2); odd sizes, single voxels and the z segmentation included."""
     rng = np.random.default_rng(Ci * 1000 + Co * 100 + W + D)
     x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
     w = (0.1 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
@@ -1094,10 +1096,10 @@ def test_convtranspose3d_channel_last_bf16(ops, oracle, monkeypatch, Ci, Co, D, 
 
 
 def test_channel_last_layers_fall_back_through_the_planar_kernels(ops, oracle):
-    """conv5 / conv6 of CostRegNet (32 -> 64 stride 2, 64 -> 64: cas_mvsnet.py:92-93) have no channel-last kernel: the
-    same entry points convert, run the planar bf16 kernels and convert back."""
+    """Shapes without a channel-last kernel (none of CostRegNet's): the same entry points convert, run the planar bf16
+    kernels and convert back."""
     rng = np.random.default_rng(77)
-    for Ci, Co, stride in [(32, 64, 2), (64, 64, 1)]:
+    for Ci, Co, stride in [(64, 32, 1), (24, 16, 2)]:
         x = rng.standard_normal((Ci, 4, 6, 8)).astype(np.float32)
         w = (0.1 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
         got = ops.conv3d_k3_cl(_cl_dev(x), dev(w), relu=True, stride=stride)
