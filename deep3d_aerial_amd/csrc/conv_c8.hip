@@ -27,7 +27,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-constexpr int TX = 64, TY = 8;             // output tile (x, y) of a workgroup
+constexpr int TY = 8;                      // output tile rows of a workgroup (columns: 16 * MGN, 64 by default)
 constexpr int PY = TY + 2;                 // staged patch rows with the 1-pixel halo (columns: 16 * MGN + 2)
 constexpr int NT = 64 * TY;                // one wave per tile row
 
@@ -63,8 +63,16 @@ __device__ __forceinline__ f4 unpack_bf16x4(uint2 u) {
 // NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32, 4: C_out = 64); INCL / OUTCL: channel-last bf16 input / output;
 // MGN: 16-pixel groups per wave (tile width 16 * MGN); WG: the weight fragments are read from global memory (L2) per use
 // instead of living in LDS -- the 64 -> 64 layer's 221 KB of weights do not fit beside a patch, its volumes are tiny.
-template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false>
+// KZF (C_out = 1, planar output: the probability layer): the three k_z slices are COLUMNS 0, 1, 2 of one weight tile, so one
+// MFMA per K block serves the three open output planes; after every input plane column 2 is complete (it is stored) and
+// the columns move one to the right (v_mov_dpp row_shr:1 within the 16-lane rows) -- a third of the MFMAs and weight reads.
+__device__ __forceinline__ float dpp_row_shr1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false>
 __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+    static_assert(!KZF || (NTN == 1 && !OUTCL && !WG), "k_z-folded form: one output channel, planar output");
     constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5)
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
     // ---- weights: resident in LDS (a K block's three k_z fragments are read once per wave and plane and reused by the
     //      four pixel groups; keeping all 3 * NKB fragments in registers would cost the second workgroup per CU) -------
     if constexpr (!WG)
-        for (int i = tid; i < 3 * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+        for (int i = tid; i < (KZF ? 1 : 3) * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
     const u4* __restrict__ wsrc = WG ? p.wpk : wlds;
 
     // ---- per-lane A offsets: K index k = 32 kb + 8 (lane >> 4) + j  ->  tap t = k / CI, channel k % CI ----------
@@ -190,8 +198,8 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
             float* __restrict__ outf = static_cast<float*>(p.out);
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                const int co = nt * 16 + (lane & 15);
-                if (co < p.CO) {
+                const int co = KZF ? 0 : nt * 16 + (lane & 15);
+                if (KZF ? (lane & 15) == 2 : co < p.CO) {   // (KZF: column 2 = the plane that has seen its three input planes)
                     const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
 #pragma unroll
                     for (int mg = 0; mg < MGN; ++mg) {
@@ -207,8 +215,15 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
                 }
             }
         }
+        if constexpr (KZF) {   // columns move up by one plane; column 0 starts the next plane at zero
 #pragma unroll
-        for (int i = 0; i < AW; ++i) a[i] = (f4){0, 0, 0, 0};
+            for (int i = 0; i < AW; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[i][r] = dpp_row_shr1(a[i][r]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < AW; ++i) a[i] = (f4){0, 0, 0, 0};
+        }
     };
 
     // input plane zi feeds output planes zi+1 (k_z = 0), zi (k_z = 1), zi-1 (k_z = 2); slot of output plane zo = phase of zo
@@ -217,6 +232,15 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
         asm volatile("" : "+v"(kgroup));   // keeps the offsets out of long-lived registers
         auto kb_body = [&](int kb) {
             const int aoffk = a_offset(kb, kgroup);
+            if constexpr (KZF) {
+                const bf16x8 bw = __builtin_bit_cast(bf16x8, wsrc[kb * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MGN; ++mg) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                    up[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, up[mg], 0, 0, 0);
+                }
+                return;
+            }
             bf16x8 b0[NTN], b1[NTN], b2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
@@ -276,20 +300,24 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_b
         __syncthreads();
         cur ^= 1;
     };
-    for (int zi = z0 - 1; zi <= z1; zi += 3) {
-        step(zi, acc[1], acc[0], acc[2]);
-        if (zi + 1 <= z1) step(zi + 1, acc[2], acc[1], acc[0]);
-        if (zi + 2 <= z1) step(zi + 2, acc[0], acc[2], acc[1]);
+    if constexpr (KZF) {
+        for (int zi = z0 - 1; zi <= z1; ++zi) step(zi, acc[0], acc[0], acc[0]);   // one accumulator set: columns = planes
+    } else {
+        for (int zi = z0 - 1; zi <= z1; zi += 3) {
+            step(zi, acc[1], acc[0], acc[2]);
+            if (zi + 1 <= z1) step(zi + 1, acc[2], acc[1], acc[0]);
+            if (zi + 2 <= z1) step(zi + 2, acc[0], acc[2], acc[1]);
+        }
     }
 }
 
-template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false>
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false>
 static int launch(const C8Params& p, hipStream_t stream) {
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
     constexpr int TXk = 16 * MGN, PXk = TXk + 2;
-    const int lds = 2 * PXk * PY * CS + (WG ? 0 : 3 * NKB * NTN * 64 * 16);
-    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG>;
+    const int lds = 2 * PXk * PY * CS + (WG ? 0 : (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
+    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -338,6 +366,32 @@ extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpac
     if (wide) return launch<64, 4, true, true, 2, true>(p, st);
     if (in_cl) return out_cl ? launch_fmt<true, true>(p, Ci, Co, st) : launch_fmt<true, false>(p, Ci, Co, st);
     return out_cl ? launch_fmt<false, true>(p, Ci, Co, st) : launch_fmt<false, false>(p, Ci, Co, st);
+}
+
+extern "C" int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+                                        const float* skip, int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    if ((Ci != 8 && Ci != 16 && Ci != 32) || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_c1_cl_bf16: C_in = %d (8 | 16 | 32), W = %d (a multiple of 4) not taken", Ci, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    C8Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (in_cl) {
+        switch (Ci) {
+            case 8: return launch<8, 1, true, false, 4, false, true>(p, st);
+            case 16: return launch<16, 1, true, false, 4, false, true>(p, st);
+            default: return launch<32, 1, true, false, 4, false, true>(p, st);
+        }
+    }
+    switch (Ci) {
+        case 8: return launch<8, 1, false, false, 4, false, true>(p, st);
+        case 16: return launch<16, 1, false, false, 4, false, true>(p, st);
+        default: return launch<32, 1, false, false, 4, false, true>(p, st);
+    }
 }
 
 extern "C" int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,

@@ -334,6 +334,19 @@ def _pack_c8_bf16(w):
     return b.reshape(3, nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_c8_kzfold_bf16(w):
+    """nn.Conv3d weight [1,Ci,3,3,3] -> B operands of d3d_conv3d_k3_c1_cl_bf16: ONE tile per K block whose columns 0, 1, 2 are
+    the k_z = 0, 1, 2 slices (K = (k_y, k_x, c_in), padded to a multiple of 32); [K block][lane][8], lane l = column l & 15,
+    K rows 8 * (l >> 4) .. + 7.  int16 bits (bf16)."""
+    Ci = w.shape[1]
+    K = 9 * Ci
+    nkb = (K + 31) // 32
+    b = torch.zeros((nkb * 32, 16), dtype=torch.float32, device=w.device)
+    b[:K, :3] = w[0].permute(2, 3, 0, 1).reshape(K, 3)          # [ci, kz, ky, kx] -> [ky, kx, ci, kz] -> rows (ky*3+kx)*Ci + ci, column kz
+    b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)            # [kb][kgroup][n][j]
+    return b.reshape(nkb, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
 def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1):
     """x [Ci,D,H,W], weight [Co,Ci,3,3,3] -> [Co,Do,Ho,Wo] with folded-BN affine, ReLU, skip (after ReLU)."""
     Ci, D, H, W = x.shape
@@ -537,6 +550,14 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     out = torch.empty(oshape, dtype=torch.bfloat16 if out_cl else torch.float32, device=x.device)
     optr = ctypes.c_void_p(out.data_ptr())
     rc = _lib.ERR_UNSUPPORTED
+    if stride == 1 and Co == 1 and not out_cl and _os.environ.get("D3D_CONV_KZFOLD", "1") != "0":
+        # the probability layer: k_z folded into the columns of one operand tile
+        wf = derived_weight(weight, "c8kzfold", _pack_c8_kzfold_bf16)
+        rc = _lib.load().d3d_conv3d_k3_c1_cl_bf16(xp, int(in_cl), ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
+                                                  _opt(shift, "shift"), sp, int(relu), Ci, D, H, W, optr, _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_conv3d_k3_c1_cl_bf16")
+            return out
     if stride == 1:
         rc = _lib.load().d3d_conv3d_k3_cl_bf16(xp, int(in_cl), wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
                                                Ci, Co, D, H, W, optr, int(out_cl), _stream())

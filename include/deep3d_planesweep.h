@@ -265,6 +265,11 @@ int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const
 int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
                           const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out, int out_cl,
                           d3d_stream_t stream);
+/* C_out = 1 (the probability layer, cas_mvsnet.py:110): in planar fp32 or CL (in_cl), out planar fp32 [D,H,W]; the three k_z
+ * slices of the weight are columns 0..2 of ONE operand tile (ops._pack_c8_kzfold_bf16), a third of the matrix work of the
+ * generic entry point.  C_in = 8 | 16 | 32, W % 4 == 0. */
+int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+                             const float* skip, int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
 int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
                             int relu, int Ci, int Co, int D, int H, int W, void* out, d3d_stream_t stream);
 int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift,

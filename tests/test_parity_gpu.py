@@ -1047,6 +1047,31 @@ def test_conv3d_channel_last_bf16(ops, oracle, Ci, Co, D, H, W, in_cl, out_cl):
         assert np.abs(host(got) - want).max() <= 2 * tol
 
 
+@pytest.mark.parametrize("Ci,D,H,W,in_cl", [(8, 1, 3, 4, True), (8, 9, 17, 72, True), (16, 6, 10, 36, True), (32, 5, 9, 68, True),
+                                            (8, 7, 8, 64, False), (16, 11, 21, 132, False), (8, 40, 16, 64, True)])
+def test_conv3d_probability_layer_kz_folded(ops, oracle, monkeypatch, Ci, D, H, W, in_cl):
+    """CostRegNet.prob (cas_mvsnet.py:110, C_out = 1) on d3d_conv3d_k3_c1_cl_bf16: the three k_z slices as columns of one
+    operand tile, planes handed on with a DPP column shift.  Against the oracle (bias, scale, ReLU, skip) and against the
+    generic kernel."""
+    rng = np.random.default_rng(Ci * 100 + D + W)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((1, Ci, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 1).astype(np.float32)
+    sh = rng.standard_normal(1).astype(np.float32)
+    sk = rng.standard_normal((1, D, H, W)).astype(np.float32)
+    xin = _cl_dev(x) if in_cl else dev(x)
+    got = host(ops.conv3d_k3_cl(xin, dev(w), dev(sc), dev(sh), dev(sk), relu=True, out_cl=False))
+    plain = host(ops.conv3d_k3_cl(xin, dev(w), None, dev(sh), None, relu=False, out_cl=False))
+    monkeypatch.setenv("D3D_CONV_KZFOLD", "0")
+    generic = host(ops.conv3d_k3_cl(xin, dev(w), None, dev(sh), None, relu=False, out_cl=False))
+    ref = oracle.conv3d_k3(_bf16_round(x), _bf16_round(w), None)
+    tol = 3e-5 * max(1.0, np.abs(ref).max())
+    assert plain.shape == (1, D, H, W)
+    assert np.abs(plain - (ref + sh[0])).max() <= tol
+    assert np.abs(got - (np.maximum(ref * sc[0] + sh[0], 0) + sk)).max() <= 2 * tol
+    assert np.abs(plain - generic).max() <= tol
+
+
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 16, 4, 16, 64), (16, 32, 8, 10, 70), (8, 8, 5, 9, 33), (16, 16, 1, 1, 1), (8, 16, 2, 34, 130),
                                          (16, 32, 13, 7, 19), (8, 16, 16, 8, 8), (32, 64, 2, 16, 32), (32, 64, 12, 29, 43),
                                          (32, 64, 5, 6, 70)])
