@@ -274,15 +274,22 @@ __device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte
 #endif
 }
 
-// channel-last bf16 output: four consecutive channels of the lane's voxel, RNE, one 8-byte store
-__device__ __forceinline__ void store_sbase_bf16x4(unsigned long long sb, unsigned byte_off, const float __attribute__((ext_vector_type(4)))& v) {
+// channel-last bf16 output: four consecutive channels of the lane's voxel, RNE, as two dwords ...
+__device__ __forceinline__ unsigned long long pack_bf16x4(const float __attribute__((ext_vector_type(4)))& v) {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     const bf2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32
-    const unsigned long long bits = (unsigned long long)__builtin_bit_cast(unsigned, a) | ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32);
+    return (unsigned long long)__builtin_bit_cast(unsigned, a) | ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32);
+}
+// ... and EIGHT of them (two finished quads) as one 16-byte store: a lane's stores are 64 cells apart from its
+// neighbours' (cell = C * 2 bytes), so every store instruction is 64 separate memory transactions whatever its width --
+// 8-byte stores made the 16-channel groups of stages 1 / 2 twice as slow as the planar fp32 kernel
+__device__ __forceinline__ void store_sbase_bf16x8(unsigned long long sb, unsigned byte_off, unsigned long long lo, unsigned long long hi) {
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v bits = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
 #ifdef D3D_NOSTORE
     asm volatile("" : : "v"(byte_off), "v"(bits), "s"(sb));
 #else
-    asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
 #endif
 }
 
@@ -875,7 +882,8 @@ __global__ __launch_bounds__(64 * (NPIXW * NSUB_T + NLOAD_T), 3) void sweep_tile
     const size_t cstride_b = (p.plane_major ? plane : (size_t)D * plane) * sizeof(T);   // bytes between channels
 
     // all CH/4.. channels of one quad: accumulators -> output values -> stores
-    auto finalize_store = [&](const f4& s, const f4& qq, unsigned long long& ob) {
+    unsigned long long even_quad = 0;   // OUTCL: the packed even quad waits for the odd one (one 16-byte store per pair)
+    auto finalize_store = [&](const f4& s, const f4& qq, unsigned long long& ob, int q) {
         f4 o;
         if (MODE == MODE_VARIANCE) {   // two channels per instruction; each half is the scalar sequence m = s/V, fma(qq, 1/V, -(m*m))
             const f2 iv = {invV, invV};
@@ -887,8 +895,12 @@ __global__ __launch_bounds__(64 * (NPIXW * NSUB_T + NLOAD_T), 3) void sweep_tile
             o = s;
         }
         if constexpr (OUTCL) {
-            store_sbase_bf16x4(ob, pixo, o);
-            ob += 8;
+            if ((q & 1) == 0) {
+                even_quad = pack_bf16x4(o);
+            } else {
+                store_sbase_bf16x8(ob, pixo, even_quad, pack_bf16x4(o));
+                ob += 16;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1148,7 +1160,7 @@ __global__ __launch_bounds__(64 * (NPIXW * NSUB_T + NLOAD_T), 3) void sweep_tile
                     asm volatile("" : "+v"(c[3]));
                     f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
                     accumulate(s, qq, pair_acc, val, q, i);
-                    if (i == NSRC - 1 && MODE != MODE_PAIR) finalize_store(s, qq, ob);
+                    if (i == NSRC - 1 && MODE != MODE_PAIR) finalize_store(s, qq, ob, q);
                 }
             } else {
                 TapG t[NSRC];
@@ -1176,7 +1188,7 @@ __global__ __launch_bounds__(64 * (NPIXW * NSUB_T + NLOAD_T), 3) void sweep_tile
                         }
                         accumulate(s, qq, pair_acc, val, q, i);
                     }
-                    if (MODE != MODE_PAIR) finalize_store(s, qq, ob);
+                    if (MODE != MODE_PAIR) finalize_store(s, qq, ob, q);
                 }
             }
             if (MODE == MODE_PAIR)
@@ -1248,7 +1260,10 @@ static void segments(int D, long tiles, int& dseg, int& nseg) {
 }
 
 // The channel-last copy pays off when the sweep is deep: it costs 2 x (n_src*C*h*w) elements of traffic.
-static bool wants_channel_last(int D, int elem_bytes) { return elem_bytes == 2 || D >= 96; }
+#ifndef D3D_CL_MIN_PLANES
+#define D3D_CL_MIN_PLANES 96
+#endif
+static bool wants_channel_last(int D, int elem_bytes) { return elem_bytes == 2 || D >= D3D_CL_MIN_PLANES; }
 
 size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes) {
     if (C % 8 != 0 || n_src > 6 || n_src < 1 || !wants_channel_last(D, elem_bytes)) return 0;
