@@ -289,7 +289,9 @@ __device__ __forceinline__ void store_sbase_bf16x8(unsigned long long sb, unsign
 #ifdef D3D_NOSTORE
     asm volatile("" : : "v"(byte_off), "v"(bits), "s"(sb));
 #else
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
+    // (a store of more than 8 bytes reads its data registers late: the next VALU write of one of them needs wait states, and
+    //  the compiler's hazard recognizer does not see inside the string -- without the s_nop some lanes stored garbage)
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
 #endif
 }
 
@@ -331,9 +333,11 @@ __device__ __forceinline__ float ldf(const __half* q) { return __half2float(*q);
 // sized for deep sweeps; SHALLOW sweeps (the last cascade stage: 8 planes) run 2 + 2 = 6 waves on half the LDS, so TWO
 // workgroups share a CU and one's planning prologue and first-window latency (most of its life: 47 % + 40 % at 8 planes)
 // overlap the other's arithmetic.
-template <int MODE, int NSRC, int CH, typename T = float, bool OUTCL = false, int NSUB_T = D3D_NSUB, int NLOAD_T = D3D_NLOADW>
-__global__ __launch_bounds__(64 * (NPIXW * NSUB_T + NLOAD_T), 3) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {   // 3 waves per SIMD: the 168-register budget for either workgroup size
-    constexpr int NSUB = NSUB_T, NLOADW = NLOAD_T, NCOMP = NPIXW * NSUB, NWAVES = NCOMP + NLOADW, THREADS = 64 * NWAVES;   // (shadow the defaults)
+template <int MODE, int NSRC, int CH, typename T = float, bool OUTCL = false, int NSUB_T = D3D_NSUB, int NLOAD_T = D3D_NLOADW,
+          int NPIXW_T = 2>
+__global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_tiled_kernel(SweepParams p, TiledArgs a) {   // 3 waves per SIMD: the 168-register budget for either workgroup size
+    constexpr int NSUB = NSUB_T, NLOADW = NLOAD_T, NPIXW = NPIXW_T, TH = 2 * NPIXW;   // (shadow the defaults)
+    constexpr int NCOMP = NPIXW * NSUB, NWAVES = NCOMP + NLOADW, THREADS = 64 * NWAVES;
     constexpr bool F16 = sizeof(T) == 2;
     static_assert(!OUTCL || (MODE == MODE_VARIANCE && !F16), "channel-last bf16 output is built for the fp32 variance volume");
     constexpr int CW = CH * (int)sizeof(T) / 4;   // words per ring position
@@ -1273,16 +1277,19 @@ size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_byt
 #ifndef D3D_SHALLOW_PLANES
 #define D3D_SHALLOW_PLANES 0    // sweeps of at most this many planes take the 6-wave workgroups (0: never -- see launch_ch)
 #endif
-constexpr int SHALLOW_NSUB = 2, SHALLOW_NLOADW = 2, SHALLOW_PLANES = D3D_SHALLOW_PLANES;
+// shallow form: 32 x 8-pixel patches (4 pixel waves x 2 depth sub-ranges + 4 loaders, still 12 waves and all of the LDS):
+// the per-workgroup planning prologue and first-window latency are paid once per 256 pixels instead of once per 128
+constexpr int SHALLOW_NSUB = 2, SHALLOW_NLOADW = D3D_NLOADW, SHALLOW_NPIXW = 4, SHALLOW_PLANES = D3D_SHALLOW_PLANES;
 
 template <int MODE, int NSRC, int CH, typename T, bool OUTCL = false, bool SHALLOW = false>
 static int launch_one(const SweepParams& p, hipStream_t stream) {
     constexpr int CW = CH * (int)sizeof(T) / 4;
     using L = Lds<CW, NSRC>;
-    constexpr int LDS_BYTES = SHALLOW ? 80 * 1024 : 160 * 1024;
+    constexpr int LDS_BYTES = 160 * 1024;
     constexpr int NSUBK = SHALLOW ? SHALLOW_NSUB : NSUB, NLOADK = SHALLOW ? SHALLOW_NLOADW : NLOADW;
-    constexpr int THREADSK = 64 * (NPIXW * NSUBK + NLOADK);
-    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T, OUTCL, NSUBK, NLOADK>;
+    constexpr int NPIXK = SHALLOW ? SHALLOW_NPIXW : NPIXW, THK = 2 * NPIXK;
+    constexpr int THREADSK = 64 * (NPIXK * NSUBK + NLOADK);
+    auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T, OUTCL, NSUBK, NLOADK, NPIXK>;
     if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
     // per device and idempotent: set on every launch (no process-global "done" flag that a second GPU would miss)
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
@@ -1291,7 +1298,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     TiledArgs a;
     a.ngroups = p.C / CH;
     a.tiles_x = ceil_div(p.w, TW);
-    a.tiles_y = ceil_div(p.h, TH);
+    a.tiles_y = ceil_div(p.h, THK);
     a.cap_floats = LDS_BYTES / 4 - L::DATA;
     segments(p.D, (long)a.tiles_x * a.tiles_y * a.ngroups, a.dseg, a.nseg);
     const long nblk = (long)a.tiles_x * a.tiles_y * a.nseg;  // a workgroup sweeps every channel group of its patch
@@ -1338,7 +1345,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
         fprintf(stderr, "[d3d tiled timing] prologue phases: depth range %.0f | candidate windows %.0f | plan tables %.0f (rest: per-lane constants)\n",
                 ht[16] / (double)nblk, ht[17] / (double)nblk, ht[18] / (double)nblk);
         fprintf(stderr, "[d3d tiled timing] barrier wait after the first, per compute wave (pixel rows, depth sub-range):");
-        for (int wv = 0; wv < NPIXW * NSUBK; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
+        for (int wv = 0; wv < NPIXK * NSUBK; ++wv) fprintf(stderr, " %.0f", ht[8 + wv] / (double)nblk);
         fprintf(stderr, "\n");
         fprintf(stderr, "[d3d tiled stats] CH=%d elem=%d wgs=%ld ring=%u fallback=%u mean_step_planes=%.2f mean_steps=%.2f mean_ring_positions=%.0f (cap %d) dseg=%d\n",
                 CH, (int)sizeof(T), nblk, hs[0], hs[1], hs[2] / (double)nblk, hs[3] / (double)nblk, hs[0] ? hs[4] / (double)hs[0] : 0.0,
@@ -1363,14 +1370,10 @@ static int group_channels(int C, int n_src, int elem_bytes) {
 template <int MODE, int NSRC>
 static int launch_ch(const SweepParams& p, hipStream_t stream) {
     const int cg = (MODE == MODE_PAIR) ? p.C : group_channels(p.C, p.n_src, 4);
-    // shallow sweeps of 8-channel groups (the full-resolution cascade stage): two half-size workgroups per CU.  Measured at
-    // 8 planes x 1856 x 2752, 5 views (tools/run_ab.sh NOEXP=1 "-DD3D_SHALLOW_PLANES=0|16"): weighted correlation 2.70 -> 2.25 ms
-    // and variance 2.41 -> 3.06 ms on the bench scene, but 2.85 -> 5.4 ms inside an AdaMVS view, whose wider windows no longer
-    // fit half the LDS (gather fallback).  Off by default (D3D_SHALLOW_PLANES=0); kept as an A/B build.
-#ifndef D3D_SHALLOW_VARIANCE
-#define D3D_SHALLOW_VARIANCE 0
-#endif
-    bool shallow = p.D <= SHALLOW_PLANES && cg == 8 && (MODE == MODE_WEIGHTED || D3D_SHALLOW_VARIANCE);
+    // shallow sweeps of 8-channel groups (the full-resolution cascade stage, 8 planes): 32 x 8-pixel patches (see SHALLOW_*).
+    // (A first attempt, 6-wave workgroups on half the LDS so that two share a CU, helped the weighted mode on the bench
+    // scene but fell back to gathering inside AdaMVS views, whose windows need more than half the LDS.)
+    bool shallow = p.D <= SHALLOW_PLANES && cg == 8;
 #ifdef D3D_EXPERIMENTS
     if (const char* e = getenv("D3D_TILED_SHALLOW")) shallow = shallow && atoi(e) != 0;
 #endif

@@ -1165,11 +1165,14 @@ def test_costregnet_channel_last_path_matches_planar_bf16_path(ops, monkeypatch)
     assert (a - b).abs().max().item() > 0                      # (the channel-last path really ran)
 
 
-@pytest.mark.parametrize("V,C,D,h,w", [(3, 8, 8, 40, 56), (5, 16, 16, 64, 96), (5, 32, 24, 48, 80), (7, 16, 8, 36, 52), (2, 8, 4, 17, 23)])
-def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, C, D, h, w):
+@pytest.mark.parametrize("V,C,D,h,w,sweep", [(3, 8, 8, 40, 56, 0.5), (5, 16, 16, 64, 96, 0.5), (5, 32, 24, 48, 80, 0.5), (7, 16, 8, 36, 52, 0.5),
+                                             (2, 8, 4, 17, 23, 0.5), (5, 16, 16, 64, 96, 12.0), (5, 8, 8, 72, 128, 16.0), (5, 32, 16, 40, 64, 10.0)])
+def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, C, D, h, w, sweep):
     """d3d_variance_volume_cl_bf16 (cas_mvsnet.py:45-60 in bf16 mode): exactly the bf16 rounding (RNE) of what
-    d3d_variance_volume writes, laid out [D,h,w,C] -- so conv0 sees the same operands either way."""
-    proj, dr = S.make_scene(V, h, w, D, sweep_px=D / 2.0, seed=V * 100 + C, yaw_deg=3.0)
+    d3d_variance_volume writes, laid out [D,h,w,C] -- so conv0 sees the same operands either way.  The wide sweeps
+    (pixels per plane) make workgroups fall back to the in-kernel gather, whose stores follow other code than the ring
+    path's (a missing wait state after the 16-byte store showed only there, and only at the cascade's full size)."""
+    proj, dr = S.make_scene(V, h, w, D, sweep_px=D * sweep, seed=V * 100 + C, yaw_deg=3.0)
     f = S.make_features(V, C, h, w, seed=C + D)
     feats = [dev(f[i]) for i in range(V)]
     p34 = ops.compose_projections(dev(proj))
