@@ -1275,7 +1275,7 @@ size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_byt
 }
 
 #ifndef D3D_SHALLOW_PLANES
-#define D3D_SHALLOW_PLANES 0    // sweeps of at most this many planes take the 6-wave workgroups (0: never -- see launch_ch)
+#define D3D_SHALLOW_PLANES 16   // sweeps of at most this many planes take the 32 x 8-pixel patches (0: never)
 #endif
 // shallow form: 32 x 8-pixel patches (4 pixel waves x 2 depth sub-ranges + 4 loaders, still 12 waves and all of the LDS):
 // the per-workgroup planning prologue and first-window latency are paid once per 256 pixels instead of once per 128
@@ -1373,13 +1373,19 @@ static int launch_ch(const SweepParams& p, hipStream_t stream) {
     // shallow sweeps of 8-channel groups (the full-resolution cascade stage, 8 planes): 32 x 8-pixel patches (see SHALLOW_*).
     // (A first attempt, 6-wave workgroups on half the LDS so that two share a CU, helped the weighted mode on the bench
     // scene but fell back to gathering inside AdaMVS views, whose windows need more than half the LDS.)
-    bool shallow = p.D <= SHALLOW_PLANES && cg == 8;
+#ifndef D3D_SHALLOW_CG16
+#define D3D_SHALLOW_CG16 0      // A/B: the 16-channel groups too
+#endif
+    bool shallow = p.D <= SHALLOW_PLANES && (cg == 8 || (D3D_SHALLOW_CG16 && cg == 16));
 #ifdef D3D_EXPERIMENTS
     if (const char* e = getenv("D3D_TILED_SHALLOW")) shallow = shallow && atoi(e) != 0;
 #endif
     if constexpr (MODE == MODE_VARIANCE) {
         if (p.out_cl) {
-            if constexpr (SHALLOW_PLANES > 0) { if (shallow) return launch_one<MODE, NSRC, 8, float, true, true>(p, stream); }
+            if constexpr (SHALLOW_PLANES > 0) {
+                if (shallow && cg == 8) return launch_one<MODE, NSRC, 8, float, true, true>(p, stream);
+                if (D3D_SHALLOW_CG16 && shallow && cg == 16) return launch_one<MODE, NSRC, 16, float, true, true>(p, stream);
+            }
             switch (cg) {
                 case 16: return launch_one<MODE, NSRC, 16, float, true>(p, stream);
                 case 8: return launch_one<MODE, NSRC, 8, float, true>(p, stream);
@@ -1389,7 +1395,8 @@ static int launch_ch(const SweepParams& p, hipStream_t stream) {
     }
     if (p.out_cl) return D3D_ERR_UNSUPPORTED;
     if constexpr (SHALLOW_PLANES > 0 && (MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED)) {
-        if (shallow) return launch_one<MODE, NSRC, 8, float, false, true>(p, stream);
+        if (shallow && cg == 8) return launch_one<MODE, NSRC, 8, float, false, true>(p, stream);
+        if (D3D_SHALLOW_CG16 && shallow && cg == 16) return launch_one<MODE, NSRC, 16, float, false, true>(p, stream);
     }
     (void)shallow;
     switch (cg) {

@@ -1,7 +1,7 @@
 #!/bin/bash
-# GPU box: shallow (6-wave, half-LDS) vs default workgroups of the ring kernel at the cascade-stage shapes (experiments build)
-for s in 0 1; do
-  echo "== D3D_TILED_SHALLOW=$s"
-  D3D_TILED_SHALLOW=$s python tools/stage_sweep_bench.py tiled 2>&1 | grep -a "^stage" 
-  D3D_TILED_STATS=1 D3D_TILED_SHALLOW=$s python tools/stage_sweep_bench.py tiled 2>&1 | grep -a "tiled stats\|per-WG" | sort | uniq -c | sort -rn | awk '{ $1=""; print }' | cut -c1-330 | grep -a "CH=8" | head -4
+# GPU box: what a ring-kernel build variant does to the cascade: stage shapes + the sweep kernels inside whole views.
+# Use as CMD of tools/run_ab.sh, e.g.  NOEXP=1 CMD="tools/shallow_ab.sh" tools/run_ab.sh "-DD3D_SHALLOW_PLANES=0" "-DD3D_SHALLOW_PLANES=16"
+python tools/stage_sweep_bench.py tiled 2>&1 | grep -a "^stage"
+for m in casmvsnet adamvs; do
+  D3D_CONV_PRECISION=bf16 python tools/model_bench.py --model $m --reps 3 2>&1 | grep -a "per reference\|sweep_tiled" | cut -c1-75,150-250
 done
