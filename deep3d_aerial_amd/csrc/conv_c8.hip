@@ -71,7 +71,7 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 }
 
 template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false>
-__global__ __launch_bounds__(NT, NTN > 1 ? 1 : CI <= 8 ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+__global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
     static_assert(!KZF || (NTN == 1 && !OUTCL && !WG), "k_z-folded form: one output channel, planar output");
     constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
@@ -341,8 +341,12 @@ template <bool INCL, bool OUTCL>
 static int launch_fmt(const C8Params& p, int Ci, int Co, hipStream_t st) {
     if (Co > 16) return launch<32, 2, INCL, OUTCL>(p, st);
     switch (Ci) {
-        case 8: return launch<8, 1, INCL, OUTCL>(p, st);
-        case 16: return launch<16, 1, INCL, OUTCL>(p, st);
+        case 8: return launch<8, 1, INCL, OUTCL>(p, st);   // (32-wide tiles: 0.63 -> 0.74 ms at 8 x 1856 x 2752 -- four workgroups per CU either way)
+        case 16:
+            // channel-last in and out: 32-wide tiles keep the kernel inside 128 registers (102), so two workgroups share a CU
+            // (16 -> 8 at 32 x 928 x 1376: 1.09 -> 0.95 ms on the same box)
+            if constexpr (INCL && OUTCL) return launch<16, 1, true, true, 2>(p, st);
+            else return launch<16, 1, INCL, OUTCL>(p, st);
         default: return launch<32, 1, INCL, OUTCL>(p, st);
     }
 }
