@@ -45,10 +45,12 @@ class Infer_UCSNet(nn.Module):
         self.feature_extraction = FeatureNet_mvsnet(base_channels=8, stride=4, num_stage=self.num_stage, arch_mode=arch_mode)
         self.cost_regularization = nn.ModuleList([CostRegNet(in_channels=self.feature_extraction.out_channels[i],
                                                              base_channels=self.base_chs[i]) for i in range(self.num_stage)])
+        self.feature_cache = None   # dataset.FeatureCache: pyramids of shared images across reference views (predict_views)
 
-    def forward(self, imgs, proj_matrices, depth_values):
-        features = extract_features(self.feature_extraction, imgs)
-        B, H, W = imgs.shape[0], imgs.shape[3], imgs.shape[4]
+    def forward(self, imgs, proj_matrices, depth_values, image_keys=None):
+        """image_keys (optional, with self.feature_cache set): one hashable key per view, as in the other drivers."""
+        features = extract_features(self.feature_extraction, imgs, image_keys, self.feature_cache)
+        B, _, H, W = features[0]["stage3"].shape   # the finest level has the image's size
         outputs = {}
         depth, exp_var = None, None
         for stage_idx in range(self.num_stage):

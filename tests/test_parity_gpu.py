@@ -1181,3 +1181,18 @@ def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, 
     got = ops.variance_volume_cl(feats, p34, dv)
     assert got.dtype == torch.bfloat16 and tuple(got.shape) == (D, h, w, C)
     assert np.array_equal(_cl_host(got), _bf16_round(planar))
+
+
+def test_predict_views_ucsnet(ops, tmp_path):
+    """`--model ucsnet` through the harness (predict.py:78-81 in the reference fails in the constructor): products
+    of a synthetic block are written and finite."""
+    from deep3d_aerial_amd import predict
+
+    net = _fill(predict.build_model("ucsnet", 64), 13)
+    ds = predict.SyntheticBlock(2, 3, 64, 96, 64, seed=5)
+    names = predict.predict_views(net, ds, str(tmp_path), rank=0, world_size=1)
+    assert names == ["view_0000", "view_0001"]
+    depth, _ = predict.load_pfm(str(tmp_path / "view_0001_init.pfm"))
+    prob, _ = predict.load_pfm(str(tmp_path / "view_0001_prob.pfm"))
+    assert depth.shape == (64, 96) and np.isfinite(depth).all() and np.isfinite(prob).all()
+    assert (prob >= 0).all() and (prob <= 1 + 1e-5).all()
