@@ -1,0 +1,243 @@
+// 3x3 stride-1 2-D convolution on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation) for the large image
+// layers of the slice regularisers in bf16 mode (BASELINE config 3): ConvReLU(C, 8) and the two convolutions of a conv-GRU
+// cell with their fused epilogues (adamvs.py:403-427 SliceCostRegNetRED, module.py:5-51 ConvGRUCell) --
+//     gates:      g = conv(cat(x, h)) + b;  out = [sigmoid(g_r) * h | sigmoid(g_u)]
+//     candidate:  c = conv(cat(x, r*h)) + b;  h' = u * h + (1 - u) * tanh(c)
+// Tensors stay planar fp32 in HBM (the recurrent state keeps its precision; only the MFMA operands are bf16, as in every
+// bf16-mode kernel), the channel concat is never materialised (two input pointers).
+//
+// Why its own kernel: the round-1 stream kernel walks an image row by row (one barrier and one epilogue per row and tile
+// column); at these shapes its waves wait 64 % of their cycles and the matrix cores are 7 % busy
+// (profiles/r02_gru_conv_counters.txt).  Here a workgroup (8 waves) takes 64 x 8 (or 32 x 8) output pixels per step: the
+// whole 66 x 10 patch is staged at once (fp32 planar -> bf16 channel-last cells, RNE), all nine taps are one sweep
+// (M = 16 consecutive pixels of a row, N = 16 output channels, K = (k_y, k_x, c_in) in blocks of 32, an A operand = one
+// ds_read_b128 of 8 channels), and the workgroup walks `tper` tiles down the image with the next patch's loads in flight
+// during the sweep.  D[pixel][channel]: a lane leaves with four consecutive pixels of one channel = 16-byte loads of
+// h / u and 16-byte stores.
+#include "common.h"
+
+namespace d3d {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr int TYZ = 8;              // output rows of a tile = waves
+constexpr int PYZ = TYZ + 2;        // staged rows
+constexpr int NTZ = 64 * TYZ;
+
+struct Z2Params {
+    const float* in;      // [C1, H, W]
+    const float* in2;     // [CI - C1, H, W] or null: second part of the channel concat
+    int C1;
+    const u4* wpk;        // [NKB][N tiles][64 lanes] B fragments (ops._pack_z2_bf16)
+    const float* scale;   // [CO] or null
+    const float* shift;   // [CO] or null (the bias)
+    const float* skip;    // act 0 | 1: [CO,H,W] added before / after the activation, or null; act 2: h [ep_split,H,W]; act 3: h [CO,H,W]
+    const float* aux1;    // act 3: the update gate u [CO,H,W]
+    float* out;           // [CO, H, W]
+    int H, W, CO;
+    int act;              // 0 none | 1 ReLU | 2 GRU gates | 3 GRU update
+    int ep_split;         // act 2: channels below it are multiplied by h
+    int skip_after_act;
+    int tper;             // tiles per workgroup along y
+};
+
+__device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+template <int CI, int NTN, int MGN>
+__global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
+    constexpr int TX = 16 * MGN, PX = TX + 2;
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);   // bytes per cell: an odd number of 16-byte slots
+    constexpr int G = CI / 8;
+    constexpr int PATCH = PX * PYZ * CS;
+    constexpr int AW = MGN * NTN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W;
+    const size_t plane = (size_t)H * W;
+    const int x0 = blockIdx.x * TX;
+    const int nty = (H + TYZ - 1) / TYZ;
+    const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
+
+    for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+
+    // ---- staging: task = (patch pixel, 8-channel group); the group's planes come from `in` or from `in2` -------------
+    constexpr int NTASK = PX * PYZ * G;
+    constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
+    float stg[ROUNDS][8];
+    auto issue = [&](int ty) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NTZ;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PX, px = pix - py * PX;
+            const int gx = x0 + px - 1, gy = ty * TYZ + py - 1;
+            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const int c = 8 * g;
+            const float* __restrict__ base = c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane;
+            const float* __restrict__ src = base + (ok ? (size_t)gy * W + gx : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * plane];
+                stg[r][k] = ok ? v : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NTZ;
+            if (task < NTASK) {
+                const int pix = task / G, g = task - pix * G;
+                const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
+                              pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+            }
+        }
+    };
+
+    // K index k = 32 kb + 8 (lane >> 4) + j -> tap t = k / CI = (k_y, k_x), channel k % CI
+    auto a_offset = [&](int kb, int kgroup) {
+        const int k0 = 32 * kb + 8 * kgroup;
+        const int t = k0 / CI, c = k0 % CI;
+        const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
+        return (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
+    };
+    const int abase = (wave * PX + (lane & 15)) * CS;
+
+    auto tile = [&](int ty, const unsigned char* buf) {
+        f4 acc[AW];
+#pragma unroll
+        for (int i = 0; i < AW; ++i) acc[i] = (f4){0, 0, 0, 0};
+        int kgroup = lane >> 4;
+        asm volatile("" : "+v"(kgroup));
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int aoffk = a_offset(kb, kgroup);
+            bf16x8 b[NTN];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(kb * NTN + nt) * 64 + lane]);
+#pragma unroll
+            for (int mg = 0; mg < MGN; ++mg) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+                    acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: D row (pixel) = (lane >> 4) * 4 + register, column (channel) = lane & 15 ---------------------
+        const int oy = ty * TYZ + wave;
+        if (oy >= H) return;
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            const int co = nt * 16 + (lane & 15);
+            if (co >= p.CO) continue;
+            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+            const bool gate_h = p.act == 2 && co < p.ep_split;
+#pragma unroll
+            for (int mg = 0; mg < MGN; ++mg) {
+                const int ox = x0 + mg * 16 + (lane >> 4) * 4;
+                if (ox >= W) continue;                              // W % 4 == 0: a quad is inside or outside as a whole
+                const size_t o = (size_t)co * plane + (size_t)oy * W + ox;
+                f4 y = acc[mg * NTN + nt] * sc + sh;
+                if (p.act == 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k] = 1.0f / (1.0f + __expf(-y[k]));
+                    if (gate_h) y *= *reinterpret_cast<const f4*>(p.skip + o);
+                } else if (p.act == 3) {
+                    const f4 u = *reinterpret_cast<const f4*>(p.aux1 + o), hh = *reinterpret_cast<const f4*>(p.skip + o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * tanhf(y[k]);
+                } else {
+                    if (p.skip && !p.skip_after_act) y += *reinterpret_cast<const f4*>(p.skip + o);
+                    if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+                    if (p.skip && p.skip_after_act) y = *reinterpret_cast<const f4*>(p.skip + o) + y;
+                }
+                *reinterpret_cast<f4*>(p.out + o) = y;
+            }
+        }
+    };
+
+    // ---- walk the tiles of this workgroup: the next patch's loads fly during the sweep -------------------------------
+    issue(t0);
+    commit(smem);
+    __syncthreads();
+    int cur = 0;
+    for (int ty = t0; ty < t1; ++ty) {
+        const bool more = ty + 1 < t1;
+        if (more) issue(ty + 1);
+        tile(ty, smem + cur * PATCH);
+        if (more) commit(smem + (cur ^ 1) * PATCH);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int CI, int NTN, int MGN>
+static int launch_z2(const Z2Params& p, hipStream_t stream) {
+    constexpr int TX = 16 * MGN, PX = TX + 2;
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * PX * PYZ * CS + NKB * NTN * 64 * 16;
+    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN>;
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
+    Z2Params q = p;
+    const int gx = ceil_div(p.W, TX), nty = ceil_div(p.H, TYZ);
+    int tper = 8;   // every tile re-reads two halo rows of its neighbour; enough workgroups for 256 CUs come first
+    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    q.tper = tper;
+    const int gy = ceil_div(nty, tper);
+    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NTZ), lds, stream, q);
+    D3D_LAUNCH_CHECK("conv2d_zs_bf16_kernel launch");
+    return D3D_OK;
+}
+
+}  // namespace
+
+}  // namespace d3d
+
+using namespace d3d;
+
+extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                                     const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                                     int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && C1 > 0 && C2 >= 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act >= 0 && act <= 3, "bad act %d", act);
+    D3D_REQUIRE(C2 == 0 || in2, "second input missing");
+    D3D_REQUIRE(act < 2 || skip, "GRU epilogue (act %d) needs the state h in `skip`", act);
+    D3D_REQUIRE(act != 2 || (ep_split > 0 && ep_split <= Co), "GRU gate epilogue: bad ep_split %d", ep_split);
+    D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
+    const int Ci = C1 + C2;
+    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && C1 % 8 == 0 && C2 % 8 == 0 && Co <= 32 && W % 4 == 0;
+    if (!shape) {
+        set_error("d3d_conv2d_k3_zs_bf16: C_in = %d + %d (8 | 16 | 32 in groups of 8), C_out = %d (<= 32), W = %d (multiple of 4) not taken",
+                  C1, C2, Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.in2 = in2; p.C1 = C1; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
+    p.skip = skip; p.aux1 = aux1; p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act; p.ep_split = ep_split;
+    p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    if (Co > 16) {
+        if (Ci == 32) return launch_z2<32, 2, 2>(p, st);
+        if (Ci == 16) return launch_z2<16, 2, 4>(p, st);
+        return launch_z2<8, 2, 4>(p, st);
+    }
+    if (Ci == 32) return launch_z2<32, 1, 2>(p, st);
+    if (Ci == 16) return launch_z2<16, 1, 4>(p, st);
+    return launch_z2<8, 1, 4>(p, st);
+}

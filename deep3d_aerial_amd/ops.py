@@ -652,6 +652,42 @@ def conv2d_stream(x, weight, scale, shift, skip, act, x2=None, aux1=None, ep_spl
     return out  # pixels from which the vector-unit streaming form of conv2d_k3 is used
 
 
+def _pack_z2_bf16(w):
+    """nn.Conv2d weight [Co,Ci,3,3] -> B operands of v_mfma_f32_16x16x32_bf16 for d3d_conv2d_k3_zs_bf16: K = (k_y, k_x, c_in)
+    padded to a multiple of 32, output channels to a multiple of 16; [K block][N tile][lane][8], lane l = column l & 15,
+    K rows 8 * (l >> 4) .. + 7 of its block.  int16 bits (bf16)."""
+    Co, Ci = w.shape[0], w.shape[1]
+    K = 9 * Ci
+    nkb = (K + 31) // 32
+    ntn = (max(Co, 16) + 15) // 16
+    b = torch.zeros((nkb * 32, ntn * 16), dtype=torch.float32, device=w.device)
+    b[:K, :Co] = w.permute(2, 3, 1, 0).reshape(K, Co)                  # [ky, kx, ci, co]
+    b = b.reshape(nkb, 4, 8, ntn, 16).permute(0, 3, 1, 4, 2)           # [kb][ntile][kgroup][n][j]
+    return b.reshape(nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
+def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False):
+    """3x3 stride-1 conv over cat(x, x2) with bf16 matrix-core operands and the fused epilogues of the slice regularisers
+    (act 0 | 1 | 2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16).  Returns None for shapes the kernel does not take."""
+    Ci0, H, W = x.shape
+    Ci1 = 0 if x2 is None else x2.shape[0]
+    Co = weight.shape[0]
+    if (Ci0 + Ci1) not in (8, 16, 32) or Ci0 % 8 or Ci1 % 8 or Co > 32 or W % 4 or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+        return None
+    if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
+        raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
+    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_conv2d_k3_zs_bf16(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
+                                           _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), _opt(aux1, "aux1"),
+                                           int(act), int(ep_split), int(bool(skip_after_act)), Co, H, W, _chk(out, "out"),
+                                           _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k3_zs_bf16")
+    return out
+
+
 def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None):
     """3x3 conv over cat(x, x2) channels. x [Ci0,H,W], x2 [Ci1,H,W]|None, weight [Co,Ci0+Ci1,3,3]."""
     Ci0, H, W = x.shape
@@ -661,6 +697,11 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
+    if stride == 1 and act in (0, 1) and conv_precision() == "bf16" and _use_mfma() and H * W >= 256 * 256:
+        # bf16 mode, large image layers of the slice regularisers: one tile per step on v_mfma_f32_16x16x32_bf16
+        y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2)
+        if y is not None:
+            return y
     if stride == 1 and act in (0, 1):
         y = conv2d_stream(x, weight, scale, shift, skip, act, x2=x2)
         if y is not None:
@@ -1144,6 +1185,13 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
     Hc = h.shape[0]
     if not _use_mfma() or _os.environ.get("D3D_CONV", "mfma") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
         return None
+    if conv_precision() == "bf16" and x.shape[1] * x.shape[2] >= 128 * 128:
+        # bf16 mode: both convolutions on the tile kernel (v_mfma_f32_16x16x32_bf16, 16-byte epilogue accesses)
+        g = conv2d_zs(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
+        if g is not None:
+            hn = conv2d_zs(x, w_cand, None, b_cand, h, 3, x2=g[:Hc], aux1=g[Hc:])
+            if hn is not None:
+                return hn
     # both convolutions of a large cell run on the vector-unit kernel (AdaMVS view, same device: 87.9 ms, with the
     # gates on the matrix cores 89.3 ms; D3D_GRU_GATES=mfma selects that)
     g = None

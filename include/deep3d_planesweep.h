@@ -247,6 +247,19 @@ int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream);
 
+/* module.py:5-51 ConvGRUCell / adamvs.py:409-413 ConvReLU of the slice regularisers, bf16 mode: 3x3 stride-1 2-D convolution
+ * over the channel concat of `in` [C1,H,W] and `in2` [C2,H,W] (may be NULL, C2 = 0) on v_mfma_f32_16x16x32_bf16, one 64 x 8
+ * (32 x 8) tile of the image per step, planar fp32 tensors in HBM.  out [Co,H,W] = epilogue(conv * scale + shift):
+ *   act 0 none | 1 ReLU, with `skip` [Co,H,W] (may be NULL) added before the activation or, skip_after_act, after it;
+ *   act 2 GRU gates: sigmoid, channels < ep_split multiplied by h = skip [ep_split,H,W]      (-> [r*h | u]);
+ *   act 3 GRU update: u*h + (1-u)*tanh(.), h = skip [Co,H,W], u = aux1 [Co,H,W].
+ * C1 + C2 = 8 | 16 | 32 in groups of 8, Co <= 32, W % 4 == 0; D3D_ERR_UNSUPPORTED otherwise (nothing launched).
+ * wpacked: the weight [Co,C1+C2,3,3] rounded to bf16 in B-operand lane order, [K block][N tile][lane][8], K = (k_y,k_x,c_in)
+ * (ops._pack_z2_bf16). */
+int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                          const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                          int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /* ---- channel-last bf16 activations between the layers of a CostRegNet (bf16 mode, BASELINE config 3) ------------------
  * "CL" volume: bf16 [D][H][W][C].  The matrix-core kernels round their operands to bf16 when they stage them, so a layer
  * that hands its output on in this form loses nothing its consumer would have kept, the activation traffic halves, and a

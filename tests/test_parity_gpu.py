@@ -720,6 +720,36 @@ def test_full_size_cascade_mfma_equals_direct_kernels(ops, model, monkeypatch):
     assert rel_l1(outs["mfma"][1], outs["direct"][1]) <= 1e-3
 
 
+def test_full_size_adamvs_bf16_within_depth_budget(ops, monkeypatch):
+    """BASELINE config 3 for the AdaMVS cascade at 2752x1856, 5 views: bf16 matrix-core operands (tile kernels for the conv-GRU
+    cells, fp32 recurrent state) stay within the north-star 1e-3 relative L1 of the fp32 depth map and agree with round 1's
+    row-streamed bf16 kernels."""
+    from deep3d_aerial_amd import predict
+
+    net = _fill(predict.build_model("adamvs", 384), 23)
+    s = predict.SyntheticBlock(1, 5, 2752, 1856, 384, seed=9)[0]
+    imgs = dev(s["imgs"])[None]
+    pm = {k: dev(v)[None] for k, v in s["proj_matrices"].items()}
+    dv = dev(s["depth_values"])[None]
+    monkeypatch.setenv("D3D_CONV", "mfma")
+    outs = {}
+    for tag, prec, zs in (("fp32", "fp32", "1"), ("bf16_tile", "bf16", "1"), ("bf16_stream", "bf16", "0")):
+        monkeypatch.setenv("D3D_CONV2D_ZS", zs)
+        ops.set_conv_precision(prec)
+        try:
+            with torch.no_grad():
+                o = net(imgs, pm, dv)
+        finally:
+            ops.set_conv_precision(None)
+        outs[tag] = host(o["depth"][0])
+        del o
+        torch.cuda.empty_cache()
+    assert np.isfinite(outs["bf16_tile"]).all()
+    assert rel_l1(outs["bf16_tile"], outs["fp32"]) <= 1e-3
+    assert rel_l1(outs["bf16_tile"], outs["bf16_stream"]) <= 5e-4
+    assert not np.array_equal(outs["bf16_tile"], outs["bf16_stream"])
+
+
 def test_full_size_cascade_bf16_regulariser_within_depth_budget(ops, monkeypatch):
     """BASELINE config 3 at the BASELINE image size (2752x1856, 5 views, CasMVSNet): bf16 matrix-core regularisation on
     channel-last bf16 activations (variance volume written channel-last by the sweep kernel) stays within the north-star
@@ -1196,3 +1226,70 @@ def test_predict_views_ucsnet(ops, tmp_path):
     prob, _ = predict.load_pfm(str(tmp_path / "view_0001_prob.pfm"))
     assert depth.shape == (64, 96) and np.isfinite(depth).all() and np.isfinite(prob).all()
     assert (prob >= 0).all() and (prob <= 1 + 1e-5).all()
+
+
+@pytest.mark.parametrize("Ci0,Ci1,Co,H,W,act", [(8, 0, 8, 9, 68, 1), (16, 0, 8, 20, 132, 0), (32, 0, 8, 7, 64, 1), (8, 8, 16, 17, 72, 2),
+                                                (8, 8, 8, 17, 72, 3), (16, 16, 32, 11, 36, 2), (16, 16, 16, 11, 36, 3), (8, 8, 16, 1, 4, 2),
+                                                (8, 8, 8, 70, 260, 3), (8, 0, 16, 33, 128, 1), (16, 16, 32, 40, 100, 2)])
+def test_conv2d_tile_kernel_bf16_with_gru_epilogues(ops, oracle, Ci0, Ci1, Co, H, W, act):
+    """d3d_conv2d_k3_zs_bf16 (module.py:5-51 ConvGRUCell, adamvs.py:409 ConvReLU in bf16 mode): the fp32 oracle convolution on
+    bf16-rounded operands over the channel concat, then the epilogue in fp32 -- none / ReLU with a skip before or after
+    the activation, the gate form [sigmoid(r) * h | sigmoid(u)], the update u * h + (1 - u) * tanh(c)."""
+    rng = np.random.default_rng(Ci0 * 100 + Co + W + act)
+    x = rng.standard_normal((Ci0, H, W)).astype(np.float32)
+    x2 = rng.standard_normal((Ci1, H, W)).astype(np.float32) if Ci1 else None
+    w = (0.1 * rng.standard_normal((Co, Ci0 + Ci1, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    xin = x if x2 is None else np.concatenate([x, x2], 0)
+    conv = oracle.conv2d_k3(_bf16_round(xin), _bf16_round(w), None) + b[:, None, None]
+    tol = 4e-5 * max(1.0, np.abs(conv).max())
+    d = lambda a: None if a is None else dev(a)
+    if act in (0, 1):
+        sk = rng.standard_normal((Co, H, W)).astype(np.float32)
+        for after in (False, True):
+            got = ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(sk), act, x2=d(x2), skip_after_act=after)
+            assert got is not None
+            y = conv + (0 if after else sk)
+            y = np.maximum(y, 0) if act == 1 else y
+            want = y + (sk if after else 0)
+            assert np.abs(host(got) - want).max() <= 2 * tol, after
+        plain = ops.conv2d_zs(dev(x), dev(w), None, dev(b), None, act, x2=d(x2))
+        want = np.maximum(conv, 0) if act == 1 else conv
+        assert np.abs(host(plain) - want).max() <= tol
+    elif act == 2:
+        Hc = Co // 2
+        h = rng.standard_normal((Hc, H, W)).astype(np.float32)
+        got = host(ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(h), 2, x2=d(x2), ep_split=Hc))
+        sg = 1.0 / (1.0 + np.exp(-conv.astype(np.float64)))
+        want = np.concatenate([sg[:Hc] * h, sg[Hc:]], 0)
+        assert np.abs(got - want).max() <= 2 * tol
+    else:
+        h = rng.standard_normal((Co, H, W)).astype(np.float32)
+        u = rng.uniform(0, 1, (Co, H, W)).astype(np.float32)
+        got = host(ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(h), 3, x2=d(x2), aux1=dev(u)))
+        want = u * h + (1 - u) * np.tanh(conv.astype(np.float64))
+        assert np.abs(got - want).max() <= 2 * tol
+    with pytest.raises(RuntimeError):
+        ops.conv2d_zs(dev(x), dev(w), None, dev(b), None, 3, x2=d(x2))        # the update epilogue needs h and u
+
+
+def test_gru_cell_bf16_tile_kernels_match_the_stream_kernels(ops, monkeypatch):
+    """ConvGRUCell.forward (module.py:24-51) in bf16 mode at a slice size that takes the tile kernels: same operands and
+    formulas as round 1's row-streamed bf16 kernels, so the two agree to fp32 summation order."""
+    from deep3d_aerial_amd.module import ConvGRUCell
+
+    torch.manual_seed(7)
+    cell = ConvGRUCell(8, 8, 3).cuda().eval()
+    x, h = torch.randn(8, 136, 260, device="cuda"), torch.randn(8, 136, 260, device="cuda")
+    ops.set_conv_precision("bf16")
+    try:
+        with torch.no_grad():
+            a, _ = cell(x, h)
+            monkeypatch.setenv("D3D_CONV2D_ZS", "0")
+            b, _ = cell(x, h)
+            ops.set_conv_precision("fp32")
+            c, _ = cell(x, h)
+    finally:
+        ops.set_conv_precision(None)
+    assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert 1e-5 < (a - c).abs().max().item() <= 0.05 * max(1.0, c.abs().max().item())     # bf16 operands, fp32 state
