@@ -16,6 +16,8 @@
 // h / u and 16-byte stores.
 #include "common.h"
 
+#include <type_traits>
+
 namespace d3d {
 
 namespace {
@@ -204,11 +206,336 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
     return D3D_OK;
 }
 
+// ---- stride 2 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1) of the slice regulariser): out (y, x) reads in (2y + k_y - 1, 2x + k_x - 1) --
+// 32 x 8 OUTPUT pixels per step; the staged 65 x 17 patch keeps the even and the odd columns of a row in separate runs, so
+// the 16 pixels of an A operand (input columns 2m + k_x - 1) are 16 consecutive cells.  p.H, p.W: INPUT size.
+template <int CI, int NTN>
+__global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
+    constexpr int MG = 2, TXO = 16 * MG, PXI = 2 * TXO + 1, PYI = 2 * TYZ + 1, NEVEN = TXO + 1;
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int G = CI / 8;
+    constexpr int PATCH = PXI * PYI * CS;
+    constexpr int AW = MG * NTN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t plane = (size_t)H * W, oplane = (size_t)Ho * Wo;
+    const int xo0 = blockIdx.x * TXO;
+    const int nty = (Ho + TYZ - 1) / TYZ;
+    const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
+
+    for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+
+    constexpr int NTASK = PXI * PYI * G;
+    constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
+    float stg[ROUNDS][8];
+    auto issue = [&](int ty) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NTZ;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PXI, px = pix - py * PXI;
+            const int gx = 2 * xo0 - 1 + px, gy = 2 * ty * TYZ - 1 + py;
+            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const float* __restrict__ src = p.in + (size_t)(8 * g) * plane + (ok ? (size_t)gy * W + gx : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * plane];
+                stg[r][k] = ok ? v : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NTZ;
+            if (task < NTASK) {
+                const int pix = task / G, g = task - pix * G;
+                const int py = pix / PXI, px = pix - py * PXI;
+                const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
+                const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
+                              pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                *reinterpret_cast<u4*>(dst + cell * CS + g * 16) = v;
+            }
+        }
+    };
+    auto a_offset = [&](int kb, int kgroup) {
+        const int k0 = 32 * kb + 8 * kgroup;
+        const int t = k0 / CI, c = k0 % CI;
+        const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;
+        const int col = kx == 1 ? NEVEN : (kx >> 1);   // even run index m (k_x = 0) | m + 1 (k_x = 2), odd run index m (k_x = 1)
+        return (ky * PXI + col) * CS + (t < 9 ? c : 0) * 2;
+    };
+    const int abase = (2 * wave * PXI + (lane & 15)) * CS;
+
+    auto tile = [&](int ty, const unsigned char* buf) {
+        f4 acc[AW];
+#pragma unroll
+        for (int i = 0; i < AW; ++i) acc[i] = (f4){0, 0, 0, 0};
+        int kgroup = lane >> 4;
+        asm volatile("" : "+v"(kgroup));
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int aoffk = a_offset(kb, kgroup);
+            bf16x8 b[NTN];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(kb * NTN + nt) * 64 + lane]);
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+                    acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+            }
+        }
+        const int oy = ty * TYZ + wave;
+        if (oy >= Ho) return;
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            const int co = nt * 16 + (lane & 15);
+            if (co >= p.CO) continue;
+            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) {
+                const int ox = xo0 + mg * 16 + (lane >> 4) * 4;
+                if (ox >= Wo) continue;                             // Wo % 4 == 0
+                const size_t o = (size_t)co * oplane + (size_t)oy * Wo + ox;
+                f4 y = acc[mg * NTN + nt] * sc + sh;
+                if (p.skip && !p.skip_after_act) y += *reinterpret_cast<const f4*>(p.skip + o);
+                if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+                if (p.skip && p.skip_after_act) y = *reinterpret_cast<const f4*>(p.skip + o) + y;
+                *reinterpret_cast<f4*>(p.out + o) = y;
+            }
+        }
+    };
+
+    issue(t0);
+    commit(smem);
+    __syncthreads();
+    int cur = 0;
+    for (int ty = t0; ty < t1; ++ty) {
+        const bool more = ty + 1 < t1;
+        if (more) issue(ty + 1);
+        tile(ty, smem + cur * PATCH);
+        if (more) commit(smem + (cur ^ 1) * PATCH);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+// ---- transposed, k = 3, stride 2, pad 1, output_pad 1 (adamvs.py:413-417 upconv1 16 -> 8 with the skip before the ReLU, upconv2d
+// 8 -> 1): four per-parity dense convolutions over one staged 33 x 9 input patch (32 x 8 input pixels = 64 x 16 outputs per
+// step); the two column parities of an output row are interleaved in registers, a lane stores 8 consecutive pixels.
+constexpr int ntaps2(int py, int px) { return (1 + py) * (1 + px); }
+constexpr int nkb2(int CI, int py, int px) { return (ntaps2(py, px) * CI + 31) / 32; }
+constexpr int frag_base2(int CI, int c) {
+    int s = 0;
+    for (int q = 0; q < c; ++q) s += nkb2(CI, q >> 1, q & 1);
+    return s;
+}
+
+template <int CI>
+__global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
+    constexpr int MG = 2, TXI = 16 * MG, PXI = TXI + 1, PYI = TYZ + 1;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int G = CI / 8;
+    constexpr int PATCH = PXI * PYI * CS;
+    constexpr int NFRAG = frag_base2(CI, 4);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W, OW = 2 * W;
+    const size_t plane = (size_t)H * W, oplane = 4 * plane;
+    const int ix0 = blockIdx.x * TXI;
+    const int nty = (H + TYZ - 1) / TYZ;
+    const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
+
+    for (int i = tid; i < NFRAG * 64; i += NTZ) wlds[i] = p.wpk[i];
+
+    constexpr int NTASK = PXI * PYI * G;
+    constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
+    float stg[ROUNDS][8];
+    auto issue = [&](int ty) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NTZ;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PXI, px = pix - py * PXI;
+            const int gx = ix0 + px, gy = ty * TYZ + py;
+            const bool ok = task < NTASK && gx < W && gy < H;
+            const float* __restrict__ src = p.in + (size_t)(8 * g) * plane + (ok ? (size_t)gy * W + gx : 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * plane];
+                stg[r][k] = ok ? v : 0.0f;
+            }
+        }
+    };
+    auto commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NTZ;
+            if (task < NTASK) {
+                const int pix = task / G, g = task - pix * G;
+                const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
+                              pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+            }
+        }
+    };
+    const int abase = (wave * PXI + (lane & 15)) * CS;
+
+    auto row = [&](auto pyc, int ty, const unsigned char* buf) {   // output row 2 iy + PY of this wave's input row: both column parities
+        constexpr int PY = decltype(pyc)::value;
+        f4 acc[2][MG];
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) acc[px][mg] = (f4){0, 0, 0, 0};
+        int kgroup = lane >> 4;
+        asm volatile("" : "+v"(kgroup));
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            const int NKB = nkb2(CI, PY, px);
+            const int FB = frag_base2(CI, PY * 2 + px);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int k0 = 32 * kb + 8 * kgroup;
+                const int t = k0 / CI, c = k0 % CI;
+                const bool real = t < ntaps2(PY, px);
+                const int dx = real ? t % (1 + px) : 0, dy = real ? t / (1 + px) : 0;
+                const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
+                const bf16x8 bw = __builtin_bit_cast(bf16x8, wlds[(FB + kb) * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
+                    acc[px][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[px][mg], 0, 0, 0);
+                }
+            }
+        }
+        const int iy = ty * TYZ + wave;
+        if (iy >= H) return;
+        const int oy = 2 * iy + PY;
+        const int co = lane & 15;
+        if (co >= p.CO) return;
+        const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            const int ix = ix0 + mg * 16 + (lane >> 4) * 4;
+            if (ix >= W) continue;                                  // W % 4 == 0: four input pixels = eight outputs, inside or outside as a whole
+            const size_t o = (size_t)co * oplane + (size_t)oy * OW + 2 * ix;
+            const f4 e = acc[0][mg] * sc + sh, od = acc[1][mg] * sc + sh;
+            f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
+            if (p.skip && !p.skip_after_act) { lo += *reinterpret_cast<const f4*>(p.skip + o); hi += *reinterpret_cast<const f4*>(p.skip + o + 4); }
+            if (p.act == 1) { lo = __builtin_elementwise_max(lo, (f4){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4){0, 0, 0, 0}); }
+            if (p.skip && p.skip_after_act) { lo = *reinterpret_cast<const f4*>(p.skip + o) + lo; hi = *reinterpret_cast<const f4*>(p.skip + o + 4) + hi; }
+            *reinterpret_cast<f4*>(p.out + o) = lo;
+            *reinterpret_cast<f4*>(p.out + o + 4) = hi;
+        }
+    };
+
+    issue(t0);
+    commit(smem);
+    __syncthreads();
+    int cur = 0;
+    for (int ty = t0; ty < t1; ++ty) {
+        const bool more = ty + 1 < t1;
+        if (more) issue(ty + 1);
+        row(std::integral_constant<int, 0>{}, ty, smem + cur * PATCH);
+        row(std::integral_constant<int, 1>{}, ty, smem + cur * PATCH);
+        if (more) commit(smem + (cur ^ 1) * PATCH);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int CI, int NTN>
+static int launch_s2z(const Z2Params& p, hipStream_t stream) {
+    constexpr int NKB = (9 * CI + 31) / 32;
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * 65 * 17 * CS + NKB * NTN * 64 * 16;
+    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN>;
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
+    Z2Params q = p;
+    const int Ho = (p.H - 1) / 2 + 1, Wo = (p.W - 1) / 2 + 1;
+    const int gx = ceil_div(Wo, 32), nty = ceil_div(Ho, TYZ);
+    int tper = 8;
+    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    q.tper = tper;
+    const int gy = ceil_div(nty, tper);
+    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NTZ), lds, stream, q);
+    D3D_LAUNCH_CHECK("conv2d_s2_zs_bf16_kernel launch");
+    return D3D_OK;
+}
+
+template <int CI>
+static int launch_tz(const Z2Params& p, hipStream_t stream) {
+    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * 33 * 9 * CS + frag_base2(CI, 4) * 64 * 16;
+    auto kern = convt2d_zs_bf16_kernel<CI>;
+    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc != D3D_OK) return rc;
+    Z2Params q = p;
+    const int gx = ceil_div(p.W, 32), nty = ceil_div(p.H, TYZ);
+    int tper = 8;
+    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    q.tper = tper;
+    const int gy = ceil_div(nty, tper);
+    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NTZ), lds, stream, q);
+    D3D_LAUNCH_CHECK("convt2d_zs_bf16_kernel launch");
+    return D3D_OK;
+}
+
 }  // namespace
 
 }  // namespace d3d
 
 using namespace d3d;
+
+extern "C" int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                       const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                       d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    const int Wo = (W - 1) / 2 + 1;
+    if ((Ci != 8 && Ci != 16) || Co > 32 || Wo % 4 != 0) {   // (C_in = 32: two 65 x 17 patches of 80-byte cells exceed the LDS)
+        set_error("d3d_conv2d_k3s2_zs_bf16: C_in = %d (8 | 16), C_out = %d (<= 32), output width %d (multiple of 4) not taken", Ci, Co, Wo);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    if (Co > 16) return Ci == 8 ? launch_s2z<8, 2>(p, st) : launch_s2z<16, 2>(p, st);
+    return Ci == 8 ? launch_s2z<8, 1>(p, st) : launch_s2z<16, 1>(p, st);
+}
+
+extern "C" int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
+                                                float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    if ((Ci != 8 && Ci != 16 && Ci != 32) || Co > 16 || W % 4 != 0) {
+        set_error("d3d_convtranspose2d_k3s2_zs_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16), W = %d (multiple of 4) not taken", Ci, Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    return Ci == 8 ? launch_tz<8>(p, st) : Ci == 16 ? launch_tz<16>(p, st) : launch_tz<32>(p, st);
+}
 
 extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                                      const float* shift, const float* skip, const float* aux1, int act, int ep_split,

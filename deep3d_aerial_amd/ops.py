@@ -688,6 +688,70 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     return out
 
 
+def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=False):
+    """3x3 stride-2 conv (pad 1) with bf16 matrix-core operands on the tile kernel; None for shapes it does not take."""
+    Ci, H, W = x.shape
+    Co = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if Ci not in (8, 16) or Co > 32 or Wo % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+        return None
+    if tuple(weight.shape) != (Co, Ci, 3, 3):
+        raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    out = torch.empty((Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape mismatch")
+    rc = _lib.load().d3d_conv2d_k3s2_zs_bf16(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                             _opt(shift, "shift"), _opt(skip, "skip"), int(act), int(bool(skip_after_act)), Ci,
+                                             Co, H, W, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k3s2_zs_bf16")
+    return out
+
+
+def _pack_t2d_bf16(w):
+    """nn.ConvTranspose2d weight [Ci,Co,3,3] -> B operands for d3d_convtranspose2d_k3s2_zs_bf16: per output parity class
+    (py,px), order py*2 + px, taps (dy,dx) with d <= p per dimension, dy-major; an even output coordinate uses kernel index 1
+    (d = 0), an odd one index 2 (d = 0) and 0 (d = 1).  K = (tap, ci) padded to 32, 16 output columns; [K block][lane][8]."""
+    Ci, Co = w.shape[0], w.shape[1]
+    kmap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+    parts = []
+    for c in range(4):
+        py, px = c >> 1, c & 1
+        taps = [(dy, dx) for dy in range(1 + py) for dx in range(1 + px)]
+        K = len(taps) * Ci
+        nkb = (K + 31) // 32
+        b = torch.zeros((nkb * 32, 16), dtype=torch.float32, device=w.device)
+        for t, (dy, dx) in enumerate(taps):
+            b[t * Ci:(t + 1) * Ci, :Co] = w[:, :, kmap[(py, dy)], kmap[(px, dx)]]
+        b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)                 # [kb][kgroup][n][j]
+        parts.append(b.reshape(nkb * 64, 8))
+    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
+def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=False):
+    """ConvTranspose2d(k 3, stride 2, pad 1, output_pad 1) with bf16 matrix-core operands on the tile kernel (four per-parity
+    convolutions over one staged patch); None for shapes it does not take."""
+    Ci, H, W = x.shape
+    Co = weight.shape[1]
+    if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+        return None
+    if tuple(weight.shape) != (Ci, Co, 3, 3):
+        raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    wp = derived_weight(weight, "t2dbf16", _pack_t2d_bf16)
+    out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape mismatch")
+    rc = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                      _opt(shift, "shift"), _opt(skip, "skip"), int(act),
+                                                      int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_convtranspose2d_k3s2_zs_bf16")
+    return out
+
+
 def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None):
     """3x3 conv over cat(x, x2) channels. x [Ci0,H,W], x2 [Ci1,H,W]|None, weight [Co,Ci0+Ci1,3,3]."""
     Ci0, H, W = x.shape
@@ -700,6 +764,10 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
     if stride == 1 and act in (0, 1) and conv_precision() == "bf16" and _use_mfma() and H * W >= 256 * 256:
         # bf16 mode, large image layers of the slice regularisers: one tile per step on v_mfma_f32_16x16x32_bf16
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2)
+        if y is not None:
+            return y
+    if stride == 2 and x2 is None and act in (0, 1) and conv_precision() == "bf16" and _use_mfma() and H * W >= 128 * 128:
+        y = conv2d_s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
     if stride == 1 and act in (0, 1):
@@ -736,6 +804,10 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    if conv_precision() == "bf16" and _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
+        y = convtranspose2d_zs(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
+        if y is not None:
+            return y
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:

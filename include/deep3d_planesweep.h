@@ -260,6 +260,17 @@ int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, con
                           const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                           int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
+/* The stride-2 and the transposed (k 3, stride 2, pad 1, output_pad 1) 2-D layers of the slice regularisers on the same tile
+ * scheme (adamvs.py:411 ConvReLU(8,16,3,2,1); :413-417 upconv1 16->8 with the skip before the ReLU, upconv2d 8->1): planar fp32
+ * in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1] resp. [Co,2H,2W]; act 0 | 1 (ReLU); skip (shape of out, may be NULL) added before
+ * the activation or, skip_after_act, after it.  Stride 2: C_in = 8 | 16, C_out <= 32, output width % 4 == 0; transposed:
+ * C_in = 8 | 16 | 32, C_out <= 16, W % 4 == 0.  wpacked: ops._pack_z2_bf16 / ops._pack_t2d_bf16 (per output parity class, as the 3-D form). */
+int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                            int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                     d3d_stream_t stream);
+
 /* ---- channel-last bf16 activations between the layers of a CostRegNet (bf16 mode, BASELINE config 3) ------------------
  * "CL" volume: bf16 [D][H][W][C].  The matrix-core kernels round their operands to bf16 when they stage them, so a layer
  * that hands its output on in this form loses nothing its consumer would have kept, the activation traffic halves, and a

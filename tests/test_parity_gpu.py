@@ -1293,3 +1293,47 @@ def test_gru_cell_bf16_tile_kernels_match_the_stream_kernels(ops, monkeypatch):
         ops.set_conv_precision(None)
     assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
     assert 1e-5 < (a - c).abs().max().item() <= 0.05 * max(1.0, c.abs().max().item())     # bf16 operands, fp32 state
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,act", [(8, 16, 16, 64, 1), (8, 16, 9, 72, 1), (16, 32, 33, 40, 0), (16, 8, 5, 16, 1), (8, 16, 70, 263, 1),
+                                           (8, 1, 12, 24, 0)])
+def test_conv2d_stride2_tile_kernel_bf16(ops, oracle, Ci, Co, H, W, act):
+    """d3d_conv2d_k3s2_zs_bf16 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1)): the fp32 oracle on bf16-rounded operands, bias, ReLU and
+    a skip before / after the activation; odd sizes and ragged tiles included (output width a multiple of 4)."""
+    rng = np.random.default_rng(Ci * 10 + Co + W)
+    x = rng.standard_normal((Ci, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Co, Ci, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    conv = oracle.conv2d_k3(_bf16_round(x), _bf16_round(w), None, stride=2) + b[:, None, None]
+    sk = rng.standard_normal(conv.shape).astype(np.float32)
+    tol = 4e-5 * max(1.0, np.abs(conv).max())
+    for after in (False, True):
+        got = ops.conv2d_s2_zs(dev(x), dev(w), None, dev(b), dev(sk), act, skip_after_act=after)
+        assert got is not None and tuple(got.shape) == conv.shape
+        y = conv + (0 if after else sk)
+        y = np.maximum(y, 0) if act == 1 else y
+        assert np.abs(host(got) - (y + (sk if after else 0))).max() <= 2 * tol, after
+    assert ops.conv2d_s2_zs(dev(x[:, :, :W - 2]), dev(w), None, dev(b), None, act) is None or ((W - 3) // 2 + 1) % 4 == 0   # ragged widths: not taken
+    assert ops.conv2d_s2_zs(dev(np.zeros((32, 8, 16), np.float32)), dev(np.zeros((8, 32, 3, 3), np.float32))) is None       # C_in = 32: not taken
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,act", [(16, 8, 8, 32, 1), (16, 8, 9, 36, 1), (8, 1, 17, 68, 0), (32, 16, 5, 8, 1), (16, 8, 40, 132, 1),
+                                           (8, 1, 1, 4, 0)])
+def test_convtranspose2d_tile_kernel_bf16(ops, oracle, Ci, Co, H, W, act):
+    """d3d_convtranspose2d_k3s2_zs_bf16 (adamvs.py:413-417: upconv1 16 -> 8 with bias and the skip before the ReLU, upconv2d
+    8 -> 1): four per-parity convolutions over one staged patch, against the fp32 oracle on bf16-rounded operands."""
+    rng = np.random.default_rng(Ci * 10 + Co + W)
+    x = rng.standard_normal((Ci, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((Ci, Co, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    conv = oracle.convtranspose2d_k3s2(_bf16_round(x), _bf16_round(w), None) + b[:, None, None]
+    sk = rng.standard_normal(conv.shape).astype(np.float32)
+    tol = 4e-5 * max(1.0, np.abs(conv).max())
+    for after in (False, True):
+        got = ops.convtranspose2d_zs(dev(x), dev(w), None, dev(b), dev(sk), act=act, skip_after_act=after)
+        assert got is not None and tuple(got.shape) == conv.shape
+        y = conv + (0 if after else sk)
+        y = np.maximum(y, 0) if act == 1 else y
+        assert np.abs(host(got) - (y + (sk if after else 0))).max() <= 2 * tol, after
+    plain = ops.convtranspose2d_zs(dev(x), dev(w), None, None, None, act=0)
+    assert np.abs(host(plain) - (conv - b[:, None, None])).max() <= tol
