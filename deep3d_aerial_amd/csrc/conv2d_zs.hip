@@ -52,11 +52,14 @@ __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
     return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
 }
 
-template <int CI, int NTN, int MGN>
+// F32: the same tile scheme with exact fp32 operands (v_mfma_f32_16x16x4_f32, the default precision of the models): cells
+// of C_in floats + 16 bytes (20 | 36-dword pitches: the 16 pixels of an A operand, one dword each, fall in 16 different
+// banks, and so do the four K groups), K blocks of 4 channels of one tap, weights fp32 in LDS.
+template <int CI, int NTN, int MGN, bool F32 = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     constexpr int TX = 16 * MGN, PX = TX + 2;
-    constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);   // bytes per cell: an odd number of 16-byte slots
+    constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
+    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);   // bytes per cell (bf16: an odd number of 16-byte slots)
     constexpr int G = CI / 8;
     constexpr int PATCH = PX * PYZ * CS;
     constexpr int AW = MGN * NTN;
@@ -70,7 +73,13 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     const int nty = (H + TYZ - 1) / TYZ;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
 
-    for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+    if constexpr (F32) {
+        float* wf = reinterpret_cast<float*>(wlds);
+        const float* wg = reinterpret_cast<const float*>(p.wpk);
+        for (int i = tid; i < NKB * NTN * 64; i += NTZ) wf[i] = wg[i];
+    } else {
+        for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+    }
 
     // ---- staging: task = (patch pixel, 8-channel group); the group's planes come from `in` or from `in2` -------------
     constexpr int NTASK = PX * PYZ * G;
@@ -100,9 +109,14 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
             const int task = tid + r * NTZ;
             if (task < NTASK) {
                 const int pix = task / G, g = task - pix * G;
-                const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
-                              pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
-                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                if constexpr (F32) {
+                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
+                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                } else {
+                    const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
+                                  pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                    *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                }
             }
         }
     };
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
         return (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
     };
-    const int abase = (wave * PX + (lane & 15)) * CS;
+    const int abase = (wave * PX + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);   // F32: K group = channel within the block of 4
 
     auto tile = [&](int ty, const unsigned char* buf) {
         f4 acc[AW];
@@ -122,6 +136,25 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         for (int i = 0; i < AW; ++i) acc[i] = (f4){0, 0, 0, 0};
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));
+        if constexpr (F32) {
+            const float* wf = reinterpret_cast<const float*>(wlds);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {   // K block = channels 4 kb % CI .. + 3 of tap 4 kb / CI
+                constexpr int dummy = 0; (void)dummy;
+                const int t = (4 * kb) / CI, c = (4 * kb) % CI;
+                const int aoffk = ((t / 3) * PX + (t % 3)) * CS + c * 4;
+                float b[NTN];
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) b[nt] = wf[(kb * NTN + nt) * 64 + lane];
+#pragma unroll
+                for (int mg = 0; mg < MGN; ++mg) {
+                    const float a = *reinterpret_cast<const float*>(buf + abase + mg * 16 * CS + aoffk);
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt)
+                        acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int aoffk = a_offset(kb, kgroup);
@@ -184,13 +217,13 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     }
 }
 
-template <int CI, int NTN, int MGN>
+template <int CI, int NTN, int MGN, bool F32 = false>
 static int launch_z2(const Z2Params& p, hipStream_t stream) {
     constexpr int TX = 16 * MGN, PX = TX + 2;
-    constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * PX * PYZ * CS + NKB * NTN * 64 * 16;
-    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN>;
+    constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
+    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * PX * PYZ * CS + NKB * NTN * 64 * (F32 ? 4 : 16);
+    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -500,6 +533,38 @@ static int launch_tz(const Z2Params& p, hipStream_t stream) {
 }  // namespace d3d
 
 using namespace d3d;
+
+extern "C" int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                                    const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                                    int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && C1 > 0 && C2 >= 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act >= 0 && act <= 3, "bad act %d", act);
+    D3D_REQUIRE(C2 == 0 || in2, "second input missing");
+    D3D_REQUIRE(act < 2 || skip, "GRU epilogue (act %d) needs the state h in `skip`", act);
+    D3D_REQUIRE(act != 2 || (ep_split > 0 && ep_split <= Co), "GRU gate epilogue: bad ep_split %d", ep_split);
+    D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
+    const int Ci = C1 + C2;
+    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && C1 % 8 == 0 && C2 % 8 == 0 && Co <= 32 && W % 4 == 0;
+    if (!shape) {
+        set_error("d3d_conv2d_k3_zs_f32: C_in = %d + %d (8 | 16 | 32 in groups of 8), C_out = %d (<= 32), W = %d (multiple of 4) not taken",
+                  C1, C2, Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.in2 = in2; p.C1 = C1; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
+    p.skip = skip; p.aux1 = aux1; p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act; p.ep_split = ep_split;
+    p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    if (Co > 16) {
+        if (Ci == 32) return launch_z2<32, 2, 2, true>(p, st);
+        if (Ci == 16) return launch_z2<16, 2, 2, true>(p, st);
+        return launch_z2<8, 2, 4, true>(p, st);
+    }
+    if (Ci == 32) return launch_z2<32, 1, 2, true>(p, st);
+    if (Ci == 16) return launch_z2<16, 1, 2, true>(p, st);
+    return launch_z2<8, 1, 4, true>(p, st);
+}
 
 extern "C" int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,

@@ -666,9 +666,21 @@ def _pack_z2_bf16(w):
     return b.reshape(nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_z2_f32(w):
+    """nn.Conv2d weight [Co,Ci,3,3] -> fp32 B operands of v_mfma_f32_16x16x4_f32 for d3d_conv2d_k3_zs_f32: K = (k_y, k_x, c_in)
+    in blocks of 4, output channels padded to a multiple of 16; [K block][N tile][lane], lane l = column l & 15, K row l >> 4."""
+    Co, Ci = w.shape[0], w.shape[1]
+    K = 9 * Ci
+    ntn = (max(Co, 16) + 15) // 16
+    b = torch.zeros((K, ntn * 16), dtype=torch.float32, device=w.device)
+    b[:, :Co] = w.permute(2, 3, 1, 0).reshape(K, Co)
+    return b.reshape(K // 4, 4, ntn, 16).permute(0, 2, 1, 3).reshape(K // 4, ntn, 64).contiguous()
+
+
 def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False):
-    """3x3 stride-1 conv over cat(x, x2) with bf16 matrix-core operands and the fused epilogues of the slice regularisers
-    (act 0 | 1 | 2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16).  Returns None for shapes the kernel does not take."""
+    """3x3 stride-1 conv over cat(x, x2) on the tile kernel with the fused epilogues of the slice regularisers (act 0 | 1 |
+    2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16) -- bf16 matrix-core operands in bf16 mode, exact fp32 ones
+    (d3d_conv2d_k3_zs_f32) otherwise.  Returns None for shapes the kernel does not take."""
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
@@ -676,15 +688,16 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
-    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    bf16 = conv_precision() == "bf16"
+    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16) if bf16 else derived_weight(weight, "z2f32", _pack_z2_f32)
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
-    rc = _lib.load().d3d_conv2d_k3_zs_bf16(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
-                                           _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), _opt(aux1, "aux1"),
-                                           int(act), int(ep_split), int(bool(skip_after_act)), Co, H, W, _chk(out, "out"),
-                                           _stream())
+    fn = _lib.load().d3d_conv2d_k3_zs_bf16 if bf16 else _lib.load().d3d_conv2d_k3_zs_f32
+    rc = fn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"),
+            _opt(skip, "skip"), _opt(aux1, "aux1"), int(act), int(ep_split), int(bool(skip_after_act)), Co, H, W,
+            _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_conv2d_k3_zs_bf16")
+    _lib.check(rc, "d3d_conv2d_k3_zs_bf16" if bf16 else "d3d_conv2d_k3_zs_f32")
     return out
 
 
@@ -761,7 +774,8 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
-    if stride == 1 and act in (0, 1) and conv_precision() == "bf16" and _use_mfma() and H * W >= 256 * 256:
+    if stride == 1 and act in (0, 1) and (conv_precision() == "bf16" or _os.environ.get("D3D_CONV2D_ZS_ALL", "0") == "1") \
+            and _use_mfma() and H * W >= 256 * 256:
         # bf16 mode, large image layers of the slice regularisers: one tile per step on v_mfma_f32_16x16x32_bf16
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2)
         if y is not None:
@@ -1257,8 +1271,9 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
     Hc = h.shape[0]
     if not _use_mfma() or _os.environ.get("D3D_CONV", "mfma") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
         return None
-    if conv_precision() == "bf16" and x.shape[1] * x.shape[2] >= 128 * 128:
-        # bf16 mode: both convolutions on the tile kernel (v_mfma_f32_16x16x32_bf16, 16-byte epilogue accesses)
+    if (conv_precision() == "bf16" or _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0") and x.shape[1] * x.shape[2] >= 128 * 128:
+        # both convolutions on the tile kernel (v_mfma_f32_16x16x32_bf16 in bf16 mode, exact v_mfma_f32_16x16x4_f32
+        # otherwise; 16-byte epilogue accesses)
         g = conv2d_zs(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
         if g is not None:
             hn = conv2d_zs(x, w_cand, None, b_cand, h, 3, x2=g[:Hc], aux1=g[Hc:])

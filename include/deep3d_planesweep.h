@@ -260,6 +260,12 @@ int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, con
                           const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                           int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
+/* The same layer in the models' default precision: exact fp32 operands on v_mfma_f32_16x16x4_f32 (weights fp32 in the same
+ * [K block of 4][N tile][lane] order, ops._pack_z2_f32); arguments as d3d_conv2d_k3_zs_bf16. */
+int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                         const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                         int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /* The stride-2 and the transposed (k 3, stride 2, pad 1, output_pad 1) 2-D layers of the slice regularisers on the same tile
  * scheme (adamvs.py:411 ConvReLU(8,16,3,2,1); :413-417 upconv1 16->8 with the skip before the ReLU, upconv2d 8->1): planar fp32
  * in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1] resp. [Co,2H,2W]; act 0 | 1 (ReLU); skip (shape of out, may be NULL) added before

@@ -1337,3 +1337,40 @@ def test_convtranspose2d_tile_kernel_bf16(ops, oracle, Ci, Co, H, W, act):
         assert np.abs(host(got) - (y + (sk if after else 0))).max() <= 2 * tol, after
     plain = ops.convtranspose2d_zs(dev(x), dev(w), None, None, None, act=0)
     assert np.abs(host(plain) - (conv - b[:, None, None])).max() <= tol
+
+
+@pytest.mark.parametrize("Ci0,Ci1,Co,H,W,act", [(8, 0, 8, 9, 68, 1), (32, 0, 8, 7, 64, 0), (8, 8, 16, 17, 72, 2), (8, 8, 8, 17, 72, 3),
+                                                (16, 16, 32, 11, 36, 2), (16, 16, 16, 40, 100, 3), (8, 0, 1, 33, 128, 0)])
+def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, Ci0, Ci1, Co, H, W, act):
+    """d3d_conv2d_k3_zs_f32 (the models' default precision): exact fp32 operands on v_mfma_f32_16x16x4_f32, against the
+    fp32 oracle without any rounding of the operands."""
+    rng = np.random.default_rng(Ci0 * 100 + Co + W + act)
+    x = rng.standard_normal((Ci0, H, W)).astype(np.float32)
+    x2 = rng.standard_normal((Ci1, H, W)).astype(np.float32) if Ci1 else None
+    w = (0.1 * rng.standard_normal((Co, Ci0 + Ci1, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(Co).astype(np.float32)
+    xin = x if x2 is None else np.concatenate([x, x2], 0)
+    conv = oracle.conv2d_k3(xin, w, None) + b[:, None, None]
+    tol = 2e-5 * max(1.0, np.abs(conv).max())
+    d = lambda a: None if a is None else dev(a)
+    ops.set_conv_precision("fp32")
+    try:
+        if act in (0, 1):
+            sk = rng.standard_normal((Co, H, W)).astype(np.float32)
+            got = ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(sk), act, x2=d(x2), skip_after_act=True)
+            want = (np.maximum(conv, 0) if act == 1 else conv) + sk
+        elif act == 2:
+            Hc = Co // 2
+            h = rng.standard_normal((Hc, H, W)).astype(np.float32)
+            got = ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(h), 2, x2=d(x2), ep_split=Hc)
+            sg = 1.0 / (1.0 + np.exp(-conv.astype(np.float64)))
+            want = np.concatenate([sg[:Hc] * h, sg[Hc:]], 0)
+        else:
+            h = rng.standard_normal((Co, H, W)).astype(np.float32)
+            u = rng.uniform(0, 1, (Co, H, W)).astype(np.float32)
+            got = ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(h), 3, x2=d(x2), aux1=dev(u))
+            want = u * h + (1 - u) * np.tanh(conv.astype(np.float64))
+    finally:
+        ops.set_conv_precision(None)
+    assert got is not None
+    assert np.abs(host(got) - want).max() <= tol
