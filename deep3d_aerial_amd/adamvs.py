@@ -124,6 +124,10 @@ class SliceCostRegNetRED(nn.Module):
             self.upconv2d = nn.Conv2d(b, 1, kernel_size=3, stride=1, padding=1)
 
     def forward(self, cost, state1, state2):
+        with ops.slice_tile_kernels():
+            return self._forward(cost, state1, state2)
+
+    def _forward(self, cost, state1, state2):
         x1 = self.conv1(cost)
         state1, _ = self.conv_gru1(x1, state1)
         x2 = self.conv2(state1)

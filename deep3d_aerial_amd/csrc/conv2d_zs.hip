@@ -242,11 +242,11 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
 // ---- stride 2 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1) of the slice regulariser): out (y, x) reads in (2y + k_y - 1, 2x + k_x - 1) --
 // 32 x 8 OUTPUT pixels per step; the staged 65 x 17 patch keeps the even and the odd columns of a row in separate runs, so
 // the 16 pixels of an A operand (input columns 2m + k_x - 1) are 16 consecutive cells.  p.H, p.W: INPUT size.
-template <int CI, int NTN>
+template <int CI, int NTN, bool F32 = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
     constexpr int MG = 2, TXO = 16 * MG, PXI = 2 * TXO + 1, PYI = 2 * TYZ + 1, NEVEN = TXO + 1;
-    constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
+    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
     constexpr int AW = MG * NTN;
@@ -260,7 +260,13 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
     const int nty = (Ho + TYZ - 1) / TYZ;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
 
-    for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+    if constexpr (F32) {
+        float* wf = reinterpret_cast<float*>(wlds);
+        const float* wg = reinterpret_cast<const float*>(p.wpk);
+        for (int i = tid; i < NKB * NTN * 64; i += NTZ) wf[i] = wg[i];
+    } else {
+        for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+    }
 
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
@@ -289,9 +295,14 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
                 const int pix = task / G, g = task - pix * G;
                 const int py = pix / PXI, px = pix - py * PXI;
                 const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
-                const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
-                              pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
-                *reinterpret_cast<u4*>(dst + cell * CS + g * 16) = v;
+                if constexpr (F32) {
+                    *reinterpret_cast<f4*>(dst + cell * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
+                    *reinterpret_cast<f4*>(dst + cell * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                } else {
+                    const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
+                                  pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                    *reinterpret_cast<u4*>(dst + cell * CS + g * 16) = v;
+                }
             }
         }
     };
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         const int col = kx == 1 ? NEVEN : (kx >> 1);   // even run index m (k_x = 0) | m + 1 (k_x = 2), odd run index m (k_x = 1)
         return (ky * PXI + col) * CS + (t < 9 ? c : 0) * 2;
     };
-    const int abase = (2 * wave * PXI + (lane & 15)) * CS;
+    const int abase = (2 * wave * PXI + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);
 
     auto tile = [&](int ty, const unsigned char* buf) {
         f4 acc[AW];
@@ -310,6 +321,25 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         for (int i = 0; i < AW; ++i) acc[i] = (f4){0, 0, 0, 0};
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));
+        if constexpr (F32) {
+            const float* wf = reinterpret_cast<const float*>(wlds);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int t = (4 * kb) / CI, c = (4 * kb) % CI;
+                const int ky = t / 3, kx = t % 3;
+                const int aoffk = (ky * PXI + (kx == 1 ? NEVEN : (kx >> 1))) * CS + c * 4;
+                float b[NTN];
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) b[nt] = wf[(kb * NTN + nt) * 64 + lane];
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    const float a = *reinterpret_cast<const float*>(buf + abase + mg * 16 * CS + aoffk);
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt)
+                        acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const int aoffk = a_offset(kb, kgroup);
@@ -363,20 +393,20 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
 // 8 -> 1): four per-parity dense convolutions over one staged 33 x 9 input patch (32 x 8 input pixels = 64 x 16 outputs per
 // step); the two column parities of an output row are interleaved in registers, a lane stores 8 consecutive pixels.
 constexpr int ntaps2(int py, int px) { return (1 + py) * (1 + px); }
-constexpr int nkb2(int CI, int py, int px) { return (ntaps2(py, px) * CI + 31) / 32; }
-constexpr int frag_base2(int CI, int c) {
+constexpr int nkb2(int CI, int py, int px, bool f32 = false) { return f32 ? ntaps2(py, px) * CI / 4 : (ntaps2(py, px) * CI + 31) / 32; }
+constexpr int frag_base2(int CI, int c, bool f32 = false) {
     int s = 0;
-    for (int q = 0; q < c; ++q) s += nkb2(CI, q >> 1, q & 1);
+    for (int q = 0; q < c; ++q) s += nkb2(CI, q >> 1, q & 1, f32);
     return s;
 }
 
-template <int CI>
+template <int CI, bool F32 = false>
 __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
     constexpr int MG = 2, TXI = 16 * MG, PXI = TXI + 1, PYI = TYZ + 1;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
-    constexpr int NFRAG = frag_base2(CI, 4);
+    constexpr int NFRAG = frag_base2(CI, 4, F32);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
 
@@ -387,7 +417,13 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
     const int nty = (H + TYZ - 1) / TYZ;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
 
-    for (int i = tid; i < NFRAG * 64; i += NTZ) wlds[i] = p.wpk[i];
+    if constexpr (F32) {
+        float* wf = reinterpret_cast<float*>(wlds);
+        const float* wg = reinterpret_cast<const float*>(p.wpk);
+        for (int i = tid; i < NFRAG * 64; i += NTZ) wf[i] = wg[i];
+    } else {
+        for (int i = tid; i < NFRAG * 64; i += NTZ) wlds[i] = p.wpk[i];
+    }
 
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
@@ -414,13 +450,18 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
             const int task = tid + r * NTZ;
             if (task < NTASK) {
                 const int pix = task / G, g = task - pix * G;
-                const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
-                              pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
-                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                if constexpr (F32) {
+                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
+                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                } else {
+                    const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
+                                  pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                    *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                }
             }
         }
     };
-    const int abase = (wave * PXI + (lane & 15)) * CS;
+    const int abase = (wave * PXI + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);
 
     auto row = [&](auto pyc, int ty, const unsigned char* buf) {   // output row 2 iy + PY of this wave's input row: both column parities
         constexpr int PY = decltype(pyc)::value;
@@ -433,8 +474,24 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         asm volatile("" : "+v"(kgroup));
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
-            const int NKB = nkb2(CI, PY, px);
-            const int FB = frag_base2(CI, PY * 2 + px);
+            const int NKB = nkb2(CI, PY, px, F32);
+            const int FB = frag_base2(CI, PY * 2 + px, F32);
+            if constexpr (F32) {
+                const float* wf = reinterpret_cast<const float*>(wlds);
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    const int t = (4 * kb) / CI, c = (4 * kb) % CI;
+                    const int dx = t % (1 + px), dy = t / (1 + px);
+                    const int aoff = (dy * PXI + dx) * CS + c * 4;
+                    const float bw = wf[(FB + kb) * 64 + lane];
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) {
+                        const float a = *reinterpret_cast<const float*>(buf + abase + mg * 16 * CS + aoff);
+                        acc[px][mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, acc[px][mg], 0, 0, 0);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 const int k0 = 32 * kb + 8 * kgroup;
@@ -486,12 +543,12 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
     }
 }
 
-template <int CI, int NTN>
+template <int CI, int NTN, bool F32 = false>
 static int launch_s2z(const Z2Params& p, hipStream_t stream) {
-    constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * 65 * 17 * CS + NKB * NTN * 64 * 16;
-    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN>;
+    constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
+    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * 65 * 17 * CS + NKB * NTN * 64 * (F32 ? 4 : 16);
+    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -508,11 +565,11 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     return D3D_OK;
 }
 
-template <int CI>
+template <int CI, bool F32 = false>
 static int launch_tz(const Z2Params& p, hipStream_t stream) {
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * 33 * 9 * CS + frag_base2(CI, 4) * 64 * 16;
-    auto kern = convt2d_zs_bf16_kernel<CI>;
+    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
+    const int lds = 2 * 33 * 9 * CS + frag_base2(CI, 4, F32) * 64 * (F32 ? 4 : 16);
+    auto kern = convt2d_zs_bf16_kernel<CI, F32>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -566,28 +623,61 @@ extern "C" int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, i
     return launch_z2<8, 1, 4, true>(p, st);
 }
 
+static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                          int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 extern "C" int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                        d3d_stream_t stream) {
+    return conv2d_k3s2_zs(false, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+}
+
+extern "C" int d3d_conv2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                      const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                      d3d_stream_t stream) {
+    return conv2d_k3s2_zs(true, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+}
+
+static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                          int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
     const int Wo = (W - 1) / 2 + 1;
-    if ((Ci != 8 && Ci != 16) || Co > 32 || Wo % 4 != 0) {   // (C_in = 32: two 65 x 17 patches of 80-byte cells exceed the LDS)
-        set_error("d3d_conv2d_k3s2_zs_bf16: C_in = %d (8 | 16), C_out = %d (<= 32), output width %d (multiple of 4) not taken", Ci, Co, Wo);
+    // (two 65 x 17 patches must fit the LDS: bf16 cells up to C_in = 16, fp32 cells C_in = 8)
+    if ((Ci != 8 && (Ci != 16 || f32)) || Co > 32 || Wo % 4 != 0) {
+        set_error("d3d_conv2d_k3s2_zs_%s: C_in = %d (8%s), C_out = %d (<= 32), output width %d (multiple of 4) not taken",
+                  f32 ? "f32" : "bf16", Ci, f32 ? "" : " | 16", Co, Wo);
         return D3D_ERR_UNSUPPORTED;
     }
     Z2Params p = {};
     p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
+    if (f32) return Co > 16 ? launch_s2z<8, 2, true>(p, st) : launch_s2z<8, 1, true>(p, st);
     if (Co > 16) return Ci == 8 ? launch_s2z<8, 2>(p, st) : launch_s2z<16, 2>(p, st);
     return Ci == 8 ? launch_s2z<8, 1>(p, st) : launch_s2z<16, 1>(p, st);
 }
 
+static int convtranspose2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift,
+                                   const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                   d3d_stream_t stream);
+
 extern "C" int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                                 const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                                 float* out, d3d_stream_t stream) {
+    return convtranspose2d_k3s2_zs(false, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+}
+
+extern "C" int d3d_convtranspose2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                               const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
+                                               float* out, d3d_stream_t stream) {
+    return convtranspose2d_k3s2_zs(true, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+}
+
+static int convtranspose2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift,
+                                   const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                   d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
@@ -599,6 +689,7 @@ extern "C" int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpa
     p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
+    if (f32) return Ci == 8 ? launch_tz<8, true>(p, st) : Ci == 16 ? launch_tz<16, true>(p, st) : launch_tz<32, true>(p, st);
     return Ci == 8 ? launch_tz<8>(p, st) : Ci == 16 ? launch_tz<16>(p, st) : launch_tz<32>(p, st);
 }
 

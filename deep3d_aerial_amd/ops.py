@@ -701,25 +701,43 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     return out
 
 
+# In the default fp32 precision the tile kernels serve the slice regularisers only (the feature pyramids keep their tuned
+# vector-unit kernels: a FeatureNet forward is 2.12 ms on those, 2.19 ms on the fp32 tile kernel): the regulariser
+# modules switch them on around their forward.
+_tile_kernels = [False]
+
+
+class slice_tile_kernels:
+    """Context manager: stride-2 / transposed 2-D layers inside may use the fp32 tile kernels."""
+
+    def __enter__(self):
+        self.saved = _tile_kernels[0]
+        _tile_kernels[0] = True
+
+    def __exit__(self, *exc):
+        _tile_kernels[0] = self.saved
+
+
 def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=False):
     """3x3 stride-2 conv (pad 1) with bf16 matrix-core operands on the tile kernel; None for shapes it does not take."""
     Ci, H, W = x.shape
     Co = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    if Ci not in (8, 16) or Co > 32 or Wo % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+    bf16 = conv_precision() == "bf16"
+    if Ci not in ((8, 16) if bf16 else (8,)) or Co > 32 or Wo % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16) if bf16 else derived_weight(weight, "z2f32", _pack_z2_f32)
     out = torch.empty((Co, Ho, Wo), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape mismatch")
-    rc = _lib.load().d3d_conv2d_k3s2_zs_bf16(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
-                                             _opt(shift, "shift"), _opt(skip, "skip"), int(act), int(bool(skip_after_act)), Ci,
-                                             Co, H, W, _chk(out, "out"), _stream())
+    fn = _lib.load().d3d_conv2d_k3s2_zs_bf16 if bf16 else _lib.load().d3d_conv2d_k3s2_zs_f32
+    rc = fn(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
+            int(act), int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_conv2d_k3s2_zs_bf16")
+    _lib.check(rc, "d3d_conv2d_k3s2_zs")
     return out
 
 
@@ -743,6 +761,23 @@ def _pack_t2d_bf16(w):
     return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_t2d_f32(w):
+    """_pack_t2d_bf16 in fp32 for d3d_convtranspose2d_k3s2_zs_f32: per parity class, K = (tap, ci) in blocks of 4, [K block][lane]
+    with lane l = column l & 15, K row l >> 4."""
+    Ci, Co = w.shape[0], w.shape[1]
+    kmap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+    parts = []
+    for c in range(4):
+        py, px = c >> 1, c & 1
+        taps = [(dy, dx) for dy in range(1 + py) for dx in range(1 + px)]
+        K = len(taps) * Ci
+        b = torch.zeros((K, 16), dtype=torch.float32, device=w.device)
+        for t, (dy, dx) in enumerate(taps):
+            b[t * Ci:(t + 1) * Ci, :Co] = w[:, :, kmap[(py, dy)], kmap[(px, dx)]]
+        parts.append(b.reshape(K // 4, 64))
+    return torch.cat(parts).contiguous()
+
+
 def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=False):
     """ConvTranspose2d(k 3, stride 2, pad 1, output_pad 1) with bf16 matrix-core operands on the tile kernel (four per-parity
     convolutions over one staged patch); None for shapes it does not take."""
@@ -752,16 +787,17 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
         return None
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    wp = derived_weight(weight, "t2dbf16", _pack_t2d_bf16)
+    bf16 = conv_precision() == "bf16"
+    wp = derived_weight(weight, "t2dbf16", _pack_t2d_bf16) if bf16 else derived_weight(weight, "t2df32", _pack_t2d_f32)
     out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape mismatch")
-    rc = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
-                                                      _opt(shift, "shift"), _opt(skip, "skip"), int(act),
-                                                      int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
+    fn = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16 if bf16 else _lib.load().d3d_convtranspose2d_k3s2_zs_f32
+    rc = fn(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
+            int(act), int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_convtranspose2d_k3s2_zs_bf16")
+    _lib.check(rc, "d3d_convtranspose2d_k3s2_zs")
     return out
 
 
@@ -780,7 +816,8 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2)
         if y is not None:
             return y
-    if stride == 2 and x2 is None and act in (0, 1) and conv_precision() == "bf16" and _use_mfma() and H * W >= 128 * 128:
+    zs_any = conv_precision() == "bf16" or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0")
+    if stride == 2 and x2 is None and act in (0, 1) and zs_any and _use_mfma() and H * W >= 128 * 128:
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
@@ -818,7 +855,8 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    if conv_precision() == "bf16" and _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
+    zs_any = conv_precision() == "bf16" or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0")
+    if zs_any and _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
         y = convtranspose2d_zs(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:
             return y

@@ -276,6 +276,13 @@ int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* s
 int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                      d3d_stream_t stream);
+/* ... and in exact fp32 (v_mfma_f32_16x16x4_f32; weights ops._pack_z2_f32 / ops._pack_t2d_f32): stride 2 takes C_in = 8 only
+ * (two 65 x 17 patches of fp32 cells must fit the LDS), transposed C_in = 8 | 16 | 32. */
+int d3d_conv2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                           int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+int d3d_convtranspose2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                    const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                    d3d_stream_t stream);
 
 /* ---- channel-last bf16 activations between the layers of a CostRegNet (bf16 mode, BASELINE config 3) ------------------
  * "CL" volume: bf16 [D][H][W][C].  The matrix-core kernels round their operands to bf16 when they stage them, so a layer

@@ -1228,10 +1228,17 @@ def test_predict_views_ucsnet(ops, tmp_path):
     assert (prob >= 0).all() and (prob <= 1 + 1e-5).all()
 
 
+@pytest.fixture
+def bf16_mode(ops):
+    ops.set_conv_precision("bf16")
+    yield
+    ops.set_conv_precision(None)
+
+
 @pytest.mark.parametrize("Ci0,Ci1,Co,H,W,act", [(8, 0, 8, 9, 68, 1), (16, 0, 8, 20, 132, 0), (32, 0, 8, 7, 64, 1), (8, 8, 16, 17, 72, 2),
                                                 (8, 8, 8, 17, 72, 3), (16, 16, 32, 11, 36, 2), (16, 16, 16, 11, 36, 3), (8, 8, 16, 1, 4, 2),
                                                 (8, 8, 8, 70, 260, 3), (8, 0, 16, 33, 128, 1), (16, 16, 32, 40, 100, 2)])
-def test_conv2d_tile_kernel_bf16_with_gru_epilogues(ops, oracle, Ci0, Ci1, Co, H, W, act):
+def test_conv2d_tile_kernel_bf16_with_gru_epilogues(ops, oracle, bf16_mode, Ci0, Ci1, Co, H, W, act):
     """d3d_conv2d_k3_zs_bf16 (module.py:5-51 ConvGRUCell, adamvs.py:409 ConvReLU in bf16 mode): the fp32 oracle convolution on
     bf16-rounded operands over the channel concat, then the epilogue in fp32 -- none / ReLU with a skip before or after
     the activation, the gate form [sigmoid(r) * h | sigmoid(u)], the update u * h + (1 - u) * tanh(c)."""
@@ -1297,7 +1304,7 @@ def test_gru_cell_bf16_tile_kernels_match_the_stream_kernels(ops, monkeypatch):
 
 @pytest.mark.parametrize("Ci,Co,H,W,act", [(8, 16, 16, 64, 1), (8, 16, 9, 72, 1), (16, 32, 33, 40, 0), (16, 8, 5, 16, 1), (8, 16, 70, 263, 1),
                                            (8, 1, 12, 24, 0)])
-def test_conv2d_stride2_tile_kernel_bf16(ops, oracle, Ci, Co, H, W, act):
+def test_conv2d_stride2_tile_kernel_bf16(ops, oracle, bf16_mode, Ci, Co, H, W, act):
     """d3d_conv2d_k3s2_zs_bf16 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1)): the fp32 oracle on bf16-rounded operands, bias, ReLU and
     a skip before / after the activation; odd sizes and ragged tiles included (output width a multiple of 4)."""
     rng = np.random.default_rng(Ci * 10 + Co + W)
@@ -1319,7 +1326,7 @@ def test_conv2d_stride2_tile_kernel_bf16(ops, oracle, Ci, Co, H, W, act):
 
 @pytest.mark.parametrize("Ci,Co,H,W,act", [(16, 8, 8, 32, 1), (16, 8, 9, 36, 1), (8, 1, 17, 68, 0), (32, 16, 5, 8, 1), (16, 8, 40, 132, 1),
                                            (8, 1, 1, 4, 0)])
-def test_convtranspose2d_tile_kernel_bf16(ops, oracle, Ci, Co, H, W, act):
+def test_convtranspose2d_tile_kernel_bf16(ops, oracle, bf16_mode, Ci, Co, H, W, act):
     """d3d_convtranspose2d_k3s2_zs_bf16 (adamvs.py:413-417: upconv1 16 -> 8 with bias and the skip before the ReLU, upconv2d
     8 -> 1): four per-parity convolutions over one staged patch, against the fp32 oracle on bf16-rounded operands."""
     rng = np.random.default_rng(Ci * 10 + Co + W)
@@ -1374,3 +1381,28 @@ def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, Ci0, Ci1, Co, H
         ops.set_conv_precision(None)
     assert got is not None
     assert np.abs(host(got) - want).max() <= tol
+
+
+def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle):
+    """d3d_conv2d_k3s2_zs_f32 / d3d_convtranspose2d_k3s2_zs_f32: exact fp32 operands, against the oracle without rounding."""
+    rng = np.random.default_rng(12)
+    ops.set_conv_precision("fp32")
+    try:
+        for Ci, Co, H, W in [(8, 16, 17, 72), (8, 8, 40, 264), (8, 1, 9, 24)]:
+            x = rng.standard_normal((Ci, H, W)).astype(np.float32)
+            w = (0.1 * rng.standard_normal((Co, Ci, 3, 3))).astype(np.float32)
+            b = rng.standard_normal(Co).astype(np.float32)
+            want = np.maximum(oracle.conv2d_k3(x, w, None, stride=2) + b[:, None, None], 0)
+            got = ops.conv2d_s2_zs(dev(x), dev(w), None, dev(b), None, 1)
+            assert got is not None and np.abs(host(got) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+        assert ops.conv2d_s2_zs(dev(np.zeros((16, 8, 16), np.float32)), dev(np.zeros((8, 16, 3, 3), np.float32))) is None
+        for Ci, Co, H, W in [(16, 8, 9, 36), (8, 1, 17, 68), (32, 16, 5, 8), (16, 8, 40, 132)]:
+            x = rng.standard_normal((Ci, H, W)).astype(np.float32)
+            w = (0.1 * rng.standard_normal((Ci, Co, 3, 3))).astype(np.float32)
+            b = rng.standard_normal(Co).astype(np.float32)
+            conv = oracle.convtranspose2d_k3s2(x, w, None) + b[:, None, None]
+            sk = rng.standard_normal(conv.shape).astype(np.float32)
+            got = ops.convtranspose2d_zs(dev(x), dev(w), None, dev(b), dev(sk), act=1, skip_after_act=False)
+            assert got is not None and np.abs(host(got) - np.maximum(conv + sk, 0)).max() <= 2e-5 * max(1.0, np.abs(conv).max())
+    finally:
+        ops.set_conv_precision(None)

@@ -9,6 +9,7 @@ from deep3d_aerial_amd import ops
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 n_cases = int(os.environ.get("FUZZ_CASES", "80"))
+ops.set_conv_precision(os.environ.get("FUZZ_PRECISION", "bf16"))
 torch.backends.cudnn.allow_tf32 = False
 bf = lambda t: t.to(torch.bfloat16).float()
 nbad, worst = 0, 0.0
