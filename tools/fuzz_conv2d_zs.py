@@ -1,6 +1,6 @@
 """Random-shape cross-check of the 2-D tile kernels of the slice regularisers (stride 1 with the two-input concat and the ReLU /
-GRU gate / GRU update epilogues, stride 2, transposed) against torch's fp32 convolutions on bf16-rounded operands (GPU box).
-FUZZ_SEED, FUZZ_CASES as the other fuzzers."""
+GRU gate / GRU update epilogues, stride 2, transposed) against torch's fp32 convolutions (on bf16-rounded operands in bf16 mode) (GPU box).
+FUZZ_SEED, FUZZ_CASES as the other fuzzers; FUZZ_PRECISION=bf16|fp32 selects the kernels' precision."""
 import os, sys
 import numpy as np, torch
 import torch.nn.functional as F
@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 n_cases = int(os.environ.get("FUZZ_CASES", "80"))
 ops.set_conv_precision(os.environ.get("FUZZ_PRECISION", "bf16"))
 torch.backends.cudnn.allow_tf32 = False
-bf = lambda t: t.to(torch.bfloat16).float()
+bf = (lambda t: t.to(torch.bfloat16).float()) if os.environ.get("FUZZ_PRECISION", "bf16") == "bf16" else (lambda t: t)   # fp32 mode: exact operands
 nbad, worst = 0, 0.0
 for case in range(n_cases):
     kind = str(rng.choice(["s1", "gates", "update", "s2", "t2"]))
