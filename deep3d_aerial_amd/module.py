@@ -21,6 +21,15 @@ from . import ops
 # ----------------------------------------------------------------------------------------
 # warp / depth hypotheses (module.py:516-557, 616-650)
 # ----------------------------------------------------------------------------------------
+
+def _feature_precision():
+    """Feature pyramids run in exact fp32 whatever the regularisers' precision (D3D_FEATURE_PRECISION=follow: experiment that
+    lets them follow the global mode)."""
+    import contextlib
+
+    return contextlib.nullcontext() if os.environ.get("D3D_FEATURE_PRECISION", "fp32") == "follow" else ops.fp32_convs()
+
+
 def compose_batch(proj_matrices):
     """[B,V,4,4] -> list of B tensors [V-1,12] (module.py:528-530 for every source view)."""
     return [ops.compose_projections(proj_matrices[b].contiguous()) for b in range(proj_matrices.shape[0])]
@@ -224,7 +233,7 @@ def feature_conv(conv, x, bn=None, relu=False, skip=None, x2=None):
             s, t = folded_bn(bn)
         else:
             s, t = None, conv.bias
-        with ops.fp32_convs():  # the bf16 mode (BASELINE config 3) is for the cost regularisers only
+        with _feature_precision():  # the bf16 mode (BASELINE config 3) is for the cost regularisers only
             outs = []
             for b in range(x.shape[0]):
                 xb = x[b].contiguous()
@@ -295,7 +304,7 @@ class Deconv2d(nn.Module):
                 and c.out_channels <= 64 and x.is_cuda and (self.bn is None or not self.bn.training)
                 and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
             s, t = folded_bn(self.bn) if self.bn is not None else (None, c.bias)
-            with ops.fp32_convs():
+            with _feature_precision():
                 outs = [ops.convtranspose2d_k3s2(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0)
                         for b in range(x.shape[0])]
             return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
