@@ -237,13 +237,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    # one process per GPU; with fewer devices than ranks (a rehearsal of the N > 1 path on a one-GPU box) the ranks share
+    # the card and the two control-plane collectives below go through gloo on host tensors
+    shared = world > 1 and ndev < world
+    torch.cuda.set_device(local_rank % max(ndev, 1))
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
 
     # every rank builds its own reference view (seed = rank): independent work items
     proj, dv = S.make_scene(V, H_FEAT, W_FEAT, D, seed=rank)
@@ -276,7 +280,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -303,7 +307,8 @@ def main():
             "config": {"workload": "config 2: fused homography-warp + variance, 5 views x 384 planes, "
                                    "features 32x688x464 fp32 (2752x1856 image at 1/4 res), one reference view per "
                                    "step per GPU", "voxels_per_step_per_gpu": voxels,
-                       "in_frame_fraction": round(in_frame, 4), "path": os.environ.get("D3D_FORCE_PATH", "auto")},
+                       "in_frame_fraction": round(in_frame, 4), "path": os.environ.get("D3D_FORCE_PATH", "auto"),
+                       **({"ranks_share_one_gpu": True} if shared else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profile": traffic_info,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": algorithmic_bytes()},

@@ -45,3 +45,27 @@ def test_all_gather_maps_on_devices(tmp_path, n_views):
     want = torch.stack([_view(i) for i in range(n_views)])
     for rank in range(2):
         assert torch.equal(torch.load(os.path.join(str(tmp_path), "rank%d.pt" % rank)), want)
+
+
+def test_bench_two_ranks(tmp_path):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per rank): process-group set-up,
+    the two barriers, the MAX over ranks and rank 0's JSON line.  With one GPU in the box the two ranks share it (gloo for
+    the control-plane collectives, noted in the line); with two or more it is the real one-process-per-GPU RCCL run."""
+    import json
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d and "secondary" not in d
+    assert d["config"].get("ranks_share_one_gpu", False) == (torch.cuda.device_count() < 2)
