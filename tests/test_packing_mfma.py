@@ -1,0 +1,159 @@
+"""Host logic of the bf16 / fp32 matrix-core kernels of round 2: the weight packers of ops.py (operand fragments in the lane
+order of v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32) against a numpy emulation of each kernel's K-index contract
+    fragment[kb][tile][lane][j]  <->  B[K = kblock * kb + krows * (lane >> 4) + j][column = 16 * tile + (lane & 15)]
+and, through it, against the oracle's convolutions (weights are chosen exactly representable in bf16).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from deep3d_aerial_amd import ops
+
+
+def bf16_exact(rng, shape):
+    """Random weights that survive the bf16 rounding of the packers unchanged."""
+    return (rng.integers(-32, 33, shape) / 64.0).astype(np.float32)
+
+
+def dense_from_fragments(frag, kblock):
+    """[nkb][ntn][64][krows] fragments (bf16 bits or fp32) -> dense B [K, ntn * 16]."""
+    f = frag.view(torch.bfloat16).float().numpy() if frag.dtype == torch.int16 else frag.numpy()
+    if f.ndim == 3:                                    # fp32 fragments: one K row per lane
+        f = f[..., None]
+    nkb, ntn, _, kr = f.shape
+    assert kblock == 4 * kr
+    B = np.zeros((nkb * kblock, ntn * 16), np.float32)
+    for lane in range(64):
+        for j in range(kr):
+            B[np.arange(nkb)[:, None] * kblock + kr * (lane >> 4) + j, np.arange(ntn)[None, :] * 16 + (lane & 15)] = f[:, :, lane, j]
+    return B
+
+
+def conv_from_B(x, B, taps, Co, out_shape, stride=1):
+    """Direct evaluation of out[co, o] = sum_{t, ci} B[t * Ci + ci, co] * x[ci, o * stride + tap_t] with zero padding."""
+    Ci = x.shape[0]
+    nd = x.ndim - 1
+    pad = 2
+    xp = np.pad(x.astype(np.float64), [(0, 0)] + [(pad, pad)] * nd)
+    out = np.zeros((Co,) + out_shape)
+    for t, off in enumerate(taps):
+        sl = tuple(slice(pad + o, pad + o + stride * n, stride) for o, n in zip(off, out_shape))
+        out += np.tensordot(B[t * Ci:(t + 1) * Ci, :Co].T.astype(np.float64), xp[(slice(None),) + sl], axes=(1, 0))
+    return out
+
+
+@pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 8), (32, 8), (16, 16), (32, 32), (64, 64), (8, 16)])
+def test_pack_conv3d_fragments(Ci, Co):
+    """ops._pack_c8_bf16 (d3d_conv3d_k3_zs_bf16 / _cl_bf16, stride 1 and 2): per k_z slice K = (k_y, k_x, c_in)."""
+    rng = np.random.default_rng(Ci + Co)
+    w = bf16_exact(rng, (Co, Ci, 3, 3, 3))
+    x = rng.standard_normal((Ci, 3, 4, 5)).astype(np.float32)
+    frag = ops._pack_c8_bf16(torch.from_numpy(w))
+    assert frag.dtype == torch.int16 and frag.shape[0] == 3
+    out = np.zeros((Co, 3, 4, 5))
+    for kz in range(3):
+        B = dense_from_fragments(frag[kz], 32)
+        assert (B[9 * Ci:] == 0).all() and (B[:, Co:] == 0).all()       # padded K rows / columns are zero
+        taps = [(kz - 1, ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+        out += conv_from_B(x, B, taps, Co, (3, 4, 5))
+    assert np.abs(out - oracle.conv3d_k3(x, w, None)).max() <= 1e-4
+
+
+def test_pack_probability_layer_kz_folded():
+    """ops._pack_c8_kzfold_bf16 (d3d_conv3d_k3_c1_cl_bf16): the k_z slices are columns 0..2 of one tile."""
+    rng = np.random.default_rng(3)
+    w = bf16_exact(rng, (1, 8, 3, 3, 3))
+    x = rng.standard_normal((8, 4, 3, 6)).astype(np.float32)
+    B = dense_from_fragments(ops._pack_c8_kzfold_bf16(torch.from_numpy(w))[:, None], 32)
+    assert (B[:, 3:] == 0).all()
+    out = np.zeros((1, 4, 3, 6))
+    for kz in range(3):
+        taps = [(kz - 1, ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+        out += conv_from_B(x, B[:, kz:kz + 1], taps, 1, (4, 3, 6))
+    assert np.abs(out - oracle.conv3d_k3(x, w, None)).max() <= 1e-4
+
+
+def _transposed_from_classes(x, classes, Co, nd):
+    """Assemble a stride-2 transposed convolution from its per-parity dense convolutions: classes[p] = (B, taps)."""
+    sp = x.shape[1:]
+    out = np.zeros((Co,) + tuple(2 * n for n in sp))
+    for p, (B, taps) in classes.items():
+        y = conv_from_B(x, B, taps, Co, sp)
+        out[(slice(None),) + tuple(slice(pi, None, 2) for pi in p)] = y
+    return out
+
+
+@pytest.mark.parametrize("Ci,Co", [(16, 8), (32, 16), (64, 32), (16, 16)])
+def test_pack_convtranspose3d_parity_classes(Ci, Co):
+    """ops._pack_t2_bf16 (d3d_convtranspose3d_k3s2_zs_bf16 / _cl_bf16): eight parity classes, taps (dz,dy,dx) dz-major."""
+    rng = np.random.default_rng(Ci * 3 + Co)
+    w = bf16_exact(rng, (Ci, Co, 3, 3, 3))
+    x = rng.standard_normal((Ci, 2, 3, 4)).astype(np.float32)
+    frag = ops._pack_t2_bf16(torch.from_numpy(w))
+    ntn = max(Co, 16) // 16
+    classes, base = {}, 0
+    for p in range(8):
+        pz, py, px = p >> 2, (p >> 1) & 1, p & 1
+        taps = [(dz, dy, dx) for dz in range(1 + pz) for dy in range(1 + py) for dx in range(1 + px)]
+        nkb = (len(taps) * Ci + 31) // 32
+        B = dense_from_fragments(frag[base:base + nkb * ntn * 64].reshape(nkb, ntn, 64, 8), 32)
+        base += nkb * ntn * 64
+        classes[(pz, py, px)] = (B, taps)
+    assert base == frag.shape[0]
+    assert np.abs(_transposed_from_classes(x, classes, Co, 3) - oracle.convtranspose3d_k3s2(x, w, None)).max() <= 1e-4
+
+
+def test_pack_convtranspose3d_x_folded():
+    """ops._pack_t2_fold_bf16 (conv11, channel-last): rows 0..7 = even output column, rows 8..15 = odd one, per (pz, py)."""
+    rng = np.random.default_rng(11)
+    Ci, Co = 16, 8
+    w = bf16_exact(rng, (Ci, Co, 3, 3, 3))
+    x = rng.standard_normal((Ci, 2, 3, 4)).astype(np.float32)
+    frag = ops._pack_t2_fold_bf16(torch.from_numpy(w))
+    classes, base = {}, 0
+    for c in range(4):
+        pz, py = c >> 1, c & 1
+        taps = [(dz, dy, dx) for dz in range(1 + pz) for dy in range(1 + py) for dx in range(2)]
+        nkb = (len(taps) * Ci + 31) // 32
+        B = dense_from_fragments(frag[base:base + nkb * 64].reshape(nkb, 1, 64, 8), 32)
+        base += nkb * 64
+        classes[(pz, py, 0)] = (B[:, 0:8], taps)
+        classes[(pz, py, 1)] = (B[:, 8:16], taps)
+    assert base == frag.shape[0]
+    assert np.abs(_transposed_from_classes(x, classes, Co, 3) - oracle.convtranspose3d_k3s2(x, w, None)).max() <= 1e-4
+
+
+@pytest.mark.parametrize("Ci,Co,packer,kblock", [(16, 16, "_pack_z2_bf16", 32), (32, 32, "_pack_z2_bf16", 32), (8, 1, "_pack_z2_bf16", 32),
+                                                  (16, 16, "_pack_z2_f32", 4), (32, 8, "_pack_z2_f32", 4)])
+def test_pack_conv2d_fragments(Ci, Co, packer, kblock):
+    """ops._pack_z2_bf16 / _pack_z2_f32 (d3d_conv2d_k3_zs_* and the stride-2 form): K = (k_y, k_x, c_in)."""
+    rng = np.random.default_rng(Ci + Co + kblock)
+    w = bf16_exact(rng, (Co, Ci, 3, 3))
+    x = rng.standard_normal((Ci, 6, 9)).astype(np.float32)
+    B = dense_from_fragments(getattr(ops, packer)(torch.from_numpy(w)), kblock)
+    taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    assert np.abs(conv_from_B(x, B, taps, Co, (6, 9)) - oracle.conv2d_k3(x, w, None)).max() <= 1e-4
+    assert np.abs(conv_from_B(x, B, taps, Co, (3, 5), stride=2) - oracle.conv2d_k3(x, w, None, stride=2)).max() <= 1e-4
+
+
+@pytest.mark.parametrize("Ci,Co,packer,kblock", [(16, 8, "_pack_t2d_bf16", 32), (8, 1, "_pack_t2d_bf16", 32), (32, 16, "_pack_t2d_f32", 4),
+                                                  (8, 1, "_pack_t2d_f32", 4)])
+def test_pack_convtranspose2d_parity_classes(Ci, Co, packer, kblock):
+    """ops._pack_t2d_bf16 / _pack_t2d_f32 (d3d_convtranspose2d_k3s2_zs_*): four parity classes, taps (dy,dx) dy-major."""
+    rng = np.random.default_rng(Ci * 5 + Co + kblock)
+    w = bf16_exact(rng, (Ci, Co, 3, 3))
+    x = rng.standard_normal((Ci, 3, 5)).astype(np.float32)
+    frag = getattr(ops, packer)(torch.from_numpy(w))
+    classes, base = {}, 0
+    for c in range(4):
+        py, px = c >> 1, c & 1
+        taps = [(dy, dx) for dy in range(1 + py) for dx in range(1 + px)]
+        K = len(taps) * Ci
+        nkb = (K + 31) // 32 if kblock == 32 else K // 4
+        rows = nkb * 64 if kblock == 32 else nkb          # bf16: [fragment lane][8 values]; fp32: [K block][64 lanes]
+        blk = frag[base:base + rows]
+        B = dense_from_fragments(blk.reshape(nkb, 1, 64, 8) if kblock == 32 else blk.reshape(nkb, 1, 64), kblock)
+        base += rows
+        classes[(py, px)] = (B, taps)
+    assert base == frag.shape[0]
+    assert np.abs(_transposed_from_classes(x, classes, Co, 2) - oracle.convtranspose2d_k3s2(x, w, None)).max() <= 1e-4
