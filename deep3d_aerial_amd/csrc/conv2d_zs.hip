@@ -704,10 +704,11 @@ extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, 
     D3D_REQUIRE(act != 2 || (ep_split > 0 && ep_split <= Co), "GRU gate epilogue: bad ep_split %d", ep_split);
     D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
     const int Ci = C1 + C2;
-    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && C1 % 8 == 0 && C2 % 8 == 0 && Co <= 32 && W % 4 == 0;
+    // (48 -> <= 48: the pair-visibility UNet of AdaMVS, adamvs.py:198-238)
+    const bool shape = (((Ci == 8 || Ci == 16 || Ci == 32) && Co <= 32) || (Ci == 48 && Co <= 48)) && C1 % 8 == 0 && C2 % 8 == 0 && W % 4 == 0;
     if (!shape) {
-        set_error("d3d_conv2d_k3_zs_bf16: C_in = %d + %d (8 | 16 | 32 in groups of 8), C_out = %d (<= 32), W = %d (multiple of 4) not taken",
-                  C1, C2, Co, W);
+        set_error("d3d_conv2d_k3_zs_bf16: C_in = %d + %d (8 | 16 | 32 | 48 in groups of 8), C_out = %d (<= 32; <= 48 with C_in = 48), "
+                  "W = %d (multiple of 4) not taken", C1, C2, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
     Z2Params p = {};
@@ -715,6 +716,7 @@ extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, 
     p.skip = skip; p.aux1 = aux1; p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act; p.ep_split = ep_split;
     p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
+    if (Ci == 48) return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);
     if (Co > 16) {
         if (Ci == 32) return launch_z2<32, 2, 2>(p, st);
         if (Ci == 16) return launch_z2<16, 2, 4>(p, st);

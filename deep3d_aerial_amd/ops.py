@@ -684,11 +684,12 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
-    if (Ci0 + Ci1) not in (8, 16, 32) or Ci0 % 8 or Ci1 % 8 or Co > 32 or W % 4 or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+    Ci, bf16 = Ci0 + Ci1, conv_precision() == "bf16"
+    ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48 and bf16)   # 48 -> 48: the pair-visibility UNet (bf16 cells only fit)
+    if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
-    bf16 = conv_precision() == "bf16"
     wp = derived_weight(weight, "z2bf16", _pack_z2_bf16) if bf16 else derived_weight(weight, "z2f32", _pack_z2_f32)
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
     fn = _lib.load().d3d_conv2d_k3_zs_bf16 if bf16 else _lib.load().d3d_conv2d_k3_zs_f32

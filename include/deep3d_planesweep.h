@@ -253,7 +253,8 @@ int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const
  *   act 0 none | 1 ReLU, with `skip` [Co,H,W] (may be NULL) added before the activation or, skip_after_act, after it;
  *   act 2 GRU gates: sigmoid, channels < ep_split multiplied by h = skip [ep_split,H,W]      (-> [r*h | u]);
  *   act 3 GRU update: u*h + (1-u)*tanh(.), h = skip [Co,H,W], u = aux1 [Co,H,W].
- * C1 + C2 = 8 | 16 | 32 in groups of 8, Co <= 32, W % 4 == 0; D3D_ERR_UNSUPPORTED otherwise (nothing launched).
+ * C1 + C2 = 8 | 16 | 32 in groups of 8 with Co <= 32, or 48 with Co <= 48 (adamvs.py:198-238, the pair-visibility UNet);
+ * W % 4 == 0; D3D_ERR_UNSUPPORTED otherwise (nothing launched).
  * wpacked: the weight [Co,C1+C2,3,3] rounded to bf16 in B-operand lane order, [K block][N tile][lane][8], K = (k_y,k_x,c_in)
  * (ops._pack_z2_bf16). */
 int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,

@@ -1237,7 +1237,8 @@ def bf16_mode(ops):
 
 @pytest.mark.parametrize("Ci0,Ci1,Co,H,W,act", [(8, 0, 8, 9, 68, 1), (16, 0, 8, 20, 132, 0), (32, 0, 8, 7, 64, 1), (8, 8, 16, 17, 72, 2),
                                                 (8, 8, 8, 17, 72, 3), (16, 16, 32, 11, 36, 2), (16, 16, 16, 11, 36, 3), (8, 8, 16, 1, 4, 2),
-                                                (8, 8, 8, 70, 260, 3), (8, 0, 16, 33, 128, 1), (16, 16, 32, 40, 100, 2)])
+                                                (8, 8, 8, 70, 260, 3), (8, 0, 16, 33, 128, 1), (16, 16, 32, 40, 100, 2),
+                                                (48, 0, 48, 19, 68, 1), (48, 0, 8, 9, 36, 0), (24, 24, 32, 12, 40, 1)])
 def test_conv2d_tile_kernel_bf16_with_gru_epilogues(ops, oracle, bf16_mode, Ci0, Ci1, Co, H, W, act):
     """d3d_conv2d_k3_zs_bf16 (module.py:5-51 ConvGRUCell, adamvs.py:409 ConvReLU in bf16 mode): the fp32 oracle convolution on
     bf16-rounded operands over the channel concat, then the epilogue in fp32 -- none / ReLU with a skip before or after
