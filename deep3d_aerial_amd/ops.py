@@ -811,7 +811,7 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
-    if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= 256 * 256 and \
+    if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= int(_os.environ.get("D3D_CONV2D_ZS_MINPIX", 256 * 256)) and \
             (conv_precision() == "bf16" or _os.environ.get("D3D_CONV2D_ZS_ALL", "0") == "1"
              or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_SLICE", "0") == "1")):   # (fp32 ConvReLU of a slice: 71.7 vs 73.1 ms per AdaMVS view in favour of the vector-unit kernel)
         # bf16 mode, large image layers of the slice regularisers: one tile per step on v_mfma_f32_16x16x32_bf16
