@@ -619,7 +619,7 @@ extern "C" int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, i
         return launch_z2<8, 2, 4, true>(p, st);
     }
     if (Ci == 32) return launch_z2<32, 1, 2, true>(p, st);
-    if (Ci == 16) return launch_z2<16, 1, 2, true>(p, st);
+    if (Ci == 16) return launch_z2<16, 1, 2, true>(p, st);   // (64-wide tiles, one workgroup per CU: 14.7 -> 16.8 ms per AdaMVS view)
     return launch_z2<8, 1, 4, true>(p, st);
 }
 
