@@ -823,6 +823,14 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
+    if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16)) and _use_mfma() and H * W >= 128 * 128 \
+            and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0":
+        # 32 -> 32 and 16 -> 16 (the quarter- / half-resolution trunks of the feature pyramids), exact fp32: the tile kernel
+        # beats the row-streamed matrix-core form (140 -> 84 us at 464 x 688) and the vector-unit kernel (140 -> 87 us at
+        # 928 x 1376); 8 -> 8 is a tie and 32 -> 8 loses (330 -> 426 us at 1856 x 2752): they stay on the kernels below
+        y = conv2d_zs(x, weight, scale, shift, skip, act)
+        if y is not None:
+            return y
     if stride == 1 and act in (0, 1):
         y = conv2d_stream(x, weight, scale, shift, skip, act, x2=x2)
         if y is not None:
