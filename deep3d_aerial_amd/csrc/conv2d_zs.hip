@@ -55,16 +55,39 @@ __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
 // F32: the same tile scheme with exact fp32 operands (v_mfma_f32_16x16x4_f32, the default precision of the models): cells
 // of C_in floats + 16 bytes (20 | 36-dword pitches: the 16 pixels of an A operand, one dword each, fall in 16 different
 // banks, and so do the four K groups), K blocks of 4 channels of one tap, weights fp32 in LDS.
-template <int CI, int NTN, int MGN, bool F32 = false>
+//
+// X3: fp32 accuracy on the bf16 matrix cores.  An fp32 value is the exact sum of three bf16 numbers (hi = rne(v), mid =
+// rne(v - hi), lo = rne(v - hi - mid): 3 x 8 significand bits); activations are split while they are staged (a cell holds
+// the hi | mid | lo runs of its C_in channels), weights on the host, and a K block of 32 takes the six products whose weight
+// is >= 2^-16 of the leading one (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi: what is dropped is <= 2^-24 of the product,
+// fp32's own rounding) -- 6 x 16 cycles against the 8 x 32 cycles of the fp32 instruction for the same K.
+template <bool F32, bool X3>
+__host__ __device__ constexpr int z2_cell_bytes(int CI) {
+    return F32 ? CI * 4 + 16 : (X3 ? 3 : 1) * CI * 2 + (CI > 8 ? 16 : 0);   // bf16: an odd number of 16-byte slots
+}
+
+__device__ __forceinline__ void split3_bf16(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pack_bf16_z2(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);   // exact
+    mid = pack_bf16_z2(ra, rb);
+    lo = pack_bf16_z2(ra - __builtin_bit_cast(float, mid << 16), rb - __builtin_bit_cast(float, mid & 0xffff0000u));
+}
+
+template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
+    static_assert(!(F32 && X3), "one operand format");
     constexpr int TX = 16 * MGN, PX = TX + 2;
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
-    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);   // bytes per cell (bf16: an odd number of 16-byte slots)
+    constexpr int NSPL = X3 ? 3 : 1;
+    constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int G = CI / 8;
     constexpr int PATCH = PX * PYZ * CS;
+    // X3: one patch buffer (commit after the sweep, two barriers per tile) -- the split cells are 1.4 x the fp32 ones and
+    // a second buffer would leave one workgroup per CU; two or three resident workgroups overlap their phases instead
+    constexpr int NBUF = X3 ? 1 : 2;
     constexpr int AW = MGN * NTN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+    u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W;
@@ -78,7 +101,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         const float* wg = reinterpret_cast<const float*>(p.wpk);
         for (int i = tid; i < NKB * NTN * 64; i += NTZ) wf[i] = wg[i];
     } else {
-        for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+        for (int i = tid; i < NSPL * NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];   // X3: [hi | mid | lo][NKB][N tiles][lane]
     }
 
     // ---- staging: task = (patch pixel, 8-channel group); the group's planes come from `in` or from `in2` -------------
@@ -112,6 +135,13 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
                 if constexpr (F32) {
                     *reinterpret_cast<f4*>(dst + pix * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
                     *reinterpret_cast<f4*>(dst + pix * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                } else if constexpr (X3) {
+                    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) split3_bf16(stg[r][2 * k], stg[r][2 * k + 1], hi[k], mid[k], lo[k]);
+                    *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = (u4){hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<u4*>(dst + pix * CS + CI * 2 + g * 16) = (u4){mid[0], mid[1], mid[2], mid[3]};
+                    *reinterpret_cast<u4*>(dst + pix * CS + CI * 4 + g * 16) = (u4){lo[0], lo[1], lo[2], lo[3]};
                 } else {
                     const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
                                   pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
@@ -152,6 +182,34 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt)
                         acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+                }
+            }
+        } else if constexpr (X3) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int aoffk = a_offset(kb, kgroup);
+                bf16x8 b[3][NTN];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt)
+                        b[s][nt] = __builtin_bit_cast(bf16x8, wlds[((s * NKB + kb) * NTN + nt) * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MGN; ++mg) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        a[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk + s * CI * 2));
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt) {   // small terms first
+                        f4 c = acc[mg * NTN + nt];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0][nt], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2][nt], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1][nt], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0][nt], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1][nt], c, 0, 0, 0);
+                        acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0][nt], c, 0, 0, 0);
+                    }
                 }
             }
         } else
@@ -211,19 +269,27 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         const bool more = ty + 1 < t1;
         if (more) issue(ty + 1);
         tile(ty, smem + cur * PATCH);
-        if (more) commit(smem + (cur ^ 1) * PATCH);
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (NBUF == 2) {
+            if (more) commit(smem + (cur ^ 1) * PATCH);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();   // every wave has read the patch
+            if (more) commit(smem);
+            __syncthreads();
+        }
     }
 }
 
-template <int CI, int NTN, int MGN, bool F32 = false>
+template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false>
 static int launch_z2(const Z2Params& p, hipStream_t stream) {
     constexpr int TX = 16 * MGN, PX = TX + 2;
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
-    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * PX * PYZ * CS + NKB * NTN * 64 * (F32 ? 4 : 16);
-    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32>;
+    constexpr int PATCH = PX * PYZ * z2_cell_bytes<F32, X3>(CI);
+    constexpr int WBYTES = NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
+    constexpr int lds = (X3 ? 1 : 2) * PATCH + WBYTES;
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -621,6 +687,38 @@ extern "C" int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, i
     if (Ci == 32) return launch_z2<32, 1, 2, true>(p, st);
     if (Ci == 16) return launch_z2<16, 1, 2, true>(p, st);   // (64-wide tiles, one workgroup per CU: 14.7 -> 16.8 ms per AdaMVS view)
     return launch_z2<8, 1, 4, true>(p, st);
+}
+
+extern "C" int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                                       const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                                       int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && C1 > 0 && C2 >= 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act >= 0 && act <= 3, "bad act %d", act);
+    D3D_REQUIRE(C2 == 0 || in2, "second input missing");
+    D3D_REQUIRE(act < 2 || skip, "GRU epilogue (act %d) needs the state h in `skip`", act);
+    D3D_REQUIRE(act != 2 || (ep_split > 0 && ep_split <= Co), "GRU gate epilogue: bad ep_split %d", ep_split);
+    D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
+    const int Ci = C1 + C2;
+    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && C1 % 8 == 0 && C2 % 8 == 0 && Co <= 32 && W % 4 == 0;
+    if (!shape) {
+        set_error("d3d_conv2d_k3_zs_bf16x3: C_in = %d + %d (8 | 16 | 32 in groups of 8), C_out = %d (<= 32), W = %d (multiple of 4) not taken",
+                  C1, C2, Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.in2 = in2; p.C1 = C1; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
+    p.skip = skip; p.aux1 = aux1; p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act; p.ep_split = ep_split;
+    p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    if (Co > 16) {
+        if (Ci == 32) return launch_z2<32, 2, 2, false, true>(p, st);
+        if (Ci == 16) return launch_z2<16, 2, 2, false, true>(p, st);
+        return launch_z2<8, 2, 4, false, true>(p, st);
+    }
+    if (Ci == 32) return launch_z2<32, 1, 1, false, true>(p, st);   // 16-wide tiles: 65 KB, two workgroups per CU
+    if (Ci == 16) return launch_z2<16, 1, 2, false, true>(p, st);
+    return launch_z2<8, 1, 4, false, true>(p, st);
 }
 
 static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,

@@ -677,10 +677,29 @@ def _pack_z2_f32(w):
     return b.reshape(K // 4, 4, ntn, 16).permute(0, 2, 1, 3).reshape(K // 4, ntn, 64).contiguous()
 
 
+def _split3_bf16(w):
+    """fp32 tensor -> its exact three-way bf16 split (hi, mid, lo as fp32 tensors; hi + mid + lo == w in fp32)."""
+    w = w.to(torch.float32)
+    hi = w.to(torch.bfloat16).to(torch.float32)
+    mid = (w - hi).to(torch.bfloat16).to(torch.float32)
+    lo = (w - hi - mid).to(torch.bfloat16).to(torch.float32)
+    return hi, mid, lo
+
+
+def _pack_z2_bf16x3(w):
+    """nn.Conv2d weight [Co,Ci,3,3] -> the B operands of d3d_conv2d_k3_zs_bf16x3: [hi | mid | lo] x _pack_z2_bf16."""
+    return torch.stack([_pack_z2_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
+def _z2_fp32_entry():
+    """fp32-mode flavour of the stride-1 tile kernel: "x3" (three-way bf16 split, the default) | "f32" (v_mfma_f32_16x16x4_f32)."""
+    return "f32" if _os.environ.get("D3D_CONV2D_FP32", "x3") == "f32" else "x3"
+
+
 def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False):
     """3x3 stride-1 conv over cat(x, x2) on the tile kernel with the fused epilogues of the slice regularisers (act 0 | 1 |
-    2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16) -- bf16 matrix-core operands in bf16 mode, exact fp32 ones
-    (d3d_conv2d_k3_zs_f32) otherwise.  Returns None for shapes the kernel does not take."""
+    2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16) -- bf16 matrix-core operands in bf16 mode; fp32 accuracy otherwise
+    (d3d_conv2d_k3_zs_bf16x3: three-way bf16 splits, or with D3D_CONV2D_FP32=f32 the fp32 instruction of d3d_conv2d_k3_zs_f32).  Returns None for shapes the kernel does not take."""
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
@@ -690,15 +709,20 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
-    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16) if bf16 else derived_weight(weight, "z2f32", _pack_z2_f32)
+    lib = _lib.load()
+    if bf16:
+        name, wp = "d3d_conv2d_k3_zs_bf16", derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    elif _z2_fp32_entry() == "x3":
+        name, wp = "d3d_conv2d_k3_zs_bf16x3", derived_weight(weight, "z2bf16x3", _pack_z2_bf16x3)
+    else:
+        name, wp = "d3d_conv2d_k3_zs_f32", derived_weight(weight, "z2f32", _pack_z2_f32)
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
-    fn = _lib.load().d3d_conv2d_k3_zs_bf16 if bf16 else _lib.load().d3d_conv2d_k3_zs_f32
-    rc = fn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"),
-            _opt(skip, "skip"), _opt(aux1, "aux1"), int(act), int(ep_split), int(bool(skip_after_act)), Co, H, W,
-            _chk(out, "out"), _stream())
+    rc = getattr(lib, name)(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                            _opt(shift, "shift"), _opt(skip, "skip"), _opt(aux1, "aux1"), int(act), int(ep_split),
+                            int(bool(skip_after_act)), Co, H, W, _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_conv2d_k3_zs_bf16" if bf16 else "d3d_conv2d_k3_zs_f32")
+    _lib.check(rc, name)
     return out
 
 

@@ -267,6 +267,15 @@ int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, int C2, cons
                          const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                          int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
+/* The same layer with fp32 accuracy on the bf16 matrix cores: every fp32 operand is the exact sum of three bf16 numbers
+ * (hi + mid + lo); the activations are split while a tile is staged, the weights on the host (wpacked: the three
+ * d3d_conv2d_k3_zs_bf16 packings of hi | mid | lo one after the other, ops._pack_z2_bf16x3), and a K block takes the six
+ * products down to 2^-16 of the leading one on v_mfma_f32_16x16x32_bf16, accumulated in fp32 -- what is dropped is below
+ * fp32's own rounding of a product.  Arguments and shapes as d3d_conv2d_k3_zs_f32 (C1 + C2 = 8 | 16 | 32, Co <= 32). */
+int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                            const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                            int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /* The stride-2 and the transposed (k 3, stride 2, pad 1, output_pad 1) 2-D layers of the slice regularisers on the same tile
  * scheme (adamvs.py:411 ConvReLU(8,16,3,2,1); :413-417 upconv1 16->8 with the skip before the ReLU, upconv2d 8->1): planar fp32
  * in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1] resp. [Co,2H,2W]; act 0 | 1 (ReLU); skip (shape of out, may be NULL) added before

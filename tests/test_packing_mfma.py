@@ -136,6 +136,32 @@ def test_pack_conv2d_fragments(Ci, Co, packer, kblock):
     assert np.abs(conv_from_B(x, B, taps, Co, (3, 5), stride=2) - oracle.conv2d_k3(x, w, None, stride=2)).max() <= 1e-4
 
 
+@pytest.mark.parametrize("Ci,Co", [(16, 16), (32, 24), (8, 1)])
+def test_pack_conv2d_three_way_bf16_split(Ci, Co):
+    """ops._pack_z2_bf16x3 (d3d_conv2d_k3_zs_bf16x3): hi + mid + lo is the fp32 weight exactly, each part is a bf16 number, and
+    the six products the kernel takes (against the same split of the activations) reproduce the fp32 convolution."""
+    rng = np.random.default_rng(Ci * 3 + Co)
+    w = (rng.standard_normal((Co, Ci, 3, 3)) * np.exp(rng.uniform(-6, 6, (Co, Ci, 3, 3)))).astype(np.float32)
+    x = (rng.standard_normal((Ci, 6, 9)) * np.exp(rng.uniform(-6, 6, (Ci, 6, 9)))).astype(np.float32)
+    ws = [t.numpy() for t in ops._split3_bf16(torch.from_numpy(w))]
+    xs = [t.numpy() for t in ops._split3_bf16(torch.from_numpy(x))]
+    assert np.array_equal(ws[0] + ws[1] + ws[2], w) and np.array_equal(xs[0] + xs[1] + xs[2], x)
+    for part in ws + xs:
+        assert np.array_equal(torch.from_numpy(part).to(torch.bfloat16).to(torch.float32).numpy(), part)
+    frag = ops._pack_z2_bf16x3(torch.from_numpy(w))
+    assert frag.shape[0] == 3
+    taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    B = [dense_from_fragments(frag[s], 32) for s in range(3)]
+    got = np.zeros((Co, 6, 9), np.float64)
+    for sa, sb in [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]:
+        got += conv_from_B(xs[sa], B[sb], taps, Co, (6, 9)).astype(np.float64)
+    Bsum = B[0].astype(np.float64) + B[1].astype(np.float64) + B[2].astype(np.float64)
+    want = conv_from_B(x, Bsum, taps, Co, (6, 9))                           # float64 arithmetic
+    assert np.abs(want - oracle.conv2d_k3(x, w, None)).max() <= 1e-5 * np.abs(want).max()
+    scale = conv_from_B(np.abs(x), np.abs(Bsum), taps, Co, (6, 9))
+    assert (np.abs(got - want) <= 2.0 ** -22 * scale).all()
+
+
 @pytest.mark.parametrize("Ci,Co,packer,kblock", [(16, 8, "_pack_t2d_bf16", 32), (8, 1, "_pack_t2d_bf16", 32), (32, 16, "_pack_t2d_f32", 4),
                                                   (8, 1, "_pack_t2d_f32", 4)])
 def test_pack_convtranspose2d_parity_classes(Ci, Co, packer, kblock):

@@ -1347,11 +1347,15 @@ def test_convtranspose2d_tile_kernel_bf16(ops, oracle, bf16_mode, Ci, Co, H, W, 
     assert np.abs(host(plain) - (conv - b[:, None, None])).max() <= tol
 
 
+@pytest.mark.parametrize("flavour", ["x3", "f32"])
 @pytest.mark.parametrize("Ci0,Ci1,Co,H,W,act", [(8, 0, 8, 9, 68, 1), (32, 0, 8, 7, 64, 0), (8, 8, 16, 17, 72, 2), (8, 8, 8, 17, 72, 3),
-                                                (16, 16, 32, 11, 36, 2), (16, 16, 16, 40, 100, 3), (8, 0, 1, 33, 128, 0)])
-def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, Ci0, Ci1, Co, H, W, act):
-    """d3d_conv2d_k3_zs_f32 (the models' default precision): exact fp32 operands on v_mfma_f32_16x16x4_f32, against the
-    fp32 oracle without any rounding of the operands."""
+                                                (16, 16, 32, 11, 36, 2), (16, 16, 16, 40, 100, 3), (8, 0, 1, 33, 128, 0),
+                                                (32, 0, 32, 70, 132, 1), (8, 0, 24, 19, 260, 1)])
+def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, monkeypatch, flavour, Ci0, Ci1, Co, H, W, act):
+    """The models' default precision on the tile kernel: d3d_conv2d_k3_zs_bf16x3 (three-way bf16 splits of both operands,
+    the default) and d3d_conv2d_k3_zs_f32 (v_mfma_f32_16x16x4_f32), against the fp32 oracle without any rounding of the
+    operands."""
+    monkeypatch.setenv("D3D_CONV2D_FP32", flavour)
     rng = np.random.default_rng(Ci0 * 100 + Co + W + act)
     x = rng.standard_normal((Ci0, H, W)).astype(np.float32)
     x2 = rng.standard_normal((Ci1, H, W)).astype(np.float32) if Ci1 else None
@@ -1382,6 +1386,31 @@ def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, Ci0, Ci1, Co, H
         ops.set_conv_precision(None)
     assert got is not None
     assert np.abs(host(got) - want).max() <= tol
+
+
+@pytest.mark.parametrize("Ci,Co,H,W", [(8, 8, 33, 132), (16, 16, 40, 100), (32, 32, 21, 68), (32, 8, 64, 64)])
+def test_three_way_bf16_split_is_as_accurate_as_the_fp32_instruction(ops, monkeypatch, Ci, Co, H, W):
+    """d3d_conv2d_k3_zs_bf16x3 against a float64 convolution, on operands that span 2^+-8 in magnitude: its error stays within
+    that of the fp32 matrix-core instruction (both accumulate in fp32) -- the three-way split loses nothing fp32 keeps."""
+    import torch
+    rng = np.random.default_rng(Ci + Co + H)
+    x = (rng.standard_normal((Ci, H, W)) * np.exp2(rng.uniform(-8, 8, (Ci, H, W)))).astype(np.float32)
+    w = (rng.standard_normal((Co, Ci, 3, 3)) * np.exp2(rng.uniform(-8, 8, (Co, Ci, 3, 3)))).astype(np.float32)
+    xd, wd = dev(x), dev(w)
+    want = torch.nn.functional.conv2d(xd.double()[None], wd.double(), padding=1)[0]
+    scale = torch.nn.functional.conv2d(xd.double().abs()[None], wd.double().abs(), padding=1)[0]
+    err = {}
+    ops.set_conv_precision("fp32")
+    try:
+        for flavour in ("x3", "f32"):
+            monkeypatch.setenv("D3D_CONV2D_FP32", flavour)
+            got = ops.conv2d_zs(xd, wd)
+            assert got is not None
+            err[flavour] = float(((got.double() - want).abs() / scale).max())
+    finally:
+        ops.set_conv_precision(None)
+    assert err["f32"] <= 2e-6                     # fp32 accumulation over K = 9 C_in
+    assert err["x3"] <= 2 * err["f32"] + 2.0 ** -22
 
 
 def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle):
