@@ -837,8 +837,9 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("x2 spatial size mismatch")
     if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= int(_os.environ.get("D3D_CONV2D_ZS_MINPIX", 256 * 256)) and \
             (conv_precision() == "bf16" or _os.environ.get("D3D_CONV2D_ZS_ALL", "0") == "1"
-             or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_SLICE", "0") == "1")):   # (fp32 ConvReLU of a slice: 71.7 vs 73.1 ms per AdaMVS view in favour of the vector-unit kernel)
-        # bf16 mode, large image layers of the slice regularisers: one tile per step on v_mfma_f32_16x16x32_bf16
+             or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_SLICE", "1") == "1")):
+        # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
+        # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2)
         if y is not None:
             return y
@@ -847,11 +848,11 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
-    if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16)) and _use_mfma() and H * W >= 128 * 128 \
-            and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0":
-        # 32 -> 32 and 16 -> 16 (the quarter- / half-resolution trunks of the feature pyramids), exact fp32: the tile kernel
-        # beats the row-streamed matrix-core form (140 -> 84 us at 464 x 688) and the vector-unit kernel (140 -> 87 us at
-        # 928 x 1376); 8 -> 8 is a tie and 32 -> 8 loses (330 -> 426 us at 1856 x 2752): they stay on the kernels below
+    if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8)) and _use_mfma() \
+            and H * W >= 128 * 128 and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0":
+        # 32 -> 32, 16 -> 16 and 8 -> 8 (the trunks of the feature pyramids) in fp32 accuracy: the tile kernel beats the
+        # row-streamed matrix-core form (140 -> 68 us at 464 x 688) and the vector-unit kernel (140 -> 68 us at 928 x 1376,
+        # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below
         y = conv2d_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
@@ -889,7 +890,9 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    zs_any = conv_precision() == "bf16" or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0")
+    # fp32: the tile kernel serves the slice regularisers and (D3D_CONVT2D_ZS_ALL, default on) the feature pyramids' deconvs
+    zs_any = conv_precision() == "bf16" or (_os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0"
+                                            and (_tile_kernels[0] or _os.environ.get("D3D_CONVT2D_ZS_ALL", "1") != "0"))
     if zs_any and _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
         y = convtranspose2d_zs(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:

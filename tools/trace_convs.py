@@ -1,5 +1,6 @@
-"""Counts, per (entry point, input shape, weight shape, stride), the convolution calls of one AdaMVS forward in bf16 mode
-(GPU box): shows which layers the tile kernels of round 2 take and which stay on round 1's kernels."""
+"""Counts, per (entry point, input shape, weight shape, stride), the convolution calls of one AdaMVS forward (GPU box): shows
+which layers the tile kernels of round 2 take and which stay on round 1's kernels.  TRACE_PRECISION=bf16|fp32 (default bf16),
+TRACE_ALL=1 lists every entry point, not just round 1's."""
 import os, sys, collections, torch
 sys.path.insert(0, os.getcwd())
 from deep3d_aerial_amd import predict, ops, synthetic as S
@@ -16,8 +17,8 @@ for n in ("conv_k3_mfma", "convtranspose_k3s2_mfma", "conv_fold", "conv2d_stream
 net = predict.build_model("adamvs", 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
 s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
 imgs = torch.from_numpy(s["imgs"])[None].cuda(); pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}; dv = torch.from_numpy(s["depth_values"])[None].cuda()
-ops.set_conv_precision("bf16")
+ops.set_conv_precision(os.environ.get("TRACE_PRECISION", "bf16"))
 with torch.no_grad(): net(imgs, pm, dv)
 for k, v in sorted(cnt.items(), key=lambda kv: -kv[1]):
-    if k[0] in ("conv_k3_mfma", "conv_fold", "convtranspose_k3s2_mfma") and k[-1]:
+    if os.environ.get("TRACE_ALL") == "1" or (k[0] in ("conv_k3_mfma", "conv_fold", "convtranspose_k3s2_mfma") and k[-1]):
         print(v, k)
