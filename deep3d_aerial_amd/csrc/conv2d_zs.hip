@@ -14,6 +14,7 @@
 // ds_read_b128 of 8 channels), and the workgroup walks `tper` tiles down the image with the next patch's loads in flight
 // during the sweep.  D[pixel][channel]: a lane leaves with four consecutive pixels of one channel = 16-byte loads of
 // h / u and 16-byte stores.
+#include <cstdint>
 #include "common.h"
 
 #include <type_traits>
@@ -25,6 +26,7 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 constexpr int TYZ = 8;              // output rows of a tile = waves
 constexpr int PYZ = TYZ + 2;        // staged rows
@@ -104,49 +106,78 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         for (int i = tid; i < NSPL * NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];   // X3: [hi | mid | lo][NKB][N tiles][lane]
     }
 
-    // ---- staging: task = (patch pixel, 8-channel group); the group's planes come from `in` or from `in2` -------------
-    constexpr int NTASK = PX * PYZ * G;
-    constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
-    float stg[ROUNDS][8];
+    // ---- staging with 16-byte loads.  A quad task = (4 channels, patch row, 4 aligned columns x0 + 4q ..): four dwordx4 loads,
+    // the lanes of a wave reading whole 128-byte runs (W % 4 == 0: a quad is inside or outside the image as a whole); an edge
+    // task = (4 channels, patch row, halo column x0 - 1 | x0 + TX): four dword loads, given to the threads the quads leave idle.
+    // A channel quad comes from `in` or from `in2` (C1 % 8 == 0).
+    constexpr int C4 = CI / 4, QX = TX / 4;
+    constexpr int NQT = C4 * PYZ * QX, RQ = (NQT + NTZ - 1) / NTZ;
+    constexpr int NST = C4 * PYZ * 2, RS = (NST + NTZ - 1) / NTZ;
+    (void)G;
+    f4 stq[RQ][4];      // [channel of the quad][4 pixels]
+    float sts[RS][4];   // [channel of the quad]
+    const int tid_e = NTZ - 1 - tid;
+    auto chan_base = [&](int c) { return c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane; };
     auto issue = [&](int ty) {
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
+        for (int r = 0; r < RQ; ++r) {
             const int task = tid + r * NTZ;
-            const int pix = task / G, g = task - pix * G;
-            const int py = pix / PX, px = pix - py * PX;
-            const int gx = x0 + px - 1, gy = ty * TYZ + py - 1;
-            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const int c = 8 * g;
-            const float* __restrict__ base = c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane;
-            const float* __restrict__ src = base + (ok ? (size_t)gy * W + gx : 0);
+            const int q = task % QX, rest = task / QX, py = rest % PYZ, c4 = rest / PYZ;
+            const int gx = x0 + 4 * q, gy = ty * TYZ + py - 1;
+            const bool ok = task < NQT && gx < W && gy >= 0 && gy < H;
+            const float* __restrict__ src = ok ? chan_base(4 * c4) + (size_t)gy * W + gx : p.in;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * plane];
-                stg[r][k] = ok ? v : 0.0f;
+            for (int k = 0; k < 4; ++k) {
+                const f4 v = *reinterpret_cast<const f4*>(src + (size_t)k * plane);
+                stq[r][k] = ok ? v : (f4){0, 0, 0, 0};
             }
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int task = tid_e + r * NTZ;
+            const int side = task & 1, rest = task >> 1, py = rest % PYZ, c4 = rest / PYZ;
+            const int gx = side ? x0 + TX : x0 - 1, gy = ty * TYZ + py - 1;
+            const bool ok = task < NST && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const float* __restrict__ src = ok ? chan_base(4 * c4) + (size_t)gy * W + gx : p.in;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = src[(size_t)k * plane];
+                sts[r][k] = ok ? v : 0.0f;
+            }
+        }
+    };
+    // one pixel's four channels 4 c4 .. + 3 into its cell
+    auto put4 = [&](unsigned char* cell, int c4, float v0, float v1, float v2, float v3) {
+        if constexpr (F32) {
+            *reinterpret_cast<f4*>(cell + c4 * 16) = (f4){v0, v1, v2, v3};
+        } else if constexpr (X3) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3_bf16(v0, v1, h0, m0, l0);
+            split3_bf16(v2, v3, h1, m1, l1);
+            *reinterpret_cast<u2*>(cell + c4 * 8) = (u2){h0, h1};
+            *reinterpret_cast<u2*>(cell + CI * 2 + c4 * 8) = (u2){m0, m1};
+            *reinterpret_cast<u2*>(cell + CI * 4 + c4 * 8) = (u2){l0, l1};
+        } else {
+            *reinterpret_cast<u2*>(cell + c4 * 8) = (u2){pack_bf16_z2(v0, v1), pack_bf16_z2(v2, v3)};
         }
     };
     auto commit = [&](unsigned char* dst) {
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
+        for (int r = 0; r < RQ; ++r) {
             const int task = tid + r * NTZ;
-            if (task < NTASK) {
-                const int pix = task / G, g = task - pix * G;
-                if constexpr (F32) {
-                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
-                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
-                } else if constexpr (X3) {
-                    unsigned hi[4], mid[4], lo[4];
+            if (task < NQT) {
+                const int q = task % QX, rest = task / QX, py = rest % PYZ, c4 = rest / PYZ;
+                unsigned char* cell = dst + (py * PX + 1 + 4 * q) * CS;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) split3_bf16(stg[r][2 * k], stg[r][2 * k + 1], hi[k], mid[k], lo[k]);
-                    *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = (u4){hi[0], hi[1], hi[2], hi[3]};
-                    *reinterpret_cast<u4*>(dst + pix * CS + CI * 2 + g * 16) = (u4){mid[0], mid[1], mid[2], mid[3]};
-                    *reinterpret_cast<u4*>(dst + pix * CS + CI * 4 + g * 16) = (u4){lo[0], lo[1], lo[2], lo[3]};
-                } else {
-                    const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
-                                  pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
-                    *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
-                }
+                for (int i = 0; i < 4; ++i) put4(cell + i * CS, c4, stq[r][0][i], stq[r][1][i], stq[r][2][i], stq[r][3][i]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int task = tid_e + r * NTZ;
+            if (task < NST) {
+                const int side = task & 1, rest = task >> 1, py = rest % PYZ, c4 = rest / PYZ;
+                put4(dst + (py * PX + (side ? PX - 1 : 0)) * CS, c4, sts[r][0], sts[r][1], sts[r][2], sts[r][3]);
             }
         }
     };
@@ -289,6 +320,11 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
     constexpr int WBYTES = NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     constexpr int lds = (X3 ? 1 : 2) * PATCH + WBYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    if ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.in2) | reinterpret_cast<uintptr_t>(p.skip) |
+         reinterpret_cast<uintptr_t>(p.aux1) | reinterpret_cast<uintptr_t>(p.out)) & 15) {
+        set_error("conv2d tile kernel: tensors must be 16-byte aligned (dwordx4 loads and stores)");
+        return D3D_ERR_UNSUPPORTED;
+    }
     auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
