@@ -109,7 +109,9 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     // ---- staging with 16-byte loads.  A quad task = (4 channels, patch row, 4 aligned columns x0 + 4q ..): four dwordx4 loads,
     // the lanes of a wave reading whole 128-byte runs (W % 4 == 0: a quad is inside or outside the image as a whole); an edge
     // task = (4 channels, patch row, halo column x0 - 1 | x0 + TX): four dword loads, given to the threads the quads leave idle.
-    // A channel quad comes from `in` or from `in2` (C1 % 8 == 0).
+    // A channel quad comes from `in` or from `in2` (C1 % 8 == 0).  Task order: channel quad fastest, then column quad, then row:
+    // a load instruction still reads whole 128-byte runs (one per channel and row), and the lanes of a cell write of the
+    // commit cover the C4 adjacent 8-byte (fp32: 16-byte) slots of one cell before moving 4 cells on.
     constexpr int C4 = CI / 4, QX = TX / 4;
     constexpr int NQT = C4 * PYZ * QX, RQ = (NQT + NTZ - 1) / NTZ;
     constexpr int NST = C4 * PYZ * 2, RS = (NST + NTZ - 1) / NTZ;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
             const int task = tid + r * NTZ;
-            const int q = task % QX, rest = task / QX, py = rest % PYZ, c4 = rest / PYZ;
+            const int c4 = task % C4, rest = task / C4, q = rest % QX, py = rest / QX;
             const int gx = x0 + 4 * q, gy = ty * TYZ + py - 1;
             const bool ok = task < NQT && gx < W && gy >= 0 && gy < H;
             const float* __restrict__ src = ok ? chan_base(4 * c4) + (size_t)gy * W + gx : p.in;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             const int task = tid_e + r * NTZ;
-            const int side = task & 1, rest = task >> 1, py = rest % PYZ, c4 = rest / PYZ;
+            const int c4 = task % C4, rest = task / C4, side = rest & 1, py = rest >> 1;
             const int gx = side ? x0 + TX : x0 - 1, gy = ty * TYZ + py - 1;
             const bool ok = task < NST && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const float* __restrict__ src = ok ? chan_base(4 * c4) + (size_t)gy * W + gx : p.in;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         for (int r = 0; r < RQ; ++r) {
             const int task = tid + r * NTZ;
             if (task < NQT) {
-                const int q = task % QX, rest = task / QX, py = rest % PYZ, c4 = rest / PYZ;
+                const int c4 = task % C4, rest = task / C4, q = rest % QX, py = rest / QX;
                 unsigned char* cell = dst + (py * PX + 1 + 4 * q) * CS;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) put4(cell + i * CS, c4, stq[r][0][i], stq[r][1][i], stq[r][2][i], stq[r][3][i]);
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         for (int r = 0; r < RS; ++r) {
             const int task = tid_e + r * NTZ;
             if (task < NST) {
-                const int side = task & 1, rest = task >> 1, py = rest % PYZ, c4 = rest / PYZ;
+                const int c4 = task % C4, rest = task / C4, side = rest & 1, py = rest >> 1;
                 put4(dst + (py * PX + (side ? PX - 1 : 0)) * CS, c4, sts[r][0], sts[r][1], sts[r][2], sts[r][3]);
             }
         }
