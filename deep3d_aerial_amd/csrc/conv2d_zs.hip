@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     constexpr int PATCH = PX * PYZ * CS;
     // X3: one patch buffer (commit after the sweep, two barriers per tile) -- the split cells are 1.4 x the fp32 ones and
     // a second buffer would leave one workgroup per CU; two or three resident workgroups overlap their phases instead
-    constexpr int NBUF = X3 ? 1 : 2;
+    constexpr int NBUF = X3 || (F32 && CI > 32) ? 1 : 2;   // (fp32 cells of 48 channels: 71 KB of patch beside 83 KB of weights)
     constexpr int AW = MGN * NTN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
@@ -320,7 +320,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
     constexpr int PATCH = PX * PYZ * z2_cell_bytes<F32, X3>(CI);
     constexpr int WBYTES = NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
-    constexpr int lds = (X3 ? 1 : 2) * PATCH + WBYTES;
+    constexpr int lds = (X3 || (F32 && CI > 32) ? 1 : 2) * PATCH + WBYTES;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     if ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.in2) | reinterpret_cast<uintptr_t>(p.skip) |
          reinterpret_cast<uintptr_t>(p.aux1) | reinterpret_cast<uintptr_t>(p.out)) & 15) {
@@ -706,10 +706,11 @@ extern "C" int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, i
     D3D_REQUIRE(act != 2 || (ep_split > 0 && ep_split <= Co), "GRU gate epilogue: bad ep_split %d", ep_split);
     D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
     const int Ci = C1 + C2;
-    const bool shape = (Ci == 8 || Ci == 16 || Ci == 32) && C1 % 8 == 0 && C2 % 8 == 0 && Co <= 32 && W % 4 == 0;
+    const bool shape = (((Ci == 8 || Ci == 16 || Ci == 32) && Co <= 32) || (Ci == 48 && Co <= 48)) && C1 % 8 == 0 && C2 % 8 == 0 &&
+                       W % 4 == 0;
     if (!shape) {
-        set_error("d3d_conv2d_k3_zs_f32: C_in = %d + %d (8 | 16 | 32 in groups of 8), C_out = %d (<= 32), W = %d (multiple of 4) not taken",
-                  C1, C2, Co, W);
+        set_error("d3d_conv2d_k3_zs_f32: C_in = %d + %d (8 | 16 | 32 in groups of 8 with C_out <= 32, or 48 with C_out <= 48), "
+                  "C_out = %d, W = %d (multiple of 4) not taken", C1, C2, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
     Z2Params p = {};
@@ -717,6 +718,11 @@ extern "C" int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, i
     p.skip = skip; p.aux1 = aux1; p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act; p.ep_split = ep_split;
     p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
+    if (Ci == 48) {   // the pair-visibility UNet (adamvs.py:198-238) in fp32 mode: one patch buffer, the K loop is the bound
+        if (Co > 32) return launch_z2<48, 3, 2, true>(p, st);
+        if (Co > 16) return launch_z2<48, 2, 2, true>(p, st);
+        return launch_z2<48, 1, 2, true>(p, st);
+    }
     if (Co > 16) {
         if (Ci == 32) return launch_z2<32, 2, 2, true>(p, st);
         if (Ci == 16) return launch_z2<16, 2, 2, true>(p, st);

@@ -704,7 +704,7 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
     Ci, bf16 = Ci0 + Ci1, conv_precision() == "bf16"
-    ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48 and bf16)   # 48 -> 48: the pair-visibility UNet (bf16 cells only fit)
+    ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48)   # 48 -> 48: the pair-visibility UNet
     if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
@@ -712,7 +712,7 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     lib = _lib.load()
     if bf16:
         name, wp = "d3d_conv2d_k3_zs_bf16", derived_weight(weight, "z2bf16", _pack_z2_bf16)
-    elif _z2_fp32_entry() == "x3":
+    elif _z2_fp32_entry() == "x3" and Ci != 48:   # (split cells of 48 channels + their weights do not fit the LDS)
         name, wp = "d3d_conv2d_k3_zs_bf16x3", derived_weight(weight, "z2bf16x3", _pack_z2_bf16x3)
     else:
         name, wp = "d3d_conv2d_k3_zs_f32", derived_weight(weight, "z2f32", _pack_z2_f32)
@@ -848,11 +848,12 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
-    if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8)) and _use_mfma() \
-            and H * W >= 128 * 128 and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0":
+    if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8), (48, 48)) and _use_mfma() \
+            and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128) and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0":
         # 32 -> 32, 16 -> 16 and 8 -> 8 (the trunks of the feature pyramids) in fp32 accuracy: the tile kernel beats the
         # row-streamed matrix-core form (140 -> 68 us at 464 x 688) and the vector-unit kernel (140 -> 68 us at 928 x 1376,
-        # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below
+        # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below.
+        # 48 -> 48 (the pair-visibility UNet of AdaMVS): fp32 instruction, one patch buffer (340 -> 90 us at 688 x 464)
         y = conv2d_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y

@@ -262,7 +262,7 @@ int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, con
                           int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
 /* The same layer in the models' default precision: exact fp32 operands on v_mfma_f32_16x16x4_f32 (weights fp32 in the same
- * [K block of 4][N tile][lane] order, ops._pack_z2_f32); arguments as d3d_conv2d_k3_zs_bf16. */
+ * [K block of 4][N tile][lane] order, ops._pack_z2_f32); arguments and shapes as d3d_conv2d_k3_zs_bf16. */
 int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                          const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                          int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);

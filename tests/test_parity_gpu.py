@@ -1350,7 +1350,8 @@ def test_convtranspose2d_tile_kernel_bf16(ops, oracle, bf16_mode, Ci, Co, H, W, 
 @pytest.mark.parametrize("flavour", ["x3", "f32"])
 @pytest.mark.parametrize("Ci0,Ci1,Co,H,W,act", [(8, 0, 8, 9, 68, 1), (32, 0, 8, 7, 64, 0), (8, 8, 16, 17, 72, 2), (8, 8, 8, 17, 72, 3),
                                                 (16, 16, 32, 11, 36, 2), (16, 16, 16, 40, 100, 3), (8, 0, 1, 33, 128, 0),
-                                                (32, 0, 32, 70, 132, 1), (8, 0, 24, 19, 260, 1)])
+                                                (32, 0, 32, 70, 132, 1), (8, 0, 24, 19, 260, 1), (48, 0, 48, 23, 72, 1),
+                                                (24, 24, 40, 9, 36, 0), (48, 0, 16, 5, 132, 1)])
 def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, monkeypatch, flavour, Ci0, Ci1, Co, H, W, act):
     """The models' default precision on the tile kernel: d3d_conv2d_k3_zs_bf16x3 (three-way bf16 splits of both operands,
     the default) and d3d_conv2d_k3_zs_f32 (v_mfma_f32_16x16x4_f32), against the fp32 oracle without any rounding of the
