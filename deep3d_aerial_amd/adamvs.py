@@ -47,6 +47,33 @@ class FeatureNet(nn.Module):
 
     @staticmethod
     def _context(feat, br_a, br_b, head):
+        """head(cat(up(br_a(feat)), up(br_b(feat)), feat)) (adamvs.py:116-151).  Fused form: both pools in one read of feat,
+        the head applied to the branch outputs at their own resolution (a 1x1 convolution commutes with the bilinear
+        resize) and one streaming kernel for W_f feat + up(.) + up(.) -- no upsampled tensors, no concat."""
+        if (feat.is_cuda and feat.dtype == torch.float32 and head.kernel_size == (1, 1) and head.bias is None
+                and isinstance(br_a[0], nn.AvgPool2d) and br_a[0].kernel_size == (4, 4) and br_b[0].kernel_size == (8, 8)):
+            outs = []
+            for i in range(feat.shape[0]):
+                f = feat[i].contiguous()
+                pools = ops.avgpool_4_8(f)
+                if pools is None:
+                    break
+                a, b = br_a[1](pools[0][None])[0], br_b[1](pools[1][None])[0]
+                Ca, Cb, Co = a.shape[0], b.shape[0], head.out_channels
+                w = head.weight.reshape(Co, -1)
+                wa = ops.derived_weight(head.weight, "ctx_a", lambda t: t.reshape(Co, -1)[:, :Ca])
+                wb = ops.derived_weight(head.weight, "ctx_b", lambda t: t.reshape(Co, -1)[:, Ca:Ca + Cb])
+                wf = ops.derived_weight(head.weight, "ctx_f", lambda t: t.reshape(Co, -1)[:, Ca + Cb:])
+                if w.shape[1] != Ca + Cb + f.shape[0]:
+                    break
+                a2 = torch.matmul(wa, a.reshape(Ca, -1)).reshape(Co, a.shape[1], a.shape[2])   # at 1/16 and 1/64 of the pixels
+                b2 = torch.matmul(wb, b.reshape(Cb, -1)).reshape(Co, b.shape[1], b.shape[2])
+                y = ops.conv1x1_context(f, wf, a2, b2)
+                if y is None:
+                    break
+                outs.append(y)
+            else:
+                return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
         size = feat.shape[2:]
         up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=False)
         return feature_conv(head, torch.cat((up(br_a(feat)), up(br_b(feat)), feat), 1))

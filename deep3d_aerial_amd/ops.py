@@ -677,6 +677,38 @@ def _pack_z2_f32(w):
     return b.reshape(K // 4, 4, ntn, 16).permute(0, 2, 1, 3).reshape(K // 4, ntn, 64).contiguous()
 
 
+def avgpool_4_8(x):
+    """AvgPool2d(4) and AvgPool2d(8) of x [C,H,W] in one read (d3d_avgpool2d_4_8) -> ([C,H//4,W//4], [C,H//8,W//8]); None for
+    shapes the kernel does not take."""
+    C, H, W = x.shape
+    if H < 8 or W < 8 or W % 4 or _os.environ.get("D3D_CONTEXT_FUSED", "1") == "0":
+        return None
+    o4 = torch.empty((C, H // 4, W // 4), dtype=torch.float32, device=x.device)
+    o8 = torch.empty((C, H // 8, W // 8), dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_avgpool2d_4_8(_chk(x, "x", 3), C, H, W, _chk(o4, "out4"), _chk(o8, "out8"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_avgpool2d_4_8")
+    return o4, o8
+
+
+def conv1x1_context(f, weight, a, b):
+    """out = weight [Co,Ci] . f [Ci,H,W] + bilinear_resize(a [Co,Ha,Wa]) + bilinear_resize(b [Co,Hb,Wb]) (align_corners=False)
+    in one pass over f (d3d_conv1x1_context: the pooled-context heads of the AdaMVS pyramid); None for other shapes."""
+    Ci, H, W = f.shape
+    Co = weight.shape[0]
+    if (tuple(weight.shape) != (Co, Ci) or Ci != Co or Ci not in (8, 16, 32) or W % 4 or a.shape[0] != Co or b.shape[0] != Co
+            or 3 * a.shape[2] > W or 3 * b.shape[2] > W or _os.environ.get("D3D_CONTEXT_FUSED", "1") == "0"):
+        return None
+    out = torch.empty((Co, H, W), dtype=torch.float32, device=f.device)
+    rc = _lib.load().d3d_conv1x1_context(_chk(f, "f", 3), Ci, _chk(weight, "weight"), _chk(a, "a", 3), a.shape[1], a.shape[2],
+                                         _chk(b, "b", 3), b.shape[1], b.shape[2], Co, H, W, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv1x1_context")
+    return out
+
+
 def _split3_bf16(w):
     """fp32 tensor -> its exact three-way bf16 split (hi, mid, lo as fp32 tensors; hi + mid + lo == w in fp32)."""
     w = w.to(torch.float32)

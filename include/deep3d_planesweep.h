@@ -276,6 +276,18 @@ int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2, int C2, c
                             const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                             int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
+/* Pooled-context heads of the AdaMVS feature pyramid (adamvs.py:75-101, 116-151 of the reference:
+ * out = head(cat(up(branch_4(f)), up(branch_8(f)), f)), up = bilinear resize with align_corners=False, head a 1x1 convolution
+ * without bias).  d3d_avgpool2d_4_8: both AvgPool2d((4,4),4) and AvgPool2d((8,8),8) of in [C,H,W] in one read ->
+ * out4 [C,H/4,W/4], out8 [C,H/8,W/8] (floor sizes; W % 4 == 0, else D3D_ERR_UNSUPPORTED).
+ * d3d_conv1x1_context: out [Co,H,W] = weight [Co,Ci] . f [Ci,H,W] + resize(a [Co,Ha,Wa]) + resize(b [Co,Hb,Wb]) -- the head
+ * applied to the branch outputs at THEIR resolution (a = W_a . branch_4 output, b = W_b . branch_8 output: a 1x1
+ * convolution commutes with the resize), so neither the upsampled branches nor the concat reach HBM.
+ * Ci == Co in 8 | 16 | 32, W % 4 == 0, 3 Wa <= W, 3 Wb <= W; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_avgpool2d_4_8(const float* in, int C, int H, int W, float* out4, float* out8, d3d_stream_t stream);
+int d3d_conv1x1_context(const float* f, int Ci, const float* weight, const float* a, int Ha, int Wa, const float* b, int Hb,
+                        int Wb, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /* The stride-2 and the transposed (k 3, stride 2, pad 1, output_pad 1) 2-D layers of the slice regularisers on the same tile
  * scheme (adamvs.py:411 ConvReLU(8,16,3,2,1); :413-417 upconv1 16->8 with the skip before the ReLU, upconv2d 8->1): planar fp32
  * in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1] resp. [Co,2H,2W]; act 0 | 1 (ReLU); skip (shape of out, may be NULL) added before

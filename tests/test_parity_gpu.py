@@ -1414,6 +1414,58 @@ def test_three_way_bf16_split_is_as_accurate_as_the_fp32_instruction(ops, monkey
     assert err["x3"] <= 2 * err["f32"] + 2.0 ** -22
 
 
+@pytest.mark.parametrize("C,H,W", [(8, 8, 8), (8, 64, 72), (16, 37, 44), (32, 116, 172), (3, 30, 100)])
+def test_avgpool_4_and_8_in_one_read(ops, C, H, W):
+    """d3d_avgpool2d_4_8 against torch's AvgPool2d((4,4),4) and ((8,8),8) (adamvs.py:75-96), floor output sizes."""
+    import torch
+    x = torch.randn(C, H, W, device="cuda")
+    got = ops.avgpool_4_8(x)
+    assert got is not None
+    w4 = torch.nn.functional.avg_pool2d(x[None], 4, 4)[0]
+    w8 = torch.nn.functional.avg_pool2d(x[None], 8, 8)[0]
+    assert got[0].shape == w4.shape and got[1].shape == w8.shape
+    assert float((got[0] - w4).abs().max()) <= 1e-6 and float((got[1] - w8).abs().max()) <= 1e-6
+    assert ops.avgpool_4_8(torch.randn(4, 16, 18, device="cuda")) is None          # W % 4 != 0: the caller's fallback
+
+
+@pytest.mark.parametrize("C,H,W", [(8, 64, 72), (16, 38, 44), (32, 116, 172), (8, 9, 12), (16, 232, 344)])
+def test_pooled_context_head_fused(ops, C, H, W):
+    """d3d_conv1x1_context: head(cat(up(a), up(b), f)) of the AdaMVS pyramid (adamvs.py:116-151) with the head applied to
+    the branch outputs at their own resolution, against the reference's formulation in torch (float64)."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    f, a, b = rn(C, H, W), rn(C // 2, max(H // 4, 1), max(W // 4, 1)), rn(C // 2, max(H // 8, 1), max(W // 8, 1))
+    w = rn(C, 2 * C) * 0.3
+    up = lambda t: F.interpolate(t[None].double(), size=(H, W), mode="bilinear", align_corners=False)[0]
+    want = F.conv2d(torch.cat((up(a), up(b), f.double()), 0)[None], w.double()[:, :, None, None])[0]
+    wa, wb, wf = w[:, :C // 2].contiguous(), w[:, C // 2:C].contiguous(), w[:, C:].contiguous()
+    a2 = torch.matmul(wa, a.reshape(C // 2, -1)).reshape(C, a.shape[1], a.shape[2])
+    b2 = torch.matmul(wb, b.reshape(C // 2, -1)).reshape(C, b.shape[1], b.shape[2])
+    got = ops.conv1x1_context(f, wf, a2, b2)
+    assert got is not None
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert ops.conv1x1_context(f, wf, F.interpolate(a2[None], size=(H // 2, W // 2))[0].contiguous(), b2) is None   # branch too fine
+
+
+def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, monkeypatch):
+    """adamvs.FeatureNet with the fused pooled-context heads against the same modules on avg_pool2d / interpolate / cat."""
+    import torch
+    from deep3d_aerial_amd import adamvs, synthetic as S
+    net = adamvs.FeatureNet(8)
+    S.fill_state_dict_(net.state_dict(), 3)
+    net = net.cuda().eval()
+    x = torch.randn(1, 3, 96, 160, device="cuda")
+    with torch.no_grad():
+        fused = net(x)
+        monkeypatch.setenv("D3D_CONTEXT_FUSED", "0")
+        plain = net(x)
+    for k in ("stage1", "stage2", "stage3"):
+        assert fused[k].shape == plain[k].shape
+        assert float((fused[k] - plain[k]).abs().max()) <= 2e-5 * max(1.0, float(plain[k].abs().max()))
+
+
 def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle):
     """d3d_conv2d_k3s2_zs_f32 / d3d_convtranspose2d_k3s2_zs_f32: exact fp32 operands, against the oracle without rounding."""
     rng = np.random.default_rng(12)

@@ -15,4 +15,4 @@ with torch.no_grad():
     with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
         net(x)
         torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=70))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=24, max_name_column_width=70))
