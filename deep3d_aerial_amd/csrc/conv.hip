@@ -579,9 +579,9 @@ static int launch_convT3d_co8(const ConvParams& p, hipStream_t stream) {
 // loads in flight during the FMAs); weights packed [C_in padded to 8][ky][kx][C_out] feed v_pk_fma_f32 from scalar
 // registers.  Channels beyond C_in (the 3-channel image layer) are staged as zeros.
 // ---------------------------------------------------------------------------------------------------------------
-template <int CO>
+template <int CO, int CK = 8>   // CK: channels per staged chunk (4 for the 3-channel image layer: half the zero work)
 __global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
-    constexpr int CK = 8, YP = 2, TY = 4 * YP;
+    constexpr int YP = 2, TY = 4 * YP;
     constexpr int PW = C1_TX + 2, PS = PW + 1, PH = TY + 2;
     constexpr int PLANE = PH * PS;
     constexpr int NLD = (CK * PH * PW + 255) / 256;
@@ -693,7 +693,9 @@ static int launch_conv2d_stream(const ConvParams& p, hipStream_t stream) {
     const int gx = ceil_div(p.W, C1_TX), gy = ceil_div(p.H, 8);
     const long in_plane = (long)p.H * p.W;
     if (gy > 65535 || (long)8 * in_plane * 4 >= (1L << 31)) return D3D_ERR_UNSUPPORTED;
-    if (p.Co == 8)
+    if (p.Co == 8 && p.Ci0 + p.Ci1 <= 4)
+        hipLaunchKernelGGL((conv2d_stream_kernel<8, 4>), dim3(gx, gy), dim3(256), 0, stream, p);
+    else if (p.Co == 8)
         hipLaunchKernelGGL(conv2d_stream_kernel<8>, dim3(gx, gy), dim3(256), 0, stream, p);
     else if (p.Co == 16)
         hipLaunchKernelGGL(conv2d_stream_kernel<16>, dim3(gx, gy), dim3(256), 0, stream, p);
