@@ -75,6 +75,26 @@ __device__ __forceinline__ void split3_bf16(float a, float b, unsigned& hi, unsi
     lo = pack_bf16_z2(ra - __builtin_bit_cast(float, mid << 16), rb - __builtin_bit_cast(float, mid & 0xffff0000u));
 }
 
+// eight channels of one pixel -> the hi | mid | lo runs of its split cell (`cell` points at the group's slot of the hi run)
+__device__ __forceinline__ void put8_split3(unsigned char* cell, int CI, const float (&v)[8]) {
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) split3_bf16(v[2 * k], v[2 * k + 1], hi[k], mid[k], lo[k]);
+    *reinterpret_cast<u4*>(cell) = (u4){hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<u4*>(cell + CI * 2) = (u4){mid[0], mid[1], mid[2], mid[3]};
+    *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
+}
+
+// the six products of a split K block, small terms first
+__device__ __forceinline__ f4 mfma_split3(const bf16x8 (&a)[3], bf16x8 bh, bf16x8 bm, bf16x8 bl, f4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bm, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bm, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bh, c, 0, 0, 0);
+}
+
 template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     static_assert(!(F32 && X3), "one operand format");
@@ -346,16 +366,18 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
 // ---- stride 2 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1) of the slice regulariser): out (y, x) reads in (2y + k_y - 1, 2x + k_x - 1) --
 // 32 x 8 OUTPUT pixels per step; the staged 65 x 17 patch keeps the even and the odd columns of a row in separate runs, so
 // the 16 pixels of an A operand (input columns 2m + k_x - 1) are 16 consecutive cells.  p.H, p.W: INPUT size.
-template <int CI, int NTN, bool F32 = false>
+template <int CI, int NTN, bool F32 = false, bool X3 = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
+    static_assert(!(F32 && X3), "one operand format");
     constexpr int MG = 2, TXO = 16 * MG, PXI = 2 * TXO + 1, PYI = 2 * TYZ + 1, NEVEN = TXO + 1;
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
-    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
+    constexpr int NBUF = X3 ? 1 : 2;   // (split operands: one patch buffer, as in the stride-1 kernel)
     constexpr int AW = MG * NTN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+    u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         const float* wg = reinterpret_cast<const float*>(p.wpk);
         for (int i = tid; i < NKB * NTN * 64; i += NTZ) wf[i] = wg[i];
     } else {
-        for (int i = tid; i < NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];
+        for (int i = tid; i < (X3 ? 3 : 1) * NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];   // X3: [hi | mid | lo][NKB][N tiles][lane]
     }
 
     constexpr int NTASK = PXI * PYI * G;
@@ -402,6 +424,8 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
                 if constexpr (F32) {
                     *reinterpret_cast<f4*>(dst + cell * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
                     *reinterpret_cast<f4*>(dst + cell * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                } else if constexpr (X3) {
+                    put8_split3(dst + cell * CS + g * 16, CI, stg[r]);
                 } else {
                     const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
                                   pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
@@ -441,6 +465,26 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt)
                         acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+                }
+            }
+        } else if constexpr (X3) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const int aoffk = a_offset(kb, kgroup);
+                bf16x8 b[3][NTN];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt)
+                        b[sp][nt] = __builtin_bit_cast(bf16x8, wlds[((sp * NKB + kb) * NTN + nt) * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp)
+                        a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk + sp * CI * 2));
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt) acc[mg * NTN + nt] = mfma_split3(a, b[0][nt], b[1][nt], b[2][nt], acc[mg * NTN + nt]);
                 }
             }
         } else
@@ -487,9 +531,15 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         const bool more = ty + 1 < t1;
         if (more) issue(ty + 1);
         tile(ty, smem + cur * PATCH);
-        if (more) commit(smem + (cur ^ 1) * PATCH);
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (NBUF == 2) {
+            if (more) commit(smem + (cur ^ 1) * PATCH);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (more) commit(smem);
+            __syncthreads();
+        }
     }
 }
 
@@ -504,15 +554,17 @@ constexpr int frag_base2(int CI, int c, bool f32 = false) {
     return s;
 }
 
-template <int CI, bool F32 = false>
+template <int CI, bool F32 = false, bool X3 = false>
 __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
+    static_assert(!(F32 && X3), "one operand format");
     constexpr int MG = 2, TXI = 16 * MG, PXI = TXI + 1, PYI = TYZ + 1;
-    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
     constexpr int NFRAG = frag_base2(CI, 4, F32);
+    constexpr int NBUF = X3 && CI > 8 ? 1 : 2;   // (split cells of 16 | 32 channels: one patch buffer, more workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+    u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W, OW = 2 * W;
@@ -526,7 +578,7 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         const float* wg = reinterpret_cast<const float*>(p.wpk);
         for (int i = tid; i < NFRAG * 64; i += NTZ) wf[i] = wg[i];
     } else {
-        for (int i = tid; i < NFRAG * 64; i += NTZ) wlds[i] = p.wpk[i];
+        for (int i = tid; i < (X3 ? 3 : 1) * NFRAG * 64; i += NTZ) wlds[i] = p.wpk[i];   // X3: [hi | mid | lo][fragments][lane]
     }
 
     constexpr int NTASK = PXI * PYI * G;
@@ -557,6 +609,8 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
                 if constexpr (F32) {
                     *reinterpret_cast<f4*>(dst + pix * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
                     *reinterpret_cast<f4*>(dst + pix * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                } else if constexpr (X3) {
+                    put8_split3(dst + pix * CS + g * 16, CI, stg[r]);
                 } else {
                     const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
                                   pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
@@ -603,6 +657,20 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
                 const bool real = t < ntaps2(PY, px);
                 const int dx = real ? t % (1 + px) : 0, dy = real ? t / (1 + px) : 0;
                 const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
+                if constexpr (X3) {
+                    bf16x8 bw[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) bw[sp] = __builtin_bit_cast(bf16x8, wlds[(sp * NFRAG + FB + kb) * 64 + lane]);
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) {
+                        bf16x8 a[3];
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp)
+                            a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff + sp * CI * 2));
+                        acc[px][mg] = mfma_split3(a, bw[0], bw[1], bw[2], acc[px][mg]);
+                    }
+                    continue;
+                }
                 const bf16x8 bw = __builtin_bit_cast(bf16x8, wlds[(FB + kb) * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
@@ -641,18 +709,25 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         if (more) issue(ty + 1);
         row(std::integral_constant<int, 0>{}, ty, smem + cur * PATCH);
         row(std::integral_constant<int, 1>{}, ty, smem + cur * PATCH);
-        if (more) commit(smem + (cur ^ 1) * PATCH);
-        __syncthreads();
-        cur ^= 1;
+        if constexpr (NBUF == 2) {
+            if (more) commit(smem + (cur ^ 1) * PATCH);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (more) commit(smem);
+            __syncthreads();
+        }
     }
 }
 
-template <int CI, int NTN, bool F32 = false>
+template <int CI, int NTN, bool F32 = false, bool X3 = false>
 static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
-    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * 65 * 17 * CS + NKB * NTN * 64 * (F32 ? 4 : 16);
-    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32>;
+    constexpr int CS = z2_cell_bytes<F32, X3>(CI);
+    constexpr int lds = (X3 ? 1 : 2) * 65 * 17 * CS + NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32, X3>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -669,11 +744,12 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     return D3D_OK;
 }
 
-template <int CI, bool F32 = false>
+template <int CI, bool F32 = false, bool X3 = false>
 static int launch_tz(const Z2Params& p, hipStream_t stream) {
-    constexpr int CS = F32 ? CI * 4 + 16 : CI * 2 + (CI > 8 ? 16 : 0);
-    const int lds = 2 * 33 * 9 * CS + frag_base2(CI, 4, F32) * 64 * (F32 ? 4 : 16);
-    auto kern = convt2d_zs_bf16_kernel<CI, F32>;
+    constexpr int CS = z2_cell_bytes<F32, X3>(CI);
+    constexpr int lds = (X3 && CI > 8 ? 1 : 2) * 33 * 9 * CS + frag_base2(CI, 4, F32) * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = convt2d_zs_bf16_kernel<CI, F32, X3>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -765,23 +841,32 @@ extern "C" int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2
     return launch_z2<8, 1, 4, false, true>(p, st);
 }
 
-static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+enum { PREC_BF16 = 0, PREC_F32 = 1, PREC_X3 = 2 };   // operand format of the stride-2 / transposed tile kernels
+
+static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+
+extern "C" int d3d_conv2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                         const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                         d3d_stream_t stream) {
+    return conv2d_k3s2_zs(PREC_X3, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+}
 
 extern "C" int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                        d3d_stream_t stream) {
-    return conv2d_k3s2_zs(false, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+    return conv2d_k3s2_zs(PREC_BF16, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
 extern "C" int d3d_conv2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
                                       const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                       d3d_stream_t stream) {
-    return conv2d_k3s2_zs(true, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+    return conv2d_k3s2_zs(PREC_F32, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
-static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    const bool f32 = prec == PREC_F32;
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
@@ -789,7 +874,7 @@ static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const 
     // (two 65 x 17 patches must fit the LDS: bf16 cells up to C_in = 16, fp32 cells C_in = 8)
     if ((Ci != 8 && (Ci != 16 || f32)) || Co > 32 || Wo % 4 != 0) {
         set_error("d3d_conv2d_k3s2_zs_%s: C_in = %d (8%s), C_out = %d (<= 32), output width %d (multiple of 4) not taken",
-                  f32 ? "f32" : "bf16", Ci, f32 ? "" : " | 16", Co, Wo);
+                  f32 ? "f32" : prec == PREC_X3 ? "bf16x3" : "bf16", Ci, f32 ? "" : " | 16", Co, Wo);
         return D3D_ERR_UNSUPPORTED;
     }
     Z2Params p = {};
@@ -797,29 +882,40 @@ static int conv2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const 
     p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
     if (f32) return Co > 16 ? launch_s2z<8, 2, true>(p, st) : launch_s2z<8, 1, true>(p, st);
+    if (prec == PREC_X3) {
+        if (Co > 16) return Ci == 8 ? launch_s2z<8, 2, false, true>(p, st) : launch_s2z<16, 2, false, true>(p, st);
+        return Ci == 8 ? launch_s2z<8, 1, false, true>(p, st) : launch_s2z<16, 1, false, true>(p, st);
+    }
     if (Co > 16) return Ci == 8 ? launch_s2z<8, 2>(p, st) : launch_s2z<16, 2>(p, st);
     return Ci == 8 ? launch_s2z<8, 1>(p, st) : launch_s2z<16, 1>(p, st);
 }
 
-static int convtranspose2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift,
+static int convtranspose2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift,
                                    const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                    d3d_stream_t stream);
+
+extern "C" int d3d_convtranspose2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                  const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
+                                                  float* out, d3d_stream_t stream) {
+    return convtranspose2d_k3s2_zs(PREC_X3, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+}
 
 extern "C" int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                                 const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                                 float* out, d3d_stream_t stream) {
-    return convtranspose2d_k3s2_zs(false, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+    return convtranspose2d_k3s2_zs(PREC_BF16, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
 extern "C" int d3d_convtranspose2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
                                                const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                                float* out, d3d_stream_t stream) {
-    return convtranspose2d_k3s2_zs(true, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
+    return convtranspose2d_k3s2_zs(PREC_F32, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
-static int convtranspose2d_k3s2_zs(bool f32, const float* in, const void* wpacked, const float* scale, const float* shift,
+static int convtranspose2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift,
                                    const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                    d3d_stream_t stream) {
+    const bool f32 = prec == PREC_F32;
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
@@ -832,6 +928,8 @@ static int convtranspose2d_k3s2_zs(bool f32, const float* in, const void* wpacke
     p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
     if (f32) return Ci == 8 ? launch_tz<8, true>(p, st) : Ci == 16 ? launch_tz<16, true>(p, st) : launch_tz<32, true>(p, st);
+    if (prec == PREC_X3)
+        return Ci == 8 ? launch_tz<8, false, true>(p, st) : Ci == 16 ? launch_tz<16, false, true>(p, st) : launch_tz<32, false, true>(p, st);
     return Ci == 8 ? launch_tz<8>(p, st) : Ci == 16 ? launch_tz<16>(p, st) : launch_tz<32>(p, st);
 }
 

@@ -723,8 +723,13 @@ def _pack_z2_bf16x3(w):
     return torch.stack([_pack_z2_bf16(part) for part in _split3_bf16(w)]).contiguous()
 
 
+def _pack_t2d_bf16x3(w):
+    """nn.ConvTranspose2d weight [Ci,Co,3,3] -> the B operands of d3d_convtranspose2d_k3s2_zs_bf16x3: [hi | mid | lo] x _pack_t2d_bf16."""
+    return torch.stack([_pack_t2d_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
 def _z2_fp32_entry():
-    """fp32-mode flavour of the stride-1 tile kernel: "x3" (three-way bf16 split, the default) | "f32" (v_mfma_f32_16x16x4_f32)."""
+    """fp32-mode flavour of the 2-D tile kernels: "x3" (three-way bf16 split, the default) | "f32" (v_mfma_f32_16x16x4_f32)."""
     return "f32" if _os.environ.get("D3D_CONV2D_FP32", "x3") == "f32" else "x3"
 
 
@@ -781,15 +786,20 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     Co = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     bf16 = conv_precision() == "bf16"
-    if Ci not in ((8, 16) if bf16 else (8,)) or Co > 32 or Wo % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+    x3 = not bf16 and _z2_fp32_entry() == "x3"
+    if Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16) if bf16 else derived_weight(weight, "z2f32", _pack_z2_f32)
+    if bf16:
+        fn, wp = _lib.load().d3d_conv2d_k3s2_zs_bf16, derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    elif x3:
+        fn, wp = _lib.load().d3d_conv2d_k3s2_zs_bf16x3, derived_weight(weight, "z2bf16x3", _pack_z2_bf16x3)
+    else:
+        fn, wp = _lib.load().d3d_conv2d_k3s2_zs_f32, derived_weight(weight, "z2f32", _pack_z2_f32)
     out = torch.empty((Co, Ho, Wo), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape mismatch")
-    fn = _lib.load().d3d_conv2d_k3s2_zs_bf16 if bf16 else _lib.load().d3d_conv2d_k3s2_zs_f32
     rc = fn(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
             int(act), int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
@@ -844,12 +854,15 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
         return None
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    bf16 = conv_precision() == "bf16"
-    wp = derived_weight(weight, "t2dbf16", _pack_t2d_bf16) if bf16 else derived_weight(weight, "t2df32", _pack_t2d_f32)
+    if conv_precision() == "bf16":
+        fn, wp = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16, derived_weight(weight, "t2dbf16", _pack_t2d_bf16)
+    elif _z2_fp32_entry() == "x3":
+        fn, wp = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16x3, derived_weight(weight, "t2dbf16x3", _pack_t2d_bf16x3)
+    else:
+        fn, wp = _lib.load().d3d_convtranspose2d_k3s2_zs_f32, derived_weight(weight, "t2df32", _pack_t2d_f32)
     out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     if skip is not None and skip.shape != out.shape:
         raise ValueError("skip shape mismatch")
-    fn = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16 if bf16 else _lib.load().d3d_convtranspose2d_k3s2_zs_f32
     rc = fn(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
             int(act), int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:

@@ -305,6 +305,15 @@ int d3d_conv2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* sc
 int d3d_convtranspose2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
                                     const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                     d3d_stream_t stream);
+/* The two layers above with fp32 accuracy from three-way bf16 splits of both operands (see d3d_conv2d_k3_zs_bf16x3; wpacked:
+ * the three bf16 packings of hi | mid | lo one after the other, ops._pack_z2_bf16x3 / ops._pack_t2d_bf16x3); shapes as the
+ * *_zs_bf16 forms (stride 2: Ci 8 | 16; transposed: Ci 8 | 16 | 32, Co <= 16). */
+int d3d_conv2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                              int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+int d3d_convtranspose2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                       const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
+                                       float* out, d3d_stream_t stream);
+
 
 /* ---- channel-last bf16 activations between the layers of a CostRegNet (bf16 mode, BASELINE config 3) ------------------
  * "CL" volume: bf16 [D][H][W][C].  The matrix-core kernels round their operands to bf16 when they stage them, so a layer

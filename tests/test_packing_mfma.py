@@ -162,6 +162,17 @@ def test_pack_conv2d_three_way_bf16_split(Ci, Co):
     assert (np.abs(got - want) <= 2.0 ** -22 * scale).all()
 
 
+def test_pack_convtranspose2d_three_way_split_is_three_bf16_packings():
+    """ops._pack_t2d_bf16x3: [hi | mid | lo] x _pack_t2d_bf16, and the parts add up to the fp32 weight."""
+    rng = np.random.default_rng(5)
+    w = torch.from_numpy((rng.standard_normal((16, 8, 3, 3)) * np.exp(rng.uniform(-4, 4, (16, 8, 3, 3)))).astype(np.float32))
+    frag = ops._pack_t2d_bf16x3(w)
+    parts = ops._split3_bf16(w)
+    assert frag.shape[0] == 3 and torch.equal(parts[0] + parts[1] + parts[2], w)
+    for s_, part in enumerate(parts):
+        assert torch.equal(frag[s_], ops._pack_t2d_bf16(part))
+
+
 @pytest.mark.parametrize("Ci,Co,packer,kblock", [(16, 8, "_pack_t2d_bf16", 32), (8, 1, "_pack_t2d_bf16", 32), (32, 16, "_pack_t2d_f32", 4),
                                                   (8, 1, "_pack_t2d_f32", 4)])
 def test_pack_convtranspose2d_parity_classes(Ci, Co, packer, kblock):

@@ -1466,8 +1466,11 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
         assert float((fused[k] - plain[k]).abs().max()) <= 2e-5 * max(1.0, float(plain[k].abs().max()))
 
 
-def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle):
-    """d3d_conv2d_k3s2_zs_f32 / d3d_convtranspose2d_k3s2_zs_f32: exact fp32 operands, against the oracle without rounding."""
+@pytest.mark.parametrize("flavour", ["x3", "f32"])
+def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle, monkeypatch, flavour):
+    """d3d_conv2d_k3s2_zs_bf16x3 / d3d_convtranspose2d_k3s2_zs_bf16x3 (three-way bf16 splits, the default of fp32 mode) and the
+    _f32 forms (fp32 instruction): against the oracle without rounding of the operands."""
+    monkeypatch.setenv("D3D_CONV2D_FP32", flavour)
     rng = np.random.default_rng(12)
     ops.set_conv_precision("fp32")
     try:
@@ -1478,7 +1481,14 @@ def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle):
             want = np.maximum(oracle.conv2d_k3(x, w, None, stride=2) + b[:, None, None], 0)
             got = ops.conv2d_s2_zs(dev(x), dev(w), None, dev(b), None, 1)
             assert got is not None and np.abs(host(got) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
-        assert ops.conv2d_s2_zs(dev(np.zeros((16, 8, 16), np.float32)), dev(np.zeros((8, 16, 3, 3), np.float32))) is None
+        if flavour == "f32":
+            assert ops.conv2d_s2_zs(dev(np.zeros((16, 8, 16), np.float32)), dev(np.zeros((8, 16, 3, 3), np.float32))) is None
+        else:   # split cells of 16 channels fit
+            x = rng.standard_normal((16, 21, 72)).astype(np.float32)
+            w = (0.1 * rng.standard_normal((32, 16, 3, 3))).astype(np.float32)
+            want = oracle.conv2d_k3(x, w, None, stride=2)
+            got = ops.conv2d_s2_zs(dev(x), dev(w))
+            assert got is not None and np.abs(host(got) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
         for Ci, Co, H, W in [(16, 8, 9, 36), (8, 1, 17, 68), (32, 16, 5, 8), (16, 8, 40, 132)]:
             x = rng.standard_normal((Ci, H, W)).astype(np.float32)
             w = (0.1 * rng.standard_normal((Ci, Co, 3, 3))).astype(np.float32)
