@@ -123,6 +123,31 @@ __global__ __launch_bounds__(256) void conv1x1_context_kernel(const float* __res
     for (int co = 0; co < CO; ++co) *reinterpret_cast<f4*>(out + co * plane + o) = acc[co];
 }
 
+// A bias b added to the INPUT of a zero-padded 3 x 3 convolution reaches output pixel p through the taps whose source lies inside
+// the image: sum of taps[co][ky][kx] over them (taps = W . b).  In the interior that is the constant sum the caller adds as an
+// ordinary bias; on the one-pixel border this kernel takes the outside taps back out.  One thread per (channel, border pixel).
+__global__ __launch_bounds__(256) void conv3x3_bias_border_kernel(float* __restrict__ out, const float* __restrict__ taps, int Co,
+                                                                  int H, int W) {
+    const int per = 2 * W + 2 * max(H - 2, 0);
+    const int i = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
+    if (i >= per) return;
+    int y, x;
+    if (i < W) { y = 0; x = i; }
+    else if (i < 2 * W) { y = H - 1; x = i - W; }
+    else { const int j = i - 2 * W; y = 1 + (j >> 1); x = (j & 1) ? W - 1 : 0; }
+    if (H == 1 && i >= W) return;                       // a single row is its own top and bottom
+    if (W == 1 && i >= 2 * W && (i & 1)) return;        // a single column its own left and right
+    float miss = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sy = y + ky - 1, sx = x + kx - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) miss += taps[(co * 3 + ky) * 3 + kx];
+        }
+    out[((size_t)co * H + y) * W + x] -= miss;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -164,5 +189,14 @@ extern "C" int d3d_conv1x1_context(const float* f, int Ci, const float* weight, 
     else if (Ci == 16) hipLaunchKernelGGL((conv1x1_context_kernel<16, 8>), grid, dim3(256), 0, st, f, weight, a, Ha, Wa, b, Hb, Wb, H, W, out);
     else hipLaunchKernelGGL((conv1x1_context_kernel<32, 8>), grid, dim3(256), 0, st, f, weight, a, Ha, Wa, b, Hb, Wb, H, W, out);
     D3D_LAUNCH_CHECK("conv1x1_context_kernel launch");
+    return D3D_OK;
+}
+
+extern "C" int d3d_conv3x3_bias_border(float* out, const float* taps, int Co, int H, int W, d3d_stream_t stream) {
+    D3D_REQUIRE(out && taps, "null pointer");
+    D3D_REQUIRE(Co > 0 && Co <= 65535 && H > 0 && W > 0, "bad dims Co=%d H=%d W=%d", Co, H, W);
+    const int per = 2 * W + 2 * (H > 2 ? H - 2 : 0);
+    hipLaunchKernelGGL(conv3x3_bias_border_kernel, dim3(ceil_div(per, 256), Co), dim3(256), 0, (hipStream_t)stream, out, taps, Co, H, W);
+    D3D_LAUNCH_CHECK("conv3x3_bias_border_kernel launch");
     return D3D_OK;
 }

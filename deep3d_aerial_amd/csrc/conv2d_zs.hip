@@ -546,22 +546,27 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
 // ---- transposed, k = 3, stride 2, pad 1, output_pad 1 (adamvs.py:413-417 upconv1 16 -> 8 with the skip before the ReLU, upconv2d
 // 8 -> 1): four per-parity dense convolutions over one staged 33 x 9 input patch (32 x 8 input pixels = 64 x 16 outputs per
 // step); the two column parities of an output row are interleaved in registers, a lane stores 8 consecutive pixels.
-constexpr int ntaps2(int py, int px) { return (1 + py) * (1 + px); }
-constexpr int nkb2(int CI, int py, int px, bool f32 = false) { return f32 ? ntaps2(py, px) * CI / 4 : (ntaps2(py, px) * CI + 31) / 32; }
-constexpr int frag_base2(int CI, int c, bool f32 = false) {
+// K4: ConvTranspose2d(k 4, stride 2, pad 1) -> [Co,2H,2W] on the same scheme: every parity class has 2 x 2 taps, output
+// (2i + p) reads inputs i - 1 + p + d, d = 0 | 1 (kernel index 3 - p - 2 d), so the patch carries a halo on both sides (34 x 10).
+// conv3x3(nearest_x2(f)) is such a layer with summed weights (ops.upsampled_conv_weight): the FPN output level.
+constexpr int ntaps2(int py, int px, bool k4 = false) { return k4 ? 4 : (1 + py) * (1 + px); }
+constexpr int nkb2(int CI, int py, int px, bool f32 = false, bool k4 = false) {
+    return f32 ? ntaps2(py, px, k4) * CI / 4 : (ntaps2(py, px, k4) * CI + 31) / 32;
+}
+constexpr int frag_base2(int CI, int c, bool f32 = false, bool k4 = false) {
     int s = 0;
-    for (int q = 0; q < c; ++q) s += nkb2(CI, q >> 1, q & 1, f32);
+    for (int q = 0; q < c; ++q) s += nkb2(CI, q >> 1, q & 1, f32, k4);
     return s;
 }
 
-template <int CI, bool F32 = false, bool X3 = false>
+template <int CI, bool F32 = false, bool X3 = false, bool K4 = false>
 __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
-    static_assert(!(F32 && X3), "one operand format");
-    constexpr int MG = 2, TXI = 16 * MG, PXI = TXI + 1, PYI = TYZ + 1;
+    static_assert(!(F32 && X3) && (!K4 || !F32), "one operand format; the k = 4 form has bf16 / split operands");
+    constexpr int MG = 2, TXI = 16 * MG, PXI = TXI + (K4 ? 2 : 1), PYI = TYZ + (K4 ? 2 : 1), ORG = K4 ? 1 : 0;
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
-    constexpr int NFRAG = frag_base2(CI, 4, F32);
+    constexpr int NFRAG = frag_base2(CI, 4, F32, K4);
     constexpr int NBUF = X3 && CI > 8 ? 1 : 2;   // (split cells of 16 | 32 channels: one patch buffer, more workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
@@ -590,8 +595,8 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
             const int task = tid + r * NTZ;
             const int pix = task / G, g = task - pix * G;
             const int py = pix / PXI, px = pix - py * PXI;
-            const int gx = ix0 + px, gy = ty * TYZ + py;
-            const bool ok = task < NTASK && gx < W && gy < H;
+            const int gx = ix0 + px - ORG, gy = ty * TYZ + py - ORG;
+            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const float* __restrict__ src = p.in + (size_t)(8 * g) * plane + (ok ? (size_t)gy * W + gx : 0);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -632,8 +637,8 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         asm volatile("" : "+v"(kgroup));
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
-            const int NKB = nkb2(CI, PY, px, F32);
-            const int FB = frag_base2(CI, PY * 2 + px, F32);
+            const int NKB = nkb2(CI, PY, px, F32, K4);
+            const int FB = frag_base2(CI, PY * 2 + px, F32, K4);
             if constexpr (F32) {
                 const float* wf = reinterpret_cast<const float*>(wlds);
 #pragma unroll
@@ -654,8 +659,8 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
             for (int kb = 0; kb < NKB; ++kb) {
                 const int k0 = 32 * kb + 8 * kgroup;
                 const int t = k0 / CI, c = k0 % CI;
-                const bool real = t < ntaps2(PY, px);
-                const int dx = real ? t % (1 + px) : 0, dy = real ? t / (1 + px) : 0;
+                const bool real = t < ntaps2(PY, px, K4);
+                const int dx = !real ? 0 : K4 ? (t & 1) + px : t % (1 + px), dy = !real ? 0 : K4 ? (t >> 1) + PY : t / (1 + px);
                 const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
                 if constexpr (X3) {
                     bf16x8 bw[3];
@@ -744,12 +749,13 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     return D3D_OK;
 }
 
-template <int CI, bool F32 = false, bool X3 = false>
+template <int CI, bool F32 = false, bool X3 = false, bool K4 = false>
 static int launch_tz(const Z2Params& p, hipStream_t stream) {
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
-    constexpr int lds = (X3 && CI > 8 ? 1 : 2) * 33 * 9 * CS + frag_base2(CI, 4, F32) * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
+    constexpr int lds = (X3 && CI > 8 ? 1 : 2) * (K4 ? 34 * 10 : 33 * 9) * CS +
+                        frag_base2(CI, 4, F32, K4) * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = convt2d_zs_bf16_kernel<CI, F32, X3>;
+    auto kern = convt2d_zs_bf16_kernel<CI, F32, X3, K4>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
@@ -893,6 +899,24 @@ static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const 
 static int convtranspose2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift,
                                    const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                    d3d_stream_t stream);
+
+extern "C" int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                  const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
+                                                  float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    if ((Ci != 8 && Ci != 16 && Ci != 32) || Co > 16 || W % 4 != 0) {
+        set_error("d3d_convtranspose2d_k4s2_zs_bf16x3: C_in = %d (8 | 16 | 32), C_out = %d (<= 16), W = %d (multiple of 4) not taken", Ci, Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    return Ci == 8 ? launch_tz<8, false, true, true>(p, st) : Ci == 16 ? launch_tz<16, false, true, true>(p, st)
+                                                                         : launch_tz<32, false, true, true>(p, st);
+}
 
 extern "C" int d3d_convtranspose2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
                                                   const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,

@@ -275,6 +275,59 @@ def lateral_upsample_add(conv, x, coarse):
     return feature_conv(conv, x, skip=F.interpolate(coarse, scale_factor=2, mode="nearest"))
 
 
+def _fpn_weights(lateral, head):
+    """Composite operands of fpn_output (host-side weight preparation, cached per parameter version)."""
+    w1 = lateral.weight
+    tag = "_%d_%d" % (w1.data_ptr(), w1._version) + ("" if lateral.bias is None else "_%d_%d" % (lateral.bias.data_ptr(), lateral.bias._version))
+
+    def comp(w3):   # (W3 . W1): a 3x3 convolution straight from the lateral's input channels
+        return torch.einsum("omyx,mc->ocyx", w3.double(), w1.detach().double().reshape(w1.shape[0], -1)).float()
+
+    def bias_taps(w3):   # what the lateral bias contributes through each tap: [Co,3,3]
+        return torch.einsum("omyx,m->oyx", w3.double(), lateral.bias.detach().double()).float()
+
+    wt = ops.derived_weight(head.weight, "fpn_up", ops.upsampled_conv_weight)
+    wb = ops.derived_weight(head.weight, "fpn_lat" + tag, comp)
+    bt = None if lateral.bias is None else ops.derived_weight(head.weight, "fpn_bias" + tag, bias_taps)
+    return wt, wb, bt
+
+
+def fpn_output(lateral, x, coarse, head):
+    """`head(F.interpolate(coarse, x2, nearest) + lateral(x))` (module.py:745-747 of the reference) without the wide tensor at
+    the output resolution.  The layer is linear in its input: head(up(coarse)) is a ConvTranspose2d(k 4, s 2, p 1) of
+    `coarse` with summed weights, head(lateral(x)) one 3x3 convolution of x with the composite weights W3 . W1, and the
+    lateral bias reaches the output through the taps that lie inside the image (a constant, corrected on the one-pixel
+    border).  Falls back to the two-kernel path for shapes the tile kernels do not take."""
+    Co, Cm = head.out_channels, head.in_channels
+    if (lateral.kernel_size == (1, 1) and lateral.groups == 1 and head.kernel_size == (3, 3) and head.padding == (1, 1)
+            and head.stride == (1, 1) and head.dilation == (1, 1) and head.groups == 1 and x.is_cuda and x.dtype == torch.float32
+            and x.shape[1] in (8, 16) and Cm == 32 and Co <= 16 and coarse.shape[1] == Cm and x.shape[3] % 8 == 0
+            and x.shape[2] == 2 * coarse.shape[2] and x.shape[3] == 2 * coarse.shape[3] and _feature_precision_is_fp32()
+            and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen" and os.environ.get("D3D_FPN_SPLIT", "1") != "0"):
+        wt, wb, bt = _fpn_weights(lateral, head)
+        bsum = None if bt is None else ops.derived_weight(head.weight, "fpn_bias_sum" + str(bt.data_ptr()), lambda _w: bt.sum((1, 2)))
+        bias = head.bias if bt is None else bsum if head.bias is None else bsum + head.bias
+        outs = []
+        with _feature_precision():
+            for b in range(x.shape[0]):
+                lat = ops.conv2d_zs(x[b].contiguous(), wb, None, bias)
+                if lat is None:
+                    break
+                if bt is not None:   # taps outside the image carry no bias: the one-pixel border
+                    ops.conv3x3_bias_border_(lat, bt)
+                y = ops.convtranspose2d_k4_zs(coarse[b].contiguous(), wt, None, None, lat)
+                if y is None:
+                    break
+                outs.append(y)
+            else:
+                return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+    return feature_conv(head, lateral_upsample_add(lateral, x, coarse))
+
+
+def _feature_precision_is_fp32():
+    return os.environ.get("D3D_FEATURE_PRECISION", "fp32") != "follow" or ops.conv_precision() != "bf16"
+
+
 class Conv2d(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
                  **kwargs):
@@ -373,6 +426,5 @@ class FeatureNet_mvsnet(nn.Module):
         else:
             f = lateral_upsample_add(self.inner1, c1, c2)
             out["stage2"] = feature_conv(self.out2, f)
-            f = lateral_upsample_add(self.inner2, c0, f)
-            out["stage3"] = feature_conv(self.out3, f)
+            out["stage3"] = fpn_output(self.inner2, c0, f, self.out3)
         return out

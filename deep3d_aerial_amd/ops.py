@@ -709,6 +709,17 @@ def conv1x1_context(f, weight, a, b):
     return out
 
 
+def conv3x3_bias_border_(out, taps):
+    """In place: out [Co,H,W] -= the taps [Co,3,3] whose source pixel lies outside the image, on the one-pixel border
+    (d3d_conv3x3_bias_border)."""
+    Co, H, W = out.shape
+    if tuple(taps.shape) != (Co, 3, 3):
+        raise ValueError("taps must be [%d,3,3]" % Co)
+    rc = _lib.load().d3d_conv3x3_bias_border(_chk(out, "out", 3), _chk(taps, "taps"), Co, H, W, _stream())
+    _lib.check(rc, "d3d_conv3x3_bias_border")
+    return out
+
+
 def _split3_bf16(w):
     """fp32 tensor -> its exact three-way bf16 split (hi, mid, lo as fp32 tensors; hi + mid + lo == w in fp32)."""
     w = w.to(torch.float32)
@@ -726,6 +737,59 @@ def _pack_z2_bf16x3(w):
 def _pack_t2d_bf16x3(w):
     """nn.ConvTranspose2d weight [Ci,Co,3,3] -> the B operands of d3d_convtranspose2d_k3s2_zs_bf16x3: [hi | mid | lo] x _pack_t2d_bf16."""
     return torch.stack([_pack_t2d_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
+def _pack_t2d_k4_bf16(w):
+    """nn.ConvTranspose2d weight [Ci,Co,4,4] (stride 2, padding 1) -> B operands of the k = 4 transposed tile kernel: per output
+    parity class (py,px), order py*2 + px, taps (dy,dx) in {0,1}^2 dy-major; output 2i + p reads input i - 1 + p + d through
+    kernel index 3 - p - 2d.  K = (tap, ci), 16 output columns; [K block][lane][8] (bf16 bits)."""
+    Ci, Co = w.shape[0], w.shape[1]
+    parts = []
+    for c in range(4):
+        py, px = c >> 1, c & 1
+        K = 4 * Ci
+        nkb = (K + 31) // 32
+        b = torch.zeros((nkb * 32, 16), dtype=torch.float32, device=w.device)
+        for t, (dy, dx) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+            b[t * Ci:(t + 1) * Ci, :Co] = w[:, :, 3 - py - 2 * dy, 3 - px - 2 * dx]
+        b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)                 # [kb][kgroup][n][j]
+        parts.append(b.reshape(nkb * 64, 8))
+    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
+def _pack_t2d_k4_bf16x3(w):
+    return torch.stack([_pack_t2d_k4_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
+def upsampled_conv_weight(w3):
+    """Conv2d weight [Co,Ci,3,3] (padding 1) -> the ConvTranspose2d weight [Ci,Co,4,4] (stride 2, padding 1) with
+    conv_transpose2d(f, .) == conv2d(nearest_x2(f), w3): the three taps of an output pixel along an axis fall on two cells
+    of f, and the weights of taps sharing a cell add (kernel index 3: tap 0; 1: taps 1 + 2; 0: tap 2; 2: taps 0 + 1)."""
+    w = w3.detach().to(torch.float64)
+    rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], 2)          # [Co,Ci,4(ky),3]
+    full = torch.stack([rows[..., 2], rows[..., 1] + rows[..., 2], rows[..., 0] + rows[..., 1], rows[..., 0]], 3)   # [Co,Ci,4,4]
+    return full.permute(1, 0, 2, 3).to(torch.float32).contiguous()
+
+
+def convtranspose2d_k4_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=False):
+    """ConvTranspose2d(k 4, stride 2, pad 1): x [Ci,H,W], weight [Ci,Co,4,4] -> [Co,2H,2W] on the transposed tile kernel with
+    split operands (fp32 accuracy; d3d_convtranspose2d_k4s2_zs_bf16x3); None for shapes it does not take."""
+    Ci, H, W = x.shape
+    Co = weight.shape[1]
+    if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or tuple(weight.shape) != (Ci, Co, 4, 4) \
+            or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+        return None
+    wp = derived_weight(weight, "t2dk4x3", _pack_t2d_k4_bf16x3)
+    out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape mismatch")
+    rc = _lib.load().d3d_convtranspose2d_k4s2_zs_bf16x3(
+        _chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), int(act),
+        int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_convtranspose2d_k4s2_zs_bf16x3")
+    return out
 
 
 def _z2_fp32_entry():

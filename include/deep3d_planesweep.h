@@ -285,6 +285,10 @@ int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2, int C2, c
  * convolution commutes with the resize), so neither the upsampled branches nor the concat reach HBM.
  * Ci == Co in 8 | 16 | 32, W % 4 == 0, 3 Wa <= W, 3 Wb <= W; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
 int d3d_avgpool2d_4_8(const float* in, int C, int H, int W, float* out4, float* out8, d3d_stream_t stream);
+/* out [Co,H,W] -= sum over the 3x3 taps whose source pixel lies OUTSIDE the image of taps[Co,3,3]: the border correction of a
+ * bias that was added to the input of a zero-padded 3x3 convolution and folded into the layer's constant (module.fpn_output:
+ * the lateral bias of the last FPN level, module.py:745-747 of the reference).  In place, border pixels only. */
+int d3d_conv3x3_bias_border(float* out, const float* taps, int Co, int H, int W, d3d_stream_t stream);
 int d3d_conv1x1_context(const float* f, int Ci, const float* weight, const float* a, int Ha, int Wa, const float* b, int Hb,
                         int Wb, int Co, int H, int W, float* out, d3d_stream_t stream);
 
@@ -311,6 +315,15 @@ int d3d_convtranspose2d_k3s2_zs_f32(const float* in, const void* wpacked, const 
 int d3d_conv2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                               int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
 int d3d_convtranspose2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                       const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
+                                       float* out, d3d_stream_t stream);
+
+/* ConvTranspose2d(kernel 4, stride 2, padding 1): in [Ci,H,W] -> out [Co,2H,2W], on the transposed tile kernel with split
+ * operands (every output parity class has 2 x 2 taps; the patch carries a halo on both sides).  conv3x3(nearest_x2(f)) -- the
+ * input side of the last FPN level, module.py:745-747 of the reference -- is this layer with summed weights
+ * (ops.upsampled_conv_weight), so the upsampled tensor is never formed.  wpacked: ops._pack_t2d_k4_bf16x3; act 0 | 1, skip
+ * [Co,2H,2W] or NULL as in the k = 3 form; Ci 8 | 16 | 32, Co <= 16, W % 4 == 0; D3D_ERR_UNSUPPORTED otherwise. */
+int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                        float* out, d3d_stream_t stream);
 

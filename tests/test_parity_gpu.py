@@ -1466,6 +1466,51 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
         assert float((fused[k] - plain[k]).abs().max()) <= 2e-5 * max(1.0, float(plain[k].abs().max()))
 
 
+@pytest.mark.parametrize("Ci,Co,H,W", [(32, 8, 9, 12), (32, 16, 20, 36), (16, 8, 33, 64), (8, 1, 5, 8), (32, 8, 70, 132)])
+def test_convtranspose2d_k4_tile_kernel(ops, Ci, Co, H, W):
+    """d3d_convtranspose2d_k4s2_zs_bf16x3 against torch's ConvTranspose2d(k 4, stride 2, pad 1) in float64, with the skip and ReLU
+    epilogues; and ops.upsampled_conv_weight: conv3x3(nearest_x2(f)) as such a layer."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(Ci + Co + H)
+    rn = lambda *s_: torch.randn(*s_, device="cuda", generator=g)
+    x, w, b, sk = rn(Ci, H, W), rn(Ci, Co, 4, 4) * 0.1, rn(Co), rn(Co, 2 * H, 2 * W)
+    want = F.conv_transpose2d(x.double()[None], w.double(), b.double(), stride=2, padding=1)[0]
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    got = ops.convtranspose2d_k4_zs(x, w, None, b, sk, act=1, skip_after_act=False)
+    assert got is not None and float((got.double() - torch.relu(want + sk.double())).abs().max()) <= tol
+    got = ops.convtranspose2d_k4_zs(x, w, None, b, sk, act=1, skip_after_act=True)
+    assert float((got.double() - (torch.relu(want) + sk.double())).abs().max()) <= tol
+    w3 = rn(Co, Ci, 3, 3) * 0.1
+    want = F.conv2d(F.interpolate(x.double()[None], scale_factor=2, mode="nearest"), w3.double(), padding=1)[0]
+    got = ops.convtranspose2d_k4_zs(x, ops.upsampled_conv_weight(w3))
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("Cl,Co,H,W,bias", [(8, 8, 16, 24, True), (8, 8, 70, 136, True), (16, 16, 18, 40, True), (8, 8, 12, 16, False)])
+def test_fpn_output_level_without_the_wide_tensor(ops, monkeypatch, Cl, Co, H, W, bias):
+    """module.fpn_output: head(nearest_x2(coarse) + lateral(x)) (module.py:745-747) as a k = 4 transposed convolution of coarse + one
+    3x3 convolution of x with the composite weights + the border-aware bias, against the layer in float64 and against the
+    two-kernel path."""
+    import torch
+    import torch.nn.functional as F
+    from deep3d_aerial_amd import module as M
+    torch.manual_seed(Cl * 7 + H)
+    lateral = torch.nn.Conv2d(Cl, 32, 1, bias=bias).cuda()
+    head = torch.nn.Conv2d(32, Co, 3, padding=1, bias=False).cuda()
+    x, coarse = torch.randn(2, Cl, H, W, device="cuda"), torch.randn(2, 32, H // 2, W // 2, device="cuda")
+    with torch.no_grad():
+        t = F.interpolate(coarse.double(), scale_factor=2, mode="nearest") + F.conv2d(x.double(), lateral.weight.double(),
+                                                                                         None if not bias else lateral.bias.double())
+        want = F.conv2d(t, head.weight.double(), padding=1)
+        got = M.fpn_output(lateral, x, coarse, head)
+        monkeypatch.setenv("D3D_FPN_SPLIT", "0")
+        two = M.fpn_output(lateral, x, coarse, head)
+    tol = 3e-5 * max(1.0, float(want.abs().max()))
+    assert float((got.double() - want).abs().max()) <= tol
+    assert float((two.double() - want).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("flavour", ["x3", "f32"])
 def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle, monkeypatch, flavour):
     """d3d_conv2d_k3s2_zs_bf16x3 / d3d_convtranspose2d_k3s2_zs_bf16x3 (three-way bf16 splits, the default of fp32 mode) and the
