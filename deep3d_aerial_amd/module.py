@@ -292,7 +292,7 @@ def _fpn_weights(lateral, head):
     return wt, wb, bt
 
 
-def fpn_output(lateral, x, coarse, head):
+def fpn_output(lateral, x, coarse, head, wide=None):
     """`head(F.interpolate(coarse, x2, nearest) + lateral(x))` (module.py:745-747 of the reference) without the wide tensor at
     the output resolution.  The layer is linear in its input: head(up(coarse)) is a ConvTranspose2d(k 4, s 2, p 1) of
     `coarse` with summed weights, head(lateral(x)) one 3x3 convolution of x with the composite weights W3 . W1, and the
@@ -321,7 +321,7 @@ def fpn_output(lateral, x, coarse, head):
                 outs.append(y)
             else:
                 return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
-    return feature_conv(head, lateral_upsample_add(lateral, x, coarse))
+    return feature_conv(head, lateral_upsample_add(lateral, x, coarse) if wide is None else wide)   # wide: the sum, where the caller has it
 
 
 def _feature_precision_is_fp32():
@@ -424,7 +424,7 @@ class FeatureNet_mvsnet(nn.Module):
             f = self.deconv2(c0, f)
             out["stage3"] = feature_conv(self.out3, f)
         else:
-            f = lateral_upsample_add(self.inner1, c1, c2)
-            out["stage2"] = feature_conv(self.out2, f)
+            f = lateral_upsample_add(self.inner1, c1, c2)   # (the coarse input of the last level)
+            out["stage2"] = fpn_output(self.inner1, c1, c2, self.out2, wide=f)
             out["stage3"] = fpn_output(self.inner2, c0, f, self.out3)
         return out
