@@ -559,14 +559,24 @@ constexpr int frag_base2(int CI, int c, bool f32 = false, bool k4 = false) {
     return s;
 }
 
-template <int CI, bool F32 = false, bool X3 = false, bool K4 = false>
+// XF (K4, split operands, C_out <= 8): both column parities of an output row as ONE 16-column tile -- columns 0..7 the channels
+// of the even output column, 8..15 those of the odd one, over the three patch columns m, m + 1, m + 2 the two parities touch
+// (weights zero where a parity does not use a column): K = 2 x 3 x C_in per row parity, 36 instead of 48 MFMAs, 36 instead of
+// 48 KB of weights at C_in = 32 -- with 16-wide tiles the kernel then fits two workgroups per CU.  The odd half reaches the
+// storing lanes with one v_mov_dpp row_ror:8 per register.
+__device__ __forceinline__ float dpp_row_ror8(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+}
+
+template <int CI, bool F32 = false, bool X3 = false, bool K4 = false, bool XF = false>
 __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
-    static_assert(!(F32 && X3) && (!K4 || !F32), "one operand format; the k = 4 form has bf16 / split operands");
-    constexpr int MG = 2, TXI = 16 * MG, PXI = TXI + (K4 ? 2 : 1), PYI = TYZ + (K4 ? 2 : 1), ORG = K4 ? 1 : 0;
+    static_assert(!(F32 && X3) && (!K4 || !F32) && (!XF || (K4 && X3)), "one operand format; the k = 4 form has bf16 / split operands");
+    constexpr int MG = XF ? 1 : 2, TXI = 16 * MG, PXI = TXI + (K4 ? 2 : 1), PYI = TYZ + (K4 ? 2 : 1), ORG = K4 ? 1 : 0;
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
-    constexpr int NFRAG = frag_base2(CI, 4, F32, K4);
+    constexpr int NKBF = (6 * CI + 31) / 32;   // XF: K blocks per row parity
+    constexpr int NFRAG = XF ? 2 * NKBF : frag_base2(CI, 4, F32, K4);
     constexpr int NBUF = X3 && CI > 8 ? 1 : 2;   // (split cells of 16 | 32 channels: one patch buffer, more workgroups per CU)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
@@ -628,6 +638,42 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
 
     auto row = [&](auto pyc, int ty, const unsigned char* buf) {   // output row 2 iy + PY of this wave's input row: both column parities
         constexpr int PY = decltype(pyc)::value;
+        if constexpr (XF) {
+            f4 accf = {0, 0, 0, 0};
+            int kg = lane >> 4;
+            asm volatile("" : "+v"(kg));
+#pragma unroll
+            for (int kb = 0; kb < NKBF; ++kb) {
+                const int k0 = 32 * kb + 8 * kg;
+                const int t = k0 / CI, c = k0 % CI;
+                const bool real = t < 6;
+                const int dxx = real ? t % 3 : 0, dy = real ? t / 3 : 0;
+                const int aoff = ((dy + PY) * PXI + dxx) * CS + (real ? c : 0) * 2;
+                bf16x8 bw[3], a[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    bw[sp] = __builtin_bit_cast(bf16x8, wlds[(sp * NFRAG + PY * NKBF + kb) * 64 + lane]);
+                    a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + aoff + sp * CI * 2));
+                }
+                accf = mfma_split3(a, bw[0], bw[1], bw[2], accf);
+            }
+            f4 oddf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oddf[r] = dpp_row_ror8(accf[r]);   // columns 8..15 -> the lanes of columns 0..7
+            const int iy = ty * TYZ + wave, co = lane & 15;
+            const int ix = ix0 + (lane >> 4) * 4;
+            if (iy >= H || co >= 8 || co >= p.CO || ix >= W) return;
+            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+            const size_t o = (size_t)co * oplane + (size_t)(2 * iy + PY) * OW + 2 * ix;
+            const f4 e = accf * sc + sh, od = oddf * sc + sh;
+            f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
+            if (p.skip && !p.skip_after_act) { lo += *reinterpret_cast<const f4*>(p.skip + o); hi += *reinterpret_cast<const f4*>(p.skip + o + 4); }
+            if (p.act == 1) { lo = __builtin_elementwise_max(lo, (f4){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4){0, 0, 0, 0}); }
+            if (p.skip && p.skip_after_act) { lo = *reinterpret_cast<const f4*>(p.skip + o) + lo; hi = *reinterpret_cast<const f4*>(p.skip + o + 4) + hi; }
+            *reinterpret_cast<f4*>(p.out + o) = lo;
+            *reinterpret_cast<f4*>(p.out + o + 4) = hi;
+            return;
+        }
         f4 acc[2][MG];
 #pragma unroll
         for (int px = 0; px < 2; ++px)
@@ -749,18 +795,19 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     return D3D_OK;
 }
 
-template <int CI, bool F32 = false, bool X3 = false, bool K4 = false>
+template <int CI, bool F32 = false, bool X3 = false, bool K4 = false, bool XF = false>
 static int launch_tz(const Z2Params& p, hipStream_t stream) {
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
-    constexpr int lds = (X3 && CI > 8 ? 1 : 2) * (K4 ? 34 * 10 : 33 * 9) * CS +
-                        frag_base2(CI, 4, F32, K4) * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
+    constexpr int TXI = XF ? 16 : 32;
+    constexpr int NFRAG = XF ? 2 * ((6 * CI + 31) / 32) : frag_base2(CI, 4, F32, K4);
+    constexpr int lds = (X3 && CI > 8 ? 1 : 2) * (K4 ? (TXI + 2) * 10 : 33 * 9) * CS + NFRAG * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = convt2d_zs_bf16_kernel<CI, F32, X3, K4>;
+    auto kern = convt2d_zs_bf16_kernel<CI, F32, X3, K4, XF>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
-    const int gx = ceil_div(p.W, 32), nty = ceil_div(p.H, TYZ);
+    const int gx = ceil_div(p.W, TXI), nty = ceil_div(p.H, TYZ);
     int tper = 8;
     while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
     q.tper = tper;
@@ -914,6 +961,9 @@ extern "C" int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* w
     p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
+    if (Co <= 8)   // both column parities in one tile (wpacked: ops._pack_t2d_k4fold_bf16 x 3)
+        return Ci == 8 ? launch_tz<8, false, true, true, true>(p, st) : Ci == 16 ? launch_tz<16, false, true, true, true>(p, st)
+                                                                                   : launch_tz<32, false, true, true, true>(p, st);
     return Ci == 8 ? launch_tz<8, false, true, true>(p, st) : Ci == 16 ? launch_tz<16, false, true, true>(p, st)
                                                                          : launch_tz<32, false, true, true>(p, st);
 }

@@ -757,8 +757,30 @@ def _pack_t2d_k4_bf16(w):
     return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_t2d_k4fold_bf16(w):
+    """The k = 4 transposed weight [Ci,Co<=8,4,4] with both column parities in one 16-column tile: per row parity py, K =
+    (dy in {0,1}, patch column dxx in {0,1,2}, ci); columns 0..7 = even output column (dxx = dx), 8..15 = odd one (dxx = 1 + dx)."""
+    Ci, Co = w.shape[0], w.shape[1]
+    parts = []
+    for py in range(2):
+        nkb = (6 * Ci + 31) // 32
+        b = torch.zeros((nkb * 32, 16), dtype=torch.float32, device=w.device)
+        for dy in range(2):
+            for dxx in range(3):
+                t = dy * 3 + dxx
+                for px in range(2):
+                    dx = dxx - px
+                    if dx in (0, 1):
+                        b[t * Ci:(t + 1) * Ci, px * 8:px * 8 + Co] = w[:, :, 3 - py - 2 * dy, 3 - px - 2 * dx]
+        b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)
+        parts.append(b.reshape(nkb * 64, 8))
+    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+
+
 def _pack_t2d_k4_bf16x3(w):
-    return torch.stack([_pack_t2d_k4_bf16(part) for part in _split3_bf16(w)]).contiguous()
+    """[hi | mid | lo] x the k = 4 packing d3d_convtranspose2d_k4s2_zs_bf16x3 takes: column-folded for C_out <= 8."""
+    pack = _pack_t2d_k4fold_bf16 if w.shape[1] <= 8 else _pack_t2d_k4_bf16
+    return torch.stack([pack(part) for part in _split3_bf16(w)]).contiguous()
 
 
 def upsampled_conv_weight(w3):

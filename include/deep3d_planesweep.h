@@ -321,7 +321,8 @@ int d3d_convtranspose2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, con
 /* ConvTranspose2d(kernel 4, stride 2, padding 1): in [Ci,H,W] -> out [Co,2H,2W], on the transposed tile kernel with split
  * operands (every output parity class has 2 x 2 taps; the patch carries a halo on both sides).  conv3x3(nearest_x2(f)) -- the
  * input side of the last FPN level, module.py:745-747 of the reference -- is this layer with summed weights
- * (ops.upsampled_conv_weight), so the upsampled tensor is never formed.  wpacked: ops._pack_t2d_k4_bf16x3; act 0 | 1, skip
+ * (ops.upsampled_conv_weight), so the upsampled tensor is never formed.  wpacked: ops._pack_t2d_k4_bf16x3 (for Co <= 8 both
+ * column parities of an output row share one 16-column operand tile: ops._pack_t2d_k4fold_bf16); act 0 | 1, skip
  * [Co,2H,2W] or NULL as in the k = 3 form; Ci 8 | 16 | 32, Co <= 16, W % 4 == 0; D3D_ERR_UNSUPPORTED otherwise. */
 int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
