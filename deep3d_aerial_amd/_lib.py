@@ -57,6 +57,7 @@ SIGNATURES = {
     "d3d_conv2d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k4s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k5s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2_zs_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3_cl_bf16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],

@@ -366,11 +366,13 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
 // ---- stride 2 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1) of the slice regulariser): out (y, x) reads in (2y + k_y - 1, 2x + k_x - 1) --
 // 32 x 8 OUTPUT pixels per step; the staged 65 x 17 patch keeps the even and the odd columns of a row in separate runs, so
 // the 16 pixels of an A operand (input columns 2m + k_x - 1) are 16 consecutive cells.  p.H, p.W: INPUT size.
-template <int CI, int NTN, bool F32 = false, bool X3 = false>
+// KS = 5 (split operands only): the 5 x 5 stride-2 layers of the feature trunks (module.py:666-673, padding 2) on the same scheme --
+// the patch is 2 T + 3 wide / high, tap column k_x reads the even run at m + k_x / 2 (k_x even) or the odd run at m + (k_x - 1) / 2.
+template <int CI, int NTN, bool F32 = false, bool X3 = false, int KS = 3, int MG = 2>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
-    static_assert(!(F32 && X3), "one operand format");
-    constexpr int MG = 2, TXO = 16 * MG, PXI = 2 * TXO + 1, PYI = 2 * TYZ + 1, NEVEN = TXO + 1;
-    constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
+    static_assert(!(F32 && X3) && (KS == 3 || (KS == 5 && X3)), "one operand format; 5 x 5 with split operands only");
+    constexpr int TXO = 16 * MG, PXI = 2 * TXO + KS - 2, PYI = 2 * TYZ + KS - 2, NEVEN = (PXI + 1) / 2, ORG = KS / 2;
+    constexpr int NKB = F32 ? KS * KS * CI / 4 : (KS * KS * CI + 31) / 32;
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
             const int task = tid + r * NTZ;
             const int pix = task / G, g = task - pix * G;
             const int py = pix / PXI, px = pix - py * PXI;
-            const int gx = 2 * xo0 - 1 + px, gy = 2 * ty * TYZ - 1 + py;
+            const int gx = 2 * xo0 - ORG + px, gy = 2 * ty * TYZ - ORG + py;
             const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const float* __restrict__ src = p.in + (size_t)(8 * g) * plane + (ok ? (size_t)gy * W + gx : 0);
 #pragma unroll
@@ -437,9 +439,9 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
     auto a_offset = [&](int kb, int kgroup) {
         const int k0 = 32 * kb + 8 * kgroup;
         const int t = k0 / CI, c = k0 % CI;
-        const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;
-        const int col = kx == 1 ? NEVEN : (kx >> 1);   // even run index m (k_x = 0) | m + 1 (k_x = 2), odd run index m (k_x = 1)
-        return (ky * PXI + col) * CS + (t < 9 ? c : 0) * 2;
+        const int ky = t < KS * KS ? t / KS : 0, kx = t < KS * KS ? t % KS : 0;
+        const int col = (kx & 1) ? NEVEN + (kx >> 1) : (kx >> 1);   // even run index m + k_x / 2, odd run index m + (k_x - 1) / 2
+        return (ky * PXI + col) * CS + (t < KS * KS ? c : 0) * 2;
     };
     const int abase = (2 * wave * PXI + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);
 
@@ -772,19 +774,19 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
     }
 }
 
-template <int CI, int NTN, bool F32 = false, bool X3 = false>
+template <int CI, int NTN, bool F32 = false, bool X3 = false, int KS = 3, int MG = 2>
 static int launch_s2z(const Z2Params& p, hipStream_t stream) {
-    constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
+    constexpr int NKB = F32 ? KS * KS * CI / 4 : (KS * KS * CI + 31) / 32;
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
-    constexpr int lds = (X3 ? 1 : 2) * 65 * 17 * CS + NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
+    constexpr int lds = (X3 ? 1 : 2) * (32 * MG + KS - 2) * (2 * TYZ + KS - 2) * CS + NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32, X3>;
+    auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32, X3, KS, MG>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int Ho = (p.H - 1) / 2 + 1, Wo = (p.W - 1) / 2 + 1;
-    const int gx = ceil_div(Wo, 32), nty = ceil_div(Ho, TYZ);
+    const int gx = ceil_div(Wo, 16 * MG), nty = ceil_div(Ho, TYZ);
     int tper = 8;
     while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
     q.tper = tper;
@@ -898,6 +900,25 @@ enum { PREC_BF16 = 0, PREC_F32 = 1, PREC_X3 = 2 };   // operand format of the st
 
 static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+
+extern "C" int d3d_conv2d_k5s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                         const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
+                                         d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    const int Wo = (W - 1) / 2 + 1;
+    if (!((Ci == 8 && Co <= 16) || (Ci == 16 && Co <= 32)) || Wo % 4 != 0) {
+        set_error("d3d_conv2d_k5s2_zs_bf16x3: C_in = %d, C_out = %d (8 -> <= 16 | 16 -> <= 32), output width %d (multiple of 4) not taken", Ci, Co, Wo);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
+    hipStream_t st = (hipStream_t)stream;
+    if (Ci == 8) return launch_s2z<8, 1, false, true, 5, 1>(p, st);
+    return Co > 16 ? launch_s2z<16, 2, false, true, 5, 1>(p, st) : launch_s2z<16, 1, false, true, 5, 1>(p, st);
+}
 
 extern "C" int d3d_conv2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
                                          const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,

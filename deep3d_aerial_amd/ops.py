@@ -657,7 +657,7 @@ def _pack_z2_bf16(w):
     padded to a multiple of 32, output channels to a multiple of 16; [K block][N tile][lane][8], lane l = column l & 15,
     K rows 8 * (l >> 4) .. + 7 of its block.  int16 bits (bf16)."""
     Co, Ci = w.shape[0], w.shape[1]
-    K = 9 * Ci
+    K = w.shape[2] * w.shape[3] * Ci                                   # (3 x 3; 5 x 5 for d3d_conv2d_k5s2_zs_bf16x3)
     nkb = (K + 31) // 32
     ntn = (max(Co, 16) + 15) // 16
     b = torch.zeros((nkb * 32, ntn * 16), dtype=torch.float32, device=w.device)
@@ -1468,7 +1468,34 @@ def conv2d_same(x, weight, scale=None, shift=None, skip=None, act=0, stride=1):
     Co, Ci = weight.shape[0], weight.shape[1]
     if x.shape[0] != Ci or Co > 64 or not _use_mfma():
         return None
+    if weight.shape[2] == 5 and stride == 2 and conv_precision() != "bf16":
+        y = conv2d_k5s2_zs(x, weight, scale, shift, skip, act)
+        if y is not None:
+            return y
     return conv_fold(x, weight, scale, shift, skip, act, stride, None, True, transposed=False)
+
+
+def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=True):
+    """Conv2d(k 5, stride 2, pad 2) on the stride-2 tile kernel with split operands (fp32 accuracy; the downsampling layers of
+    the feature trunks, d3d_conv2d_k5s2_zs_bf16x3); None for shapes it does not take."""
+    Ci, H, W = x.shape
+    Co = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if (Ci, Co <= 16) != (8, True) and (Ci, Co <= 32) != (16, True) or Wo % 4 or act not in (0, 1) or H * W < 128 * 128 \
+            or tuple(weight.shape) != (Co, Ci, 5, 5) or _z2_fp32_entry() != "x3" or _os.environ.get("D3D_CONV2D_ZS", "1") == "0" \
+            or _os.environ.get("D3D_CONV2D_K5", "1") == "0":
+        return None
+    wp = derived_weight(weight, "z2k5bf16x3", _pack_z2_bf16x3)
+    out = torch.empty((Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape mismatch")
+    rc = _lib.load().d3d_conv2d_k5s2_zs_bf16x3(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"),
+                                               _opt(skip, "skip"), int(act), int(bool(skip_after_act)), Ci, Co, H, W, _chk(out, "out"),
+                                               _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k5s2_zs_bf16x3")
+    return out
 
 
 def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):

@@ -1466,6 +1466,25 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
         assert float((fused[k] - plain[k]).abs().max()) <= 2e-5 * max(1.0, float(plain[k].abs().max()))
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,act", [(8, 16, 128, 136, 1), (8, 16, 131, 256, 0), (16, 32, 130, 200, 1), (16, 16, 129, 144, 1), (8, 8, 256, 64, 1)])
+def test_conv2d_5x5_stride2_tile_kernel(ops, Ci, Co, H, W, act):
+    """d3d_conv2d_k5s2_zs_bf16x3 (the 5 x 5 stride-2 layers of the feature trunks, module.py:666-673) against torch's Conv2d(k 5,
+    stride 2, pad 2) in float64, folded BN + ReLU + skip epilogue."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(Ci + Co + H)
+    rn = lambda *s_: torch.randn(*s_, device="cuda", generator=g)
+    x, w, sc, sh = rn(Ci, H, W), rn(Co, Ci, 5, 5) * 0.05, rn(Co) * 0.5 + 1.0, rn(Co)
+    conv = F.conv2d(x.double()[None], w.double(), stride=2, padding=2)[0] * sc.double()[:, None, None] + sh.double()[:, None, None]
+    sk = rn(*conv.shape)
+    want = (torch.relu(conv) if act else conv) + sk.double()
+    got = ops.conv2d_k5s2_zs(x, w, sc, sh, sk, act)
+    assert got is not None and got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    same = ops.conv2d_same(x, w, sc, sh, sk, act, stride=2)       # the route the feature pyramids take
+    assert float((same.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 @pytest.mark.parametrize("Ci,Co,H,W", [(32, 8, 9, 12), (32, 16, 20, 36), (16, 8, 33, 64), (8, 1, 5, 8), (32, 8, 70, 132)])
 def test_convtranspose2d_k4_tile_kernel(ops, Ci, Co, H, W):
     """d3d_convtranspose2d_k4s2_zs_bf16x3 against torch's ConvTranspose2d(k 4, stride 2, pad 1) in float64, with the skip and ReLU
