@@ -366,7 +366,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
 // ---- stride 2 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1) of the slice regulariser): out (y, x) reads in (2y + k_y - 1, 2x + k_x - 1) --
 // 32 x 8 OUTPUT pixels per step; the staged 65 x 17 patch keeps the even and the odd columns of a row in separate runs, so
 // the 16 pixels of an A operand (input columns 2m + k_x - 1) are 16 consecutive cells.  p.H, p.W: INPUT size.
-// KS = 5 (split operands only): the 5 x 5 stride-2 layers of the feature trunks (module.py:666-673, padding 2) on the same scheme --
+// KS = 5 (split operands only): the 5 x 5 stride-2 layers of the feature trunks (module.py:669, 675, padding 2) on the same scheme --
 // the patch is 2 T + 3 wide / high, tap column k_x reads the even run at m + k_x / 2 (k_x even) or the odd run at m + (k_x - 1) / 2.
 template <int CI, int NTN, bool F32 = false, bool X3 = false, int KS = 3, int MG = 2>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {

@@ -328,7 +328,7 @@ int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, con
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                        float* out, d3d_stream_t stream);
 
-/* Conv2d(kernel 5, stride 2, padding 2) -- the downsampling layers of the feature trunks (module.py:666-673 of the reference) --
+/* Conv2d(kernel 5, stride 2, padding 2) -- the downsampling layers of the feature trunks (module.py:669, 675; adamvs.py:64, 70 of the reference) --
  * on the stride-2 tile kernel with split operands (fp32 accuracy): in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1]; wpacked:
  * ops._pack_z2_bf16x3 of the weight [Co,Ci,5,5] (K = (k_y,k_x,c_in)); scale / shift / skip / act as d3d_conv2d_k3s2_zs_bf16.
  * Ci 8 with Co <= 16 | Ci 16 with Co <= 32, output width % 4 == 0; D3D_ERR_UNSUPPORTED otherwise. */

@@ -1468,7 +1468,7 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
 
 @pytest.mark.parametrize("Ci,Co,H,W,act", [(8, 16, 128, 136, 1), (8, 16, 131, 256, 0), (16, 32, 130, 200, 1), (16, 16, 129, 144, 1), (8, 8, 256, 64, 1)])
 def test_conv2d_5x5_stride2_tile_kernel(ops, Ci, Co, H, W, act):
-    """d3d_conv2d_k5s2_zs_bf16x3 (the 5 x 5 stride-2 layers of the feature trunks, module.py:666-673) against torch's Conv2d(k 5,
+    """d3d_conv2d_k5s2_zs_bf16x3 (the 5 x 5 stride-2 layers of the feature trunks, module.py:669, 675) against torch's Conv2d(k 5,
     stride 2, pad 2) in float64, folded BN + ReLU + skip epilogue."""
     import torch
     import torch.nn.functional as F
