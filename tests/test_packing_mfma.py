@@ -194,3 +194,59 @@ def test_pack_convtranspose2d_parity_classes(Ci, Co, packer, kblock):
         classes[(py, px)] = (B, taps)
     assert base == frag.shape[0]
     assert np.abs(_transposed_from_classes(x, classes, Co, 2) - oracle.convtranspose2d_k3s2(x, w, None)).max() <= 1e-4
+
+
+def test_upsampled_conv_weight_is_a_k4_transposed_convolution():
+    """ops.upsampled_conv_weight: conv2d(nearest_x2(f), w3, padding 1) == conv_transpose2d(f, ., stride 2, padding 1), zero
+    padding included (the input side of module.fpn_output)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    f = torch.randn(1, 5, 6, 7, generator=g, dtype=torch.float64)
+    w3 = torch.randn(4, 5, 3, 3, generator=g)
+    want = F.conv2d(F.interpolate(f, scale_factor=2, mode="nearest"), w3.double(), padding=1)
+    got = F.conv_transpose2d(f, ops.upsampled_conv_weight(w3).double(), stride=2, padding=1)
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("Ci,Co", [(32, 8), (16, 1), (32, 16), (8, 12)])
+def test_pack_convtranspose2d_k4_parity_classes(Ci, Co):
+    """ops._pack_t2d_k4_bf16 (16 columns per parity class) and _pack_t2d_k4fold_bf16 (C_out <= 8: both column parities in one
+    tile over three patch columns) against torch's ConvTranspose2d(k 4, stride 2, padding 1): output 2i + p reads input
+    i - 1 + p + d through kernel index 3 - p - 2d."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(Ci + Co)
+    w = torch.from_numpy(bf16_exact(rng, (Ci, Co, 4, 4)))
+    x = rng.standard_normal((Ci, 3, 5)).astype(np.float32)
+    want = F.conv_transpose2d(torch.from_numpy(x).double()[None], w.double(), stride=2, padding=1)[0].numpy()
+    out = np.zeros((Co, 6, 10))
+    if Co <= 8:
+        frag = ops._pack_t2d_k4fold_bf16(w)
+        nkb = (6 * Ci + 31) // 32
+        assert frag.shape[0] == 2 * nkb * 64
+        for py in range(2):
+            B = dense_from_fragments(frag[py * nkb * 64:(py + 1) * nkb * 64].reshape(nkb, 1, 64, 8), 32)
+            taps = [(dy + py - 1, dxx - 1) for dy in range(2) for dxx in range(3)]      # patch column dxx = input column m - 1 + dxx
+            for px in range(2):
+                out[:, py::2, px::2] = conv_from_B(x, B[:, px * 8:px * 8 + 8], taps, Co, (3, 5))
+    else:
+        frag = ops._pack_t2d_k4_bf16(w)
+        nkb = (4 * Ci + 31) // 32
+        assert frag.shape[0] == 4 * nkb * 64
+        for c in range(4):
+            py, px = c >> 1, c & 1
+            B = dense_from_fragments(frag[c * nkb * 64:(c + 1) * nkb * 64].reshape(nkb, 1, 64, 8), 32)
+            taps = [(dy + py - 1, dx + px - 1) for dy in range(2) for dx in range(2)]
+            out[:, py::2, px::2] = conv_from_B(x, B, taps, Co, (3, 5))
+    assert np.abs(out - want).max() <= 1e-4
+
+
+def test_pack_conv2d_5x5_fragments():
+    """ops._pack_z2_bf16 on a 5 x 5 weight (d3d_conv2d_k5s2_zs_bf16x3): K = (k_y, k_x, c_in) over 25 taps."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(55)
+    w = bf16_exact(rng, (16, 8, 5, 5))
+    x = rng.standard_normal((8, 9, 12)).astype(np.float32)
+    B = dense_from_fragments(ops._pack_z2_bf16(torch.from_numpy(w)), 32)
+    taps = [(ky - 2, kx - 2) for ky in range(5) for kx in range(5)]
+    want = F.conv2d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double(), stride=2, padding=2)[0].numpy()
+    assert np.abs(conv_from_B(x, B, taps, 16, (5, 6), stride=2) - want).max() <= 1e-4
