@@ -47,6 +47,7 @@ struct Z2Params {
     int ep_split;         // act 2: channels below it are multiplied by h
     int skip_after_act;
     int tper;             // tiles per workgroup along y
+    int sub2;             // stride-1 kernel: keep the even rows / columns only = the stride-2 layer (act 0 | 1; out, skip [CO,(H+1)/2,W/2])
 };
 
 __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
@@ -295,6 +296,17 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
                 if (ox >= W) continue;                              // W % 4 == 0: a quad is inside or outside as a whole
                 const size_t o = (size_t)co * plane + (size_t)oy * W + ox;
                 f4 y = acc[mg * NTN + nt] * sc + sh;
+                if (p.sub2) {   // the stride-2 layer of a shape the stride-2 kernel has no room for: three quarters of the tile are dropped
+                    if (oy & 1) continue;
+                    const size_t o2 = ((size_t)co * ((H + 1) >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
+                    float y0 = y[0], y2 = y[2];
+                    if (p.skip && !p.skip_after_act) { y0 += p.skip[o2]; y2 += p.skip[o2 + 1]; }
+                    if (p.act == 1) { y0 = fmaxf(y0, 0.0f); y2 = fmaxf(y2, 0.0f); }
+                    if (p.skip && p.skip_after_act) { y0 = p.skip[o2] + y0; y2 = p.skip[o2 + 1] + y2; }
+                    p.out[o2] = y0;
+                    p.out[o2 + 1] = y2;
+                    continue;
+                }
                 if (p.act == 2) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) y[k] = 1.0f / (1.0f + __expf(-y[k]));
@@ -945,6 +957,16 @@ static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const 
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
     const int Wo = (W - 1) / 2 + 1;
+    if (Ci == 48 && Co <= 48 && W % 4 == 0 && prec != PREC_X3) {
+        // the pair-visibility UNet (adamvs.py:198-238): 48-channel cells leave no room for a stride-2 patch, and at its image
+        // sizes the layer is latency, not work -- the stride-1 tile kernel computes every position and keeps the even ones
+        Z2Params p = {};
+        p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+        p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.sub2 = 1;
+        hipStream_t st = (hipStream_t)stream;
+        if (f32) return Co > 32 ? launch_z2<48, 3, 2, true>(p, st) : Co > 16 ? launch_z2<48, 2, 2, true>(p, st) : launch_z2<48, 1, 2, true>(p, st);
+        return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);
+    }
     // (two 65 x 17 patches must fit the LDS: bf16 cells up to C_in = 16, fp32 cells C_in = 8)
     if ((Ci != 8 && (Ci != 16 || f32)) || Co > 32 || Wo % 4 != 0) {
         set_error("d3d_conv2d_k3s2_zs_%s: C_in = %d (8%s), C_out = %d (<= 32), output width %d (multiple of 4) not taken",

@@ -828,6 +828,13 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     Co = weight.shape[0]
     Ci, bf16 = Ci0 + Ci1, conv_precision() == "bf16"
     ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48)   # 48 -> 48: the pair-visibility UNet
+    if ok and W % 4 and x2 is None and aux1 is None and act in (0, 1) and H * W <= 256 * 256 and Ci0 % 8 == 0:
+        # small images whose width is not a multiple of 4 (the coarsest UNet level, 58 x 86): zero columns on the right are the
+        # layer's own padding, so the padded image gives the same outputs; the extra columns are dropped
+        pw = (-W) % 4
+        y = conv2d_zs(torch.nn.functional.pad(x, (0, pw)), weight, scale, shift,
+                      None if skip is None else torch.nn.functional.pad(skip, (0, pw)), act, skip_after_act=skip_after_act)
+        return None if y is None else y[:, :, :W].contiguous()
     if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
@@ -872,8 +879,10 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     Co = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     bf16 = conv_precision() == "bf16"
-    x3 = not bf16 and _z2_fp32_entry() == "x3"
-    if Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+    x3 = not bf16 and _z2_fp32_entry() == "x3" and Ci != 48
+    wide = Ci == 48 and Co <= 48 and W % 4 == 0   # the pair-visibility UNet: the stride-1 kernel with a subsampled store
+    if not wide and (Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4) or act not in (0, 1) \
+            or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
@@ -971,12 +980,12 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
              or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_SLICE", "1") == "1")):
         # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
         # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
-        y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2)
+        y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True)   # conv2d_k3: the skip is added last
         if y is not None:
             return y
-    zs_any = conv_precision() == "bf16" or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0")
-    if stride == 2 and x2 is None and act in (0, 1) and zs_any and _use_mfma() and H * W >= 128 * 128:
-        y = conv2d_s2_zs(x, weight, scale, shift, skip, act)
+    zs_any = conv_precision() == "bf16" or ((_tile_kernels[0] or Ci0 == 48) and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0")
+    if stride == 2 and x2 is None and act in (0, 1) and zs_any and _use_mfma() and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128):
+        y = conv2d_s2_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
         if y is not None:
             return y
     if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8), (48, 48)) and _use_mfma() \
@@ -985,7 +994,7 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         # row-streamed matrix-core form (140 -> 68 us at 464 x 688) and the vector-unit kernel (140 -> 68 us at 928 x 1376,
         # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below.
         # 48 -> 48 (the pair-visibility UNet of AdaMVS): fp32 instruction, one patch buffer (340 -> 90 us at 688 x 464)
-        y = conv2d_zs(x, weight, scale, shift, skip, act)
+        y = conv2d_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
         if y is not None:
             return y
     if stride == 1 and act in (0, 1):

@@ -1466,6 +1466,47 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
         assert float((fused[k] - plain[k]).abs().max()) <= 2e-5 * max(1.0, float(plain[k].abs().max()))
 
 
+def test_tile_kernel_takes_small_images_of_any_width(ops, oracle):
+    """ops.conv2d_zs pads a small image whose width is not a multiple of 4 with zero columns (the layer's own padding) and
+    drops them again: the 58 x 86 level of AdaMVS's pair-visibility UNet."""
+    rng = np.random.default_rng(58)
+    x = rng.standard_normal((48, 58, 86)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((48, 48, 3, 3))).astype(np.float32)
+    b, sk = rng.standard_normal(48).astype(np.float32), rng.standard_normal((48, 58, 86)).astype(np.float32)
+    want = np.maximum(oracle.conv2d_k3(x, w, None) + b[:, None, None], 0) + sk
+    ops.set_conv_precision("fp32")
+    try:
+        got = ops.conv2d_zs(dev(x), dev(w), None, dev(b), dev(sk), 1, skip_after_act=True)
+        routed = ops.conv2d_k3(dev(x), dev(w), None, dev(b), dev(sk), act=1)
+    finally:
+        ops.set_conv_precision(None)
+    assert got is not None and got.shape == want.shape and got.is_contiguous()
+    assert np.abs(host(got) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    assert np.abs(host(routed) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,W", [(116, 172), (33, 72), (64, 64)])
+def test_stride2_48_channels_on_the_stride1_tile_kernel(ops, oracle, precision, H, W):
+    """d3d_conv2d_k3s2_zs_* at 48 channels (AdaMVS's pair-visibility UNet, adamvs.py:198-238): the stride-1 tile kernel with
+    the even positions stored, against the oracle's stride-2 convolution."""
+    rng = np.random.default_rng(H + W)
+    x = rng.standard_normal((48, H, W)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((48, 48, 3, 3))).astype(np.float32)
+    sc, sh = (0.5 + rng.uniform(0, 1, 48)).astype(np.float32), rng.standard_normal(48).astype(np.float32)
+    rnd = (lambda a: a) if precision == "fp32" else _bf16_round
+    want = np.maximum(oracle.conv2d_k3(rnd(x), rnd(w), None, stride=2) * sc[:, None, None] + sh[:, None, None], 0)
+    ops.set_conv_precision(precision)
+    try:
+        got = ops.conv2d_s2_zs(dev(x), dev(w), dev(sc), dev(sh), None, 1)
+        routed = ops.conv2d_k3(dev(x), dev(w), dev(sc), dev(sh), None, act=1, stride=2)
+    finally:
+        ops.set_conv_precision(None)
+    assert got is not None and got.shape == want.shape
+    tol = (2e-5 if precision == "fp32" else 2e-3) * max(1.0, np.abs(want).max())
+    assert np.abs(host(got) - want).max() <= tol and np.abs(host(routed) - want).max() <= tol
+
+
 @pytest.mark.parametrize("Ci,Co,H,W,act", [(8, 16, 128, 136, 1), (8, 16, 131, 256, 0), (16, 32, 130, 200, 1), (16, 16, 129, 144, 1), (8, 8, 256, 64, 1)])
 def test_conv2d_5x5_stride2_tile_kernel(ops, Ci, Co, H, W, act):
     """d3d_conv2d_k5s2_zs_bf16x3 (the 5 x 5 stride-2 layers of the feature trunks, module.py:669, 675) against torch's Conv2d(k 5,
