@@ -1038,6 +1038,18 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
         y = convtranspose2d_zs(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:
             return y
+    if Ci == 48 and Co <= 48 and _use_mfma() and act in (0, 1) and W % 2 == 0 and H * W <= 512 * 512 \
+            and _os.environ.get("D3D_CONVT2D_STUFF", "1") != "0":
+        # the pair-visibility UNet (adamvs.py:198-238): no transposed tile kernel has room for 48-channel cells, and at its
+        # image sizes the four per-parity launches of round 1's kernel are latency, not work.  A transposed convolution (k 3,
+        # s 2, p 1, output_pad 1) is the stride-1 convolution of the zero-stuffed input with the flipped kernel: one launch
+        # of the tile kernel (three quarters of its products are zeros)
+        z = x.new_zeros((Ci, 2 * H, 2 * W))
+        z[:, ::2, ::2] = x
+        wf = derived_weight(weight, "t2flip", lambda w: w.flip(2, 3).transpose(0, 1))
+        y = conv2d_zs(z, wf, scale, shift, skip, act, skip_after_act=skip_after_act)
+        if y is not None:
+            return y
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:

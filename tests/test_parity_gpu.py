@@ -1486,6 +1486,27 @@ def test_tile_kernel_takes_small_images_of_any_width(ops, oracle):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,W", [(58, 86), (29, 44), (116, 172)])
+def test_transposed_48_channels_as_a_convolution_of_the_zero_stuffed_input(ops, oracle, precision, H, W):
+    """ops.convtranspose2d_k3s2 at 48 channels (AdaMVS's pair-visibility UNet): the stride-1 tile kernel over the zero-stuffed
+    input with the flipped kernel, against the oracle's transposed convolution; skip before the ReLU as adamvs.py uses it."""
+    rng = np.random.default_rng(H * 3 + W)
+    x = rng.standard_normal((48, H, W)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((48, 48, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(48).astype(np.float32)
+    sk = rng.standard_normal((48, 2 * H, 2 * W)).astype(np.float32)
+    rnd = (lambda a: a) if precision == "fp32" else _bf16_round
+    want = np.maximum(oracle.convtranspose2d_k3s2(rnd(x), rnd(w), None) + b[:, None, None] + sk, 0)
+    ops.set_conv_precision(precision)
+    try:
+        got = ops.convtranspose2d_k3s2(dev(x), dev(w), None, dev(b), dev(sk), skip_after_act=False, act=1)
+    finally:
+        ops.set_conv_precision(None)
+    assert got.shape == want.shape
+    assert np.abs(host(got) - want).max() <= (2e-5 if precision == "fp32" else 2e-3) * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("H,W", [(116, 172), (33, 72), (64, 64)])
 def test_stride2_48_channels_on_the_stride1_tile_kernel(ops, oracle, precision, H, W):
     """d3d_conv2d_k3s2_zs_* at 48 channels (AdaMVS's pair-visibility UNet, adamvs.py:198-238): the stride-1 tile kernel with
