@@ -70,8 +70,9 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
 }
 
-template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false>
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false>
 __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+    static_assert(!CO8 || (OUTCL && NTN == 1), "CO8: the channel-last epilogue for exactly 8 output channels");
     static_assert(!KZF || (NTN == 1 && !OUTCL && !WG), "k_z-folded form: one output channel, planar output");
     constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
@@ -171,7 +172,33 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
         if constexpr (OUTCL) {
             // operands swapped (weights as A): D row = channel (lane >> 4) * 4 + register, column = pixel lane & 15 -- a
             // lane owns four consecutive channels of one pixel = one 8-byte store into the pixel's cell
-            if (oy < H && zo >= z0 && zo < z1) {
+            if constexpr (CO8) {
+              if (oy < H && zo >= z0 && zo < z1) {
+                // C_out = 8: rows 8..15 of the tile are padding and half of the wave has nothing to store.  The lanes of
+                // channels 4..7 hand their packed pair to the lanes of channels 0..3 of the same pixel (v_permlane16_swap:
+                // row 1 -> row 0), which then write the pixel's whole 16-byte cell -- 16 lanes x 16 contiguous bytes
+                // instead of 32 lanes x 8.
+                const int cb = (lane >> 4) * 4;
+                const bool live = cb < 8;
+                const f4 sc = p.scale && live ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+                const f4 sh = p.shift && live ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+                for (int mg = 0; mg < MGN; ++mg) {
+                    const int ox = x0 + mg * 16 + (lane & 15);
+                    const size_t o = (((size_t)zo * H + oy) * W + min(ox, W - 1)) * 8 + (live ? cb : 0);
+                    f4 v = a[mg] * sc + sh;
+                    if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                    if (p.skip && live) v += unpack_bf16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                    const unsigned px = pack_bf16(v[0], v[1]), py = pack_bf16(v[2], v[3]);
+                    const auto qx = __builtin_amdgcn_permlane16_swap(px, px, false, false);
+                    const auto qy = __builtin_amdgcn_permlane16_swap(py, py, false, false);
+                    if (cb == 0 && ox < W) {
+                        typedef unsigned u4s __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<u4s*>(static_cast<unsigned short*>(p.out) + o) = (u4s){px, py, qx[1], qy[1]};
+                    }
+                }
+              }
+            } else if (oy < H && zo >= z0 && zo < z1) {
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) {
                     const int cb = nt * 16 + (lane >> 4) * 4;
@@ -311,13 +338,15 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
     }
 }
 
-template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false>
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false>
 static int launch(const C8Params& p, hipStream_t stream) {
+    if constexpr (OUTCL && NTN == 1 && !KZF && !WG && !CO8)
+        if (p.CO == 8) return launch<CI, NTN, INCL, OUTCL, MGN, WG, KZF, true>(p, stream);   // whole-cell stores (see store_plane)
     constexpr int NKB = (9 * CI + 31) / 32;
     constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
     constexpr int TXk = 16 * MGN, PXk = TXk + 2;
     const int lds = 2 * PXk * PY * CS + (WG ? 0 : (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
-    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF>;
+    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF, CO8>;
     int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                         "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
     if (rc != D3D_OK) return rc;
