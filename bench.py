@@ -108,8 +108,10 @@ def torch_cpu_leg(proj_host, feats_host, depth_host, threads, budget_s=6.0):
         torch.set_num_threads(old)
 
 
-def cpu_baseline(proj34_host, feats_host, depth_host):
-    """Times the CPU oracle on a depth sub-range of the same workload (bounded to ~10-20 s)."""
+def cpu_baseline(proj34_host, feats_host, depth_host, gpu_volume=None):
+    """Times the CPU oracle on a depth sub-range of the same workload (bounded to ~10-20 s).  The planes the oracle
+    computed are then compared with the same planes of the volume the timed kernel left in HBM (outside every timed
+    region): BASELINE.json's "L1 vs ref" half of the metric, at the cost-volume level, at full size."""
     import oracle
 
     oracle.build()
@@ -122,12 +124,25 @@ def cpu_baseline(proj34_host, feats_host, depth_host):
     planes = int(min(D, max(probe, probe * 12.0 / max(dt, 1e-3))))
     start = (D - planes) // 2
     t0 = time.perf_counter()
-    oracle.variance_volume(feats_host[0], feats_host[1:], proj34_host, depth_host[start:start + planes])
+    want = oracle.variance_volume(feats_host[0], feats_host[1:], proj34_host, depth_host[start:start + planes])
     dt = time.perf_counter() - t0
     vox = planes * H_FEAT * W_FEAT
-    return {"value": round(vox / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": "%d of %d depth planes (planes %d..%d) of the same 5-view 32x688x464 workload, %.1f s"
-                      % (planes, D, start, start + planes - 1, dt)}
+    cb = {"value": round(vox / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": oracle.num_threads(), "kind": "port",
+          "sample": "%d of %d depth planes (planes %d..%d) of the same 5-view 32x688x464 workload, %.1f s"
+                    % (planes, D, start, start + planes - 1, dt)}
+    parity = None
+    if gpu_volume is not None:
+        # up to 16 of the oracle's planes, evenly spread over its range (16 planes = 654 MB of device-to-host copy)
+        sel = np.unique(np.linspace(0, planes - 1, min(planes, 16)).round().astype(np.int64))
+        got = gpu_volume[:, torch.from_numpy(start + sel).to(gpu_volume.device)].cpu().numpy()
+        ref = np.ascontiguousarray(want[:, sel])
+        num = float(np.abs(got - ref).mean(dtype=np.float64))
+        den = float(np.abs(ref).mean(dtype=np.float64))
+        parity = {"variance_rel_l1": num / max(den, 1e-30), "variance_max_abs": float(np.abs(got - ref).max()),
+                  "planes": [int(start + k) for k in sel], "voxels": int(sel.size * H_FEAT * W_FEAT),
+                  "tolerance_rel_l1": 5e-5, "against": "oracle/planesweep_oracle.c (restates module.py:516-557 + cas_mvsnet.py:45-60)",
+                  "ok": bool(num / max(den, 1e-30) < 5e-5)}
+    return cb, parity
 
 
 def profiled_traffic():
@@ -241,6 +256,11 @@ def main():
     # one process per GPU; with fewer devices than ranks (a rehearsal of the N > 1 path on a one-GPU box) the ranks share
     # the card and the two control-plane collectives below go through gloo on host tensors
     shared = world > 1 and ndev < world
+    if shared and os.environ.get("D3D_BENCH_SHARE_GPU", "0") != "1":
+        # a scaling run must have one device per rank: sharing a card is a rehearsal of the control path only, and has to be
+        # asked for (tests/test_sharding_gpu.py does), never fallen into
+        sys.exit("bench.py --gpus %d: %d ranks but only %d visible device(s); set D3D_BENCH_SHARE_GPU=1 to rehearse the "
+                 "N > 1 path with ranks sharing a card" % (args.gpus, world, ndev))
     torch.cuda.set_device(local_rank % max(ndev, 1))
     dist = None
     if world > 1:
@@ -279,12 +299,21 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, stops)]))
+    per_rank = None
+    if dist:
+        # what a first multi-GPU run needs to be diagnosable: every rank's own kernel time, wall time and device
+        mine = {"rank": rank, "kernel_ms": round(kern_ms, 4), "elapsed_s": round(local_elapsed, 5),
+                "device_index": local_rank % max(ndev, 1), "device": torch.cuda.get_device_name(),
+                "in_frame_fraction": round(in_frame, 4)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     voxels = D * H_FEAT * W_FEAT
     value = world * args.steps * voxels / elapsed / 1e6
     achieved = algorithmic_bytes() / (kern_ms * 1e-3) / 1e9
@@ -313,9 +342,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profile": traffic_info,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": algorithmic_bytes()},
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             p34_host = p34.cpu().numpy().reshape(-1, 3, 4)
-            cb = cpu_baseline(p34_host, feats_host, depth_host)
+            cb, parity = cpu_baseline(p34_host, feats_host, depth_host, gpu_volume=out)
+            line["parity"] = parity
             # second baseline of SURVEY.md 8(d): the reference's op sequence in plain PyTorch CPU, all cores and 8 threads
             allc = host_threads()
             cb["torch_ops_all_cores"] = torch_cpu_leg(proj, feats_host, depth_host, allc)

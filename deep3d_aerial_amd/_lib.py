@@ -10,7 +10,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libdeep3d_planesweep.so")
+# D3D_LIBRARY: load another build of the library (tools/run_ab.sh links its -D variants to a scratch path and points this
+# at them, so the in-tree production library is never overwritten by an experiment).  Read once, at import.
+SO_PATH = os.environ.get("D3D_LIBRARY") or os.path.join(CSRC, "libdeep3d_planesweep.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
 
 ABI_VERSION = 2

@@ -64,6 +64,28 @@ constexpr int PFD = 2;          // delta staging items (64 positions x CH channe
 #ifndef D3D_LDS_PIPE
 #define D3D_LDS_PIPE 1
 #endif
+// D3D_GRAB: the planes of a step are handed out DYNAMICALLY (one LDS counter per step and pixel wave) instead of plane j
+// going to depth sub-range j mod NSUB.  Why: issue arbitration on a SIMD goes by wave age, so the oldest wave of a SIMD
+// runs its planes at full single-wave speed, the younger ones on the leftover slots; with a static split the old waves
+// then idle at the step barrier while the SIMD drops to the (much lower: tools/plane_loop_rate.hip) throughput of one or
+// two active waves.  Handing out planes as waves become free keeps every wave of a SIMD busy until the step runs out.
+// (Lowering a wave's priority with s_setprio as it advances was tried instead: priorities are STRICT -- a lower-priority
+// wave does not even get the leftover slots -- and the step took 1.3x longer.)
+#ifndef D3D_GRAB
+#define D3D_GRAB 0
+#endif
+// D3D_FREERUN: no step barriers.  The compute waves take planes from ONE queue per pixel wave that runs through the whole
+// pass, and meet the loader waves only through two LDS counters per step: staged[k] (loader waves that have finished
+// delta k) and done[k] (planes of step k that have been swept).  A compute wave enters step k once staged[k] is
+// complete; the loaders start delta k once done[k-2] is complete (delta k may reuse slots of window k-2 only: the rings
+// hold the union of two consecutive windows), so the compute waves of a workgroup are at most one step apart and never
+// wait for EACH OTHER.  Why it matters: a SIMD of gfx950 reaches its vector throughput only with three or more waves
+// issuing (tools/plane_loop_rate.hip: 1766 / 1667 / 1125 cycles per plane and channel group at 1 / 2 / 3 waves per SIMD),
+// issue arbitration goes by wave age, and with a barrier per step the old waves of a SIMD finish their planes first and
+// then idle while the young ones run alone at the one-wave rate.
+#ifndef D3D_FREERUN
+#define D3D_FREERUN 0
+#endif
 constexpr int LDS_PIPE = D3D_LDS_PIPE;     // (quad, view) units whose taps are requested ahead of the one being blended
 constexpr int NCAND = 4;        // candidate step sizes: 4, 2, 1, 1/2 times NSUB planes
 constexpr int MAXRECTS = 512;   // non-empty delta rectangles per workgroup segment (4 words each)
@@ -83,6 +105,15 @@ __host__ __device__ __forceinline__ int ring_row_floats(int RW) {
 }
 // non-empty delta rectangles per workgroup segment: MAXRECTS
 
+// Cycle stamps and plan statistics of the kernel (D3D_TILED_STATS): compiled only into -DD3D_EXPERIMENTS builds -- in the
+// production kernel the stamps and their accumulators would be live scalar registers across the plane loop.
+#ifdef D3D_EXPERIMENTS
+#define D3D_STAMPS 1
+#else
+#define D3D_STAMPS 0
+#endif
+#define D3D_CLOCK() (D3D_STAMPS ? clock64() : 0ll)
+
 struct TiledArgs {
     int ngroups;     // channel groups (C / CH), one workgroup pass each
     int dseg;        // planes per workgroup segment
@@ -98,7 +129,7 @@ struct TiledArgs {
 //   [zero cell 2*STRIDE][pmin DSEG_MAX][pmax DSEG_MAX][header 32][plan table MAXSTEPS*NSRC*8]
 //   [rect starts MAXSTEPS+4][rect descriptors MAXRECTS*8][rings ...]
 // header: 0 mode (1 rings, 0 global gather) | 1 planes per step | 2 nsteps | 4+4i.. RW, RH, base, RW | RH << 8 | (base/4) << 16 per view
-// plan entry (per step, view): wx0, wy0, ww, wh, ox, oy, -, -
+// plan entry (per step, view): wx0, wy0, ww, wh, ox, oy, ox - wx0, oy - wy0
 // rect descriptor (non-empty delta rectangles, grouped by step), 4 words:
 //   (rx + 1) | (ry + 1) << 16,  width | view << 12 | first position (cumulative within the step) << 16,
 //   positions,  ring col | row << 16 of the rect origin (unwrapped)
@@ -115,10 +146,6 @@ struct Lds {
     static constexpr int STOT = SST + MAXSTEPS + 4;   // positions to stage per step
     static constexpr int RECTS = ((STOT + MAXSTEPS + 3) / 4) * 4;
     static constexpr int DATA = RECTS + (MAXRECTS + 1) * 4;  // 16-byte aligned
-};
-
-struct Win {  // wave-uniform window of one view at one step
-    int x0, y0, w, h, ox, oy;
 };
 
 struct Rects {  // window(k) minus window(k-1): left | right | top | bottom (any may be empty)
@@ -170,6 +197,23 @@ __device__ __forceinline__ void step_wait(int* ctr, int target) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// Counter hand-off in LDS (D3D_FREERUN).  The LDS executes the DS operations of the CU in arrival order and those of one wave
+// in program order, so "ring writes, then counter add" by one wave and "counter read, then ring reads" by another need no
+// fence beyond keeping the COMPILER from reordering them (a workgroup-scope fence would also wait for every global store
+// the wave has in flight).  Waits are bounded: a wave that gives up sweeps on (wrong results, never a hang).
+__device__ __forceinline__ void ctr_add(int* ctr, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ctr_wait(int* ctr, int target) {
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ int posmod(int a, int n) {
     int r = a % n;
     return r < 0 ? r + n : r;
@@ -181,26 +225,46 @@ struct TapL {
     float nw, ne, sw, se;  // bilinear weights (taps outside the image are zeros in LDS)
 };
 
+// Wave-uniform constants of one source view's ring (scalar registers in the plane loop).
+struct RingView {
+    int RW, RH;  // torus size in positions
+    int rowb;    // bytes between ring rows
+    int base;    // absolute LDS byte address of ring position (0, 0)
+};
+
+// Projection + bilinear weights + ring addresses of one (pixel, plane, view): ~34 VALU instructions, no branches, no
+// predicates.  (u, v) are CLAMPED to [-1, w] x [-1, h] instead of being tested against the window: the planner clamps the
+// hull of the patch the same way (monotone, so a clamped sample lies in the clamped hull), windows may reach one position
+// past the image on the left / top and two on the right / bottom, and every position outside the image is staged as
+// zeros -- a sample outside the image reads zero taps (or taps of weight exactly 0), which is per-tap zero padding.
+// (kx, ky) = ring offset minus window origin of the current step.  Non-finite projections end at a clamp bound
+// (v_med3_f32 returns the smallest operand when one is a NaN).
 template <int STRIDE>
-__device__ __forceinline__ TapL make_tap_ring(float u, float v, const Win& W, int RW, int RH, int base_bytes) {
+__device__ __forceinline__ TapL geo_ring(const Ray& r, float tx, float ty, float tz, float d, float umax, float vmax, int kx, int ky,
+                                         const RingView& R) {
+    const float px = __fadd_rn(__fmul_rn(r.rx, d), tx);
+    const float py = __fadd_rn(__fmul_rn(r.ry, d), ty);
+    const float pz = __fadd_rn(__fmul_rn(r.rz, d), tz);
+    // quotient = v_rcp_f32 estimate + one Newton correction (correctly rounded in practice: common.h project())
+    const float iz = __builtin_amdgcn_rcpf(pz);
+    const float u0 = px * iz, v0 = py * iz;
+    float u = fmaf(fmaf(-u0, pz, px), iz, u0);
+    float v = fmaf(fmaf(-v0, pz, py), iz, v0);
+    u = __builtin_amdgcn_fmed3f(u, -1.0f, umax);
+    v = __builtin_amdgcn_fmed3f(v, -1.0f, vmax);
+    const float fu = floorf(u), fv = floorf(v);
+    const float ax = u - fu, ay = v - fv;
+    const float bx = (fu + 1.0f) - u, by = (fv + 1.0f) - v;
     TapL t;
-    float fu = floorf(u), fv = floorf(v);
-    float ax = u - fu, ay = v - fv;
-    float bx = (fu + 1.0f) - u, by = (fv + 1.0f) - v;
     t.nw = bx * by;
     t.ne = ax * by;
     t.sw = bx * ay;
     t.se = ax * ay;
-    int cx = (int)fu - W.x0, cy = (int)fv - W.y0;
-    // W.w == 0 (empty / unused view) must reject everything: max() keeps the unsigned bound at 0
-    bool in = ((unsigned)cx < (unsigned)max(W.w - 1, 0)) && ((unsigned)cy < (unsigned)max(W.h - 1, 0));
-    unsigned c = (unsigned)(cx + W.ox), r = (unsigned)(cy + W.oy);
-    c = min(c, c - (unsigned)RW);  // one conditional wrap: cx < RW and ox < RW
-    r = min(r, r - (unsigned)RH);
-    const int rowb = ring_row_floats<STRIDE>(RW) * 4;
-    int a = base_bytes + (int)r * rowb + (int)c * (STRIDE * 4);
-    t.a0 = in ? a : 0;  // zero cell: two all-zero positions at LDS offset 0
-    t.a1 = in ? a + rowb : 0;
+    unsigned c = (unsigned)((int)fu + kx), rr = (unsigned)((int)fv + ky);
+    c = min(c, c - (unsigned)R.RW);  // one conditional wrap: 0 <= c < 2 RW
+    rr = min(rr, rr - (unsigned)R.RH);
+    t.a0 = R.base + (int)__umul24(rr, (unsigned)R.rowb) + (int)__umul24(c, (unsigned)(STRIDE * 4));
+    t.a1 = t.a0 + R.rowb;
     return t;
 }
 
@@ -235,6 +299,11 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 lds_read4(const float* lds, int byte_addr) {
     return *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(lds) + byte_addr);
 }
+// ds_read_b128 at an ABSOLUTE LDS byte address (the dynamic-LDS base is folded into RingView::base once, so the plane
+// loop has no "base + offset" addition per tap address)
+typedef __attribute__((address_space(3))) const f4* lds_f4_ptr;
+__device__ __forceinline__ f4 lds_read4_abs(int byte_addr) { return *(lds_f4_ptr)(unsigned)byte_addr; }
+__device__ __forceinline__ int lds_base_bytes(float* lds) { return (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)lds; }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 // Two channels per VALU instruction (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32): each half is the IEEE operation,
@@ -347,12 +416,13 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     constexpr int Q = CW / 4;                     // 16-byte chunks per position
     static_assert(!F16 || MODE == MODE_VARIANCE, "fp16 storage is built for the variance volume only");
     constexpr bool VIEW_MAJOR = F16;             // unit order of the compute loop (see there)
+    constexpr bool FREERUN = D3D_FREERUN && NLOADW > 0 && NPIXW <= 2;   // (the plane queues: one per pixel wave, two header words)
     constexpr int MAXRS = 4 * NSRC;               // delta rectangles a step can have (left | right | top | bottom per view)
     static_assert(NSRC <= 15, "rect descriptors keep the view in 4 bits");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int* ldsi = reinterpret_cast<int*>(lds);
 
-    const long long t_start = clock64();
+    const long long t_start = D3D_CLOCK();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = rfl(tid >> 6);
@@ -430,7 +500,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
         }
     }
     __syncthreads();
-    const long long t_range = clock64();
+    const long long t_range = D3D_CLOCK();
 
     // --- plan every step of the segment ---------------------------------------------------------
     // P1: wave (candidate, view) computes, one lane per step, that view's windows for the candidate
@@ -467,20 +537,22 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 float iz = 1.0f / qz;
                 float u = qx * iz, v = qy * iz;
                 ok = ok && (fabsf(u) < 1e30f) && (fabsf(v) < 1e30f);
-                // clamp before the float->int conversion; windows are clipped to the image plus a zero ring
-                u = fminf(fmaxf(u, -8.0f), (float)w + 8.0f);
-                v = fminf(fmaxf(v, -8.0f), (float)h + 8.0f);
+                // the same clamp as the samples' (geo_ring): windows lie in [-1, w + 1] x [-1, h + 1]
+                u = fminf(fmaxf(u, -1.0f), (float)w);
+                v = fminf(fmaxf(v, -1.0f), (float)h);
                 umin = fminf(umin, u); umax = fmaxf(umax, u);
                 vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
             }
             // interior samples differ from the corner hull by fp32 rounding only (<< 1/16 px)
             int wx0 = max((int)floorf(umin - 0.0625f), -1);
             int wy0 = max((int)floorf(vmin - 0.0625f), -1);
-            int wx1 = min((int)floorf(umax + 0.0625f) + 1, w);
-            int wy1 = min((int)floorf(vmax + 0.0625f) + 1, h);
-            int ww = max(wx1 - wx0 + 1, 0), wh = max(wy1 - wy0 + 1, 0);
-            if (ww < 2 || wh < 2) { ww = 0; wh = 0; }  // nothing of the image is touched
-            if (vsel >= p.n_src || !act) { ww = 0; wh = 0; ok = true; }
+            int wx1 = min((int)floorf(umax + 0.0625f) + 1, w + 1);
+            int wy1 = min((int)floorf(vmax + 0.0625f) + 1, h + 1);
+            int ww = max(wx1 - wx0 + 1, 0), wh = max(wy1 - wy0 + 1, 0);   // >= 2 x 2: every sample has its four taps in the window
+            // unused view of the template (n_src < NSRC): its samples sit at (-1, -1) (geo_ring with a zero ray), weight 1 on
+            // the tap at (-1, -1) -- a zero -- and weight 0 on the other three
+            if (vsel >= p.n_src) { wx0 = -1; wy0 = -1; ww = 2; wh = 2; ok = true; }
+            if (!act) { ww = 0; wh = 0; ok = true; }
             // ring size: the union of consecutive windows must fit (asynchronous delta staging)
             int ux = ww, uy = wh;
             {
@@ -506,7 +578,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     constexpr int NCAND1 = NCAND - 1;
     for (int wk = wave; wk < NCAND1 * NSRC; wk += NWAVES) candidate_windows(wk / NSRC, wk % NSRC);
     __syncthreads();
-    const long long t_p1 = clock64();
+    const long long t_p1 = D3D_CLOCK();
     auto plan_tables = [&](int cbeg, int cend) {  // wave 0: first candidate in [cbeg, cend) whose rings fit
         int mode = 0, sp_sel = NSUB, nsteps_sel = (nplanes + NSUB - 1) / NSUB;
         for (int cand = cbeg; cand < cend && !mode; ++cand) {
@@ -555,6 +627,8 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                         e[0] = wx0[i]; e[1] = wy0[i]; e[2] = ww[i]; e[3] = wh[i];
                         e[4] = oxv[i];
                         e[5] = oyv[i];
+                        e[6] = oxv[i] - wx0[i];   // ring column of source column 0 (geo_ring's kx, ky)
+                        e[7] = oyv[i] - wy0[i];
                     }
                     if (lane == 0) {
                         ldsi[L::HDR + 4 + 4 * i + 0] = RW[i];
@@ -633,6 +707,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             ldsi[L::HDR + 2] = nsteps_sel;
         }
         for (int i = lane; i < 2 * MAXSTEPS; i += 64) ldsi[L::CNT + i] = 0;
+        if (lane < 2) ldsi[L::HDR + 28 + lane] = 0;   // plane queues of the pixel waves (D3D_FREERUN)
     };
     if (wave == 0) plan_tables(0, NCAND1);
     __syncthreads();
@@ -643,7 +718,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
         if (wave == 0) plan_tables(NCAND1, NCAND);
         __syncthreads();
     }
-    if (a.tstats && tid == 0) {  // prologue phases: depth range | windows of every candidate | plan + rectangle tables
+    if (D3D_STAMPS && a.tstats && tid == 0) {  // prologue phases: depth range | windows of every candidate | plan + rectangle tables
         const long long t_p2 = clock64();
         atomicAdd(a.tstats + 16, (unsigned long long)(t_range - t_start));
         atomicAdd(a.tstats + 17, (unsigned long long)(t_p1 - t_range));
@@ -652,7 +727,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     const int ring = rfl(ldsi[L::HDR + 0]);
     const int SP = rfl(ldsi[L::HDR + 1]);  // planes per step
     const int nsteps = rfl(ldsi[L::HDR + 2]);
-    if (a.stats && tid == 0) {
+    if (D3D_STAMPS && a.stats && tid == 0) {
         atomicAdd(a.stats + (ring ? 0 : 1), 1u);
         atomicAdd(a.stats + 2, (unsigned)SP);
         atomicAdd(a.stats + 3, (unsigned)nsteps);
@@ -662,13 +737,6 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             atomicAdd(a.stats + 4, tot);
         }
     }
-    auto load_win = [&](int k, int i) -> Win {  // k, i wave-uniform (may be run-time values)
-        Win W;
-        const int* e = ldsi + L::PLAN + (k * NSRC + i) * 8;
-        W.x0 = rfl(e[0]); W.y0 = rfl(e[1]); W.w = rfl(e[2]); W.h = rfl(e[3]); W.ox = rfl(e[4]); W.oy = rfl(e[5]);
-        return W;
-    };
-
     // ---------------------------------------------------------------------------------------
     // Delta staging: step k owns the item descriptors [sst[k], sst[k+1]); wave wv takes items
     // wv, wv + NWAVES, ...; the first PFD of them are prefetched one step ahead.
@@ -747,7 +815,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             for (int q = 0; q < Q; ++q) put(pmeta[j], pgeo[j], q, pf[j][q]);
     };
     // Loader waves: bring window(k) minus window(k-1) into the rings.
-    const bool ltiming = a.tstats != nullptr && lw == 0;
+    const bool ltiming = D3D_STAMPS && a.tstats != nullptr && lw == 0;
     long long lt_desc = 0, lt_issue = 0, lt_write = 0, lt_bar = 0;
     // (sw, snw): this wave's index among the snw waves sharing the step's items -- the loaders for the deltas;
     // ALL waves for the initial window, which nothing can overlap (one workgroup per CU): the compute waves
@@ -804,7 +872,16 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
         for (int gi = 0; gi < a.ngroups; ++gi) {
         grp = gi;
         c0 = gi * CH;
-        if (ring) {
+        if (FREERUN && ring) {
+            stage(0, wave, NWAVES);
+            __syncthreads();   // start of the pass: window 0 is complete, the counters are clear
+            for (int k = 1; k < nsteps; ++k) {
+                // delta k may land on slots of window k-2 (never of window k-1): every plane of step k-2 has to be swept
+                if (k >= 2) ctr_wait(ldsi + L::CNT + (k - 2), min(SP, nplanes - (k - 2) * SP) * NPIXW);
+                stage(k, lw, NLOADW);
+                ctr_add(ldsi + L::CNT + MAXSTEPS + k, lane);   // (after this wave's ring writes, in program order)
+            }
+        } else if (ring) {
             stage(0, STAGE0_ALL_EFF ? wave : lw, STAGE0_ALL_EFF ? NCOMP + NLOADW : NLOADW);
 #if D3D_DECOUPLE
             step_signal(ldsi + L::CNT + 0, lane);
@@ -820,7 +897,9 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             for (int k = 0; k < nsteps; ++k) {
                 long long tb = 0;
                 if (ltiming) tb = clock64();
+#ifndef D3D_X_NOBAR   // timing experiment (results wrong): no step barriers at all
                 __syncthreads();
+#endif
                 if (ltiming) lt_bar += clock64() - tb;
                 if (k + 1 < nsteps) stage(k + 1, lw, NLOADW);
             }
@@ -839,15 +918,25 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     // --- per-lane constants: rays, reference features, weights -------------------------------
     Ray ray[NSRC];
     float T0[NSRC], T1[NSRC], T2[NSRC];
-    int RW[NSRC], RH[NSRC], rbase[NSRC];
+    RingView RV[NSRC];
+    const int lds0 = lds_base_bytes(lds);
+    const float umax = (float)w, vmax = (float)h;   // geo_ring's clamp bounds
 #pragma unroll
     for (int i = 0; i < NSRC; ++i) {
         const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
         ray[i] = make_ray(M, xf, yf);
         T0[i] = M[3]; T1[i] = M[7]; T2[i] = M[11];
-        RW[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 0]) : 1;
-        RH[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 1]) : 1;
-        rbase[i] = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 2]) : L::DATA;
+        if (ring && i >= p.n_src) {   // unused view of the template: every sample at (-1, -1), see the planner
+            ray[i].rx = 0.0f; ray[i].ry = 0.0f; ray[i].rz = 0.0f;
+            T0[i] = -1.0f; T1[i] = -1.0f; T2[i] = 1.0f;
+        }
+        RV[i].RW = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 0]) : 1;
+        RV[i].RH = ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 1]) : 1;
+        RV[i].rowb = ring_row_floats<STRIDE>(RV[i].RW) * 4;
+        RV[i].base = lds0 + 4 * (ring ? rfl(ldsi[L::HDR + 4 + 4 * i + 2]) : L::DATA);
+#ifdef D3D_RV_VGPR   // experiment: the ring constants as (uniform) vector registers instead of spilled scalar registers
+        asm volatile("" : "+v"(RV[i].RW), "+v"(RV[i].RH), "+v"(RV[i].rowb), "+v"(RV[i].base));
+#endif
     }
     f4 r[F16 ? 1 : Q];
     float rh[F16 ? Q : 1][8];   // fp16 storage: reference features of the group, 8 channels per chunk
@@ -906,11 +995,16 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 ob += 16;
             }
         } else {
+#ifdef D3D_X_STORE4   // timing experiment (layout wrong): the quad leaves as ONE 16-byte store per lane instead of four 4-byte ones
+            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(pixb * 4u), "v"(o), "s"(ob));
+            ob += 4 * cstride_b;
+#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 store_sbase(ob, pixb, o[k]);
                 ob += cstride_b;
             }
+#endif
         }
     };
     auto accumulate = [&](f4& s, f4& qq, float& pair_acc, const f4& val, int q, int i) {
@@ -930,8 +1024,8 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     };
 
     // ================================ main loop over steps ======================================
-    const bool timing = a.tstats != nullptr && wave == 0;
-    const bool wtiming = a.tstats != nullptr;  // every compute wave: its own barrier wait
+    const bool timing = D3D_STAMPS && a.tstats != nullptr && wave == 0;
+    const bool wtiming = D3D_STAMPS && a.tstats != nullptr;  // every compute wave: its own barrier wait
     long long t_ww = 0;
     long long t_w = 0, t_w0 = 0, t_c = 0, t_mark = 0;
     if (timing) { t_mark = clock64(); if (lane == 0) atomicAdd(a.tstats + 0, (unsigned long long)(t_mark - t_start)); }
@@ -942,33 +1036,17 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     // while the younger one runs alone.  Static priority for the younger half evens the two out.
     if (wave >= NCOMP / 2) __builtin_amdgcn_s_setprio(D3D_YOUNG_PRIO);
 #endif
-    for (int gi = 0; gi < a.ngroups; ++gi) {
-    grp = gi;
-    c0 = gi * CH;
-    load_reference();
-#if STAGE0_ALL_EFF
-    if (ring) stage(0, wave, NCOMP + NLOADW);  // first window of the pass: every wave of the workgroup stages
-#endif
-    for (int k = 0; k < nsteps; ++k) {
-        if (ring) {
-            long long ta = 0;
-            if (timing) ta = clock64();
-            long long tw0 = 0;
-            if (wtiming) tw0 = clock64();
-            __syncthreads();  // barrier k: rings hold window(k)
-            if (wtiming && k > 0) t_ww += clock64() - tw0;
-            if (timing) { t_mark = clock64(); t_w += t_mark - ta; if (k == 0) t_w0 = t_mark - ta; }
-        }
-        Win W[NSRC];
+    // ---- one plane of the segment (dl_ = plane index within the segment) for this wave's pixels and the current group ----
+    int kx[NSRC], ky[NSRC];   // ring offset minus window origin of the current step, per view (scalar registers)
+    auto load_step = [&](int k) {
 #pragma unroll
-        for (int i = 0; i < NSRC; ++i) W[i] = load_win(ring ? k : 0, i);
-#ifdef D3D_X_GEO
-        TapL tkeep[NSRC];
-#endif
-
-        for (int j = 0; sub + NSUB * j < SP; ++j) {
-            const int dl_ = k * SP + sub + NSUB * j;
-            if (dl_ >= nplanes) break;
+        for (int i = 0; i < NSRC; ++i) {
+            const int* e = ldsi + L::PLAN + ((ring ? k : 0) * NSRC + i) * 8;
+            kx[i] = rfl(e[6]);
+            ky[i] = rfl(e[7]);
+        }
+    };
+    auto sweep_plane = [&](const int dl_) {
             const int d = ds + dl_;
             float dv;
             if (p.depth_mode == D3D_DEPTH_PER_PIXEL) {
@@ -980,7 +1058,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) + (size_t)d * plane * p.C + c0)
                                           : uniform64(reinterpret_cast<T*>(p.out) + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);  // scalar base, once per plane
             float pair_acc = 0.0f;
-            if (!valid) continue;  // one EXEC region per plane instead of one branch per store
+            if (!valid) return;  // one EXEC region per plane instead of one branch per store
 
             if constexpr (VIEW_MAJOR) {
                 // ---- view-major order (fp16 storage, or more than four source views) -----------------------------
@@ -1014,17 +1092,13 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 };
                 if (ring) {
                     auto geometry = [&](int i) -> TapL {
-                        const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
-                        const Ray rr = make_ray(M, xf, yf);
-                        float u, v;
-                        project(rr, M[3], M[7], M[11], dv, h, w, u, v);
-                        return make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
+                        return geo_ring<STRIDE>(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, kx[i], ky[i], RV[i]);
                     };
                     auto fetch = [&](const TapL& g, int q, f4 (&dst)[4]) {
-                        dst[0] = lds_read4(lds, g.a0 + q * 16);
-                        dst[1] = lds_read4(lds, g.a0 + q * 16 + STRIDE * 4);
-                        dst[2] = lds_read4(lds, g.a1 + q * 16);
-                        dst[3] = lds_read4(lds, g.a1 + q * 16 + STRIDE * 4);
+                        dst[0] = lds_read4_abs(g.a0 + q * 16);
+                        dst[1] = lds_read4_abs(g.a0 + q * 16 + STRIDE * 4);
+                        dst[2] = lds_read4_abs(g.a1 + q * 16);
+                        dst[3] = lds_read4_abs(g.a1 + q * 16 + STRIDE * 4);
                     };
                     f4 tp[2][4];
                     TapL gc = geometry(0);
@@ -1095,45 +1169,19 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                         else store_sbase(ob, pixb, o);
                         ob += cstride_b;
                     }
-                continue;
+                return;
             }
 
             if (ring) {
-#ifdef D3D_X_GEO   // timing experiment (results wrong): geometry once per step instead of once per plane
-                static_assert(true, "");
                 TapL t[NSRC];
-                if (j == 0) {
 #pragma unroll
-                    for (int i = 0; i < NSRC; ++i) {
-                        float u, v;
-                        project(ray[i], T0[i], T1[i], T2[i], dv, h, w, u, v);
-                        tkeep[i] = make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NSRC; ++i) t[i] = tkeep[i];
+                for (int i = 0; i < NSRC; ++i) {
+#ifdef D3D_X_NOGEO   // timing experiment (results wrong): no projection / weights / addresses
+                    t[i].nw = dv; t[i].ne = dv * 0.5f; t[i].sw = dv * 0.25f; t[i].se = 1.0f - dv; t[i].a0 = RV[i].base; t[i].a1 = RV[i].base + 80;
 #else
-                TapL t[NSRC];
-#pragma unroll
-                for (int i = 0; i < NSRC; ++i) {
-                    float u, v;
-                    project(ray[i], T0[i], T1[i], T2[i], dv, h, w, u, v);
-                    t[i] = make_tap_ring<STRIDE>(u, v, W[i], RW[i], RH[i], rbase[i] * 4);
+                    t[i] = geo_ring<STRIDE>(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, kx[i], ky[i], RV[i]);
+#endif
                 }
-#endif
-#ifdef D3D_X_ADDR  // timing experiment (results wrong): conflict-free tap addresses (16 consecutive ring positions per lane group)
-#pragma unroll
-                for (int i = 0; i < NSRC; ++i) {
-#if D3D_X_ADDR == 2   // keep the real address computation alive (same VALU work), then discard it
-                    asm volatile("" : : "v"(t[i].a0), "v"(t[i].a1));
-#endif
-#if D3D_X_ADDR == 3   // real addresses, but all lanes forced inside the ring (no zero-cell reads): add 0 through an opaque register
-                    { int z = 0; asm volatile("" : "+v"(z)); t[i].a0 += z; t[i].a1 += z; continue; }
-#endif
-                    t[i].a0 = rbase[i] * 4 + ((lane & 31) + (lane >> 5) * (RW[i] + 1)) * (STRIDE * 4);
-                    t[i].a1 = t[i].a0 + (RW[i] + 1) * (STRIDE * 4);
-                }
-#endif
                 // Units u = (quad q, view i) in q-major order; the four taps of unit u+1 are requested
                 // before unit u is blended, so LDS latency overlaps the 24 VALU ops of a unit.
                 constexpr int NU = Q * NSRC;
@@ -1141,10 +1189,16 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 f4 tp[PD + 1][4];
                 auto request = [&](int u, f4 (&dst)[4]) {
                     const int q2 = u / NSRC, i2 = u % NSRC;
-                    dst[0] = lds_read4(lds, t[i2].a0 + q2 * 16);
-                    dst[1] = lds_read4(lds, t[i2].a0 + q2 * 16 + STRIDE * 4);
-                    dst[2] = lds_read4(lds, t[i2].a1 + q2 * 16);
-                    dst[3] = lds_read4(lds, t[i2].a1 + q2 * 16 + STRIDE * 4);
+#ifdef D3D_X_NOLDS   // timing experiment (results wrong): no tap reads (the reference features stand in for the taps: no
+                     // instruction replaces the reads), the arithmetic and everything else kept
+                    asm volatile("" : : "v"(t[i2].a0), "v"(t[i2].a1));
+                    dst[0] = r[(q2 + 0) % Q]; dst[1] = r[(q2 + 1) % Q]; dst[2] = r[(q2 + 2) % Q]; dst[3] = r[(q2 + 3) % Q];
+                    return;
+#endif
+                    dst[0] = lds_read4_abs(t[i2].a0 + q2 * 16);
+                    dst[1] = lds_read4_abs(t[i2].a0 + q2 * 16 + STRIDE * 4);
+                    dst[2] = lds_read4_abs(t[i2].a1 + q2 * 16);
+                    dst[3] = lds_read4_abs(t[i2].a1 + q2 * 16 + STRIDE * 4);
                 };
 #pragma unroll
                 for (int u = 0; u < PD && u < NU; ++u) request(u, tp[u % (PD + 1)]);
@@ -1162,7 +1216,12 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                     // LDS returns in order: touching the last-requested tap first makes the compiler emit ONE
                     // s_waitcnt for the unit instead of one per tap
                     asm volatile("" : "+v"(c[3]));
+#ifdef D3D_X_NOBLEND   // timing experiment (results wrong): the taps are read and waited for, but not blended
+                    asm volatile("" : : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+                    f4 val = c[0];
+#else
                     f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
+#endif
                     accumulate(s, qq, pair_acc, val, q, i);
                     if (i == NSRC - 1 && MODE != MODE_PAIR) finalize_store(s, qq, ob, q);
                 }
@@ -1197,10 +1256,81 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             }
             if (MODE == MODE_PAIR)
                 store_sbase(uniform64(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
+    };
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+    grp = gi;
+    c0 = gi * CH;
+    load_reference();
+    if (FREERUN && ring) {   // (see D3D_FREERUN)
+        stage(0, wave, NWAVES);
+        __syncthreads();   // start of the pass: window 0 is complete, the counters are clear
+        int kcur = 0;
+        load_step(0);
+        for (;;) {
+            int pg = 0;
+            if (lane == 0) pg = __hip_atomic_fetch_add(ldsi + L::HDR + 28 + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pg = rfl(pg);
+            if (pg >= nplanes) break;
+            if (pg >= (kcur + 1) * SP) {   // first plane this wave takes of a later step
+                while (pg >= (kcur + 1) * SP) ++kcur;
+                ctr_wait(ldsi + L::CNT + MAXSTEPS + kcur, NLOADW);
+                load_step(kcur);
+            }
+            sweep_plane(pg);
+            ctr_add(ldsi + L::CNT + kcur, lane);   // (after this plane's tap reads, in program order)
+        }
+        __syncthreads();   // end of the pass (matches the loaders'): the rings may be overwritten
+        if (wave == 0) {
+            for (int i = lane; i < 2 * MAXSTEPS; i += 64) ldsi[L::CNT + i] = 0;
+            if (lane < 2) ldsi[L::HDR + 28 + lane] = 0;
+        }
+        continue;
+    }
+#if STAGE0_ALL_EFF
+    if (ring) stage(0, wave, NCOMP + NLOADW);  // first window of the pass: every wave of the workgroup stages
+#endif
+    for (int k = 0; k < nsteps; ++k) {
+        if (ring) {
+            long long ta = 0;
+            if (timing) ta = clock64();
+            long long tw0 = 0;
+            if (wtiming) tw0 = clock64();
+#ifndef D3D_X_NOBAR
+            __syncthreads();  // barrier k: rings hold window(k)
+#endif
+            if (wtiming && k > 0) t_ww += clock64() - tw0;
+            if (timing) { t_mark = clock64(); t_w += t_mark - ta; if (k == 0) t_w0 = t_mark - ta; }
+        }
+        load_step(k);
+
+#if D3D_GRAB
+        static_assert(NPIXW <= 2, "one plane counter per step and pixel wave: CNT holds two rows of MAXSTEPS");
+        const int spk = min(SP, nplanes - k * SP);   // planes of this step
+        for (;;) {
+            int jg = 0;
+            if (lane == 0) jg = __hip_atomic_fetch_add(ldsi + L::CNT + pw * MAXSTEPS + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            jg = rfl(jg);
+            if (jg >= spk) break;
+            const int dl_ = k * SP + jg;
+#else
+        for (int j = 0; sub + NSUB * j < SP; ++j) {
+            const int dl_ = k * SP + sub + NSUB * j;
+            if (dl_ >= nplanes) break;
+#endif
+            sweep_plane(dl_);
         }
         if (timing) t_c += clock64() - t_mark;
+        // no loader waves (NLOAD_T = 0): every wave stages its share of the next step's delta once its own planes are done
+        // (the delta's ring slots are not part of the window the other waves are still reading)
+        if constexpr (NLOADW == 0) {
+            if (ring && k + 1 < nsteps) stage(k + 1, wave, NWAVES);
+        }
     }
     __syncthreads();  // end of the pass (matches the loaders')
+#if D3D_GRAB
+    // every wave has left the last step: clear the plane counters for the next pass (its first grab follows a barrier)
+    if (wave == 0) for (int i = lane; i < 2 * MAXSTEPS; i += 64) ldsi[L::CNT + i] = 0;
+#endif
     if (timing) t_mark = clock64();
     }
     if (wtiming && lane == 0) atomicAdd(a.tstats + 8 + wave, (unsigned long long)t_ww);
@@ -1415,6 +1545,9 @@ static int launch_f16(const SweepParams& p, hipStream_t stream) {
 }
 
 int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
+#ifdef D3D_DEV_ONLY_HEADLINE   // development builds (ISA inspection): instantiate the config-2 kernel alone
+    return launch_one<MODE_VARIANCE, 4, 16, float>(p, stream);
+#else
     if (p.C % 8 != 0 || (mode == MODE_PAIR && p.C != 32 && p.C != 16 && p.C != 8)) {
         set_error("tiled kernel unsupported: C=%d", p.C);
         return D3D_ERR_UNSUPPORTED;
@@ -1440,6 +1573,7 @@ int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {
     }
     set_error("internal: bad mode %d", mode);
     return D3D_ERR_INVALID_ARG;
+#endif
 }
 
 }  // namespace d3d

@@ -59,6 +59,8 @@ def test_bench_two_ranks(tmp_path):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["D3D_BENCH_SHARE_GPU"] = "1"    # bench.py refuses to share a card unless asked to
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -69,3 +71,26 @@ def test_bench_two_ranks(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d and "secondary" not in d
     assert d["config"].get("ranks_share_one_gpu", False) == (torch.cuda.device_count() < 2)
+    # every rank reports its own kernel time, wall time and device, so a first multi-GPU run can be read rank by rank
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1]
+    assert all(r["kernel_ms"] > 0 and r["elapsed_s"] > 0 and isinstance(r["device"], str) and r["device"] for r in pr)
+    if torch.cuda.device_count() >= 2:
+        assert pr[0]["device_index"] != pr[1]["device_index"]
+    else:
+        assert pr[0]["device_index"] == pr[1]["device_index"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_share_a_card_silently():
+    """With fewer devices than ranks bench.py exits with a message unless D3D_BENCH_SHARE_GPU=1 (a scaling number measured
+    with two ranks on one card would be meaningless)."""
+    import subprocess
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    env.pop("D3D_BENCH_SHARE_GPU", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "D3D_BENCH_SHARE_GPU" in (res.stderr + res.stdout)
