@@ -87,19 +87,23 @@ class CostRegNet(nn.Module):
         return torch.stack([self.forward_one(x[b].contiguous()) for b in range(x.shape[0])]).unsqueeze(1)
 
 
+AFFINE_DEPTH = True   # stages 2+ hand the sweep (lo, step) maps instead of a [D,h,w] hypothesis volume (ops.AffineDepth)
+
+
 class DepthNet(nn.Module):
     """cas_mvsnet.py:31-78."""
 
     def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, prob_volume_init=None):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
-        assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
-            depth_values.shape[1], num_depth)
+        affine = isinstance(depth_values, (list, tuple))   # one ops.AffineDepth per batch item (see Infer_CascadeMVSNet.forward)
+        nd = depth_values[0].D if affine else depth_values.shape[1]
+        assert nd == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(nd, num_depth)
         if prob_volume_init is not None:
             raise NotImplementedError("prob_volume_init is never passed at inference (cas_mvsnet.py:228-230)")
         depths, confs = [], []
         for b in range(features[0].shape[0]):
             p34 = ops.compose_projections(proj_matrices[b].contiguous())
-            dv = depth_values[b].contiguous()
+            dv = depth_values[b] if affine else depth_values[b].contiguous()
             fb = [f[b].contiguous() for f in features]
             # bf16 mode: the volume leaves the sweep kernel in the form conv0 stages (same rounding, half the bytes)
             cl = getattr(cost_regularization, "channel_last", None)
@@ -159,12 +163,19 @@ class Infer_CascadeMVSNet(nn.Module):
             else:
                 # cas_mvsnet.py:211-226: depth -> full res (bilinear), hypotheses at full res,
                 # then the trilinear resample to the stage grid (identity along D).
+                # The hypotheses are affine in the plane index (module.py:616-631: lo + k * step per pixel) and the resample
+                # is bilinear plane by plane, so the two generating maps travel instead of the [D,h,w] volume: the sweep
+                # and the soft-argmin read 2 maps, not D planes (AFFINE_DEPTH = False: the volume, as the reference).
                 dvs = []
                 for b in range(B):
                     cur = ops.resize_bilinear(depth[b:b + 1].contiguous(), img_h, img_w)[0]
-                    full = ops.depth_range_samples(cur, D, self.depth_intervals_ratio[s] * depth_interval)
-                    dvs.append(full if (h, w) == (img_h, img_w) else ops.resize_bilinear(full, h, w))
-                dv = torch.stack(dvs)
+                    if AFFINE_DEPTH:
+                        aff = ops.depth_range_affine(cur, D, self.depth_intervals_ratio[s] * depth_interval)
+                        dvs.append(aff if (h, w) == (img_h, img_w) else ops.AffineDepth(ops.resize_bilinear(aff.maps, h, w), D))
+                    else:
+                        full = ops.depth_range_samples(cur, D, self.depth_intervals_ratio[s] * depth_interval)
+                        dvs.append(full if (h, w) == (img_h, img_w) else ops.resize_bilinear(full, h, w))
+                dv = dvs if AFFINE_DEPTH else torch.stack(dvs)
             cr = self.cost_regularization if self.share_cr else self.cost_regularization[s]
             out = self.DepthNet(feats, proj_matrices[key], depth_values=dv, num_depth=D, cost_regularization=cr)
             depth = out["depth"]

@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256) void sweep_direct_kernel(SweepParams p) {
     const float invV = 1.0f / (float)(p.n_src + 1);
 
     for (int d = d0; d < d1; ++d) {
-        const float dv = p.depth_mode == D3D_DEPTH_PER_PIXEL ? p.depth[(size_t)d * plane + pix] : p.depth[d];
+        const float dv = p.depth_mode == D3D_DEPTH_PER_PIXEL ? p.depth[(size_t)d * plane + pix]
+                         : p.depth_mode == D3D_DEPTH_AFFINE ? __fadd_rn(p.depth[pix], __fmul_rn((float)d, p.depth[plane + pix]))
+                                                            : p.depth[d];
         float den = 1e-5f;
         if (MODE == MODE_WEIGHTED)
             for (int i = 0; i < p.n_src; ++i) den += p.weights[(size_t)i * plane + pix];
@@ -400,7 +402,7 @@ static int fill_multi(SweepParams& p, const float* const* feats, const float* pr
                       size_t workspace_bytes, int elem_bytes = 4) {
     D3D_REQUIRE(feats && proj34 && depth && out, "null pointer");
     D3D_REQUIRE(n_views >= 2 && n_views <= D3D_MAX_VIEWS, "n_views=%d out of range [2,%d]", n_views, D3D_MAX_VIEWS);
-    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    D3D_REQUIRE(depth_mode >= 0 && depth_mode <= 2, "bad depth_mode %d", depth_mode);
     int rc = check_dims(C, D, h, w);
     if (rc) return rc;
     for (int i = 0; i < n_views; ++i) {

@@ -449,7 +449,6 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     const int tx = b / (a.tiles_y * a.nseg);
     // The workgroup sweeps ALL channel groups of its (patch, depth segment), one after the other: the plan (windows,
     // step size, staging rectangles) does not depend on the channels, so the prologue is paid once.
-    int grp = 0, c0 = 0;  // current channel group / its first channel
     const int x0 = tx * TW, y0 = ty * TH;
     const int ds = seg * a.dseg;
     const int de = min(ds + a.dseg, D);
@@ -470,6 +469,69 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     const unsigned pixo = OUTCL ? (unsigned)pix * (unsigned)p.C * 2u : pixb;   // channel-last cells: h*w*C*2 < 2^32 (checked at launch)
     const float xf = (float)px, yf = (float)py;
 
+    // --- per-lane inputs of the compute waves, requested BEFORE the planning phases below so that their global-memory latency
+    //     (projection rows, the reference features of the first channel group, view weights, hypothesis maps) runs under
+    //     the planning instead of after it: on the cascade's shallow sweeps the prologue is most of a workgroup's life ----
+    //     (Up to four source views.  With six, 36 more registers live across the planning make the plane loop spill.)
+    constexpr bool EARLY_INPUTS = NSRC <= 4 && !F16 && CH <= 16;
+    int grp = 0, c0 = 0;  // current channel group / its first channel
+    Ray ray[NSRC];
+    float T0[NSRC], T1[NSRC], T2[NSRC];
+    auto projection_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) {
+            const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
+            ray[i] = make_ray(M, xf, yf);
+            T0[i] = M[3]; T1[i] = M[7]; T2[i] = M[11];
+            // (kept in vector registers: as scalars they would be live across the whole planning prologue, and the scalar
+            //  file is what spills into the plane loop -- one v_readlane per use)
+            if constexpr (EARLY_INPUTS) asm volatile("" : "+v"(T0[i]), "+v"(T1[i]), "+v"(T2[i]));
+        }
+    };
+    if constexpr (EARLY_INPUTS) projection_rows();
+    f4 r[F16 ? 1 : Q];
+    float rh[F16 ? Q : 1][8];   // fp16 storage: reference features of the group, 8 channels per chunk
+    auto load_reference = [&]() {
+        if (F16) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float t = ldf(reinterpret_cast<const T*>(p.feats[0]) + (size_t)(c0 + 8 * q + k) * plane + pix);
+                    rh[F16 ? q : 0][k] = valid ? t : 0.0f;
+                }
+        } else if (MODE != MODE_WARP) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
+                    r[F16 ? 0 : q][k] = valid ? t : 0.0f;
+                }
+        }
+    };
+    float vw[NSRC];
+    float rden = 0.0f;
+    float aff_lo = 1.0f, aff_step = 0.0f;   // D3D_DEPTH_AFFINE: this lane's pixel
+    auto lane_inputs = [&]() {
+        if (MODE == MODE_WEIGHTED) {
+            float den = 1e-5f;
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) {
+                float t = p.weights[(size_t)min(i, p.n_src - 1) * plane + pix];
+                vw[i] = (valid && i < p.n_src) ? t : 0.0f;
+                den += vw[i];
+            }
+            rden = 1.0f / den;
+        }
+        load_reference();   // group 0
+        if (p.depth_mode == D3D_DEPTH_AFFINE && valid) {
+            aff_lo = p.depth[pix];
+            aff_step = p.depth[plane + pix];
+        }
+    };
+    if (EARLY_INPUTS && !loader) lane_inputs();
+
     // --- zero cell and per-plane depth range of this patch -------------------------------------
     for (int i = tid; i < 2 * STRIDE; i += THREADS) lds[L::ZERO + i] = 0.0f;
     if (p.depth_mode == D3D_DEPTH_PER_PLANE) {
@@ -477,6 +539,34 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             float dv = p.depth[ds + i];
             lds[L::PMIN + i] = dv;
             lds[L::PMAX + i] = dv;
+        }
+    } else if (p.depth_mode == D3D_DEPTH_AFFINE) {
+        // hypotheses lo + k * step per pixel (two maps): each lane reads its pixels' pair ONCE, the per-plane range of the patch
+        // is arithmetic (the per-pixel form below re-reads the patch for every plane: a global-latency chain per plane)
+        float blo[(TW * TH) / 64], bst[(TW * TH) / 64];
+        bool bok[(TW * TH) / 64];
+#pragma unroll
+        for (int k = 0; k < (TW * TH) / 64; ++k) {
+            const int q = lane + 64 * k;
+            const int qx = x0 + (q & 31), qy = y0 + (q >> 5);
+            bok[k] = qx < w && qy < h;
+            const size_t qi = bok[k] ? (size_t)qy * w + qx : 0;
+            blo[k] = p.depth[qi];
+            bst[k] = p.depth[plane + qi];
+        }
+        for (int i = wave; i < nplanes; i += NWAVES) {
+            float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < (TW * TH) / 64; ++k) {
+                const float dv = __fadd_rn(blo[k], __fmul_rn((float)(ds + i), bst[k]));
+                if (bok[k]) { lo = fminf(lo, dv); hi = fmaxf(hi, dv); }
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if (lane == 0) {
+                lds[L::PMIN + i] = lo;
+                lds[L::PMAX + i] = hi;
+            }
         }
     } else {
         for (int i = wave; i < nplanes; i += NWAVES) {
@@ -916,16 +1006,15 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     }
 
     // --- per-lane constants: rays, reference features, weights -------------------------------
-    Ray ray[NSRC];
-    float T0[NSRC], T1[NSRC], T2[NSRC];
+    if constexpr (!EARLY_INPUTS) {
+        projection_rows();
+        lane_inputs();
+    }
     RingView RV[NSRC];
     const int lds0 = lds_base_bytes(lds);
     const float umax = (float)w, vmax = (float)h;   // geo_ring's clamp bounds
 #pragma unroll
     for (int i = 0; i < NSRC; ++i) {
-        const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
-        ray[i] = make_ray(M, xf, yf);
-        T0[i] = M[3]; T1[i] = M[7]; T2[i] = M[11];
         if (ring && i >= p.n_src) {   // unused view of the template: every sample at (-1, -1), see the planner
             ray[i].rx = 0.0f; ray[i].ry = 0.0f; ray[i].rz = 0.0f;
             T0[i] = -1.0f; T1[i] = -1.0f; T2[i] = 1.0f;
@@ -937,39 +1026,6 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
 #ifdef D3D_RV_VGPR   // experiment: the ring constants as (uniform) vector registers instead of spilled scalar registers
         asm volatile("" : "+v"(RV[i].RW), "+v"(RV[i].RH), "+v"(RV[i].rowb), "+v"(RV[i].base));
 #endif
-    }
-    f4 r[F16 ? 1 : Q];
-    float rh[F16 ? Q : 1][8];   // fp16 storage: reference features of the group, 8 channels per chunk
-    auto load_reference = [&]() {
-        if (F16) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float t = ldf(reinterpret_cast<const T*>(p.feats[0]) + (size_t)(c0 + 8 * q + k) * plane + pix);
-                    rh[F16 ? q : 0][k] = valid ? t : 0.0f;
-                }
-        } else if (MODE != MODE_WARP) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
-                    r[F16 ? 0 : q][k] = valid ? t : 0.0f;
-                }
-        }
-    };
-    float vw[NSRC];
-    float rden = 0.0f;
-    if (MODE == MODE_WEIGHTED) {
-        float den = 1e-5f;
-#pragma unroll
-        for (int i = 0; i < NSRC; ++i) {
-            float t = p.weights[(size_t)min(i, p.n_src - 1) * plane + pix];
-            vw[i] = (valid && i < p.n_src) ? t : 0.0f;
-            den += vw[i];
-        }
-        rden = 1.0f / den;
     }
     const float invV = 1.0f / (float)(p.n_src + 1);
     const size_t cstride_b = (p.plane_major ? plane : (size_t)D * plane) * sizeof(T);   // bytes between channels
@@ -1052,6 +1108,8 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             if (p.depth_mode == D3D_DEPTH_PER_PIXEL) {
                 float t = p.depth[(size_t)d * plane + pix];
                 dv = valid ? t : 1.0f;
+            } else if (p.depth_mode == D3D_DEPTH_AFFINE) {
+                dv = __fadd_rn(aff_lo, __fmul_rn((float)d, aff_step));   // (no load in the plane loop)
             } else {
                 dv = lds[L::PMIN + dl_];
             }
@@ -1260,7 +1318,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     for (int gi = 0; gi < a.ngroups; ++gi) {
     grp = gi;
     c0 = gi * CH;
-    load_reference();
+    if (gi > 0) load_reference();   // (group 0: requested ahead of the planning)
     if (FREERUN && ring) {   // (see D3D_FREERUN)
         stage(0, wave, NWAVES);
         __syncthreads();   // start of the pass: window 0 is complete, the counters are clear

@@ -21,6 +21,13 @@ template <> __device__ __forceinline__ void vset<4>(VecT<4>::type& v, int k, flo
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// depth of plane d at pixel i: [D] | [D,plane] | affine (lo, step) maps [2,plane] (include/deep3d_planesweep.h)
+__device__ __forceinline__ float depth_at(const float* __restrict__ depth, int depth_mode, int d, long plane, long i) {
+    if (depth_mode == D3D_DEPTH_PER_PIXEL) return depth[d * plane + i];
+    if (depth_mode == D3D_DEPTH_AFFINE) return __fadd_rn(depth[i], __fmul_rn((float)d, depth[plane + i]));
+    return depth[d];
+}
+
 // cas_mvsnet.py:69-76 (and, WITH_VAR, ucsnet.py:137-151: the spread of the distribution around the regressed depth,
 // exp_variance = lamb * sqrt(sum_d p_d (dv_d - depth)^2) -- one more sweep over D).  Two sweeps over D (max, then
 // exp-sums); the 4-plane window is re-read from cache at the end.
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(256) void softargmin_conf4_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const float e = __expf(vget<VEC>(c, k) - mx[k]);
-            const float dvk = depth_mode == D3D_DEPTH_PER_PIXEL ? vget<VEC>(dv, k) : depth[d];
+            const float dvk = depth_mode == D3D_DEPTH_PER_PIXEL ? vget<VEC>(dv, k) : depth_at(depth, depth_mode, d, plane, i + k);
             den[k] += e;
             dep[k] = fmaf(e, dvk, dep[k]);
             idx[k] = fmaf(e, (float)d, idx[k]);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(256) void softargmin_conf4_kernel(const float* __re
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 const float e = __expf(vget<VEC>(c, k) - mx[k]);
-                const float dvk = depth_mode == D3D_DEPTH_PER_PIXEL ? vget<VEC>(dv, k) : depth[d];
+                const float dvk = depth_mode == D3D_DEPTH_PER_PIXEL ? vget<VEC>(dv, k) : depth_at(depth, depth_mode, d, plane, i + k);
                 const float t = dvk - vget<VEC>(dout, k);
                 var[k] = fmaf(t * t, e * inv[k], var[k]);
             }
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256) void softargmin_conf4_cached_kernel(const floa
 #pragma unroll
     for (int d = 0; d < DC; ++d) {
         c[d] = d < D ? cost[d * plane + i] : -INFINITY;
-        dvv[d] = d < D ? (depth_mode == D3D_DEPTH_PER_PIXEL ? depth[d * plane + i] : depth[d]) : 0.0f;
+        dvv[d] = d < D ? depth_at(depth, depth_mode, d, plane, i) : 0.0f;
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -312,6 +319,17 @@ __global__ __launch_bounds__(256) void depth_samples_pixel_kernel(const float* _
     }
 }
 
+// the two maps the D planes above are generated from (D3D_DEPTH_AFFINE): out[0] = lo, out[1] = step
+__global__ __launch_bounds__(256) void depth_samples_affine_kernel(const float* __restrict__ cur, int D, float interval, long plane,
+                                                                    float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const float half = (float)D / 2.0f * interval;
+    const float lo = cur[i] - half, hi = cur[i] + half;
+    out[i] = lo;
+    out[plane + i] = (hi - lo) / (float)(D - 1);
+}
+
 __global__ void depth_samples_plane_kernel(const float* __restrict__ minmax, int D, float* __restrict__ out) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
@@ -435,7 +453,7 @@ int d3d_softargmin_conf4(const float* cost, const float* depth, int depth_mode, 
                          float* depth_out, float* conf_out, d3d_stream_t stream) {
     D3D_REQUIRE(cost && depth && depth_out && conf_out, "null pointer");
     D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
-    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    D3D_REQUIRE(depth_mode >= 0 && depth_mode <= 2, "bad depth_mode %d", depth_mode);
     long plane = (long)h * w;
     if (launch_softargmin_cached<false>(cost, depth, depth_mode, D, plane, 0.0f, depth_out, conf_out, nullptr, (hipStream_t)stream)) {
     } else if (plane % 4 == 0 && aligned16(cost) && aligned16(depth) && aligned16(depth_out) && aligned16(conf_out))
@@ -452,7 +470,7 @@ int d3d_softargmin_conf4_var(const float* cost, const float* depth, int depth_mo
                              float* depth_out, float* conf_out, float* var_out, d3d_stream_t stream) {
     D3D_REQUIRE(cost && depth && depth_out && conf_out && var_out, "null pointer");
     D3D_REQUIRE(D > 0 && h > 0 && w > 0, "bad dims D=%d h=%d w=%d", D, h, w);
-    D3D_REQUIRE(depth_mode == 0 || depth_mode == 1, "bad depth_mode %d", depth_mode);
+    D3D_REQUIRE(depth_mode >= 0 && depth_mode <= 2, "bad depth_mode %d", depth_mode);
     long plane = (long)h * w;
     if (launch_softargmin_cached<true>(cost, depth, depth_mode, D, plane, lamb, depth_out, conf_out, var_out, (hipStream_t)stream)) {
     } else if (plane % 4 == 0 && aligned16(cost) && aligned16(depth) && aligned16(depth_out) && aligned16(conf_out) && aligned16(var_out))
@@ -542,6 +560,11 @@ int d3d_depth_range_samples(const float* cur_depth, int mode, int D, float inter
         else
             hipLaunchKernelGGL(depth_samples_pixel_kernel<1>, dim3(ceil_div(plane, 256)), dim3(256), 0,
                                (hipStream_t)stream, cur_depth, D, interval, plane, out);
+    } else if (mode == D3D_DEPTH_AFFINE) {
+        D3D_REQUIRE(h > 0 && w > 0, "bad dims h=%d w=%d", h, w);
+        const long plane = (long)h * w;
+        hipLaunchKernelGGL(depth_samples_affine_kernel, dim3(ceil_div(plane, 256)), dim3(256), 0, (hipStream_t)stream, cur_depth, D,
+                           interval, plane, out);
     } else {
         set_error("bad mode %d", mode);
         return D3D_ERR_INVALID_ARG;

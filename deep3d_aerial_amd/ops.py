@@ -11,7 +11,23 @@ import torch
 
 from . import _lib
 
-PER_PLANE, PER_PIXEL = 0, 1
+PER_PLANE, PER_PIXEL, AFFINE = 0, 1, 2
+
+
+class AffineDepth:
+    """Per-pixel depth hypotheses in their generating form (include/deep3d_planesweep.h, D3D_DEPTH_AFFINE): `maps` is
+    [2,h,w] = (lo, step) and plane k of a pixel lies at lo + k * step, k < D -- what module.py:616-631 builds its
+    [D,h,w] volume from.  Every op that takes a depth volume takes this in its place and reads two maps instead of D."""
+
+    def __init__(self, maps, D):
+        if not (isinstance(maps, torch.Tensor) and maps.dim() == 3 and maps.shape[0] == 2):
+            raise ValueError("AffineDepth maps must be [2,h,w]")
+        self.maps, self.D = maps, int(D)
+
+    def volume(self):
+        """The [D,h,w] volume these maps stand for (same two roundings as the kernels': product, then sum)."""
+        k = torch.arange(self.D, dtype=torch.float32, device=self.maps.device).view(-1, 1, 1)
+        return (self.maps[0:1] + k * self.maps[1:2]).contiguous()
 
 
 def _stream():
@@ -63,6 +79,10 @@ def _opt(t, name):
 
 
 def _depth(depth, h, w):
+    if isinstance(depth, AffineDepth):
+        if tuple(depth.maps.shape[1:]) != (h, w):
+            raise ValueError("affine depth maps must be [2,%d,%d] (got %s)" % (h, w, tuple(depth.maps.shape)))
+        return _chk(depth.maps, "depth.maps", 3), AFFINE, depth.D
     if depth.dim() == 1:
         return _chk(depth, "depth"), PER_PLANE, depth.shape[0]
     if depth.dim() == 3:
@@ -308,6 +328,17 @@ def depth_range_samples(cur_depth, D, interval, h=0, w=0):
                                                  w, _chk(out, "out"), _stream())
     _lib.check(rc, "d3d_depth_range_samples")
     return out
+
+
+def depth_range_affine(cur_depth, D, interval):
+    """cur_depth [h,w] -> AffineDepth([2,h,w] = (lo, step), D): the two maps module.py:616-631 generates its D planes
+    from (depth_range_samples(cur_depth, D, interval) == depth_range_affine(cur_depth, D, interval).volume(), bit for bit)."""
+    h, w = cur_depth.shape
+    out = torch.empty((2, h, w), dtype=torch.float32, device=cur_depth.device)
+    rc = _lib.load().d3d_depth_range_samples(_chk(cur_depth, "cur_depth", 2), AFFINE, D, float(interval), h, w,
+                                             _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_depth_range_samples")
+    return AffineDepth(out, D)
 
 
 def resize_bilinear(x, H, W):

@@ -21,6 +21,12 @@
  *   - Depth hypotheses are given either per plane (depth_mode = D3D_DEPTH_PER_PLANE,
  *     pointer to [D]) or per pixel (D3D_DEPTH_PER_PIXEL, pointer to [D,h,w]); both are
  *     accepted by the reference's homo_warping_float (module.py:520-521,539).
+ *     D3D_DEPTH_AFFINE is the per-pixel form without the volume: the pointer is to [2,h,w] =
+ *     (lo, step) maps and plane k of pixel (y,x) lies at lo[y,x] + k * step[y,x] (fp32, the
+ *     product rounded, then the sum: exactly the statement of module.py:616-631, whose
+ *     hypotheses are affine in the plane index).  A sweep in this mode reads two maps instead
+ *     of D planes, and its results are bit-identical to the D3D_DEPTH_PER_PIXEL sweep over
+ *     the volume those maps generate.
  *   - proj34 is the composed homography of module.py:528-530,
  *     (src_proj @ inverse(ref_proj))[:3,:4] = [rot | trans], row-major 12 floats per
  *     source view, in DEVICE memory (d3d_compose_projections produces it).
@@ -49,6 +55,7 @@ extern "C" {
 
 #define D3D_DEPTH_PER_PLANE 0
 #define D3D_DEPTH_PER_PIXEL 1
+#define D3D_DEPTH_AFFINE 2
 
 #define D3D_MAX_VIEWS 16
 
@@ -180,6 +187,10 @@ int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const fl
  * mode D3D_DEPTH_PER_PLANE: cur_depth is [2] = (min,max) -> out [D] = linspace.
  * mode D3D_DEPTH_PER_PIXEL: cur_depth is [h,w] -> out [D,h,w],
  *     lo = cur - D/2*interval, hi = cur + D/2*interval, out[k] = lo + k*(hi-lo)/(D-1).
+ * mode D3D_DEPTH_AFFINE: cur_depth is [h,w] -> out [2,h,w] = (lo, (hi-lo)/(D-1)): the two maps the
+ *     D planes of the per-pixel mode are generated from (the sweep, soft-argmin and resize entry
+ *     points take them in place of the volume: cas_mvsnet.py:224-226 resamples the volume
+ *     bilinearly plane by plane, which commutes with the affine form).
  */
 int d3d_depth_range_samples(const float* cur_depth, int mode, int D, float interval, int h, int w, float* out,
                             d3d_stream_t stream);

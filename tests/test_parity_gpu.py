@@ -249,6 +249,111 @@ def test_full_size_properties(ops):
     assert out.min().item() >= -1e-4
 
 
+@pytest.mark.parametrize("path_", ["tiled", "direct", "auto"])
+def test_full_size_config2_against_oracle_planes(ops, oracle, path_):
+    """BASELINE config 2 at FULL size (5 views x 384 planes, 32 x 688 x 464) against the CPU oracle on six planes spread
+    over the sweep (start, both sides of two depth-segment boundaries, end), on each kernel family: the comparison the
+    small cases make, at the size the metric is quoted on."""
+    V, C, h, w, D = 5, 32, 688, 464, 384
+    proj, dv = S.make_scene(V, h, w, D, seed=0)
+    feats_h = S.make_features(V, C, h, w, seed=0)
+    feats = [dev(f) for f in feats_h]
+    p34 = ops.compose_projections(dev(proj))
+    p34_host = host(p34).reshape(-1, 3, 4)
+    depth_h = S.uniform_depths(dv, D)
+    planes = [0, 127, 128, 255, 256, 383]
+    want = oracle.variance_volume(feats_h[0], feats_h[1:], p34_host, depth_h[planes])
+    if path_ == "auto":
+        os.environ.pop("D3D_FORCE_PATH", None)
+    else:
+        os.environ["D3D_FORCE_PATH"] = path_
+    try:
+        if path_ == "direct":   # (the gather kernel takes ~25 ms per full sweep: the six planes alone)
+            got = host(ops.variance_volume(feats, p34, dev(depth_h[planes])))
+        else:                   # the full sweep, as benchmarked; the six planes are read back
+            full = ops.variance_volume(feats, p34, dev(depth_h))
+            got = host(full[:, planes])
+            del full
+    finally:
+        os.environ.pop("D3D_FORCE_PATH", None)
+    assert np.abs(got - want).max() <= 2 * ABS_GATHER
+    assert rel_l1(got, want) <= REL_VOLUME
+
+
+def test_full_size_config5_against_oracle_planes(ops, oracle):
+    """BASELINE config 5 (7 views x 512 planes, 32 x 928 x 688, fp16 storage) at full size against the CPU oracle on four
+    planes: the oracle works on the fp16-rounded features in fp32 and the result is compared after one fp16 rounding."""
+    V, C, h, w, D = 7, 32, 928, 688, 512
+    proj, dv = S.make_scene(V, h, w, D, seed=5)
+    feats16 = [torch.from_numpy(f).cuda().half() for f in S.make_features(V, C, h, w, seed=5)]
+    feats_h = [f.float().cpu().numpy() for f in feats16]
+    p34 = ops.compose_projections(dev(proj))
+    p34_host = host(p34).reshape(-1, 3, 4)
+    depth_h = S.uniform_depths(dv, D)
+    planes = [0, 170, 341, 511]
+    want = oracle.variance_volume(feats_h[0], feats_h[1:], p34_host, depth_h[planes])
+    os.environ["D3D_FORCE_PATH"] = "tiled"
+    try:
+        full = ops.variance_volume(feats16, p34, dev(depth_h))
+        got = full[:, planes].float().cpu().numpy()
+        del full
+    finally:
+        os.environ.pop("D3D_FORCE_PATH", None)
+    # fp16 output: half an ulp of the value (2^-11 relative) on top of the fp32 gather tolerance
+    assert np.all(np.abs(got - want) <= 2 * ABS_GATHER + 2.0 ** -10 * np.abs(want))
+    assert rel_l1(got, want) <= REL_VOLUME + 2.0 ** -11
+
+
+AFFINE_CASES = [
+    # V, C, h, w, D, sweep_px, yaw   (ring kernel: 16-channel groups / 8-channel groups + 32 x 8 patches; direct kernel)
+    (5, 16, 72, 88, 32, 8.0, 1.0),
+    (5, 8, 64, 96, 8, 1.5, 1.0),
+    (3, 32, 40, 56, 12, 6.0, 4.0),
+    (4, 12, 33, 70, 5, 3.0, 10.0),
+]
+
+
+@pytest.mark.parametrize("case", AFFINE_CASES, ids=lambda c: "V%d_C%d_%dx%d_D%d" % c[:5])
+def test_affine_depth_mode_is_the_per_pixel_mode_without_the_volume(ops, oracle, path, case):
+    """D3D_DEPTH_AFFINE (hypotheses lo + k * step per pixel, module.py:616-631, given as two maps): every op that takes a
+    [D,h,w] hypothesis volume gives bit-identical results from the two maps that generate it, and both match the oracle."""
+    V, C, h, w, D, sweep, yaw = case
+    proj, dv = S.make_scene(V, h, w, D, sweep_px=sweep, seed=V * 10 + C, yaw_deg=yaw)
+    feats = S.make_features(V, C, h, w, seed=C + D)
+    rng = np.random.default_rng(D + C)
+    span = float(dv[1] - dv[0])
+    cur = (0.5 * (dv[0] + dv[1]) + 0.25 * span * rng.uniform(-1, 1, (h, w))).astype(np.float32)
+    aff = ops.depth_range_affine(dev(cur), D, span / 4.0 / D)
+    vol = ops.depth_range_samples(dev(cur), D, span / 4.0 / D)
+    assert torch.equal(aff.volume(), vol)                       # the maps generate the volume bit for bit
+    fd = [dev(f) for f in feats]
+    p34 = ops.compose_projections(dev(proj))
+    p34_host = host(p34).reshape(-1, 3, 4)
+
+    va = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, aff), path)
+    vv = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, vol), path)
+    assert torch.equal(va, vv)
+    want = oracle.variance_volume(feats[0], feats[1:], p34_host, host(vol))
+    assert rel_l1(host(va), want) <= REL_VOLUME
+    vw = dev(rng.uniform(0.02, 1.0, (V - 1, h, w)))
+    assert torch.equal(_run_or_skip_unsupported(lambda: ops.weighted_corr(fd, p34, vw, aff), path),
+                       _run_or_skip_unsupported(lambda: ops.weighted_corr(fd, p34, vw, vol), path))
+    if C % 8 == 0 and path != "direct":
+        assert torch.equal(ops.variance_volume_cl(fd, p34, aff), ops.variance_volume_cl(fd, p34, vol))
+    cost = dev(rng.standard_normal((D, h, w)) * 3.0)
+    da, ca = ops.softargmin_conf4(cost, aff)
+    dvv, cv = ops.softargmin_conf4(cost, vol)
+    assert torch.equal(da, dvv) and torch.equal(ca, cv)
+    d3, c3, v3 = ops.softargmin_conf4_var(cost, aff, 1.5)
+    d4, c4, v4 = ops.softargmin_conf4_var(cost, vol, 1.5)
+    assert torch.equal(d3, d4) and torch.equal(c3, c4) and torch.equal(v3, v4)
+    # the resampled maps stand for the resampled volume (cas_mvsnet.py:224-226: bilinear, plane by plane) up to rounding
+    H2, W2 = 2 * (h // 4), 2 * (w // 4)
+    vol2 = ops.resize_bilinear(vol, H2, W2)
+    aff2 = ops.AffineDepth(ops.resize_bilinear(aff.maps, H2, W2), D)
+    assert rel_l1(host(aff2.volume()), host(vol2)) <= 1e-6
+
+
 def test_full_size_config5_fp16_ring(ops):
     """BASELINE config 5 on its own terms: 7 views x 512 planes, features 32 x 928 x 688, fp16 storage, through the
     LDS-ring kernel (fp16 ring cells, fp32 arithmetic).  Size-independent properties, as above."""
@@ -693,6 +798,25 @@ def test_model_forward_matches_reference(ops, tag):
     if "adamvs" in tag:
         vw = torch.stack([t[0, 0] for t in out["stage1"]["pair_confidence"]])
         assert rel_l1(host(vw), g["stage1_view_weights"]) <= REL_MODEL
+
+
+def test_casmvsnet_affine_hypotheses_equal_the_volume_path(ops, monkeypatch):
+    """Infer_CascadeMVSNet hands stages 2 and 3 (lo, step) maps instead of [D,h,w] hypothesis volumes (cas_mvsnet.AFFINE_DEPTH):
+    the two forms of the same forward agree to rounding of the resampled maps (the goldens above pin the default form)."""
+    from deep3d_aerial_amd import cas_mvsnet
+
+    g = load_golden("model_casmvsnet_v5")
+    net = _fill(cas_mvsnet.Infer_CascadeMVSNet(num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(cas_mvsnet, "AFFINE_DEPTH", flag)
+        with torch.no_grad():
+            outs[flag] = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    for s in ("stage2", "stage3"):
+        assert rel_l1(host(outs[True][s]["depth"]), host(outs[False][s]["depth"])) <= 2e-6, s
+        assert rel_l1(host(outs[True][s]["photometric_confidence"]), host(outs[False][s]["photometric_confidence"])) <= 1e-4, s
+    assert torch.equal(outs[True]["stage1"]["depth"], outs[False]["stage1"]["depth"])
 
 
 @pytest.mark.parametrize("model", ["casmvsnet", "adamvs"])
