@@ -956,7 +956,9 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
 #if D3D_DECOUPLE
 #error "the counter hand-off experiment predates the channel-group loop (its counters are per step, not per pass)"
 #endif
-    if (loader) {
+    // (In gather mode -- rings do not fit, or p.z <= 0 at a corner -- there is nothing to stage: the loader waves sweep
+    //  planes too, see GATHER_ALL below.)
+    if (loader && ring) {
         // (Raising the loaders' issue priority with s_setprio was measured: their decode time halves,
         // but the compute waves lose the same slots and the kernel gets 5 % slower -- left at default.)
         for (int gi = 0; gi < a.ngroups; ++gi) {
@@ -1009,6 +1011,8 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     if constexpr (!EARLY_INPUTS) {
         projection_rows();
         lane_inputs();
+    } else {
+        if (loader) lane_inputs();   // (gather mode: the loader waves sweep planes, and skipped their inputs above)
     }
     RingView RV[NSRC];
     const int lds0 = lds_base_bytes(lds);
@@ -1342,6 +1346,16 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             for (int i = lane; i < 2 * MAXSTEPS; i += 64) ldsi[L::CNT + i] = 0;
             if (lane < 2) ldsi[L::HDR + 28 + lane] = 0;
         }
+        continue;
+    }
+    if (!ring) {
+        // GATHER_ALL: taps straight from global memory, no windows, no steps, no barriers inside the pass: every wave of the
+        // workgroup (the loader waves too) takes planes sub, sub + NW, ... of its pixel rows
+        constexpr int NW = NWAVES / NPIXW;
+        static_assert(NWAVES % NPIXW == 0, "the loader waves must come in whole sets of pixel waves");
+        load_step(0);
+        for (int dl_ = wave / NPIXW; dl_ < nplanes; dl_ += NW) sweep_plane(dl_);
+        __syncthreads();   // end of the pass (uniform with the ring passes of other workgroups: one barrier per pass)
         continue;
     }
 #if STAGE0_ALL_EFF
