@@ -125,6 +125,28 @@ def fill_state_dict_(state_dict, seed):
     return state_dict
 
 
+LOGIT_LAYER_SUFFIXES = (".prob.weight", ".prob.bias", ".upconv2d.weight", ".upconv2d.bias")
+
+
+def sharpen_state_dict_(state_dict, gain):
+    """Multiplies the last (logit) layer of every regulariser by `gain`, in place: cost_regularization.N.prob of the 3-D UNets
+    (cas_mvsnet.py:95, ucsnet.py:70), reg_fuse.upconv2d / reg.prob of AdaMVS (adamvs.py:412-413, 216) and
+    cost_regularization.N.upconv2d of RED-Net (msrednet.py:352).  With the He-scaled weights of fill_state_dict_ the softmax /
+    exp-sum over the depth planes is nearly flat (confidence ~ 4/D), and a flat distribution regresses to the middle of the
+    hypothesis range whatever the regulariser computed; with the logits scaled up the distribution is peaked and the regressed
+    depth follows the arg-max plane -- the "peaked" model fixtures (tests/golden/make_golden.py) use this on the reference's
+    modules and the tests on this package's, which have the same keys."""
+    import torch
+
+    n = 0
+    with torch.no_grad():
+        for k, t in state_dict.items():
+            if k.endswith(LOGIT_LAYER_SUFFIXES):
+                t.mul_(float(gain))
+                n += 1
+    return n
+
+
 def make_fusion_scene(h, w, n_src=3, seed=0, noise=0.004, src_scale=1.0):
     """A reference view and n_src source views of one tilted ground plane, as the fusion step reads them
     (fuse/fusion_3d_normal.py:425-505): per view a depth map [h,w], a camera-space normal map [h,w,3], K [3,3] and

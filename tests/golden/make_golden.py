@@ -372,8 +372,24 @@ def model_inputs(V, H, W, num_depth, seed):
     return imgs.astype(np.float32), pm, dv[None]
 
 
-def gen_models(only=None):
+PEAKED_GAIN = {"casmvsnet": 20.0, "adamvs": 20.0, "msrednet": 5.0}   # (the slice families regress with exp() and no
+                                                                        # max-subtraction, SURVEY.md F10: larger gains overflow)
+
+
+def gen_models_peaked():
+    """The "peaked" variants of the V = 5 model fixtures: same inputs protocol, same seeded weights, but the last (logit) layer
+    of every regulariser is scaled by PEAKED_GAIN (synthetic.sharpen_state_dict_), so that the distribution over the depth
+    planes is peaked and the regressed depth follows the arg-max plane instead of sitting at the middle of a flat range
+    (hard parts: random-weight volumes are a weak test of arg-max-sensitive outputs)."""
+    gen_models(peaked=True)
+
+
+def gen_models(only=None, peaked=False):
     for tag, ctor, V, nd, seed in [
+        ("model_casmvsnet_v5_peaked", lambda nd: RC.Infer_CascadeMVSNet(num_depth=nd), 5, 384, 7102),
+        ("model_adamvs_v5_peaked", lambda nd: RA.Infer_AdaMVSNet(num_depth=nd), 5, 384, 7104),
+        ("model_msrednet_v5_peaked", lambda nd: RR.Infer_CascadeREDNet(num_depth=nd), 5, 384, 7106),
+    ] if peaked else [
         ("model_casmvsnet_v3", lambda nd: RC.Infer_CascadeMVSNet(num_depth=nd), 3, 64, 7001),
         ("model_casmvsnet_v5", lambda nd: RC.Infer_CascadeMVSNet(num_depth=nd), 5, 384, 7002),
         ("model_adamvs_v3", lambda nd: RA.Infer_AdaMVSNet(num_depth=nd), 3, 64, 7003),
@@ -386,10 +402,18 @@ def gen_models(only=None):
         H, W = 64, 96
         net = ctor(nd).eval()
         S.fill_state_dict_(net.state_dict(), seed)
+        gain = PEAKED_GAIN[tag.split("_")[1]] if peaked else 1.0
+        if peaked:
+            assert S.sharpen_state_dict_(net.state_dict(), gain) > 0
         imgs, pm, dv = model_inputs(V, H, W, nd, seed)
         with torch.no_grad():
             o = net(T(imgs), {k: T(v) for k, v in pm.items()}, T(dv))
-        out = {"imgs": imgs, "depth_values": dv, "seed": np.array(seed), "num_depth": np.array(nd),
+        if peaked:
+            c1 = o["stage1"]["photometric_confidence"].numpy()
+            print("  %s: logit gain %g, stage-1 confidence median %.3f (flat: %.3f), depth std %.1f" % (
+                tag, gain, float(np.median(c1)), (4.0 if "casmvsnet" in tag else 1.0) / 48.0, float(o["depth"].std())))
+            assert np.isfinite(o["depth"].numpy()).all()
+        out = {"imgs": imgs, "depth_values": dv, "seed": np.array(seed), "num_depth": np.array(nd), "logit_gain": np.array(gain),
                "n_state_keys": np.array(len(net.state_dict())),
                "state_keys": np.array(list(net.state_dict().keys())),
                "state_shapes": np.array([",".join(map(str, v.shape)) for v in net.state_dict().values()])}
@@ -457,7 +481,7 @@ def gen_ucsnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models", "ucsnet"]
+    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models", "models_peaked", "ucsnet"]
     for wname in which:
         if wname.startswith("model_"):
             gen_models(only=[wname])

@@ -22,7 +22,9 @@ pytestmark = pytest.mark.gpu
 ABS_GATHER = 1e-3     # max abs error of a warped N(0,1) white-noise feature
 REL_VOLUME = 5e-5     # relative L1 of a whole cost volume
 REL_DEPTH = 1e-5      # relative L1 of regressed depth maps (op level)
-REL_MODEL = 1e-3      # north_star: depth / confidence of a full cascade vs the reference
+REL_MODEL = 1e-3      # north_star: depth / confidence of a full cascade vs the reference (the bf16 mode is held to this)
+REL_MODEL_FP32 = 2e-5  # fp32 mode, depth: ~10 x the measured error of the model fixtures (1.3e-7 .. 1.4e-6 over 6 fixtures x 3 stages)
+REL_CONF_FP32 = 4e-4   # fp32 mode, confidence: ~10 x measured (3e-7 .. 3.5e-5; the .long() window index is discontinuous)
 
 
 @pytest.fixture(scope="module")
@@ -790,14 +792,52 @@ def test_model_forward_matches_reference(ops, tag):
     with torch.no_grad():
         out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
     assert out["depth"].shape == (1,) + g["depth"].shape
+    meas = []
     for s in ("stage1", "stage2", "stage3"):
-        assert rel_l1(host(out[s]["depth"][0]), g[s + "_depth"]) <= REL_MODEL, s
-        assert rel_l1(host(out[s]["photometric_confidence"][0]), g[s + "_conf"]) <= 5 * REL_MODEL, s
-    assert rel_l1(host(out["depth"][0]), g["depth"]) <= REL_MODEL
-    assert rel_l1(host(out["photometric_confidence"][0]), g["photometric_confidence"]) <= 5 * REL_MODEL
+        ed, ec = rel_l1(host(out[s]["depth"][0]), g[s + "_depth"]), rel_l1(host(out[s]["photometric_confidence"][0]), g[s + "_conf"])
+        meas.append("%s depth %.1e conf %.1e" % (s, ed, ec))
+        assert ed <= REL_MODEL_FP32, (s, meas)
+        assert ec <= REL_CONF_FP32, (s, meas)
+    print("\n%s rel-L1: %s" % (tag, "; ".join(meas)))
+    assert rel_l1(host(out["depth"][0]), g["depth"]) <= REL_MODEL_FP32
+    assert rel_l1(host(out["photometric_confidence"][0]), g["photometric_confidence"]) <= REL_CONF_FP32
     if "adamvs" in tag:
         vw = torch.stack([t[0, 0] for t in out["stage1"]["pair_confidence"]])
         assert rel_l1(host(vw), g["stage1_view_weights"]) <= REL_MODEL
+
+
+@pytest.mark.parametrize("tag", ["model_casmvsnet_v5_peaked", "model_adamvs_v5_peaked", "model_msrednet_v5_peaked"])
+def test_model_forward_peaked_matches_reference(ops, tag):
+    """The arg-max-sensitive model fixtures: the reference run with the logit layer of every regulariser scaled up
+    (synthetic.sharpen_state_dict_; tests/golden/make_golden.py models_peaked), so that the distribution over the depth planes
+    is peaked -- stage-1 confidence 0.97 / 0.15 / 0.38 against 0.08 / 0.02 / 0.02 for the flat fixtures above -- and the
+    regressed depth follows the regulariser's arg-max instead of resting at the middle of the hypothesis range.  The error is
+    measured the way the reference scores depth maps (utils.py:299-328): in units of the finest (stage-3) depth interval."""
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+    from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
+
+    g = load_golden(tag)
+    ctor = {"casmvsnet": Infer_CascadeMVSNet, "adamvs": Infer_AdaMVSNet, "msrednet": Infer_CascadeREDNet}[tag.split("_")[1]]
+    net = ctor(num_depth=int(g["num_depth"]))
+    S.fill_state_dict_(net.state_dict(), int(g["seed"]))
+    assert S.sharpen_state_dict_(net.state_dict(), float(g["logit_gain"])) > 0
+    net = net.cuda().eval()
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    with torch.no_grad():
+        out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    interval = float(g["depth_values"][0, -1] - g["depth_values"][0, 0]) / float(g["num_depth"])   # stage 3: ratio 1
+    report = []
+    for s in ("stage1", "stage2", "stage3"):
+        err = np.abs(host(out[s]["depth"][0]) - g[s + "_depth"]) / interval
+        cerr = np.abs(host(out[s]["photometric_confidence"][0]) - g[s + "_conf"])
+        report.append("%s: depth error %.2e intervals (max %.2e, %.4f of the pixels > 0.5), confidence error %.2e" % (
+            s, err.mean(), err.max(), (err > 0.5).mean(), cerr.mean()))
+        assert err.mean() <= 0.03, report                   # measured 4e-4 .. 2.7e-3 (fp32 mode); the budget asked for: 0.05
+        assert (err > 0.5).mean() <= 0.001, report          # (a pixel whose arg-max plane flipped: none measured)
+        assert cerr.mean() <= 5e-3, report
+    print("\n" + tag + "\n  " + "\n  ".join(report))
+    assert float(np.median(g["stage1_conf"])) >= 3.0 * (4.0 if "casmvsnet" in tag else 1.0) / 48.0   # the fixture IS peaked
 
 
 def test_casmvsnet_affine_hypotheses_equal_the_volume_path(ops, monkeypatch):
