@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from deep3d_aerial_amd import ops, synthetic as S  # noqa: E402
+from deep3d_aerial_amd import config, ops, synthetic as S  # noqa: E402
 
 V, C, D, H_FEAT, W_FEAT = 5, 32, 384, 688, 464
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -336,7 +336,7 @@ def main():
             "config": {"workload": "config 2: fused homography-warp + variance, 5 views x 384 planes, "
                                    "features 32x688x464 fp32 (2752x1856 image at 1/4 res), one reference view per "
                                    "step per GPU", "voxels_per_step_per_gpu": voxels,
-                       "in_frame_fraction": round(in_frame, 4), "path": os.environ.get("D3D_FORCE_PATH", "auto"),
+                       "in_frame_fraction": round(in_frame, 4), "path": (config.switches.get("D3D_FORCE_PATH") or "auto"),
                        **({"ranks_share_one_gpu": True} if shared else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profile": traffic_info,

@@ -11,6 +11,10 @@ namespace d3d {
 
 void set_error(const char* fmt, ...);
 int hip_status(hipError_t e, const char* what);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size reached): a launch path calls this before
+// every launch, the runtime is asked only when the kernel has not been given that much on the current device yet
+// (a CasMVSNet view made ~800 of these calls, ~1 us of host time each).
+int ensure_dynamic_lds(const void* kernel, int bytes);
 
 #define D3D_REQUIRE(cond, ...)                \
     do {                                      \

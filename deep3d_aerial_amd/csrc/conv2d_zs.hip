@@ -360,8 +360,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
         return D3D_ERR_UNSUPPORTED;
     }
     auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3>;
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int gx = ceil_div(p.W, TX), nty = ceil_div(p.H, TYZ);
@@ -793,8 +792,7 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     constexpr int lds = (X3 ? 1 : 2) * (32 * MG + KS - 2) * (2 * TYZ + KS - 2) * CS + NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32, X3, KS, MG>;
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int Ho = (p.H - 1) / 2 + 1, Wo = (p.W - 1) / 2 + 1;
@@ -817,8 +815,7 @@ static int launch_tz(const Z2Params& p, hipStream_t stream) {
     constexpr int lds = (X3 && CI > 8 ? 1 : 2) * (K4 ? (TXI + 2) * 10 : 33 * 9) * CS + NFRAG * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = convt2d_zs_bf16_kernel<CI, F32, X3, K4, XF>;
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int gx = ceil_div(p.W, TXI), nty = ceil_div(p.H, TYZ);

@@ -347,8 +347,7 @@ static int launch(const C8Params& p, hipStream_t stream) {
     constexpr int TXk = 16 * MGN, PXk = TXk + 2;
     const int lds = 2 * PXk * PY * CS + (WG ? 0 : (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
     auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF, CO8>;
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     C8Params q = p;
     const int gx = ceil_div(p.W, TXk), gy = ceil_div(p.H, TY);

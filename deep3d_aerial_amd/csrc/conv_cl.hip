@@ -224,8 +224,7 @@ static int launch_s2(const S2Params& p, hipStream_t stream) {
     constexpr int TXOk = 16 * MGK, PXIk = 2 * TXOk + 1;
     const int lds = 2 * PXIk * PYI * CS + (WG ? 0 : 3 * NKB * NTN * 64 * 16);
     auto kern = conv3d_s2_cl_kernel<CI, NTN, MGK, WG>;
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     S2Params q = p;
     const int gx = ceil_div(p.Wo, TXOk), gy = ceil_div(p.Ho, TYO);

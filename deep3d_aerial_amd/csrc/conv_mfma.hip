@@ -270,9 +270,7 @@ static int launch_cfg(const ConvMParams& pin, hipStream_t stream) {
     auto kern = conv_mfma_kernel<MT, CK>;
     static int attr_bytes = 0;
     if (bytes > attr_bytes) {
-        int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
         if (rc != D3D_OK) return rc;
         attr_bytes = 160 * 1024;
     }

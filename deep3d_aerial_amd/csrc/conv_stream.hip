@@ -802,9 +802,7 @@ static int launch_stream(ConvZParams& p, hipStream_t stream) {
     auto kern = conv_stream_kernel<MT, NT, NS, CK, BF16, SPLIT>;
     static bool attr_set = false;
     if (!attr_set) {
-        int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                            "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
         if (rc != D3D_OK) return rc;
         attr_set = true;
     }

@@ -316,8 +316,7 @@ static int launch(const T2Params& p, hipStream_t stream) {
     constexpr int CS = CI * 2 + 16;
     const int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16;
     auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD>;
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     T2Params q = p;
     const int gx = ceil_div(p.W, TXI), gy = ceil_div(p.H, TYI);

@@ -12,8 +12,11 @@
 
 #include "common.h"
 
+#include <array>
 #include <atomic>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 namespace d3d {
 
@@ -30,6 +33,27 @@ int hip_status(hipError_t e, const char* what) {
     if (e == hipSuccess) return D3D_OK;
     set_error("%s: %s", what, hipGetErrorString(e));
     return D3D_ERR_HIP;
+}
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    constexpr int MAXDEV = 16;
+    static std::mutex mu;
+    static std::unordered_map<const void*, std::array<int, MAXDEV>> granted;   // per-device cache, nothing else global
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev >= 0 && dev < MAXDEV) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = granted.find(kernel);
+        if (it != granted.end() && it->second[dev] >= bytes) return D3D_OK;
+    }
+    const int rc = hip_status(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes),
+                              "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    if (rc == D3D_OK && dev >= 0 && dev < MAXDEV) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto& slot = granted[kernel];   // (value-initialised to zeros)
+        if (slot[dev] < bytes) slot[dev] = bytes;
+    }
+    return rc;
 }
 
 // defined in planesweep_tiled.hip: returns D3D_ERR_UNSUPPORTED when the shape is outside

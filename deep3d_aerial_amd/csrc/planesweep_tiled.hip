@@ -1494,8 +1494,7 @@ static int launch_one(const SweepParams& p, hipStream_t stream) {
     auto kern = sweep_tiled_kernel<MODE, NSRC, CH, T, OUTCL, NSUBK, NLOADK, NPIXK>;
     if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
     // per device and idempotent: set on every launch (no process-global "done" flag that a second GPU would miss)
-    int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES),
-                        "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_BYTES);
     if (rc != D3D_OK) return rc;
     TiledArgs a;
     a.ngroups = p.C / CH;

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import config as _cfg
 from . import ops
 
 
@@ -27,7 +28,7 @@ def _feature_precision():
     lets them follow the global mode)."""
     import contextlib
 
-    return contextlib.nullcontext() if os.environ.get("D3D_FEATURE_PRECISION", "fp32") == "follow" else ops.fp32_convs()
+    return contextlib.nullcontext() if _cfg.get("D3D_FEATURE_PRECISION") == "follow" else ops.fp32_convs()
 
 
 def compose_batch(proj_matrices):
@@ -228,7 +229,7 @@ def feature_conv(conv, x, bn=None, relu=False, skip=None, x2=None):
     if (conv.kernel_size == (K, K) and K % 2 == 1 and conv.padding == (K // 2, K // 2) and conv.stride in ((1, 1), (2, 2))
             and conv.dilation == (1, 1) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
             and conv.out_channels <= 64 and (bn is None or not bn.training)
-            and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+            and _cfg.get("D3D_FEATURE_CONV") != "miopen"):
         if bn is not None:
             s, t = folded_bn(bn)
         else:
@@ -263,7 +264,7 @@ def lateral_upsample_add(conv, x, coarse):
     """`F.interpolate(coarse, scale_factor=2, mode="nearest") + conv(x)` (module.py:742,746 of the reference) with the
     upsampling folded into the 1x1 convolution's epilogue where the fused kernel takes the shape."""
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and x.is_cuda and x.dtype == torch.float32
-            and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+            and _cfg.get("D3D_FEATURE_CONV") != "miopen"):
         outs = []
         for b in range(x.shape[0]):
             y = ops.conv1x1_upskip(x[b].contiguous(), conv.weight, conv.bias, coarse[b].contiguous())
@@ -303,7 +304,7 @@ def fpn_output(lateral, x, coarse, head, wide=None):
             and head.stride == (1, 1) and head.dilation == (1, 1) and head.groups == 1 and x.is_cuda and x.dtype == torch.float32
             and x.shape[1] in (8, 16) and Cm == 32 and Co <= 16 and coarse.shape[1] == Cm and x.shape[3] % 8 == 0
             and x.shape[2] == 2 * coarse.shape[2] and x.shape[3] == 2 * coarse.shape[3] and _feature_precision_is_fp32()
-            and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen" and os.environ.get("D3D_FPN_SPLIT", "1") != "0"):
+            and _cfg.get("D3D_FEATURE_CONV") != "miopen" and _cfg.get("D3D_FPN_SPLIT") != "0"):
         wt, wb, bt = _fpn_weights(lateral, head)
         bsum = None if bt is None else ops.derived_weight(head.weight, "fpn_bias_sum" + str(bt.data_ptr()), lambda _w: bt.sum((1, 2)))
         bias = head.bias if bt is None else bsum if head.bias is None else bsum + head.bias
@@ -325,7 +326,7 @@ def fpn_output(lateral, x, coarse, head, wide=None):
 
 
 def _feature_precision_is_fp32():
-    return os.environ.get("D3D_FEATURE_PRECISION", "fp32") != "follow" or ops.conv_precision() != "bf16"
+    return _cfg.get("D3D_FEATURE_PRECISION") != "follow" or ops.conv_precision() != "bf16"
 
 
 class Conv2d(nn.Module):
@@ -355,7 +356,7 @@ class Deconv2d(nn.Module):
         c = self.conv
         if (self.stride == 2 and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.output_padding == (1, 1)
                 and c.out_channels <= 64 and x.is_cuda and (self.bn is None or not self.bn.training)
-                and os.environ.get("D3D_FEATURE_CONV", "mfma") != "miopen"):
+                and _cfg.get("D3D_FEATURE_CONV") != "miopen"):
             s, t = folded_bn(self.bn) if self.bn is not None else (None, c.bias)
             with _feature_precision():
                 outs = [ops.convtranspose2d_k3s2(x[b].contiguous(), c.weight, s, t, None, act=1 if self.relu else 0)

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import _lib
+from . import config as _cfg
 
 PER_PLANE, PER_PIXEL, AFFINE = 0, 1, 2
 
@@ -54,7 +55,7 @@ _forced = [None]
 
 def _sync_force_path():
     """D3D_FORCE_PATH = direct | tiled (tests, profiling): forwarded to the library's test hook when it changes."""
-    want = os.environ.get("D3D_FORCE_PATH", "")
+    want = _cfg.get("D3D_FORCE_PATH")
     if want != _forced[0]:
         code = {"": 0, "auto": 0, "direct": 1, "tiled": 2}.get(want)
         if code is None:
@@ -386,7 +387,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
     # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
-    if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and _os.environ.get("D3D_CONV_CO8", "1") != "0" \
+    if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and _cfg.get("D3D_CONV_CO8") != "0" \
             and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv0 of every CostRegNet): z-streaming kernel on the fp32 vector units (same peak as the fp32 matrix
         # cores, which an 8-row GEMM half fills); weights re-laid out [Ci][ky][kx][kz][8] once per parameter version
@@ -399,7 +400,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         _lib.check(rc, "d3d_conv3d_k3_co8")
         return out
     if stride == 1 and Ci in (8, 16, 32) and (Co in (8, 16) or (Co == 32 and Ci == 32)) and W % 4 == 0 and _use_mfma() \
-            and conv_precision() == "bf16" and _os.environ.get("D3D_CONV_C8", "1") != "0":
+            and conv_precision() == "bf16" and _cfg.get("D3D_CONV_C8") != "0":
         # conv0 / conv2 / conv4 of every CostRegNet with bf16 operands: z-streaming matrix-core kernel (each plane read once)
         wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
         out = torch.empty((Co, D, H, W), dtype=torch.float32, device=x.device)
@@ -411,7 +412,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_zs_bf16")
             return out
-    co1 = Co == 1 and stride == 1 and Ci == 8 and _os.environ.get("D3D_CONV_CO1", "1") != "0"
+    co1 = Co == 1 and stride == 1 and Ci == 8 and _cfg.get("D3D_CONV_CO1") != "0"
     if _use_mfma() and Co <= 64 and not co1:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)
         if y is not None:
@@ -482,7 +483,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    if Co == 8 and Ci % 8 == 0 and _use_mfma() and _os.environ.get("D3D_CONV_CO8", "1") != "0" \
+    if Co == 8 and Ci % 8 == 0 and _use_mfma() and _cfg.get("D3D_CONV_CO8") != "0" \
             and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv11 of every CostRegNet): z-streaming kernel on the fp32 vector units, weights [Ci][kz][ky][kx][8]
         wp = derived_weight(weight, "coT8", lambda w: w.permute(0, 2, 3, 4, 1))
@@ -495,7 +496,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
         _lib.check(rc, "d3d_convtranspose3d_k3s2_co8")
         return out
     if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() == "bf16" \
-            and _os.environ.get("D3D_CONV_T2", "1") != "0":
+            and _cfg.get("D3D_CONV_T2") != "0":
         # decoder layers of CostRegNet with bf16 operands: eight per-parity dense convolutions on the matrix cores, z-streaming
         wp = derived_weight(weight, "t2bf16", _pack_t2_bf16)
         out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
@@ -526,7 +527,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
 # A "CL" volume is a torch.bfloat16 tensor [D,H,W,C]; a planar one the usual float32 [C,D,H,W].
 # ----------------------------------------------------------------------------------------
 def channel_last_enabled():
-    return _os.environ.get("D3D_CONV_CL", "1") != "0"
+    return _cfg.get("D3D_CONV_CL") != "0"
 
 
 def _chk_cl(t, name):
@@ -581,7 +582,7 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     out = torch.empty(oshape, dtype=torch.bfloat16 if out_cl else torch.float32, device=x.device)
     optr = ctypes.c_void_p(out.data_ptr())
     rc = _lib.ERR_UNSUPPORTED
-    if stride == 1 and Co == 1 and not out_cl and _os.environ.get("D3D_CONV_KZFOLD", "1") != "0":
+    if stride == 1 and Co == 1 and not out_cl and _cfg.get("D3D_CONV_KZFOLD") != "0":
         # the probability layer: k_z folded into the columns of one operand tile
         wf = derived_weight(weight, "c8kzfold", _pack_c8_kzfold_bf16)
         rc = _lib.load().d3d_conv3d_k3_c1_cl_bf16(xp, int(in_cl), ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
@@ -598,12 +599,12 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     if rc != _lib.ERR_UNSUPPORTED:
         _lib.check(rc, "d3d_conv3d_k3_cl_bf16" if stride == 1 else "d3d_conv3d_k3s2_cl_bf16")
         return out
-    saved = _conv_precision[0]
-    _conv_precision[0] = "bf16"
+    saved = _cfg.state.conv_precision
+    _cfg.state.conv_precision = "bf16"
     try:
         y = conv3d_k3(_planar(x), weight, scale, shift, _planar(skip), relu=relu, stride=stride)
     finally:
-        _conv_precision[0] = saved
+        _cfg.state.conv_precision = saved
     return to_cl(y) if out_cl else y
 
 
@@ -617,7 +618,7 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
     if skip is not None and (tuple(skip.shape) != oshape or skip.dtype != torch.bfloat16):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
     if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)):
-        fold = (Ci, Co) == (16, 8) and _os.environ.get("D3D_CONV_T2_FOLD", "1") != "0"   # conv11: both column parities in one GEMM
+        fold = (Ci, Co) == (16, 8) and _cfg.get("D3D_CONV_T2_FOLD") != "0"   # conv11: both column parities in one GEMM
         wp = derived_weight(weight, "t2foldbf16", _pack_t2_fold_bf16) if fold else derived_weight(weight, "t2bf16", _pack_t2_bf16)
         out = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
         rc = _lib.load().d3d_convtranspose3d_k3s2_cl_bf16(_chk_cl(x, "x"), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
@@ -627,12 +628,12 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_convtranspose3d_k3s2_cl_bf16")
             return out
-    saved = _conv_precision[0]
-    _conv_precision[0] = "bf16"
+    saved = _cfg.state.conv_precision
+    _cfg.state.conv_precision = "bf16"
     try:
         y = convtranspose3d_k3s2(from_cl(x), weight, scale, shift, _planar(skip), relu=relu)
     finally:
-        _conv_precision[0] = saved
+        _cfg.state.conv_precision = saved
     return to_cl(y)
 
 
@@ -642,7 +643,7 @@ def conv1x1_upskip(x, weight, bias, coarse):
     Ci, H, W = x.shape
     Co = weight.shape[0]
     if (Ci, Co) not in ((8, 32), (16, 32)) or H % 2 or W % 2 or tuple(coarse.shape) != (Co, H // 2, W // 2) \
-            or tuple(weight.shape) != (Co, Ci, 1, 1) or _os.environ.get("D3D_CONV1X1_UPSKIP", "1") == "0":
+            or tuple(weight.shape) != (Co, Ci, 1, 1) or _cfg.get("D3D_CONV1X1_UPSKIP") == "0":
         return None
     wp = derived_weight(weight, "c11", lambda w: w.reshape(Co, Ci).t())
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
@@ -663,7 +664,7 @@ def conv2d_stream(x, weight, scale, shift, skip, act, x2=None, aux1=None, ep_spl
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
     if (Co not in (8, 16) or not _use_mfma() or conv_precision() == "bf16" or H * W < _CONV2D_STREAM_MIN
-            or 8 * H * W * 4 >= 2 ** 31 or _os.environ.get("D3D_CONV2D_STREAM", "1") == "0"
+            or 8 * H * W * 4 >= 2 ** 31 or _cfg.get("D3D_CONV2D_STREAM") == "0"
             or (x2 is not None and Ci0 % 8 != 0) or tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3)):
         return None
 
@@ -712,7 +713,7 @@ def avgpool_4_8(x):
     """AvgPool2d(4) and AvgPool2d(8) of x [C,H,W] in one read (d3d_avgpool2d_4_8) -> ([C,H//4,W//4], [C,H//8,W//8]); None for
     shapes the kernel does not take."""
     C, H, W = x.shape
-    if H < 8 or W < 8 or W % 4 or _os.environ.get("D3D_CONTEXT_FUSED", "1") == "0":
+    if H < 8 or W < 8 or W % 4 or _cfg.get("D3D_CONTEXT_FUSED") == "0":
         return None
     o4 = torch.empty((C, H // 4, W // 4), dtype=torch.float32, device=x.device)
     o8 = torch.empty((C, H // 8, W // 8), dtype=torch.float32, device=x.device)
@@ -729,7 +730,7 @@ def conv1x1_context(f, weight, a, b):
     Ci, H, W = f.shape
     Co = weight.shape[0]
     if (tuple(weight.shape) != (Co, Ci) or Ci != Co or Ci not in (8, 16, 32) or W % 4 or a.shape[0] != Co or b.shape[0] != Co
-            or 3 * a.shape[2] > W or 3 * b.shape[2] > W or _os.environ.get("D3D_CONTEXT_FUSED", "1") == "0"):
+            or 3 * a.shape[2] > W or 3 * b.shape[2] > W or _cfg.get("D3D_CONTEXT_FUSED") == "0"):
         return None
     out = torch.empty((Co, H, W), dtype=torch.float32, device=f.device)
     rc = _lib.load().d3d_conv1x1_context(_chk(f, "f", 3), Ci, _chk(weight, "weight"), _chk(a, "a", 3), a.shape[1], a.shape[2],
@@ -830,7 +831,7 @@ def convtranspose2d_k4_zs(x, weight, scale=None, shift=None, skip=None, act=0, s
     Ci, H, W = x.shape
     Co = weight.shape[1]
     if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or tuple(weight.shape) != (Ci, Co, 4, 4) \
-            or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+            or _cfg.get("D3D_CONV2D_ZS") == "0":
         return None
     wp = derived_weight(weight, "t2dk4x3", _pack_t2d_k4_bf16x3)
     out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
@@ -847,7 +848,7 @@ def convtranspose2d_k4_zs(x, weight, scale=None, shift=None, skip=None, act=0, s
 
 def _z2_fp32_entry():
     """fp32-mode flavour of the 2-D tile kernels: "x3" (three-way bf16 split, the default) | "f32" (v_mfma_f32_16x16x4_f32)."""
-    return "f32" if _os.environ.get("D3D_CONV2D_FP32", "x3") == "f32" else "x3"
+    return "f32" if _cfg.get("D3D_CONV2D_FP32") == "f32" else "x3"
 
 
 def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False):
@@ -866,7 +867,7 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
         y = conv2d_zs(torch.nn.functional.pad(x, (0, pw)), weight, scale, shift,
                       None if skip is None else torch.nn.functional.pad(skip, (0, pw)), act, skip_after_act=skip_after_act)
         return None if y is None else y[:, :, :W].contiguous()
-    if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+    if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _cfg.get("D3D_CONV2D_ZS") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
@@ -890,18 +891,17 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
 # In the default fp32 precision the tile kernels serve the slice regularisers only (the feature pyramids keep their tuned
 # vector-unit kernels: a FeatureNet forward is 2.12 ms on those, 2.19 ms on the fp32 tile kernel): the regulariser
 # modules switch them on around their forward.
-_tile_kernels = [False]
 
 
 class slice_tile_kernels:
     """Context manager: stride-2 / transposed 2-D layers inside may use the fp32 tile kernels."""
 
     def __enter__(self):
-        self.saved = _tile_kernels[0]
-        _tile_kernels[0] = True
+        self.saved = _cfg.state.tile_kernels
+        _cfg.state.tile_kernels = True
 
     def __exit__(self, *exc):
-        _tile_kernels[0] = self.saved
+        _cfg.state.tile_kernels = self.saved
 
 
 def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=False):
@@ -913,7 +913,7 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     x3 = not bf16 and _z2_fp32_entry() == "x3" and Ci != 48
     wide = Ci == 48 and Co <= 48 and W % 4 == 0   # the pair-visibility UNet: the stride-1 kernel with a subsampled store
     if not wide and (Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4) or act not in (0, 1) \
-            or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+            or _cfg.get("D3D_CONV2D_ZS") == "0":
         return None
     if tuple(weight.shape) != (Co, Ci, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
@@ -976,7 +976,7 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
     convolutions over one staged patch); None for shapes it does not take."""
     Ci, H, W = x.shape
     Co = weight.shape[1]
-    if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or _os.environ.get("D3D_CONV2D_ZS", "1") == "0":
+    if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or _cfg.get("D3D_CONV2D_ZS") == "0":
         return None
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
@@ -1006,21 +1006,21 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
-    if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= int(_os.environ.get("D3D_CONV2D_ZS_MINPIX", 256 * 256)) and \
-            (conv_precision() == "bf16" or _os.environ.get("D3D_CONV2D_ZS_ALL", "0") == "1"
-             or (_tile_kernels[0] and _os.environ.get("D3D_CONV2D_ZS_SLICE", "1") == "1")):
+    if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= int(_cfg.get("D3D_CONV2D_ZS_MINPIX")) and \
+            (conv_precision() == "bf16" or _cfg.get("D3D_CONV2D_ZS_ALL") == "1"
+             or (_cfg.state.tile_kernels and _cfg.get("D3D_CONV2D_ZS_SLICE") == "1")):
         # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
         # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True)   # conv2d_k3: the skip is added last
         if y is not None:
             return y
-    zs_any = conv_precision() == "bf16" or ((_tile_kernels[0] or Ci0 == 48) and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0")
+    zs_any = conv_precision() == "bf16" or ((_cfg.state.tile_kernels or Ci0 == 48) and _cfg.get("D3D_CONV2D_ZS_F32") != "0")
     if stride == 2 and x2 is None and act in (0, 1) and zs_any and _use_mfma() and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128):
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
         if y is not None:
             return y
     if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8), (48, 48)) and _use_mfma() \
-            and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128) and _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0":
+            and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128) and _cfg.get("D3D_CONV2D_ZS_F32") != "0":
         # 32 -> 32, 16 -> 16 and 8 -> 8 (the trunks of the feature pyramids) in fp32 accuracy: the tile kernel beats the
         # row-streamed matrix-core form (140 -> 68 us at 464 x 688) and the vector-unit kernel (140 -> 68 us at 928 x 1376,
         # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below.
@@ -1063,14 +1063,14 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     # fp32: the tile kernel serves the slice regularisers and (D3D_CONVT2D_ZS_ALL, default on) the feature pyramids' deconvs
-    zs_any = conv_precision() == "bf16" or (_os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0"
-                                            and (_tile_kernels[0] or _os.environ.get("D3D_CONVT2D_ZS_ALL", "1") != "0"))
+    zs_any = conv_precision() == "bf16" or (_cfg.get("D3D_CONV2D_ZS_F32") != "0"
+                                            and (_cfg.state.tile_kernels or _cfg.get("D3D_CONVT2D_ZS_ALL") != "0"))
     if zs_any and _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
         y = convtranspose2d_zs(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:
             return y
     if Ci == 48 and Co <= 48 and _use_mfma() and act in (0, 1) and W % 2 == 0 and H * W <= 512 * 512 \
-            and _os.environ.get("D3D_CONVT2D_STUFF", "1") != "0":
+            and _cfg.get("D3D_CONVT2D_STUFF") != "0":
         # the pair-visibility UNet (adamvs.py:198-238): no transposed tile kernel has room for 48-channel cells, and at its
         # image sizes the four per-parity launches of round 1's kernel are latency, not work.  A transposed convolution (k 3,
         # s 2, p 1, output_pad 1) is the stride-1 convolution of the zero-stuffed input with the flipped kernel: one launch
@@ -1196,7 +1196,6 @@ def _mpad(co):
     return 16 * (4 if mt == 3 else mt)
 
 
-_conv_precision = [None]
 
 
 def set_conv_precision(mode):
@@ -1204,27 +1203,27 @@ def set_conv_precision(mode):
     the convolutions that go through d3d_conv_fold_*.  None = follow the environment (D3D_CONV_PRECISION)."""
     if mode not in (None, "fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16'")
-    _conv_precision[0] = mode
+    _cfg.state.conv_precision = mode
 
 
 def conv_precision():
-    return _conv_precision[0] or _os.environ.get("D3D_CONV_PRECISION", "fp32")
+    return _cfg.state.conv_precision or _cfg.get("D3D_CONV_PRECISION")
 
 
 class fp32_convs:
     """Context manager: exact fp32 convolutions inside, whatever the global precision (feature pyramids)."""
 
     def __enter__(self):
-        self.saved = _conv_precision[0]
-        _conv_precision[0] = "fp32"
+        self.saved = _cfg.state.conv_precision
+        _cfg.state.conv_precision = "fp32"
 
     def __exit__(self, *exc):
-        _conv_precision[0] = self.saved
+        _cfg.state.conv_precision = self.saved
         return False
 
 
 def _use_mfma():
-    return _os.environ.get("D3D_CONV", "mfma") != "direct"
+    return _cfg.get("D3D_CONV") != "direct"
 
 
 def _packed(weight, transposed):
@@ -1304,7 +1303,7 @@ def _gemm(x, x2, wpack, taps, ntaps, Co, scale, shift, skip, skip_after_act, act
 
 def conv_k3_mfma(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None, skip_after_act=True):
     """k=3, pad 1 conv (2D: x [Ci,H,W]; 3D: x [Ci,D,H,W]) over cat(x, x2) on the matrix cores."""
-    if _os.environ.get("D3D_CONV", "mfma") != "mfma_slice":
+    if _cfg.get("D3D_CONV") != "mfma_slice":
         y = conv_fold(x, weight, scale, shift, skip, act, stride, x2, skip_after_act, transposed=False)
         if y is not None:
             return y
@@ -1325,7 +1324,7 @@ def conv_k3_mfma(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, 
 
 def convtranspose_k3s2_mfma(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=True):
     """k=3, stride 2, pad 1, output_pad 1 transposed conv as 4 (2D) / 8 (3D) parity-class launches."""
-    if _os.environ.get("D3D_CONV", "mfma") != "mfma_slice":
+    if _cfg.get("D3D_CONV") != "mfma_slice":
         y = conv_fold(x, weight, scale, shift, skip, act, 2, None, skip_after_act, transposed=True)
         if y is not None:
             return y
@@ -1407,9 +1406,9 @@ def _conv_fold_choice(Co, Ci, three_d, stride, K=3):
     """Fold (f_y, f_x) that fills the 16 GEMM rows of a narrow layer.  Limits: the kernel's 128 taps, and resident
     weights (ntaps * Ci * 16 floats) small enough that two workgroups still share a CU's LDS -- a wide-C_in layer
     is faster unfolded at twice the occupancy (stage-1 conv0 32->8: 9.4 ms folded, 5.3 ms unfolded)."""
-    if _os.environ.get("D3D_CONV_NOFOLD"):
+    if _cfg.get("D3D_CONV_NOFOLD"):
         return (1, 1)
-    budget = int(_os.environ.get("D3D_CONV_FOLD_KB", "48")) * 1024
+    budget = int(_cfg.get("D3D_CONV_FOLD_KB")) * 1024
     ntaps = lambda f: (K if three_d else 1) * ((f[0] - 1) * stride + K) * ((f[1] - 1) * stride + K)
     for f in [(4, 4), (2, 4), (2, 2), (1, 2)]:
         # (the kernel's column step f_x * stride must be 1, 2 or 4)
@@ -1534,8 +1533,8 @@ def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_aft
     Co = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if (Ci, Co <= 16) != (8, True) and (Ci, Co <= 32) != (16, True) or Wo % 4 or act not in (0, 1) or H * W < 128 * 128 \
-            or tuple(weight.shape) != (Co, Ci, 5, 5) or _z2_fp32_entry() != "x3" or _os.environ.get("D3D_CONV2D_ZS", "1") == "0" \
-            or _os.environ.get("D3D_CONV2D_K5", "1") == "0":
+            or tuple(weight.shape) != (Co, Ci, 5, 5) or _z2_fp32_entry() != "x3" or _cfg.get("D3D_CONV2D_ZS") == "0" \
+            or _cfg.get("D3D_CONV2D_K5") == "0":
         return None
     wp = derived_weight(weight, "z2k5bf16x3", _pack_z2_bf16x3)
     out = torch.empty((Co, Ho, Wo), dtype=torch.float32, device=x.device)
@@ -1555,9 +1554,9 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
     the candidate conv over cat(x, r*h) -> h' = u*h + (1-u)*tanh(c).  Returns None when the layer does not fit the
     image stream kernel (the caller then runs the four-kernel form)."""
     Hc = h.shape[0]
-    if not _use_mfma() or _os.environ.get("D3D_CONV", "mfma") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
+    if not _use_mfma() or _cfg.get("D3D_CONV") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
         return None
-    if (conv_precision() == "bf16" or _os.environ.get("D3D_CONV2D_ZS_F32", "1") != "0") and x.shape[1] * x.shape[2] >= 128 * 128:
+    if (conv_precision() == "bf16" or _cfg.get("D3D_CONV2D_ZS_F32") != "0") and x.shape[1] * x.shape[2] >= 128 * 128:
         # both convolutions on the tile kernel (v_mfma_f32_16x16x32_bf16 in bf16 mode, exact v_mfma_f32_16x16x4_f32
         # otherwise; 16-byte epilogue accesses)
         g = conv2d_zs(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
@@ -1568,7 +1567,7 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
     # both convolutions of a large cell run on the vector-unit kernel (AdaMVS view, same device: 87.9 ms, with the
     # gates on the matrix cores 89.3 ms; D3D_GRU_GATES=mfma selects that)
     g = None
-    if _os.environ.get("D3D_GRU_GATES", "stream") == "stream":
+    if _cfg.get("D3D_GRU_GATES") == "stream":
         g = conv2d_stream(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
     if g is None:
         g = conv_fold(x, w_gates, None, b_gates, h, act=2, stride=1, x2=h, ep_split=Hc)

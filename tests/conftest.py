@@ -32,3 +32,11 @@ def oracle():
 
     _o.build()
     return _o
+
+
+def set_switch(monkeypatch, name, value):
+    """One kernel-selection switch of deep3d_aerial_amd.config for the duration of a test (value None: its default).  The
+    switches are read from the environment once, at import: a test changes the table, not os.environ."""
+    from deep3d_aerial_amd import config
+
+    monkeypatch.setitem(config.switches, name, config.SWITCHES[name][0] if value is None else str(value))

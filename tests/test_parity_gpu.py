@@ -14,8 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_l1
-from deep3d_aerial_amd import synthetic as S
+from conftest import load_golden, rel_l1, set_switch
+from deep3d_aerial_amd import config, synthetic as S
 
 pytestmark = pytest.mark.gpu
 
@@ -47,16 +47,16 @@ def host(t):
 @pytest.fixture(params=["auto", "direct", "tiled"])
 def path(request):
     """Runs a test on the dispatcher's choice and with each kernel family forced."""
-    old = os.environ.get("D3D_FORCE_PATH")
+    old = config.switches.get("D3D_FORCE_PATH")
     if request.param == "auto":
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     else:
-        os.environ["D3D_FORCE_PATH"] = request.param
+        config.switches["D3D_FORCE_PATH"] = request.param
     yield request.param
     if old is None:
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     else:
-        os.environ["D3D_FORCE_PATH"] = old
+        config.switches["D3D_FORCE_PATH"] = old
 
 
 def _run_or_skip_unsupported(fn, path):
@@ -240,11 +240,11 @@ def test_full_size_properties(ops):
     sub = ops.variance_volume(feats, p34, depth[100:116].contiguous())
     assert bool((sub == out[:, 100:116]).all())
     # (3) a cropped spot check against the direct kernel (different code path, same arithmetic)
-    os.environ["D3D_FORCE_PATH"] = "direct"
+    config.switches["D3D_FORCE_PATH"] = "direct"
     try:
         ref = ops.variance_volume(feats, p34, depth[200:204].contiguous())
     finally:
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     err = (ref - out[:, 200:204]).abs().max().item()
     assert err <= 1e-5, err
     # (4) variance is non-negative up to cancellation noise
@@ -266,9 +266,9 @@ def test_full_size_config2_against_oracle_planes(ops, oracle, path_):
     planes = [0, 127, 128, 255, 256, 383]
     want = oracle.variance_volume(feats_h[0], feats_h[1:], p34_host, depth_h[planes])
     if path_ == "auto":
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     else:
-        os.environ["D3D_FORCE_PATH"] = path_
+        config.switches["D3D_FORCE_PATH"] = path_
     try:
         if path_ == "direct":   # (the gather kernel takes ~25 ms per full sweep: the six planes alone)
             got = host(ops.variance_volume(feats, p34, dev(depth_h[planes])))
@@ -277,7 +277,7 @@ def test_full_size_config2_against_oracle_planes(ops, oracle, path_):
             got = host(full[:, planes])
             del full
     finally:
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     assert np.abs(got - want).max() <= 2 * ABS_GATHER
     assert rel_l1(got, want) <= REL_VOLUME
 
@@ -294,13 +294,13 @@ def test_full_size_config5_against_oracle_planes(ops, oracle):
     depth_h = S.uniform_depths(dv, D)
     planes = [0, 170, 341, 511]
     want = oracle.variance_volume(feats_h[0], feats_h[1:], p34_host, depth_h[planes])
-    os.environ["D3D_FORCE_PATH"] = "tiled"
+    config.switches["D3D_FORCE_PATH"] = "tiled"
     try:
         full = ops.variance_volume(feats16, p34, dev(depth_h))
         got = full[:, planes].float().cpu().numpy()
         del full
     finally:
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     # fp16 output: half an ulp of the value (2^-11 relative) on top of the fp32 gather tolerance
     assert np.all(np.abs(got - want) <= 2 * ABS_GATHER + 2.0 ** -10 * np.abs(want))
     assert rel_l1(got, want) <= REL_VOLUME + 2.0 ** -11
@@ -364,7 +364,7 @@ def test_full_size_config5_fp16_ring(ops):
     feats = [torch.from_numpy(f).cuda().half() for f in S.make_features(V, C, h, w, seed=5)]
     p34 = ops.compose_projections(dev(proj))
     depth = dev(S.uniform_depths(dv, D))
-    os.environ["D3D_FORCE_PATH"] = "tiled"   # fail instead of silently taking the direct kernel
+    config.switches["D3D_FORCE_PATH"] = "tiled"   # fail instead of silently taking the direct kernel
     try:
         out = ops.variance_volume(feats, p34, depth)
         torch.cuda.synchronize()
@@ -375,10 +375,10 @@ def test_full_size_config5_fp16_ring(ops):
         assert bool((sub == out[:, 300:316]).all())
         del sub
     finally:
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     # (2) planes from the start, the middle and the end against the direct-gather kernel (other code path, same
     #     fp32 arithmetic, one RNE rounding): identical up to the last fp16 bit of a cancelling variance
-    os.environ["D3D_FORCE_PATH"] = "direct"
+    config.switches["D3D_FORCE_PATH"] = "direct"
     try:
         for d0 in (0, 254, 508):
             ref = ops.variance_volume(feats, p34, depth[d0:d0 + 4].contiguous())
@@ -387,7 +387,7 @@ def test_full_size_config5_fp16_ring(ops):
             assert diff.max().item() <= 2.0 ** -10 * ref.float().abs().max().item() + 1e-6
             assert (diff > 0).float().mean().item() < 1e-3    # almost every voxel bit-identical
     finally:
-        os.environ.pop("D3D_FORCE_PATH", None)
+        config.switches["D3D_FORCE_PATH"] = ""
     # (3) exact homogeneity: every view x 2 -> variance x 4 (powers of two commute with every rounding, fp16 included,
     #     away from the fp16 overflow / subnormal ranges: N(0,1) features keep the variance in [1e-3, 60])
     out2 = ops.variance_volume([f * 2 for f in feats], p34, depth[128:136].contiguous())
@@ -479,7 +479,7 @@ def _fill(mod, seed):
 def convpath(request, monkeypatch):
     """The implementations of the conv family: z-streaming folded MFMA GEMM (default, with the per-slice
     MFMA kernel where the weights do not fit LDS), per-slice MFMA only, and the direct VALU kernels."""
-    monkeypatch.setenv("D3D_CONV", request.param)
+    set_switch(monkeypatch, "D3D_CONV", request.param)
     return request.param
 
 
@@ -511,7 +511,7 @@ def test_conv_primitives_vs_oracle(ops, oracle, convpath):
 @pytest.mark.parametrize("mode", ["mfma", "mfma_slice"])
 def test_conv_gemm_channel_counts_and_epilogue(ops, oracle, Ci, Co, mode, monkeypatch):
     """MFMA implicit GEMMs across their tile variants (MT 1..4, folds, chunk tails), ragged rows, full epilogue."""
-    monkeypatch.setenv("D3D_CONV", mode)
+    set_switch(monkeypatch, "D3D_CONV", mode)
     rng = np.random.default_rng(100 + Ci + Co)
     x = rng.standard_normal((Ci, 3, 9, 71)).astype(np.float32)
     w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
@@ -556,8 +556,8 @@ def _bf16_round(a):
 def test_conv_bf16_operands_match_rounded_oracle(ops, oracle, Ci, Co, monkeypatch):
     """d3d_conv_fold_bf16: operands rounded to bf16 (RNE), fp32 accumulation -- so it must agree with the fp32
     oracle run on pre-rounded inputs and weights to fp32 summation-order accuracy."""
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.setenv("D3D_CONV_CO1", "0")  # (the C_out = 1 streaming kernel is exact fp32 in either precision mode)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV_CO1", "0")  # (the C_out = 1 streaming kernel is exact fp32 in either precision mode)
     rng = np.random.default_rng(Ci * 7 + Co)
     x = rng.standard_normal((Ci, 4, 10, 40)).astype(np.float32)
     w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
@@ -872,8 +872,8 @@ def test_full_size_cascade_mfma_equals_direct_kernels(ops, model, monkeypatch):
     dv = dev(s["depth_values"])[None]
     outs = {}
     for path in ("mfma", "direct"):
-        monkeypatch.setenv("D3D_CONV", path)
-        monkeypatch.setenv("D3D_FEATURE_CONV", "mfma" if path == "mfma" else "miopen")
+        set_switch(monkeypatch, "D3D_CONV", path)
+        set_switch(monkeypatch, "D3D_FEATURE_CONV", "mfma" if path == "mfma" else "miopen")
         with torch.no_grad():
             o = net(imgs, pm, dv)
         outs[path] = (host(o["depth"][0]), host(o["photometric_confidence"][0]))
@@ -895,10 +895,10 @@ def test_full_size_adamvs_bf16_within_depth_budget(ops, monkeypatch):
     imgs = dev(s["imgs"])[None]
     pm = {k: dev(v)[None] for k, v in s["proj_matrices"].items()}
     dv = dev(s["depth_values"])[None]
-    monkeypatch.setenv("D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
     outs = {}
     for tag, prec, zs in (("fp32", "fp32", "1"), ("bf16_tile", "bf16", "1"), ("bf16_stream", "bf16", "0")):
-        monkeypatch.setenv("D3D_CONV2D_ZS", zs)
+        set_switch(monkeypatch, "D3D_CONV2D_ZS", zs)
         ops.set_conv_precision(prec)
         try:
             with torch.no_grad():
@@ -926,10 +926,10 @@ def test_full_size_cascade_bf16_regulariser_within_depth_budget(ops, monkeypatch
     imgs = dev(s["imgs"])[None]
     pm = {k: dev(v)[None] for k, v in s["proj_matrices"].items()}
     dv = dev(s["depth_values"])[None]
-    monkeypatch.setenv("D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
     outs = {}
     for tag, prec, cl in (("fp32", "fp32", "1"), ("bf16_cl", "bf16", "1"), ("bf16_planar", "bf16", "0")):
-        monkeypatch.setenv("D3D_CONV_CL", cl)
+        set_switch(monkeypatch, "D3D_CONV_CL", cl)
         ops.set_conv_precision(prec)
         try:
             with torch.no_grad():
@@ -974,15 +974,15 @@ def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, 
     w = (0.2 * rng.standard_normal((1, 8, 3, 3, 3))).astype(np.float32)
     b = rng.standard_normal(1).astype(np.float32)
     sk = rng.standard_normal((1, D, H, W)).astype(np.float32)
-    monkeypatch.delenv("D3D_CONV_CO1", raising=False)
-    monkeypatch.setenv("D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV_CO1", None)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
     got = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
     want = oracle.conv3d_k3(x, w, b)
     assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
     got2 = host(ops.conv3d_k3(dev(x), dev(w), dev(np.full(1, 0.5, np.float32)), dev(b), dev(sk), relu=True))
     want2 = np.maximum(0.5 * oracle.conv3d_k3(x, w, None) + b[0], 0.0) + sk
     assert np.abs(got2 - want2).max() <= 2e-6 * max(1.0, np.abs(want2).max()) * 8
-    monkeypatch.setenv("D3D_CONV_CO1", "0")
+    set_switch(monkeypatch, "D3D_CONV_CO1", "0")
     folded = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
     assert np.abs(got - folded).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
 
@@ -1000,14 +1000,14 @@ def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D,
     sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
     sh = rng.standard_normal(8).astype(np.float32)
     sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.delenv("D3D_CONV_CO8", raising=False)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV_CO8", None)
     want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
     got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert np.abs(got - want).max() <= tol
     plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
-    monkeypatch.setenv("D3D_CONV_CO8", "0")
+    set_switch(monkeypatch, "D3D_CONV_CO8", "0")
     folded = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
     assert np.abs(plain - folded).max() <= tol
     assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() <= tol
@@ -1023,14 +1023,14 @@ def test_convtranspose3d_eight_output_channels_streaming(ops, oracle, monkeypatc
     sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
     sh = rng.standard_normal(8).astype(np.float32)
     sk = rng.standard_normal((8, 2 * D, 2 * H, 2 * W)).astype(np.float32)
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.delenv("D3D_CONV_CO8", raising=False)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV_CO8", None)
     want = np.maximum(oracle.convtranspose3d_k3s2(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
     got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert got.shape == want.shape and np.abs(got - want).max() <= tol
     plain = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
-    monkeypatch.setenv("D3D_CONV_CO8", "0")
+    set_switch(monkeypatch, "D3D_CONV_CO8", "0")
     folded = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
     assert np.abs(plain - folded).max() <= tol
 
@@ -1046,15 +1046,15 @@ def test_conv2d_streaming_vector_unit_kernel(ops, oracle, monkeypatch, Ci, Co, H
     sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
     sh = rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, H, W)).astype(np.float32)
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.delenv("D3D_CONV2D_STREAM", raising=False)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV2D_STREAM", None)
     monkeypatch.setattr(ops, "_CONV2D_STREAM_MIN", 1)
     want = np.maximum(oracle.conv2d_k3(x, w, None) * sc[:, None, None] + sh[:, None, None], 0) + sk
     got = host(ops.conv2d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), act=1))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert np.abs(got - want).max() <= tol
     plain = host(ops.conv2d_k3(dev(x), dev(w)))
-    monkeypatch.setenv("D3D_CONV2D_STREAM", "0")
+    set_switch(monkeypatch, "D3D_CONV2D_STREAM", "0")
     folded = host(ops.conv2d_k3(dev(x), dev(w)))
     assert np.abs(plain - folded).max() <= tol
 
@@ -1088,14 +1088,14 @@ def test_gru_cell_on_streaming_kernel(ops, oracle, monkeypatch, Cx, Hc, H, W):
          "g.convc.0.weight": (0.15 * rng.standard_normal((Hc, Cx + Hc, 3, 3))).astype(np.float32),
          "g.convc.0.bias": rng.standard_normal(Hc).astype(np.float32)}
     want = oracle.conv_gru_cell(x, h, p, "g.")
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.delenv("D3D_CONV2D_STREAM", raising=False)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV2D_STREAM", None)
     monkeypatch.setattr(ops, "_CONV2D_STREAM_MIN", 1)
     args = (dev(x), dev(h), dev(p["g.conv_gates.0.weight"]), dev(p["g.conv_gates.0.bias"]), dev(p["g.convc.0.weight"]),
             dev(p["g.convc.0.bias"]))
     got = host(ops.gru_cell_fused(*args))
     assert np.abs(got - want).max() <= 2e-5
-    monkeypatch.setenv("D3D_CONV2D_STREAM", "0")
+    set_switch(monkeypatch, "D3D_CONV2D_STREAM", "0")
     folded = host(ops.gru_cell_fused(*args))
     assert np.abs(got - folded).max() <= 2e-5
 
@@ -1132,13 +1132,13 @@ def test_conv3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, Co, D, 
     sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
     sh = rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, D, H, W)).astype(np.float32)
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.delenv("D3D_CONV_C8", raising=False)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV_C8", None)
     ops.set_conv_precision("bf16")
     try:
         got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
         plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
-        monkeypatch.setenv("D3D_CONV_C8", "0")                       # the round-1 bf16 stream kernel, same operands
+        set_switch(monkeypatch, "D3D_CONV_C8", "0")                       # the round-1 bf16 stream kernel, same operands
         other = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
     finally:
         ops.set_conv_precision(None)
@@ -1164,8 +1164,8 @@ def test_convtranspose3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci
     sc = rng.uniform(0.5, 1.5, Co).astype(np.float32)
     sh = rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, 2 * D, 2 * H, 2 * W)).astype(np.float32)
-    monkeypatch.setenv("D3D_CONV", "mfma")
-    monkeypatch.delenv("D3D_CONV_T2", raising=False)
+    set_switch(monkeypatch, "D3D_CONV", "mfma")
+    set_switch(monkeypatch, "D3D_CONV_T2", None)
     ops.set_conv_precision("bf16")
     try:
         got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
@@ -1256,7 +1256,7 @@ def test_conv3d_probability_layer_kz_folded(ops, oracle, monkeypatch, Ci, D, H, 
     xin = _cl_dev(x) if in_cl else dev(x)
     got = host(ops.conv3d_k3_cl(xin, dev(w), dev(sc), dev(sh), dev(sk), relu=True, out_cl=False))
     plain = host(ops.conv3d_k3_cl(xin, dev(w), None, dev(sh), None, relu=False, out_cl=False))
-    monkeypatch.setenv("D3D_CONV_KZFOLD", "0")
+    set_switch(monkeypatch, "D3D_CONV_KZFOLD", "0")
     generic = host(ops.conv3d_k3_cl(xin, dev(w), None, dev(sh), None, relu=False, out_cl=False))
     ref = oracle.conv3d_k3(_bf16_round(x), _bf16_round(w), None)
     tol = 3e-5 * max(1.0, np.abs(ref).max())
@@ -1297,7 +1297,7 @@ def test_convtranspose3d_channel_last_bf16(ops, oracle, monkeypatch, Ci, Co, D, 
     the per-parity form."""
     if fold == "0" and (Ci, Co) != (16, 8):
         pytest.skip("only 16 -> 8 has two forms")
-    monkeypatch.setenv("D3D_CONV_T2_FOLD", fold)
+    set_switch(monkeypatch, "D3D_CONV_T2_FOLD", fold)
     rng = np.random.default_rng(Ci * 1000 + W + D)
     x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
     w = (0.1 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
@@ -1346,7 +1346,7 @@ def test_costregnet_channel_last_path_matches_planar_bf16_path(ops, monkeypatch)
     try:
         with torch.no_grad():
             a = net.forward_one(x)
-            monkeypatch.setenv("D3D_CONV_CL", "0")
+            set_switch(monkeypatch, "D3D_CONV_CL", "0")
             b = net.forward_one(x)
             ops.set_conv_precision("fp32")
             c = net.forward_one(x)
@@ -1457,7 +1457,7 @@ def test_gru_cell_bf16_tile_kernels_match_the_stream_kernels(ops, monkeypatch):
     try:
         with torch.no_grad():
             a, _ = cell(x, h)
-            monkeypatch.setenv("D3D_CONV2D_ZS", "0")
+            set_switch(monkeypatch, "D3D_CONV2D_ZS", "0")
             b, _ = cell(x, h)
             ops.set_conv_precision("fp32")
             c, _ = cell(x, h)
@@ -1520,7 +1520,7 @@ def test_conv2d_tile_kernel_fp32_with_gru_epilogues(ops, oracle, monkeypatch, fl
     """The models' default precision on the tile kernel: d3d_conv2d_k3_zs_bf16x3 (three-way bf16 splits of both operands,
     the default) and d3d_conv2d_k3_zs_f32 (v_mfma_f32_16x16x4_f32), against the fp32 oracle without any rounding of the
     operands."""
-    monkeypatch.setenv("D3D_CONV2D_FP32", flavour)
+    set_switch(monkeypatch, "D3D_CONV2D_FP32", flavour)
     rng = np.random.default_rng(Ci0 * 100 + Co + W + act)
     x = rng.standard_normal((Ci0, H, W)).astype(np.float32)
     x2 = rng.standard_normal((Ci1, H, W)).astype(np.float32) if Ci1 else None
@@ -1568,7 +1568,7 @@ def test_three_way_bf16_split_is_as_accurate_as_the_fp32_instruction(ops, monkey
     ops.set_conv_precision("fp32")
     try:
         for flavour in ("x3", "f32"):
-            monkeypatch.setenv("D3D_CONV2D_FP32", flavour)
+            set_switch(monkeypatch, "D3D_CONV2D_FP32", flavour)
             got = ops.conv2d_zs(xd, wd)
             assert got is not None
             err[flavour] = float(((got.double() - want).abs() / scale).max())
@@ -1623,7 +1623,7 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
     x = torch.randn(1, 3, 96, 160, device="cuda")
     with torch.no_grad():
         fused = net(x)
-        monkeypatch.setenv("D3D_CONTEXT_FUSED", "0")
+        set_switch(monkeypatch, "D3D_CONTEXT_FUSED", "0")
         plain = net(x)
     for k in ("stage1", "stage2", "stage3"):
         assert fused[k].shape == plain[k].shape
@@ -1749,7 +1749,7 @@ def test_fpn_output_level_without_the_wide_tensor(ops, monkeypatch, Cl, Co, H, W
                                                                                          None if not bias else lateral.bias.double())
         want = F.conv2d(t, head.weight.double(), padding=1)
         got = M.fpn_output(lateral, x, coarse, head)
-        monkeypatch.setenv("D3D_FPN_SPLIT", "0")
+        set_switch(monkeypatch, "D3D_FPN_SPLIT", "0")
         two = M.fpn_output(lateral, x, coarse, head)
     tol = 3e-5 * max(1.0, float(want.abs().max()))
     assert float((got.double() - want).abs().max()) <= tol
@@ -1760,7 +1760,7 @@ def test_fpn_output_level_without_the_wide_tensor(ops, monkeypatch, Cl, Co, H, W
 def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle, monkeypatch, flavour):
     """d3d_conv2d_k3s2_zs_bf16x3 / d3d_convtranspose2d_k3s2_zs_bf16x3 (three-way bf16 splits, the default of fp32 mode) and the
     _f32 forms (fp32 instruction): against the oracle without rounding of the operands."""
-    monkeypatch.setenv("D3D_CONV2D_FP32", flavour)
+    set_switch(monkeypatch, "D3D_CONV2D_FP32", flavour)
     rng = np.random.default_rng(12)
     ops.set_conv_precision("fp32")
     try:

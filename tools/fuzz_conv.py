@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from deep3d_aerial_amd import ops
+from deep3d_aerial_amd import config, ops
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 n_cases = int(os.environ.get("FUZZ_CASES", "60"))
@@ -29,7 +29,7 @@ for case in range(n_cases):
     sh = torch.randn(Co, device="cuda")
     outs = {}
     for path in ("mfma", "direct"):
-        os.environ["D3D_CONV"] = path
+        config.switches["D3D_CONV"] = path
         ops.clear_weight_cache()
         if transposed:
             f = ops.convtranspose3d_k3s2 if three_d else ops.convtranspose2d_k3s2

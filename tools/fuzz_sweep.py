@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from deep3d_aerial_amd import ops, synthetic as S
+from deep3d_aerial_amd import config, ops, synthetic as S
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 n_cases = int(os.environ.get("FUZZ_CASES", "40"))
@@ -25,7 +25,7 @@ for case in range(n_cases):
     wts = torch.rand(V - 1, h, w, device="cuda")
     outs = {}
     for path in ("tiled", "direct"):
-        os.environ["D3D_FORCE_PATH"] = path
+        config.switches["D3D_FORCE_PATH"] = path
         try:
             if mode == "variance":
                 y = ops.variance_volume(feats, p34, depth)
@@ -48,7 +48,7 @@ for case in range(n_cases):
     bad = (not torch.isfinite(a).all().item()) or rel > 5e-5 or err > 2e-3
     cl_note = ""
     if mode == "variance" and C % 8 == 0:   # the channel-last bf16 volume must be the rounding of the ring kernel's planar one
-        os.environ["D3D_FORCE_PATH"] = "tiled"
+        config.switches["D3D_FORCE_PATH"] = "tiled"
         cl = ops.variance_volume_cl(feats, p34, depth)
         want = a.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
         nbad = int((cl.view(torch.int16) != want.view(torch.int16)).sum())

@@ -1,7 +1,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from conftest import load_golden, rel_l1
-from deep3d_aerial_amd import ops, synthetic as S
+from deep3d_aerial_amd import config, ops, synthetic as S
 from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
 from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
 from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
@@ -16,7 +16,7 @@ for tag in ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "mode
     pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
     res = []
     for feat in ("fp32", "follow"):
-        os.environ["D3D_FEATURE_PRECISION"] = feat
+        config.switches["D3D_FEATURE_PRECISION"] = feat
         ops.set_conv_precision("bf16")
         with torch.no_grad():
             out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from deep3d_aerial_amd import ops, synthetic as S
+from deep3d_aerial_amd import config, ops, synthetic as S
 
 H, W = 1856, 2752
 AFFINE = os.environ.get("STAGE_AFFINE", "1") != "0"   # STAGE_AFFINE=0: per-pixel hypothesis volumes [D,h,w] (rounds 1-2)
@@ -32,7 +32,7 @@ for (tag, C, D, sc, perpix) in [("stage1", 32, 48, 4, False), ("stage2", 16, 32,
     reads = 5 * C * h * w * 4 + (0 if not perpix else (2 if AFFINE else D) * h * w * 4)
     gb_var, gb_cl = (reads + C * D * h * w * 4) / 1e9, (reads + C * D * h * w * 2) / 1e9
     for path in (sys.argv[1:] or ("tiled", "direct")):
-        os.environ["D3D_FORCE_PATH"] = path
+        config.switches["D3D_FORCE_PATH"] = path
         try:
             t1 = timeit(lambda: ops.variance_volume(feats, p34, depth))
             t2 = timeit(lambda: ops.weighted_corr(feats, p34, vw, depth))
