@@ -318,7 +318,7 @@ def scale_image(image, scale=1.0):
     """preprocess.py:41-46 scale_image -> cv2.resize(image, None, fx=scale, fy=scale, INTER_LINEAR).
     scale == 1 (the pipeline's setting: mvs_dl.py never passes --resize_scale) returns the image as cv2 does.  Other
     scales follow OpenCV's documented INTER_LINEAR rule (output size round(n*scale); source coordinate
-    (dst + 0.5)/scale - 0.5, clamped; round half up for 8-bit) in float64 -- OpenCV itself is absent from the build
+    (dst + 0.5)/scale - 0.5 with the GIVEN scale -- not n_in/n_out --, clamped; round half up for 8-bit) in float64 -- OpenCV itself is absent from the build
     image, so this branch is NOT pinned against it (its 8-bit path uses 11-bit fixed-point weights and may differ by
     one grey level)."""
     if scale == 1 or scale == 1.0:
@@ -330,13 +330,13 @@ def scale_image(image, scale=1.0):
     def taps(n_out, n_in, s):
         x = (np.arange(n_out) + 0.5) / s - 0.5
         x0 = np.floor(x).astype(np.int64)
-        f = x - x0
+        f = np.where((x0 < 0) | (x0 >= n_in - 1), 0.0, x - x0)   # OpenCV zeroes the fraction where a tap is clamped
         a = np.clip(x0, 0, n_in - 1)
         b = np.clip(x0 + 1, 0, n_in - 1)
         return a, b, f
 
-    ya, yb, fy = taps(nh, h, nh / float(h))
-    xa, xb, fx = taps(nw, w, nw / float(w))
+    ya, yb, fy = taps(nh, h, float(scale))   # cv2.resize(..., fx=scale, fy=scale) keeps inv_scale = 1/scale, NOT n_in/n_out
+    xa, xb, fx = taps(nw, w, float(scale))
     src = img.astype(np.float64)
     if src.ndim == 2:
         src = src[:, :, None]

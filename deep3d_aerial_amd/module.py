@@ -284,13 +284,14 @@ def _fpn_weights(lateral, head):
     def comp(w3):   # (W3 . W1): a 3x3 convolution straight from the lateral's input channels
         return torch.einsum("omyx,mc->ocyx", w3.double(), w1.detach().double().reshape(w1.shape[0], -1)).float()
 
-    def bias_taps(w3):   # what the lateral bias contributes through each tap: [Co,3,3]
-        return torch.einsum("omyx,m->oyx", w3.double(), lateral.bias.detach().double()).float()
+    def bias_taps(w3):   # what the lateral bias contributes through each tap: [Co,3,3], and its sum over the taps [Co]
+        bt = torch.einsum("omyx,m->oyx", w3.double(), lateral.bias.detach().double()).float()
+        return bt, bt.sum((1, 2))
 
     wt = ops.derived_weight(head.weight, "fpn_up", ops.upsampled_conv_weight)
     wb = ops.derived_weight(head.weight, "fpn_lat" + tag, comp)
-    bt = None if lateral.bias is None else ops.derived_weight(head.weight, "fpn_bias" + tag, bias_taps)
-    return wt, wb, bt
+    bt, bsum = (None, None) if lateral.bias is None else ops.derived_weight(head.weight, "fpn_bias" + tag, bias_taps)
+    return wt, wb, bt, bsum
 
 
 def fpn_output(lateral, x, coarse, head, wide=None):
@@ -305,8 +306,7 @@ def fpn_output(lateral, x, coarse, head, wide=None):
             and x.shape[1] in (8, 16) and Cm == 32 and Co <= 16 and coarse.shape[1] == Cm and x.shape[3] % 8 == 0
             and x.shape[2] == 2 * coarse.shape[2] and x.shape[3] == 2 * coarse.shape[3] and _feature_precision_is_fp32()
             and _cfg.get("D3D_FEATURE_CONV") != "miopen" and _cfg.get("D3D_FPN_SPLIT") != "0"):
-        wt, wb, bt = _fpn_weights(lateral, head)
-        bsum = None if bt is None else ops.derived_weight(head.weight, "fpn_bias_sum" + str(bt.data_ptr()), lambda _w: bt.sum((1, 2)))
+        wt, wb, bt, bsum = _fpn_weights(lateral, head)   # bt and its sum come from ONE cache entry keyed on both layers' versions
         bias = head.bias if bt is None else bsum if head.bias is None else bsum + head.bias
         outs = []
         with _feature_precision():

@@ -1173,7 +1173,8 @@ def derived_weight(weight, tag, fn):
     if hit is not None and hit[0]() is weight and hit[1] == (weight.data_ptr(), weight._version):
         return hit[2]
     with torch.no_grad():
-        out = fn(weight.detach()).contiguous()
+        out = fn(weight.detach())
+        out = tuple(t.contiguous() for t in out) if isinstance(out, tuple) else out.contiguous()
     if len(_derived_cache) > 4096:
         _derived_cache.clear()
     _derived_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), out)

@@ -92,8 +92,10 @@ class PfmWriter(object):
         self._thread = threading.Thread(target=self._run, name="pfm-writer", daemon=True)
         self._thread.start()
 
-    def submit(self, maps, paths):
-        """maps: n device tensors of h*w fp32 elements each; paths: n file names."""
+    def submit(self, maps, paths, display=None):
+        """maps: n device tensors of h*w fp32 elements each; paths: n file names.  display = (output_folder, name) has the
+        writer thread render the colour maps of predict.py:155-176 from the same host copy (maps[0] depth, maps[1]
+        confidence) after the files are written -- the GPU does not wait for the PNG encoder."""
         import ctypes
 
         from . import _lib
@@ -117,14 +119,14 @@ class PfmWriter(object):
             sl["host"].copy_(sl["dev"], non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.copy_stream)
-        self._q.put((sl, done, list(paths)))
+        self._q.put((sl, done, list(paths), display))
 
     def _run(self):
         while True:
             item = self._q.get()
             if item is None:
                 return
-            sl, done, paths = item
+            sl, done, paths, display = item
             try:
                 done.synchronize()
                 payload = sl["host"].numpy()
@@ -132,6 +134,8 @@ class PfmWriter(object):
                     with open(path, "wb") as f:
                         f.write(_pfm_header(self.h, self.w))
                         payload[k].tofile(f)
+                if display is not None:   # the staging buffer is in file order (bottom row first): flip back
+                    write_display_maps(display[0], display[1], payload[0][::-1].copy(), payload[1][::-1].copy())
             except Exception as e:  # surfaced by the next submit() / close()
                 self._err = e
             finally:
@@ -349,6 +353,8 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
     from .dataset import FeatureCache
 
     os.makedirs(output_folder, exist_ok=True)
+    if display:
+        _display_backend()   # a missing matplotlib fails here, before the first view is computed
     model.eval()
     if feature_cache_bytes > 0:
         # items without "image_keys" (the reference's layout) are matched by content: exact comparison, same results
@@ -373,11 +379,10 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
                     if writer is not None:
                         writer.close()
                     writer = PfmWriter(depth.shape[0], depth.shape[1], 2, device=depth.device)
-                writer.submit([depth, prob], paths)  # the files land while the next view is computed
+                # the files (and with --display the colour maps) land while the next view is computed
+                writer.submit([depth, prob], paths, display=(output_folder, name) if display else None)
                 write_red_cam(os.path.join(output_folder, "%s.txt" % name), s["outcam"], s["outlocation"],
                               s["ref_image_path"])
-                if display:
-                    write_display_maps(output_folder, name, depth.cpu().numpy(), prob.cpu().numpy())
                 if keep_maps:
                     done[name] = (depth, prob)
                 else:
@@ -428,14 +433,19 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def write_display_maps(output_folder, name, depth, prob):
-    """predict.py:155-176: colour renderings of the depth (36000 - depth, non-finite columns patched) and confidence
-    maps under <output>/color/.  Needs matplotlib, like the reference."""
+def _display_backend():
     import matplotlib
 
     matplotlib.use("Agg")
     import matplotlib.pyplot as plt
 
+    return plt
+
+
+def write_display_maps(output_folder, name, depth, prob):
+    """predict.py:155-176: colour renderings of the depth (36000 - depth, non-finite columns patched) and confidence
+    maps under <output>/color/.  Needs matplotlib, like the reference."""
+    plt = _display_backend()
     os.makedirs(os.path.join(output_folder, "color"), exist_ok=True)
     img = (np.float32(36000) - depth).astype(np.float32)
     img[np.isinf(img)] = np.nan

@@ -181,6 +181,23 @@ def test_scale_image_unit_scale_is_identity_and_half_scale_averages():
     assert half.shape == (2, 3, 3) and np.array_equal(half, want)
 
 
+def test_scale_image_follows_the_given_scale_when_the_output_size_is_rounded():
+    """cv2.resize(image, None, fx=s, fy=s): the output size is round(n*s) but the source coordinate is
+    (dst + 0.5)/s - 0.5 with the GIVEN s (preprocess.py:41-46), not n_in/n_out.  5 columns at s = 0.7 -> 4 columns
+    (3.5 rounds to 4); source coordinates 0.2143, 1.6429, 3.0714 and 4.5 (clamped to the last column)."""
+    from deep3d_aerial_amd import dataset as D
+
+    row = np.array([[10.0, 20.0, 40.0, 80.0, 160.0]], dtype=np.float32)
+    out = D.scale_image(row, 0.7)
+    assert out.shape == (1, 4)
+    xs = (np.arange(4) + 0.5) / 0.7 - 0.5
+    want = np.interp(xs, np.arange(5), row[0])            # np.interp clamps at the ends like the border rule
+    assert np.allclose(out[0], want, rtol=0, atol=1e-4)
+    assert abs(out[0, 0] - (10 + 0.2142857 * 10)) < 1e-3 and out[0, 3] == 160.0
+    ratio_rule = np.interp((np.arange(4) + 0.5) / (4 / 5.0) - 0.5, np.arange(5), row[0])
+    assert not np.allclose(out[0], ratio_rule, atol=0.5)   # the n_out/n_in rule gives other values here
+
+
 def test_feature_cache_hit_survives_eviction_by_an_earlier_miss():
     """An item whose cached view sits BEHIND an uncached one, with room for about one pyramid: the put() for the miss
     evicts the cached key; the pyramid taken in the first pass must still be used (advisor finding, round 1)."""

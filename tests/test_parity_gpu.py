@@ -965,6 +965,22 @@ def test_predict_views_writes_reference_products(ops, tmp_path):
     assert (tmp_path / "view_0001.txt").read_text().startswith("extrinsic: XrightYdown, [Rcw|tcw]")
 
 
+def test_predict_views_display_maps_come_from_the_writer_thread(ops, tmp_path):
+    """--display (predict.py:155-176): the colour maps are rendered by the PfmWriter thread from its host copy, rows
+    back in image order, and are the ones a direct rendering of the device maps gives."""
+    pytest.importorskip("matplotlib")
+    from deep3d_aerial_amd import predict
+
+    net = _fill(predict.build_model("casmvsnet", 64), 11)
+    ds = predict.SyntheticBlock(2, 3, 64, 96, 64, seed=5)
+    kept = predict.predict_views(net, ds, str(tmp_path / "a"), display=True, keep_maps=True)
+    for name, (depth, prob) in kept.items():
+        predict.write_display_maps(str(tmp_path / "b"), name, host(depth), host(prob))
+        for kind in ("init", "prob"):
+            got = (tmp_path / "a" / "color" / ("%s_%s.png" % (name, kind))).read_bytes()
+            assert got == (tmp_path / "b" / "color" / ("%s_%s.png" % (name, kind))).read_bytes() and len(got) > 100
+
+
 @pytest.mark.parametrize("D,H,W", [(1, 3, 5), (2, 4, 64), (5, 9, 70), (8, 37, 130), (11, 64, 65), (19, 6, 300)])
 def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, W):
     """C_out = 1 layers (CostRegNet.prob, cas_mvsnet.py:110) run on the z-streaming VALU kernel behind d3d_conv3d_k3:

@@ -76,7 +76,12 @@ __global__ __launch_bounds__(NT, 1) void plane_loop(unsigned long long* stamps, 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     float dv = consts[70];
     int* ldsi = reinterpret_cast<int*>(lds);
-    const unsigned pixb = (unsigned)((blockIdx.x * NT + threadIdx.x) * 4) % (688u * 464u * 4u);
+    unsigned pixb = (unsigned)((blockIdx.x * NT + threadIdx.x) * 4) % (688u * 464u * 4u);
+    if (STORES == 2) {   // two 128-byte row segments per instruction, rows 1856 bytes apart (w = 464: every other row starts mid-line)
+        const unsigned wv = (blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
+        const unsigned tx = wv % 14u, ty = (wv / 14u) % 343u;
+        pixb = ((2u * ty + ((threadIdx.x >> 5) & 1u)) * 464u + 32u * tx + (threadIdx.x & 31u)) * 4u;
+    }
     for (int pl = 0; pl < planes; ++pl) {
         dv += 1.04f;
         if (OVH) {
@@ -225,7 +230,8 @@ int main(int argc, char** argv) {
     run_nt<1, 1, NT, 1, 1, 1, 0, 0>("+ taps + stores, taps NOT requested ahead", d_st, d_sink, d_c, vol); \
     run_nt<1, 1, NT, 1, 1, 1, 1, 1>("+ taps + stores, reference features from LDS", d_st, d_sink, d_c, vol); \
     run_nt<1, 1, NT, 1, 1, 1, 0, 1>("+ taps + stores, no request ahead, reference from LDS", d_st, d_sink, d_c, vol); \
-    run_nt<1, 1, NT, 1, 1, 1, 1, 0, 8>("+ taps + stores, taps as 2 x ds_read_b64", d_st, d_sink, d_c, vol);
+    run_nt<1, 1, NT, 0, 2, 1>("+ stores in the kernel's shape (2 x 128 B rows, pitch 1856 B), no taps", d_st, d_sink, d_c, vol); \
+    run_nt<1, 1, NT, 1, 2, 1>("+ taps + stores in the kernel's shape", d_st, d_sink, d_c, vol);
     if (!only || only == 256) { ALL(256) }
     if (!only || only == 512) { ALL(512) }
     if (!only || only == 768) { ALL(768) }
