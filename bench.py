@@ -12,7 +12,9 @@ timed region.  With N > 1 every rank sweeps its own reference views (independent
 collective on the data path): weak scaling, value = all ranks' voxels / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      -- algorithmic HBM bytes per launch / mean kernel time from HIP events
+  roofline      -- algorithmic HBM bytes per launch / mean kernel time from HIP events; `issue_floor_ms` = what the
+                   plane loop's instruction stream alone costs on this chip (measured replay, see issue_floor_ms)
+  parity        -- 16 planes of the volume just produced against the CPU oracle (N = 1 only)
   cpu_baseline  -- the CPU oracle (oracle/planesweep_oracle.c, OpenMP) timed on a bounded
                    sample of the same workload on this box's host cores (N = 1 only).
 """
@@ -32,6 +34,21 @@ from deep3d_aerial_amd import config, ops, synthetic as S  # noqa: E402
 
 V, C, D, H_FEAT, W_FEAT = 5, 32, 384, 688, 464
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+# What the vector units and the LDS allow this formulation of the kernel: tools/sweep_sandbox.hip
+# replays the plane loop's instruction stream -- geometry of 4 views, 64 `ds_read_b128` taps, blend + sum / sum of squares,
+# 16 stores per 16-channel group -- with no planner, no staging and no barriers: 2555 shader cycles per (64 pixels x 1 plane x
+# 16 channels) per SIMD at the kernel's 2 compute waves per SIMD, 2098 at 3 (profiles/r03_sweep_sandbox.txt), at the
+# 2.1 GHz the chip holds under this load (profiles/r03_pk_rate.txt).  The launch cannot be faster than that while it keeps
+# this instruction mix; the HBM roofline (`frac`) stays the figure of merit.
+SANDBOX_CYCLES_PER_GROUP = {"2_compute_waves_per_simd": 2555.0, "3_compute_waves_per_simd": 2098.0}
+SANDBOX_CLOCK_GHZ, SIMDS = 2.1, 256 * 4
+
+
+def issue_floor_ms(waves="2_compute_waves_per_simd"):
+    groups_per_simd = (D * H_FEAT * W_FEAT / 64.0) * (C // 16) / SIMDS
+    return groups_per_simd * SANDBOX_CYCLES_PER_GROUP[waves] / (SANDBOX_CLOCK_GHZ * 1e6)
 
 
 def algorithmic_bytes():
@@ -340,7 +357,12 @@ def main():
                        **({"ranks_share_one_gpu": True} if shared else {})},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profile": traffic_info,
-                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": algorithmic_bytes()},
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": algorithmic_bytes(),
+                         "issue_floor_ms": round(issue_floor_ms(), 3),
+                         "issue_floor": {"ms_at_3_compute_waves_per_simd": round(issue_floor_ms("3_compute_waves_per_simd"), 3),
+                                         "source": "tools/sweep_sandbox.hip replay of the plane loop (taps + arithmetic + "
+                                                   "stores, nothing else), profiles/r03_sweep_sandbox.txt",
+                                         "kernel_over_floor": round(kern_ms / issue_floor_ms(), 3)}},
         }
         if per_rank is not None:
             line["per_rank"] = per_rank

@@ -31,7 +31,15 @@ class AffineDepth:
         return (self.maps[0:1] + k * self.maps[1:2]).contiguous()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The HIP stream torch currently queues work on.  torch.cuda.current_stream() builds a Stream object through several
+    Python layers (8 us; an AdaMVS view makes 860 launches: tools/host_profile.py); the raw handle is one C call."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
