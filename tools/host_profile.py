@@ -12,7 +12,6 @@ model = sys.argv[1] if len(sys.argv) > 1 else "casmvsnet"
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 config.switches["D3D_CONV_PRECISION"] = prec
 from deep3d_aerial_amd import ops
-ops.set_conv_precision(prec) if hasattr(ops, "set_conv_precision") else None
 net = predict.build_model(model, 384)
 S.fill_state_dict_(net.state_dict(), 1)
 net = net.cuda().eval()
@@ -38,6 +37,14 @@ with torch.no_grad():
     wall = (time.perf_counter() - t_all) / reps
     print("%s %s: forward returns after %.2f ms (median, host side incl. the model's one sync); %.2f ms per view with the GPU drained"
           % (model, prec, sorted(host)[reps // 2] * 1e3, wall * 1e3))
+    disp = []
+    for _ in range(reps):
+        torch.cuda.synchronize()          # idle GPU: the forward's own sync returns at once, the rest is queueing
+        t0 = time.perf_counter()
+        net(imgs, pm, dv, image_keys=keys)
+        disp.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    print("host dispatch of one view on an idle GPU (Python + launches, no waiting): %.2f ms (median of %d)" % (sorted(disp)[reps // 2] * 1e3, reps))
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(reps):
