@@ -59,6 +59,9 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
 // defined in planesweep_tiled.hip: returns D3D_ERR_UNSUPPORTED when the shape is outside
 // what the tiled kernel handles, in which case the caller uses the direct kernel.
 int launch_tiled(int mode, const struct SweepParams& p, hipStream_t stream);
+// defined in planesweep_window.hip: the shallow sweeps of the cascades (one window per patch, two workgroups per CU);
+// D3D_ERR_UNSUPPORTED outside its shapes
+int launch_window(int mode, const struct SweepParams& p, hipStream_t stream, bool forced);
 size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes);
 
 }  // namespace d3d
@@ -329,11 +332,15 @@ static int check_dims(int C, int D, int h, int w) {
 
 // Test hook (d3d_debug_force_path): pins the kernel family so that the parity suite can run both on the same inputs.
 // Every other experiment switch needs a -DD3D_EXPERIMENTS build; nothing here reads the environment.
-static std::atomic<int> g_force_path{0};   // 0 dispatcher's choice | 1 direct-gather kernel | 2 LDS-ring kernel
+static std::atomic<int> g_force_path{0};   // 0 dispatcher's choice | 1 direct-gather kernel | 2 LDS-ring kernel | 3 window kernel
 static int forced_path() { return g_force_path.load(std::memory_order_relaxed); }
 
 static int sweep_dispatch(int mode, const SweepParams& p, hipStream_t stream) {
     const int force = forced_path();
+    if (force == 0 || force == 3) {
+        int rc = launch_window(mode, p, stream, force == 3);
+        if (rc != D3D_ERR_UNSUPPORTED || force == 3) return rc;
+    }
     if (force != 1) {
         int rc = launch_tiled(mode, p, stream);
         if (rc != D3D_ERR_UNSUPPORTED) return rc;
@@ -369,7 +376,7 @@ int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_
 }
 
 int d3d_debug_force_path(int path) {
-    D3D_REQUIRE(path >= 0 && path <= 2, "path must be 0 (auto), 1 (direct) or 2 (tiled)");
+    D3D_REQUIRE(path >= 0 && path <= 3, "path must be 0 (auto), 1 (direct), 2 (tiled) or 3 (window)");
     g_force_path.store(path, std::memory_order_relaxed);
     return D3D_OK;
 }
@@ -463,8 +470,12 @@ int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, 
     if (rc) return rc;
     p.out_cl = 1;
     if (forced_path() == 1) {
-        set_error("d3d_variance_volume_cl_bf16: only the LDS-ring kernel writes channel-last volumes");
+        set_error("d3d_variance_volume_cl_bf16: only the LDS-ring and window kernels write channel-last volumes");
         return D3D_ERR_UNSUPPORTED;
+    }
+    if (forced_path() != 2) {
+        rc = launch_window(MODE_VARIANCE, p, (hipStream_t)stream, forced_path() == 3);
+        if (rc != D3D_ERR_UNSUPPORTED || forced_path() == 3) return rc;
     }
     return launch_tiled(MODE_VARIANCE, p, (hipStream_t)stream);
 }

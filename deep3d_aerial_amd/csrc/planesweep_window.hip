@@ -1,0 +1,660 @@
+// Window plane-sweep kernel for gfx950: the SHALLOW sweeps of the cascades (cas_mvsnet.py:211-226 -- stages 2 and 3 sweep 32 /
+// 8 hypotheses around the previous stage's depth, a few source pixels of disparity in all).
+//
+// The ring kernel (planesweep_tiled.hip) is built for deep sweeps: a planner picks step sizes, loader waves stream window
+// deltas into torus rings while compute waves sweep, one 12-wave workgroup owns all of a CU's LDS.  On an 8-plane sweep
+// a workgroup of that kernel lives ~38 k cycles of which ~6 k are arithmetic: the planning chain, the first window's
+// latency and the step barriers are all exposed because nothing else runs on the CU.  Here instead:
+//   * workgroup = a 32 x PH patch of reference pixels x ALL the planes of its segment x all channel groups; 8 or 6 waves
+//     (PH/2 pixel waves x plane sub-ranges), at most HALF a CU's LDS and 128 / 168 registers per lane, so TWO workgroups
+//     share a CU and one's loads run under the other's arithmetic;
+//   * no planner, no rings, no loader waves: per source view ONE window -- the hull of the patch over the depth range of
+//     the chunk of planes being swept (the projection is monotone in x, y and d separately, so the hull of the eight box
+//     corners bounds every sample; same margins and clamps as the ring kernel's planner) -- staged by all waves with
+//     coalesced planar loads, positions outside the image as zeros (= zero padding per tap);
+//   * every wave derives the windows itself from the same inputs (32 lanes = 8 corners x 4 views, DPP reductions,
+//     v_readlane): no planning barrier, the only barriers are "window staged" and "window free";
+//   * LDS layout: per view and 4-channel quad a dense [rows][cols] array of 16-byte cells, no padding: the 16 lanes a
+//     ds_read_b128 services together hold 16 consecutive pixels of a row, whose taps are 16 consecutive cells (64 banks);
+//   * if the windows of the whole segment do not fit, the segment is swept in chunks of half the planes (then a quarter ...);
+//     if not even one plane per sub-range fits (p.z <= 0 at a corner, extreme geometry) the chunk gathers from global
+//     memory with the ring kernel's fallback arithmetic.
+// Arithmetic per sample is the ring kernel's, instruction for instruction (geometry with two roundings + rcp/Newton, packed
+// blend in nw, ne, sw, se order, sum / sum of squares in view order): results are bit-identical to it and to the direct kernel.
+#include "common.h"
+
+#include "sweep_params.h"
+#include "sweep_device.h"
+
+#include <cstdlib>
+
+namespace d3d {
+
+namespace {
+
+constexpr int WTW = 32;               // patch width: one 128-byte output row segment per lane row
+// Two shapes of workgroup on the 32 x 8 patch:
+//   8 waves (4 pixel waves x 2 plane sub-ranges), 8-channel groups, half a CU's LDS, 128 registers: TWO workgroups per CU --
+//     shallow sweeps, where a workgroup's loads must run under another's arithmetic;
+//   12 waves (4 x 3), 16-channel groups (the geometry is paid once per 16 channels; four views' geometry stays live: 168
+//     registers), ALL of a CU's LDS, one workgroup per CU -- deep sweeps, where a chunk of planes computes for tens of
+//     thousands of cycles and the exposed staging of the next chunk is a few percent.
+constexpr int window_waves(int CH) { return CH == 8 ? 8 : 12; }
+constexpr int window_lds_bytes(int CH) { return CH == 8 ? 80 * 1024 : 160 * 1024; }
+constexpr int WDSEG_MAX = 32;         // planes per workgroup segment (upper bound)
+constexpr int WTAB = 2 * WDSEG_MAX;   // floats: per-plane depth range of the patch (pmin, pmax)
+
+struct WindowArgs {
+    int tiles_x, tiles_y, nseg, dseg, ngroups;
+    int cap_bytes;   // LDS bytes available for windows
+    unsigned long long* stats;   // -DD3D_EXPERIMENTS + D3D_WINDOW_STATS: [0] workgroups [1] staged chunks [2] planes in them [3] gathered planes
+                                 // [4] staged bytes / 16 [5] cycles staging (wave 0) [6] cycles sweeping (wave 0) [7] cycles total (wave 0)
+};
+
+#ifdef D3D_EXPERIMENTS
+#define D3D_WSTAT(i, v) do { if (a.stats && tid == 0) atomicAdd(a.stats + (i), (unsigned long long)(v)); } while (0)
+#define D3D_WCLOCK() (a.stats ? clock64() : 0ll)
+#else
+#define D3D_WSTAT(i, v) do { } while (0)
+#define D3D_WCLOCK() 0ll
+#endif
+
+// wave-uniform description of one view's staged window (scalar registers)
+struct WinView {
+    int wx0, wy0;   // source coordinates of cell (0, 0)
+    int ww, wh;     // cells per row / rows
+    int rowb;       // bytes per row of a quad plane (ww * 16)
+    int qb;         // bytes per quad plane (ww * wh * 16)
+    int base;       // absolute LDS byte address of quad 0, cell (0, 0)
+};
+
+// geo_ring (planesweep_tiled.hip) without the torus: same projection, clamps and weights; the cell address is relative to the
+// window origin.  Clamped samples lie in the clamped hull, so 0 <= column <= ww - 2 and 0 <= row <= wh - 2.
+__device__ __forceinline__ TapL geo_win(const Ray& r, float tx, float ty, float tz, float d, float umax, float vmax, const WinView& W) {
+    const float px = __fadd_rn(__fmul_rn(r.rx, d), tx);
+    const float py = __fadd_rn(__fmul_rn(r.ry, d), ty);
+    const float pz = __fadd_rn(__fmul_rn(r.rz, d), tz);
+    const float iz = __builtin_amdgcn_rcpf(pz);
+    const float u0 = px * iz, v0 = py * iz;
+    float u = fmaf(fmaf(-u0, pz, px), iz, u0);
+    float v = fmaf(fmaf(-v0, pz, py), iz, v0);
+    u = __builtin_amdgcn_fmed3f(u, -1.0f, umax);
+    v = __builtin_amdgcn_fmed3f(v, -1.0f, vmax);
+    const float fu = floorf(u), fv = floorf(v);
+    const float ax = u - fu, ay = v - fv;
+    const float bx = (fu + 1.0f) - u, by = (fv + 1.0f) - v;
+    TapL t;
+    t.nw = bx * by;
+    t.ne = ax * by;
+    t.sw = bx * ay;
+    t.se = ax * ay;
+    const int c = (int)fu - W.wx0, rr = (int)fv - W.wy0;
+    t.a0 = W.base + (int)__umul24((unsigned)rr, (unsigned)W.rowb) + c * 16;
+    t.a1 = t.a0 + W.rowb;
+    return t;
+}
+
+__device__ __forceinline__ void lds_write4_abs(int byte_addr, const f4& v) {
+    *(__attribute__((address_space(3))) f4*)(unsigned)byte_addr = v;
+}
+
+// min / max over aligned groups of 8 lanes
+__device__ __forceinline__ float grp8_min(float v) {
+    v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2)); v = fminf(v, __shfl_xor(v, 4));
+    return v;
+}
+__device__ __forceinline__ float grp8_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+    return v;
+}
+
+}  // namespace
+
+// PH: patch height (PH / 2 pixel waves; the rest of the workgroup's waves are plane sub-ranges).
+template <int MODE, int NSRC, int CH, bool OUTCL, int PH>
+__global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_window_kernel(SweepParams p, WindowArgs a) {
+    constexpr int WWAVES = window_waves(CH), WTHREADS = 64 * WWAVES;
+    static_assert(MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED, "window kernel: variance and weighted correlation");
+    static_assert(!OUTCL || MODE == MODE_VARIANCE, "channel-last bf16 output is the variance volume's");
+    static_assert(NSRC <= 8, "one lane per (corner, view): 8 x NSRC <= 64");
+    constexpr int NPW = PH / 2, NSUBW = WWAVES / NPW;   // pixel waves, plane sub-ranges
+    constexpr int Q = CH / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int pw = wave % NPW, sub = wave / NPW;
+    const long long t_begin = D3D_WCLOCK();
+    long long t_stage = 0, t_sweep = 0;
+    const int h = p.h, w = p.w, D = p.D;
+    const size_t plane = (size_t)h * w;
+
+    // block -> (patch row, segment, patch column): blocks b, b + 8, ... share an XCD (and its L2); within an XCD's run vertically
+    // adjacent patches come first (they share most of their source rows), as in the ring kernel
+    int b = blockIdx.x;
+    {
+        const int nblk = gridDim.x, per = nblk / 8;
+        if (nblk % 8 == 0) b = (b % 8) * per + b / 8;
+    }
+    const int ty = b % a.tiles_y;
+    const int seg = (b / a.tiles_y) % a.nseg;
+    const int tx = b / (a.tiles_y * a.nseg);
+    const int x0 = tx * WTW, y0 = ty * PH;
+    const int ds = seg * a.dseg, de = min(ds + a.dseg, D), nplanes = de - ds;
+    const int x1c = min(x0 + WTW - 1, w - 1), y1c = min(y0 + PH - 1, h - 1);
+
+    // lane -> pixel: row-major over the wave's two patch rows
+    const int px = x0 + (lane & 31), py = y0 + 2 * pw + (lane >> 5);
+    const bool valid = px < w && py < h;
+    const int pix = valid ? py * w + px : 0;
+    const unsigned pixb = (unsigned)pix * 4u;
+    const unsigned pixo = OUTCL ? (unsigned)pix * (unsigned)p.C * 2u : pixb;   // channel-last cells: h*w*C*2 < 2^32 (checked at launch)
+    const float xf = (float)px, yf = (float)py;
+
+    // ---- per-lane inputs, requested first: their latency runs under the range / window phases ------------------------------
+    Ray ray[NSRC];
+    float T0[NSRC], T1[NSRC], T2[NSRC];
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
+        ray[i] = make_ray(M, xf, yf);
+        T0[i] = M[3]; T1[i] = M[7]; T2[i] = M[11];
+        if (i >= p.n_src) {   // unused view of the template: every sample at (-1, -1), a zero cell (window (-1, -1, 2, 2) below)
+            ray[i].rx = 0.0f; ray[i].ry = 0.0f; ray[i].rz = 0.0f;
+            T0[i] = -1.0f; T1[i] = -1.0f; T2[i] = 1.0f;
+        }
+    }
+    float vw[NSRC];
+    float rden = 0.0f;
+    if (MODE == MODE_WEIGHTED) {
+        float den = 1e-5f;
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) {
+            const float t = p.weights[(size_t)min(i, p.n_src - 1) * plane + pix];
+            vw[i] = (valid && i < p.n_src) ? t : 0.0f;
+            den += vw[i];
+        }
+        rden = 1.0f / den;
+    }
+    float aff_lo = 1.0f, aff_step = 0.0f;
+    if (p.depth_mode == D3D_DEPTH_AFFINE && valid) {
+        aff_lo = p.depth[pix];
+        aff_step = p.depth[plane + pix];
+    }
+    // corner lanes: lane = 8 * view + corner (x end, y end, depth end)
+    const int cview = min(lane >> 3, NSRC - 1), ck = lane & 7;
+    Ray cray;
+    float cT0, cT1, cT2;
+    {
+        const float* __restrict__ M = p.proj34 + 12 * min(cview, p.n_src - 1);
+        cray = make_ray(M, (ck & 1) ? (float)x1c : (float)x0, (ck & 2) ? (float)y1c : (float)y0);
+        cT0 = M[3]; cT1 = M[7]; cT2 = M[11];
+    }
+
+    // ---- per-plane depth range of the patch (pmin, pmax) -> LDS table -------------------------------------------------------
+    constexpr int PPL = (WTW * PH) / 64;   // patch pixels per lane when one wave covers the patch
+    if (p.depth_mode == D3D_DEPTH_PER_PLANE) {
+        for (int i = tid; i < nplanes; i += WTHREADS) {
+            const float dv = p.depth[ds + i];
+            lds[i] = dv;
+            lds[WDSEG_MAX + i] = dv;
+        }
+    } else if (p.depth_mode == D3D_DEPTH_AFFINE) {
+        float blo[PPL], bst[PPL];
+        bool bok[PPL];
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int q = lane + 64 * k;
+            const int qx = x0 + (q & 31), qy = y0 + (q >> 5);
+            bok[k] = qx < w && qy < h;
+            const size_t qi = bok[k] ? (size_t)qy * w + qx : 0;
+            blo[k] = p.depth[qi];
+            bst[k] = p.depth[plane + qi];
+        }
+        for (int i = wave; i < nplanes; i += WWAVES) {
+            float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const float dv = __fadd_rn(blo[k], __fmul_rn((float)(ds + i), bst[k]));
+                if (bok[k]) { lo = fminf(lo, dv); hi = fmaxf(hi, dv); }
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if (lane == 0) { lds[i] = lo; lds[WDSEG_MAX + i] = hi; }
+        }
+    } else {
+        for (int i = wave; i < nplanes; i += WWAVES) {
+            float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const int q = lane + 64 * k;
+                const int qx = x0 + (q & 31), qy = y0 + (q >> 5);
+                if (qx < w && qy < h) {
+                    const float dv = p.depth[(size_t)(ds + i) * plane + (size_t)qy * w + qx];
+                    lo = fminf(lo, dv);
+                    hi = fmaxf(hi, dv);
+                }
+            }
+            lo = wave_min(lo);
+            hi = wave_max(hi);
+            if (lane == 0) { lds[i] = lo; lds[WDSEG_MAX + i] = hi; }
+        }
+    }
+    __syncthreads();
+
+    // 16-channel groups: the patch's REFERENCE features live in LDS too ([quad][pixel] 16-byte cells, a lane reads its own cell
+    // once per plane and quad) -- sixteen registers per lane the 128-register budget of two workgroups per CU does not have
+    constexpr bool REF_LDS = Q > 2;
+    constexpr int NPIX = WTW * PH;
+    constexpr int REF_BYTES = REF_LDS ? CH * NPIX * 4 : 0;
+    const int ref0 = lds_base_bytes(lds) + WTAB * 4;
+    const int my_ref = ref0 + (pw * 64 + lane) * 16;
+    const int lds0 = ref0 + REF_BYTES;
+    const int cap_bytes = a.cap_bytes - REF_BYTES;
+    const float umax = (float)w, vmax = (float)h;
+    const float invV = 1.0f / (float)(p.n_src + 1);
+    const size_t cstride_b = (p.plane_major ? plane : (size_t)D * plane) * 4;   // bytes between channels
+
+    // windows of the planes [c0p, c0p + n) of the segment; returns false when they cannot be bounded or do not fit
+    WinView W[NSRC];
+    auto windows = [&](int c0p, int n) -> bool {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = c0p; i < c0p + n; ++i) {
+            lo = fminf(lo, lds[i]);
+            hi = fmaxf(hi, lds[WDSEG_MAX + i]);
+        }
+        const float dv = (ck & 4) ? hi : lo;
+        const float qx = __fadd_rn(__fmul_rn(cray.rx, dv), cT0);
+        const float qy = __fadd_rn(__fmul_rn(cray.ry, dv), cT1);
+        const float qz = __fadd_rn(__fmul_rn(cray.rz, dv), cT2);
+        bool ok = (qz > 1e-20f) && (qz < 1e30f);
+        const float iz = 1.0f / qz;
+        float u = qx * iz, v = qy * iz;
+        ok = ok && (fabsf(u) < 1e30f) && (fabsf(v) < 1e30f);
+        u = fminf(fmaxf(u, -1.0f), (float)w);   // the same clamp as the samples' (geo_win)
+        v = fminf(fmaxf(v, -1.0f), (float)h);
+        const float umn = grp8_min(u), umx = grp8_max(u), vmn = grp8_min(v), vmx = grp8_max(v);
+        const float okf = grp8_min(ok ? 1.0f : 0.0f);
+        // interior samples differ from the corner hull by fp32 rounding only (<< 1/16 px)
+        const int wx0 = max((int)floorf(umn - 0.0625f), -1);
+        const int wy0 = max((int)floorf(vmn - 0.0625f), -1);
+        const int wx1 = min((int)floorf(umx + 0.0625f) + 1, w + 1);
+        const int wy1 = min((int)floorf(vmx + 0.0625f) + 1, h + 1);
+        bool good = true;
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) {
+            const int src = 8 * i;
+            W[i].wx0 = __builtin_amdgcn_readlane(wx0, src);
+            W[i].wy0 = __builtin_amdgcn_readlane(wy0, src);
+            W[i].ww = max(__builtin_amdgcn_readlane(wx1, src) - W[i].wx0 + 1, 2);
+            W[i].wh = max(__builtin_amdgcn_readlane(wy1, src) - W[i].wy0 + 1, 2);
+            good = good && (__builtin_amdgcn_readlane(__float_as_int(okf), src) != 0);
+            if (i >= p.n_src) { W[i].wx0 = -1; W[i].wy0 = -1; W[i].ww = 2; W[i].wh = 2; }
+            W[i].rowb = W[i].ww * 16;
+            W[i].qb = W[i].rowb * W[i].wh;
+            W[i].base = lds0 + off;
+            good = good && W[i].ww < 1024 && W[i].wh < 1024;
+            off += good ? W[i].qb * Q : 0;
+            good = good && off <= cap_bytes;
+        }
+        return good;
+    };
+
+    f4 r[REF_LDS ? 1 : Q];   // reference features of the group (8-channel groups: registers)
+    unsigned long long even_quad = 0;
+    auto finalize_store = [&](const f4& s, const f4& qq, unsigned long long& ob, int q) {
+        f4 o;
+        if (MODE == MODE_VARIANCE) {
+            const f2 iv = {invV, invV};
+            const f2 ml = lo2(s) * iv, mh = hi2(s) * iv;
+            o = cat2(pk_fma(lo2(qq), iv, -(ml * ml)), pk_fma(hi2(qq), iv, -(mh * mh)));
+        } else {
+            o = s * rden;
+        }
+        if constexpr (OUTCL) {
+            if ((q & 1) == 0) {
+                even_quad = pack_bf16x4(o);
+            } else {
+                store_sbase_bf16x8(ob, pixo, even_quad, pack_bf16x4(o));
+                ob += 16;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                store_sbase(ob, pixb, o[k]);
+                ob += cstride_b;
+            }
+        }
+    };
+    auto accumulate = [&](f4& s, f4& qq, const f4& val, const f4& rq, int i) {
+        if (MODE == MODE_VARIANCE) {
+            const f2 vl = lo2(val), vh = hi2(val);
+            s = cat2(lo2(s) + vl, hi2(s) + vh);
+            qq = cat2(pk_fma(vl, vl, lo2(qq)), pk_fma(vh, vh, hi2(qq)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = fmaf(val[k] * rq[k], vw[i], s[k]);
+        }
+    };
+
+    for (int gi = 0; gi < a.ngroups; ++gi) {
+        const int c0 = gi * CH;
+        if constexpr (REF_LDS) {
+            for (int idx = tid; idx < Q * NPIX; idx += WTHREADS) {   // (read after the chunk's "windows staged" barrier)
+                const int q = idx / NPIX, pp = idx - q * NPIX;
+                const int qx = x0 + (pp & 31), qy = y0 + (pp >> 5);
+                const bool in = qx < w && qy < h;
+                const float* __restrict__ sq = p.feats[0] + (size_t)(c0 + 4 * q) * plane + (in ? (size_t)qy * w + qx : 0);
+                f4 v;
+                v[0] = sq[0]; v[1] = sq[plane]; v[2] = sq[2 * plane]; v[3] = sq[3 * plane];
+                if (!in) v = (f4){0, 0, 0, 0};
+                lds_write4_abs(ref0 + idx * 16, v);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
+                    r[REF_LDS ? 0 : q][k] = valid ? t : 0.0f;
+                }
+        }
+        // one plane of the segment for this wave's pixels
+        auto sweep_plane = [&](const int dl_, const bool staged) {
+            const int d = ds + dl_;
+            float dv;
+            if (p.depth_mode == D3D_DEPTH_PER_PIXEL) {
+                const float t = p.depth[(size_t)d * plane + pix];
+                dv = valid ? t : 1.0f;
+            } else if (p.depth_mode == D3D_DEPTH_AFFINE) {
+                dv = __fadd_rn(aff_lo, __fmul_rn((float)d, aff_step));
+            } else {
+                dv = lds[dl_];
+            }
+            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) + (size_t)d * plane * p.C + c0)
+                                          : uniform64(p.out + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);
+            if (!valid) return;
+            if constexpr (Q > 2) { if (staged) {
+                // Unit-major (16-channel groups): units u = (quad q, view i) in q-major order, one quad's accumulators live, the
+                // four views' geometry kept for the whole plane (the ring kernel's order)
+                TapL t[NSRC];
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) t[i] = geo_win(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, W[i]);
+                constexpr int NU = Q * NSRC;
+                f4 tp[2][4];
+                auto request = [&](int u, f4 (&dst)[4]) {
+                    const int q2 = u / NSRC, i2 = u % NSRC;
+                    const int n = t[i2].a0 + q2 * W[i2].qb, s_ = t[i2].a1 + q2 * W[i2].qb;
+                    dst[0] = lds_read4_abs(n);
+                    dst[1] = lds_read4_abs(n + 16);
+                    dst[2] = lds_read4_abs(s_);
+                    dst[3] = lds_read4_abs(s_ + 16);
+                };
+                f4 rq = lds_read4_abs(my_ref);
+                request(0, tp[0]);
+                f4 s, qq;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int q = u / NSRC, i = u % NSRC;
+                    if (u + 1 < NU) request(u + 1, tp[(u + 1) & 1]);
+                    if (i == 0) {
+                        if (MODE == MODE_VARIANCE) { s = rq; qq = s * s; }
+                        else { s = (f4){0, 0, 0, 0}; qq = s; }
+                    }
+                    f4 (&c)[4] = tp[u & 1];
+                    asm volatile("" : "+v"(c[3]));   // one wait per unit (LDS returns in order)
+                    const f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
+                    accumulate(s, qq, val, rq, i);
+                    if (i == NSRC - 1 && q + 1 < Q) rq = lds_read4_abs(my_ref + (q + 1) * (NPIX * 16));   // (weighted mode reads rq until here)
+                    if (i == NSRC - 1) finalize_store(s, qq, ob, q);
+                }
+            } }
+            if constexpr (Q <= 2) { if (staged) {
+                // View-major (8-channel groups): ONE view's geometry is live at a time (the next view's is computed while this view's taps are in
+                // flight) and the accumulators of the group's quads stay in registers until the last view -- the unit-major
+                // order of the ring kernel keeps 4 x (2 addresses + 4 weights) alive and does not fit 128 registers.  Per channel
+                // the views are still added in order 0, 1, ...: the same sums.
+                f4 s[Q], qq[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    if (MODE == MODE_VARIANCE) { s[q] = r[REF_LDS ? 0 : q]; qq[q] = s[q] * s[q]; }
+                    else { s[q] = (f4){0, 0, 0, 0}; qq[q] = s[q]; }
+                }
+                f4 tp[Q][4];
+                auto request = [&](const TapL& g, int i2, int q2) {
+                    const int n = g.a0 + q2 * W[i2].qb, s_ = g.a1 + q2 * W[i2].qb;
+                    tp[q2][0] = lds_read4_abs(n);
+                    tp[q2][1] = lds_read4_abs(n + 16);
+                    tp[q2][2] = lds_read4_abs(s_);
+                    tp[q2][3] = lds_read4_abs(s_ + 16);
+                };
+                TapL gc = geo_win(ray[0], T0[0], T1[0], T2[0], dv, umax, vmax, W[0]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) request(gc, 0, q);
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every view's geometry to the top)
+                    TapL gn = gc;
+                    if (i + 1 < NSRC) gn = geo_win(ray[i + 1], T0[i + 1], T1[i + 1], T2[i + 1], dv, umax, vmax, W[i + 1]);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        asm volatile("" : "+v"(tp[q][3]));   // one wait per quad (LDS returns in order)
+                        const f4 val = blend(tp[q][0], tp[q][1], tp[q][2], tp[q][3], gc.nw, gc.ne, gc.sw, gc.se);
+                        if (i + 1 < NSRC) request(gn, i + 1, q);   // the next view's taps of this quad, into the registers just read
+                        accumulate(s[q], qq[q], val, r[REF_LDS ? 0 : q], i);
+                    }
+                    gc = gn;
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) finalize_store(s[q], qq[q], ob, q);
+            } }
+            if (!staged) {   // taps from the planar maps in global memory (the ring kernel's fallback arithmetic), one view at a time
+                f4 s[Q], qq[Q], rf[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    if constexpr (REF_LDS) {   // (no barrier on this path: the reference features straight from global memory)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rf[q][k] = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
+                    } else {
+                        rf[q] = r[REF_LDS ? 0 : q];
+                    }
+                    if (MODE == MODE_VARIANCE) { s[q] = rf[q]; qq[q] = s[q] * s[q]; }
+                    else { s[q] = (f4){0, 0, 0, 0}; qq[q] = s[q]; }
+                }
+                for (int i = 0; i < p.n_src; ++i) {
+                    const float* __restrict__ M = p.proj34 + 12 * i;
+                    const Ray rr = make_ray(M, xf, yf);
+                    float u, v;
+                    project(rr, M[3], M[7], M[11], dv, h, w, u, v);
+                    const TapG t = make_tap_glb(u, v, h, w);
+                    const float vwi = (MODE == MODE_WEIGHTED) ? p.weights[(size_t)i * plane + pix] : 0.0f;
+                    const float* __restrict__ g = p.feats[i + 1] + (size_t)c0 * plane + t.off;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        f4 val;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const float* __restrict__ gk = g + (size_t)(4 * q + kk) * plane;
+                            val[kk] = fmaf(gk[t.dyw + t.dx], t.se, fmaf(gk[t.dyw], t.sw, fmaf(gk[t.dx], t.ne, gk[0] * t.nw)));
+                        }
+                        if (MODE == MODE_VARIANCE) {
+                            accumulate(s[q], qq[q], val, rf[q], 0);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) s[q][k] = fmaf(val[k] * rf[q][k], vwi, s[q][k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) finalize_store(s[q], qq[q], ob, q);
+            }
+        };
+
+        // ---- chunks of planes: as many of the planes that are left as have windows that fit -----------------------------------
+        int done = 0;
+        while (done < nplanes) {
+            int n = nplanes - done;
+            bool fit = windows(done, n);
+            while (!fit && n > NSUBW) {   // three quarters of the planes, in whole rounds of the sub-ranges
+                n = max((n * 3 / 4) / NSUBW * NSUBW, NSUBW);
+                fit = windows(done, n);
+            }
+            if (fit) {
+                const long long ts0 = D3D_WCLOCK();
+                D3D_WSTAT(1, 1); D3D_WSTAT(2, n);
+                // Stage.  A wave takes whole (quad, row) items of a view: the row is wave-uniform (scalar address arithmetic, no
+                // division), the lane is the column; the loads of SU items (4 x SU coalesced 4-byte loads per lane, addresses
+                // clamped into the image so none is conditional) are issued before the first 16-byte LDS write.  The other
+                // workgroup of the CU sweeps meanwhile.  (Tried and dropped: one batch over all views -- the 64 data registers
+                // and their 64-bit addresses spill into the plane loop; buffer loads with scalar row offsets -- the same.)
+                constexpr int SU = 4;
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) {
+                    if (i >= p.n_src) {   // the zero cells of an unused view
+                        for (int idx = tid; idx < 4 * Q; idx += WTHREADS) lds_write4_abs(W[i].base + idx * 16, (f4){0, 0, 0, 0});
+                        continue;
+                    }
+                    const int nitem = Q * W[i].wh;
+                    const float* __restrict__ src = p.feats[i + 1] + (size_t)c0 * plane;
+                    for (int col0 = 0; col0 < W[i].ww; col0 += 64) {   // (windows wider than 64 cells: rare)
+                        const int col = col0 + lane;
+                        const int sx = W[i].wx0 + col;
+                        const bool colin = col < W[i].ww;
+                        const bool xin = colin && sx >= 0 && sx < w;
+                        const int sxc = min(max(sx, 0), w - 1);
+                        const int cadr = W[i].base + col * 16;
+                        for (int it0 = wave; it0 < nitem; it0 += SU * WWAVES) {
+                            f4 v[SU];
+#pragma unroll
+                            for (int k = 0; k < SU; ++k) {
+                                const int it = min(it0 + k * WWAVES, nitem - 1);
+                                int q = 0;
+#pragma unroll
+                                for (int qq_ = 1; qq_ < Q; ++qq_) q += (it >= qq_ * W[i].wh) ? 1 : 0;
+                                const int row = it - q * W[i].wh;
+                                const int sy = W[i].wy0 + row;
+                                const bool yin = sy >= 0 && sy < h;
+                                const int syc = min(max(sy, 0), h - 1);
+                                const float* __restrict__ g = src + (size_t)(4 * q) * plane + (size_t)syc * w + sxc;
+                                v[k][0] = g[0]; v[k][1] = g[plane]; v[k][2] = g[2 * plane]; v[k][3] = g[3 * plane];
+                                if (!(xin && yin)) v[k] = (f4){0, 0, 0, 0};
+                            }
+#pragma unroll
+                            for (int k = 0; k < SU; ++k) {
+                                const int it = it0 + k * WWAVES;
+                                int q = 0;
+#pragma unroll
+                                for (int qq_ = 1; qq_ < Q; ++qq_) q += (it >= qq_ * W[i].wh) ? 1 : 0;
+                                const int row = it - q * W[i].wh;
+                                if (it < nitem && colin) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[k]);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();   // windows staged
+                const long long ts1 = D3D_WCLOCK();
+                for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, true);
+                __syncthreads();   // windows free (next chunk / next channel group)
+                t_stage += ts1 - ts0;
+                t_sweep += D3D_WCLOCK() - ts1;
+#ifdef D3D_EXPERIMENTS
+                { int cells = 0;
+#pragma unroll
+                  for (int i = 0; i < NSRC; ++i) cells += W[i].qb / 16 * Q;
+                  D3D_WSTAT(4, cells); }
+#endif
+            } else {
+                D3D_WSTAT(3, n);
+                for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, false);
+            }
+            done += n;
+        }
+    }
+    D3D_WSTAT(0, 1); D3D_WSTAT(5, t_stage); D3D_WSTAT(6, t_sweep); D3D_WSTAT(7, D3D_WCLOCK() - t_begin);
+    (void)t_begin; (void)t_stage; (void)t_sweep;
+}
+
+template <int MODE, int NSRC, int CH, bool OUTCL, int PH>
+static int launch_window_one(const SweepParams& p, hipStream_t stream) {
+    auto kern = sweep_window_kernel<MODE, NSRC, CH, OUTCL, PH>;
+    constexpr int WLDS_BYTES = window_lds_bytes(CH);
+    if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WLDS_BYTES);
+    if (rc != D3D_OK) return rc;
+    WindowArgs a;
+    a.ngroups = p.C / CH;
+    a.tiles_x = ceil_div(p.w, WTW);
+    a.tiles_y = ceil_div(p.h, PH);
+    a.nseg = ceil_div(p.D, WDSEG_MAX);
+    a.dseg = ceil_div(p.D, a.nseg);
+    a.nseg = ceil_div(p.D, a.dseg);
+    a.cap_bytes = WLDS_BYTES - WTAB * 4;
+    a.stats = nullptr;
+    const long nblk = (long)a.tiles_x * a.tiles_y * a.nseg;
+    if (nblk > 0x7fffffffL) return D3D_ERR_UNSUPPORTED;
+#ifdef D3D_EXPERIMENTS
+    if (getenv("D3D_WINDOW_STATS")) {   // debug only: synchronous, allocates
+        (void)hipMalloc(&a.stats, 8 * sizeof(unsigned long long));
+        (void)hipMemset(a.stats, 0, 8 * sizeof(unsigned long long));
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * window_waves(CH)), WLDS_BYTES, stream, p, a);
+    D3D_LAUNCH_CHECK("sweep_window_kernel launch");
+#ifdef D3D_EXPERIMENTS
+    if (a.stats) {
+        unsigned long long hs[8];
+        (void)hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
+        const double n = (double)hs[0];
+        fprintf(stderr, "[d3d window stats] CH=%d waves=%d wgs=%.0f groups=%d | per workgroup: staged chunks %.2f, planes per chunk %.2f, gathered planes %.2f, "
+                "staged KB %.1f | cycles (wave 0): staging %.0f, sweeping %.0f, total %.0f\n", CH, window_waves(CH), n, a.ngroups, hs[1] / n,
+                hs[1] ? (double)hs[2] / hs[1] : 0.0, hs[3] / n, hs[4] * 16.0 / 1024.0 / n, hs[5] / n, hs[6] / n, hs[7] / n);
+        (void)hipFree(a.stats);
+    }
+#endif
+    return D3D_OK;
+}
+
+#ifndef D3D_WINDOW_PLANES
+#define D3D_WINDOW_PLANES 48   // sweeps of at most this many planes take the window kernel (0: never): every stage of the cascades
+#endif
+
+template <int MODE, int NSRC>
+static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
+    // (-DD3D_WINDOW_CG16: 16-channel groups on 12-wave workgroups that own the CU's LDS, for deep sweeps -- the geometry is paid
+    //  once per 16 channels, but the windows are twice as large, nothing hides their staging, and chunks shrink: config 2 7.3 ms
+    //  against 6.7 ms for the 8-channel form and 5.8 ms for the ring kernel; stage 2 of the cascade 1.33 against 1.31 ms)
+#ifdef D3D_WINDOW_CG16
+    const bool cg16 = p.C % 16 == 0 && p.D >= D3D_WINDOW_CG16;
+#else
+    constexpr bool cg16 = false;
+#endif
+    if constexpr (MODE == MODE_VARIANCE) {
+        if (p.out_cl) {
+#ifdef D3D_WINDOW_CG16
+            if (cg16) return launch_window_one<MODE, NSRC, 16, true, 8>(p, stream);
+#endif
+            return launch_window_one<MODE, NSRC, 8, true, 8>(p, stream);
+        }
+    }
+    if (p.out_cl) return D3D_ERR_UNSUPPORTED;
+#ifdef D3D_WINDOW_CG16
+    if (cg16) return launch_window_one<MODE, NSRC, 16, false, 8>(p, stream);
+#endif
+    (void)cg16;
+    return launch_window_one<MODE, NSRC, 8, false, 8>(p, stream);
+}
+
+// Returns D3D_ERR_UNSUPPORTED for shapes outside what the window kernel is built for (the caller then takes the ring kernel).
+// `forced`: the test hook asked for this kernel -- the plane limit of the dispatcher's choice does not apply.
+int launch_window(int mode, const SweepParams& p, hipStream_t stream, bool forced) {
+    if (p.elem_bytes != 4 || p.C % 8 != 0 || p.n_src > 4 || p.n_src < 1) return D3D_ERR_UNSUPPORTED;
+    if (mode != MODE_VARIANCE && mode != MODE_WEIGHTED) return D3D_ERR_UNSUPPORTED;
+    if (!forced && (D3D_WINDOW_PLANES == 0 || p.D > D3D_WINDOW_PLANES)) return D3D_ERR_UNSUPPORTED;
+    if (mode == MODE_VARIANCE)
+        return p.n_src <= 2 ? launch_window_ch<MODE_VARIANCE, 2>(p, stream) : launch_window_ch<MODE_VARIANCE, 4>(p, stream);
+    return p.n_src <= 2 ? launch_window_ch<MODE_WEIGHTED, 2>(p, stream) : launch_window_ch<MODE_WEIGHTED, 4>(p, stream);
+}
+
+}  // namespace d3d

@@ -65,9 +65,9 @@ def _sync_force_path():
     """D3D_FORCE_PATH = direct | tiled (tests, profiling): forwarded to the library's test hook when it changes."""
     want = _cfg.get("D3D_FORCE_PATH")
     if want != _forced[0]:
-        code = {"": 0, "auto": 0, "direct": 1, "tiled": 2}.get(want)
+        code = {"": 0, "auto": 0, "direct": 1, "tiled": 2, "window": 3}.get(want)
         if code is None:
-            raise ValueError("D3D_FORCE_PATH must be direct, tiled or unset (got %r)" % want)
+            raise ValueError("D3D_FORCE_PATH must be direct, tiled, window or unset (got %r)" % want)
         _lib.check(_lib.load().d3d_debug_force_path(code), "d3d_debug_force_path")
         _forced[0] = want
 

@@ -44,7 +44,7 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(params=["auto", "direct", "tiled"])
+@pytest.fixture(params=["auto", "direct", "tiled", "window"])
 def path(request):
     """Runs a test on the dispatcher's choice and with each kernel family forced."""
     old = config.switches.get("D3D_FORCE_PATH")
@@ -63,8 +63,8 @@ def _run_or_skip_unsupported(fn, path):
     try:
         return fn()
     except RuntimeError as e:
-        if path == "tiled" and "unsupported" in str(e):
-            pytest.skip("shape outside the tiled kernel's domain (dispatcher uses the direct kernel)")
+        if path in ("tiled", "window") and "unsupported" in str(e):
+            pytest.skip("shape outside the %s kernel's domain (the dispatcher takes another kernel)" % path)
         raise
 
 
@@ -354,6 +354,75 @@ def test_affine_depth_mode_is_the_per_pixel_mode_without_the_volume(ops, oracle,
     vol2 = ops.resize_bilinear(vol, H2, W2)
     aff2 = ops.AffineDepth(ops.resize_bilinear(aff.maps, H2, W2), D)
     assert rel_l1(host(aff2.volume()), host(vol2)) <= 1e-6
+
+
+WINDOW_CASES = [
+    # V, C, h, w, D, sweep_px, yaw, per-pixel hypotheses
+    (5, 8, 464, 688, 8, 6.0, 1.0, True),       # the last cascade stage's form (quarter size)
+    (5, 16, 232, 344, 32, 20.0, 2.0, True),    # stage 2's: two channel groups of 8
+    (3, 8, 37, 70, 16, 4.0, 8.0, True),        # ragged patches, two source views on the four-view template
+    (4, 32, 50, 90, 48, 30.0, 3.0, False),     # three sources, two depth segments, per-plane depths
+    (5, 8, 96, 160, 8, 260.0, 5.0, False),     # windows that do not fit: chunks of planes, then the gather fallback
+    (2, 8, 33, 41, 3, 2.0, 0.0, True),         # one source view
+]
+
+
+@pytest.mark.parametrize("case", WINDOW_CASES, ids=lambda c: "V%d_C%d_%dx%d_D%d_sweep%d" % c[:6])
+def test_window_kernel_repeats_the_ring_kernel_bit_for_bit(ops, oracle, case):
+    """The window kernel (planesweep_window.hip: one staged window per patch, the cascades' shallow sweeps) against the ring
+    kernel and the oracle: same arithmetic per sample, so the volumes are bit-identical in every mode and output format."""
+    V, C, h, w, D, sweep, yaw, perpix = case
+    proj, dv = S.make_scene(V, h, w, max(D, 8), sweep_px=sweep, seed=V + C + D, yaw_deg=yaw)
+    feats = S.make_features(V, C, h, w, seed=C + D)
+    rng = np.random.default_rng(D + C + h)
+    fd = [dev(f) for f in feats]
+    p34 = ops.compose_projections(dev(proj))
+    span = float(dv[1] - dv[0])
+    if perpix:
+        cur = (0.5 * (dv[0] + dv[1]) + 0.2 * span * rng.uniform(-1, 1, (h, w))).astype(np.float32)
+        depth = ops.depth_range_affine(dev(cur), D, span / 2.0 / D)
+        depth_vol = depth.volume()
+    else:
+        depth = dev(S.uniform_depths(dv, D))
+        depth_vol = None
+    vw = dev(rng.uniform(0.02, 1.0, (V - 1, h, w)))
+    outs = {}
+    for path_ in ("tiled", "window"):
+        config.switches["D3D_FORCE_PATH"] = path_
+        try:
+            outs[path_] = (ops.variance_volume(fd, p34, depth), ops.weighted_corr(fd, p34, vw, depth),
+                           ops.variance_volume_cl(fd, p34, depth),
+                           None if depth_vol is None else ops.variance_volume(fd, p34, depth_vol))
+        finally:
+            config.switches["D3D_FORCE_PATH"] = ""
+    for a, b in zip(outs["tiled"], outs["window"]):
+        assert a is None or torch.equal(a, b)
+    if h * w * D <= 1 << 21:
+        want = oracle.variance_volume(feats[0], feats[1:], host(p34).reshape(-1, 3, 4),
+                                      host(depth_vol) if perpix else host(depth))
+        assert rel_l1(host(outs["window"][0]), want) <= REL_VOLUME
+
+
+def test_window_kernel_full_size_last_stage(ops):
+    """The shape the dispatcher sends to the window kernel inside a cascade view: 8 channels x 8 per-pixel hypotheses at
+    1856 x 2752, five views -- dispatcher's choice against the ring kernel, bit for bit, all three products."""
+    V, C, h, w, D = 5, 8, 1856, 2752, 8
+    proj, dv = S.make_scene(V, h, w, 96, seed=3)
+    fd = [torch.randn(C, h, w, device="cuda", generator=torch.Generator("cuda").manual_seed(i)) for i in range(V)]
+    p34 = ops.compose_projections(dev(proj))
+    cur = torch.full((h, w), float(dv.mean()), device="cuda") + 0.02 * float(dv[1] - dv[0]) * torch.rand(h, w, device="cuda")
+    depth = ops.depth_range_affine(cur, D, float(dv[1] - dv[0]) / 384)
+    vw = torch.rand(V - 1, h, w, device="cuda")
+    res = {}
+    for path_ in ("tiled", ""):
+        config.switches["D3D_FORCE_PATH"] = path_
+        try:
+            res[path_] = (ops.variance_volume(fd, p34, depth), ops.weighted_corr(fd, p34, vw, depth),
+                          ops.variance_volume_cl(fd, p34, depth))
+        finally:
+            config.switches["D3D_FORCE_PATH"] = ""
+    for a, b in zip(res["tiled"], res[""]):
+        assert torch.equal(a, b)
 
 
 def test_full_size_config5_fp16_ring(ops):

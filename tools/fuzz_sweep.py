@@ -1,4 +1,5 @@
-"""Random-scene cross-check of the ring (tiled) cost-volume kernel against the direct-gather kernel (GPU box)."""
+"""Random-scene cross-check of the ring (tiled) and window cost-volume kernels against the direct-gather kernel (GPU box):
+ring vs direct within the gather tolerance, window vs ring bit for bit (the same arithmetic per sample)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +25,7 @@ for case in range(n_cases):
         depth = torch.from_numpy(S.uniform_depths(dv, D)).cuda()
     wts = torch.rand(V - 1, h, w, device="cuda")
     outs = {}
-    for path in ("tiled", "direct"):
+    for path in ("tiled", "direct", "window"):
         config.switches["D3D_FORCE_PATH"] = path
         try:
             if mode == "variance":
@@ -54,6 +55,16 @@ for case in range(n_cases):
         nbad = int((cl.view(torch.int16) != want.view(torch.int16)).sum())
         cl_note = " | channel-last: %d differing values" % nbad
         bad = bad or nbad > 0
+    if outs["window"] is not None:   # the window kernel (forced: any depth of sweep) repeats the ring kernel's arithmetic exactly
+        nw = int((outs["window"] != a).sum())
+        cl_note += " | window: %d differing values" % nw
+        bad = bad or nw > 0
+        if mode == "variance" and C % 8 == 0:
+            config.switches["D3D_FORCE_PATH"] = "window"
+            clw = ops.variance_volume_cl(feats, p34, depth)
+            nwc = int((clw.view(torch.int16) != outs["window"].to(torch.bfloat16).permute(1, 2, 3, 0).contiguous().view(torch.int16)).sum())
+            cl_note += ", its channel-last form %d" % nwc
+            bad = bad or nwc > 0
     print("%-66s rel-L1 %.2e max-abs %.2e%s %s" % (tag, rel, err, cl_note, "  <-- MISMATCH" if bad else ""), flush=True)
     if bad:
         worst = 1.0

@@ -4,7 +4,8 @@
 # Each variant is linked to a scratch library of its own and selected through D3D_LIBRARY (deep3d_aerial_amd/_lib.py):
 # the in-tree production library is never touched.  EXP=1 builds the variants with -DD3D_EXPERIMENTS (cycle statistics,
 # D3D_TILED_* switches; prints the per-workgroup statistics).  CMD="..." runs that command instead of bench.py;
-# C5=f16|f32 runs tools/config5_bench.py.  PMC=1 adds one rocprofv3 counter pass per variant.
+# C5=f16|f32 runs tools/config5_bench.py.  PMC=1 adds one rocprofv3 counter pass per variant.  SRC=planesweep_window.hip builds
+# variants of the window kernel instead (D3D_WINDOW_STATS=1 is set beside D3D_TILED_STATS=1 for CMD runs).
 [ -n "$GRAFT_REPO_ROOT" ] || { echo "GRAFT_REPO_ROOT is not set"; exit 2; }
 cd "$GRAFT_REPO_ROOT" || exit 2
 CS=deep3d_aerial_amd/csrc
@@ -12,14 +13,15 @@ OBJS=$(make -s -C $CS print-objs)
 VDIR=$(mktemp -d /tmp/d3d_ab.XXXXXX)
 trap 'rm -rf "$VDIR"' EXIT
 EXPF=; [ -n "$EXP" ] && EXPF=-DD3D_EXPERIMENTS
+SRC=${SRC:-planesweep_tiled.hip}
 n=0
 for flags in "$@"; do
   n=$((n+1)); V=$VDIR/v$n.so
-  (cd $CS && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -w $EXPF $flags -c -o $VDIR/v.o planesweep_tiled.hip \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $V $(echo $OBJS | sed "s#planesweep_tiled.o#$VDIR/v.o#")) || { echo "build failed: $flags"; continue; }
+  (cd $CS && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=off -w $EXPF $flags -c -o $VDIR/v.o $SRC \
+    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $V $(echo $OBJS | sed "s#${SRC%.hip}.o#$VDIR/v.o#")) || { echo "build failed: $flags"; continue; }
   export D3D_LIBRARY=$V
   if [ -n "$CMD" ]; then
-    echo "[$flags]"; D3D_TILED_STATS=1 $CMD 2>&1 | grep -av amdgpu.ids | cut -c1-400
+    echo "[$flags]"; D3D_TILED_STATS=1 D3D_WINDOW_STATS=1 $CMD 2>&1 | grep -av amdgpu.ids | cut -c1-400
   elif [ -n "$C5" ]; then
     D3D_TILED_STATS=1 D3D_FORCE_PATH=tiled python tools/config5_bench.py $C5 tiled 2>&1 | grep -a "per-WG\|tiled stats\|config 5" | tail -3 | cut -c1-330
   else
