@@ -66,6 +66,8 @@ struct WinView {
     int rowb;       // bytes per row of a quad plane (ww * 16)
     int qb;         // bytes per quad plane (ww * wh * 16)
     int base;       // absolute LDS byte address of quad 0, cell (0, 0)
+    int basem;      // base - wy0 * rowb - wx0 * 16: the address of source position (0, 0), so that the plane loop adds floor(v) * rowb
+                    // + floor(u) * 16 without subtracting the window origin (two instructions and two scalar registers per view less)
 };
 
 // geo_ring (planesweep_tiled.hip) without the torus: same projection, clamps and weights; the cell address is relative to the
@@ -88,8 +90,7 @@ __device__ __forceinline__ TapL geo_win(const Ray& r, float tx, float ty, float 
     t.ne = ax * by;
     t.sw = bx * ay;
     t.se = ax * ay;
-    const int c = (int)fu - W.wx0, rr = (int)fv - W.wy0;
-    t.a0 = W.base + (int)__umul24((unsigned)rr, (unsigned)W.rowb) + c * 16;
+    t.a0 = __mul24((int)fv, W.rowb) + W.basem + ((int)fu << 4);   // floor(v) >= -1: signed 24-bit product
     t.a1 = t.a0 + W.rowb;
     return t;
 }
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
             W[i].rowb = W[i].ww * 16;
             W[i].qb = W[i].rowb * W[i].wh;
             W[i].base = lds0 + off;
+            W[i].basem = W[i].base - W[i].wy0 * W[i].rowb - W[i].wx0 * 16;
             good = good && W[i].ww < 1024 && W[i].wh < 1024;
             off += good ? W[i].qb * Q : 0;
             good = good && off <= cap_bytes;
@@ -360,6 +362,15 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
                     const float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
                     r[REF_LDS ? 0 : q][k] = valid ? t : 0.0f;
                 }
+            // The loads above are waited for HERE, once: a wait left to the first use would sit inside the plane loop, where the
+            // counter it waits on also counts the previous plane's stores -- every plane would wait for its predecessor's stores.
+#pragma unroll
+            for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(r[REF_LDS ? 0 : q]));
+        }
+        asm volatile("" : "+v"(aff_lo), "+v"(aff_step), "+v"(rden));
+        if (MODE == MODE_WEIGHTED) {
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) asm volatile("" : "+v"(vw[i]));
         }
         // one plane of the segment for this wave's pixels
         auto sweep_plane = [&](const int dl_, const bool staged) {
@@ -504,26 +515,27 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
             if (fit) {
                 const long long ts0 = D3D_WCLOCK();
                 D3D_WSTAT(1, 1); D3D_WSTAT(2, n);
-                // Stage.  A wave takes whole (quad, row) items of a view: the row is wave-uniform (scalar address arithmetic, no
-                // division), the lane is the column; the loads of SU items (4 x SU coalesced 4-byte loads per lane, addresses
-                // clamped into the image so none is conditional) are issued before the first 16-byte LDS write.  The other
-                // workgroup of the CU sweeps meanwhile.  (Tried and dropped: one batch over all views -- the 64 data registers
-                // and their 64-bit addresses spill into the plane loop; buffer loads with scalar row offsets -- the same.)
+                // Stage.  A wave takes whole (quad, row) items of a view: the row is wave-uniform, the lane is the column.  Loads are
+                // buffer loads -- the view's descriptor and the row's byte offset in scalar registers, the column as a 32-bit lane
+                // offset, no 64-bit address registers -- and a lane or row outside the image gets an offset beyond the buffer, for
+                // which the hardware returns zeros: no clamps, no selects.  The loads of SU items (4 x SU per lane) are issued
+                // before the first 16-byte LDS write; the other workgroup of the CU sweeps meanwhile.
                 constexpr int SU = 4;
+                constexpr int OOB = 0x7ffffff0;   // (launch check: C * h * w * 4 < 2^31, so any offset from here on is out of range)
+                const int fbytes = p.C * (int)plane * 4;
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
                     if (i >= p.n_src) {   // the zero cells of an unused view
                         for (int idx = tid; idx < 4 * Q; idx += WTHREADS) lds_write4_abs(W[i].base + idx * 16, (f4){0, 0, 0, 0});
                         continue;
                     }
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats[i + 1]), 0, fbytes, 0x00020000);
                     const int nitem = Q * W[i].wh;
-                    const float* __restrict__ src = p.feats[i + 1] + (size_t)c0 * plane;
                     for (int col0 = 0; col0 < W[i].ww; col0 += 64) {   // (windows wider than 64 cells: rare)
                         const int col = col0 + lane;
                         const int sx = W[i].wx0 + col;
                         const bool colin = col < W[i].ww;
-                        const bool xin = colin && sx >= 0 && sx < w;
-                        const int sxc = min(max(sx, 0), w - 1);
+                        const int voff = (colin && sx >= 0 && sx < w) ? sx * 4 : OOB;
                         const int cadr = W[i].base + col * 16;
                         for (int it0 = wave; it0 < nitem; it0 += SU * WWAVES) {
                             f4 v[SU];
@@ -533,13 +545,13 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
                                 int q = 0;
 #pragma unroll
                                 for (int qq_ = 1; qq_ < Q; ++qq_) q += (it >= qq_ * W[i].wh) ? 1 : 0;
-                                const int row = it - q * W[i].wh;
-                                const int sy = W[i].wy0 + row;
+                                const int sy = W[i].wy0 + (it - q * W[i].wh);
                                 const bool yin = sy >= 0 && sy < h;
-                                const int syc = min(max(sy, 0), h - 1);
-                                const float* __restrict__ g = src + (size_t)(4 * q) * plane + (size_t)syc * w + sxc;
-                                v[k][0] = g[0]; v[k][1] = g[plane]; v[k][2] = g[2 * plane]; v[k][3] = g[3 * plane];
-                                if (!(xin && yin)) v[k] = (f4){0, 0, 0, 0};
+                                const int soff = yin ? ((c0 + 4 * q) * (int)plane + sy * w) * 4 : OOB;
+                                const int pb = yin ? (int)plane * 4 : 0;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + c * pb, 0));
                             }
 #pragma unroll
                             for (int k = 0; k < SU; ++k) {
@@ -550,6 +562,11 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
                                 const int row = it - q * W[i].wh;
                                 if (it < nitem && colin) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[k]);
                             }
+                            // every load of the batch is consumed here, written or not: a load left pending would be waited for
+                            // where its register is next overwritten -- inside the plane loop, on the counter that also counts the
+                            // planes' stores
+#pragma unroll
+                            for (int k = 0; k < SU; ++k) asm volatile("" : : "v"(v[k]));
                         }
                     }
                 }
@@ -581,6 +598,7 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
     auto kern = sweep_window_kernel<MODE, NSRC, CH, OUTCL, PH>;
     constexpr int WLDS_BYTES = window_lds_bytes(CH);
     if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
+    if ((size_t)p.h * p.w * p.C * 4 >= 0x7ffffff0u) return D3D_ERR_UNSUPPORTED;   // buffer-load offsets of the staging (see OOB)
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WLDS_BYTES);
     if (rc != D3D_OK) return rc;
     WindowArgs a;
