@@ -76,9 +76,9 @@ const char* d3d_last_error(void);
 int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_stream_t stream);
 
 /*
- * Test hook, process-wide: 0 = the dispatcher chooses (default), 1 = direct-gather kernel, 2 = LDS-ring kernel
+ * Test hook, process-wide: 0 = the dispatcher chooses (default), 1 = direct-gather kernel, 2 = LDS-ring kernel, 3 = window kernel
  * (D3D_ERR_UNSUPPORTED where that kernel does not take the shape).  The parity suite runs every sweep case on
- * all three.  Not for production callers.
+ * all of them.  Not for production callers.
  */
 int d3d_debug_force_path(int path);
 

@@ -1,0 +1,27 @@
+import sys, os, time, torch
+sys.path.insert(0, "/root/repo")
+from deep3d_aerial_amd import config, predict, synthetic as S, ops
+config.switches["D3D_CONV_PRECISION"] = "bf16"
+model = sys.argv[1] if len(sys.argv) > 1 else "msrednet"
+net = predict.build_model(model, 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
+s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
+imgs = torch.from_numpy(s["imgs"])[None].cuda()
+pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}
+dv = torch.from_numpy(s["depth_values"])[None].cuda()
+def wrap(name):
+    orig = getattr(ops, name)
+    def f(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        y = orig(*a, **k)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+        feats = a[0]; depth = a[-1]
+        dd = depth.maps.shape if isinstance(depth, ops.AffineDepth) else tuple(depth.shape)
+        print("%s feats %d x %s depth %s -> %.3f ms" % (name, len(feats), tuple(feats[0].shape), dd, dt), flush=True)
+        return y
+    setattr(ops, name, f)
+for n in ("variance_volume", "variance_volume_cl", "weighted_corr"): wrap(n)
+with torch.no_grad():
+    net(imgs, pm, dv); print("--- second forward")
+    for path in ("", "tiled"):
+        config.switches["D3D_FORCE_PATH"] = path; print("path", path or "auto")
+        net(imgs, pm, dv)
