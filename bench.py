@@ -211,10 +211,54 @@ def secondary_models(reps=2):
             del net, imgs, pm, dv
             torch.cuda.empty_cache()
         res["casmvsnet"]["regulariser"] = regulariser_leg()
+        res["cascade_sweeps"] = cascade_sweeps_leg()
     finally:
         ops.set_conv_precision(old)
     res["config"] = "config 3: full cascade forward, 5 views, 2752x1856, ndepths 48/32/8, bf16 regulariser operands (fp32 accumulate), synthetic"
     return res
+
+
+def cascade_sweeps_leg(reps=5):
+    """The cost-volume sweeps of a cascade view on their own: the three stage shapes of config 3
+    (5 views; stage 1 per-plane depths, stages 2 / 3 per-pixel hypotheses as (lo, step) maps, as cas_mvsnet.py passes them),
+    planar fp32 variance, visibility-weighted correlation and the channel-last bf16 variance volume of the bf16 regulariser:
+    ms per launch and the fraction of 8 TB/s on the algorithmic bytes (source maps + hypothesis maps read once, volume
+    written once).  Scene and shapes are tools/stage_sweep_bench.py's."""
+    H, W = 1856, 2752
+    out = {}
+    for tag, C, D, sc, perpix in (("stage1", 32, 48, 4, False), ("stage2", 16, 32, 2, True), ("stage3", 8, 8, 1, True)):
+        h, w = H // sc, W // sc
+        proj, dv = S.make_scene(5, h, w, 384 // (1 if not perpix else 4), seed=3)
+        feats = [torch.randn(C, h, w, device="cuda") for _ in range(5)]
+        p34 = ops.compose_projections(torch.from_numpy(proj).cuda())
+        if perpix:
+            base = torch.full((h, w), float(dv.mean()), device="cuda")
+            depth = ops.depth_range_affine(base, D, float(dv[1] - dv[0]) / 384 * sc)
+        else:
+            depth = torch.from_numpy(S.uniform_depths(dv, D)).cuda()
+        vw = torch.rand(4, h, w, device="cuda")
+        reads = 5 * C * h * w * 4 + (2 * h * w * 4 if perpix else 0)
+
+        def timed(fn):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        t_var = timed(lambda: ops.variance_volume(feats, p34, depth))
+        t_w = timed(lambda: ops.weighted_corr(feats, p34, vw, depth))
+        t_cl = timed(lambda: ops.variance_volume_cl(feats, p34, depth))
+        out[tag] = {"shape": "C %d x D %d x %d x %d" % (C, D, h, w),
+                    "variance_ms": round(t_var, 3), "variance_hbm_frac": round((reads + C * D * h * w * 4) / t_var / 8e9, 3),
+                    "weighted_ms": round(t_w, 3),
+                    "variance_cl_bf16_ms": round(t_cl, 3), "variance_cl_bf16_hbm_frac": round((reads + C * D * h * w * 2) / t_cl / 8e9, 3)}
+        del feats, depth, vw
+        torch.cuda.empty_cache()
+    return out
 
 
 def regulariser_leg(reps=5):

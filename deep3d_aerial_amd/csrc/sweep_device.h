@@ -115,6 +115,11 @@ __device__ __forceinline__ unsigned long long pack_bf16x4(const float __attribut
 // ... and EIGHT of them (two finished quads) as one 16-byte store: a lane's stores are 64 cells apart from its
 // neighbours' (cell = C * 2 bytes), so every store instruction is 64 separate memory transactions whatever its width --
 // 8-byte stores made the 16-channel groups of stages 1 / 2 twice as slow as the planar fp32 kernel
+// PARTIAL (experiment, not used): with C > 8 the 16 bytes are only part of the voxel's cell -- the other channel groups arrive
+// in later passes of the same workgroup -- and WRITE_SIZE shows every 16-byte store as a 32-byte write (stage 2, C = 16:
+// 2.66 GB for a 1.31 GB volume, the planar volume's bytes).  Dropping `nt` so that the halves could merge in L2 / the
+// Infinity Cache left WRITE_SIZE unchanged and moved the time by -5 % (window kernel, stage 2) to +20 % (ring kernel, stage 1).
+template <bool PARTIAL = false>
 __device__ __forceinline__ void store_sbase_bf16x8(unsigned long long sb, unsigned byte_off, unsigned long long lo, unsigned long long hi) {
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     const u4v bits = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
@@ -123,7 +128,8 @@ __device__ __forceinline__ void store_sbase_bf16x8(unsigned long long sb, unsign
 #else
     // (a store of more than 8 bytes reads its data registers late: the next VALU write of one of them needs wait states, and
     //  the compiler's hazard recognizer does not see inside the string -- without the s_nop some lanes stored garbage)
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
+    if constexpr (PARTIAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
+    else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
 #endif
 }
 }  // namespace
