@@ -251,7 +251,7 @@ def cascade_sweeps_leg(reps=5):
 
         t_var = timed(lambda: ops.variance_volume(feats, p34, depth))
         t_w = timed(lambda: ops.weighted_corr(feats, p34, vw, depth))
-        t_cl = timed(lambda: ops.variance_volume_cl(feats, p34, depth))
+        t_cl = timed(lambda: ops.variance_volume_cl(feats, p34, depth, layout="cl8"))
         out[tag] = {"shape": "C %d x D %d x %d x %d" % (C, D, h, w),
                     "variance_ms": round(t_var, 3), "variance_hbm_frac": round((reads + C * D * h * w * 4) / t_var / 8e9, 3),
                     "weighted_ms": round(t_w, 3),

@@ -59,8 +59,8 @@ class CostRegNet(nn.Module):
         return ops.conv_precision() == "bf16" and ops.channel_last_enabled()
 
     def forward_one(self, x):  # [C,D,H,W] fp32 (or channel-last bf16 [D,H,W,C] in bf16 mode) -> [D,H,W]
-        cl_in = x.dtype == torch.bfloat16
-        D, H, W = x.shape[:3] if cl_in else x.shape[1:]
+        cl_in = x.dtype == torch.bfloat16   # [D,H,W,C], or the sweep kernels' CL8 form [D,C/8,H,W,8]
+        D, H, W = ((x.shape[0], x.shape[2], x.shape[3]) if x.dim() == 5 else x.shape[:3]) if cl_in else x.shape[1:]
         if D % 8 or H % 8 or W % 8:
             raise ValueError("CostRegNet needs D,H,W divisible by 8 (got %s)" % ((D, H, W),))
         if cl_in or (self.channel_last() and x.shape[0] % 8 == 0):
@@ -87,6 +87,7 @@ class CostRegNet(nn.Module):
         return torch.stack([self.forward_one(x[b].contiguous()) for b in range(x.shape[0])]).unsqueeze(1)
 
 
+CL_LAYOUT = "cl8"   # layout of the variance volume handed to conv0 in bf16 mode ("cl": [D,h,w,C], rounds 2-3)
 AFFINE_DEPTH = True   # stages 2+ hand the sweep (lo, step) maps instead of a [D,h,w] hypothesis volume (ops.AffineDepth)
 
 
@@ -107,7 +108,8 @@ class DepthNet(nn.Module):
             fb = [f[b].contiguous() for f in features]
             # bf16 mode: the volume leaves the sweep kernel in the form conv0 stages (same rounding, half the bytes)
             cl = getattr(cost_regularization, "channel_last", None)
-            var = ops.variance_volume_cl(fb, p34, dv) if (cl is not None and cl() and fb[0].shape[0] % 8 == 0) \
+            # (CL8: planes of 8-channel groups -- whole-cell stores for the 16- and 32-channel stages)
+            var = ops.variance_volume_cl(fb, p34, dv, layout=CL_LAYOUT) if (cl is not None and cl() and fb[0].shape[0] % 8 == 0) \
                 else ops.variance_volume(fb, p34, dv)
             cost = cost_regularization.forward_one(var)
             d, c = ops.softargmin_conf4(cost, dv)

@@ -46,6 +46,7 @@ struct C8Params {
     int relu;
     int zper;             // output planes per workgroup along z
     int CO;               // real output channels (<= 16 * NTN)
+    int in_cl8;           // CL input in planes of 8-channel groups [D, CI/8, H, W, 8] (the sweep kernels' CL8 volume) instead of [D, H, W, CI]
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
             const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
             if constexpr (INCL) {
                 const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
-                    (ok ? (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16 : 0);
+                    (!ok ? 0 : p.in_cl8 ? ((((size_t)zi * G + g) * H + gy) * W + gx) * 16 : (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16);
                 const u4 v = *reinterpret_cast<const u4*>(src);
                 stc[rr] = ok ? v : (u4){0, 0, 0, 0};
             } else {
@@ -394,6 +395,7 @@ extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpac
     C8Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
+    p.in_cl8 = in_cl == 2;   // (in_cl: 0 planar fp32 | 1 channel-last bf16 [D,H,W,Ci] | 2 CL8 [D,Ci/8,H,W,8])
     hipStream_t st = (hipStream_t)stream;
     if (wide) return launch<64, 4, true, true, 2, true>(p, st);
     if (in_cl) return out_cl ? launch_fmt<true, true>(p, Ci, Co, st) : launch_fmt<true, false>(p, Ci, Co, st);
@@ -411,6 +413,7 @@ extern "C" int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* w
     C8Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = 1;
+    p.in_cl8 = in_cl == 2;
     hipStream_t st = (hipStream_t)stream;
     if (in_cl) {
         switch (Ci) {

@@ -461,14 +461,14 @@ int d3d_variance_volume(const float* const* feats, const float* proj34, const fl
     return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
 }
 
-int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+static int variance_volume_cl_any(int layout, const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                 d3d_stream_t stream) {
     SweepParams p = {};
     int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, reinterpret_cast<float*>(out), workspace,
                         workspace_bytes);
     if (rc) return rc;
-    p.out_cl = 1;
+    p.out_cl = layout;
     if (forced_path() == 1) {
         set_error("d3d_variance_volume_cl_bf16: only the LDS-ring and window kernels write channel-last volumes");
         return D3D_ERR_UNSUPPORTED;
@@ -478,6 +478,18 @@ int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, 
         if (rc != D3D_ERR_UNSUPPORTED || forced_path() == 3) return rc;
     }
     return launch_tiled(MODE_VARIANCE, p, (hipStream_t)stream);
+}
+
+int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                                int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
+                                d3d_stream_t stream) {
+    return variance_volume_cl_any(1, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes, stream);
+}
+
+int d3d_variance_volume_cl8_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
+                                 d3d_stream_t stream) {
+    return variance_volume_cl_any(2, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes, stream);
 }
 
 int d3d_variance_volume_f16(const void* const* feats, const float* proj34, const float* depth, int depth_mode,

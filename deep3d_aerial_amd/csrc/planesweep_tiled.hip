@@ -351,7 +351,8 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     const bool valid = (px < w) && (py < h);
     const int pix = valid ? py * w + px : 0;
     const unsigned pixb = (unsigned)pix * (unsigned)sizeof(T);  // per-lane byte offset (h*w < 2^30)
-    const unsigned pixo = OUTCL ? (unsigned)pix * (unsigned)p.C * 2u : pixb;   // channel-last cells: h*w*C*2 < 2^32 (checked at launch)
+    // channel-last cells: C * 2 bytes per pixel (h*w*C*2 < 2^32, checked at launch), or 16 in a plane of 8-channel groups (CL8)
+    const unsigned pixo = OUTCL ? (p.out_cl == 2 ? (unsigned)pix * 16u : (unsigned)pix * (unsigned)p.C * 2u) : pixb;
     const float xf = (float)px, yf = (float)py;
 
     // --- per-lane inputs of the compute waves, requested BEFORE the planning phases below so that their global-memory latency
@@ -918,6 +919,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     }
     const float invV = 1.0f / (float)(p.n_src + 1);
     const size_t cstride_b = (p.plane_major ? plane : (size_t)D * plane) * sizeof(T);   // bytes between channels
+    const size_t cl_step = p.out_cl == 2 ? plane * 16 : 16;
 
     // all CH/4.. channels of one quad: accumulators -> output values -> stores
     unsigned long long even_quad = 0;   // OUTCL: the packed even quad waits for the odd one (one 16-byte store per pair)
@@ -937,7 +939,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 even_quad = pack_bf16x4(o);
             } else {
                 store_sbase_bf16x8(ob, pixo, even_quad, pack_bf16x4(o));
-                ob += 16;
+                ob += cl_step;   // the next 8 channels: the next 16 bytes of the cell, or the next group plane (CL8)
             }
         } else {
 #ifdef D3D_X_STORE4   // timing experiment (layout wrong): the quad leaves as ONE 16-byte store per lane instead of four 4-byte ones
@@ -1002,7 +1004,8 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             } else {
                 dv = lds[L::PMIN + dl_];
             }
-            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) + (size_t)d * plane * p.C + c0)
+            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) +
+                                                      (p.out_cl == 2 ? ((size_t)d * (p.C / 8) + c0 / 8) * plane * 8 : (size_t)d * plane * p.C + c0))
                                           : uniform64(reinterpret_cast<T*>(p.out) + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);  // scalar base, once per plane
             float pair_acc = 0.0f;
             if (!valid) return;  // one EXEC region per plane instead of one branch per store

@@ -41,7 +41,10 @@ constexpr int WTW = 32;               // patch width: one 128-byte output row se
 //     thousands of cycles and the exposed staging of the next chunk is a few percent.
 constexpr int window_waves(int CH) { return CH == 8 ? 8 : 12; }
 constexpr int window_lds_bytes(int CH) { return CH == 8 ? 80 * 1024 : 160 * 1024; }
-constexpr int WDSEG_MAX = 32;         // planes per workgroup segment (upper bound)
+#ifndef D3D_WINDOW_DSEG
+#define D3D_WINDOW_DSEG 32
+#endif
+constexpr int WDSEG_MAX = D3D_WINDOW_DSEG;   // planes per workgroup segment (upper bound)
 constexpr int WTAB = 2 * WDSEG_MAX;   // floats: per-plane depth range of the patch (pmin, pmax)
 
 struct WindowArgs {
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
     const bool valid = px < w && py < h;
     const int pix = valid ? py * w + px : 0;
     const unsigned pixb = (unsigned)pix * 4u;
-    const unsigned pixo = OUTCL ? (unsigned)pix * (unsigned)p.C * 2u : pixb;   // channel-last cells: h*w*C*2 < 2^32 (checked at launch)
+    // channel-last cells: C * 2 bytes per pixel (h*w*C*2 < 2^32, checked at launch), or 16 in a plane of 8-channel groups (CL8)
+    const unsigned pixo = OUTCL ? (p.out_cl == 2 ? (unsigned)pix * 16u : (unsigned)pix * (unsigned)p.C * 2u) : pixb;
     const float xf = (float)px, yf = (float)py;
 
     // ---- per-lane inputs, requested first: their latency runs under the range / window phases ------------------------------
@@ -319,6 +323,10 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
             if ((q & 1) == 0) {
                 even_quad = pack_bf16x4(o);
             } else {
+#ifdef D3D_CL_PARTIAL_DEFAULT_POLICY   // experiment: see store_sbase_bf16x8
+                if (a.ngroups > 1) store_sbase_bf16x8<true>(ob, pixo, even_quad, pack_bf16x4(o));
+                else
+#endif
                 store_sbase_bf16x8(ob, pixo, even_quad, pack_bf16x4(o));
                 ob += 16;
             }
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
         }
     };
 
+    int guess = nplanes;   // planes to try first for the next chunk
     for (int gi = 0; gi < a.ngroups; ++gi) {
         const int c0 = gi * CH;
         if constexpr (REF_LDS) {
@@ -384,7 +393,8 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
             } else {
                 dv = lds[dl_];
             }
-            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) + (size_t)d * plane * p.C + c0)
+            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) +
+                                                      (p.out_cl == 2 ? ((size_t)d * (p.C / 8) + c0 / 8) * plane * 8 : (size_t)d * plane * p.C + c0))
                                           : uniform64(p.out + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);
             if (!valid) return;
             if constexpr (Q > 2) { if (staged) {
@@ -506,7 +516,10 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
         // ---- chunks of planes: as many of the planes that are left as have windows that fit -----------------------------------
         int done = 0;
         while (done < nplanes) {
-            int n = nplanes - done;
+            // first try: what fitted last time plus a quarter (a sweep with wide plane spacing settles at a few planes per chunk:
+            // searching down from "everything that is left" for every chunk cost seven window computations per chunk at stage 1)
+            const int first = min(nplanes - done, guess);
+            int n = first;
             bool fit = windows(done, n);
             while (!fit && n > NSUBW) {   // three quarters of the planes, in whole rounds of the sub-ranges
                 n = max((n * 3 / 4) / NSUBW * NSUBW, NSUBW);
@@ -587,6 +600,9 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
                 for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, false);
             }
             done += n;
+            if (!fit) guess = NSUBW;
+            else if (!(n == first && first < guess))   // (a chunk cut short by the end of the segment says nothing about what fits)
+                guess = max((n + n / 4 + NSUBW - 1) / NSUBW * NSUBW, n + NSUBW);
         }
     }
     D3D_WSTAT(0, 1); D3D_WSTAT(5, t_stage); D3D_WSTAT(6, t_sweep); D3D_WSTAT(7, D3D_WCLOCK() - t_begin);
@@ -605,7 +621,17 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
     a.ngroups = p.C / CH;
     a.tiles_x = ceil_div(p.w, WTW);
     a.tiles_y = ceil_div(p.h, PH);
+    // plane segments: at most WDSEG_MAX planes, and short enough that the launch has ~ten rounds of workgroups (two per CU) -- but
+    // not below 8 planes: a segment pays its own prologue and restages windows its neighbour segment has in LDS
     a.nseg = ceil_div(p.D, WDSEG_MAX);
+    {
+        const long tiles = (long)a.tiles_x * a.tiles_y;
+#ifndef D3D_WINDOW_ROUNDS
+#define D3D_WINDOW_ROUNDS 0
+#endif
+        const int want = (int)min((long)ceil_div(p.D, 8), (long)ceil_div((long)D3D_WINDOW_ROUNDS * 512, tiles));
+        a.nseg = max(a.nseg, want);
+    }
     a.dseg = ceil_div(p.D, a.nseg);
     a.nseg = ceil_div(p.D, a.dseg);
     a.cap_bytes = WLDS_BYTES - WTAB * 4;

@@ -21,7 +21,8 @@ struct SweepParams {
     int d_chunk;
     int elem_bytes;                     // 4 (fp32 tensors) | 2 (fp16 storage, fp32 arithmetic)
     int plane_major;                    // 0: out [C,D,h,w] | 1: out [D,C,h,w] (one contiguous [C,h,w] slice per plane)
-    int out_cl;                         // 1: MODE_VARIANCE writes a channel-last bf16 volume [D,h,w,C] (tiled kernel only)
+    int out_cl;                         // MODE_VARIANCE, ring / window kernels: 1 = channel-last bf16 volume [D,h,w,C];
+                                        // 2 = the same in planes of 8-channel groups [D,C/8,h,w,8] ("CL8": every 16-byte store a whole cell)
 };
 
 }  // namespace d3d

@@ -195,22 +195,39 @@ def variance_volume(feats, proj34, depth, out=None):
     return out
 
 
-def variance_volume_cl(feats, proj34, depth):
+def variance_volume_cl(feats, proj34, depth, layout="cl"):
     """variance_volume for the bf16 mode of the regulariser (BASELINE config 3): fp32 features and arithmetic, the volume
-    written once as a channel-last bf16 tensor [D,h,w,C] (the rounding conv0 would apply when it stages the planar volume).
-    Shapes the ring kernel does not take go through the planar kernel and the format conversion."""
+    written once as a channel-last bf16 tensor [D,h,w,C] (the rounding conv0 would apply when it stages the planar volume),
+    or with layout="cl8" in planes of 8-channel groups [D,C/8,h,w,8] -- whole 16-byte cells per store, the form
+    `conv3d_k3_cl` takes as a 5-d tensor (for C = 8 the same bytes).  Shapes the ring / window kernels do not take go
+    through the planar kernel and the format conversion."""
+    if layout not in ("cl", "cl8"):
+        raise ValueError("layout must be 'cl' or 'cl8'")
     C, h, w = _check_feats(feats, proj34)
     dp, mode, D = _depth(depth, h, w)
     if C % 8 == 0:
-        out = torch.empty((D, h, w, C), dtype=torch.bfloat16, device=feats[0].device)
+        out = torch.empty((D, C // 8, h, w, 8) if layout == "cl8" else (D, h, w, C), dtype=torch.bfloat16, device=feats[0].device)
         arr = _ptr_array(feats, "feats")
         ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
-        rc = _lib.load().d3d_variance_volume_cl_bf16(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
-                                                     ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
+        name = "d3d_variance_volume_cl8_bf16" if layout == "cl8" else "d3d_variance_volume_cl_bf16"
+        rc = getattr(_lib.load(), name)(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
+                                        ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_variance_volume_cl_bf16")
+            _lib.check(rc, name)
             return out
-    return to_cl(variance_volume(feats, proj34, depth))
+    y = to_cl(variance_volume(feats, proj34, depth))
+    return cl_to_cl8(y) if layout == "cl8" else y
+
+
+def cl_to_cl8(x):
+    """[D,H,W,C] -> [D,C/8,H,W,8] (torch permutation: the fallback route of variance_volume_cl and the tests' reference)."""
+    D, H, W, C = x.shape
+    return x.view(D, H, W, C // 8, 8).permute(0, 3, 1, 2, 4).contiguous()
+
+
+def cl8_to_cl(x):
+    D, G, H, W, _ = x.shape
+    return x.permute(0, 2, 3, 1, 4).reshape(D, H, W, G * 8).contiguous()
 
 
 def weighted_corr(feats, proj34, weights, depth, out=None, plane_major=False):
@@ -538,9 +555,10 @@ def channel_last_enabled():
     return _cfg.get("D3D_CONV_CL") != "0"
 
 
-def _chk_cl(t, name):
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.dim() == 4):
-        raise TypeError("%s must be a contiguous CUDA bfloat16 tensor [D,H,W,C]" % name)
+def _chk_cl(t, name, cl8=False):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()
+            and (t.dim() == 4 or (cl8 and t.dim() == 5 and t.shape[4] == 8))):
+        raise TypeError("%s must be a contiguous CUDA bfloat16 tensor [D,H,W,C]%s" % (name, " or [D,C/8,H,W,8]" if cl8 else ""))
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -575,7 +593,11 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     returns CL [Do,Ho,Wo,Co] (out_cl) or planar fp32 [Co,Do,Ho,Wo]; `skip` comes in the output's format.  Shapes the
     channel-last kernels do not take go through the planar kernels and the two format conversions."""
     in_cl = x.dtype == torch.bfloat16
-    (D, H, W, Ci) = x.shape if in_cl else (x.shape[1], x.shape[2], x.shape[3], x.shape[0])
+    cl8 = in_cl and x.dim() == 5   # [D,Ci/8,H,W,8]: the sweep kernels' CL8 volume (stride-1 layers on the conv0 kernel family)
+    if cl8 and (stride != 1 or x.shape[4] != 8):
+        raise ValueError("a CL8 input [D,Ci/8,H,W,8] is taken by the stride-1 layers only")
+    (D, H, W, Ci) = ((x.shape[0], x.shape[2], x.shape[3], x.shape[1] * 8) if cl8 else x.shape) if in_cl \
+        else (x.shape[1], x.shape[2], x.shape[3], x.shape[0])
     Co = weight.shape[0]
     if tuple(weight.shape) != (Co, Ci, 3, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
@@ -583,7 +605,8 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     oshape = (o(D), o(H), o(W), Co) if out_cl else (Co, o(D), o(H), o(W))
     if skip is not None and (tuple(skip.shape) != oshape or (skip.dtype == torch.bfloat16) != bool(out_cl)):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
-    xp = _chk_cl(x, "x") if in_cl else _chk(x, "x", 4)
+    xp = _chk_cl(x, "x", cl8=True) if in_cl else _chk(x, "x", 4)
+    fmt = 2 if cl8 else int(in_cl)
     sp = None if skip is None else (_chk_cl(skip, "skip") if out_cl else _chk(skip, "skip"))
     wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
     wptr = ctypes.c_void_p(wp.data_ptr())
@@ -593,13 +616,13 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     if stride == 1 and Co == 1 and not out_cl and _cfg.get("D3D_CONV_KZFOLD") != "0":
         # the probability layer: k_z folded into the columns of one operand tile
         wf = derived_weight(weight, "c8kzfold", _pack_c8_kzfold_bf16)
-        rc = _lib.load().d3d_conv3d_k3_c1_cl_bf16(xp, int(in_cl), ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
+        rc = _lib.load().d3d_conv3d_k3_c1_cl_bf16(xp, fmt, ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
                                                   _opt(shift, "shift"), sp, int(relu), Ci, D, H, W, optr, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_c1_cl_bf16")
             return out
     if stride == 1:
-        rc = _lib.load().d3d_conv3d_k3_cl_bf16(xp, int(in_cl), wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
+        rc = _lib.load().d3d_conv3d_k3_cl_bf16(xp, fmt, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
                                                Ci, Co, D, H, W, optr, int(out_cl), _stream())
     elif stride == 2 and in_cl and out_cl:
         rc = _lib.load().d3d_conv3d_k3s2_cl_bf16(xp, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu), Ci, Co,
@@ -610,7 +633,7 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     saved = _cfg.state.conv_precision
     _cfg.state.conv_precision = "bf16"
     try:
-        y = conv3d_k3(_planar(x), weight, scale, shift, _planar(skip), relu=relu, stride=stride)
+        y = conv3d_k3(_planar(cl8_to_cl(x) if cl8 else x), weight, scale, shift, _planar(skip), relu=relu, stride=stride)
     finally:
         _cfg.state.conv_precision = saved
     return to_cl(y) if out_cl else y

@@ -28,7 +28,7 @@ def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb):
     assert len(feats) == proj_mats.shape[0], "Different number of images and projection matrices"
     p34 = ops.compose_projections(proj_mats.contiguous())
     cl = cost_reg.channel_last() and feats[0].shape[0] % 8 == 0
-    var = ops.variance_volume_cl(feats, p34, depth_samps) if cl else ops.variance_volume(feats, p34, depth_samps)
+    var = ops.variance_volume_cl(feats, p34, depth_samps, layout="cl8") if cl else ops.variance_volume(feats, p34, depth_samps)
     cost = cost_reg.forward_one(var)
     return ops.softargmin_conf4_var(cost, depth_samps, lamb)
 

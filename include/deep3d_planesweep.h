@@ -132,6 +132,13 @@ int d3d_variance_volume(const float* const* feats, const float* proj34, const fl
 int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                 d3d_stream_t stream);
+/* The same volume in planes of 8-channel groups, "CL8": out [D, C/8, h, w, 8] bf16 -- the 16 bytes a lane stores per voxel
+ * and group are then a WHOLE cell (with C > 8 the [D,h,w,C] form above makes every store a partial 32-byte write: the
+ * write traffic of a C = 16 volume was that of the planar fp32 one).  d3d_conv3d_k3_cl_bf16 / d3d_conv3d_k3_c1_cl_bf16 take
+ * it with in_cl = 2.  For C = 8 the two layouts coincide. */
+int d3d_variance_volume_cl8_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                                int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
+                                d3d_stream_t stream);
 
 /* The same volume with fp16 STORAGE (BASELINE config 5): feats[i] and out are IEEE half tensors of the shapes
  * above; projections, depth and every product / sum stay fp32, the result is rounded once (RNE).  With a
@@ -353,7 +360,8 @@ int d3d_conv2d_k5s2_zs_bf16x3(const float* in, const void* wpacked, const float*
  * staging task is one 16-byte load.  Same layers and weight packings as the *_zs_bf16 entry points above
  * (cas_mvsnet.py:84-118: conv0 planar -> CL, conv1 .. conv11 CL -> CL with CL skips, prob CL -> planar).
  *
- * d3d_conv3d_k3_cl_bf16: stride 1; in_cl / out_cl select the format of `in` and of `out` + `skip` (0: planar fp32
+ * d3d_conv3d_k3_cl_bf16: stride 1; in_cl / out_cl select the format of `in` (also 2: CL8 [D,Ci/8,H,W,8], see
+ * d3d_variance_volume_cl8_bf16) and of `out` + `skip` (0: planar fp32
  *   [C,D,H,W], 1: CL).  C_in = 8 | 16 | 32, C_out <= 16 or 32 -> 32; C_out % 4 == 0 for CL output, W % 4 == 0 for planar.
  * d3d_conv3d_k3s2_cl_bf16: stride 2, pad 1; CL in [D,H,W,Ci] -> CL out [(D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Co];
  *   8->8, 8->16, 16->16, 16->32.

@@ -1460,6 +1460,33 @@ def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, 
     got = ops.variance_volume_cl(feats, p34, dv)
     assert got.dtype == torch.bfloat16 and tuple(got.shape) == (D, h, w, C)
     assert np.array_equal(_cl_host(got), _bf16_round(planar))
+    # CL8 (d3d_variance_volume_cl8_bf16): the same values in planes of 8-channel groups [D,C/8,h,w,8], on every kernel family
+    for path_ in ("", "tiled", "window"):
+        config.switches["D3D_FORCE_PATH"] = path_
+        try:
+            got8 = ops.variance_volume_cl(feats, p34, dv, layout="cl8")
+        except RuntimeError as e:
+            if "unsupported" in str(e):
+                continue
+            raise
+        finally:
+            config.switches["D3D_FORCE_PATH"] = ""
+        assert tuple(got8.shape) == (D, C // 8, h, w, 8)
+        assert torch.equal(ops.cl8_to_cl(got8), got), path_
+
+
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 8, 24, 40), (32, 8, 4, 16, 64), (8, 8, 3, 9, 36), (16, 16, 5, 17, 32), (32, 1, 6, 16, 48)])
+def test_conv0_takes_the_cl8_volume(ops, bf16_mode, Ci, Co, D, H, W):
+    """d3d_conv3d_k3_cl_bf16 / d3d_conv3d_k3_c1_cl_bf16 with in_cl = 2: a CL8 input [D,Ci/8,H,W,8] gives bit for bit the
+    output of the same values handed over as [D,H,W,Ci]."""
+    rng = np.random.default_rng(Ci + Co + D)
+    x = dev(rng.standard_normal((D, H, W, Ci))).to(torch.bfloat16)
+    wt = dev(0.1 * rng.standard_normal((Co, Ci, 3, 3, 3)))
+    sc, sh = dev(rng.uniform(0.5, 1.5, Co)), dev(rng.standard_normal(Co))
+    out_cl = Co % 4 == 0
+    a = ops.conv3d_k3_cl(x, wt, sc, sh, relu=True, out_cl=out_cl)
+    b = ops.conv3d_k3_cl(ops.cl_to_cl8(x), wt, sc, sh, relu=True, out_cl=out_cl)
+    assert torch.equal(a, b)
 
 
 def test_predict_views_ucsnet(ops, tmp_path):

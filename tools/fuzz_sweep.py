@@ -53,7 +53,9 @@ for case in range(n_cases):
         cl = ops.variance_volume_cl(feats, p34, depth)
         want = a.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
         nbad = int((cl.view(torch.int16) != want.view(torch.int16)).sum())
-        cl_note = " | channel-last: %d differing values" % nbad
+        cl8 = ops.variance_volume_cl(feats, p34, depth, layout="cl8")
+        nbad += int((ops.cl8_to_cl(cl8).view(torch.int16) != want.view(torch.int16)).sum())
+        cl_note = " | channel-last (both layouts): %d differing values" % nbad
         bad = bad or nbad > 0
     if outs["window"] is not None:   # the window kernel (forced: any depth of sweep) repeats the ring kernel's arithmetic exactly
         nw = int((outs["window"] != a).sum())
@@ -62,7 +64,9 @@ for case in range(n_cases):
         if mode == "variance" and C % 8 == 0:
             config.switches["D3D_FORCE_PATH"] = "window"
             clw = ops.variance_volume_cl(feats, p34, depth)
-            nwc = int((clw.view(torch.int16) != outs["window"].to(torch.bfloat16).permute(1, 2, 3, 0).contiguous().view(torch.int16)).sum())
+            wantw = outs["window"].to(torch.bfloat16).permute(1, 2, 3, 0).contiguous().view(torch.int16)
+            nwc = int((clw.view(torch.int16) != wantw).sum())
+            nwc += int((ops.cl8_to_cl(ops.variance_volume_cl(feats, p34, depth, layout="cl8")).view(torch.int16) != wantw).sum())
             cl_note += ", its channel-last form %d" % nwc
             bad = bad or nwc > 0
     print("%-66s rel-L1 %.2e max-abs %.2e%s %s" % (tag, rel, err, cl_note, "  <-- MISMATCH" if bad else ""), flush=True)

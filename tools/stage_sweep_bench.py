@@ -36,7 +36,7 @@ for (tag, C, D, sc, perpix) in [("stage1", 32, 48, 4, False), ("stage2", 16, 32,
         try:
             t1 = timeit(lambda: ops.variance_volume(feats, p34, depth))
             t2 = timeit(lambda: ops.weighted_corr(feats, p34, vw, depth))
-            t3 = timeit(lambda: ops.variance_volume_cl(feats, p34, depth)) if path != "direct" else float("nan")
+            t3 = timeit(lambda: ops.variance_volume_cl(feats, p34, depth, layout="cl8")) if path != "direct" else float("nan")
             print("%s C=%d D=%d %dx%d %-6s variance %.3f ms (%.3f of 8 TB/s)  weighted %.3f ms  channel-last bf16 %.3f ms (%.3f)  (%.1f Gvoxel/s)" % (
                 tag, C, D, h, w, path, t1, gb_var / t1 / 8.0, t2, t3, gb_cl / t3 / 8.0, D * h * w / t1 / 1e6), flush=True)
         except RuntimeError as e:

@@ -22,7 +22,7 @@ vw = torch.rand(4, h, w, device="cuda")
 for _ in range(reps):
     a = ops.variance_volume(feats, p34, depth)
     b = ops.weighted_corr(feats, p34, vw, depth)
-    c = ops.variance_volume_cl(feats, p34, depth)
+    c = ops.variance_volume_cl(feats, p34, depth, layout="cl8")
 torch.cuda.synchronize()
 reads = 5 * C * h * w * 4 + (2 * h * w * 4 if perpix else 0)
 print("%s C=%d D=%d %dx%d: algorithmic MB per launch: planar %.1f, channel-last bf16 %.1f" % (tag, C, D, h, w, (reads + C * D * h * w * 4) / 1e6, (reads + C * D * h * w * 2) / 1e6))
