@@ -45,7 +45,8 @@ constexpr int window_lds_bytes(int CH) { return CH == 8 ? 80 * 1024 : 160 * 1024
 #define D3D_WINDOW_DSEG 32
 #endif
 constexpr int WDSEG_MAX = D3D_WINDOW_DSEG;   // planes per workgroup segment (upper bound)
-constexpr int WTAB = 2 * WDSEG_MAX;   // floats: per-plane depth range of the patch (pmin, pmax)
+constexpr int WTAB = 2 * WDSEG_MAX + 32;   // floats: per-plane depth range of the patch (pmin, pmax) + the views' translations (4 each)
+constexpr int WTOFF = 2 * WDSEG_MAX;      // where the translations start
 
 struct WindowArgs {
     int tiles_x, tiles_y, nseg, dseg, ngroups;
@@ -170,6 +171,17 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
             T0[i] = -1.0f; T1[i] = -1.0f; T2[i] = 1.0f;
         }
     }
+#ifndef D3D_WINDOW_T_SGPR
+    // The translations live in LDS and are read back per view and plane (one broadcast ds_read_b128): as scalar registers they
+    // were the ones spilled -- 48 v_readlane in a plane loop of 428 instructions.
+    if (tid < NSRC) {
+        f4 tv = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NSRC; ++i) if (tid == i) tv = (f4){T0[i], T1[i], T2[i], 0.0f};
+        *reinterpret_cast<f4*>(lds + WTOFF + 4 * tid) = tv;
+    }
+    const int tadr = lds_base_bytes(lds) + WTOFF * 4;
+#endif
     float vw[NSRC];
     float rden = 0.0f;
     if (MODE == MODE_WEIGHTED) {
@@ -451,14 +463,22 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_
                     tp[q2][2] = lds_read4_abs(s_);
                     tp[q2][3] = lds_read4_abs(s_ + 16);
                 };
-                TapL gc = geo_win(ray[0], T0[0], T1[0], T2[0], dv, umax, vmax, W[0]);
+#ifndef D3D_WINDOW_T_SGPR
+                auto geo_view = [&](int i) {
+                    const f4 tv = *(volatile lds_f4_ptr)(unsigned)(tadr + 16 * i);   // (volatile: not hoisted out of the plane loop)
+                    return geo_win(ray[i], tv[0], tv[1], tv[2], dv, umax, vmax, W[i]);
+                };
+#else
+                auto geo_view = [&](int i) { return geo_win(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, W[i]); };
+#endif
+                TapL gc = geo_view(0);
 #pragma unroll
                 for (int q = 0; q < Q; ++q) request(gc, 0, q);
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
                     __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every view's geometry to the top)
                     TapL gn = gc;
-                    if (i + 1 < NSRC) gn = geo_win(ray[i + 1], T0[i + 1], T1[i + 1], T2[i + 1], dv, umax, vmax, W[i + 1]);
+                    if (i + 1 < NSRC) gn = geo_view(i + 1);
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         asm volatile("" : "+v"(tp[q][3]));   // one wait per quad (LDS returns in order)
