@@ -141,7 +141,8 @@ struct Lds {
     static constexpr int PMIN = 2 * STRIDE;
     static constexpr int PMAX = PMIN + DSEG_MAX;
     static constexpr int HDR = PMAX + DSEG_MAX;
-    static constexpr int CNT = HDR + 32;               // per-step hand-off counters: [MAXSTEPS] staged, [MAXSTEPS] done
+    static constexpr int VT = HDR + 32;                // per view: T0, T1, T2, -, RW, RH, row bytes, absolute ring base (view-major plane loop)
+    static constexpr int CNT = VT + 8 * NSRC;          // per-step hand-off counters: [MAXSTEPS] staged, [MAXSTEPS] done
     static constexpr int PLAN = CNT + 2 * MAXSTEPS;
     static constexpr int SST = PLAN + MAXSTEPS * NSRC * 8;
     static constexpr int STOT = SST + MAXSTEPS + 4;   // positions to stage per step
@@ -611,6 +612,18 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                         ldsi[L::HDR + 4 + 4 * i + 1] = RH[i];
                         ldsi[L::HDR + 4 + 4 * i + 2] = base;
                         ldsi[L::HDR + 4 + 4 * i + 3] = RW[i] | (RH[i] << 8) | ((base >> 2) << 16);
+                        if constexpr (VIEW_MAJOR) {   // the plane loop reads its per-view constants back from here (see `geometry`)
+                            const float* __restrict__ M = p.proj34 + 12 * min(i, p.n_src - 1);
+                            const bool dummy = i >= p.n_src;   // unused view of the template: every sample at (-1, -1)
+                            lds[L::VT + 8 * i + 0] = dummy ? -1.0f : M[3];
+                            lds[L::VT + 8 * i + 1] = dummy ? -1.0f : M[7];
+                            lds[L::VT + 8 * i + 2] = dummy ? 1.0f : M[11];
+                            lds[L::VT + 8 * i + 3] = 0.0f;
+                            ldsi[L::VT + 8 * i + 4] = RW[i];
+                            ldsi[L::VT + 8 * i + 5] = RH[i];
+                            ldsi[L::VT + 8 * i + 6] = ring_row_floats<STRIDE>(RW[i]) * 4;
+                            ldsi[L::VT + 8 * i + 7] = lds_base_bytes(lds) + 4 * base;
+                        }
                     }
                     base += ring_row_floats<STRIDE>(RW[i]) * (RH[i] + 1);
                 }
@@ -985,7 +998,12 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
 #endif
     // ---- one plane of the segment (dl_ = plane index within the segment) for this wave's pixels and the current group ----
     int kx[NSRC], ky[NSRC];   // ring offset minus window origin of the current step, per view (scalar registers)
+    int plan_adr = 0;   // view-major: absolute LDS byte address of the current step's plan entries
     auto load_step = [&](int k) {
+        if constexpr (VIEW_MAJOR) {
+            plan_adr = lds_base_bytes(lds) + 4 * (L::PLAN + (ring ? k : 0) * NSRC * 8);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NSRC; ++i) {
             const int* e = ldsi + L::PLAN + ((ring ? k : 0) * NSRC + i) * 8;
@@ -1041,8 +1059,19 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                     }
                 };
                 if (ring) {
+                    // Per-view constants (translation, ring size / pitch / base, the step's ring offset) come from LDS -- three
+                    // broadcast reads per view and plane.  As scalar registers (17 per view, six views) most of them were spilled:
+                    // 104 v_readlane + 85 s_nop in a plane loop of 1093 instructions (config 5's kernel).
+                    const int vt_adr = lds0 + 4 * L::VT;
                     auto geometry = [&](int i) -> TapL {
-                        return geo_ring<STRIDE>(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, kx[i], ky[i], RV[i]);
+                        typedef int i4v __attribute__((ext_vector_type(4)));
+                        typedef int i2v __attribute__((ext_vector_type(2)));
+                        const f4 tv = *(volatile lds_f4_ptr)(unsigned)(vt_adr + 32 * i);
+                        const i4v rv = *(volatile __attribute__((address_space(3))) const i4v*)(unsigned)(vt_adr + 32 * i + 16);
+                        const i2v kk = *(volatile __attribute__((address_space(3))) const i2v*)(unsigned)(plan_adr + 32 * i + 24);
+                        RingView R;
+                        R.RW = rv[0]; R.RH = rv[1]; R.rowb = rv[2]; R.base = rv[3];
+                        return geo_ring<STRIDE>(ray[i], tv[0], tv[1], tv[2], dv, umax, vmax, kk[0], kk[1], R);
                     };
                     auto fetch = [&](const TapL& g, int q, f4 (&dst)[4]) {
                         dst[0] = lds_read4_abs(g.a0 + q * 16);
