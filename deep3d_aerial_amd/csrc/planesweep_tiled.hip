@@ -1098,11 +1098,21 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                             asm volatile("" : "+v"(c[3]));
                             float val[CPC];
                             if constexpr (F16) {
+                                // same summation order as grid_sample: nw, ne, sw, se -- tap by tap ACROSS the eight channels, so that
+                                // consecutive instructions are independent: the compiler puts an s_nop between an inline-asm
+                                // instruction and a consumer of its result (152 of them in a loop of 1140 with the channel-major order)
+                                const float tw[4] = {gc.nw, gc.ne, gc.sw, gc.se};
 #pragma unroll
-                                for (int k = 0; k < CPC; k += 2) {   // same summation order as grid_sample: nw, ne, sw, se
-                                    const int wi = k >> 1;           // word wi of a tap holds channels k (low half) and k + 1
-                                    val[k] = fma_mix_lo(c[3][wi], gc.se, fma_mix_lo(c[2][wi], gc.sw, fma_mix_lo(c[1][wi], gc.ne, fma_mix_lo(c[0][wi], gc.nw, 0.0f))));
-                                    val[k + 1] = fma_mix_hi(c[3][wi], gc.se, fma_mix_hi(c[2][wi], gc.sw, fma_mix_hi(c[1][wi], gc.ne, fma_mix_hi(c[0][wi], gc.nw, 0.0f))));
+                                for (int k = 0; k < CPC; ++k) val[k] = 0.0f;
+#pragma unroll
+                                for (int tp_ = 0; tp_ < 4; ++tp_) {
+#pragma unroll
+                                    for (int k = 0; k < CPC; k += 2) {
+                                        const int wi = k >> 1;           // word wi of a tap holds channels k (low half) and k + 1
+                                        val[k] = fma_mix_lo(c[tp_][wi], tw[tp_], val[k]);
+                                        val[k + 1] = fma_mix_hi(c[tp_][wi], tw[tp_], val[k + 1]);
+                                    }
+                                    if (tp_ < 3) __builtin_amdgcn_sched_barrier(0);   // (keep the order: the scheduler would re-chain them)
                                 }
                             } else {
                                 const f4 v4 = blend(c[0], c[1], c[2], c[3], gc.nw, gc.ne, gc.sw, gc.se);
