@@ -39,8 +39,13 @@ constexpr int WTW = 32;               // patch width: one 128-byte output row se
 //   12 waves (4 x 3), 16-channel groups (the geometry is paid once per 16 channels; four views' geometry stays live: 168
 //     registers), ALL of a CU's LDS, one workgroup per CU -- deep sweeps, where a chunk of planes computes for tens of
 //     thousands of cycles and the exposed staging of the next chunk is a few percent.
-constexpr int window_waves(int CH) { return CH == 8 ? 8 : 12; }
-constexpr int window_lds_bytes(int CH) { return CH == 8 ? 80 * 1024 : 160 * 1024; }
+#ifndef D3D_WINDOW_WG3   // experiment: 8-channel form as 4-wave workgroups (one plane sub-range), THREE per CU on a third of the LDS each:
+                        // stage 3 0.80 -> 0.86 ms, stage 2 1.20 -> 1.46, stage 1 1.87 -> 2.55; inside a CasMVSNet view the stage-3 windows
+                        // no longer fit (0.83 -> 3.4 ms)
+#define D3D_WINDOW_WG3 0
+#endif
+constexpr int window_waves(int CH) { return CH == 8 ? (D3D_WINDOW_WG3 ? 4 : 8) : 12; }
+constexpr int window_lds_bytes(int CH) { return CH == 8 ? (D3D_WINDOW_WG3 ? 53 * 1024 : 80 * 1024) : 160 * 1024; }
 #ifndef D3D_WINDOW_DSEG
 #define D3D_WINDOW_DSEG 32
 #endif
@@ -117,7 +122,7 @@ __device__ __forceinline__ float grp8_max(float v) {
 
 // PH: patch height (PH / 2 pixel waves; the rest of the workgroup's waves are plane sub-ranges).
 template <int MODE, int NSRC, int CH, bool OUTCL, int PH>
-__global__ __launch_bounds__(64 * window_waves(CH), CH == 8 ? 4 : 3) void sweep_window_kernel(SweepParams p, WindowArgs a) {
+__global__ __launch_bounds__(64 * window_waves(CH), CH == 8 && !D3D_WINDOW_WG3 ? 4 : 3) void sweep_window_kernel(SweepParams p, WindowArgs a) {
     constexpr int WWAVES = window_waves(CH), WTHREADS = 64 * WWAVES;
     static_assert(MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED, "window kernel: variance and weighted correlation");
     static_assert(!OUTCL || MODE == MODE_VARIANCE, "channel-last bf16 output is the variance volume's");
