@@ -1,3 +1,5 @@
+"""Times every cost-volume sweep call inside one model forward (sync-bracketed), on the dispatcher's choice and with the ring
+and direct kernels forced: python tools/sweep_in_model.py casmvsnet|adamvs|msrednet|ucsnet"""
 import sys, os, time, torch
 sys.path.insert(0, "/root/repo")
 from deep3d_aerial_amd import config, predict, synthetic as S, ops
@@ -22,6 +24,6 @@ def wrap(name):
 for n in ("variance_volume", "variance_volume_cl", "weighted_corr"): wrap(n)
 with torch.no_grad():
     net(imgs, pm, dv); print("--- second forward")
-    for path in ("", "tiled"):
+    for path in ("", "tiled", "direct"):
         config.switches["D3D_FORCE_PATH"] = path; print("path", path or "auto")
         net(imgs, pm, dv)
