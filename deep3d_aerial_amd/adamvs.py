@@ -21,6 +21,9 @@ from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _n
                      plane_depths)
 
 
+AFFINE_SWEEP = True   # stages 2+ hand the sweep (lo, step) maps (ops.AffineDepth) instead of the [D,h,w] hypothesis volume
+
+
 class FeatureNet(nn.Module):
     """adamvs.py:50-153 -- image pyramid with pooled context branches (PyTorch-ROCm/MIOpen)."""
 
@@ -178,8 +181,9 @@ class InferDepthNet(nn.Module):
         self.reg = CostRegNet2D(in_depths, base_channels)
         self.reg_fuse = SliceCostRegNetRED(in_channels, in_up, base_channels)
 
-    def _one(self, feats, proj44, dv, D, conf_in):
-        """feats: V x [C,h,w]; dv [D] or [D,h,w]; conf_in: None or [V-1,hc,wc]."""
+    def _one(self, feats, proj44, dv, D, conf_in, dv_sweep=None):
+        """feats: V x [C,h,w]; dv [D] or [D,h,w]; conf_in: None or [V-1,hc,wc]; dv_sweep: the (lo, step) maps that generate dv
+        (ops.AffineDepth), handed to the sweep instead of the volume -- no depth load in its plane loop, same values."""
         C, h, w = feats[0].shape
         if h % 2 or w % 2:
             raise ValueError("feature map must have even size (got %dx%d)" % (h, w))
@@ -200,7 +204,7 @@ class InferDepthNet(nn.Module):
         else:  # adamvs.py:502, once per stage instead of once per plane
             weights = ops.resize_bilinear(conf_in, h, w)
 
-        sim = ops.weighted_corr(feats, p34, weights, dv, plane_major=True)  # [D,C,h,w]: plane d is one contiguous block
+        sim = ops.weighted_corr(feats, p34, weights, dv if dv_sweep is None else dv_sweep, plane_major=True)  # [D,C,h,w]: plane d is one contiguous block
         H, W = (2 * h, 2 * w) if self.in_up else (h, w)
         s1 = torch.zeros((8, h, w), dtype=torch.float32, device=dev)
         s2 = torch.zeros((16, h // 2, w // 2), dtype=torch.float32, device=dev)
@@ -214,7 +218,7 @@ class InferDepthNet(nn.Module):
         depth, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
         return depth, conf, weights, pair_results
 
-    def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None):
+    def forward(self, features, proj_matrices, depth_values, num_depth, confidence_map=None, sweep_depth=None):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
             depth_values.shape[1], num_depth)
@@ -227,7 +231,8 @@ class InferDepthNet(nn.Module):
             if confidence_map is not None:
                 conf_in = torch.stack([confidence_map[i][b, 0] for i in range(nsrc)]).contiguous()
             d, c, wts, pr = self._one([f[b].contiguous() for f in features], proj_matrices[b].contiguous(),
-                                      depth_values[b].contiguous(), num_depth, conf_in)
+                                      depth_values[b].contiguous(), num_depth, conf_in,
+                                      None if sweep_depth is None else sweep_depth[b])
             depths.append(d)
             confs.append(c)
             weights.append(wts)
@@ -279,8 +284,11 @@ class Infer_AdaMVSNet(nn.Module):
                 dv = torch.stack([ops.depth_range_samples(depth[b].contiguous(), D,
                                                           self.depth_intervals_ratio[s] * depth_interval)
                                   for b in range(B)])
+                # the same hypotheses as two maps for the sweep (bit-identical values; the volume stays for the per-slice regression)
+                aff = [ops.depth_range_affine(depth[b].contiguous(), D, self.depth_intervals_ratio[s] * depth_interval)
+                       for b in range(B)] if AFFINE_SWEEP else None
             out = self.DepthNet[s](feats, proj_matrices[key], depth_values=dv, num_depth=D,
-                                   confidence_map=pair_confidence)
+                                   confidence_map=pair_confidence, sweep_depth=None if depth is None else aff)
             depth = out["depth"]
             pair_confidence = out["pair_confidence"]
             outputs[key] = out

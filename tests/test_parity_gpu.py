@@ -928,6 +928,24 @@ def test_casmvsnet_affine_hypotheses_equal_the_volume_path(ops, monkeypatch):
     assert torch.equal(outs[True]["stage1"]["depth"], outs[False]["stage1"]["depth"])
 
 
+def test_adamvs_affine_sweep_hypotheses_equal_the_volume_path(ops, monkeypatch):
+    """Infer_AdaMVSNet hands the weighted-correlation sweep of stages 2 and 3 the (lo, step) maps that generate the hypothesis
+    volume (adamvs.AFFINE_SWEEP; the volume itself still feeds the per-slice regression): bit-identical outputs."""
+    from deep3d_aerial_amd import adamvs
+
+    g = load_golden("model_adamvs_v5")
+    net = _fill(adamvs.Infer_AdaMVSNet(num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(adamvs, "AFFINE_SWEEP", flag)
+        with torch.no_grad():
+            outs[flag] = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    for s in ("stage1", "stage2", "stage3"):
+        assert torch.equal(outs[True][s]["depth"], outs[False][s]["depth"]), s
+        assert torch.equal(outs[True][s]["photometric_confidence"], outs[False][s]["photometric_confidence"]), s
+
+
 @pytest.mark.parametrize("model", ["casmvsnet", "adamvs"])
 def test_full_size_cascade_mfma_equals_direct_kernels(ops, model, monkeypatch):
     """BASELINE image size (2752x1856, 5 views): the matrix-core convolution path (z-streaming, folds, z segments,
