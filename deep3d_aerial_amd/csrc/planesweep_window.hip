@@ -5,20 +5,21 @@
 // deltas into torus rings while compute waves sweep, one 12-wave workgroup owns all of a CU's LDS.  On an 8-plane sweep
 // a workgroup of that kernel lives ~38 k cycles of which ~6 k are arithmetic: the planning chain, the first window's
 // latency and the step barriers are all exposed because nothing else runs on the CU.  Here instead:
-//   * workgroup = a 32 x PH patch of reference pixels x ALL the planes of its segment x all channel groups; 8 or 6 waves
-//     (PH/2 pixel waves x plane sub-ranges), at most HALF a CU's LDS and 128 / 168 registers per lane, so TWO workgroups
-//     share a CU and one's loads run under the other's arithmetic;
+//   * workgroup = a 32 x 8 patch of reference pixels x ALL the planes of its segment (<= 32) x all 8-channel groups; 8 waves
+//     (4 pixel waves x 2 plane sub-ranges), HALF a CU's LDS and 128 registers per lane, so TWO workgroups share a CU and
+//     one's loads run under the other's arithmetic;
 //   * no planner, no rings, no loader waves: per source view ONE window -- the hull of the patch over the depth range of
 //     the chunk of planes being swept (the projection is monotone in x, y and d separately, so the hull of the eight box
 //     corners bounds every sample; same margins and clamps as the ring kernel's planner) -- staged by all waves with
-//     coalesced planar loads, positions outside the image as zeros (= zero padding per tap);
+//     coalesced buffer loads from the planar maps, positions outside the image as zeros (= zero padding per tap);
 //   * every wave derives the windows itself from the same inputs (32 lanes = 8 corners x 4 views, DPP reductions,
 //     v_readlane): no planning barrier, the only barriers are "window staged" and "window free";
 //   * LDS layout: per view and 4-channel quad a dense [rows][cols] array of 16-byte cells, no padding: the 16 lanes a
 //     ds_read_b128 services together hold 16 consecutive pixels of a row, whose taps are 16 consecutive cells (64 banks);
-//   * if the windows of the whole segment do not fit, the segment is swept in chunks of half the planes (then a quarter ...);
-//     if not even one plane per sub-range fits (p.z <= 0 at a corner, extreme geometry) the chunk gathers from global
-//     memory with the ring kernel's fallback arithmetic.
+//   * if the windows of the whole segment do not fit, the segment is swept in chunks (first try: what fitted last time plus a
+//     quarter; then three quarters of that ...); if not even one plane per sub-range fits (p.z <= 0 at a corner, a depth
+//     discontinuity inside the patch) the chunk gathers from global memory with the ring kernel's fallback arithmetic;
+//   * the channel-last bf16 volume leaves in planes of 8-channel groups (CL8, sweep_params.h): whole-cell stores.
 // Arithmetic per sample is the ring kernel's, instruction for instruction (geometry with two roundings + rcp/Newton, packed
 // blend in nw, ne, sw, se order, sum / sum of squares in view order): results are bit-identical to it and to the direct kernel.
 #include "common.h"
@@ -33,12 +34,10 @@ namespace d3d {
 namespace {
 
 constexpr int WTW = 32;               // patch width: one 128-byte output row segment per lane row
-// Two shapes of workgroup on the 32 x 8 patch:
-//   8 waves (4 pixel waves x 2 plane sub-ranges), 8-channel groups, half a CU's LDS, 128 registers: TWO workgroups per CU --
-//     shallow sweeps, where a workgroup's loads must run under another's arithmetic;
-//   12 waves (4 x 3), 16-channel groups (the geometry is paid once per 16 channels; four views' geometry stays live: 168
-//     registers), ALL of a CU's LDS, one workgroup per CU -- deep sweeps, where a chunk of planes computes for tens of
-//     thousands of cycles and the exposed staging of the next chunk is a few percent.
+// Shapes of workgroup on the 32 x 8 patch.  Built: 8 waves (4 pixel waves x 2 plane sub-ranges), 8-channel groups, half a CU's
+// LDS, 128 registers.  Behind -DD3D_WINDOW_CG16 (measured, slower: see launch_window_ch): 12 waves (4 x 3), 16-channel groups
+// -- the geometry is paid once per 16 channels, four views' geometry stays live (168 registers), reference features in LDS --
+// on ALL of a CU's LDS, one workgroup per CU.
 #ifndef D3D_WINDOW_WG3   // experiment: 8-channel form as 4-wave workgroups (one plane sub-range), THREE per CU on a third of the LDS each:
                         // stage 3 0.80 -> 0.86 ms, stage 2 1.20 -> 1.46, stage 1 1.87 -> 2.55; inside a CasMVSNet view the stage-3 windows
                         // no longer fit (0.83 -> 3.4 ms)
