@@ -43,8 +43,9 @@ constexpr int WTW = 32;               // patch width: one 128-byte output row se
                         // no longer fit (0.83 -> 3.4 ms)
 #define D3D_WINDOW_WG3 0
 #endif
-constexpr int window_waves(int CH) { return CH == 8 ? (D3D_WINDOW_WG3 ? 4 : 8) : 12; }
-constexpr int window_lds_bytes(int CH) { return CH == 8 ? (D3D_WINDOW_WG3 ? 53 * 1024 : 80 * 1024) : 160 * 1024; }
+constexpr bool window_big(int MODE, int CH) { return CH != 8 && MODE != MODE_PAIR; }   // the 12-wave form (16-channel groups of the multi-view modes)
+constexpr int window_waves(int MODE, int CH) { return window_big(MODE, CH) ? 12 : (D3D_WINDOW_WG3 ? 4 : 8); }
+constexpr int window_lds_bytes(int MODE, int CH) { return window_big(MODE, CH) ? 160 * 1024 : (D3D_WINDOW_WG3 ? 53 * 1024 : 80 * 1024); }
 #ifndef D3D_WINDOW_DSEG
 #define D3D_WINDOW_DSEG 32
 #endif
@@ -121,9 +122,10 @@ __device__ __forceinline__ float grp8_max(float v) {
 
 // PH: patch height (PH / 2 pixel waves; the rest of the workgroup's waves are plane sub-ranges).
 template <int MODE, int NSRC, int CH, bool OUTCL, int PH>
-__global__ __launch_bounds__(64 * window_waves(CH), CH == 8 && !D3D_WINDOW_WG3 ? 4 : 3) void sweep_window_kernel(SweepParams p, WindowArgs a) {
-    constexpr int WWAVES = window_waves(CH), WTHREADS = 64 * WWAVES;
-    static_assert(MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED, "window kernel: variance and weighted correlation");
+__global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) && !D3D_WINDOW_WG3 ? 4 : 3) void sweep_window_kernel(SweepParams p, WindowArgs a) {
+    constexpr int WWAVES = window_waves(MODE, CH), WTHREADS = 64 * WWAVES;
+    static_assert(MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED || (MODE == MODE_PAIR && NSRC == 1),
+                  "window kernel: variance, weighted correlation, and the channel mean of one pair's correlation");
     static_assert(!OUTCL || MODE == MODE_VARIANCE, "channel-last bf16 output is the variance volume's");
     static_assert(NSRC <= 8, "one lane per (corner, view): 8 x NSRC <= 64");
     constexpr int NPW = PH / 2, NSUBW = WWAVES / NPW;   // pixel waves, plane sub-ranges
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 && !D3D_WINDOW_WG3 ?
 
     // 16-channel groups: the patch's REFERENCE features live in LDS too ([quad][pixel] 16-byte cells, a lane reads its own cell
     // once per plane and quad) -- sixteen registers per lane the 128-register budget of two workgroups per CU does not have
-    constexpr bool REF_LDS = Q > 2;
+    constexpr bool REF_LDS = Q > 2 && MODE != MODE_PAIR;   // (a pair sweep has one view's geometry live: room for the reference in registers)
     constexpr int NPIX = WTW * PH;
     constexpr int REF_BYTES = REF_LDS ? CH * NPIX * 4 : 0;
     const int ref0 = lds_base_bytes(lds) + WTAB * 4;
@@ -413,6 +415,52 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 && !D3D_WINDOW_WG3 ?
                                                       (p.out_cl == 2 ? ((size_t)d * (p.C / 8) + c0 / 8) * plane * 8 : (size_t)d * plane * p.C + c0))
                                           : uniform64(p.out + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);
             if (!valid) return;
+            if constexpr (MODE == MODE_PAIR) {
+                // adamvs.py:469-474: mean over the channels of reference x warped source, all C channels in one pass (quads in
+                // order, channels in order: the ring kernel's sum)
+                float pair_acc = 0.0f;
+                if (staged) {
+#ifndef D3D_WINDOW_T_SGPR
+                    const f4 tv = *(volatile lds_f4_ptr)(unsigned)tadr;
+                    const TapL g = geo_win(ray[0], tv[0], tv[1], tv[2], dv, umax, vmax, W[0]);
+#else
+                    const TapL g = geo_win(ray[0], T0[0], T1[0], T2[0], dv, umax, vmax, W[0]);
+#endif
+                    f4 tp[2][4];
+                    auto request = [&](int q2, f4 (&dst)[4]) {
+                        const int n = g.a0 + q2 * W[0].qb, s_ = g.a1 + q2 * W[0].qb;
+                        dst[0] = lds_read4_abs(n);
+                        dst[1] = lds_read4_abs(n + 16);
+                        dst[2] = lds_read4_abs(s_);
+                        dst[3] = lds_read4_abs(s_ + 16);
+                    };
+                    request(0, tp[0]);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        if (q + 1 < Q) request(q + 1, tp[(q + 1) & 1]);
+                        f4 (&c)[4] = tp[q & 1];
+                        asm volatile("" : "+v"(c[3]));
+                        const f4 val = blend(c[0], c[1], c[2], c[3], g.nw, g.ne, g.sw, g.se);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_acc = fmaf(r[REF_LDS ? 0 : q][k], val[k], pair_acc);
+                    }
+                } else {
+                    float u, v;
+                    project(ray[0], T0[0], T1[0], T2[0], dv, h, w, u, v);
+                    const TapG t = make_tap_glb(u, v, h, w);
+                    const float* __restrict__ gsrc = p.feats[1] + t.off;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const float* __restrict__ gk = gsrc + (size_t)(4 * q + kk) * plane;
+                            const float val = fmaf(gk[t.dyw + t.dx], t.se, fmaf(gk[t.dyw], t.sw, fmaf(gk[t.dx], t.ne, gk[0] * t.nw)));
+                            pair_acc = fmaf(r[REF_LDS ? 0 : q][kk], val, pair_acc);
+                        }
+                }
+                store_sbase(uniform64(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
+                return;
+            }
             if constexpr (Q > 2) { if (staged) {
                 // Unit-major (16-channel groups): units u = (quad q, view i) in q-major order, one quad's accumulators live, the
                 // four views' geometry kept for the whole plane (the ring kernel's order)
@@ -636,7 +684,7 @@ __global__ __launch_bounds__(64 * window_waves(CH), CH == 8 && !D3D_WINDOW_WG3 ?
 template <int MODE, int NSRC, int CH, bool OUTCL, int PH>
 static int launch_window_one(const SweepParams& p, hipStream_t stream) {
     auto kern = sweep_window_kernel<MODE, NSRC, CH, OUTCL, PH>;
-    constexpr int WLDS_BYTES = window_lds_bytes(CH);
+    constexpr int WLDS_BYTES = window_lds_bytes(MODE, CH);
     if (OUTCL && (size_t)p.h * p.w * p.C * 2 >= ((size_t)1 << 32)) return D3D_ERR_UNSUPPORTED;
     if ((size_t)p.h * p.w * p.C * 4 >= 0x7ffffff0u) return D3D_ERR_UNSUPPORTED;   // buffer-load offsets of the staging (see OOB)
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WLDS_BYTES);
@@ -668,7 +716,7 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
         (void)hipMemset(a.stats, 0, 8 * sizeof(unsigned long long));
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * window_waves(CH)), WLDS_BYTES, stream, p, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * window_waves(MODE, CH)), WLDS_BYTES, stream, p, a);
     D3D_LAUNCH_CHECK("sweep_window_kernel launch");
 #ifdef D3D_EXPERIMENTS
     if (a.stats) {
@@ -676,7 +724,7 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
         (void)hipMemcpy(hs, a.stats, sizeof(hs), hipMemcpyDeviceToHost);
         const double n = (double)hs[0];
         fprintf(stderr, "[d3d window stats] CH=%d waves=%d wgs=%.0f groups=%d | per workgroup: staged chunks %.2f, planes per chunk %.2f, gathered planes %.2f, "
-                "staged KB %.1f | cycles (wave 0): staging %.0f, sweeping %.0f, total %.0f\n", CH, window_waves(CH), n, a.ngroups, hs[1] / n,
+                "staged KB %.1f | cycles (wave 0): staging %.0f, sweeping %.0f, total %.0f\n", CH, window_waves(MODE, CH), n, a.ngroups, hs[1] / n,
                 hs[1] ? (double)hs[2] / hs[1] : 0.0, hs[3] / n, hs[4] * 16.0 / 1024.0 / n, hs[5] / n, hs[6] / n, hs[7] / n);
         (void)hipFree(a.stats);
     }
@@ -718,8 +766,17 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
 // `forced`: the test hook asked for this kernel -- the plane limit of the dispatcher's choice does not apply.
 int launch_window(int mode, const SweepParams& p, hipStream_t stream, bool forced) {
     if (p.elem_bytes != 4 || p.C % 8 != 0 || p.n_src > 4 || p.n_src < 1) return D3D_ERR_UNSUPPORTED;
-    if (mode != MODE_VARIANCE && mode != MODE_WEIGHTED) return D3D_ERR_UNSUPPORTED;
+    if (mode != MODE_VARIANCE && mode != MODE_WEIGHTED && mode != MODE_PAIR) return D3D_ERR_UNSUPPORTED;
     if (!forced && (D3D_WINDOW_PLANES == 0 || p.D > D3D_WINDOW_PLANES)) return D3D_ERR_UNSUPPORTED;
+    if (mode == MODE_PAIR) {   // one source view, every channel in one pass
+        if (p.n_src != 1 || p.out_cl) return D3D_ERR_UNSUPPORTED;
+        switch (p.C) {
+            case 8: return launch_window_one<MODE_PAIR, 1, 8, false, 8>(p, stream);
+            case 16: return launch_window_one<MODE_PAIR, 1, 16, false, 8>(p, stream);
+            case 32: return launch_window_one<MODE_PAIR, 1, 32, false, 8>(p, stream);
+        }
+        return D3D_ERR_UNSUPPORTED;
+    }
     if (mode == MODE_VARIANCE)
         return p.n_src <= 2 ? launch_window_ch<MODE_VARIANCE, 2>(p, stream) : launch_window_ch<MODE_VARIANCE, 4>(p, stream);
     return p.n_src <= 2 ? launch_window_ch<MODE_WEIGHTED, 2>(p, stream) : launch_window_ch<MODE_WEIGHTED, 4>(p, stream);

@@ -392,7 +392,9 @@ def test_window_kernel_repeats_the_ring_kernel_bit_for_bit(ops, oracle, case):
         try:
             outs[path_] = (ops.variance_volume(fd, p34, depth), ops.weighted_corr(fd, p34, vw, depth),
                            ops.variance_volume_cl(fd, p34, depth),
-                           None if depth_vol is None else ops.variance_volume(fd, p34, depth_vol))
+                           None if depth_vol is None else ops.variance_volume(fd, p34, depth_vol),
+                           ops.pair_corr_mean(fd[0], fd[1], p34[0].contiguous(), depth),
+                           None if depth_vol is None else ops.pair_corr_mean(fd[0], fd[V - 1], p34[V - 2].contiguous(), depth_vol))
         finally:
             config.switches["D3D_FORCE_PATH"] = ""
     for a, b in zip(outs["tiled"], outs["window"]):
