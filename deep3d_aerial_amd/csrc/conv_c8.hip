@@ -71,13 +71,19 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
 }
 
-template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false>
-__global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+// X3 (fp32 accuracy on the bf16 matrix cores, the 3-D form of conv2d_zs.hip's split operands; planar fp32 in and out): every
+// input value and every weight is the exact sum of three bf16 numbers (hi + mid + lo); a staged cell holds the hi, mid and lo
+// runs of its channels, the host packs the weights' three parts, and per K block the six products whose error terms matter --
+// lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, small terms first -- are accumulated in fp32: the error is that of the fp32
+// instruction v_mfma_f32_16x16x4_f32, at six eighths of its time per product and with the z-streaming traffic of this kernel.
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false, bool X3 = false>
+__global__ __launch_bounds__(NT, X3 ? 2 : NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+    static_assert(!X3 || (!INCL && !OUTCL && !KZF && !CO8), "split operands: planar fp32 tensors");
     static_assert(!CO8 || (OUTCL && NTN == 1), "CO8: the channel-last epilogue for exactly 8 output channels");
     static_assert(!KZF || (NTN == 1 && !OUTCL && !WG), "k_z-folded form: one output channel, planar output");
     constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5)
+    constexpr int CS = (X3 ? 6 : 2) * CI + (CI > 8 ? 16 : 0);   // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5; split: 3 | 7 | 13)
     constexpr int G = CI / 8;                          // 8-channel groups per pixel
     constexpr int PATCH = PX * PY * CS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
     // ---- weights: resident in LDS (a K block's three k_z fragments are read once per wave and plane and reused by the
     //      four pixel groups; keeping all 3 * NKB fragments in registers would cost the second workgroup per CU) -------
     if constexpr (!WG)
-        for (int i = tid; i < (KZF ? 1 : 3) * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+        for (int i = tid; i < (X3 ? 3 : 1) * (KZF ? 1 : 3) * NKB * NTN * 64; i += NT) wlds[i] = p.wpk[i];   // (split: [part][k_z][K block][tile][lane])
     const u4* __restrict__ wsrc = WG ? p.wpk : wlds;
 
     // ---- per-lane A offsets: K index k = 32 kb + 8 (lane >> 4) + j  ->  tap t = k / CI, channel k % CI ----------
@@ -151,6 +157,25 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
             const int task = tid + r * NT;
             if (task < NTASK) {
                 const int pix = task / G, g = task - pix * G;
+                if constexpr (X3) {   // hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the differences are exact in fp32
+                    float r1[8], r2[8];
+                    unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        hi[k >> 1] = pack_bf16(stg[rr][k], stg[rr][k + 1]);
+                        r1[k] = stg[rr][k] - __builtin_bit_cast(float, hi[k >> 1] << 16);
+                        r1[k + 1] = stg[rr][k + 1] - __builtin_bit_cast(float, hi[k >> 1] & 0xffff0000u);
+                        mi[k >> 1] = pack_bf16(r1[k], r1[k + 1]);
+                        r2[k] = r1[k] - __builtin_bit_cast(float, mi[k >> 1] << 16);
+                        r2[k + 1] = r1[k + 1] - __builtin_bit_cast(float, mi[k >> 1] & 0xffff0000u);
+                        lo[k >> 1] = pack_bf16(r2[k], r2[k + 1]);
+                    }
+                    unsigned char* cell = dst + pix * CS + g * 16;
+                    *reinterpret_cast<u4*>(cell) = (u4){hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<u4*>(cell + CI * 2) = (u4){mi[0], mi[1], mi[2], mi[3]};
+                    *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
+                    continue;
+                }
                 u4 v;
                 if constexpr (INCL) v = stc[rr];
                 else v = (u4){pack_bf16(stg[rr][0], stg[rr][1]), pack_bf16(stg[rr][2], stg[rr][3]), pack_bf16(stg[rr][4], stg[rr][5]),
@@ -269,6 +294,36 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
                 }
                 return;
             }
+            if constexpr (X3) {
+                // weights [part s][k_z][K block][tile][lane]; A parts at + s * CI * 2 inside the cell
+                constexpr int WS = 3 * NKB * NTN * 64;   // fragments per weight part
+#pragma unroll
+                for (int mg = 0; mg < MGN; ++mg) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp)
+                        a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk + sp * CI * 2));
+#pragma unroll
+                    for (int kz = 0; kz < 3; ++kz) {
+                        f4 (&dstacc)[AW] = kz == 0 ? up : kz == 1 ? mid : down;
+#pragma unroll
+                        for (int nt = 0; nt < NTN; ++nt) {
+                            const int wi = ((kz * NKB + kb) * NTN + nt) * 64 + lane;
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, wsrc[wi]);
+                            const bf16x8 bm = __builtin_bit_cast(bf16x8, wsrc[WS + wi]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, wsrc[2 * WS + wi]);
+                            f4 c = dstacc[mg * NTN + nt];   // small terms first
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bm, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bm, c, 0, 0, 0);
+                            dstacc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bh, c, 0, 0, 0);
+                        }
+                    }
+                }
+                return;
+            }
             bf16x8 b0[NTN], b1[NTN], b2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
@@ -339,15 +394,16 @@ __global__ __launch_bounds__(NT, NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) voi
     }
 }
 
-template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false>
+template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false, bool X3 = false>
 static int launch(const C8Params& p, hipStream_t stream) {
     if constexpr (OUTCL && NTN == 1 && !KZF && !WG && !CO8)
         if (p.CO == 8) return launch<CI, NTN, INCL, OUTCL, MGN, WG, KZF, true>(p, stream);   // whole-cell stores (see store_plane)
     constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int CS = (X3 ? 6 : 2) * CI + (CI > 8 ? 16 : 0);
     constexpr int TXk = 16 * MGN, PXk = TXk + 2;
-    const int lds = 2 * PXk * PY * CS + (WG ? 0 : (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
-    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF, CO8>;
+    constexpr int lds = 2 * PXk * PY * CS + (WG ? 0 : (X3 ? 3 : 1) * (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF, CO8, X3>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     C8Params q = p;
@@ -426,6 +482,27 @@ extern "C" int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* w
         case 8: return launch<8, 1, false, false, 4, false, true>(p, st);
         case 16: return launch<16, 1, false, false, 4, false, true>(p, st);
         default: return launch<32, 1, false, false, 4, false, true>(p, st);
+    }
+}
+
+extern "C" int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                        const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                        d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    if ((Ci != 8 && Ci != 16 && Ci != 32) || Co < 1 || Co > 16 || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_zs_bf16x3: C_in = %d (8 | 16 | 32), C_out = %d (<= 16), W = %d (a multiple of 4) not taken", Ci, Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    C8Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
+    hipStream_t st = (hipStream_t)stream;
+    // 32-wide tiles (split cells are three times as wide); C_in = 32: the 81 KB of weight fragments stay in L2
+    switch (Ci) {
+        case 8: return launch<8, 1, false, false, 2, false, false, false, true>(p, st);
+        case 16: return launch<16, 1, false, false, 2, false, false, false, true>(p, st);
+        default: return launch<32, 1, false, false, 2, true, false, false, true>(p, st);
     }
 }
 

@@ -391,6 +391,11 @@ def _pack_c8_bf16(w):
     return b.reshape(3, nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_c8_bf16x3(w):
+    """[Co,Ci,3,3,3] -> the B operands of d3d_conv3d_k3_zs_bf16x3: [hi | mid | lo] x _pack_c8_bf16 (the exact three-way bf16 split)."""
+    return torch.stack([_pack_c8_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
 def _pack_c8_kzfold_bf16(w):
     """nn.Conv3d weight [1,Ci,3,3,3] -> B operands of d3d_conv3d_k3_c1_cl_bf16: ONE tile per K block whose columns 0, 1, 2 are
     the k_z = 0, 1, 2 slices (K = (k_y, k_x, c_in), padded to a multiple of 32); [K block][lane][8], lane l = column l & 15,
@@ -412,6 +417,24 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
     # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
+    x3 = _cfg.get("D3D_CONV_C8X3")
+    if stride == 1 and Ci in (8, 16, 32) and Co in (8, 16) and W % 4 == 0 and _use_mfma() and conv_precision() != "bf16" \
+            and (x3 == "all" or (x3 != "0" and (Ci == 8 or (Ci == 16 and Co == 16)))):
+        # fp32 mode of conv0 at the last stage (8 -> 8) and of conv2 (16 -> 16; cas_mvsnet.py:84,87): the z-streaming matrix-core
+        # kernel on three-way bf16 splits of both operands -- fp32 accuracy (six products per K block), each plane staged once.
+        # Measured against the kernels it replaces (tools/x3_bench.py): 8 -> 8 at 8 x 1856 x 2752 1.87 -> 1.67 ms (3.86 -> 1.83
+        # inside a view), 16 -> 16 0.49 / 1.00 / 0.82 -> 0.23 / 0.53 / 0.59 ms; 16 -> 8 and 32 -> 8 (conv0 of stages 2 / 1) are
+        # slower on it (3.27 -> 3.56, 2.62 -> 2.95 ms: one workgroup per CU) and stay where they were (D3D_CONV_C8X3=all)
+        wp = derived_weight(weight, "c8bf16x3", _pack_c8_bf16x3)
+        out = torch.empty((Co, D, H, W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_conv3d_k3_zs_bf16x3(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                 _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
+                                                 _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_conv3d_k3_zs_bf16x3")
+            return out
     if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and _cfg.get("D3D_CONV_CO8") != "0" \
             and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv0 of every CostRegNet): z-streaming kernel on the fp32 vector units (same peak as the fp32 matrix

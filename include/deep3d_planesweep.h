@@ -244,6 +244,12 @@ int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* sca
  * wpacked: [k_z][K block][N tile of 16 channels][lane][8 values]. */
 int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
+/* The same kernel with fp32 ACCURACY (the default precision of the regularisers): both operands as exact three-way bf16
+ * splits (hi + mid + lo), six v_mfma_f32_16x16x32_bf16 products per K block accumulated in fp32 -- the 3-D form of
+ * d3d_conv2d_k3_zs_bf16x3.  C_in = 8 | 16 | 32, C_out <= 16, W % 4 == 0.  wpacked: [hi | mid | lo] x the layout above
+ * (ops._pack_c8_bf16x3). */
+int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                            int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
 
 
 /* module.py:307-314 Deconv3d (+BN+ReLU) / cas_mvsnet.py:103,118 for C_out = 8 (conv11 of CostRegNet: 16 -> 8, then the
