@@ -77,17 +77,20 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi, small terms first -- are accumulated in fp32: the error is that of the fp32
 // instruction v_mfma_f32_16x16x4_f32, at six eighths of its time per product and with the z-streaming traffic of this kernel.
 template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false, bool X3 = false>
-__global__ __launch_bounds__(NT, X3 ? 2 : NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
+__global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
     static_assert(!X3 || (!INCL && !OUTCL && !KZF && !CO8), "split operands: planar fp32 tensors");
     static_assert(!CO8 || (OUTCL && NTN == 1), "CO8: the channel-last epilogue for exactly 8 output channels");
     static_assert(!KZF || (NTN == 1 && !OUTCL && !WG), "k_z-folded form: one output channel, planar output");
     constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
-    constexpr int CS = (X3 ? 6 : 2) * CI + (CI > 8 ? 16 : 0);   // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5; split: 3 | 7 | 13)
+    // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5) -- split operands: 3 slots, 6 (16 channels: unpadded, so that
+    // patch + weights stay under half the LDS and two workgroups share a CU; the A reads are a quarter of the LDS reads) or 13
+    constexpr int CS = X3 ? (CI == 16 ? 96 : 6 * CI + (CI > 8 ? 16 : 0)) : 2 * CI + (CI > 8 ? 16 : 0);
+    constexpr int NBUF = X3 && CI >= 16 ? 1 : 2;   // split cells of 16 | 32 channels: ONE patch buffer (commit after every wave has read it)
     constexpr int G = CI / 8;                          // 8-channel groups per pixel
     constexpr int PATCH = PX * PY * CS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
+    u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(NT, X3 ? 2 : NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
     // (measured at the cascade shapes: C_in = 32 1.18 ms split vs 2.37 ms unsplit; C_in = 16 1.52 ms unsplit at one workgroup
     //  per CU vs 2.1-2.5 ms split or at two workgroups per CU; C_in = 8 0.76 ms at two workgroups per CU vs 1.54 ms at one)
-    constexpr int RH = (CI > 16 && !INCL) ? (ROUNDS + 1) / 2 : ROUNDS;   // rounds in the first half
+    constexpr int RH = (CI > 16 && !INCL && NBUF == 2) ? (ROUNDS + 1) / 2 : ROUNDS;   // rounds in the first half
     float stg[INCL ? 1 : RH][8];
     u4 stc[INCL ? RH : 1];
     auto issue = [&](int zi, int r0, int r1) {   // global loads of input plane zi, rounds [r0, r1), into registers (zeros outside the volume)
@@ -373,6 +376,15 @@ __global__ __launch_bounds__(NT, X3 ? 2 : NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4
     auto step = [&](int zi, f4 (&up)[AW], f4 (&mid)[AW], f4 (&down)[AW]) {   // up: zi+1, mid: zi, down: zi-1
         const bool more = zi + 1 <= z1, live = zi >= 0 && zi < D;
         constexpr int KH = (NKB + 1) / 2;
+        if constexpr (NBUF == 1) {
+            if (more) issue(zi + 1, 0, ROUNDS);        // the next plane waits in registers
+            if (live) sweep(smem, up, mid, down, 0, NKB);
+            store_plane(zi - 1, down);
+            __syncthreads();                           // every wave has read the patch
+            if (more) commit(smem, 0, ROUNDS);
+            __syncthreads();
+            return;
+        }
         if (more) issue(zi + 1, 0, RH);                // the next plane's loads fly during the MFMA sweep
         if (live) sweep(smem + cur * PATCH, up, mid, down, 0, KH);
         if (more) commit(smem + (cur ^ 1) * PATCH, 0, RH);
@@ -399,9 +411,9 @@ static int launch(const C8Params& p, hipStream_t stream) {
     if constexpr (OUTCL && NTN == 1 && !KZF && !WG && !CO8)
         if (p.CO == 8) return launch<CI, NTN, INCL, OUTCL, MGN, WG, KZF, true>(p, stream);   // whole-cell stores (see store_plane)
     constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = (X3 ? 6 : 2) * CI + (CI > 8 ? 16 : 0);
+    constexpr int CS = X3 ? (CI == 16 ? 96 : 6 * CI + (CI > 8 ? 16 : 0)) : 2 * CI + (CI > 8 ? 16 : 0);
     constexpr int TXk = 16 * MGN, PXk = TXk + 2;
-    constexpr int lds = 2 * PXk * PY * CS + (WG ? 0 : (X3 ? 3 : 1) * (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
+    constexpr int lds = (X3 && CI >= 16 ? 1 : 2) * PXk * PY * CS + (WG ? 0 : (X3 ? 3 : 1) * (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF, CO8, X3>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
@@ -498,11 +510,11 @@ extern "C" int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, con
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
     hipStream_t st = (hipStream_t)stream;
-    // 32-wide tiles (split cells are three times as wide); C_in = 32: the 81 KB of weight fragments stay in L2
+    // 32-wide tiles (split cells are three times as wide); 16 | 32 input channels: one patch buffer beside the weights
     switch (Ci) {
         case 8: return launch<8, 1, false, false, 2, false, false, false, true>(p, st);
         case 16: return launch<16, 1, false, false, 2, false, false, false, true>(p, st);
-        default: return launch<32, 1, false, false, 2, true, false, false, true>(p, st);
+        default: return launch<32, 1, false, false, 2, false, false, false, true>(p, st);
     }
 }
 

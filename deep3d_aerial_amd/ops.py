@@ -417,14 +417,12 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
     # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
-    x3 = _cfg.get("D3D_CONV_C8X3")
     if stride == 1 and Ci in (8, 16, 32) and Co in (8, 16) and W % 4 == 0 and _use_mfma() and conv_precision() != "bf16" \
-            and (x3 == "all" or (x3 != "0" and (Ci == 8 or (Ci == 16 and Co == 16)))):
-        # fp32 mode of conv0 at the last stage (8 -> 8) and of conv2 (16 -> 16; cas_mvsnet.py:84,87): the z-streaming matrix-core
-        # kernel on three-way bf16 splits of both operands -- fp32 accuracy (six products per K block), each plane staged once.
-        # Measured against the kernels it replaces (tools/x3_bench.py): 8 -> 8 at 8 x 1856 x 2752 1.87 -> 1.67 ms (3.86 -> 1.83
-        # inside a view), 16 -> 16 0.49 / 1.00 / 0.82 -> 0.23 / 0.53 / 0.59 ms; 16 -> 8 and 32 -> 8 (conv0 of stages 2 / 1) are
-        # slower on it (3.27 -> 3.56, 2.62 -> 2.95 ms: one workgroup per CU) and stay where they were (D3D_CONV_C8X3=all)
+            and _cfg.get("D3D_CONV_C8X3") != "0":
+        # fp32 mode of conv0 and conv2 (cas_mvsnet.py:84,87): the z-streaming matrix-core kernel on three-way bf16 splits of both
+        # operands -- fp32 accuracy (six products per K block), each plane staged once.  Against the kernels it replaces
+        # (tools/x3_bench.py): conv0 32 -> 8 / 16 -> 8 / 8 -> 8 at the three stage volumes 2.65 / 3.22 / 1.85 -> 2.47 / 2.84 / 1.69 ms,
+        # conv2 16 -> 16 0.49 / 0.99 / 0.83 -> 0.18 / 0.43 / 0.44 ms
         wp = derived_weight(weight, "c8bf16x3", _pack_c8_bf16x3)
         out = torch.empty((Co, D, H, W), dtype=torch.float32, device=x.device)
         if skip is not None and skip.shape != out.shape:

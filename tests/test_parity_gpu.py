@@ -1507,7 +1507,7 @@ def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch,
     sc, sh = rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, D, H, W)).astype(np.float32)
     want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0.0) + sk
-    set_switch(monkeypatch, "D3D_CONV_C8X3", "all")
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "1")
     got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert np.abs(got - want).max() <= tol
@@ -1515,7 +1515,7 @@ def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch,
     old = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     assert np.abs(got - old).max() <= tol
     plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
-    set_switch(monkeypatch, "D3D_CONV_C8X3", "all")
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "1")
     assert np.abs(host(ops.conv3d_k3(dev(x), dev(w), relu=False)) - plain).max() <= tol
 
 

@@ -14,7 +14,7 @@ for tag, Ci, Co, D, h, w in (("conv0 stage1", 32, 8, 48, 464, 688), ("conv0 stag
                              ("conv2 stage1", 16, 16, 24, 232, 344), ("conv2 stage2", 16, 16, 16, 464, 688), ("conv2 stage3", 16, 16, 4, 928, 1376)):
     x = torch.randn(Ci, D, h, w, device="cuda"); wt = torch.randn(Co, Ci, 3, 3, 3, device="cuda") * 0.1
     r = []
-    for sw in ("all", "0"):
+    for sw in ("1", "0"):
         config.switches["D3D_CONV_C8X3"] = sw
         r.append(timeit(lambda: ops.conv3d_k3(x, wt, relu=True)))
     config.switches["D3D_CONV_C8X3"] = "1"
