@@ -70,13 +70,16 @@ constexpr int fold_base(int CI, int c) {
 // FOLD (CL, C_out = 8): both column parities in ONE GEMM -- rows 0..7 of the weight operand are the 8 channels of the even
 // output column (taps with dx = 1 zeroed), rows 8..15 those of the odd one, so no half of the tile idles, the four lane
 // groups of a pixel leave with the 32 contiguous bytes of the output cells (2 ix, 2 ix + 1) and every lane stores.
-template <int CI, int NTN, int MG, bool CL, bool FOLD = false>
+// X3 (planar fp32 tensors, fp32 accuracy): cells hold the hi | mid | lo runs of the exact three-way bf16 split of their channels,
+// the weight fragments come in three parts, six products per K block (see conv_c8.hip).
+template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false>
 __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     static_assert(!FOLD || (CL && NTN == 1), "x-folded form: channel-last, C_out = 8");
+    static_assert(!X3 || (!CL && !FOLD), "split operands: planar fp32 tensors");
     constexpr int NT = 64 * TYI;
     constexpr int TXI = 16 * MG;
     constexpr int PXI = TXI + 1, PYI = TYI + 1;         // input patch: one more column / row for the d = 1 taps
-    constexpr int CS = CI * 2 + 16;                     // bytes per cell: 3 | 5 | 9 sixteen-byte slots (odd)
+    constexpr int CS = (X3 ? 6 : 2) * CI + 16;          // bytes per cell: 3 | 5 | 9 sixteen-byte slots (odd); split: 7 | 13
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
     constexpr int NFRAG = FOLD ? fold_base(CI, 4) : frag_base(CI, 8);
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     const size_t oplane = 4 * iplane, ovol = (size_t)(2 * D) * oplane;
     const int OW = 2 * W;
 
-    for (int i = tid; i < NFRAG * NTN * 64; i += NT) wlds[i] = p.wpk[i];
+    for (int i = tid; i < (X3 ? 3 : 1) * NFRAG * NTN * 64; i += NT) wlds[i] = p.wpk[i];   // (split: [part][fragment])
 
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
@@ -128,6 +131,24 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             const int task = tid + r * NT;
             if (task < NTASK) {
                 const int pix = task / G, g = task - pix * G;
+                if constexpr (X3) {   // hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the differences are exact in fp32
+                    unsigned hi[4], mi[4], lo[4];
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        hi[k >> 1] = pack_bf16_t2(stg[r][k], stg[r][k + 1]);
+                        const float a1 = stg[r][k] - __builtin_bit_cast(float, hi[k >> 1] << 16);
+                        const float b1 = stg[r][k + 1] - __builtin_bit_cast(float, hi[k >> 1] & 0xffff0000u);
+                        mi[k >> 1] = pack_bf16_t2(a1, b1);
+                        const float a2 = a1 - __builtin_bit_cast(float, mi[k >> 1] << 16);
+                        const float b2 = b1 - __builtin_bit_cast(float, mi[k >> 1] & 0xffff0000u);
+                        lo[k >> 1] = pack_bf16_t2(a2, b2);
+                    }
+                    unsigned char* cell = dst + pix * CS + g * 16;
+                    *reinterpret_cast<u4*>(cell) = (u4){hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<u4*>(cell + CI * 2) = (u4){mi[0], mi[1], mi[2], mi[3]};
+                    *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
+                    continue;
+                }
                 u4 v;
                 if constexpr (CL) v = stc[r];
                 else v = (u4){pack_bf16_t2(stg[r][0], stg[r][1]), pack_bf16_t2(stg[r][2], stg[r][3]), pack_bf16_t2(stg[r][4], stg[r][5]),
@@ -211,6 +232,31 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                 const int dz = real ? t / ((1 + px) * (1 + PY)) : 0;
                 const unsigned char* buf = dz ? b1 : b0;
                 const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
+                if constexpr (X3) {
+                    constexpr int WS = NFRAG * NTN * 64;   // fragments per weight part
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) {
+                        bf16x8 a[3];
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp)
+                            a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff + sp * CI * 2));
+#pragma unroll
+                        for (int nt = 0; nt < NTN; ++nt) {
+                            const int wi = ((FB + kb) * NTN + nt) * 64 + lane;
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, wlds[wi]);
+                            const bf16x8 bm = __builtin_bit_cast(bf16x8, wlds[WS + wi]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, wlds[2 * WS + wi]);
+                            f4 c = acc[px][mg][nt];   // small terms first
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bm, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bm, c, 0, 0, 0);
+                            acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bh, c, 0, 0, 0);
+                        }
+                    }
+                    continue;
+                }
                 bf16x8 bfrag[NTN];
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) bfrag[nt] = __builtin_bit_cast(bf16x8, wlds[((FB + kb) * NTN + nt) * 64 + lane]);
@@ -310,12 +356,13 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     }
 }
 
-template <int CI, int NTN, int MG, bool CL, bool FOLD = false>
+template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false>
 static int launch(const T2Params& p, hipStream_t stream) {
     constexpr int TXI = 16 * MG;
-    constexpr int CS = CI * 2 + 16;
-    const int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16;
-    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD>;
+    constexpr int CS = (X3 ? 6 : 2) * CI + 16;
+    constexpr int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (X3 ? 3 : 1) * (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD, X3>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     T2Params q = p;
@@ -361,6 +408,21 @@ extern "C" int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpac
     if (Ci == 16) return launch<16, 1, 2, false>(p, st);
     if (Ci == 32) return launch<32, 1, 2, false>(p, st);
     return launch<64, 2, 1, false>(p, st);
+}
+
+extern "C" int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                  const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                                  d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    if (Ci != 16 || (Co != 8 && Co != 16) || ceil_div(H, TYI) > 65535 || 2 * D > 65535) {
+        set_error("d3d_convtranspose3d_k3s2_zs_bf16x3: %d -> %d channels not taken (16 -> 8, 16 -> 16)", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    T2Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.CO = Co; p.relu = relu;
+    return launch<16, 1, 2, false, false, true>(p, (hipStream_t)stream);
 }
 
 extern "C" int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,

@@ -391,6 +391,11 @@ def _pack_c8_bf16(w):
     return b.reshape(3, nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_t2_bf16x3(w):
+    """nn.ConvTranspose3d weight [Ci,Co,3,3,3] -> the B operands of d3d_convtranspose3d_k3s2_zs_bf16x3: [hi | mid | lo] x _pack_t2_bf16."""
+    return torch.stack([_pack_t2_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
 def _pack_c8_bf16x3(w):
     """[Co,Ci,3,3,3] -> the B operands of d3d_conv3d_k3_zs_bf16x3: [hi | mid | lo] x _pack_c8_bf16 (the exact three-way bf16 split)."""
     return torch.stack([_pack_c8_bf16(part) for part in _split3_bf16(w)]).contiguous()
@@ -529,6 +534,19 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    if (Ci, Co) in ((16, 8), (16, 16)) and _use_mfma() and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
+        # fp32 mode of conv11 (cas_mvsnet.py:103: 16 -> 8 to the full-resolution volume): the per-parity matrix-core kernel on
+        # three-way bf16 splits of both operands (fp32 accuracy, see conv3d_k3)
+        wp = derived_weight(weight, "t2bf16x3", _pack_t2_bf16x3)
+        out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_convtranspose3d_k3s2_zs_bf16x3(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                            _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
+                                                            _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_convtranspose3d_k3s2_zs_bf16x3")
+            return out
     if Co == 8 and Ci % 8 == 0 and _use_mfma() and _cfg.get("D3D_CONV_CO8") != "0" \
             and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv11 of every CostRegNet): z-streaming kernel on the fp32 vector units, weights [Ci][kz][ky][kx][8]

@@ -270,6 +270,11 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
 int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream);
+/* ... and with fp32 accuracy from three-way bf16 splits of both operands (16 -> 8 | 16: conv11 of every CostRegNet in the
+ * default precision); wpacked: [hi | mid | lo] x the layout above (ops._pack_t2_bf16x3). */
+int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                     d3d_stream_t stream);
 
 /* module.py:5-51 ConvGRUCell / adamvs.py:409-413 ConvReLU of the slice regularisers, bf16 mode: 3x3 stride-1 2-D convolution
  * over the channel concat of `in` [C1,H,W] and `in2` [C2,H,W] (may be NULL, C2 = 0) on v_mfma_f32_16x16x32_bf16, one 64 x 8

@@ -1519,6 +1519,25 @@ def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch,
     assert np.abs(host(ops.conv3d_k3(dev(x), dev(w), relu=False)) - plain).max() <= tol
 
 
+@pytest.mark.parametrize("Co,D,H,W", [(8, 4, 12, 20), (8, 1, 9, 33), (16, 3, 17, 16), (8, 5, 8, 70)])
+def test_convtranspose3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch, Co, D, H, W):
+    """d3d_convtranspose3d_k3s2_zs_bf16x3 (fp32 mode of conv11, cas_mvsnet.py:103): against the fp32 oracle with affine, ReLU
+    and skip, and against the kernel it replaces."""
+    rng = np.random.default_rng(Co + D + W)
+    x = rng.standard_normal((16, D, H, W)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((16, Co, 3, 3, 3))).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.standard_normal(Co).astype(np.float32)
+    sk = rng.standard_normal((Co, 2 * D, 2 * H, 2 * W)).astype(np.float32)
+    want = np.maximum(oracle.convtranspose3d_k3s2(x, w) * sc[:, None, None, None] + sh[:, None, None, None], 0.0) + sk
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "1")
+    got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
+    tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
+    assert np.abs(got - want).max() <= tol
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "0")
+    old = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
+    assert np.abs(got - old).max() <= tol
+
+
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 8, 24, 40), (32, 8, 4, 16, 64), (8, 8, 3, 9, 36), (16, 16, 5, 17, 32), (32, 1, 6, 16, 48)])
 def test_conv0_takes_the_cl8_volume(ops, bf16_mode, Ci, Co, D, H, W):
     """d3d_conv3d_k3_cl_bf16 / d3d_conv3d_k3_c1_cl_bf16 with in_cl = 2: a CL8 input [D,Ci/8,H,W,8] gives bit for bit the

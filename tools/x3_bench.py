@@ -19,3 +19,12 @@ for tag, Ci, Co, D, h, w in (("conv0 stage1", 32, 8, 48, 464, 688), ("conv0 stag
         r.append(timeit(lambda: ops.conv3d_k3(x, wt, relu=True)))
     config.switches["D3D_CONV_C8X3"] = "1"
     print("%s %2d -> %2d at %2d x %4d x %4d: split operands %.3f ms, previous kernel %.3f ms" % (tag, Ci, Co, D, h, w, r[0], r[1]), flush=True)
+for tag, Co, D, h, w in (("conv11 stage1", 8, 24, 232, 344), ("conv11 stage2", 8, 16, 464, 688), ("conv11 stage3", 8, 4, 928, 1376)):
+    x = torch.randn(16, D, h, w, device="cuda"); wt = torch.randn(16, Co, 3, 3, 3, device="cuda") * 0.1
+    sk = torch.randn(Co, 2 * D, 2 * h, 2 * w, device="cuda")
+    r = []
+    for sw in ("1", "0"):
+        config.switches["D3D_CONV_C8X3"] = sw
+        r.append(timeit(lambda: ops.convtranspose3d_k3s2(x, wt, skip=sk, relu=True)))
+    config.switches["D3D_CONV_C8X3"] = "1"
+    print("%s 16 -> %2d (transposed, x2) from %2d x %4d x %4d: split operands %.3f ms, previous kernel %.3f ms" % (tag, Co, D, h, w, r[0], r[1]), flush=True)
