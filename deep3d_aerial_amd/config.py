@@ -21,7 +21,7 @@ SWITCHES = {
     "D3D_CONV_PRECISION": ("fp32", "default operand precision of the regularisers: 'fp32' | 'bf16' (ops.set_conv_precision overrides)"),
     "D3D_CONV_CO8": ("1", "0: the 8-output-channel streaming kernels off"),
     "D3D_CONV_C8": ("1", "0: the bf16 z-streaming conv0 kernel off"),
-    "D3D_CONV_C8X3": ("1", "0: fp32 mode of the 3-D stride-1 layers with C_out = 8 | 16 not on the split-operand (3 x bf16) matrix-core kernel"),
+    "D3D_CONV_C8X3": ("1", "fp32 mode of conv0 / conv2 / conv11 on the split-operand (3 x bf16) matrix-core kernels: '1' | '0' off | 'all' also the probability layer (slower there)"),
     "D3D_CONV_CO1": ("1", "0: the single-output-channel probability kernel off"),
     "D3D_CONV_T2": ("1", "0: the transposed stride-2 streaming kernel off"),
     "D3D_CONV_CL": ("1", "0: channel-last bf16 activations off (planar bf16 path)"),

@@ -78,7 +78,7 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // instruction v_mfma_f32_16x16x4_f32, at six eighths of its time per product and with the z-streaming traffic of this kernel.
 template <int CI, int NTN, bool INCL, bool OUTCL, int MGN = 4, bool WG = false, bool KZF = false, bool CO8 = false, bool X3 = false>
 __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 8 || MGN < 4) ? 4 : 2) void conv3d_c8_bf16_kernel(C8Params p) {
-    static_assert(!X3 || (!INCL && !OUTCL && !KZF && !CO8), "split operands: planar fp32 tensors");
+    static_assert(!X3 || (!INCL && !OUTCL && !CO8), "split operands: planar fp32 tensors");
     static_assert(!CO8 || (OUTCL && NTN == 1), "CO8: the channel-last epilogue for exactly 8 output channels");
     static_assert(!KZF || (NTN == 1 && !OUTCL && !WG), "k_z-folded form: one output channel, planar output");
     constexpr int TX = 16 * MGN, PX = TX + 2;          // (shadow the 64-wide defaults)
@@ -288,6 +288,27 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
         asm volatile("" : "+v"(kgroup));   // keeps the offsets out of long-lived registers
         auto kb_body = [&](int kb) {
             const int aoffk = a_offset(kb, kgroup);
+            if constexpr (KZF && X3) {   // one tile set (columns = k_z), three weight parts
+                constexpr int WS1 = NKB * 64;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, wsrc[kb * 64 + lane]);
+                const bf16x8 bm = __builtin_bit_cast(bf16x8, wsrc[WS1 + kb * 64 + lane]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, wsrc[2 * WS1 + kb * 64 + lane]);
+#pragma unroll
+                for (int mg = 0; mg < MGN; ++mg) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp)
+                        a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk + sp * CI * 2));
+                    f4 c = up[mg];   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bm, c, 0, 0, 0);
+                    up[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bh, c, 0, 0, 0);
+                }
+                return;
+            }
             if constexpr (KZF) {
                 const bf16x8 bw = __builtin_bit_cast(bf16x8, wsrc[kb * 64 + lane]);
 #pragma unroll
@@ -495,6 +516,20 @@ extern "C" int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* w
         case 16: return launch<16, 1, false, false, 4, false, true>(p, st);
         default: return launch<32, 1, false, false, 4, false, true>(p, st);
     }
+}
+
+extern "C" int d3d_conv3d_k3_c1_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                                        int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
+    if (Ci != 8 || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_c1_bf16x3: C_in = %d (8), W = %d (a multiple of 4) not taken", Ci, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    C8Params p = {};
+    p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+    p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = 1;
+    return launch<8, 1, false, false, 4, false, true, false, true>(p, (hipStream_t)stream);
 }
 
 extern "C" int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,

@@ -391,6 +391,11 @@ def _pack_c8_bf16(w):
     return b.reshape(3, nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
 
 
+def _pack_c8_kzfold_bf16x3(w):
+    """[1,Ci,3,3,3] -> the B operands of d3d_conv3d_k3_c1_bf16x3: [hi | mid | lo] x _pack_c8_kzfold_bf16."""
+    return torch.stack([_pack_c8_kzfold_bf16(part) for part in _split3_bf16(w)]).contiguous()
+
+
 def _pack_t2_bf16x3(w):
     """nn.ConvTranspose3d weight [Ci,Co,3,3,3] -> the B operands of d3d_convtranspose3d_k3s2_zs_bf16x3: [hi | mid | lo] x _pack_t2_bf16."""
     return torch.stack([_pack_t2_bf16(part) for part in _split3_bf16(w)]).contiguous()
@@ -462,6 +467,21 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
                                                _chk(out, "out"), _stream())
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_zs_bf16")
+            return out
+    if Co == 1 and stride == 1 and Ci == 8 and W % 4 == 0 and _use_mfma() and conv_precision() != "bf16" \
+            and _cfg.get("D3D_CONV_C8X3") == "all":
+        # fp32 mode of the probability layer (cas_mvsnet.py:110) on the k_z-folded matrix-core kernel with split operands: built
+        # and tested, but SLOWER than the vector-unit kernel it would replace (0.25 / 0.59 / 0.61 -> 0.34 / 0.87 / 0.85 ms at the
+        # three stage volumes: one output channel fills 3 of 16 columns), so only D3D_CONV_C8X3=all routes here
+        wf = derived_weight(weight, "c8kzfoldx3", _pack_c8_kzfold_bf16x3)
+        out = torch.empty((1, D, H, W), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_conv3d_k3_c1_bf16x3(_chk(x, "x", 4), ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
+                                                 _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, D, H, W,
+                                                 _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_conv3d_k3_c1_bf16x3")
             return out
     co1 = Co == 1 and stride == 1 and Ci == 8 and _cfg.get("D3D_CONV_CO1") != "0"
     if _use_mfma() and Co <= 64 and not co1:

@@ -250,6 +250,10 @@ int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* sca
  * (ops._pack_c8_bf16x3). */
 int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                             int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
+/* C_out = 1 (the probability layer) the same way: k_z folded into the columns of one tile (d3d_conv3d_k3_c1_cl_bf16's form),
+ * planar fp32 in [8,D,H,W] and out [D,H,W]; wpacked: [hi | mid | lo] x ops._pack_c8_kzfold_bf16. */
+int d3d_conv3d_k3_c1_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                            int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
 
 
 /* module.py:307-314 Deconv3d (+BN+ReLU) / cas_mvsnet.py:103,118 for C_out = 8 (conv11 of CostRegNet: 16 -> 8, then the

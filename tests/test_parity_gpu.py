@@ -1496,7 +1496,7 @@ def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, 
 
 
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 8, 8, 24, 40), (16, 8, 5, 17, 68), (32, 8, 4, 16, 64), (8, 8, 1, 9, 36), (16, 16, 6, 33, 32),
-                                         (32, 16, 3, 8, 100), (8, 16, 9, 40, 24)])
+                                         (32, 16, 3, 8, 100), (8, 16, 9, 40, 24), (8, 1, 6, 19, 72), (8, 1, 1, 8, 132)])
 def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch, Ci, Co, D, H, W):
     """d3d_conv3d_k3_zs_bf16x3 (fp32 mode of conv0 / conv2, cas_mvsnet.py:84,87): three-way bf16 splits of both operands on the
     bf16 matrix cores against the fp32 oracle, with affine / ReLU / skip -- the tolerance of the fp32-instruction kernels --
@@ -1507,7 +1507,7 @@ def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch,
     sc, sh = rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, D, H, W)).astype(np.float32)
     want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0.0) + sk
-    set_switch(monkeypatch, "D3D_CONV_C8X3", "1")
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "all")   # ("all": the probability layer too -- off by default, it is slower there)
     got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert np.abs(got - want).max() <= tol
@@ -1515,7 +1515,7 @@ def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch,
     old = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     assert np.abs(got - old).max() <= tol
     plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
-    set_switch(monkeypatch, "D3D_CONV_C8X3", "1")
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "all")
     assert np.abs(host(ops.conv3d_k3(dev(x), dev(w), relu=False)) - plain).max() <= tol
 
 

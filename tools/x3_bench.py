@@ -11,10 +11,11 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 for tag, Ci, Co, D, h, w in (("conv0 stage1", 32, 8, 48, 464, 688), ("conv0 stage2", 16, 8, 32, 928, 1376), ("conv0 stage3", 8, 8, 8, 1856, 2752),
+                             ("prob stage1", 8, 1, 48, 464, 688), ("prob stage2", 8, 1, 32, 928, 1376), ("prob stage3", 8, 1, 8, 1856, 2752),
                              ("conv2 stage1", 16, 16, 24, 232, 344), ("conv2 stage2", 16, 16, 16, 464, 688), ("conv2 stage3", 16, 16, 4, 928, 1376)):
     x = torch.randn(Ci, D, h, w, device="cuda"); wt = torch.randn(Co, Ci, 3, 3, 3, device="cuda") * 0.1
     r = []
-    for sw in ("1", "0"):
+    for sw in ("all", "0"):
         config.switches["D3D_CONV_C8X3"] = sw
         r.append(timeit(lambda: ops.conv3d_k3(x, wt, relu=True)))
     config.switches["D3D_CONV_C8X3"] = "1"
