@@ -93,8 +93,21 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-    const int z0 = blockIdx.z * p.zper, z1 = min(z0 + p.zper, p.D);
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order (x fastest): give each XCD a CONTIGUOUS run of the logical
+    // order instead, x then y fastest, so that neighbouring tiles -- which share their halo rows and columns -- share an L2.
+    int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;
+#ifndef D3D_CONV_NO_XCD   // (regulariser leg 6.03 -> 5.97 ms)
+    {
+        const int nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+        if (n % 8 == 0) {
+            int lin = (bzi * ny + byi) * nx + bxi;
+            lin = (lin % 8) * (n / 8) + lin / 8;
+            bxi = lin % nx; byi = (lin / nx) % ny; bzi = lin / (nx * ny);
+        }
+    }
+#endif
+    const int x0 = bxi * TX, y0 = byi * TY;
+    const int z0 = bzi * p.zper, z1 = min(z0 + p.zper, p.D);
     const int D = p.D, H = p.H, W = p.W;
     const size_t plane = (size_t)H * W, vol = (size_t)D * plane;
 

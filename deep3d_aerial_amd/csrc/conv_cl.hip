@@ -64,8 +64,19 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     u4* wlds = reinterpret_cast<u4*>(smem + 2 * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int xo0 = blockIdx.x * TXO, yo0 = blockIdx.y * TYO;
-    const int zo0 = blockIdx.z * p.zper, zo1 = min(zo0 + p.zper, p.Do);
+    int bxi = blockIdx.x, byi = blockIdx.y, bzi = blockIdx.z;   // (XCD-contiguous tile order: see conv_c8.hip)
+#ifdef D3D_S2_XCD   // (measured: no change -- off)
+    {
+        const int nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+        if (n % 8 == 0) {
+            int lin = (bzi * ny + byi) * nx + bxi;
+            lin = (lin % 8) * (n / 8) + lin / 8;
+            bxi = lin % nx; byi = (lin / nx) % ny; bzi = lin / (nx * ny);
+        }
+    }
+#endif
+    const int xo0 = bxi * TXO, yo0 = byi * TYO;
+    const int zo0 = bzi * p.zper, zo1 = min(zo0 + p.zper, p.Do);
     const int D = p.D, H = p.H, W = p.W;
 
     if constexpr (!WG)
