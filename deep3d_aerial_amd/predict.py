@@ -345,11 +345,13 @@ def _item_views(s, model, device):
 # the per-view loop of predict.py:126-183, sharded over ranks
 # ----------------------------------------------------------------------------------------
 def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda", keep_maps=False,
-                  feature_cache_bytes=0, display=False):
+                  feature_cache_bytes=0, display=False, partition="block", stats=None):
     """Returns the names of the views this rank produced; with keep_maps=True a dict name -> (depth, confidence)
     of device tensors instead, so the fusion step (fuse.ViewFusion) can start without re-reading the PFM files.
     feature_cache_bytes > 0 keeps the feature pyramids of that many bytes of images resident across views (items must
-    carry "image_keys"); results do not change."""
+    carry "image_keys"); results do not change.  partition: how the views are dealt to the ranks (sharding.shard_views;
+    "block" keeps neighbouring views -- which share source images -- on one rank, so its cache keeps hitting).
+    stats: a dict that receives this rank's view count, cache hits / misses and feature pyramids computed per view."""
     from .dataset import FeatureCache
 
     os.makedirs(output_folder, exist_ok=True)
@@ -361,9 +363,11 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
         model.feature_cache = FeatureCache(feature_cache_bytes, by_content=True)
     done = {} if keep_maps else []
     writer = None
+    pyramids = []
+    hook = model.feature.register_forward_hook(lambda *_: pyramids.append(1)) if stats is not None and hasattr(model, "feature") else None
     try:
         with torch.no_grad():
-            for idx in sharding.shard_views(len(dataset), rank, world_size):
+            for idx in sharding.shard_views(len(dataset), rank, world_size, partition):
                 s = dataset[idx]
                 imgs, keys = _item_views(s, model, device)
                 pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(device)
@@ -390,6 +394,14 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
     finally:
         if writer is not None:
             writer.close()
+        if hook is not None:
+            hook.remove()
+        if stats is not None:
+            cache = getattr(model, "feature_cache", None)
+            n = len(done)
+            stats.update(views=n, partition=partition, cache_hits=cache.hits if cache is not None else 0,
+                         cache_misses=cache.misses if cache is not None else 0,
+                         pyramids_per_view=(len(pyramids) / n) if n else 0.0)
         if feature_cache_bytes > 0:
             model.feature_cache = None
     return done
@@ -430,6 +442,8 @@ def parse_args(argv=None):
     ap.add_argument("--synthetic_items", type=int, default=0, help="run on a synthetic block of this many views instead of --data_folder")
     ap.add_argument("--random_weights", action="store_true", help="run without --loadckpt (seeded random weights; plumbing tests only)")
     ap.add_argument("--feature_cache_gb", type=float, default=8.0, help="HBM kept for feature pyramids of shared images (0 = off)")
+    ap.add_argument("--partition", default="block", choices=list(sharding.POLICIES),
+                    help="views per rank: contiguous blocks (neighbouring views share images: the cache keeps hitting) or round_robin")
     return ap.parse_args(argv)
 
 
@@ -486,9 +500,14 @@ def main(argv=None):
     else:
         synthetic.fill_state_dict_(model.state_dict(), 0)
     model = model.cuda()
+    st = {}
     names = predict_views(model, ds, a.output_folder, rank, world, display=_truthy(a.display),
-                          feature_cache_bytes=int(a.feature_cache_gb * (1 << 30)) if a.synthetic_items <= 0 else 0)
-    print("rank %d/%d wrote %d views" % (rank, world, len(names)))
+                          feature_cache_bytes=int(a.feature_cache_gb * (1 << 30)) if a.synthetic_items <= 0 else 0,
+                          partition=a.partition, stats=st)
+    acc = st.get("cache_hits", 0) + st.get("cache_misses", 0)
+    print("rank %d/%d wrote %d views (%s partition): feature cache %d hits / %d lookups (%.0f %%), %.2f pyramids computed per view"
+          % (rank, world, len(names), st.get("partition"), st.get("cache_hits", 0), acc,
+             100.0 * st.get("cache_hits", 0) / acc if acc else 0.0, st.get("pyramids_per_view", 0.0)))
     return names
 
 

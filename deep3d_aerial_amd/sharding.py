@@ -4,8 +4,13 @@ no collective on the data path.
 The reference runs one GPU (nn.DataParallel at batch 1, predict.py:49,100) and hands depth maps
 to fusion through PFM files (predict.py:179-183 -> fuse/fusion_3d_normal.py:433,448).  A
 reference view (ref image + its sources from viewpair.txt) is an independent work item
-(datasets/cas_normal_eval.py:94-182), so the views of a block are dealt round-robin to the
-ranks and every rank sweeps its own list.  The only exchange step is OPTIONAL: an all-gather of
+(datasets/cas_normal_eval.py:94-182), so the views of a block are partitioned over the ranks and
+every rank sweeps its own list.  The partition is CONTIGUOUS by default (rank r takes views
+[r n / N, (r + 1) n / N)): consecutive reference views of a block share most of their source images
+(viewpair.txt lists neighbours), so a rank's feature cache (dataset.FeatureCache) keeps hitting; dealt
+round-robin, neighbouring views land on different ranks and at N = 8 the cache hits on almost nothing
+(round 3's default; kept as policy="round_robin" for callers whose items are unrelated).
+The only exchange step is OPTIONAL: an all-gather of
 the per-view (depth, confidence) maps so that every rank holds its neighbours' maps for the
 geometric consistency check (fuse/consistency_check_n.py:141-147).  It runs over
 torch.distributed -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
@@ -16,15 +21,42 @@ import torch
 import torch.distributed as dist
 
 
-def shard_views(n_views, rank, world_size):
-    """Indices of the reference views rank `rank` sweeps: i = rank (mod world_size)."""
+POLICIES = ("block", "round_robin")
+
+
+def _check(rank, world_size, policy):
     if not (0 <= rank < world_size):
         raise ValueError("rank %d outside world of %d" % (rank, world_size))
-    return list(range(rank, n_views, world_size))
+    if policy not in POLICIES:
+        raise ValueError("unknown partition %r (one of %s)" % (policy, ", ".join(POLICIES)))
 
 
-def owner_of(view_index, world_size):
-    return view_index % world_size
+def shard_views(n_views, rank, world_size, policy="block"):
+    """Indices of the reference views rank `rank` sweeps, ascending.
+    "block": the contiguous run [rank * n // N, (rank + 1) * n // N) -- sizes differ by at most one;
+    "round_robin": i = rank (mod world_size)."""
+    _check(rank, world_size, policy)
+    if policy == "round_robin":
+        return list(range(rank, n_views, world_size))
+    return list(range(rank * n_views // world_size, (rank + 1) * n_views // world_size))
+
+
+def owner_of(view_index, world_size, n_views=None, policy="block"):
+    """Rank that sweeps view `view_index` (the block partition needs the number of views)."""
+    _check(0, world_size, policy)
+    if policy == "round_robin":
+        return view_index % world_size
+    if n_views is None:
+        raise ValueError("owner_of: the block partition depends on n_views")
+    if not (0 <= view_index < n_views):
+        raise ValueError("view %d outside 0..%d" % (view_index, n_views - 1))
+    # the r with r * n // N <= i < (r + 1) * n // N
+    r = min(world_size - 1, (view_index * world_size + world_size - 1) // max(n_views, 1))
+    while r > 0 and r * n_views // world_size > view_index:
+        r -= 1
+    while (r + 1) * n_views // world_size <= view_index:
+        r += 1
+    return r
 
 
 def init_from_env(backend=None):
@@ -42,7 +74,7 @@ def init_from_env(backend=None):
     return rank, world
 
 
-def all_gather_maps(local_maps, n_views, rank=None, world_size=None):
+def all_gather_maps(local_maps, n_views, rank=None, world_size=None, policy="block"):
     """All-gather the per-view (depth, confidence) maps.
 
     local_maps: tensor [n_local, 2, H, W] holding this rank's views in shard_views() order.
@@ -53,7 +85,7 @@ def all_gather_maps(local_maps, n_views, rank=None, world_size=None):
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    mine = shard_views(n_views, rank, world_size)
+    mine = shard_views(n_views, rank, world_size, policy)
     if local_maps.shape[0] != len(mine):
         raise ValueError("rank %d holds %d maps, expected %d" % (rank, local_maps.shape[0], len(mine)))
     if world_size == 1:
@@ -63,15 +95,15 @@ def all_gather_maps(local_maps, n_views, rank=None, world_size=None):
     padded[: local_maps.shape[0]] = local_maps
     gathered = local_maps.new_empty((world_size * per,) + tuple(local_maps.shape[1:]))
     dist.all_gather_into_tensor(gathered, padded.contiguous())
-    # gathered[r*per + j] is view r + j*world_size
+    # gathered[r*per + j] is the j-th view of rank r's list
     out = local_maps.new_empty((n_views,) + tuple(local_maps.shape[1:]))
     for r in range(world_size):
-        idx = shard_views(n_views, r, world_size)
+        idx = shard_views(n_views, r, world_size, policy)
         out[idx] = gathered[r * per: r * per + len(idx)]
     return out
 
 
-def run_sharded(process_view, n_views, rank=None, world_size=None, gather=False):
+def run_sharded(process_view, n_views, rank=None, world_size=None, gather=False, policy="block"):
     """Sweep this rank's views with `process_view(i) -> tensor [2,H,W]` (depth, confidence).
 
     Returns {view index: tensor} for the local views, or -- with gather=True -- the
@@ -81,7 +113,7 @@ def run_sharded(process_view, n_views, rank=None, world_size=None, gather=False)
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    mine = shard_views(n_views, rank, world_size)
+    mine = shard_views(n_views, rank, world_size, policy)
     results = {i: process_view(i) for i in mine}
     if not gather:
         return results
@@ -89,4 +121,4 @@ def run_sharded(process_view, n_views, rank=None, world_size=None, gather=False)
         local = torch.stack([results[i] for i in mine])
     else:
         raise ValueError("gather=True needs at least one view per rank (n_views >= world_size)")
-    return all_gather_maps(local, n_views, rank, world_size)
+    return all_gather_maps(local, n_views, rank, world_size, policy)

@@ -80,6 +80,32 @@ def test_feature_cache_does_not_change_results(name, tmp_path):
             assert (tmp_path / "plain" / (n + suffix)).read_bytes() == (tmp_path / "cached" / (n + suffix)).read_bytes()
 
 
+def test_block_partition_products_and_cache_statistics(tmp_path):
+    """Row e x N3: the ranks of a world of 4 (run one after the other here) write, between them, exactly the files of the
+    single-rank run, and with contiguous blocks a rank featurises ~1 + (V - 1) / views-per-rank images per view where
+    round-robin featurises all V."""
+    from deep3d_aerial_amd import predict as P
+
+    model = P.build_model("casmvsnet", 64)
+    S.fill_state_dict_(model.state_dict(), 5)
+    model = model.cuda().eval()
+    ds = P.SyntheticStrip(12, 3, 64, 96, 64, seed=11)
+    one = P.predict_views(model, ds, str(tmp_path / "one"), feature_cache_bytes=1 << 30)
+    for part, want in (("block", (3 + 2) / 3.0), ("round_robin", 3.0)):
+        names = []
+        for r in range(4):
+            st = {}
+            names += P.predict_views(model, ds, str(tmp_path / part), rank=r, world_size=4, feature_cache_bytes=1 << 30,
+                                     partition=part, stats=st)
+            assert st["views"] == 3 and st["partition"] == part
+            assert abs(st["pyramids_per_view"] - want) < 1e-9, (part, st)
+            assert st["cache_hits"] + st["cache_misses"] == 9
+        assert sorted(names) == sorted(one)
+        for n in one:
+            for suffix in ("_init.pfm", "_prob.pfm", ".txt"):
+                assert (tmp_path / "one" / (n + suffix)).read_bytes() == (tmp_path / part / (n + suffix)).read_bytes()
+
+
 def test_in_process_launch_writes_products(tmp_path):
     """Row N4: MVS_Inference.run (mvs/mvs_dl.py:39-65) calls the harness in this process; products land in mvs_path."""
     from deep3d_aerial_amd import mvs_dl
