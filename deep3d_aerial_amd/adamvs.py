@@ -157,11 +157,16 @@ class SliceCostRegNetRED(nn.Module):
         with ops.slice_tile_kernels():
             return self._forward(cost, state1, state2)
 
+    @staticmethod
+    def _cell(pre, gru, x, state, stride):
+        """relu(pre(x)) -> gru: one launch in bf16 mode (ops.gru_cell_conv_fused), the separate layers otherwise."""
+        g, c = gru.conv_gates[0], gru.convc[0]
+        fused = ops.gru_cell_conv_fused(x, state, pre.conv.weight, g.weight, g.bias, c.weight, c.bias, stride)
+        return fused if fused is not None else gru(pre(x), state)[0]
+
     def _forward(self, cost, state1, state2):
-        x1 = self.conv1(cost)
-        state1, _ = self.conv_gru1(x1, state1)
-        x2 = self.conv2(state1)
-        state2, _ = self.conv_gru2(x2, state2)
+        state1 = self._cell(self.conv1, self.conv_gru1, cost, state1, 1)
+        state2 = self._cell(self.conv2, self.conv_gru2, state1, state2, 2)
         # relu(upconv1(state2) + state1): skip added before the activation (adamvs.py:423-424)
         up = ops.convtranspose2d_k3s2(state2, self.upconv1.weight, None, self.upconv1.bias, state1,
                                       skip_after_act=False, act=1)

@@ -42,6 +42,7 @@ SWITCHES = {
     "D3D_CONV_NOFOLD": ("", "non-empty: never fold taps into K"),
     "D3D_CONV_FOLD_KB": ("48", "LDS budget (KB) of the tap fold"),
     "D3D_GRU_GATES": ("stream", "GRU gate kernel: 'stream' | 'separate'"),
+    "D3D_GRU_FUSED": ("1", "0: the one-launch conv-GRU cell of bf16 mode off (three tile-kernel launches instead)"),
     "D3D_FEATURE_PRECISION": ("fp32", "feature pyramids: 'fp32' | 'follow' (the regularisers' precision)"),
     "D3D_FEATURE_CONV": ("mfma", "feature pyramids: 'mfma' (own kernels) | 'miopen'"),
     "D3D_FPN_SPLIT": ("1", "0: FPN output levels through the wide tensor"),

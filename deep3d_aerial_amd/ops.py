@@ -1313,6 +1313,14 @@ class fp32_convs:
         return False
 
 
+class bf16_convs(fp32_convs):
+    """Context manager: bf16 matrix-core operands inside (BASELINE config 3's precision), whatever the global precision."""
+
+    def __enter__(self):
+        self.saved = _cfg.state.conv_precision
+        _cfg.state.conv_precision = "bf16"
+
+
 def _use_mfma():
     return _cfg.get("D3D_CONV") != "direct"
 
@@ -1637,6 +1645,36 @@ def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_aft
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "d3d_conv2d_k5s2_zs_bf16x3")
+    return out
+
+
+def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride=1):
+    """relu(conv3x3(cost, stride)) followed by the conv-GRU cell on it, ONE launch (d3d_gru_cell_fused_bf16, csrc/gru_fused.hip;
+    adamvs.py:409-412: conv1 + conv_gru1 at stride 1, conv2 + conv_gru2 at stride 2).  bf16 mode only (the operands are bf16, the
+    state stays fp32): bit-identical to conv2d_zs + gru_cell_fused.  Returns the new state, or None for shapes / modes the
+    kernel does not take (the caller then runs the separate launches)."""
+    if conv_precision() != "bf16" or not _use_mfma() or _cfg.get("D3D_GRU_FUSED") == "0" or cost.dim() != 3:
+        return None
+    CP, HI, WI = cost.shape
+    HID, H, W = h.shape
+    if stride == 1:
+        ok = CP in (8, 16, 32) and HID == 8 and (HI, WI) == (H, W)
+    else:
+        ok = stride == 2 and CP == 8 and HID == 16 and (H, W) == ((HI - 1) // 2 + 1, (WI - 1) // 2 + 1)
+    if not ok or b_gates is None or b_cand is None:
+        return None
+    if tuple(w_pre.shape) != (HID, CP, 3, 3) or tuple(w_gates.shape) != (2 * HID, 2 * HID, 3, 3) or tuple(w_cand.shape) != (HID, 2 * HID, 3, 3):
+        raise ValueError("conv-GRU cell weights do not match C = %d, hidden = %d" % (CP, HID))
+    w1 = derived_weight(w_pre, "z2bf16", _pack_z2_bf16)
+    wg = derived_weight(w_gates, "z2bf16", _pack_z2_bf16)
+    wc = derived_weight(w_cand, "z2bf16", _pack_z2_bf16)
+    out = torch.empty_like(h)
+    rc = _lib.load().d3d_gru_cell_fused_bf16(_chk(cost, "cost", 3), CP, HI, WI, int(stride), _chk(h, "h", 3), HID, H, W,
+                                             ctypes.c_void_p(w1.data_ptr()), ctypes.c_void_p(wg.data_ptr()), _chk(b_gates, "b_gates"),
+                                             ctypes.c_void_p(wc.data_ptr()), _chk(b_cand, "b_cand"), _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_gru_cell_fused_bf16")
     return out
 
 

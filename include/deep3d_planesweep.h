@@ -361,6 +361,18 @@ int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, con
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                        float* out, d3d_stream_t stream);
 
+/* One conv-GRU cell of the slice regularisers in ONE launch (csrc/gru_fused.hip; replaces adamvs.py:409-412 conv1 + conv_gru1 resp.
+ * conv2 + conv_gru2, module.py:5-51 ConvGRUCell, run as three d3d_conv2d_k3*_zs_bf16 launches before):
+ *     x = relu(conv3x3_stride(cost));  r, u = sigmoid(conv3x3(cat(x, h)) + bg);  c = tanh(conv3x3(cat(x, r * h)) + bc);
+ *     hout = u * h + (1 - u) * c
+ * cost [CP,HI,WI], h / hout [HID,H,W] planar fp32, hout != h.  stride 1: HI, WI = H, W, CP = 8 | 16 | 32, HID = 8; stride 2:
+ * H, W = (HI-1)/2+1, (WI-1)/2+1, CP = 8, HID = 16.  w1 / wg / wc: ops._pack_z2_bf16 of the three weights (bf16 matrix-core
+ * operands, fp32 accumulation, the state stays fp32); bg [2 HID], bc [HID].  Bit-identical to the three-launch form.
+ * D3D_ERR_UNSUPPORTED for other channel counts. */
+int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
+                            const void* w1, const void* wg, const float* bg, const void* wc, const float* bc, float* hout,
+                            d3d_stream_t stream);
+
 /* Conv2d(kernel 5, stride 2, padding 2) -- the downsampling layers of the feature trunks (module.py:669, 675; adamvs.py:64, 70 of the reference) --
  * on the stride-2 tile kernel with split operands (fp32 accuracy): in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1]; wpacked:
  * ops._pack_z2_bf16x3 of the weight [Co,Ci,5,5] (K = (k_y,k_x,c_in)); scale / shift / skip / act as d3d_conv2d_k3s2_zs_bf16.

@@ -751,6 +751,50 @@ def test_slice_gru_golden(ops, convpath):
         assert np.abs(host(s2) - g[k + "state2"]).max() <= 1e-4
 
 
+@pytest.mark.parametrize("C,stride,h,w", [(8, 1, 136, 132), (16, 1, 131, 148), (32, 1, 128, 128), (8, 1, 72, 248),
+                                         (8, 2, 272, 264), (8, 2, 135, 249)])
+def test_gru_cell_fused_is_bit_identical_to_the_three_launches(ops, C, stride, h, w):
+    """csrc/gru_fused.hip: relu(conv(cost)) -> conv-GRU cell in one launch (adamvs.py:409-412, module.py:24-51) equals the
+    three tile-kernel launches it replaces BIT FOR BIT (same K order, same packed weights, same epilogue expressions), on
+    tiles that straddle every image border (sizes that are no multiples of the 60 x 8 / 28 x 8 output tiles)."""
+    rng = np.random.default_rng(100 * C + stride)
+    hid = 8 if stride == 1 else 16
+    H, W = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
+    cost = dev(rng.standard_normal((C, h, w)).astype(np.float32))
+    state = dev(rng.standard_normal((hid, H, W)).astype(np.float32))
+    w1 = dev((rng.standard_normal((hid, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32))
+    wg = dev((rng.standard_normal((2 * hid, 2 * hid, 3, 3)) / np.sqrt(18 * hid)).astype(np.float32))
+    wc = dev((rng.standard_normal((hid, 2 * hid, 3, 3)) / np.sqrt(18 * hid)).astype(np.float32))
+    bg, bc = dev(rng.standard_normal(2 * hid).astype(np.float32)), dev(rng.standard_normal(hid).astype(np.float32))
+    with ops.bf16_convs():
+        got = ops.gru_cell_conv_fused(cost, state, w1, wg, bg, wc, bc, stride)
+        assert got is not None
+        if stride == 1 and w % 4 == 0:
+            x = ops.conv2d_zs(cost, w1, None, None, None, 1)
+        elif stride == 2 and W % 4 == 0:
+            x = ops.conv2d_s2_zs(cost, w1, None, None, None, 1)
+        else:
+            x = None   # (widths the separate tile kernels do not take: compared with a float64 evaluation below only)
+        if x is not None:
+            gates = ops.conv2d_zs(x, wg, None, bg, state, 2, x2=state, ep_split=hid)
+            want = ops.conv2d_zs(x, wc, None, bc, state, 3, x2=gates[:hid].contiguous(), aux1=gates[hid:].contiguous())
+            assert x is not None and gates is not None and want is not None
+            assert torch.equal(got, want)
+    # and against the cell evaluated in float64 on bf16-rounded operands (what the matrix cores multiply)
+    import torch.nn.functional as F
+
+    bf = lambda t: t.to(torch.bfloat16).double()
+    x64 = F.relu(F.conv2d(bf(cost)[None], bf(w1), stride=stride, padding=1))
+    xb = bf(x64.float())
+    g64 = torch.sigmoid(F.conv2d(torch.cat([xb, bf(state)[None]], 1), bf(wg), bg.double(), padding=1))
+    rh = bf((g64[:, :hid] * state.double()[None]).float())
+    c64 = torch.tanh(F.conv2d(torch.cat([xb, rh], 1), bf(wc), bc.double(), padding=1))
+    u = g64[:, hid:]
+    ref = (u * state.double()[None] + (1 - u) * c64)[0]
+    assert float((got.double() - ref).abs().max()) <= 2e-3   # (a bf16 rounding of x or r*h flipping across the fp32 / fp64 sums)
+    assert float((got.double() - ref).abs().mean()) <= 2e-5
+
+
 def test_slice_red_gru2_golden(ops, convpath):
     """msrednet.py:337-370 slice regulariser (GroupNorm conv-GRUs) vs the reference's rollouts."""
     from deep3d_aerial_amd.module import ConvGRUCell2
