@@ -752,7 +752,7 @@ def test_slice_gru_golden(ops, convpath):
 
 
 @pytest.mark.parametrize("C,stride,h,w", [(8, 1, 136, 132), (16, 1, 131, 148), (32, 1, 128, 128), (8, 1, 72, 248),
-                                         (8, 2, 272, 264), (8, 2, 135, 249)])
+                                         (8, 2, 272, 264), (8, 2, 135, 248)])
 def test_gru_cell_fused_is_bit_identical_to_the_three_launches(ops, C, stride, h, w):
     """csrc/gru_fused.hip: relu(conv(cost)) -> conv-GRU cell in one launch (adamvs.py:409-412, module.py:24-51) equals the
     three tile-kernel launches it replaces BIT FOR BIT (same K order, same packed weights, same epilogue expressions), on
@@ -769,6 +769,8 @@ def test_gru_cell_fused_is_bit_identical_to_the_three_launches(ops, C, stride, h
     with ops.bf16_convs():
         got = ops.gru_cell_conv_fused(cost, state, w1, wg, bg, wc, bc, stride)
         assert got is not None
+        if stride == 1:   # widths that are no multiple of 4 are left to the separate launches (16-byte epilogue accesses)
+            assert ops.gru_cell_conv_fused(cost[:, :, :w - 2].contiguous(), state[:, :, :w - 2].contiguous(), w1, wg, bg, wc, bc, 1) is None
         if stride == 1 and w % 4 == 0:
             x = ops.conv2d_zs(cost, w1, None, None, None, 1)
         elif stride == 2 and W % 4 == 0:
