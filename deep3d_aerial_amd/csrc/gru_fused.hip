@@ -19,7 +19,8 @@
 //   Every phase is the implicit GEMM of conv2d_zs.hip (M = 16 consecutive pixels of a region row, N = 16 output channels,
 //   K = (k_y, k_x, c_in) in blocks of 32 = v_mfma_f32_16x16x32_bf16; an A operand is one ds_read_b128 of 8 channels), on the
 //   SAME K order and the same packed weights (ops._pack_z2_bf16), with the same epilogue expressions -- so h' is bit-identical to
-//   the three-launch form (tests/test_parity_gpu.py::test_gru_cell_fused_*).  All phases run on the 16 MG-column grid of the
+//   the three-launch form (tests/test_parity_gpu.py::test_gru_cell_fused_*; v_exp / v_rcp forms of sigmoid and tanh were
+//   measured -- 411 -> 405 us at stage 3 -- and dropped: a cell is a chain of latencies, not an instruction count).  All phases run on the 16 MG-column grid of the
 //   region: the outermost columns of P2 / P3 read one cell beyond the region (row pitch 16 MG + 2 cells) and their results are
 //   dropped, which keeps a lane's four pixels the same in P2 and P3 (u never leaves its registers).
 //
@@ -42,9 +43,9 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #ifndef D3D_GRU_X
 #define D3D_GRU_X 0
 #endif
-#ifndef D3D_GRU_PREFETCH
-#define D3D_GRU_PREFETCH 0   // 1: the next tile's patches are requested a phase ahead (measured: the compiler spills them at 128 registers)
-#endif
+// The next tile's patches are requested a phase ahead where a workgroup owns its CU (LDS > 80 KB: 256 registers, +3 .. 7 %);
+// the 8-channel stride-1 instance shares the CU with a second workgroup at 128 registers, where the prefetched patches spill
+// (593 against 411 us at stage 3) -- there the other workgroup is what overlaps the loads.  -DD3D_GRU_PREFETCH=0|1 forces it.
 #ifndef D3D_GRU_WAVES2
 #define D3D_GRU_WAVES2 4   // waves per SIMD the small-LDS instances are compiled for (4: two workgroups per CU, 128 registers)
 #endif
@@ -98,6 +99,11 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
     using G = GruGeom<CP, HID, S, MG, TY>;
     constexpr int RX = G::RX, RY = G::RY, PITCH = G::PITCH, XC = G::XC, REG = G::REG, CS1 = G::CS1, SPX = G::SPX, SPY = G::SPY;
     constexpr int NEVEN = G::NEVEN, NKB1 = G::NKB1, NKBG = G::NKBG, NTNG = G::NTNG;
+#ifdef D3D_GRU_PREFETCH
+    constexpr bool PREFETCH = D3D_GRU_PREFETCH != 0;
+#else
+    constexpr bool PREFETCH = G::LDS > 80 * 1024;
+#endif
     static_assert(HID == 8 || HID == 16, "hidden state of 8 or 16 channels");
     static_assert((TY * MG) % GW == 0, "every wave keeps the same number of candidate tasks");
     static_assert(2 * MG <= GW, "one halo-row task per wave at most");
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
     const int hid_ = min(wave, 2 * MG - 1);   // halo task of the gates (waves 0 .. 2 MG - 1): rows 1 and TY + 2
     const int hrow = hid_ < MG ? 1 : RY - 2, hgrp = hid_ % MG;
 
-    if (D3D_GRU_PREFETCH) {
+    if (PREFETCH) {
         issue_cost(t0);
         issue_state(t0);
         commit_cost();
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
         asm volatile("" : "+v"(tid), "+v"(m), "+v"(kgroup));
         const int ry0 = ty * TY - 2;
         const bool more = ty + 1 < t1;
-        if (D3D_GRU_PREFETCH) {
+        if (PREFETCH) {
             if (more) issue_cost(ty + 1);   // in flight during P1 (committed behind it: nothing else reads `sim`)
         } else {
             issue_cost(ty);
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
             }
         }
         __syncthreads();
-        if (D3D_GRU_PREFETCH && more) {
+        if (PREFETCH && more) {
             commit_cost();
             issue_state(ty + 1);        // in flight during P2 (committed behind it: the candidate reads x and r*h only)
         }
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
             }
         }
         __syncthreads();
-        if (D3D_GRU_PREFETCH && more) commit_state();
+        if (PREFETCH && more) commit_state();
 
         // ---- P3: candidate and state update on the core tasks ---------------------------------------------------------------
         {

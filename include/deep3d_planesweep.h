@@ -368,6 +368,7 @@ int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, con
  * cost [CP,HI,WI], h / hout [HID,H,W] planar fp32, hout != h.  stride 1: HI, WI = H, W, CP = 8 | 16 | 32, HID = 8; stride 2:
  * H, W = (HI-1)/2+1, (WI-1)/2+1, CP = 8, HID = 16.  w1 / wg / wc: ops._pack_z2_bf16 of the three weights (bf16 matrix-core
  * operands, fp32 accumulation, the state stays fp32); bg [2 HID], bc [HID].  Bit-identical to the three-launch form.
+ * W, WI multiples of 4, 16-byte aligned tensors.
  * D3D_ERR_UNSUPPORTED for other channel counts. */
 int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
                             const void* w1, const void* wg, const float* bg, const void* wc, const float* bc, float* hout,

@@ -756,7 +756,7 @@ def test_slice_gru_golden(ops, convpath):
 def test_gru_cell_fused_is_bit_identical_to_the_three_launches(ops, C, stride, h, w):
     """csrc/gru_fused.hip: relu(conv(cost)) -> conv-GRU cell in one launch (adamvs.py:409-412, module.py:24-51) equals the
     three tile-kernel launches it replaces BIT FOR BIT (same K order, same packed weights, same epilogue expressions), on
-    tiles that straddle every image border (sizes that are no multiples of the 60 x 8 / 28 x 8 output tiles)."""
+    tiles that straddle every image border (sizes that are no multiples of the 56 x 8 / 56 x 4 output tiles)."""
     rng = np.random.default_rng(100 * C + stride)
     hid = 8 if stride == 1 else 16
     H, W = (h, w) if stride == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)
