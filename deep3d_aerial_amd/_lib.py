@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("D3D_LIBRARY") or os.path.join(CSRC, "libdeep3d_planesweep.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -29,6 +29,8 @@ SIGNATURES = {
     "d3d_last_error": [],
     "d3d_compose_projections": [_vp, _i, _vp, _vp],
     "d3d_debug_force_path": [_i],
+    "d3d_debug_dispatch_counts": [_vp, _i],
+    "d3d_build_flags": [],
     "d3d_compose_projections_f64": [_vp, _i, _vp, _vp],
     "d3d_homo_warp_f64coord": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],  # returns size_t
@@ -141,7 +143,7 @@ def load():
         except AttributeError as e:
             raise LibraryMissing("symbol %s missing from %s" % (name, SO_PATH)) from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name == "d3d_last_error" else
+        fn.restype = (ctypes.c_char_p if name in ("d3d_last_error", "d3d_build_flags") else
                       ctypes.c_size_t if name in ("d3d_sweep_workspace_bytes", "d3d_fusion_points_scratch_bytes") else ctypes.c_int)
     if lib.d3d_version() != ABI_VERSION:
         raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))

@@ -433,6 +433,24 @@ static int launch_gru(const GruParams& p, hipStream_t stream) {
 
 }  // namespace
 
+// Non-default compile-time knobs of this translation unit (d3d_build_flags): empty for the production build.
+const char* gru_build_flags() {
+    return ""
+#if D3D_GRU_X
+           " D3D_GRU_X"
+#endif
+#ifdef D3D_GRU_PREFETCH
+           " D3D_GRU_PREFETCH"
+#endif
+#if D3D_GRU_WAVES2 != 4
+           " D3D_GRU_WAVES2"
+#endif
+#ifdef D3D_GRU_TY_C8
+           " D3D_GRU_TY_C8"
+#endif
+        ;
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -460,10 +478,11 @@ extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI
     p.wc = reinterpret_cast<const u4*>(wc); p.bg = bg; p.bc = bc; p.H = H; p.W = W; p.HI = HI; p.WI = WI;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1 && HID == 8) {
-#ifndef D3D_GRU_TY_C8
-#define D3D_GRU_TY_C8 8
-#endif
+#ifdef D3D_GRU_TY_C8
         if (CP == 8) return launch_gru<8, 8, 1, 4, D3D_GRU_TY_C8>(p, st);
+#else
+        if (CP == 8) return launch_gru<8, 8, 1, 4, 8>(p, st);
+#endif
         if (CP == 16) return launch_gru<16, 8, 1, 4, 8>(p, st);
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }

@@ -63,6 +63,10 @@ int launch_tiled(int mode, const struct SweepParams& p, hipStream_t stream);
 // D3D_ERR_UNSUPPORTED outside its shapes
 int launch_window(int mode, const struct SweepParams& p, hipStream_t stream, bool forced);
 size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes);
+// non-default compile-time knobs of the translation units that have any (d3d_build_flags)
+const char* tiled_build_flags();
+const char* window_build_flags();
+const char* gru_build_flags();
 
 }  // namespace d3d
 
@@ -335,23 +339,31 @@ static int check_dims(int C, int D, int h, int w) {
 static std::atomic<int> g_force_path{0};   // 0 dispatcher's choice | 1 direct-gather kernel | 2 LDS-ring kernel | 3 window kernel
 static int forced_path() { return g_force_path.load(std::memory_order_relaxed); }
 
+// Which kernel family served the sweep calls so far (d3d_debug_dispatch_counts): [1] direct gather, [2] LDS rings, [3] windows.
+// The model-level parity tests read it to prove that the production kernels -- not a fallback -- produced what they compare.
+static std::atomic<unsigned long long> g_dispatched[4];
+static int counted(int family, int rc) {
+    if (rc == D3D_OK) g_dispatched[family].fetch_add(1, std::memory_order_relaxed);
+    return rc;
+}
+
 static int sweep_dispatch(int mode, const SweepParams& p, hipStream_t stream) {
     const int force = forced_path();
     if (force == 0 || force == 3) {
-        int rc = launch_window(mode, p, stream, force == 3);
+        int rc = counted(3, launch_window(mode, p, stream, force == 3));
         if (rc != D3D_ERR_UNSUPPORTED || force == 3) return rc;
     }
     if (force != 1) {
-        int rc = launch_tiled(mode, p, stream);
+        int rc = counted(2, launch_tiled(mode, p, stream));
         if (rc != D3D_ERR_UNSUPPORTED) return rc;
         if (force == 2) return rc;
     }
-    if (p.elem_bytes == 2) return launch_direct<MODE_VARIANCE, __half>(p, stream);
+    if (p.elem_bytes == 2) return counted(1, launch_direct<MODE_VARIANCE, __half>(p, stream));
     switch (mode) {
-        case MODE_WARP: return launch_direct<MODE_WARP>(p, stream);
-        case MODE_VARIANCE: return launch_direct<MODE_VARIANCE>(p, stream);
-        case MODE_WEIGHTED: return launch_direct<MODE_WEIGHTED>(p, stream);
-        case MODE_PAIR: return launch_direct<MODE_PAIR>(p, stream);
+        case MODE_WARP: return counted(1, launch_direct<MODE_WARP>(p, stream));
+        case MODE_VARIANCE: return counted(1, launch_direct<MODE_VARIANCE>(p, stream));
+        case MODE_WEIGHTED: return counted(1, launch_direct<MODE_WEIGHTED>(p, stream));
+        case MODE_PAIR: return counted(1, launch_direct<MODE_PAIR>(p, stream));
     }
     set_error("internal: bad mode %d", mode);
     return D3D_ERR_INVALID_ARG;
@@ -373,6 +385,26 @@ int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_
     hipLaunchKernelGGL(compose_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, proj44, n_views, out34);
     D3D_LAUNCH_CHECK("compose_kernel launch");
     return D3D_OK;
+}
+
+int d3d_debug_dispatch_counts(unsigned long long* out4, int reset) {
+    D3D_REQUIRE(out4, "null pointer");
+    for (int i = 0; i < 4; ++i) out4[i] = reset ? g_dispatched[i].exchange(0, std::memory_order_relaxed) : g_dispatched[i].load(std::memory_order_relaxed);
+    return D3D_OK;
+}
+
+const char* d3d_build_flags(void) {
+    static char buf[512];
+    static std::atomic<int> done{0};
+    if (!done.load(std::memory_order_acquire)) {
+        char tmp[512];
+        snprintf(tmp, sizeof(tmp), "%s%s%s", tiled_build_flags(), window_build_flags(), gru_build_flags());
+        const char* s = tmp;
+        while (*s == ' ') ++s;
+        snprintf(buf, sizeof(buf), "%s", s);   // (idempotent: concurrent first calls write the same bytes)
+        done.store(1, std::memory_order_release);
+    }
+    return buf;
 }
 
 int d3d_debug_force_path(int path) {
@@ -474,10 +506,10 @@ static int variance_volume_cl_any(int layout, const float* const* feats, const f
         return D3D_ERR_UNSUPPORTED;
     }
     if (forced_path() != 2) {
-        rc = launch_window(MODE_VARIANCE, p, (hipStream_t)stream, forced_path() == 3);
+        rc = counted(3, launch_window(MODE_VARIANCE, p, (hipStream_t)stream, forced_path() == 3));
         if (rc != D3D_ERR_UNSUPPORTED || forced_path() == 3) return rc;
     }
-    return launch_tiled(MODE_VARIANCE, p, (hipStream_t)stream);
+    return counted(2, launch_tiled(MODE_VARIANCE, p, (hipStream_t)stream));
 }
 
 int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,

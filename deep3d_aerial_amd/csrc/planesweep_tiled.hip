@@ -254,11 +254,7 @@ __device__ __forceinline__ TapL geo_ring(const Ray& r, float tx, float ty, float
 __device__ __forceinline__ void store_sbase_h(unsigned long long sb, unsigned byte_off, float v) {
     const _Float16 hv = (_Float16)v;   // RNE
     const unsigned bits = __builtin_bit_cast(unsigned short, hv);
-#ifdef D3D_NOSTORE
-    asm volatile("" : : "v"(byte_off), "v"(bits), "s"(sb));
-#else
     asm volatile("global_store_short %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
-#endif
 }
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // fp32 fma whose first factor is the LOW / HIGH fp16 half of a 32-bit word (v_fma_mix_f32): the fp16 tap is widened
@@ -810,9 +806,6 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
     // ALL waves for the initial window, which nothing can overlap (one workgroup per CU): the compute waves
     // would only wait for it.
     auto stage = [&](int k, int sw, int snw) {
-#ifdef D3D_NOSTAGE  // timing experiment build: only the first window is staged (results are wrong)
-        if (k > 0) return;
-#endif
         const int rb = rfl(ldsi[L::SST + k]), re = rfl(ldsi[L::SST + k + 1]);
         const int Tn = rfl(ldsi[L::STOT + k]);
         const int nitems = (Tn + 63) >> 6;
@@ -888,9 +881,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             for (int k = 0; k < nsteps; ++k) {
                 long long tb = 0;
                 if (ltiming) tb = clock64();
-#ifndef D3D_X_NOBAR   // timing experiment (results wrong): no step barriers at all
                 __syncthreads();
-#endif
                 if (ltiming) lt_bar += clock64() - tb;
                 if (k + 1 < nsteps) stage(k + 1, lw, NLOADW);
             }
@@ -955,16 +946,11 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 ob += cl_step;   // the next 8 channels: the next 16 bytes of the cell, or the next group plane (CL8)
             }
         } else {
-#ifdef D3D_X_STORE4   // timing experiment (layout wrong): the quad leaves as ONE 16-byte store per lane instead of four 4-byte ones
-            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(pixb * 4u), "v"(o), "s"(ob));
-            ob += 4 * cstride_b;
-#else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 store_sbase(ob, pixb, o[k]);
                 ob += cstride_b;
             }
-#endif
         }
     };
     auto accumulate = [&](f4& s, f4& qq, float& pair_acc, const f4& val, int q, int i) {
@@ -1165,11 +1151,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 TapL t[NSRC];
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
-#ifdef D3D_X_NOGEO   // timing experiment (results wrong): no projection / weights / addresses
-                    t[i].nw = dv; t[i].ne = dv * 0.5f; t[i].sw = dv * 0.25f; t[i].se = 1.0f - dv; t[i].a0 = RV[i].base; t[i].a1 = RV[i].base + 80;
-#else
                     t[i] = geo_ring<STRIDE>(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, kx[i], ky[i], RV[i]);
-#endif
                 }
                 // Units u = (quad q, view i) in q-major order; the four taps of unit u+1 are requested
                 // before unit u is blended, so LDS latency overlaps the 24 VALU ops of a unit.
@@ -1178,12 +1160,6 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                 f4 tp[PD + 1][4];
                 auto request = [&](int u, f4 (&dst)[4]) {
                     const int q2 = u / NSRC, i2 = u % NSRC;
-#ifdef D3D_X_NOLDS   // timing experiment (results wrong): no tap reads (the reference features stand in for the taps: no
-                     // instruction replaces the reads), the arithmetic and everything else kept
-                    asm volatile("" : : "v"(t[i2].a0), "v"(t[i2].a1));
-                    dst[0] = r[(q2 + 0) % Q]; dst[1] = r[(q2 + 1) % Q]; dst[2] = r[(q2 + 2) % Q]; dst[3] = r[(q2 + 3) % Q];
-                    return;
-#endif
                     dst[0] = lds_read4_abs(t[i2].a0 + q2 * 16);
                     dst[1] = lds_read4_abs(t[i2].a0 + q2 * 16 + STRIDE * 4);
                     dst[2] = lds_read4_abs(t[i2].a1 + q2 * 16);
@@ -1205,12 +1181,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
                     // LDS returns in order: touching the last-requested tap first makes the compiler emit ONE
                     // s_waitcnt for the unit instead of one per tap
                     asm volatile("" : "+v"(c[3]));
-#ifdef D3D_X_NOBLEND   // timing experiment (results wrong): the taps are read and waited for, but not blended
-                    asm volatile("" : : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
-                    f4 val = c[0];
-#else
                     f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
-#endif
                     accumulate(s, qq, pair_acc, val, q, i);
                     if (i == NSRC - 1 && MODE != MODE_PAIR) finalize_store(s, qq, ob, q);
                 }
@@ -1294,9 +1265,7 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
             if (timing) ta = clock64();
             long long tw0 = 0;
             if (wtiming) tw0 = clock64();
-#ifndef D3D_X_NOBAR
             __syncthreads();  // barrier k: rings hold window(k)
-#endif
             if (wtiming && k > 0) t_ww += clock64() - tw0;
             if (timing) { t_mark = clock64(); t_w += t_mark - ta; if (k == 0) t_w0 = t_mark - ta; }
         }
@@ -1540,6 +1509,56 @@ template <int NSRC>
 static int launch_f16(const SweepParams& p, hipStream_t stream) {
     if (p.C % 16 != 0) return D3D_ERR_UNSUPPORTED;
     return launch_one<MODE_VARIANCE, NSRC, 16, __half>(p, stream);
+}
+
+// Non-default compile-time knobs of this translation unit (d3d_build_flags): empty for the production build.  The
+// timing-only experiments of rounds 1-3 (no stores / no staging / no taps / no blend / no barriers: results wrong by
+// construction) are gone from the source; their numbers live in profiles/r03_ab_variants.txt.
+const char* tiled_build_flags() {
+    return ""
+#ifdef D3D_EXPERIMENTS
+           " D3D_EXPERIMENTS"
+#endif
+#ifdef D3D_DEV_ONLY_HEADLINE
+           " D3D_DEV_ONLY_HEADLINE"
+#endif
+#if D3D_NSUB != 4
+           " D3D_NSUB"
+#endif
+#if D3D_NLOADW != 4
+           " D3D_NLOADW"
+#endif
+#if D3D_LDS_PIPE != 1
+           " D3D_LDS_PIPE"
+#endif
+#if D3D_GRAB
+           " D3D_GRAB"
+#endif
+#if D3D_FREERUN
+           " D3D_FREERUN"
+#endif
+#if D3D_DECOUPLE
+           " D3D_DECOUPLE"
+#endif
+#if STAGE0_ALL != 1
+           " STAGE0_ALL"
+#endif
+#if D3D_SHALLOW_PLANES != 16
+           " D3D_SHALLOW_PLANES"
+#endif
+#if D3D_SHALLOW_CG16
+           " D3D_SHALLOW_CG16"
+#endif
+#if D3D_CL_MIN_PLANES != 96
+           " D3D_CL_MIN_PLANES"
+#endif
+#ifdef D3D_YOUNG_PRIO
+           " D3D_YOUNG_PRIO"
+#endif
+#ifdef D3D_RV_VGPR
+           " D3D_RV_VGPR"
+#endif
+        ;
 }
 
 int launch_tiled(int mode, const SweepParams& p, hipStream_t stream) {

@@ -782,4 +782,25 @@ int launch_window(int mode, const SweepParams& p, hipStream_t stream, bool force
     return p.n_src <= 2 ? launch_window_ch<MODE_WEIGHTED, 2>(p, stream) : launch_window_ch<MODE_WEIGHTED, 4>(p, stream);
 }
 
+// Non-default compile-time knobs of this translation unit (d3d_build_flags): empty for the production build.
+const char* window_build_flags() {
+    return ""
+#ifdef D3D_EXPERIMENTS
+           " D3D_EXPERIMENTS(window)"
+#endif
+#if D3D_WINDOW_WG3
+           " D3D_WINDOW_WG3"
+#endif
+#ifdef D3D_WINDOW_CG16
+           " D3D_WINDOW_CG16"
+#endif
+#if D3D_WINDOW_DSEG != 32
+           " D3D_WINDOW_DSEG"
+#endif
+#ifdef D3D_CL_PARTIAL_DEFAULT_POLICY
+           " D3D_CL_PARTIAL_DEFAULT_POLICY"
+#endif
+        ;
+}
+
 }  // namespace d3d

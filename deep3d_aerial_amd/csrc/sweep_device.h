@@ -97,13 +97,9 @@ __device__ __forceinline__ unsigned long long uniform64(const void* ptr) {  // f
 __device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte_off, float v) {
     // no "memory" clobber: nothing in the kernel reads the output, and a clobber would stop the
     // scheduler from hoisting the next unit's LDS reads above these stores
-#ifdef D3D_NOSTORE  // timing experiment build: keep the value alive, skip the store
-    asm volatile("" : : "v"(byte_off), "v"(v), "s"(sb));
-#else
     // "nt": the cost volume is write-once streaming data; keep it from evicting the source windows
     // (re-read by neighbouring workgroups) out of L2 / Infinity Cache
     asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(byte_off), "v"(v), "s"(sb));
-#endif
 }
 
 // channel-last bf16 output: four consecutive channels of the lane's voxel, RNE, as two dwords ...
@@ -123,14 +119,10 @@ template <bool PARTIAL = false>
 __device__ __forceinline__ void store_sbase_bf16x8(unsigned long long sb, unsigned byte_off, unsigned long long lo, unsigned long long hi) {
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     const u4v bits = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-#ifdef D3D_NOSTORE
-    asm volatile("" : : "v"(byte_off), "v"(bits), "s"(sb));
-#else
     // (a store of more than 8 bytes reads its data registers late: the next VALU write of one of them needs wait states, and
     //  the compiler's hazard recognizer does not see inside the string -- without the s_nop some lanes stored garbage)
     if constexpr (PARTIAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
     else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
-#endif
 }
 }  // namespace
 }  // namespace d3d

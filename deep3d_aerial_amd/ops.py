@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the current HIP stream; all 
 happens in libdeep3d_planesweep.so.  Tensors must be fp32, contiguous and on the GPU --
 anything else raises (no CPU path exists).  Shapes are unbatched, as in the header.
 """
+import collections
 import ctypes
 import os
 
@@ -41,6 +42,19 @@ def _stream():
     if _raw_stream is not None and _raw_device is not None:
         return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Which kernels served the calls so far: name -> count.  The model-level parity tests clear it, run a forward and assert that
+# the production kernels (tile convolutions, fused conv-GRU cell, channel-last volumes, window / ring sweeps) were the ones
+# dispatched -- not a fallback that happens to give the same numbers.
+dispatch_counts = collections.Counter()
+
+
+def sweep_dispatch_counts(reset=False):
+    """{'direct': n, 'tiled': n, 'window': n}: sweep calls served by each kernel family (the C dispatcher's own counters)."""
+    buf = (ctypes.c_ulonglong * 4)()
+    _lib.check(_lib.load().d3d_debug_dispatch_counts(buf, int(bool(reset))), "d3d_debug_dispatch_counts")
+    return {"direct": int(buf[1]), "tiled": int(buf[2]), "window": int(buf[3])}
 
 
 def _chk(t, name, ndim=None):
@@ -214,7 +228,9 @@ def variance_volume_cl(feats, proj34, depth, layout="cl"):
                                         ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, name)
+            dispatch_counts["variance_" + layout] += 1
             return out
+    dispatch_counts["variance_cl_fallback"] += 1
     y = to_cl(variance_volume(feats, proj34, depth))
     return cl_to_cl8(y) if layout == "cl8" else y
 
@@ -679,6 +695,7 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
                                                   _opt(shift, "shift"), sp, int(relu), Ci, D, H, W, optr, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_c1_cl_bf16")
+            dispatch_counts["conv3d_cl"] += 1
             return out
     if stride == 1:
         rc = _lib.load().d3d_conv3d_k3_cl_bf16(xp, fmt, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
@@ -688,7 +705,9 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
                                                  D, H, W, optr, _stream())
     if rc != _lib.ERR_UNSUPPORTED:
         _lib.check(rc, "d3d_conv3d_k3_cl_bf16" if stride == 1 else "d3d_conv3d_k3s2_cl_bf16")
+        dispatch_counts["conv3d_cl8_in" if cl8 else "conv3d_cl"] += 1
         return out
+    dispatch_counts["conv3d_cl_fallback"] += 1
     saved = _cfg.state.conv_precision
     _cfg.state.conv_precision = "bf16"
     try:
@@ -717,7 +736,9 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
                                                           2 if fold else 1, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_convtranspose3d_k3s2_cl_bf16")
+            dispatch_counts["convtranspose3d_cl"] += 1
             return out
+    dispatch_counts["conv3d_cl_fallback"] += 1
     saved = _cfg.state.conv_precision
     _cfg.state.conv_precision = "bf16"
     try:
@@ -975,6 +996,7 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, name)
+    dispatch_counts["conv2d_tile"] += 1
     return out
 
 
@@ -1084,6 +1106,7 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "d3d_convtranspose2d_k3s2_zs")
+    dispatch_counts["convtranspose2d_tile"] += 1
     return out
 
 
@@ -1675,6 +1698,7 @@ def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     _lib.check(rc, "d3d_gru_cell_fused_bf16")
+    dispatch_counts["gru_cell_fused"] += 1
     return out
 
 

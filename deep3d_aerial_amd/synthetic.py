@@ -60,6 +60,23 @@ def make_scene(n_views, h, w, num_planes, sweep_px=None, depth_min=400.0, depth_
     return np.stack(projs).astype(np.float32), np.array([depth_min, depth_max], np.float32)
 
 
+def model_inputs(V, H, W, num_depth, seed):
+    """Seeded inputs of a whole Infer_* forward: imgs [1,V,3,H,W], proj_matrices {stageN: [1,V,4,4]}, depth_values [1,2].
+    The model fixtures (tests/golden/make_golden.py) are the reference's outputs on exactly these; the large fixtures
+    store only the outputs and the tests regenerate the inputs from (V, H, W, num_depth, seed)."""
+    rng = np.random.default_rng(seed)
+    imgs = rng.standard_normal((1, V, 3, H, W), dtype=np.float32)
+    # smooth a little so features are not pure noise
+    imgs = (imgs + np.roll(imgs, 1, -1) + np.roll(imgs, 1, -2)) / 1.7
+    proj_full, dv = make_scene(V, H, W, num_depth, sweep_px=24.0, seed=seed, yaw_deg=2.0)
+    pm = {}
+    for name, sc in (("stage1", 0.25), ("stage2", 0.5), ("stage3", 1.0)):
+        p = proj_full.copy()
+        p[:, :2, :] = proj_full[:, :2, :] * np.float32(sc)
+        pm[name] = p[None]
+    return imgs.astype(np.float32), pm, dv[None]
+
+
 def uniform_depths(depth_values, num_planes):
     """linspace(min, max, D) as float32 -- the stage-1 hypothesis set (module.py:637-642)."""
     lo, hi = np.float32(depth_values[0]), np.float32(depth_values[1])

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 2
+#define D3D_ABI_VERSION 3
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -81,6 +81,20 @@ int d3d_compose_projections(const float* proj44, int n_views, float* out34, d3d_
  * all of them.  Not for production callers.
  */
 int d3d_debug_force_path(int path);
+
+/*
+ * Test hook, process-wide: out4[1] / out4[2] / out4[3] = sweep calls (homo_warp, variance, weighted, pair) served so far by the
+ * direct-gather / LDS-ring / window kernel; reset != 0 clears the counters.  The model-level parity tests use it to prove that
+ * the production kernels, not a fallback, produced what they compare with the reference's outputs.
+ */
+int d3d_debug_dispatch_counts(unsigned long long* out4, int reset);
+
+/*
+ * Compile-time experiment knobs this library was built with that differ from the production defaults, as a space-separated
+ * list ("" for the production build: tests/test_abi.py asserts that).  Several -D switches of the kernels change block
+ * shapes or select measured-and-dropped variants; one of them set by accident in the Makefile must not ship silently.
+ */
+const char* d3d_build_flags(void);
 
 /*
  * Scratch bytes the plane-sweep entry points below (d3d_homo_warp, d3d_variance_volume[_f16],

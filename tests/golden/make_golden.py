@@ -359,17 +359,7 @@ def gen_pairnet():
 
 
 def model_inputs(V, H, W, num_depth, seed):
-    rng = np.random.default_rng(seed)
-    imgs = rng.standard_normal((1, V, 3, H, W), dtype=np.float32)
-    # smooth a little so features are not pure noise
-    imgs = (imgs + np.roll(imgs, 1, -1) + np.roll(imgs, 1, -2)) / 1.7
-    proj_full, dv = S.make_scene(V, H, W, num_depth, sweep_px=24.0, seed=seed, yaw_deg=2.0)
-    pm = {}
-    for name, sc in (("stage1", 0.25), ("stage2", 0.5), ("stage3", 1.0)):
-        p = proj_full.copy()
-        p[:, :2, :] = proj_full[:, :2, :] * np.float32(sc)
-        pm[name] = p[None]
-    return imgs.astype(np.float32), pm, dv[None]
+    return S.model_inputs(V, H, W, num_depth, seed)   # (lives in the package: the large-fixture tests regenerate inputs from the seed)
 
 
 PEAKED_GAIN = {"casmvsnet": 20.0, "adamvs": 20.0, "msrednet": 5.0}   # (the slice families regress with exp() and no
@@ -431,6 +421,36 @@ def gen_models(only=None, peaked=False):
         save(tag, **out)
 
 
+def gen_models_large():
+    """Model fixtures at 256 x 384, V = 5, num_depth = 384 -- a size at which the PRODUCTION kernels are the ones selected
+    (stage-3 maps of 98 304 pixels: the 2-D tile kernels, the fused conv-GRU cell, the window sweep, the CL8 volume), flat and
+    peaked.  Only the reference's OUTPUTS are stored; the tests regenerate the inputs with synthetic.model_inputs."""
+    H, W, V, nd = 256, 384, 5, 384
+    for tag, ctor, seed in [("casmvsnet", lambda: RC.Infer_CascadeMVSNet(num_depth=nd), 7202),
+                            ("adamvs", lambda: RA.Infer_AdaMVSNet(num_depth=nd), 7204),
+                            ("msrednet", lambda: RR.Infer_CascadeREDNet(num_depth=nd), 7206)]:
+        for peaked in (False, True):
+            net = ctor().eval()
+            S.fill_state_dict_(net.state_dict(), seed)
+            # (the slice families regress with exp() and no max-subtraction, SURVEY.md F10: at this size the small fixtures' gain of
+            #  20 overflows AdaMVS's exp-sum)
+            gain = {"casmvsnet": 20.0, "adamvs": 8.0, "msrednet": 4.0}[tag] if peaked else 1.0
+            if peaked:
+                assert S.sharpen_state_dict_(net.state_dict(), gain) > 0
+            imgs, pm, dv = model_inputs(V, H, W, nd, seed)
+            with torch.no_grad():
+                o = net(T(imgs), {k: T(v) for k, v in pm.items()}, T(dv))
+            assert np.isfinite(o["depth"].numpy()).all()
+            out = {"seed": np.array(seed), "num_depth": np.array(nd), "V": np.array(V), "H": np.array(H), "W": np.array(W),
+                   "logit_gain": np.array(gain), "imgs_checksum": np.array(float(np.abs(imgs.astype(np.float64)).sum()))}
+            for st in ("stage1", "stage2", "stage3"):
+                out[st + "_depth"] = o[st]["depth"][0].numpy()
+                out[st + "_conf"] = o[st]["photometric_confidence"][0].numpy()
+            name = "model_%s_v5_256%s" % (tag, "_peaked" if peaked else "")
+            print("  %s: stage-1 confidence median %.3f, depth std %.1f" % (name, float(np.median(out["stage1_conf"])), float(o["depth"].std())))
+            save(name, **out)
+
+
 def gen_ucsnet():
     """UCS-Net (ucsnet.py): uncertainty_aware_samples both branches (30-53), the variance tail of compute_depth (137-151),
     and Infer_UCSNet end to end.  The class is built with its own constructor arguments; `num_depth`, which forward reads
@@ -481,7 +501,8 @@ def gen_ucsnet():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models", "models_peaked", "ucsnet"]
+    which = sys.argv[1:] or ["warp", "aggregate", "regress", "gru", "gru2", "costreg3d", "pairnet", "models", "models_peaked", "ucsnet",
+                             "models_large"]
     for wname in which:
         if wname.startswith("model_"):
             gen_models(only=[wname])

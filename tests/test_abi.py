@@ -29,6 +29,10 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     assert lib.d3d_version() == _lib.ABI_VERSION
     assert lib.d3d_last_error() is not None
+    # the production build carries no experiment knob: one wrong -D in the Makefile must not ship silently
+    assert lib.d3d_build_flags() == b"", lib.d3d_build_flags()
+    counts = (ctypes.c_ulonglong * 4)()
+    assert lib.d3d_debug_dispatch_counts(counts, 1) == 0 and lib.d3d_debug_dispatch_counts(None, 0) == -1
 
 
 def test_invalid_arguments_are_reported_not_thrown():
