@@ -1,7 +1,9 @@
 """Kernel-selection switches of the host side: read from the environment ONCE, at import, into one table.
 
 Every switch below selects between kernels that compute the same thing (A/B measurements, cross-checks in the tests, a
-fall-back to MIOpen for the feature pyramids); none is needed in normal use.  The operators look them up here -- a dict
+fall-back to MIOpen for the feature pyramids); none is needed in normal use.  Round 4: eight entries (thirty in round 3) --
+the fourteen "kernel X off" booleans are ONE list (D3D_KERNELS_OFF, names in KERNELS), and the eleven switches nothing
+used any more are gone with the choices they made frozen at their defaults.  The operators look them up here -- a dict
 access -- instead of calling os.environ on every convolution (round 2 read ~50 of them per call).  Code that wants another
 value at run time (the tests, the tools) sets `config.switches[name]` -- for a scope: `with config.override(name=value):` --
 or calls `config.reload()` after changing os.environ.
@@ -19,33 +21,30 @@ SWITCHES = {
     "D3D_FORCE_PATH": ("", "sweep kernels: 'direct' | 'tiled' | 'window' forces one kernel family (tests, profiling); '' = dispatcher"),
     "D3D_CONV": ("mfma", "3-D / 2-D convolutions: 'mfma' (matrix cores) | 'mfma_slice' | 'direct' (vector-unit cross-check)"),
     "D3D_CONV_PRECISION": ("fp32", "default operand precision of the regularisers: 'fp32' | 'bf16' (ops.set_conv_precision overrides)"),
-    "D3D_CONV_CO8": ("1", "0: the 8-output-channel streaming kernels off"),
-    "D3D_CONV_C8": ("1", "0: the bf16 z-streaming conv0 kernel off"),
     "D3D_CONV_C8X3": ("1", "fp32 mode of conv0 / conv2 / conv11 on the split-operand (3 x bf16) matrix-core kernels: '1' | '0' off | 'all' also the probability layer (slower there)"),
-    "D3D_CONV_CO1": ("1", "0: the single-output-channel probability kernel off"),
-    "D3D_CONV_T2": ("1", "0: the transposed stride-2 streaming kernel off"),
-    "D3D_CONV_CL": ("1", "0: channel-last bf16 activations off (planar bf16 path)"),
-    "D3D_CONV_KZFOLD": ("1", "0: kz-folded probability layer off"),
-    "D3D_CONV_T2_FOLD": ("1", "0: conv11 column-parity fold off"),
-    "D3D_CONV1X1_UPSKIP": ("1", "0: fused 1x1 + upsample + skip off"),
-    "D3D_CONV2D_STREAM": ("1", "0: row-streamed 2-D vector kernel off"),
-    "D3D_CONTEXT_FUSED": ("1", "0: fused pooled-context heads of the AdaMVS pyramid off"),
-    "D3D_CONV2D_ZS": ("1", "0: 2-D tile kernels off"),
     "D3D_CONV2D_FP32": ("x3", "fp32 mode of the 2-D tile kernels: 'x3' (three-way bf16 split) | 'f32' (fp32 MFMA)"),
-    "D3D_CONV2D_ZS_MINPIX": (str(256 * 256), "smallest image (pixels) the bf16 2-D tile kernel takes"),
-    "D3D_CONV2D_ZS_ALL": ("0", "1: 2-D tile kernels for every layer in fp32 mode too"),
-    "D3D_CONV2D_ZS_SLICE": ("1", "0: slice-loop layers off the tile kernels"),
-    "D3D_CONV2D_ZS_F32": ("1", "0: fp32-mode tile kernels off"),
-    "D3D_CONVT2D_ZS_ALL": ("1", "0: transposed 2-D tile kernels only inside slice loops"),
-    "D3D_CONVT2D_STUFF": ("1", "0: 48-channel transposed layers not as zero-stuffed convolutions"),
-    "D3D_CONV2D_K5": ("1", "0: 5x5 stride-2 tile kernel off"),
-    "D3D_CONV_NOFOLD": ("", "non-empty: never fold taps into K"),
-    "D3D_CONV_FOLD_KB": ("48", "LDS budget (KB) of the tap fold"),
-    "D3D_GRU_GATES": ("stream", "GRU gate kernel: 'stream' | 'separate'"),
-    "D3D_GRU_FUSED": ("1", "0: the one-launch conv-GRU cell of bf16 mode off (three tile-kernel launches instead)"),
     "D3D_FEATURE_PRECISION": ("fp32", "feature pyramids: 'fp32' | 'follow' (the regularisers' precision)"),
     "D3D_FEATURE_CONV": ("mfma", "feature pyramids: 'mfma' (own kernels) | 'miopen'"),
-    "D3D_FPN_SPLIT": ("1", "0: FPN output levels through the wide tensor"),
+    "D3D_KERNELS_OFF": ("", "comma-separated specialised kernels to leave out of the dispatch, so that the next-best kernel serves the "
+                            "call (cross-checks in the tests, A/B measurements): " + "see KERNELS below"),
+}
+
+# The specialised kernels D3D_KERNELS_OFF can take out of the dispatch (each one's fallback computes the same thing):
+KERNELS = {
+    "co8": "8-output-channel 3-D streaming kernels",
+    "c8": "bf16 z-streaming conv0 kernel",
+    "co1": "single-output-channel probability kernel",
+    "t2": "transposed stride-2 3-D streaming kernel",
+    "cl": "channel-last bf16 activations between the layers of a CostRegNet (planar bf16 path instead)",
+    "kzfold": "k_z-folded probability layer",
+    "t2fold": "column-parity fold of conv11",
+    "upskip": "fused 1x1 + upsample + skip (FPN lateral)",
+    "conv2d_stream": "row-streamed 2-D vector kernel",
+    "context_fused": "fused pooled-context heads of the AdaMVS pyramid",
+    "conv2d_zs": "2-D tile kernels (stride 1 / 2 / transposed)",
+    "conv2d_k5": "5x5 stride-2 tile kernel of the feature trunks",
+    "gru_fused": "one-launch conv-GRU cell of bf16 mode (three tile-kernel launches instead)",
+    "fpn_split": "FPN output levels without the wide tensor",
 }
 
 
@@ -58,6 +57,24 @@ switches = _read()
 
 def get(name):
     return switches[name]
+
+
+_off_cache = ("", frozenset())
+
+
+def off(kernel):
+    """True when `kernel` (a key of KERNELS) is listed in D3D_KERNELS_OFF."""
+    global _off_cache
+    text = switches["D3D_KERNELS_OFF"]
+    if text != _off_cache[0]:
+        names = frozenset(n.strip() for n in text.split(",") if n.strip())
+        unknown = names - set(KERNELS)
+        if unknown:
+            raise KeyError("D3D_KERNELS_OFF: unknown kernel(s) %s (known: %s)" % (", ".join(sorted(unknown)), ", ".join(sorted(KERNELS))))
+        _off_cache = (text, names)
+    if kernel not in KERNELS:
+        raise KeyError("unknown kernel %r" % kernel)
+    return kernel in _off_cache[1]
 
 
 def reload():

@@ -632,11 +632,15 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                                 for (int qq_ = 1; qq_ < Q; ++qq_) q += (it >= qq_ * W[i].wh) ? 1 : 0;
                                 const int sy = W[i].wy0 + (it - q * W[i].wh);
                                 const bool yin = sy >= 0 && sy < h;
-                                const int soff = yin ? ((c0 + 4 * q) * (int)plane + sy * w) * 4 : OOB;
+                                // rows outside the image: the out-of-range marker travels in the VECTOR offset, which the hardware
+                                // range-checks against num_records (zeros come back); the scalar offset is documented as excluded
+                                // from that check, so it always stays inside the buffer
+                                const int soff = yin ? ((c0 + 4 * q) * (int)plane + sy * w) * 4 : 0;
                                 const int pb = yin ? (int)plane * 4 : 0;
+                                const int vo = yin ? voff : OOB;
 #pragma unroll
                                 for (int c = 0; c < 4; ++c)
-                                    v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + c * pb, 0));
+                                    v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff + c * pb, 0));
                             }
 #pragma unroll
                             for (int k = 0; k < SU; ++k) {

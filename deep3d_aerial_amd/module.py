@@ -305,7 +305,7 @@ def fpn_output(lateral, x, coarse, head, wide=None):
             and head.stride == (1, 1) and head.dilation == (1, 1) and head.groups == 1 and x.is_cuda and x.dtype == torch.float32
             and x.shape[1] in (8, 16) and Cm == 32 and Co <= 16 and coarse.shape[1] == Cm and x.shape[3] % 8 == 0
             and x.shape[2] == 2 * coarse.shape[2] and x.shape[3] == 2 * coarse.shape[3] and _feature_precision_is_fp32()
-            and _cfg.get("D3D_FEATURE_CONV") != "miopen" and _cfg.get("D3D_FPN_SPLIT") != "0"):
+            and _cfg.get("D3D_FEATURE_CONV") != "miopen" and not _cfg.off("fpn_split")):
         wt, wb, bt, bsum = _fpn_weights(lateral, head)   # bt and its sum come from ONE cache entry keyed on both layers' versions
         bias = head.bias if bt is None else bsum if head.bias is None else bsum + head.bias
         outs = []

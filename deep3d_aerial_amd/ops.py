@@ -19,7 +19,9 @@ PER_PLANE, PER_PIXEL, AFFINE = 0, 1, 2
 class AffineDepth:
     """Per-pixel depth hypotheses in their generating form (include/deep3d_planesweep.h, D3D_DEPTH_AFFINE): `maps` is
     [2,h,w] = (lo, step) and plane k of a pixel lies at lo + k * step, k < D -- what module.py:616-631 builds its
-    [D,h,w] volume from.  Every op that takes a depth volume takes this in its place and reads two maps instead of D."""
+    [D,h,w] volume from.  The aggregation and regression ops (variance_volume*, weighted_corr, pair_corr_mean, softargmin_conf4*)
+    take it in place of the volume and read two maps instead of D; homo_warp and pair_softmax_max take [D] or [D,h,w] only
+    (pass `.volume()`)."""
 
     def __init__(self, maps, D):
         if not (isinstance(maps, torch.Tensor) and maps.dim() == 3 and maps.shape[0] == 2):
@@ -48,6 +50,7 @@ def _stream():
 # the production kernels (tile convolutions, fused conv-GRU cell, channel-last volumes, window / ring sweeps) were the ones
 # dispatched -- not a fallback that happens to give the same numbers.
 dispatch_counts = collections.Counter()
+CONV2D_ZS_MINPIX = 256 * 256   # smallest image (pixels) conv2d_k3 hands to the 2-D tile kernel
 
 
 def sweep_dispatch_counts(reset=False):
@@ -101,8 +104,10 @@ def _opt(t, name):
     return None if t is None else _chk(t, name)
 
 
-def _depth(depth, h, w):
+def _depth(depth, h, w, affine_ok=True, op=""):
     if isinstance(depth, AffineDepth):
+        if not affine_ok:
+            raise TypeError("%s takes depth hypotheses as [D] or [D,h,w]; pass AffineDepth.volume()" % op)
         if tuple(depth.maps.shape[1:]) != (h, w):
             raise ValueError("affine depth maps must be [2,%d,%d] (got %s)" % (h, w, tuple(depth.maps.shape)))
         return _chk(depth.maps, "depth.maps", 3), AFFINE, depth.D
@@ -136,7 +141,7 @@ def compose_projections(proj44):
 def homo_warp(src, proj34, depth, out=None):
     """src [C,h,w], proj34 [12], depth [D]|[D,h,w] -> [C,D,h,w]."""
     C, h, w = src.shape
-    dp, mode, D = _depth(depth, h, w)
+    dp, mode, D = _depth(depth, h, w, affine_ok=False, op="homo_warp")
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=src.device)
     ws, wp, wn = _workspace(2, C, D, h, w, 4, src.device)
@@ -153,7 +158,7 @@ def homo_warp_double(src, src_proj, ref_proj, depth):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and tuple(t.shape) == (4, 4)):
             raise TypeError("%s must be a CUDA float64 [4,4] tensor" % name)
     C, h, w = src.shape
-    dp, mode, D = _depth(depth, h, w)
+    dp, mode, D = _depth(depth, h, w, affine_ok=False, op="homo_warp_double")
     p44 = torch.stack([ref_proj, src_proj]).contiguous()
     p34 = torch.empty((1, 12), dtype=torch.float64, device=src.device)
     lib = _lib.load()
@@ -324,7 +329,7 @@ def uncertainty_aware_samples(cur_depth, exp_var, ndepth, shape=None):
 def pair_softmax_max(score, depth):
     """score [D,h,w] -> (view_weight [h,w], pair_depth [h,w]) (adamvs.py:478-486)."""
     D, h, w = score.shape
-    dp, mode, D2 = _depth(depth, h, w)
+    dp, mode, D2 = _depth(depth, h, w, affine_ok=False, op="pair_softmax_max")
     if D2 != D:
         raise ValueError("depth has %d planes, score has %d" % (D2, D))
     vw = torch.empty((h, w), dtype=torch.float32, device=score.device)
@@ -459,7 +464,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_zs_bf16x3")
             return out
-    if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and _cfg.get("D3D_CONV_CO8") != "0" \
+    if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and not _cfg.off("co8") \
             and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv0 of every CostRegNet): z-streaming kernel on the fp32 vector units (same peak as the fp32 matrix
         # cores, which an 8-row GEMM half fills); weights re-laid out [Ci][ky][kx][kz][8] once per parameter version
@@ -472,7 +477,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         _lib.check(rc, "d3d_conv3d_k3_co8")
         return out
     if stride == 1 and Ci in (8, 16, 32) and (Co in (8, 16) or (Co == 32 and Ci == 32)) and W % 4 == 0 and _use_mfma() \
-            and conv_precision() == "bf16" and _cfg.get("D3D_CONV_C8") != "0":
+            and conv_precision() == "bf16" and not _cfg.off("c8"):
         # conv0 / conv2 / conv4 of every CostRegNet with bf16 operands: z-streaming matrix-core kernel (each plane read once)
         wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
         out = torch.empty((Co, D, H, W), dtype=torch.float32, device=x.device)
@@ -499,7 +504,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_c1_bf16x3")
             return out
-    co1 = Co == 1 and stride == 1 and Ci == 8 and _cfg.get("D3D_CONV_CO1") != "0"
+    co1 = Co == 1 and stride == 1 and Ci == 8 and not _cfg.off("co1")
     if _use_mfma() and Co <= 64 and not co1:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)
         if y is not None:
@@ -583,7 +588,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_convtranspose3d_k3s2_zs_bf16x3")
             return out
-    if Co == 8 and Ci % 8 == 0 and _use_mfma() and _cfg.get("D3D_CONV_CO8") != "0" \
+    if Co == 8 and Ci % 8 == 0 and _use_mfma() and not _cfg.off("co8") \
             and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv11 of every CostRegNet): z-streaming kernel on the fp32 vector units, weights [Ci][kz][ky][kx][8]
         wp = derived_weight(weight, "coT8", lambda w: w.permute(0, 2, 3, 4, 1))
@@ -596,7 +601,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
         _lib.check(rc, "d3d_convtranspose3d_k3s2_co8")
         return out
     if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() == "bf16" \
-            and _cfg.get("D3D_CONV_T2") != "0":
+            and not _cfg.off("t2"):
         # decoder layers of CostRegNet with bf16 operands: eight per-parity dense convolutions on the matrix cores, z-streaming
         wp = derived_weight(weight, "t2bf16", _pack_t2_bf16)
         out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
@@ -627,7 +632,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
 # A "CL" volume is a torch.bfloat16 tensor [D,H,W,C]; a planar one the usual float32 [C,D,H,W].
 # ----------------------------------------------------------------------------------------
 def channel_last_enabled():
-    return _cfg.get("D3D_CONV_CL") != "0"
+    return not _cfg.off("cl")
 
 
 def _chk_cl(t, name, cl8=False):
@@ -688,7 +693,7 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
     out = torch.empty(oshape, dtype=torch.bfloat16 if out_cl else torch.float32, device=x.device)
     optr = ctypes.c_void_p(out.data_ptr())
     rc = _lib.ERR_UNSUPPORTED
-    if stride == 1 and Co == 1 and not out_cl and _cfg.get("D3D_CONV_KZFOLD") != "0":
+    if stride == 1 and Co == 1 and not out_cl and not _cfg.off("kzfold"):
         # the probability layer: k_z folded into the columns of one operand tile
         wf = derived_weight(weight, "c8kzfold", _pack_c8_kzfold_bf16)
         rc = _lib.load().d3d_conv3d_k3_c1_cl_bf16(xp, fmt, ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
@@ -727,7 +732,7 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
     if skip is not None and (tuple(skip.shape) != oshape or skip.dtype != torch.bfloat16):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
     if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)):
-        fold = (Ci, Co) == (16, 8) and _cfg.get("D3D_CONV_T2_FOLD") != "0"   # conv11: both column parities in one GEMM
+        fold = (Ci, Co) == (16, 8) and not _cfg.off("t2fold")   # conv11: both column parities in one GEMM
         wp = derived_weight(weight, "t2foldbf16", _pack_t2_fold_bf16) if fold else derived_weight(weight, "t2bf16", _pack_t2_bf16)
         out = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
         rc = _lib.load().d3d_convtranspose3d_k3s2_cl_bf16(_chk_cl(x, "x"), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
@@ -754,7 +759,7 @@ def conv1x1_upskip(x, weight, bias, coarse):
     Ci, H, W = x.shape
     Co = weight.shape[0]
     if (Ci, Co) not in ((8, 32), (16, 32)) or H % 2 or W % 2 or tuple(coarse.shape) != (Co, H // 2, W // 2) \
-            or tuple(weight.shape) != (Co, Ci, 1, 1) or _cfg.get("D3D_CONV1X1_UPSKIP") == "0":
+            or tuple(weight.shape) != (Co, Ci, 1, 1) or _cfg.off("upskip"):
         return None
     wp = derived_weight(weight, "c11", lambda w: w.reshape(Co, Ci).t())
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
@@ -775,7 +780,7 @@ def conv2d_stream(x, weight, scale, shift, skip, act, x2=None, aux1=None, ep_spl
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
     if (Co not in (8, 16) or not _use_mfma() or conv_precision() == "bf16" or H * W < _CONV2D_STREAM_MIN
-            or 8 * H * W * 4 >= 2 ** 31 or _cfg.get("D3D_CONV2D_STREAM") == "0"
+            or 8 * H * W * 4 >= 2 ** 31 or _cfg.off("conv2d_stream")
             or (x2 is not None and Ci0 % 8 != 0) or tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3)):
         return None
 
@@ -824,7 +829,7 @@ def avgpool_4_8(x):
     """AvgPool2d(4) and AvgPool2d(8) of x [C,H,W] in one read (d3d_avgpool2d_4_8) -> ([C,H//4,W//4], [C,H//8,W//8]); None for
     shapes the kernel does not take."""
     C, H, W = x.shape
-    if H < 8 or W < 8 or W % 4 or _cfg.get("D3D_CONTEXT_FUSED") == "0":
+    if H < 8 or W < 8 or W % 4 or _cfg.off("context_fused"):
         return None
     o4 = torch.empty((C, H // 4, W // 4), dtype=torch.float32, device=x.device)
     o8 = torch.empty((C, H // 8, W // 8), dtype=torch.float32, device=x.device)
@@ -841,7 +846,7 @@ def conv1x1_context(f, weight, a, b):
     Ci, H, W = f.shape
     Co = weight.shape[0]
     if (tuple(weight.shape) != (Co, Ci) or Ci != Co or Ci not in (8, 16, 32) or W % 4 or a.shape[0] != Co or b.shape[0] != Co
-            or 3 * a.shape[2] > W or 3 * b.shape[2] > W or _cfg.get("D3D_CONTEXT_FUSED") == "0"):
+            or 3 * a.shape[2] > W or 3 * b.shape[2] > W or _cfg.off("context_fused")):
         return None
     out = torch.empty((Co, H, W), dtype=torch.float32, device=f.device)
     rc = _lib.load().d3d_conv1x1_context(_chk(f, "f", 3), Ci, _chk(weight, "weight"), _chk(a, "a", 3), a.shape[1], a.shape[2],
@@ -942,7 +947,7 @@ def convtranspose2d_k4_zs(x, weight, scale=None, shift=None, skip=None, act=0, s
     Ci, H, W = x.shape
     Co = weight.shape[1]
     if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or tuple(weight.shape) != (Ci, Co, 4, 4) \
-            or _cfg.get("D3D_CONV2D_ZS") == "0":
+            or _cfg.off("conv2d_zs"):
         return None
     wp = derived_weight(weight, "t2dk4x3", _pack_t2d_k4_bf16x3)
     out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
@@ -978,7 +983,7 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
         y = conv2d_zs(torch.nn.functional.pad(x, (0, pw)), weight, scale, shift,
                       None if skip is None else torch.nn.functional.pad(skip, (0, pw)), act, skip_after_act=skip_after_act)
         return None if y is None else y[:, :, :W].contiguous()
-    if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _cfg.get("D3D_CONV2D_ZS") == "0":
+    if not ok or Ci0 % 8 or Ci1 % 8 or W % 4 or _cfg.off("conv2d_zs"):
         return None
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
@@ -1025,7 +1030,7 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     x3 = not bf16 and _z2_fp32_entry() == "x3" and Ci != 48
     wide = Ci == 48 and Co <= 48 and W % 4 == 0   # the pair-visibility UNet: the stride-1 kernel with a subsampled store
     if not wide and (Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4) or act not in (0, 1) \
-            or _cfg.get("D3D_CONV2D_ZS") == "0":
+            or _cfg.off("conv2d_zs"):
         return None
     if tuple(weight.shape) != (Co, Ci, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
@@ -1088,7 +1093,7 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
     convolutions over one staged patch); None for shapes it does not take."""
     Ci, H, W = x.shape
     Co = weight.shape[1]
-    if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or _cfg.get("D3D_CONV2D_ZS") == "0":
+    if Ci not in (8, 16, 32) or Co > 16 or W % 4 or act not in (0, 1) or _cfg.off("conv2d_zs"):
         return None
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
@@ -1119,21 +1124,20 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
-    if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= int(_cfg.get("D3D_CONV2D_ZS_MINPIX")) and \
-            (conv_precision() == "bf16" or _cfg.get("D3D_CONV2D_ZS_ALL") == "1"
-             or (_cfg.state.tile_kernels and _cfg.get("D3D_CONV2D_ZS_SLICE") == "1")):
+    if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= CONV2D_ZS_MINPIX and \
+            (conv_precision() == "bf16" or _cfg.state.tile_kernels):
         # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
         # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True)   # conv2d_k3: the skip is added last
         if y is not None:
             return y
-    zs_any = conv_precision() == "bf16" or ((_cfg.state.tile_kernels or Ci0 == 48) and _cfg.get("D3D_CONV2D_ZS_F32") != "0")
+    zs_any = conv_precision() == "bf16" or _cfg.state.tile_kernels or Ci0 == 48
     if stride == 2 and x2 is None and act in (0, 1) and zs_any and _use_mfma() and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128):
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
         if y is not None:
             return y
     if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8), (48, 48)) and _use_mfma() \
-            and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128) and _cfg.get("D3D_CONV2D_ZS_F32") != "0":
+            and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128):
         # 32 -> 32, 16 -> 16 and 8 -> 8 (the trunks of the feature pyramids) in fp32 accuracy: the tile kernel beats the
         # row-streamed matrix-core form (140 -> 68 us at 464 x 688) and the vector-unit kernel (140 -> 68 us at 928 x 1376,
         # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below.
@@ -1175,15 +1179,12 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    # fp32: the tile kernel serves the slice regularisers and (D3D_CONVT2D_ZS_ALL, default on) the feature pyramids' deconvs
-    zs_any = conv_precision() == "bf16" or (_cfg.get("D3D_CONV2D_ZS_F32") != "0"
-                                            and (_cfg.state.tile_kernels or _cfg.get("D3D_CONVT2D_ZS_ALL") != "0"))
-    if zs_any and _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
+    # (fp32 mode: the tile kernel serves the slice regularisers and the feature pyramids' deconvs alike)
+    if _use_mfma() and act in (0, 1) and H * W >= 64 * 64:
         y = convtranspose2d_zs(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:
             return y
-    if Ci == 48 and Co <= 48 and _use_mfma() and act in (0, 1) and W % 2 == 0 and H * W <= 512 * 512 \
-            and _cfg.get("D3D_CONVT2D_STUFF") != "0":
+    if Ci == 48 and Co <= 48 and _use_mfma() and act in (0, 1) and W % 2 == 0 and H * W <= 512 * 512:
         # the pair-visibility UNet (adamvs.py:198-238): no transposed tile kernel has room for 48-channel cells, and at its
         # image sizes the four per-parity launches of round 1's kernel are latency, not work.  A transposed convolution (k 3,
         # s 2, p 1, output_pad 1) is the stride-1 convolution of the zero-stuffed input with the flipped kernel: one launch
@@ -1314,7 +1315,10 @@ def _mpad(co):
 
 def set_conv_precision(mode):
     """"fp32" (default; exact fp32 MFMA) or "bf16" (bf16 MFMA operands, fp32 accumulate: BASELINE config 3) for
-    the convolutions that go through d3d_conv_fold_*.  None = follow the environment (D3D_CONV_PRECISION)."""
+    the convolutions that go through d3d_conv_fold_*.  None = follow the environment (D3D_CONV_PRECISION).
+    PER THREAD (config.state is a threading.local): a forward run in a worker thread follows the switch table's
+    D3D_CONV_PRECISION unless that thread calls this itself; to change the process-wide default set
+    config.switches["D3D_CONV_PRECISION"]."""
     if mode not in (None, "fp32", "bf16"):
         raise ValueError("precision must be 'fp32' or 'bf16'")
     _cfg.state.conv_precision = mode
@@ -1528,9 +1532,7 @@ def _conv_fold_choice(Co, Ci, three_d, stride, K=3):
     """Fold (f_y, f_x) that fills the 16 GEMM rows of a narrow layer.  Limits: the kernel's 128 taps, and resident
     weights (ntaps * Ci * 16 floats) small enough that two workgroups still share a CU's LDS -- a wide-C_in layer
     is faster unfolded at twice the occupancy (stage-1 conv0 32->8: 9.4 ms folded, 5.3 ms unfolded)."""
-    if _cfg.get("D3D_CONV_NOFOLD"):
-        return (1, 1)
-    budget = int(_cfg.get("D3D_CONV_FOLD_KB")) * 1024
+    budget = 48 * 1024
     ntaps = lambda f: (K if three_d else 1) * ((f[0] - 1) * stride + K) * ((f[1] - 1) * stride + K)
     for f in [(4, 4), (2, 4), (2, 2), (1, 2)]:
         # (the kernel's column step f_x * stride must be 1, 2 or 4)
@@ -1655,8 +1657,8 @@ def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_aft
     Co = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if (Ci, Co <= 16) != (8, True) and (Ci, Co <= 32) != (16, True) or Wo % 4 or act not in (0, 1) or H * W < 128 * 128 \
-            or tuple(weight.shape) != (Co, Ci, 5, 5) or _z2_fp32_entry() != "x3" or _cfg.get("D3D_CONV2D_ZS") == "0" \
-            or _cfg.get("D3D_CONV2D_K5") == "0":
+            or tuple(weight.shape) != (Co, Ci, 5, 5) or _z2_fp32_entry() != "x3" or _cfg.off("conv2d_zs") \
+            or _cfg.off("conv2d_k5"):
         return None
     wp = derived_weight(weight, "z2k5bf16x3", _pack_z2_bf16x3)
     out = torch.empty((Co, Ho, Wo), dtype=torch.float32, device=x.device)
@@ -1676,7 +1678,7 @@ def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride
     adamvs.py:409-412: conv1 + conv_gru1 at stride 1, conv2 + conv_gru2 at stride 2).  bf16 mode only (the operands are bf16, the
     state stays fp32): bit-identical to conv2d_zs + gru_cell_fused.  Returns the new state, or None for shapes / modes the
     kernel does not take (the caller then runs the separate launches)."""
-    if conv_precision() != "bf16" or not _use_mfma() or _cfg.get("D3D_GRU_FUSED") == "0" or cost.dim() != 3:
+    if conv_precision() != "bf16" or not _use_mfma() or _cfg.off("gru_fused") or cost.dim() != 3:
         return None
     CP, HI, WI = cost.shape
     HID, H, W = h.shape
@@ -1709,7 +1711,7 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
     Hc = h.shape[0]
     if not _use_mfma() or _cfg.get("D3D_CONV") == "mfma_slice" or x.dim() != 3 or 2 * Hc > 64:
         return None
-    if (conv_precision() == "bf16" or _cfg.get("D3D_CONV2D_ZS_F32") != "0") and x.shape[1] * x.shape[2] >= 128 * 128:
+    if x.shape[1] * x.shape[2] >= 128 * 128:
         # both convolutions on the tile kernel (v_mfma_f32_16x16x32_bf16 in bf16 mode, exact v_mfma_f32_16x16x4_f32
         # otherwise; 16-byte epilogue accesses)
         g = conv2d_zs(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
@@ -1717,11 +1719,9 @@ def gru_cell_fused(x, h, w_gates, b_gates, w_cand, b_cand):
             hn = conv2d_zs(x, w_cand, None, b_cand, h, 3, x2=g[:Hc], aux1=g[Hc:])
             if hn is not None:
                 return hn
-    # both convolutions of a large cell run on the vector-unit kernel (AdaMVS view, same device: 87.9 ms, with the
-    # gates on the matrix cores 89.3 ms; D3D_GRU_GATES=mfma selects that)
-    g = None
-    if _cfg.get("D3D_GRU_GATES") == "stream":
-        g = conv2d_stream(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
+    # both convolutions of a small cell run on the vector-unit kernel (AdaMVS view, same device: 87.9 ms, with the
+    # gates on the matrix cores 89.3 ms)
+    g = conv2d_stream(x, w_gates, None, b_gates, h, 2, x2=h, ep_split=Hc)
     if g is None:
         g = conv_fold(x, w_gates, None, b_gates, h, act=2, stride=1, x2=h, ep_split=Hc)
     if g is None:

@@ -26,7 +26,9 @@
  *     product rounded, then the sum: exactly the statement of module.py:616-631, whose
  *     hypotheses are affine in the plane index).  A sweep in this mode reads two maps instead
  *     of D planes, and its results are bit-identical to the D3D_DEPTH_PER_PIXEL sweep over
- *     the volume those maps generate.
+ *     the volume those maps generate.  Taken by the aggregation and regression entry points
+ *     (d3d_variance_volume*, d3d_weighted_corr, d3d_pair_corr_mean, d3d_softargmin_conf4*);
+ *     d3d_homo_warp, d3d_homo_warp_f64coord and d3d_pair_softmax_max take modes 0 and 1 only.
  *   - proj34 is the composed homography of module.py:528-530,
  *     (src_proj @ inverse(ref_proj))[:3,:4] = [rot | trans], row-major 12 floats per
  *     source view, in DEVICE memory (d3d_compose_projections produces it).

@@ -34,6 +34,18 @@ def oracle():
     return _o
 
 
+def set_kernel(monkeypatch, kernel, on):
+    """Take one specialised kernel (a key of config.KERNELS) out of / back into the dispatch for the duration of a test: the
+    next-best kernel then serves the call (D3D_KERNELS_OFF)."""
+    from deep3d_aerial_amd import config
+
+    if kernel not in config.KERNELS:
+        raise KeyError(kernel)
+    names = {n for n in config.switches["D3D_KERNELS_OFF"].split(",") if n}
+    names = (names - {kernel}) if on else (names | {kernel})
+    monkeypatch.setitem(config.switches, "D3D_KERNELS_OFF", ",".join(sorted(names)))
+
+
 def set_switch(monkeypatch, name, value):
     """One kernel-selection switch of deep3d_aerial_amd.config for the duration of a test (value None: its default).  The
     switches are read from the environment once, at import: a test changes the table, not os.environ."""

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_l1, set_switch
+from conftest import load_golden, rel_l1, set_kernel, set_switch
 from deep3d_aerial_amd import config, synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -628,7 +628,7 @@ def test_conv_bf16_operands_match_rounded_oracle(ops, oracle, Ci, Co, monkeypatc
     """d3d_conv_fold_bf16: operands rounded to bf16 (RNE), fp32 accumulation -- so it must agree with the fp32
     oracle run on pre-rounded inputs and weights to fp32 summation-order accuracy."""
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV_CO1", "0")  # (the C_out = 1 streaming kernel is exact fp32 in either precision mode)
+    set_kernel(monkeypatch, "co1", False)  # (the C_out = 1 streaming kernel is exact fp32 in either precision mode)
     rng = np.random.default_rng(Ci * 7 + Co)
     x = rng.standard_normal((Ci, 4, 10, 40)).astype(np.float32)
     w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
@@ -1102,7 +1102,7 @@ def test_full_size_adamvs_bf16_within_depth_budget(ops, monkeypatch):
     set_switch(monkeypatch, "D3D_CONV", "mfma")
     outs = {}
     for tag, prec, zs in (("fp32", "fp32", "1"), ("bf16_tile", "bf16", "1"), ("bf16_stream", "bf16", "0")):
-        set_switch(monkeypatch, "D3D_CONV2D_ZS", zs)
+        set_kernel(monkeypatch, "conv2d_zs", zs != "0")
         ops.set_conv_precision(prec)
         try:
             with torch.no_grad():
@@ -1133,7 +1133,7 @@ def test_full_size_cascade_bf16_regulariser_within_depth_budget(ops, monkeypatch
     set_switch(monkeypatch, "D3D_CONV", "mfma")
     outs = {}
     for tag, prec, cl in (("fp32", "fp32", "1"), ("bf16_cl", "bf16", "1"), ("bf16_planar", "bf16", "0")):
-        set_switch(monkeypatch, "D3D_CONV_CL", cl)
+        set_kernel(monkeypatch, "cl", cl != "0")
         ops.set_conv_precision(prec)
         try:
             with torch.no_grad():
@@ -1158,7 +1158,7 @@ def test_predict_views_writes_reference_products(ops, tmp_path):
     ds = predict.SyntheticBlock(3, 3, 64, 96, 64, seed=5)
     names0 = predict.predict_views(net, ds, str(tmp_path), rank=0, world_size=2)
     names1 = predict.predict_views(net, ds, str(tmp_path), rank=1, world_size=2)
-    assert sorted(names0 + names1) == ["view_0000", "view_0001", "view_0002"] and len(names0) == 2
+    assert names0 == ["view_0000"] and names1 == ["view_0001", "view_0002"]   # contiguous blocks (sharding.shard_views)
     s = ds[1]
     with torch.no_grad():
         out = net(dev(s["imgs"])[None], {k: dev(v)[None] for k, v in s["proj_matrices"].items()},
@@ -1194,7 +1194,7 @@ def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, 
     w = (0.2 * rng.standard_normal((1, 8, 3, 3, 3))).astype(np.float32)
     b = rng.standard_normal(1).astype(np.float32)
     sk = rng.standard_normal((1, D, H, W)).astype(np.float32)
-    set_switch(monkeypatch, "D3D_CONV_CO1", None)
+    set_kernel(monkeypatch, "co1", True)
     set_switch(monkeypatch, "D3D_CONV", "mfma")
     got = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
     want = oracle.conv3d_k3(x, w, b)
@@ -1202,7 +1202,7 @@ def test_conv3d_single_output_channel_streaming(ops, oracle, monkeypatch, D, H, 
     got2 = host(ops.conv3d_k3(dev(x), dev(w), dev(np.full(1, 0.5, np.float32)), dev(b), dev(sk), relu=True))
     want2 = np.maximum(0.5 * oracle.conv3d_k3(x, w, None) + b[0], 0.0) + sk
     assert np.abs(got2 - want2).max() <= 2e-6 * max(1.0, np.abs(want2).max()) * 8
-    set_switch(monkeypatch, "D3D_CONV_CO1", "0")
+    set_kernel(monkeypatch, "co1", False)
     folded = host(ops.conv3d_k3(dev(x), dev(w), None, dev(b), None, relu=False))
     assert np.abs(got - folded).max() <= 2e-6 * max(1.0, np.abs(want).max()) * 8
 
@@ -1221,13 +1221,13 @@ def test_conv3d_eight_output_channels_streaming(ops, oracle, monkeypatch, Ci, D,
     sh = rng.standard_normal(8).astype(np.float32)
     sk = rng.standard_normal((8, D, H, W)).astype(np.float32)
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV_CO8", None)
+    set_kernel(monkeypatch, "co8", True)
     want = np.maximum(oracle.conv3d_k3(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
     got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert np.abs(got - want).max() <= tol
     plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
-    set_switch(monkeypatch, "D3D_CONV_CO8", "0")
+    set_kernel(monkeypatch, "co8", False)
     folded = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
     assert np.abs(plain - folded).max() <= tol
     assert np.abs(plain - oracle.conv3d_k3(x, w, None)).max() <= tol
@@ -1244,13 +1244,13 @@ def test_convtranspose3d_eight_output_channels_streaming(ops, oracle, monkeypatc
     sh = rng.standard_normal(8).astype(np.float32)
     sk = rng.standard_normal((8, 2 * D, 2 * H, 2 * W)).astype(np.float32)
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV_CO8", None)
+    set_kernel(monkeypatch, "co8", True)
     want = np.maximum(oracle.convtranspose3d_k3s2(x, w, None) * sc[:, None, None, None] + sh[:, None, None, None], 0) + sk
     got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert got.shape == want.shape and np.abs(got - want).max() <= tol
     plain = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
-    set_switch(monkeypatch, "D3D_CONV_CO8", "0")
+    set_kernel(monkeypatch, "co8", False)
     folded = host(ops.convtranspose3d_k3s2(dev(x), dev(w), relu=False))
     assert np.abs(plain - folded).max() <= tol
 
@@ -1267,14 +1267,14 @@ def test_conv2d_streaming_vector_unit_kernel(ops, oracle, monkeypatch, Ci, Co, H
     sh = rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, H, W)).astype(np.float32)
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV2D_STREAM", None)
+    set_kernel(monkeypatch, "conv2d_stream", True)
     monkeypatch.setattr(ops, "_CONV2D_STREAM_MIN", 1)
     want = np.maximum(oracle.conv2d_k3(x, w, None) * sc[:, None, None] + sh[:, None, None], 0) + sk
     got = host(ops.conv2d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), act=1))
     tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
     assert np.abs(got - want).max() <= tol
     plain = host(ops.conv2d_k3(dev(x), dev(w)))
-    set_switch(monkeypatch, "D3D_CONV2D_STREAM", "0")
+    set_kernel(monkeypatch, "conv2d_stream", False)
     folded = host(ops.conv2d_k3(dev(x), dev(w)))
     assert np.abs(plain - folded).max() <= tol
 
@@ -1309,13 +1309,13 @@ def test_gru_cell_on_streaming_kernel(ops, oracle, monkeypatch, Cx, Hc, H, W):
          "g.convc.0.bias": rng.standard_normal(Hc).astype(np.float32)}
     want = oracle.conv_gru_cell(x, h, p, "g.")
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV2D_STREAM", None)
+    set_kernel(monkeypatch, "conv2d_stream", True)
     monkeypatch.setattr(ops, "_CONV2D_STREAM_MIN", 1)
     args = (dev(x), dev(h), dev(p["g.conv_gates.0.weight"]), dev(p["g.conv_gates.0.bias"]), dev(p["g.convc.0.weight"]),
             dev(p["g.convc.0.bias"]))
     got = host(ops.gru_cell_fused(*args))
     assert np.abs(got - want).max() <= 2e-5
-    set_switch(monkeypatch, "D3D_CONV2D_STREAM", "0")
+    set_kernel(monkeypatch, "conv2d_stream", False)
     folded = host(ops.gru_cell_fused(*args))
     assert np.abs(got - folded).max() <= 2e-5
 
@@ -1353,12 +1353,12 @@ def test_conv3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci, Co, D, 
     sh = rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, D, H, W)).astype(np.float32)
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV_C8", None)
+    set_kernel(monkeypatch, "c8", True)
     ops.set_conv_precision("bf16")
     try:
         got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
         plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
-        set_switch(monkeypatch, "D3D_CONV_C8", "0")                       # the round-1 bf16 stream kernel, same operands
+        set_kernel(monkeypatch, "c8", False)                       # the round-1 bf16 stream kernel, same operands
         other = host(ops.conv3d_k3(dev(x), dev(w), relu=False))
     finally:
         ops.set_conv_precision(None)
@@ -1385,7 +1385,7 @@ def test_convtranspose3d_zs_bf16_matrix_core_kernel(ops, oracle, monkeypatch, Ci
     sh = rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, 2 * D, 2 * H, 2 * W)).astype(np.float32)
     set_switch(monkeypatch, "D3D_CONV", "mfma")
-    set_switch(monkeypatch, "D3D_CONV_T2", None)
+    set_kernel(monkeypatch, "t2", True)
     ops.set_conv_precision("bf16")
     try:
         got = host(ops.convtranspose3d_k3s2(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True))
@@ -1476,7 +1476,7 @@ def test_conv3d_probability_layer_kz_folded(ops, oracle, monkeypatch, Ci, D, H, 
     xin = _cl_dev(x) if in_cl else dev(x)
     got = host(ops.conv3d_k3_cl(xin, dev(w), dev(sc), dev(sh), dev(sk), relu=True, out_cl=False))
     plain = host(ops.conv3d_k3_cl(xin, dev(w), None, dev(sh), None, relu=False, out_cl=False))
-    set_switch(monkeypatch, "D3D_CONV_KZFOLD", "0")
+    set_kernel(monkeypatch, "kzfold", False)
     generic = host(ops.conv3d_k3_cl(xin, dev(w), None, dev(sh), None, relu=False, out_cl=False))
     ref = oracle.conv3d_k3(_bf16_round(x), _bf16_round(w), None)
     tol = 3e-5 * max(1.0, np.abs(ref).max())
@@ -1517,7 +1517,7 @@ def test_convtranspose3d_channel_last_bf16(ops, oracle, monkeypatch, Ci, Co, D, 
     the per-parity form."""
     if fold == "0" and (Ci, Co) != (16, 8):
         pytest.skip("only 16 -> 8 has two forms")
-    set_switch(monkeypatch, "D3D_CONV_T2_FOLD", fold)
+    set_kernel(monkeypatch, "t2fold", fold != "0")
     rng = np.random.default_rng(Ci * 1000 + W + D)
     x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
     w = (0.1 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
@@ -1566,7 +1566,7 @@ def test_costregnet_channel_last_path_matches_planar_bf16_path(ops, monkeypatch)
     try:
         with torch.no_grad():
             a = net.forward_one(x)
-            set_switch(monkeypatch, "D3D_CONV_CL", "0")
+            set_kernel(monkeypatch, "cl", False)
             b = net.forward_one(x)
             ops.set_conv_precision("fp32")
             c = net.forward_one(x)
@@ -1747,7 +1747,7 @@ def test_gru_cell_bf16_tile_kernels_match_the_stream_kernels(ops, monkeypatch):
     try:
         with torch.no_grad():
             a, _ = cell(x, h)
-            set_switch(monkeypatch, "D3D_CONV2D_ZS", "0")
+            set_kernel(monkeypatch, "conv2d_zs", False)
             b, _ = cell(x, h)
             ops.set_conv_precision("fp32")
             c, _ = cell(x, h)
@@ -1913,7 +1913,7 @@ def test_adamvs_feature_pyramid_fused_context_matches_the_unfused_modules(ops, m
     x = torch.randn(1, 3, 96, 160, device="cuda")
     with torch.no_grad():
         fused = net(x)
-        set_switch(monkeypatch, "D3D_CONTEXT_FUSED", "0")
+        set_kernel(monkeypatch, "context_fused", False)
         plain = net(x)
     for k in ("stage1", "stage2", "stage3"):
         assert fused[k].shape == plain[k].shape
@@ -2039,7 +2039,7 @@ def test_fpn_output_level_without_the_wide_tensor(ops, monkeypatch, Cl, Co, H, W
                                                                                          None if not bias else lateral.bias.double())
         want = F.conv2d(t, head.weight.double(), padding=1)
         got = M.fpn_output(lateral, x, coarse, head)
-        set_switch(monkeypatch, "D3D_FPN_SPLIT", "0")
+        set_kernel(monkeypatch, "fpn_split", False)
         two = M.fpn_output(lateral, x, coarse, head)
     tol = 3e-5 * max(1.0, float(want.abs().max()))
     assert float((got.double() - want).abs().max()) <= tol

@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from deep3d_aerial_amd import ops  # noqa: E402
+from deep3d_aerial_amd import config, ops  # noqa: E402
 from conv_bench import timeit  # noqa: E402
 
 SHAPES = [("stage1 32->8", 32, 48, 688, 464), ("stage2 16->8", 16, 32, 1376, 928), ("stage3  8->8", 8, 8, 2752, 1856)]
@@ -17,13 +17,14 @@ for tag, Ci, D, h, w in SHAPES:
     fn = lambda: ops.conv3d_k3(x, wt, sc, sh, relu=True)
     gb = 4 * (Ci + 8) * D * h * w / 1e9
     res = []
-    for mode, env in (("bf16 c8 mfma", {"D3D_CONV_C8": "1"}), ("bf16 stream (r1)", {"D3D_CONV_C8": "0"}), ("fp32 co8 valu", None)):
-        if env is None:
-            ops.set_conv_precision(None)
-        else:
-            ops.set_conv_precision("bf16")
-            os.environ.update(env)
-        ms = timeit(fn, 5)
+    # (the switches are read from the environment once, at import: a tool changes the table -- config.override -- not os.environ;
+    #  the third column is the fp32 mode's kernel: the split-operand matrix-core layer since round 3, the vector-unit one with
+    #  D3D_CONV_C8X3=0)
+    for mode, env in (("bf16 c8 mfma", {}), ("bf16 stream (r1)", {"D3D_KERNELS_OFF": "c8"}),
+                      ("fp32 x3 mfma", None), ("fp32 co8 valu", {"D3D_CONV_C8X3": "0"})):
+        ops.set_conv_precision("bf16" if mode.startswith("bf16") else "fp32")
+        with config.override(**(env or {})):
+            ms = timeit(fn, 5)
         res.append("%s %7.3f ms (%5.0f GB/s, %4.2f of 8 TB/s)" % (mode, ms, gb / ms * 1e3, gb / ms / 8.0))
     ops.set_conv_precision(None)
     print("%-14s %2d x %4d x %4d  %.2f GB in+out | %s" % (tag, D, h, w, gb, " | ".join(res)), flush=True)

@@ -1,7 +1,12 @@
 #!/bin/bash
 # GPU box: SQ / LDS counters of ONE kernel of a command (separate --pmc passes, no trace domains), averaged per dispatch.
 # usage: tools/pmc_kernel.sh OUTDIR 'KERNEL_NAME_SUBSTRING' -- PROGRAM ARGS...   (PROGRAM is python3 or a binary: no wrappers)
-out=$GRAFT_REPO_ROOT/$1; pat=$2; shift 3
+usage() { echo "usage: tools/pmc_kernel.sh OUTDIR KERNEL_NAME_SUBSTRING -- PROGRAM ARGS..."; }
+[ -n "$GRAFT_REPO_ROOT" ] && [ -n "$1" ] && [ -n "$2" ] && [ "$3" = "--" ] && [ $# -ge 4 ] || { usage; exit 2; }
+out=$(realpath -m "$GRAFT_REPO_ROOT/$1"); root=$(realpath -m "$GRAFT_REPO_ROOT")
+# OUTDIR is deleted and recreated: it has to be a directory strictly INSIDE the checkout's gpurun_out/
+case "$out" in "$root"/gpurun_out/?*) ;; *) echo "OUTDIR must lie under gpurun_out/ (got $out)"; exit 2;; esac
+pat=$2; shift 3
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() { rocprofv3 --pmc $2 --output-format csv -d "$out/$1" -- "${@:3}" > "$out/$1.log" 2>&1 || echo "pass $1 failed"; }

@@ -1,7 +1,7 @@
 """Times every cost-volume sweep call inside one model forward (sync-bracketed), on the dispatcher's choice and with the ring
 and direct kernels forced: python tools/sweep_in_model.py casmvsnet|adamvs|msrednet|ucsnet"""
 import sys, os, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep3d_aerial_amd import config, predict, synthetic as S, ops
 config.switches["D3D_CONV_PRECISION"] = "bf16"
 model = sys.argv[1] if len(sys.argv) > 1 else "msrednet"
