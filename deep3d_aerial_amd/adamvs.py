@@ -164,17 +164,31 @@ class SliceCostRegNetRED(nn.Module):
         fused = ops.gru_cell_conv_fused(x, state, pre.conv.weight, g.weight, g.bias, c.weight, c.bias, stride)
         return fused if fused is not None else gru(pre(x), state)[0]
 
-    def _forward(self, cost, state1, state2):
+    def _trunk(self, cost, state1, state2):
         state1 = self._cell(self.conv1, self.conv_gru1, cost, state1, 1)
         state2 = self._cell(self.conv2, self.conv_gru2, state1, state2, 2)
         # relu(upconv1(state2) + state1): skip added before the activation (adamvs.py:423-424)
         up = ops.convtranspose2d_k3s2(state2, self.upconv1.weight, None, self.upconv1.bias, state1,
                                       skip_after_act=False, act=1)
+        return up, state1, state2
+
+    def _head(self, up):
         if self.up:
-            reg = ops.convtranspose2d_k3s2(up, self.upconv2d.weight, None, self.upconv2d.bias, None, act=0)
-        else:
-            reg = ops.conv2d_k3(up, self.upconv2d.weight, None, self.upconv2d.bias, None, act=0)
-        return reg, state1, state2
+            return ops.convtranspose2d_k3s2(up, self.upconv2d.weight, None, self.upconv2d.bias, None, act=0)
+        return ops.conv2d_k3(up, self.upconv2d.weight, None, self.upconv2d.bias, None, act=0)
+
+    def _forward(self, cost, state1, state2):
+        up, state1, state2 = self._trunk(cost, state1, state2)
+        return self._head(up), state1, state2
+
+    def step_regress(self, cost, state1, state2, dplane, max_p, sum_d, sum_p):
+        """One slice AND its online-regression update (adamvs.py:512-525 around this module): in bf16 mode the head layer and
+        the update are one kernel and `reg` never reaches memory (ops.slice_head_regress).  Returns the new states."""
+        with ops.slice_tile_kernels():
+            up, state1, state2 = self._trunk(cost, state1, state2)
+            if not ops.slice_head_regress(up, self.upconv2d.weight, self.upconv2d.bias, self.up, dplane, max_p, sum_d, sum_p):
+                ops.online_regress_update(self._head(up)[0], dplane, max_p, sum_d, sum_p)
+        return state1, state2
 
 
 class InferDepthNet(nn.Module):
@@ -217,9 +231,8 @@ class InferDepthNet(nn.Module):
         sum_d = torch.zeros_like(max_p)
         sum_p = torch.zeros_like(max_p)
         for d in range(D):
-            reg, s1, s2 = self.reg_fuse(sim[d], s1, s2)
             dplane = dv[d].reshape(1, 1) if dv.dim() == 1 else dv[d]
-            ops.online_regress_update(reg[0], dplane, max_p, sum_d, sum_p)
+            s1, s2 = self.reg_fuse.step_regress(sim[d], s1, s2, dplane, max_p, sum_d, sum_p)
         depth, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
         return depth, conf, weights, pair_results
 

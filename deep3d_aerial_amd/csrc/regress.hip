@@ -282,6 +282,136 @@ __global__ __launch_bounds__(256) void online_regress_update_kernel(const float*
     sum_p[i] = sum_p[i] + p;
 }
 
+// The head of a slice regulariser and the online regression in ONE streaming kernel (bf16 mode): adamvs.py:417-418 `reg =
+// upconv2d(up)` -- ConvTranspose2d(8, 1, k 3, s 2, p 1, output_pad 1) at stages 1-2, Conv2d(8, 1, 3, pad 1) at stage 3, both with
+// a bias -- followed by adamvs.py:514-525 (the kernel above).  As two launches the 8 -> 1 layer ran on the matrix-core tile
+// kernel with 15 of its 16 output columns idle and four storing lanes per wave, and `reg` made a round trip through HBM; here
+// a thread owns one input pixel (= 2 x 2 outputs) resp. one output pixel, the 72 weights are wave-uniform, operands are
+// rounded to bf16 (RNE) as the matrix cores' are, products and sums are fp32.
+__device__ __forceinline__ float bf16_round(float v) {
+    const __bf16 b = (__bf16)v;
+    return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// four consecutive outputs of one row (X % 4 == 0, W % 4 == 0): the accumulators move as 16-byte accesses
+__device__ __forceinline__ void regress_row4(const float (&reg)[4], long i, int X, int Y, const float* __restrict__ dplane, int hd, int wd,
+                                             int H, int W, float* __restrict__ max_p, float* __restrict__ sum_d, float* __restrict__ sum_p) {
+    typedef float f4r __attribute__((ext_vector_type(4)));
+    f4r dv;
+    if (hd == H && wd == W) {
+        dv = *reinterpret_cast<const f4r*>(dplane + i);
+    } else {
+        int y0, y1;
+        float ly;
+        lin_coord(Y, (float)hd / (float)H, hd, y0, y1, ly);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int x0, x1;
+            float lx;
+            lin_coord(X + k, (float)wd / (float)W, wd, x0, x1, lx);
+            dv[k] = bilerp(dplane, wd, y0, y1, x0, x1, ly, lx);
+        }
+    }
+    f4r mp = *reinterpret_cast<const f4r*>(max_p + i), sd = *reinterpret_cast<const f4r*>(sum_d + i), sp = *reinterpret_cast<const f4r*>(sum_p + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float p = __expf(reg[k]);
+        mp[k] = fmaxf(mp[k], p);
+        sd[k] = fmaf(dv[k], p, sd[k]);
+        sp[k] = sp[k] + p;
+    }
+    *reinterpret_cast<f4r*>(max_p + i) = mp;
+    *reinterpret_cast<f4r*>(sum_d + i) = sd;
+    *reinterpret_cast<f4r*>(sum_p + i) = sp;
+}
+
+// wt: the 72 weights ALREADY rounded to bf16 (host: ops.slice_head_regress), [c][k_y][k_x]; wave-uniform scalar loads.
+// TRANSPOSED: a thread owns the input pixels (y, 2 q), (y, 2 q + 1) = outputs rows 2 y, 2 y + 1 x columns 4 q .. 4 q + 3 (w % 2 == 0);
+// otherwise the outputs (y, 4 q .. 4 q + 3) (w % 4 == 0).
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void slice_head_regress_kernel(const float* __restrict__ up, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                                  const float* __restrict__ dplane, int hd, int wd, int h, int w,
+                                                                  float* __restrict__ max_p, float* __restrict__ sum_d, float* __restrict__ sum_p) {
+    typedef float f4r __attribute__((ext_vector_type(4)));
+    typedef float f2r __attribute__((ext_vector_type(2)));
+    const int q = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const long plane = (long)h * w;
+    const float b0 = bias[0];
+    if constexpr (TRANSPOSED) {
+        // output 2 i + p per axis: p = 0 takes kernel tap 1 of input i; p = 1 takes tap 2 of input i and tap 0 of input i + 1
+        const int x = 2 * q;
+        if (x >= w || y >= h) return;
+        const bool xin = x + 2 < w, yin = y + 1 < h;
+        float e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};   // rows 2 y and 2 y + 1
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float* __restrict__ r0 = up + c * plane + (long)y * w + x;
+            const f2r a = *reinterpret_cast<const f2r*>(r0);
+            const float a2 = xin ? r0[2] : 0.0f;
+            const f2r bq = yin ? *reinterpret_cast<const f2r*>(r0 + w) : (f2r){0, 0};
+            const float b2 = (xin && yin) ? r0[w + 2] : 0.0f;
+            const float x0 = bf16_round(a[0]), x1 = bf16_round(a[1]), x2 = bf16_round(a2);
+            const float z0 = bf16_round(bq[0]), z1 = bf16_round(bq[1]), z2 = bf16_round(b2);
+            const float* __restrict__ k = wt + c * 9;   // [k_y][k_x]
+            e[0] = fmaf(x0, k[4], e[0]);
+            e[1] = fmaf(x1, k[3], fmaf(x0, k[5], e[1]));
+            e[2] = fmaf(x1, k[4], e[2]);
+            e[3] = fmaf(x2, k[3], fmaf(x1, k[5], e[3]));
+            o[0] = fmaf(z0, k[1], fmaf(x0, k[7], o[0]));
+            o[1] = fmaf(z1, k[0], fmaf(z0, k[2], fmaf(x1, k[6], fmaf(x0, k[8], o[1]))));
+            o[2] = fmaf(z1, k[1], fmaf(x1, k[7], o[2]));
+            o[3] = fmaf(z2, k[0], fmaf(z1, k[2], fmaf(x2, k[6], fmaf(x1, k[8], o[3]))));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[k] = e[k] * 1.0f + b0; o[k] = o[k] * 1.0f + b0; }
+        const int H = 2 * h, W = 2 * w;
+        const long i0 = (long)(2 * y) * W + 2 * x;
+        regress_row4(e, i0, 2 * x, 2 * y, dplane, hd, wd, H, W, max_p, sum_d, sum_p);
+        regress_row4(o, i0 + W, 2 * x, 2 * y + 1, dplane, hd, wd, H, W, max_p, sum_d, sum_p);
+    } else {
+        const int lane = threadIdx.x & 63;
+        const bool live = 4 * q < w && y < h;   // (lanes past the row end stay for the shuffles; they read a valid quad and store nothing)
+        const int x = live ? 4 * q : 0;
+        if (y >= h) return;                      // (wave-uniform: a wave is one row)
+        float o[4] = {0, 0, 0, 0};
+        // four channels at a time: their twelve row quads are requested together, THEN shuffled and multiplied (a shuffle right
+        // behind its load would wait for it: 24 memory latencies in a row per thread)
+#pragma unroll
+        for (int c0 = 0; c0 < 8; c0 += 4) {
+            f4r v[4][3];
+            float el[4][3], er[4][3];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = y + ky - 1;
+                    const bool rin = yy >= 0 && yy < h;
+                    const float* __restrict__ r = up + (c0 + cc) * plane + (long)(rin ? yy : 0) * w + x;
+                    v[cc][ky] = rin ? *reinterpret_cast<const f4r*>(r) : (f4r){0, 0, 0, 0};
+                    // (the first / last lane of a wave has no neighbour lane: it loads the edge pixel itself)
+                    el[cc][ky] = (lane == 0 && rin && x > 0) ? r[-1] : 0.0f;
+                    er[cc][ky] = ((lane == 63 || x + 4 >= w) && rin && x + 4 < w) ? r[4] : 0.0f;
+                }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    float lft = __shfl_up(v[cc][ky][3], 1), rgt = __shfl_down(v[cc][ky][0], 1);
+                    if (lane == 0) lft = el[cc][ky];
+                    if (lane == 63 || x + 4 >= w) rgt = er[cc][ky];
+                    const float a[6] = {bf16_round(lft), bf16_round(v[cc][ky][0]), bf16_round(v[cc][ky][1]), bf16_round(v[cc][ky][2]),
+                                        bf16_round(v[cc][ky][3]), bf16_round(rgt)};
+                    const float* __restrict__ k = wt + (c0 + cc) * 9 + ky * 3;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(a[j + 2], k[2], fmaf(a[j + 1], k[1], fmaf(a[j], k[0], o[j])));
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = o[k] * 1.0f + b0;
+        if (live) regress_row4(o, (long)y * w + x, x, y, dplane, hd, wd, h, w, max_p, sum_d, sum_p);
+    }
+}
+
 __global__ __launch_bounds__(256) void online_regress_finalize_kernel(const float* __restrict__ max_p,
                                                                        const float* __restrict__ sum_d,
                                                                        const float* __restrict__ sum_p, long n,
@@ -531,6 +661,26 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
     hipLaunchKernelGGL(online_regress_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, reg, dplane, hd, wd, H,
                        W, max_p, sum_d, sum_p);
     D3D_LAUNCH_CHECK("online_regress_update_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
+                                int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream) {
+    D3D_REQUIRE(up && weight && bias && dplane && max_p && sum_d && sum_p, "null pointer");
+    D3D_REQUIRE(hd > 0 && wd > 0 && h > 0 && w > 0, "bad dims %dx%d / %dx%d", hd, wd, h, w);
+    if (w % (transposed ? 2 : 4) != 0) {
+        set_error("d3d_slice_head_regress_bf16: w = %d must be a multiple of %d", w, transposed ? 2 : 4);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    dim3 grid(ceil_div(w / (transposed ? 2 : 4), 64), ceil_div(h, 4));
+    D3D_REQUIRE(grid.y <= 65535, "h=%d too large", h);
+    if (transposed)
+        hipLaunchKernelGGL(slice_head_regress_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, up, weight, bias, dplane, hd, wd, h, w,
+                           max_p, sum_d, sum_p);
+    else
+        hipLaunchKernelGGL(slice_head_regress_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, up, weight, bias, dplane, hd, wd, h, w,
+                           max_p, sum_d, sum_p);
+    D3D_LAUNCH_CHECK("slice_head_regress_kernel launch");
     return D3D_OK;
 }
 

@@ -350,6 +350,29 @@ def online_regress_update(reg, dplane, max_p, sum_d, sum_p):
     _lib.check(rc, "d3d_online_regress_update")
 
 
+def slice_head_regress(up, weight, bias, transposed, dplane, max_p, sum_d, sum_p):
+    """reg = upconv2d(up) + bias (ConvTranspose2d(8,1,3,2,1,1) if `transposed` else Conv2d(8,1,3,pad 1); adamvs.py:417-418) and
+    the online regression update of that plane (adamvs.py:514-525) in ONE streaming kernel: `reg` never reaches memory.  bf16
+    mode only (operands rounded to bf16 as the matrix cores round them).  Returns False when the fused kernel does not apply
+    (the caller then runs the layer and online_regress_update)."""
+    if conv_precision() != "bf16" or _cfg.off("head_fused") or up.dim() != 3 or up.shape[0] != 8 or bias is None:
+        return False
+    _, h, w = up.shape
+    H, W = (2 * h, 2 * w) if transposed else (h, w)
+    if tuple(max_p.shape) != (H, W) or weight.numel() != 72:
+        return False
+    if w % (2 if transposed else 4):
+        return False
+    hd, wd = dplane.shape
+    wr = derived_weight(weight, "bf16round", lambda t: t.to(torch.bfloat16).float().contiguous())   # the matrix cores' rounding, once
+    rc = _lib.load().d3d_slice_head_regress_bf16(_chk(up, "up", 3), _chk(wr, "weight"), _chk(bias, "bias"), int(bool(transposed)),
+                                                 _chk(dplane, "dplane", 2), hd, wd, h, w, _chk(max_p, "max_p", 2),
+                                                 _chk(sum_d, "sum_d", 2), _chk(sum_p, "sum_p", 2), _stream())
+    _lib.check(rc, "d3d_slice_head_regress_bf16")
+    dispatch_counts["slice_head_regress"] += 1
+    return True
+
+
 def online_regress_finalize(max_p, sum_d, sum_p):
     dep = torch.empty_like(sum_d)
     conf = torch.empty_like(sum_d)

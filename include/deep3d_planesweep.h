@@ -202,6 +202,14 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
                               float* sum_d, float* sum_p, d3d_stream_t stream);
 
 /* adamvs.py:527-529 -- depth = sum_d/(sum_p+1e-10); conf = max_p/(sum_p+1e-10). */
+/* The head of a slice regulariser fused with d3d_online_regress_update (bf16 mode): reg = ConvTranspose2d(8, 1, k 3, s 2, p 1,
+ * output_pad 1)(up) + bias (transposed != 0: adamvs.py:417, stages 1-2; accumulators [2h,2w]) or Conv2d(8, 1, 3, pad 1)(up) + bias
+ * (stage 3; accumulators [h,w]) with operands rounded to bf16 as the matrix cores round them, then the update of adamvs.py:514-525
+ * with dplane [hd,wd] resampled as d3d_online_regress_update resamples it.  up [8,h,w], weight 72 floats [c][k_y][k_x] (the
+ * nn.ConvTranspose2d [8,1,3,3] / nn.Conv2d [1,8,3,3] tensor, ALREADY rounded to bf16 values), bias [1]; w % 2 == 0 (transposed) /
+ * w % 4 == 0, else D3D_ERR_UNSUPPORTED.  `reg` never reaches memory. */
+int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
+                                int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream);
 int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const float* sum_p, int64_t n,
                                 float* depth_out, float* conf_out, d3d_stream_t stream);
 

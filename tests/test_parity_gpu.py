@@ -797,6 +797,32 @@ def test_gru_cell_fused_is_bit_identical_to_the_three_launches(ops, C, stride, h
     assert float((got.double() - ref).abs().mean()) <= 2e-5
 
 
+@pytest.mark.parametrize("transposed,h,w,per_pixel", [(True, 70, 100, False), (True, 66, 132, True), (False, 72, 96, True)])
+def test_slice_head_regress_fused_equals_the_two_launches(ops, monkeypatch, transposed, h, w, per_pixel):
+    """regress.hip slice_head_regress_kernel: the 8 -> 1 head layer of a slice regulariser (adamvs.py:417-418) and the online
+    regression update (adamvs.py:514-525) in one kernel, against the tile-kernel layer followed by d3d_online_regress_update --
+    same bf16-rounded operands, fp32 sums in another order: accumulators equal to 1e-5 relative."""
+    rng = np.random.default_rng(h * 7 + w)
+    up = dev(rng.standard_normal((8, h, w)).astype(np.float32))
+    wshape = (8, 1, 3, 3) if transposed else (1, 8, 3, 3)
+    wt = dev((0.3 * rng.standard_normal(wshape)).astype(np.float32))
+    bias = dev(rng.standard_normal(1).astype(np.float32))
+    H, W = (2 * h, 2 * w) if transposed else (h, w)
+    dplane = dev((600 + 50 * rng.standard_normal((h, w) if per_pixel else (1, 1))).astype(np.float32))
+    acc0 = [dev(np.abs(rng.standard_normal((H, W))).astype(np.float32)) for _ in range(3)]
+    with ops.bf16_convs():
+        got = [t.clone() for t in acc0]
+        assert ops.slice_head_regress(up, wt, bias, transposed, dplane, *got)
+        want = [t.clone() for t in acc0]
+        reg = (ops.convtranspose2d_k3s2(up, wt, None, bias, None, act=0) if transposed
+               else ops.conv2d_k3(up, wt, None, bias, None, act=0))
+        ops.online_regress_update(reg[0], dplane, *want)
+    for g_, w_ in zip(got, want):
+        assert float((g_ - w_).abs().max()) <= 1e-5 * float(w_.abs().max())
+    with ops.fp32_convs():   # fp32 mode keeps the separate launches
+        assert not ops.slice_head_regress(up, wt, bias, transposed, dplane, *[t.clone() for t in acc0])
+
+
 def test_slice_red_gru2_golden(ops, convpath):
     """msrednet.py:337-370 slice regulariser (GroupNorm conv-GRUs) vs the reference's rollouts."""
     from deep3d_aerial_amd.module import ConvGRUCell2
