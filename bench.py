@@ -38,17 +38,52 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 
 # What the vector units and the LDS allow this formulation of the kernel: tools/sweep_sandbox.hip
 # replays the plane loop's instruction stream -- geometry of 4 views, 64 `ds_read_b128` taps, blend + sum / sum of squares,
-# 16 stores per 16-channel group -- with no planner, no staging and no barriers: 2555 shader cycles per (64 pixels x 1 plane x
-# 16 channels) per SIMD at the kernel's 2 compute waves per SIMD, 2098 at 3 (profiles/r03_sweep_sandbox.txt), at the
-# 2.1 GHz the chip holds under this load (profiles/r03_pk_rate.txt).  The launch cannot be faster than that while it keeps
-# this instruction mix; the HBM roofline (`frac`) stays the figure of merit.
-SANDBOX_CYCLES_PER_GROUP = {"2_compute_waves_per_simd": 2555.0, "3_compute_waves_per_simd": 2098.0}
-SANDBOX_CLOCK_GHZ, SIMDS = 2.1, 256 * 4
+# 16 stores per 16-channel group -- with no planner, no staging and no barriers.  The cycles per (64 pixels x 1 plane x
+# 16 channels) per SIMD are PARSED from the tool's committed raw output, and only while that file and the tool still hash to
+# what profiles/issue_floor.json recorded (no hard-coded constants without a guard); the clock is the one
+# the chip held in the committed counter profile of the same kernel source (GRBM_GUI_ACTIVE / 8 / kernel time).
+SIMDS = 256 * 4
 
 
-def issue_floor_ms(waves="2_compute_waves_per_simd"):
-    groups_per_simd = (D * H_FEAT * W_FEAT / 64.0) * (C // 16) / SIMDS
-    return groups_per_simd * SANDBOX_CYCLES_PER_GROUP[waves] / (SANDBOX_CLOCK_GHZ * 1e6)
+def issue_floor():
+    """{'2_compute_waves_per_simd': ms, '3_compute_waves_per_simd': ms, 'clock_ghz': f, ...} or None when a guard fails."""
+    import hashlib
+    import re
+
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", "issue_floor.json")))
+        sha = lambda rel: hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+        if sha(meta["source"]) != meta["source_sha256"] or sha(meta["tool"]) != meta["tool_sha256"]:
+            return None
+        text = open(os.path.join(ROOT, meta["source"])).read().split("== later run")[0]
+        cyc = {int(m.group(1)): float(m.group(2)) for m in re.finditer(
+            r"\+ taps \+ stores\s+waves/SIMD (\d) :\s+\d+ cycles per plane-group per wave,\s+(\d+) per SIMD", text)}
+        clock, clock_src = float(meta["clock_ghz_fallback"]), "fallback (profiles/r03_pk_rate.txt)"
+        traffic, info = profiled_traffic()
+        if info and info.get("matches_current_source"):
+            prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            g = prof.get("sq_counters_per_launch", {}).get("GRBM_GUI_ACTIVE")
+            if g and prof.get("kernel_trace_avg_ns"):
+                clock, clock_src = g / 8.0 / prof["kernel_trace_avg_ns"], "GRBM_GUI_ACTIVE / 8 / kernel time of profiles/pmc_latest.json"
+        groups_per_simd = (D * H_FEAT * W_FEAT / 64.0) * (C // 16) / SIMDS
+        ms = lambda w: groups_per_simd * cyc[w] / (clock * 1e6)
+        return {"2_compute_waves_per_simd": ms(2), "3_compute_waves_per_simd": ms(3), "clock_ghz": clock, "clock_source": clock_src,
+                "cycles_per_group_per_simd": {"2": cyc[2], "3": cyc[3]}, "source": meta["source"], "source_sha256": meta["source_sha256"][:16]}
+    except Exception:
+        return None
+
+
+def issue_floor_fields(kern_ms):
+    f = issue_floor()
+    if f is None:
+        return {"issue_floor_ms": None}
+    return {"issue_floor_ms": round(f["2_compute_waves_per_simd"], 3),
+            "issue_floor": {"ms_at_3_compute_waves_per_simd": round(f["3_compute_waves_per_simd"], 3),
+                            "clock_ghz": round(f["clock_ghz"], 3), "clock_source": f["clock_source"],
+                            "cycles_per_group_per_simd": f["cycles_per_group_per_simd"],
+                            "source": "tools/sweep_sandbox.hip replay of the plane loop (taps + arithmetic + stores, nothing else), "
+                                      + f["source"] + " (sha256 " + f["source_sha256"] + ", guarded by profiles/issue_floor.json)",
+                            "kernel_over_floor": round(kern_ms / f["2_compute_waves_per_simd"], 3)}}
 
 
 def algorithmic_bytes():
@@ -402,11 +437,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_profile": traffic_info,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": algorithmic_bytes(),
-                         "issue_floor_ms": round(issue_floor_ms(), 3),
-                         "issue_floor": {"ms_at_3_compute_waves_per_simd": round(issue_floor_ms("3_compute_waves_per_simd"), 3),
-                                         "source": "tools/sweep_sandbox.hip replay of the plane loop (taps + arithmetic + "
-                                                   "stores, nothing else), profiles/r03_sweep_sandbox.txt",
-                                         "kernel_over_floor": round(kern_ms / issue_floor_ms(), 3)}},
+                         **issue_floor_fields(kern_ms)},
         }
         if per_rank is not None:
             line["per_rank"] = per_rank

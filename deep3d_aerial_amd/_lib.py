@@ -61,6 +61,7 @@ SIGNATURES = {
     "d3d_conv3x3_bias_border": [_vp, _vp, _i, _i, _i, _vp],
     "d3d_conv1x1_context": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3_wide_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "d3d_slice_head_regress_bf16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_gru_cell_fused_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "d3d_convtranspose2d_k3s2_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],

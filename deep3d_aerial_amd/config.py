@@ -43,6 +43,7 @@ KERNELS = {
     "context_fused": "fused pooled-context heads of the AdaMVS pyramid",
     "conv2d_zs": "2-D tile kernels (stride 1 / 2 / transposed)",
     "conv2d_k5": "5x5 stride-2 tile kernel of the feature trunks",
+    "conv2d_wide": "bf16 tile kernel for 64 | 128 input channels (RED-Net's coarse conv-GRU levels; the generic fp32 matrix-core kernel instead)",
     "gru_fused": "one-launch conv-GRU cell of bf16 mode (three tile-kernel launches instead)",
     "head_fused": "slice regulariser head + online regression update in one kernel (bf16 mode; the 8 -> 1 layer and the update as two launches instead)",
     "fpn_split": "FPN output levels without the wide tensor",

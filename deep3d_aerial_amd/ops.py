@@ -1138,6 +1138,28 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
     return out
 
 
+def conv2d_wide(x, weight, scale=None, shift=None, skip=None, act=0, x2=None):
+    """3x3 stride-1 conv over cat(x, x2) with 64 | 128 input channels (parts of 32) and 32 | 64 | 128 output channels on the
+    bf16 matrix cores, K walked in chunks of 32 channels (d3d_conv2d_k3_wide_bf16, csrc/conv2d_wide.hip: the coarse conv-GRU
+    levels of the RED-Net slice regulariser).  bf16 mode only; None for other shapes."""
+    Ci0, H, W = x.shape
+    Ci1 = 0 if x2 is None else x2.shape[0]
+    Co = weight.shape[0]
+    if conv_precision() != "bf16" or _cfg.off("conv2d_wide") or (Ci0 + Ci1) not in (64, 128) or Ci0 % 32 or Ci1 % 32 \
+            or Co not in (32, 64, 128) or act not in (0, 1) or not _use_mfma():
+        return None
+    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_conv2d_k3_wide_bf16(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
+                                             _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), int(act), Co, H, W,
+                                             _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k3_wide_bf16")
+    dispatch_counts["conv2d_wide"] += 1
+    return out
+
+
 def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None):
     """3x3 conv over cat(x, x2) channels. x [Ci0,H,W], x2 [Ci1,H,W]|None, weight [Co,Ci0+Ci1,3,3]."""
     Ci0, H, W = x.shape
@@ -1152,6 +1174,10 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
         # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True)   # conv2d_k3: the skip is added last
+        if y is not None:
+            return y
+    if stride == 1 and act in (0, 1) and (Ci0 + Ci1) in (64, 128):
+        y = conv2d_wide(x, weight, scale, shift, skip, act, x2=x2)   # (bf16 mode: the wide conv-GRU levels of RED-Net)
         if y is not None:
             return y
     zs_any = conv_precision() == "bf16" or _cfg.state.tile_kernels or Ci0 == 48

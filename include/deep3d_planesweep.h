@@ -385,6 +385,14 @@ int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, con
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                        float* out, d3d_stream_t stream);
 
+/* 3x3 stride-1 convolution over cat(in, in2) with WIDE channel counts on the bf16 matrix cores (csrc/conv2d_wide.hip; the coarse
+ * conv-GRU levels of the RED-Net slice regulariser, msrednet.py:337-370 with module.py:53-99): C1 + C2 = 64 | 128 in parts of 32,
+ * Co = 32 | 64 | 128; out [Co,H,W] = act(conv * scale + shift) (+ skip, added last); act 0 | 1 (ReLU).  K is walked in
+ * chunks of 32 input channels (the tile kernels above keep a whole layer in LDS, which ends at 48 channels).  wpacked:
+ * ops._pack_z2_bf16(weight [Co,C1+C2,3,3]).  D3D_ERR_UNSUPPORTED for other shapes. */
+int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                            const float* shift, const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /* One conv-GRU cell of the slice regularisers in ONE launch (csrc/gru_fused.hip; replaces adamvs.py:409-412 conv1 + conv_gru1 resp.
  * conv2 + conv_gru2, module.py:5-51 ConvGRUCell, run as three d3d_conv2d_k3*_zs_bf16 launches before):
  *     x = relu(conv3x3_stride(cost));  r, u = sigmoid(conv3x3(cat(x, h)) + bg);  c = tanh(conv3x3(cat(x, r * h)) + bc);

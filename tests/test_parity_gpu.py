@@ -823,6 +823,33 @@ def test_slice_head_regress_fused_equals_the_two_launches(ops, monkeypatch, tran
         assert not ops.slice_head_regress(up, wt, bias, transposed, dplane, *[t.clone() for t in acc0])
 
 
+@pytest.mark.parametrize("C1,C2,Co,h,w,act", [(32, 32, 64, 70, 132, 0), (32, 32, 32, 64, 64, 1), (64, 64, 128, 40, 68, 0),
+                                               (64, 64, 64, 86, 58, 0), (64, 0, 32, 33, 61, 1)])
+def test_conv2d_wide_bf16_vs_float64_on_rounded_operands(ops, C1, C2, Co, h, w, act):
+    """csrc/conv2d_wide.hip (the 64- and 128-channel conv-GRU levels of RED-Net, msrednet.py:337-370, K in chunks of 32
+    channels): against a float64 convolution of the bf16-rounded operands -- what the matrix cores multiply -- with bias, ReLU
+    and the skip added last; tiles across every border; both workgroup shapes (2 and 4 output tiles)."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(C1 + C2 + Co + h)
+    x = dev(rng.standard_normal((C1, h, w)).astype(np.float32))
+    x2 = dev(rng.standard_normal((C2, h, w)).astype(np.float32)) if C2 else None
+    wt = dev((rng.standard_normal((Co, C1 + C2, 3, 3)) / np.sqrt(9 * (C1 + C2))).astype(np.float32))
+    bias = dev(rng.standard_normal(Co).astype(np.float32))
+    skip = dev(rng.standard_normal((Co, h, w)).astype(np.float32))
+    with ops.bf16_convs():
+        got = ops.conv2d_wide(x, wt, None, bias, skip, act, x2=x2)
+        assert got is not None
+        assert torch.equal(got, ops.conv2d_k3(x, wt, None, bias, skip, act=act, stride=1, x2=x2))   # the dispatcher takes it
+    with ops.fp32_convs():
+        assert ops.conv2d_wide(x, wt, None, bias, skip, act, x2=x2) is None                           # bf16 mode only
+    bf = lambda t: t.to(torch.bfloat16).double()
+    xin = bf(x) if x2 is None else torch.cat([bf(x), bf(x2)])
+    want = F.conv2d(xin[None], bf(wt), bias.double(), padding=1)[0]
+    want = (F.relu(want) if act else want) + skip.double()
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_slice_red_gru2_golden(ops, convpath):
     """msrednet.py:337-370 slice regulariser (GroupNorm conv-GRUs) vs the reference's rollouts."""
     from deep3d_aerial_amd.module import ConvGRUCell2
