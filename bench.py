@@ -226,7 +226,7 @@ def secondary_models(reps=2):
     old = ops.conv_precision()
     ops.set_conv_precision("bf16")
     try:
-        for name in ("casmvsnet", "adamvs"):
+        for name in ("casmvsnet", "adamvs", "msrednet"):
             net = predict.build_model(name, 384)
             S.fill_state_dict_(net.state_dict(), 1)
             net = net.cuda().eval()
@@ -243,6 +243,13 @@ def secondary_models(reps=2):
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / reps * 1e3
             res[name] = {"ms_per_view": round(ms, 2), "mvoxels_per_s": round(97.05e6 / ms / 1e3, 1)}
+            # which kernels served the view (ops.dispatch_counts; the sweeps' families come from the C dispatcher's own counters)
+            ops.dispatch_counts.clear()
+            ops.sweep_dispatch_counts(reset=True)
+            with torch.no_grad():
+                net(imgs, pm, dv)
+            torch.cuda.synchronize()
+            res[name]["dispatch"] = {**dict(ops.dispatch_counts), "sweeps": ops.sweep_dispatch_counts()}
             del net, imgs, pm, dv
             torch.cuda.empty_cache()
         res["casmvsnet"]["regulariser"] = regulariser_leg()
