@@ -66,7 +66,8 @@ __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
 // fp32's own rounding) -- 6 x 16 cycles against the 8 x 32 cycles of the fp32 instruction for the same K.
 template <bool F32, bool X3>
 __host__ __device__ constexpr int z2_cell_bytes(int CI) {
-    return F32 ? CI * 4 + 16 : (X3 ? 3 : 1) * CI * 2 + (CI > 8 ? 16 : 0);   // bf16: an odd number of 16-byte slots
+    // bf16: an odd number of 16-byte slots (24 and 40 channels -- RED-Net's finest conv-GRU level at stages 2 / 1 -- are 3 and 5 already)
+    return F32 ? CI * 4 + 16 : (X3 ? 3 : 1) * CI * 2 + ((CI > 8 && CI != 24 && CI != 40) || X3 ? (CI > 8 ? 16 : 0) : 0);
 }
 
 __device__ __forceinline__ void split3_bf16(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -1059,9 +1060,11 @@ extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, 
     D3D_REQUIRE(act != 3 || aux1, "GRU update epilogue needs the update gate u in `aux1`");
     const int Ci = C1 + C2;
     // (48 -> <= 48: the pair-visibility UNet of AdaMVS, adamvs.py:198-238)
-    const bool shape = (((Ci == 8 || Ci == 16 || Ci == 32) && Co <= 32) || (Ci == 48 && Co <= 48)) && C1 % 8 == 0 && C2 % 8 == 0 && W % 4 == 0;
+    // (24 | 40 -> <= 16: conv_gru1 of the RED-Net slice regulariser at stages 2 / 1, msrednet.py:340: 16 | 32 cost channels + 8 state channels)
+    const bool shape = (((Ci == 8 || Ci == 16 || Ci == 32) && Co <= 32) || (Ci == 48 && Co <= 48) || ((Ci == 24 || Ci == 40) && Co <= 16)) &&
+                       C1 % 8 == 0 && C2 % 8 == 0 && W % 4 == 0;
     if (!shape) {
-        set_error("d3d_conv2d_k3_zs_bf16: C_in = %d + %d (8 | 16 | 32 | 48 in groups of 8), C_out = %d (<= 32; <= 48 with C_in = 48), "
+        set_error("d3d_conv2d_k3_zs_bf16: C_in = %d + %d (8 | 16 | 32 | 48 in groups of 8; 24 | 40 with C_out <= 16), C_out = %d (<= 32; <= 48 with C_in = 48), "
                   "W = %d (multiple of 4) not taken", C1, C2, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
@@ -1071,6 +1074,8 @@ extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, 
     p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
     if (Ci == 48) return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);
+    if (Ci == 40) return launch_z2<40, 1, 2>(p, st);
+    if (Ci == 24) return launch_z2<24, 1, 4>(p, st);
     if (Co > 16) {
         if (Ci == 32) return launch_z2<32, 2, 2>(p, st);
         if (Ci == 16) return launch_z2<16, 2, 4>(p, st);

@@ -998,7 +998,7 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
     Ci, bf16 = Ci0 + Ci1, conv_precision() == "bf16"
-    ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48)   # 48 -> 48: the pair-visibility UNet
+    ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48) or (bf16 and Ci in (24, 40) and Co <= 16)   # 48 -> 48: the pair-visibility UNet; 24 | 40: RED-Net's conv_gru1 at stages 2 / 1
     if ok and W % 4 and x2 is None and aux1 is None and act in (0, 1) and H * W <= 256 * 256 and Ci0 % 8 == 0:
         # small images whose width is not a multiple of 4 (the coarsest UNet level, 58 x 86): zero columns on the right are the
         # layer's own padding, so the padded image gives the same outputs; the extra columns are dropped

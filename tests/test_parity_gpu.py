@@ -850,6 +850,24 @@ def test_conv2d_wide_bf16_vs_float64_on_rounded_operands(ops, C1, C2, Co, h, w, 
     assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("C1,C2,Co,h,w", [(16, 8, 16, 130, 136), (32, 8, 16, 128, 132), (32, 8, 8, 140, 128)])
+def test_conv2d_tile_kernel_24_and_40_channels(ops, C1, C2, Co, h, w):
+    """The bf16 tile kernel at 24 and 40 input channels (conv_gru1 of RED-Net at stages 2 / 1, msrednet.py:340: the cost slice's
+    16 | 32 channels + 8 state channels; 48- and 80-byte cells) against a float64 convolution of the bf16-rounded operands."""
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(C1 * 3 + Co + h)
+    x, x2 = dev(rng.standard_normal((C1, h, w)).astype(np.float32)), dev(rng.standard_normal((C2, h, w)).astype(np.float32))
+    wt = dev((rng.standard_normal((Co, C1 + C2, 3, 3)) / np.sqrt(9 * (C1 + C2))).astype(np.float32))
+    bias = dev(rng.standard_normal(Co).astype(np.float32))
+    with ops.bf16_convs():
+        got = ops.conv2d_zs(x, wt, None, bias, None, 0, x2=x2)
+        assert got is not None
+    bf = lambda t: t.to(torch.bfloat16).double()
+    want = F.conv2d(torch.cat([bf(x), bf(x2)])[None], bf(wt), bias.double(), padding=1)[0]
+    assert float((got.double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_slice_red_gru2_golden(ops, convpath):
     """msrednet.py:337-370 slice regulariser (GroupNorm conv-GRUs) vs the reference's rollouts."""
     from deep3d_aerial_amd.module import ConvGRUCell2
