@@ -72,6 +72,11 @@ class CostRegNet(nn.Module):
             y = self.conv6.forward_cl(self.conv5.forward_cl(c4))
             y = self.conv7.forward_cl(y, c4)
             y = self.conv9.forward_cl(y, c2)
+            _no_train(self.conv11)
+            s11, t11 = folded_bn(self.conv11[1])
+            fused = ops.convtranspose3d_prob_cl(y, self.conv11[0].weight, s11, t11, c0, self.prob.weight, self.prob.bias)
+            if fused is not None:   # conv11 + prob in one kernel: the full-resolution 8-channel volume stays in LDS
+                return fused
             y = self.conv11.forward_cl(y, c0)
             return ops.conv3d_k3_cl(y, self.prob.weight, None, self.prob.bias, None, relu=False, stride=1, out_cl=False)[0]
         c0 = self.conv0(x)

@@ -38,6 +38,7 @@ KERNELS = {
     "cl": "channel-last bf16 activations between the layers of a CostRegNet (planar bf16 path instead)",
     "kzfold": "k_z-folded probability layer",
     "t2fold": "column-parity fold of conv11",
+    "t2prob": "conv11 + probability layer of a CostRegNet in one kernel (bf16 mode, channel-last; the two layers as two launches instead)",
     "upskip": "fused 1x1 + upsample + skip (FPN lateral)",
     "conv2d_stream": "row-streamed 2-D vector kernel",
     "context_fused": "fused pooled-context heads of the AdaMVS pyramid",

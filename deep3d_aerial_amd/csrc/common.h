@@ -32,6 +32,22 @@ int ensure_dynamic_lds(const void* kernel, int bytes);
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Two floats -> one register of two bf16 (RNE, NaN stays NaN) in ONE v_cvt_pk_bf16_f32.  Written as two scalar casts the
+// compiler emits a conversion per value plus a shift and an or: four instructions -- on kernels bound by instruction issue
+// (every epilogue of the channel-last layers) that is a tenth of the work.  Same values either way.
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+
+// Workgroup barrier for data handed over through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the
+// fence waits for EVERY memory operation the wave has in flight (s_waitcnt vmcnt(0)): the global stores of the plane just
+// finished and the global loads issued ahead for a later plane -- a z-streaming kernel then pays a store's round trip per
+// plane and cannot prefetch across the barrier.  This one waits for the wave's LDS (and scalar) operations only; the
+// "memory" clobber keeps the compiler from moving memory accesses across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------
 // Geometry shared by every warp kernel.  module.py:532-546: p = (rot@[x,y,1])*d + trans,
 // (u,v) = p.xy/p.z, sampled bilinearly with align_corners=True so (u,v) are pixel

@@ -49,8 +49,7 @@ struct WideParams {
 };
 
 __device__ __forceinline__ unsigned pack_bf16_w(float a, float b) {
-    const __bf16 x = (__bf16)a, y = (__bf16)b;
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 
 template <int NW>

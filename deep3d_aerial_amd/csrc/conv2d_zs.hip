@@ -51,8 +51,7 @@ struct Z2Params {
 };
 
 __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
-    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 
 // F32: the same tile scheme with exact fp32 operands (v_mfma_f32_16x16x4_f32, the default precision of the models): cells

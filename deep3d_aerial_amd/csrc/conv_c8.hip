@@ -50,8 +50,7 @@ struct C8Params {
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 
 // waves per SIMD the register budget is sized for: two workgroups per CU (the second one's loads and stores fly while the
@@ -118,14 +117,20 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
     const u4* __restrict__ wsrc = WG ? p.wpk : wlds;
 
     // ---- per-lane A offsets: K index k = 32 kb + 8 (lane >> 4) + j  ->  tap t = k / CI, channel k % CI ----------
-    // (recomputed per use from an opaque copy of the lane's K group: NKB loop-invariant registers would cost the second
-    //  workgroup per CU at C_in = 16)
+    // One register per K block, computed once: recomputed per use (to spare NKB registers) the divisions and products were
+    // ~25 vector instructions per K block and plane -- 375 of the 800 of a plane triple at C_in = 16, in kernels bound by
+    // instruction issue (profiles/r04_t2p.txt).  WG (64 -> 64: weights from L2, tiny volumes) keeps the per-use form.
     auto a_offset = [&](int kb, int kgroup) {
         const int k0 = 32 * kb + 8 * kgroup;
         const int t = k0 / CI, c = k0 % CI;
         const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
         return (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
     };
+    int aoffs[WG ? 1 : NKB];
+    if constexpr (!WG) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) aoffs[kb] = a_offset(kb, lane >> 4);
+    }
     const int abase = (wave * PX + (lane & 15)) * CS;   // pixel (m, row) of the patch: + mg * 16 * CS per pixel group
 
     // ---- staging: task = (patch pixel, 8-channel group) ------------------------------------------------------
@@ -138,8 +143,39 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
     constexpr int RH = (CI > 16 && !INCL && NBUF == 2) ? (ROUNDS + 1) / 2 : ROUNDS;   // rounds in the first half
     float stg[INCL ? 1 : RH][8];
     u4 stc[INCL ? RH : 1];
+    // Channel-last input: what a staging task reads and writes does not change from plane to plane -- its 16 bytes' offset inside
+    // a plane (clamped into the image: the load is always issued, the value zeroed outside), whether it is inside, its cell in the
+    // patch -- so it is per-lane state computed once.  These kernels are bound by instruction issue (profiles/r04_t2p.txt), and
+    // recomputing (pixel, group, row, column, bounds, 64-bit address) per plane was a third of their vector instructions.
+    unsigned stoff[INCL ? ROUNDS : 1];
+    int stdst[INCL ? ROUNDS : 1];
+    bool stok[INCL ? ROUNDS : 1];
+    if constexpr (INCL) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PX, px = pix - py * PX;
+            const int gx = x0 + px - 1, gy = y0 + py - 1;
+            stok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const unsigned cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+            stoff[r] = p.in_cl8 ? ((g * H + cy) * W + cx) * 16 : (cy * W + cx) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes)
+            stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
+        }
+    }
     auto issue = [&](int zi, int r0, int r1) {   // global loads of input plane zi, rounds [r0, r1), into registers (zeros outside the volume)
         const bool zin = zi >= 0 && zi < D;
+        if constexpr (INCL) {
+            const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * plane * (CI * 2);
+#pragma unroll
+            for (int rr = 0; rr < RH; ++rr) {
+                const int r = r0 + rr;
+                if (r >= r1) break;
+                const u4 v = *reinterpret_cast<const u4*>(src + stoff[r]);
+                stc[rr] = zin && stok[r] ? v : (u4){0, 0, 0, 0};
+            }
+            return;
+        }
 #pragma unroll
         for (int rr = 0; rr < RH; ++rr) {
             const int r = r0 + rr;
@@ -149,23 +185,25 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             const int py = pix / PX, px = pix - py * PX;
             const int gx = x0 + px - 1, gy = y0 + py - 1;
             const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            if constexpr (INCL) {
-                const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
-                    (!ok ? 0 : p.in_cl8 ? ((((size_t)zi * G + g) * H + gy) * W + gx) * 16 : (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16);
-                const u4 v = *reinterpret_cast<const u4*>(src);
-                stc[rr] = ok ? v : (u4){0, 0, 0, 0};
-            } else {
-                const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * vol + (size_t)(ok ? zi : 0) * plane +
-                    (ok ? (size_t)gy * W + gx : 0);
+            const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * vol + (size_t)(ok ? zi : 0) * plane +
+                (ok ? (size_t)gy * W + gx : 0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float v = src[(size_t)k * vol];
-                    stg[rr][k] = ok ? v : 0.0f;
-                }
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * vol];
+                stg[rr][k] = ok ? v : 0.0f;
             }
         }
     };
     auto commit = [&](unsigned char* dst, int r0, int r1) {   // registers -> bf16 cells
+        if constexpr (INCL) {
+#pragma unroll
+            for (int rr = 0; rr < RH; ++rr) {
+                const int r = r0 + rr;
+                if (r >= r1) break;
+                if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stc[rr];
+            }
+            return;
+        }
 #pragma unroll
         for (int rr = 0; rr < RH; ++rr) {
             const int r = r0 + rr;
@@ -210,6 +248,20 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
 
     const int oy = y0 + wave;
 
+    // plane-invariant state of the C_out = 8 channel-last epilogue
+    struct { f4 sc, sh; unsigned oo[MGN]; bool st[MGN]; bool live; } c8s;
+    if constexpr (CO8) {
+        const int cb = (lane >> 4) * 4;
+        c8s.live = cb < 8;
+        c8s.sc = p.scale && c8s.live ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+        c8s.sh = p.shift && c8s.live ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+        for (int mg = 0; mg < MGN; ++mg) {
+            const int ox = x0 + mg * 16 + (lane & 15);
+            c8s.oo[mg] = ((unsigned)min(oy, H - 1) * W + min(ox, W - 1)) * 8 + (c8s.live ? cb : 0);   // bf16 elements inside an output plane
+            c8s.st[mg] = cb == 0 && ox < W;
+        }
+    }
     auto store_plane = [&](int zo, f4 (&a)[AW]) {   // epilogue of a finished output plane
         if constexpr (OUTCL) {
             // operands swapped (weights as A): D row = channel (lane >> 4) * 4 + register, column = pixel lane & 15 -- a
@@ -219,22 +271,18 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                 // C_out = 8: rows 8..15 of the tile are padding and half of the wave has nothing to store.  The lanes of
                 // channels 4..7 hand their packed pair to the lanes of channels 0..3 of the same pixel (v_permlane16_swap:
                 // row 1 -> row 0), which then write the pixel's whole 16-byte cell -- 16 lanes x 16 contiguous bytes
-                // instead of 32 lanes x 8.
-                const int cb = (lane >> 4) * 4;
-                const bool live = cb < 8;
-                const f4 sc = p.scale && live ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
-                const f4 sh = p.shift && live ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+                // instead of 32 lanes x 8.  (affine, offsets inside the plane and store mask: per-lane state, see c8s)
+                const size_t ob = (size_t)zo * plane * 8;
 #pragma unroll
                 for (int mg = 0; mg < MGN; ++mg) {
-                    const int ox = x0 + mg * 16 + (lane & 15);
-                    const size_t o = (((size_t)zo * H + oy) * W + min(ox, W - 1)) * 8 + (live ? cb : 0);
-                    f4 v = a[mg] * sc + sh;
+                    const size_t o = ob + c8s.oo[mg];
+                    f4 v = a[mg] * c8s.sc + c8s.sh;
                     if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                    if (p.skip && live) v += unpack_bf16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                    if (p.skip && c8s.live) v += unpack_bf16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
                     const unsigned px = pack_bf16(v[0], v[1]), py = pack_bf16(v[2], v[3]);
                     const auto qx = __builtin_amdgcn_permlane16_swap(px, px, false, false);
                     const auto qy = __builtin_amdgcn_permlane16_swap(py, py, false, false);
-                    if (cb == 0 && ox < W) {
+                    if (c8s.st[mg]) {
                         typedef unsigned u4s __attribute__((ext_vector_type(4)));
                         *reinterpret_cast<u4s*>(static_cast<unsigned short*>(p.out) + o) = (u4s){px, py, qx[1], qy[1]};
                     }
@@ -300,7 +348,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));   // keeps the offsets out of long-lived registers
         auto kb_body = [&](int kb) {
-            const int aoffk = a_offset(kb, kgroup);
+            const int aoffk = WG ? a_offset(kb, kgroup) : aoffs[WG ? 0 : kb];
             if constexpr (KZF && X3) {   // one tile set (columns = k_z), three weight parts
                 constexpr int WS1 = NKB * 64;
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, wsrc[kb * 64 + lane]);

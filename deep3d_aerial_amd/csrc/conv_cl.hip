@@ -41,8 +41,7 @@ struct S2Params {
 };
 
 __device__ __forceinline__ unsigned pack_bf16_cl(float a, float b) {
-    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 __device__ __forceinline__ f4 unpack_bf16x4_cl(uint2 u) {
     return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),

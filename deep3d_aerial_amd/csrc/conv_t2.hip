@@ -41,8 +41,7 @@ struct T2Params {
 };
 
 __device__ __forceinline__ unsigned pack_bf16_t2(float a, float b) {
-    const __bf16 x = (__bf16)a, y = (__bf16)b;
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 
 constexpr int ntaps(int pz, int py, int px) { return (1 + pz) * (1 + py) * (1 + px); }

@@ -67,8 +67,7 @@ struct GruParams {
 };
 
 __device__ __forceinline__ unsigned pack_bf16_g(float a, float b) {
-    const __bf16 x = (__bf16)a, y = (__bf16)b;   // v_cvt_pk_bf16_f32: RNE
-    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 __device__ __forceinline__ unsigned short bf16_bits(float a) {
     const __bf16 x = (__bf16)a;

@@ -776,6 +776,32 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
     return to_cl(y)
 
 
+def convtranspose3d_prob_cl(x, weight, scale, shift, skip, prob_weight, prob_bias, relu=True):
+    """conv11 + prob of a CostRegNet (cas_mvsnet.py:103-105,118-119) in one launch: x CL [D,H,W,16] bf16, skip CL
+    [2D,2H,2W,8] bf16 -> planar fp32 [2D,2H,2W] = Conv3d_8->1(skip + act(scale * ConvTranspose3d_16->8(x) + shift)) + bias,
+    the 8-channel volume rounded to bf16 as between the two unfused layers (bit-identical to them) but kept in LDS
+    (d3d_convtranspose3d_prob_cl_bf16).  None for shapes the kernel does not take."""
+    D, H, W, Ci = x.shape
+    if _cfg.off("t2prob") or _cfg.off("t2fold") or _cfg.off("kzfold") or Ci != 16 or W % 2 \
+            or tuple(weight.shape) != (16, 8, 3, 3, 3) or tuple(prob_weight.shape) != (1, 8, 3, 3, 3):
+        return None
+    oshape = (2 * D, 2 * H, 2 * W)
+    if skip is not None and (tuple(skip.shape) != oshape + (8,) or skip.dtype != torch.bfloat16):
+        raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape + (8,)))
+    wt = derived_weight(weight, "t2foldbf16", _pack_t2_fold_bf16)
+    wp = derived_weight(prob_weight, "c8kzfold", _pack_c8_kzfold_bf16)
+    out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_convtranspose3d_prob_cl_bf16(
+        _chk_cl(x, "x"), ctypes.c_void_p(wt.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"),
+        None if skip is None else _chk_cl(skip, "skip"), int(relu), ctypes.c_void_p(wp.data_ptr()), _opt(prob_bias, "prob_bias"),
+        D, H, W, ctypes.c_void_p(out.data_ptr()), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_convtranspose3d_prob_cl_bf16")
+    dispatch_counts["convtranspose3d_prob_cl"] += 1
+    return out
+
+
 def conv1x1_upskip(x, weight, bias, coarse):
     """conv1x1(x) + bias + nearest-x2 upsampling of `coarse` (FPN lateral, module.py:736-747) in one pass.
     x [Ci,H,W], weight [Co,Ci,1,1], coarse [Co,H/2,W/2].  Returns None for shapes the kernel does not take."""

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 3
+#define D3D_ABI_VERSION 4
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -443,6 +443,14 @@ int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* sc
 int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift,
                                      const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out,
                                      int channel_last, d3d_stream_t stream);
+/* conv11 + prob of a CostRegNet in one kernel (cas_mvsnet.py:103-105,118-119; csrc/conv_t2p.hip):
+ *   y = skip + ReLU(scale * ConvTranspose3d_16->8(in) + shift) rounded to bf16, out = Conv3d_8->1(y) + prob_bias[0];
+ * y lives in LDS only.  in CL [D,H,W,16], skip CL [2D,2H,2W,8] (or null), out planar fp32 [2D,2H,2W]; wt_folded as for
+ * d3d_convtranspose3d_k3s2_cl_bf16(channel_last = 2), wprob_kzfolded as for d3d_conv3d_k3_c1_cl_bf16.  Bit-identical to
+ * those two calls in sequence.  W even; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_convtranspose3d_prob_cl_bf16(const void* in, const void* wt_folded, const float* scale, const float* shift,
+                                     const void* skip, int relu, const void* wprob_kzfolded, const float* prob_bias,
+                                     int D, int H, int W, float* out, d3d_stream_t stream);
 int d3d_volume_planar_to_cl_bf16(const float* in, int C, size_t n, void* out, d3d_stream_t stream);
 int d3d_volume_cl_bf16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream);
 

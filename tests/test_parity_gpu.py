@@ -1065,7 +1065,9 @@ def test_model_forward_at_production_kernel_size_matches_reference(ops, name, mo
     assert sweeps["direct"] == 0 and sweeps["window"] + sweeps["tiled"] > 0, sweeps
     if name == "casmvsnet":
         if mode == "bf16":   # ... the regularisers on channel-last bf16 volumes fed by CL8 variance volumes
-            assert counts.get("variance_cl8", 0) == 3 and counts.get("conv3d_cl8_in", 0) == 3 and counts.get("conv3d_cl", 0) >= 20, counts
+            assert counts.get("variance_cl8", 0) == 3 and counts.get("conv3d_cl8_in", 0) == 3 and counts.get("conv3d_cl", 0) >= 18, counts
+            # conv11 + prob of the three stages in one kernel each (the full-resolution 8-channel volume stays in LDS)
+            assert counts.get("convtranspose3d_prob_cl", 0) == 3 and counts.get("convtranspose3d_cl", 0) == 6, counts
             assert counts.get("conv3d_cl_fallback", 0) == 0 and counts.get("variance_cl_fallback", 0) == 0, counts
     else:                    # ... the slice regularisers' finest level on the 2-D tile kernels (and, bf16 AdaMVS, the fused cell)
         assert counts.get("conv2d_tile", 0) + counts.get("gru_cell_fused", 0) > 0 and counts.get("convtranspose2d_tile", 0) > 0, counts
@@ -1603,6 +1605,42 @@ def test_convtranspose3d_channel_last_bf16(ops, oracle, monkeypatch, Ci, Co, D, 
     assert tuple(plain.shape) == (2 * D, 2 * H, 2 * W, Co)
     _assert_bf16_of(_cl_host(plain), ref, tol)
     _assert_bf16_of(_cl_host(got), want, tol)
+
+
+@pytest.mark.parametrize("D,H,W,skip", [(1, 1, 2, True), (2, 3, 4, True), (4, 10, 30, True), (4, 11, 32, False), (3, 23, 62, True),
+                                         (16, 12, 34, True), (24, 29, 44, True), (5, 40, 128, True)])
+def test_conv11_prob_fused_is_the_two_layers(ops, monkeypatch, D, H, W, skip):
+    """conv11 + prob of a CostRegNet (cas_mvsnet.py:103-105,118-119) in one kernel (d3d_convtranspose3d_prob_cl_bf16: the
+    full-resolution 8-channel volume lives in LDS) against the two launches it replaces -- same K order, same epilogue,
+    same rounding of the intermediate volume: bit-identical, on tile-edge sizes (30 x 10 coarse cells per workgroup), one
+    and several z segments, with and without the skip operand."""
+    rng = np.random.default_rng(D * 100 + W)
+    x = rng.standard_normal((16, D, H, W)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((16, 8, 3, 3, 3))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 8).astype(np.float32)
+    sh = rng.standard_normal(8).astype(np.float32)
+    sk = _cl_dev(rng.standard_normal((8, 2 * D, 2 * H, 2 * W)).astype(np.float32)) if skip else None
+    wp = (0.1 * rng.standard_normal((1, 8, 3, 3, 3))).astype(np.float32)
+    bp = rng.standard_normal(1).astype(np.float32)
+    xd, wd, scd, shd, wpd, bpd = _cl_dev(x), dev(w), dev(sc), dev(sh), dev(wp), dev(bp)
+    before = ops.dispatch_counts["convtranspose3d_prob_cl"]
+    got = ops.convtranspose3d_prob_cl(xd, wd, scd, shd, sk, wpd, bpd)
+    assert got is not None and ops.dispatch_counts["convtranspose3d_prob_cl"] == before + 1
+    y = ops.convtranspose3d_k3s2_cl(xd, wd, scd, shd, sk, relu=True)
+    want = ops.conv3d_k3_cl(y, wpd, None, bpd, None, relu=False, stride=1, out_cl=False)[0]
+    assert tuple(got.shape) == tuple(want.shape) == (2 * D, 2 * H, 2 * W)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want), float((got - want).abs().max())
+    set_kernel(monkeypatch, "t2prob", False)
+    assert ops.convtranspose3d_prob_cl(xd, wd, scd, shd, sk, wpd, bpd) is None   # the switch takes it out of the dispatch
+
+
+def test_conv11_prob_fused_odd_width_not_taken(ops):
+    """W odd: rows of 2 W floats are not made of 16-byte quads -- the entry point declines and the model runs the two layers."""
+    x = torch.zeros(2, 3, 5, 16, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(16, 8, 3, 3, 3, device="cuda")
+    wp = torch.zeros(1, 8, 3, 3, 3, device="cuda")
+    assert ops.convtranspose3d_prob_cl(x, w, None, None, None, wp, None) is None
 
 
 def test_channel_last_layers_fall_back_through_the_planar_kernels(ops, oracle):
