@@ -163,8 +163,10 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
         }
     }
+    bool stzin = false;   // the plane in the staging registers is inside the volume
     auto issue = [&](int zi, int r0, int r1) {   // global loads of input plane zi, rounds [r0, r1), into registers (zeros outside the volume)
         const bool zin = zi >= 0 && zi < D;
+        stzin = zin;
         if constexpr (INCL) {
             const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * plane * (CI * 2);
 #pragma unroll
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                 const int r = r0 + rr;
                 if (r >= r1) break;
                 const u4 v = *reinterpret_cast<const u4*>(src + stoff[r]);
-                stc[rr] = zin && stok[r] ? v : (u4){0, 0, 0, 0};
+                stc[rr] = v;   // raw: zeroed for cells outside the volume when it is committed -- a select here would wait for the load
             }
             return;
         }
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             for (int rr = 0; rr < RH; ++rr) {
                 const int r = r0 + rr;
                 if (r >= r1) break;
-                if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stc[rr];
+                if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stzin && stok[r] ? stc[rr] : (u4){0, 0, 0, 0};
             }
             return;
         }
@@ -462,9 +464,9 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             if (more) issue(zi + 1, 0, ROUNDS);        // the next plane waits in registers
             if (live) sweep(smem, up, mid, down, 0, NKB);
             store_plane(zi - 1, down);
-            __syncthreads();                           // every wave has read the patch
+            lds_barrier();                             // every wave has read the patch (LDS only: the plane's stores stay in flight)
             if (more) commit(smem, 0, ROUNDS);
-            __syncthreads();
+            lds_barrier();
             return;
         }
         if (more) issue(zi + 1, 0, RH);                // the next plane's loads fly during the MFMA sweep
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
         if (live) sweep(smem + cur * PATCH, up, mid, down, KH, NKB);
         store_plane(zi - 1, down);                     // complete: it has seen input planes zi-2, zi-1, zi
         if (more && ROUNDS > RH) commit(smem + (cur ^ 1) * PATCH, RH, ROUNDS);
-        __syncthreads();
+        lds_barrier();                                 // (LDS only: the stores of the finished plane stay in flight, common.h)
         cur ^= 1;
     };
     if constexpr (KZF) {

@@ -86,32 +86,39 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
     u4 stc[ROUNDS];
+    // What a task reads and writes is the same for every plane: per-lane state computed once (these kernels are bound by
+    // instruction issue -- profiles/r04_t2p.txt -- and the per-plane address arithmetic was most of their vector instructions).
+    // Loads are clamped into the image and always issued; the value is zeroed outside.
+    unsigned stoff[ROUNDS];   // byte offset of the task's 16 bytes inside an input plane (host: a plane is < 2^31 bytes)
+    int stdst[ROUNDS];        // its cell in the patch, -1: no task
+    bool stok[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int task = tid + r * NT;
+        const int pix = task / G, g = task - pix * G;
+        const int py = pix / PXI, px = pix - py * PXI;
+        const int gx = 2 * xo0 - 1 + px, gy = 2 * yo0 - 1 + py;
+        stok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        stoff[r] = ((unsigned)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * (CI * 2) + g * 16;
+        const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
+        stdst[r] = task < NTASK ? cell * CS + g * 16 : -1;
+    }
+    const size_t iplane = (size_t)H * W * (CI * 2);
+    bool stzin = false;   // the plane in the staging registers is inside the volume
     auto issue = [&](int zi) {
         const bool zin = zi >= 0 && zi < D;
+        stzin = zin;
+        const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * iplane;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NT;
-            const int pix = task / G, g = task - pix * G;
-            const int py = pix / PXI, px = pix - py * PXI;
-            const int gx = 2 * xo0 - 1 + px, gy = 2 * yo0 - 1 + py;
-            const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
-                (ok ? (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16 : 0);
-            const u4 v = *reinterpret_cast<const u4*>(src);
-            stc[r] = ok ? v : (u4){0, 0, 0, 0};
+            const u4 v = *reinterpret_cast<const u4*>(src + stoff[r]);
+            stc[r] = v;   // raw: zeroed for cells outside the volume when it is committed -- a select here would wait for the load
         }
     };
     auto commit = [&](unsigned char* dst) {
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NT;
-            if (task < NTASK) {
-                const int pix = task / G, g = task - pix * G;
-                const int py = pix / PXI, px = pix - py * PXI;
-                const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
-                *reinterpret_cast<u4*>(dst + cell * CS + g * 16) = stc[r];
-            }
-        }
+        for (int r = 0; r < ROUNDS; ++r)
+            if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stzin && stok[r] ? stc[r] : (u4){0, 0, 0, 0};
     };
 
     // K index k = 32 kb + 8 (lane >> 4) + j -> tap t = k / CI = (k_y, k_x), channel k % CI.  Output pixel m of the row reads
@@ -124,6 +131,11 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
         return (ky * PXI + col) * CS + (t < 9 ? c : 0) * 2;
     };
     const int abase = (2 * wave * PXI + (lane & 15)) * CS;
+    int aoffs[WG ? 1 : NKB];   // one register per K block, computed once (WG: tiny volumes, per use)
+    if constexpr (!WG) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) aoffs[kb] = a_offset(kb, lane >> 4);
+    }
 
     f4 acc[2][AW];
 #pragma unroll
@@ -132,25 +144,38 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
         for (int i = 0; i < AW; ++i) acc[s][i] = (f4){0, 0, 0, 0};
 
     const int oy = yo0 + wave;
+    // plane-invariant state of the epilogue: affine per channel tile, offsets inside an output plane and store masks per pixel group
+    f4 esc[NTN], esh[NTN];
+    bool est[NTN][MG];
+    unsigned eoff[MG];   // bf16 elements inside an output plane, channel tile 0 (host: a plane is < 2^31 elements)
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int cb = nt * 16 + (lane >> 4) * 4;
+        const bool cin = cb < p.CO;
+        esc[nt] = p.scale && cin ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+        esh[nt] = p.shift && cin ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) est[nt][mg] = cin && xo0 + mg * 16 + (lane & 15) < p.Wo;
+    }
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg)
+        eoff[mg] = ((unsigned)min(oy, p.Ho - 1) * p.Wo + min(xo0 + mg * 16 + (lane & 15), p.Wo - 1)) * p.CO + (lane >> 4) * 4;
+    const size_t oplane = (size_t)p.Ho * p.Wo * p.CO;
     auto store_plane = [&](int zo, f4 (&a)[AW]) {
         if (oy < p.Ho && zo >= zo0) {
+            const unsigned short* __restrict__ sk = static_cast<const unsigned short*>(p.skip) + (size_t)zo * oplane;
+            unsigned short* __restrict__ dst = static_cast<unsigned short*>(p.out) + (size_t)zo * oplane;
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                const int cb = nt * 16 + (lane >> 4) * 4;
-                if (cb < p.CO) {
-                    const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
-                    const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
 #pragma unroll
-                    for (int mg = 0; mg < MG; ++mg) {
-                        const int ox = xo0 + mg * 16 + (lane & 15);
-                        if (ox < p.Wo) {
-                            const size_t o = (((size_t)zo * p.Ho + oy) * p.Wo + ox) * p.CO + cb;   // bf16 element index
-                            f4 v = a[mg * NTN + nt] * sc + sh;
-                            if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                            if (p.skip) v += unpack_bf16x4_cl(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
-                            const uint2 pk = {pack_bf16_cl(v[0], v[1]), pack_bf16_cl(v[2], v[3])};
-                            *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
-                        }
+                for (int mg = 0; mg < MG; ++mg) {
+                    if (est[nt][mg]) {
+                        const unsigned o = eoff[mg] + nt * 16;
+                        f4 v = a[mg * NTN + nt] * esc[nt] + esh[nt];
+                        if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                        if (p.skip) v += unpack_bf16x4_cl(*reinterpret_cast<const uint2*>(sk + o));
+                        const uint2 pk = {pack_bf16_cl(v[0], v[1]), pack_bf16_cl(v[2], v[3])};
+                        *reinterpret_cast<uint2*>(dst + o) = pk;
                     }
                 }
             }
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
         int kgroup = lane >> 4;
         asm volatile("" : "+v"(kgroup));
 auto kb_body = [&](int kb) {
-            const int aoffk = a_offset(kb, kgroup);
+            const int aoffk = WG ? a_offset(kb, kgroup) : aoffs[WG ? 0 : kb];
             bf16x8 w1[NTN], w2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
@@ -200,9 +225,9 @@ auto kb_body = [&](int kb) {
         const bool more = zi < zlast, live = zi >= 0 && zi < D;
         if (more) issue(zi + 1);
         if (live) sweep(smem + cur * PATCH, 2, lo, 0, hi, true);
+        if (more) commit(smem + (cur ^ 1) * PATCH);   // before the stores: waiting for the staged loads must not wait for them too
         store_plane((zi - 1) >> 1, lo);
-        if (more) commit(smem + (cur ^ 1) * PATCH);
-        __syncthreads();
+        lds_barrier();                                // (LDS only: the stores stay in flight, common.h)
         cur ^= 1;
     };
     auto even_step = [&](f4 (&mid)[AW]) {               // zi = 2a: k_z = 1 of output plane a; never the last plane
@@ -210,7 +235,7 @@ auto kb_body = [&](int kb) {
         issue(zi + 1);
         if (live) sweep(smem + cur * PATCH, 1, mid, 1, mid, false);
         commit(smem + (cur ^ 1) * PATCH);
-        __syncthreads();
+        lds_barrier();
         cur ^= 1;
     };
     while (true) {
@@ -287,7 +312,7 @@ extern "C" int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, cons
     p.D = D; p.H = H; p.W = W; p.Do = (D - 1) / 2 + 1; p.Ho = (H - 1) / 2 + 1; p.Wo = (W - 1) / 2 + 1; p.CO = Co; p.relu = relu;
     const bool shape = (Ci == 8 && Co == 16) || (Ci == 16 && Co == 32) || (Ci == 8 && Co == 8) || (Ci == 16 && Co == 16) ||
                        (Ci == 32 && Co == 64);
-    if (!shape || ceil_div(p.Ho, TYO) > 65535 || p.Do > 65535) {
+    if (!shape || ceil_div(p.Ho, TYO) > 65535 || p.Do > 65535 || (long)H * W * Ci * 2 >= (1L << 31)) {   // (32-bit offsets inside a plane)
         set_error("d3d_conv3d_k3s2_cl_bf16: %d -> %d channels not taken (8->8, 8->16, 16->16, 16->32, 32->64)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }

@@ -111,8 +111,36 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
     float stg[CL ? 1 : ROUNDS][8];
     u4 stc[CL ? ROUNDS : 1];
+    // channel-last input: a task's offset inside an input plane (clamped: always loaded, zeroed outside), its cell and whether it is
+    // inside are per-lane state computed once (instruction issue bounds these kernels, see conv_c8.hip)
+    unsigned stoff[CL ? ROUNDS : 1];
+    int stdst[CL ? ROUNDS : 1];
+    bool stok[CL ? ROUNDS : 1];
+    if constexpr (CL) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PXI, px = pix - py * PXI;
+            const int gx = ix0 + px, gy = iy0 + py;
+            stok[r] = task < NTASK && gx < W && gy < H;
+            stoff[r] = ((unsigned)min(gy, H - 1) * W + min(gx, W - 1)) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes)
+            stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
+        }
+    }
+    bool stzin = false;   // the plane in the staging registers is inside the volume
     auto issue = [&](int zi) {
         const bool zin = zi >= 0 && zi < D;
+        stzin = zin;
+        if constexpr (CL) {
+            const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * iplane * (CI * 2);
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const u4 v = *reinterpret_cast<const u4*>(src + stoff[r]);
+                stc[r] = v;   // raw: zeroed for cells outside the volume when it is committed -- a select here would wait for the load
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int task = tid + r * NT;
@@ -120,23 +148,22 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             const int py = pix / PXI, px = pix - py * PXI;
             const int gx = ix0 + px, gy = iy0 + py;
             const bool ok = zin && task < NTASK && gx < W && gy < H;
-            if constexpr (CL) {
-                const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) +
-                    (ok ? (((size_t)zi * H + gy) * W + gx) * (CI * 2) + g * 16 : 0);
-                const u4 v = *reinterpret_cast<const u4*>(src);
-                stc[r] = ok ? v : (u4){0, 0, 0, 0};
-            } else {
-                const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * ivol + (size_t)(ok ? zi : 0) * iplane +
-                    (ok ? (size_t)gy * W + gx : 0);
+            const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * ivol + (size_t)(ok ? zi : 0) * iplane +
+                (ok ? (size_t)gy * W + gx : 0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float v = src[(size_t)k * ivol];
-                    stg[r][k] = ok ? v : 0.0f;
-                }
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(size_t)k * ivol];
+                stg[r][k] = ok ? v : 0.0f;
             }
         }
     };
     auto commit = [&](unsigned char* dst) {
+        if constexpr (CL) {
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r)
+                if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stzin && stok[r] ? stc[r] : (u4){0, 0, 0, 0};
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int task = tid + r * NT;
@@ -173,6 +200,29 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     const int iy = iy0 + wave;                     // this wave's input row
     const int abase = (wave * PXI + (lane & 15)) * CS;
 
+    // plane-invariant state of the channel-last epilogues: affine of the lane's four channels, offsets (bf16 elements) inside
+    // an output plane of output row 2 iy (+ PY rows of 2 W cells) and store masks per pixel group
+    f4 esc[CL ? NTN : 1], esh[CL ? NTN : 1];
+    unsigned eoff[CL ? MG : 1];
+    bool est[CL ? NTN : 1][CL ? MG : 1];
+    if constexpr (CL) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+            const int cb = FOLD ? (g & 1) * 4 : nt * 16 + g * 4;
+            const bool cin = cb < p.CO;
+            esc[nt] = p.scale && cin ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
+            esh[nt] = p.shift && cin ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) est[nt][mg] = cin && iy < H && ix0 + mg * 16 + (lane & 15) < W;
+        }
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            const int ix = min(ix0 + mg * 16 + (lane & 15), W - 1);
+            eoff[mg] = ((unsigned)(2 * min(iy, H - 1)) * OW + 2 * ix + (FOLD ? g >> 1 : 0)) * p.CO + (FOLD ? (g & 1) * 4 : g * 4);   // (host: a plane is < 2^31 elements)
+        }
+    }
+    const size_t oplane_cl = (size_t)4 * iplane * p.CO;   // bf16 elements of a channel-last output plane
     // one (pz, py) row of outputs: both column parities, all pixel groups and channel tiles
     auto row = [&](auto pzc, auto pyc, int oz, const unsigned char* b0, const unsigned char* b1) {
         constexpr int PZ = decltype(pzc)::value, PY = decltype(pyc)::value;
@@ -180,8 +230,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             f4 accf[MG];
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) accf[mg] = (f4){0, 0, 0, 0};
-            int kgroup = lane >> 4;
-            asm volatile("" : "+v"(kgroup));
+            const int kgroup = lane >> 4;   // (not opaque: the K offsets are plane-invariant, the compiler keeps or folds them)
             constexpr int NKB = nkb(CI, PZ, PY, 1);
             constexpr int FB = fold_base(CI, PZ * 2 + PY);
 #pragma unroll
@@ -200,21 +249,17 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                 }
             }
             // D row (lane >> 4) * 4 + r = (column parity, channel), column = input pixel lane & 15
-            if (iy < H) {
-                const int g = lane >> 4, cb = (g & 1) * 4, px = g >> 1;
-                const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
-                const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
-                const int oyf = 2 * iy + PY;
+            {
+                const unsigned short* __restrict__ sk = static_cast<const unsigned short*>(p.skip) + (size_t)oz * oplane_cl + PY * (OW * 8);
+                unsigned short* __restrict__ dst = static_cast<unsigned short*>(p.out) + (size_t)oz * oplane_cl + PY * (OW * 8);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
-                    const int ix = ix0 + mg * 16 + (lane & 15);
-                    if (ix < W) {
-                        const size_t o = (((size_t)oz * (2 * H) + oyf) * OW + 2 * ix + px) * 8 + cb;   // bf16 element index
-                        f4 v = accf[mg] * sc + sh;
+                    if (est[0][mg]) {
+                        f4 v = accf[mg] * esc[0] + esh[0];
                         if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                        if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                        if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(sk + eoff[mg]));
                         const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
-                        *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
+                        *reinterpret_cast<uint2*>(dst + eoff[mg]) = pk;
                     }
                 }
             }
@@ -227,8 +272,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             for (int mg = 0; mg < MG; ++mg)
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) acc[px][mg][nt] = (f4){0, 0, 0, 0};
-        int kgroup = lane >> 4;
-        asm volatile("" : "+v"(kgroup));
+        const int kgroup = lane >> 4;
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
             const int NKB = nkb(CI, PZ, PY, px);
@@ -287,27 +331,21 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
         if constexpr (CL) {
             // weights were the A operand: D row = channel (lane >> 4) * 4 + register, column = input pixel lane & 15; a lane
             // stores four consecutive channels of the output pixels (2 ix, 2 ix + 1) = one 8-byte store each
-            if (iy < H) {
+            const unsigned short* __restrict__ sk = static_cast<const unsigned short*>(p.skip) + (size_t)oz * oplane_cl + (size_t)PY * OW * p.CO;
+            unsigned short* __restrict__ dst = static_cast<unsigned short*>(p.out) + (size_t)oz * oplane_cl + (size_t)PY * OW * p.CO;
 #pragma unroll
-                for (int nt = 0; nt < NTN; ++nt) {
-                    const int cb = nt * 16 + (lane >> 4) * 4;
-                    if (cb < p.CO) {
-                        const f4 sc = p.scale ? *reinterpret_cast<const f4*>(p.scale + cb) : (f4){1, 1, 1, 1};
-                        const f4 sh = p.shift ? *reinterpret_cast<const f4*>(p.shift + cb) : (f4){0, 0, 0, 0};
+            for (int nt = 0; nt < NTN; ++nt) {
 #pragma unroll
-                        for (int mg = 0; mg < MG; ++mg) {
-                            const int ix = ix0 + mg * 16 + (lane & 15);
-                            if (ix < W) {
+                for (int mg = 0; mg < MG; ++mg) {
+                    if (est[nt][mg]) {
 #pragma unroll
-                                for (int px = 0; px < 2; ++px) {
-                                    const size_t o = (((size_t)oz * (2 * H) + oy) * OW + 2 * ix + px) * p.CO + cb;   // bf16 element index
-                                    f4 v = acc[px][mg][nt] * sc + sh;
-                                    if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                                    if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
-                                    const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
-                                    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
-                                }
-                            }
+                        for (int px = 0; px < 2; ++px) {
+                            const unsigned o = eoff[mg] + px * p.CO + nt * 16;
+                            f4 v = acc[px][mg][nt] * esc[nt] + esh[nt];
+                            if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
+                            if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(sk + o));
+                            const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
+                            *reinterpret_cast<uint2*>(dst + o) = pk;
                         }
                     }
                 }
@@ -363,7 +401,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             row(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, oz, b0, b1);
             row(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, oz, b0, b1);
         }
-        __syncthreads();
+        lds_barrier();   // (LDS only: the stores of the plane stay in flight, common.h)
     }
 }
 
@@ -398,7 +436,7 @@ extern "C" int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpac
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     const bool shape = (Ci == 16 && Co == 8) || (Ci == 16 && Co == 16) || (Ci == 32 && Co == 16) || (Ci == 64 && Co == 32);
-    if (!shape || ceil_div(H, TYI) > 65535 || 2 * D > 65535) {
+    if (!shape || ceil_div(H, TYI) > 65535 || 2 * D > 65535 || (channel_last && (long)H * W * 4 * (Ci > Co ? Ci : Co) * 2 >= (1L << 31))) {   // (32-bit offsets inside a plane)
         set_error("d3d_convtranspose3d_k3s2_cl_bf16: %d -> %d channels not taken (16->8, 16->16, 32->16, 64->32)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }

@@ -120,19 +120,21 @@ __global__ __launch_bounds__(NT, 4) void convt3d_prob_kernel(T2PParams p) {
         stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
     }
     u4 stc[ROUNDS];
+    bool stzin = false;   // the plane in the staging registers is inside the volume
     auto issue = [&](int zi) {
         const bool zin = zi >= 0 && zi < D;
+        stzin = zin;
         const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * iplane;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const u4 v = *reinterpret_cast<const u4*>(src + stoff[r]);
-            stc[r] = zin && stok[r] ? v : (u4){0, 0, 0, 0};
+            stc[r] = v;   // raw: zeroed for cells outside the volume when it is committed -- a select here would wait for the load
         }
     };
     auto commit = [&](unsigned char* dst) {
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r)
-            if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stc[r];
+            if (stdst[r] >= 0) *reinterpret_cast<u4*>(dst + stdst[r]) = stzin && stok[r] ? stc[r] : (u4){0, 0, 0, 0};
     };
 
     // ---- conv11: this wave's tiles are coarse rows r0 + 4 t (t < 3), 16-cell group mg ----------------------------------
