@@ -41,6 +41,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
 }
 
+// sigmoid and tanh of the conv-GRU epilogues (adamvs.py:60-72 / module.py ConvGRUCell: torch.sigmoid, torch.tanh): one v_exp_f32
+// and one v_rcp_f32 each, ~2e-7 of the exact value (relative for the sigmoid, absolute for the tanh) -- far inside what the
+// state's own fp32 rounding moves.  The IEEE division and tanhf they replace expand to ~12 and ~35 instructions per value, a
+// quarter of the fused cell's instruction stream.  Every kernel family uses these two, so fused and unfused cells agree bit for bit.
+__device__ __forceinline__ float gru_sigmoid(float y) { return __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
+__device__ __forceinline__ float gru_tanh(float y) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * y)); }
+
 // Workgroup barrier for data handed over through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the
 // fence waits for EVERY memory operation the wave has in flight (s_waitcnt vmcnt(0)): the global stores of the plane just
 // finished and the global loads issued ahead for a later plane -- a z-streaming kernel then pays a store's round trip per

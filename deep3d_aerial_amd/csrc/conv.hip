@@ -675,11 +675,11 @@ __global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
                     if (p.scale) yv *= p.scale[o];
                     if (p.shift) yv += p.shift[o];
                     if (p.act == 2) {
-                        yv = 1.0f / (1.0f + __expf(-yv));
+                        yv = gru_sigmoid(yv);
                         if (o < p.ep_split) yv *= p.skip[oidx];
                     } else {
                         const float u = p.aux1[oidx], hv = p.skip[oidx];
-                        yv = u * hv + (1.0f - u) * tanhf(yv);
+                        yv = u * hv + (1.0f - u) * gru_tanh(yv);
                     }
                     p.out[oidx] = yv;
                 }

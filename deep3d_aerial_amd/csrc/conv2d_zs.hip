@@ -309,12 +309,12 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
                 }
                 if (p.act == 2) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = 1.0f / (1.0f + __expf(-y[k]));
+                    for (int k = 0; k < 4; ++k) y[k] = gru_sigmoid(y[k]);
                     if (gate_h) y *= *reinterpret_cast<const f4*>(p.skip + o);
                 } else if (p.act == 3) {
                     const f4 u = *reinterpret_cast<const f4*>(p.aux1 + o), hh = *reinterpret_cast<const f4*>(p.skip + o);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * tanhf(y[k]);
+                    for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * gru_tanh(y[k]);
                 } else {
                     if (p.skip && !p.skip_after_act) y += *reinterpret_cast<const f4*>(p.skip + o);
                     if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});

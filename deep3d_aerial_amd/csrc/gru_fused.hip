@@ -6,7 +6,7 @@
 //       c  = tanh(conv3x3(cat(x, r * h)) + b_c)
 //       h' = u * h + (1 - u) * c
 //   Round 2/3 ran this as three launches of the tile kernel (csrc/conv2d_zs.hip) that move x, h, r*h, u through HBM five
-//   times (72 channel-planes per cell where 24 are compulsory) and are latency-bound at the cascade's image sizes.  Here a
+//   times (72 channel-planes per cell where 24 are compulsory).  Here a
 //   workgroup owns output tiles of (16 MG - 8) x TY pixels and keeps everything between `cost` / `h` and `h'` in LDS:
 //
 //     stage   cost patch (halo 3) and h patch (halo 2): planar fp32 -> channel-last bf16 cells (RNE), zeros outside the image
@@ -18,9 +18,10 @@
 //
 //   Every phase is the implicit GEMM of conv2d_zs.hip (M = 16 consecutive pixels of a region row, N = 16 output channels,
 //   K = (k_y, k_x, c_in) in blocks of 32 = v_mfma_f32_16x16x32_bf16; an A operand is one ds_read_b128 of 8 channels), on the
-//   SAME K order and the same packed weights (ops._pack_z2_bf16), with the same epilogue expressions -- so h' is bit-identical to
-//   the three-launch form (tests/test_parity_gpu.py::test_gru_cell_fused_*; v_exp / v_rcp forms of sigmoid and tanh were
-//   measured -- 411 -> 405 us at stage 3 -- and dropped: a cell is a chain of latencies, not an instruction count).  All phases run on the 16 MG-column grid of the
+//   SAME K order and the same packed weights (ops._pack_z2_bf16), with the same epilogue expressions (sigmoid / tanh of common.h in
+//   both) -- so h' is bit-identical to the three-launch form (tests/test_parity_gpu.py::test_gru_cell_fused_*).  P1 runs the
+//   transposed GEMM (weights as the A operand: a lane then holds four channels of one pixel, one 8-byte cell write); P2 / P3 run
+//   on the 16 MG-column grid of the
 //   region: the outermost columns of P2 / P3 read one cell beyond the region (row pitch 16 MG + 2 cells) and their results are
 //   dropped, which keeps a lane's four pixels the same in P2 and P3 (u never leaves its registers).
 //
@@ -38,19 +39,19 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-// D3D_GRU_X (timing experiments only, results wrong; never set in the production build: d3d_build_flags reports it):
-//   1 no staging loads | 2 no h loads in the gate epilogue | 4 no exp / tanh | 8 no stores | 16 no matrix-core loops
-#ifndef D3D_GRU_X
-#define D3D_GRU_X 0
-#endif
-// The next tile's patches are requested a phase ahead where a workgroup owns its CU (LDS > 80 KB: 256 registers, +3 .. 7 %);
-// the 8-channel stride-1 instance shares the CU with a second workgroup at 128 registers, where the prefetched patches spill
-// (593 against 411 us at stage 3) -- there the other workgroup is what overlaps the loads.  -DD3D_GRU_PREFETCH=0|1 forces it.
+// The cell is bound by instruction issue (profiles/r04_gru_slice.txt, second part): a tile of the first build was 1650 vector
+// instructions per wave for 63 MFMAs -- per-tile index arithmetic recomputed from opaque lane ids, selects behind every load,
+// IEEE divisions and tanhf, 2-byte LDS writes.  This build keeps everything that does not change from tile to tile as per-lane
+// state, reads and writes global memory through buffer instructions (a 32-bit per-lane offset that is OOB for pixels outside the
+// image -- the hardware returns zeros / drops the store -- plus scalar tile and channel offsets: no address arithmetic and no
+// select on the vector unit), writes x channel-last from the transposed GEMM (8 bytes per lane), and takes sigmoid / tanh from
+// common.h.  -DD3D_GRU_PREFETCH=0|1 forces the patch prefetch off / on; -DD3D_GRU_WAVES2 the register budget of the small instance.
 #ifndef D3D_GRU_WAVES2
 #define D3D_GRU_WAVES2 4   // waves per SIMD the small-LDS instances are compiled for (4: two workgroups per CU, 128 registers)
 #endif
 constexpr int GW = 8;            // waves per workgroup
 constexpr int GNT = 64 * GW;
+constexpr unsigned OOB = 0xffffffffu;   // a buffer offset outside every tensor: loads return zeros, stores are dropped
 
 struct GruParams {
     const float* cost;   // [CP, HI, WI]: input of the leading convolution (HI, WI = H, W for S = 1; the finer level for S = 2)
@@ -69,9 +70,15 @@ struct GruParams {
 __device__ __forceinline__ unsigned pack_bf16_g(float a, float b) {
     return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
-__device__ __forceinline__ unsigned short bf16_bits(float a) {
-    const __bf16 x = (__bf16)a;
-    return __builtin_bit_cast(unsigned short, x);
+// raw buffer over a tensor from `origin` on (which may lie before the tensor: lanes that would read there carry OOB offsets)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor_rsrc(const void* origin) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, (int)0xfffffffeu, 0x00020000);
+}
+__device__ __forceinline__ f4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float dpp_row_shl8(float v) {   // lane m of a 16-lane row takes lane m + 8
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xf, 0xf, true));
 }
 
 template <int CP, int HID, int S, int MG, int TY>
@@ -90,140 +97,175 @@ struct GruGeom {
     static constexpr int LDS = SIMB + 3 * REG + WB;
 };
 
-// A workgroup walks `tper` tiles down the image: the weights are loaded once, and the next tile's cost / state patches are
-// in flight (registers) while the current tile is swept -- at these image sizes a cell is a chain of latencies (patch
-// loads, three barriers, the state's fp32 reload for the epilogues), not arithmetic: profiles/r04_gru_slice.txt.
+// A workgroup walks `tper` tiles down the image: the weights are loaded once, and (PREFETCH) the next tile's cost / state
+// patches are in flight -- raw, in registers -- while the current tile is swept.
 template <int CP, int HID, int S, int MG, int TY>
-__global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024 ? D3D_GRU_WAVES2 : 2)) void gru_cell_fused_kernel(GruParams p) {   // two workgroups per CU where the LDS allows: 128 registers
+__global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024 ? D3D_GRU_WAVES2 : 2)) void gru_cell_fused_kernel(GruParams p) {
     using G = GruGeom<CP, HID, S, MG, TY>;
     constexpr int RX = G::RX, RY = G::RY, PITCH = G::PITCH, XC = G::XC, REG = G::REG, CS1 = G::CS1, SPX = G::SPX, SPY = G::SPY;
     constexpr int NEVEN = G::NEVEN, NKB1 = G::NKB1, NKBG = G::NKBG, NTNG = G::NTNG;
 #ifdef D3D_GRU_PREFETCH
     constexpr bool PREFETCH = D3D_GRU_PREFETCH != 0;
 #else
-    constexpr bool PREFETCH = G::LDS > 80 * 1024;
+    constexpr bool PREFETCH = true;
 #endif
     static_assert(HID == 8 || HID == 16, "hidden state of 8 or 16 channels");
-    static_assert((TY * MG) % GW == 0, "every wave keeps the same number of candidate tasks");
-    static_assert(2 * MG <= GW, "one halo-row task per wave at most");
+    static_assert(MG == 4 && GW == 8, "a wave's tasks: rows (wave >> 2) + 2 t of pixel group wave & 3");
+    static_assert((TY * MG) % GW == 0 && (RY * MG) % GW == 0, "every wave keeps the same number of tasks");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sim = smem;
-    unsigned char* XA = smem + G::SIMB;
-    unsigned char* HA = XA + REG;
-    unsigned char* RA = HA + REG;
-    u4* w1l = reinterpret_cast<u4*>(RA + REG);
-    u4* wgl = w1l + NKB1 * 64;
-    u4* wcl = wgl + NKBG * NTNG * 64;
+    // LDS: X | H | R regions first (their cell offsets fit the DS instructions' 16-bit immediates), cost patch, weights
+    unsigned char* const XA = smem;
+    unsigned char* const sim = smem + 3 * REG;
+    u4* const w1l = reinterpret_cast<u4*>(sim + G::SIMB);
+    u4* const wgl = w1l + NKB1 * 64;
+    u4* const wcl = wgl + NKBG * NTNG * 64;
 
-    int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int H = p.H, W = p.W;
-    const size_t plane = (size_t)H * W, iplane = (size_t)p.HI * p.WI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, HI = p.HI, WI = p.WI;
+    const unsigned plane4 = (unsigned)H * W * 4, iplane4 = (unsigned)HI * WI * 4;   // bytes of a channel plane (host: tensors < 2^31 bytes)
     const int rx0 = blockIdx.x * G::OX - 4;   // first region column: a multiple of 4 (the lanes' pixel quads are 16-byte aligned)
     const int nty = (H + TY - 1) / TY;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
-    int m = lane & 15, kgroup = lane >> 4;
+    const int m = lane & 15, kg = lane >> 4;
 
     // ---- weights (once per workgroup) ------------------------------------------------------------------------------------
     for (int i = tid; i < NKB1 * 64; i += GNT) w1l[i] = p.w1[i];
     for (int i = tid; i < NKBG * NTNG * 64; i += GNT) wgl[i] = p.wg[i];
     for (int i = tid; i < NKBG * 64; i += GNT) wcl[i] = p.wc[i];
 
-    // ---- staging: a task = (row, aligned quad of 4 pixels, 4 channels): four dwordx4 loads (W % 4 == 0 and a region that starts
-    //      at a multiple of 4: a quad is inside or outside the image as a whole) -> four 8-byte chunks of channel-last bf16
-    //      cells; zeros outside the image.  issue_*() leaves the values in registers, commit_*() writes the cells: the loads of
-    //      tile t + 1 fly during P1 (cost) and P2 (state) of tile t.
+    // ---- staging: a task = (row, aligned quad of 4 pixels, 4 channels): four 16-byte loads (W % 4 == 0 and a region that starts
+    //      at a multiple of 4: a quad is inside or outside the image as a whole) -> four 8-byte chunks of channel-last bf16 cells.
     //      cost patch: columns gxc0 .. gxc0 + SPX - 1 with gxc0 = rx0 - 1 (S = 1) | 2 rx0 - 1 (S = 2); the quads start at
-    //      gxc0 - 3 (a multiple of 4) and the 3 + (4 NQC - SPX - 3) columns outside the patch are dropped at the commit.
+    //      gxc0 - 3 (a multiple of 4) and the columns outside the patch are dropped at the commit.
+    //      Per task and for good: its byte offset from the patch origin (OOB where the column is outside the image), its patch
+    //      row, its first cell; per tile: rows outside the image turn the offset OOB (a uniform test skips that for inner tiles).
     constexpr int NQC = (SPX + 3 + 3) / 4, C4C = CP / 4, NTC = SPY * NQC * C4C, RC = (NTC + GNT - 1) / GNT;
     constexpr int NQH = RX / 4, C4H = HID / 4, NTH = RY * NQH * C4H, RH = (NTH + GNT - 1) / GNT;
+    const int qx0 = (S == 2 ? 2 * rx0 : rx0) - 4;
+    unsigned cvo[RC];    // cost task: offset | OOB
+    int cpy[RC], ccell[RC];
+    bool ckeep[RC][4];   // the pixel's column lies inside the patch
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+        const int task = r * GNT + tid;
+        const int q = task % NQC, rest = task / NQC, c4 = rest % C4C, py = rest / C4C;
+        const int gx = qx0 + 4 * q;
+        cvo[r] = task < NTC && gx >= 0 && gx < WI ? (unsigned)(4 * c4) * iplane4 + (unsigned)(py * WI + 4 * q) * 4 : OOB;
+        cpy[r] = py;
+        const int px0 = 4 * q - 3;   // patch column of the quad's first pixel (odd)
+        ccell[r] = task < NTC ? (S == 2 ? py * SPX + NEVEN + ((px0 - 1) >> 1) : py * SPX + px0) * CS1 + c4 * 8 : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ckeep[r][i] = task < NTC && px0 + i >= 0 && px0 + i < SPX;
+    }
+    unsigned hvo[RH];
+    int hpy[RH], hcell[RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+        const int task = r * GNT + tid;
+        const int q = task % NQH, rest = task / NQH, c4 = rest % C4H, py = rest / C4H;
+        const int gx = rx0 + 4 * q;
+        hvo[r] = task < NTH && gx >= 0 && gx < W ? (unsigned)(4 * c4) * plane4 + (unsigned)(py * W + 4 * q) * 4 : OOB;
+        hpy[r] = py;
+        hcell[r] = task < NTH ? REG + (py * PITCH + 4 * q + 1) * XC + c4 * 8 : -1;   // (H region = XA + REG)
+    }
     f4 sc[RC][4], sh[RH][4];
     auto issue_cost = [&](int ty) {
-        const int ry0 = ty * TY - 2;
-        const int qx0 = (S == 2 ? 2 * rx0 : rx0) - 4, gy0 = S == 2 ? 2 * ry0 - 1 : ry0 - 1;
+        const int gy0 = S == 2 ? 2 * (ty * TY - 2) - 1 : ty * TY - 3;
+        const __amdgpu_buffer_rsrc_t rs = tensor_rsrc(p.cost + ((long)gy0 * WI + qx0));
+        const bool inner = gy0 >= 0 && gy0 + SPY <= HI;
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
-            const int task = r * GNT + tid;
-            const int q = task % NQC, rest = task / NQC, c4 = rest % C4C, py = rest / C4C;
-            const int gx = qx0 + 4 * q, gy = gy0 + py;
-            const bool ok = task < NTC && gx >= 0 && gx < p.WI && gy >= 0 && gy < p.HI;
-            const float* __restrict__ src = p.cost + (size_t)(4 * c4) * iplane + (ok ? (size_t)gy * p.WI + gx : 0);
+            unsigned vo = cvo[r];
+            if (!inner) vo = (unsigned)(cpy[r] + gy0) < (unsigned)HI ? vo : OOB;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f4 t = (D3D_GRU_X & 1) ? (f4){0.5f, 0.5f, 0.5f, 0.5f} : *reinterpret_cast<const f4*>(src + (size_t)k * iplane);
-                sc[r][k] = ok ? t : (f4){0, 0, 0, 0};
-            }
+            for (int k = 0; k < 4; ++k) sc[r][k] = buf_load4(rs, vo, k * iplane4);
         }
     };
     auto issue_state = [&](int ty) {
         const int ry0 = ty * TY - 2;
+        const __amdgpu_buffer_rsrc_t rs = tensor_rsrc(p.h + ((long)ry0 * W + rx0));
+        const bool inner = ry0 >= 0 && ry0 + RY <= H;
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
-            const int task = r * GNT + tid;
-            const int q = task % NQH, rest = task / NQH, c4 = rest % C4H, py = rest / C4H;
-            const int gx = rx0 + 4 * q, gy = ry0 + py;
-            const bool ok = task < NTH && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = p.h + (size_t)(4 * c4) * plane + (ok ? (size_t)gy * W + gx : 0);
+            unsigned vo = hvo[r];
+            if (!inner) vo = (unsigned)(hpy[r] + ry0) < (unsigned)H ? vo : OOB;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f4 t = (D3D_GRU_X & 1) ? (f4){0.25f, 0.25f, 0.25f, 0.25f} : *reinterpret_cast<const f4*>(src + (size_t)k * plane);
-                sh[r][k] = ok ? t : (f4){0, 0, 0, 0};
-            }
+            for (int k = 0; k < 4; ++k) sh[r][k] = buf_load4(rs, vo, k * plane4);
         }
     };
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     auto commit_cost = [&]() {
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
-            const int task = r * GNT + tid;
-            if (task < NTC) {
-                const int q = task % NQC, rest = task / NQC, c4 = rest % C4C, py = rest / C4C;
+            if (ccell[r] < 0) continue;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int px = 4 * q + i - 3;   // column of the patch
-                    if (px >= 0 && px < SPX) {
-                        const int cell = S == 2 ? py * SPX + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1)) : py * SPX + px;
-                        *reinterpret_cast<u2*>(sim + cell * CS1 + c4 * 8) =
-                            (u2){pack_bf16_g(sc[r][0][i], sc[r][1][i]), pack_bf16_g(sc[r][2][i], sc[r][3][i])};
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                // S = 1: consecutive cells; S = 2: pixel i of the quad is odd, even, odd, even -> the odd run, the even run
+                constexpr int dummy = 0; (void)dummy;
+                const int off = S == 2 ? ((i & 1) ? ((i + 1) >> 1) - NEVEN : (i >> 1)) * CS1 : i * CS1;
+                if (ckeep[r][i])
+                    *reinterpret_cast<u2*>(sim + ccell[r] + off) = (u2){pack_bf16_g(sc[r][0][i], sc[r][1][i]), pack_bf16_g(sc[r][2][i], sc[r][3][i])};
             }
         }
     };
     auto commit_state = [&]() {
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
-            const int task = r * GNT + tid;
-            if (task < NTH) {
-                const int q = task % NQH, rest = task / NQH, c4 = rest % C4H, py = rest / C4H;
+            if (hcell[r] < 0) continue;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<u2*>(HA + (py * PITCH + 4 * q + i + 1) * XC + c4 * 8) =
-                        (u2){pack_bf16_g(sh[r][0][i], sh[r][1][i]), pack_bf16_g(sh[r][2][i], sh[r][3][i])};
-            }
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<u2*>(XA + hcell[r] + i * XC) = (u2){pack_bf16_g(sh[r][0][i], sh[r][1][i]), pack_bf16_g(sh[r][2][i], sh[r][3][i])};
         }
     };
 
-    // K group kk = 4 kb + kgroup (8 channels each) of the gates / candidate: tap kk / GPT, part kk % GPT -- the first half of a
-    // tap's channels is x, the second h | r*h
-    constexpr int GPT = 2 * HID / 8;
-    auto a_off = [&](int kb, int& second) {
-        const int kk = 4 * kb + kgroup;
+    // ---- P1 (x on the whole region): this wave's tasks are region rows (wave >> 2) + 2 t, t < RY / 2, pixel group wave & 3.
+    //      Transposed GEMM (weights as the A operand): D row = channel 4 kg + register, column = pixel m -- a lane leaves with four
+    //      consecutive channels of one pixel = ONE 8-byte write into the pixel's cell.
+    constexpr int NT1 = RY * MG / GW;
+    const int wrow = wave >> 2, wgrp = wave & 3;
+    const int a1base = (S == 2 ? (2 * wrow * SPX + 16 * wgrp + m) : (wrow * SPX + 16 * wgrp + m)) * CS1;   // + t * (S == 2 ? 4 : 2) * SPX * CS1
+    int a1off[NKB1];   // K index k = 32 kb + 8 kg + j -> tap k / CP = (k_y, k_x), channel k % CP (padded taps: zero weights, any valid cell)
+#pragma unroll
+    for (int kb = 0; kb < NKB1; ++kb) {
+        const int k0 = 32 * kb + 8 * kg;
+        const int t9 = k0 / CP, c = k0 % CP;
+        const int ky = t9 < 9 ? t9 / 3 : 0, kx = t9 < 9 ? t9 % 3 : 0;
+        a1off[kb] = (S == 2 ? (ky * SPX + ((kx & 1) ? NEVEN : 0) + (kx >> 1)) : (ky * SPX + kx)) * CS1 + (t9 < 9 ? c : 0) * 2;
+    }
+    const int xwr = (wrow * PITCH + 16 * wgrp + m + 1) * XC + kg * 8;      // x cell of task 0: + t * 2 * PITCH * XC
+    const bool xcol = 4 * kg < HID;                                        // the lane holds real channels
+    const bool xin = rx0 + 16 * wgrp + m >= 0 && rx0 + 16 * wgrp + m < W;  // its pixel's column is inside the image
+
+    // ---- P2 / P3: core tasks = region rows 2 + (wave >> 2) + 2 t (t < NCT), pixel group wave & 3 -- gates AND candidate of
+    //      the same pixels by the same wave (u and the fp32 state stay in registers); one halo task of the gates per wave
+    //      (rows 1 and RY - 2).  Plain GEMM: D row = pixel 4 kg + register, column = channel m.
+    constexpr int NCT = TY * MG / GW;
+    constexpr int GPT = 2 * HID / 8;   // K groups of 8 channels per tap: the first half is x, the second h | r*h
+    const int hid_ = min(wave, 2 * MG - 1);
+    const int hrow = hid_ < MG ? 1 : RY - 2, hgrp = hid_ % MG;
+    const int gbase = ((2 + wrow) * PITCH + 16 * wgrp + m) * XC;           // A operands of the core tasks: + t * 2 * PITCH * XC
+    const int hbase = (hrow * PITCH + 16 * hgrp + m) * XC;                 // ... of the halo task
+    int goff[NKBG], csec[NKBG];   // K group 4 kb + kg -> (tap, part): offset from the pixel's x cell; part in the second half: + REG (h), + 2 REG (r*h)
+#pragma unroll
+    for (int kb = 0; kb < NKBG; ++kb) {
+        const int kk = 4 * kb + kg;
         const int t9 = kk / GPT, part = kk - t9 * GPT;
         const int ky = t9 < 9 ? t9 / 3 : 0, kx = t9 < 9 ? t9 % 3 : 0;
-        second = part >= GPT / 2 ? 1 : 0;
-        return ((ky - 1) * PITCH + kx) * XC + (part % (GPT / 2)) * 16;
-    };
-    const int hch = m & (HID - 1);
-    constexpr int NCT = TY * MG / GW;   // core tasks of a wave: rows 2 .. TY + 1 of the region, gates AND candidate by the same wave
-    int crow[NCT], cgrp[NCT];
-#pragma unroll
-    for (int t = 0; t < NCT; ++t) {
-        const int id = wave + GW * t;
-        crow[t] = 2 + id / MG; cgrp[t] = id % MG;
+        const int second = part >= GPT / 2 ? 1 : 0;
+        goff[kb] = ((ky - 1) * PITCH + kx) * XC + (part % (GPT / 2)) * 16 + second * REG;
+        csec[kb] = second * REG;
     }
-    const int hid_ = min(wave, 2 * MG - 1);   // halo task of the gates (waves 0 .. 2 MG - 1): rows 1 and TY + 2
-    const int hrow = hid_ < MG ? 1 : RY - 2, hgrp = hid_ % MG;
+    const int hch = m & (HID - 1);
+    // fp32 state of the lane's pixel quads (channel hch) and where h' goes: offsets from the region origin
+    const bool lane_h = m < HID;
+    const int ccq = 16 * wgrp + 4 * kg, hcq = 16 * hgrp + 4 * kg;         // first column of the lane's quad: core tasks, halo task
+    const bool cin = rx0 + ccq >= 0 && rx0 + ccq < W, hin = rx0 + hcq >= 0 && rx0 + hcq < W;
+    const unsigned hq_c = lane_h && cin ? (unsigned)hch * plane4 + (unsigned)((2 + wrow) * W + ccq) * 4 : OOB;   // + t * 2 * W * 4
+    const unsigned hq_h = lane_h && hin ? (unsigned)hch * plane4 + (unsigned)(hrow * W + hcq) * 4 : OOB;
+    const unsigned st_c = lane_h && cin && ccq >= 4 && ccq < RX - 4 ? hq_c : OOB;                                 // stored columns 4 .. RX - 5
+    const int rwr_c = 2 * REG + ((2 + wrow) * PITCH + ccq + 1) * XC + m * 2;   // r*h cells of the lane's quad (R region = XA + 2 REG): + k * XC
+    const int rwr_h = 2 * REG + (hrow * PITCH + hcq + 1) * XC + m * 2;
+    const float bgr = p.bg[m], bgu = HID == 16 ? p.bg[16 + m] : 0.0f, bcm = lane_h ? p.bc[hch] : 0.0f;
 
     if (PREFETCH) {
         issue_cost(t0);
@@ -233,9 +275,6 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
     }
     __syncthreads();
     for (int ty = t0; ty < t1; ++ty) {
-        // (opaque per tile: otherwise every phase's index arithmetic -- tile-invariant -- is hoisted out of this loop and kept in
-        //  ~100 registers, and the two-workgroups-per-CU build spills)
-        asm volatile("" : "+v"(tid), "+v"(m), "+v"(kgroup));
         const int ry0 = ty * TY - 2;
         const bool more = ty + 1 < t1;
         if (PREFETCH) {
@@ -245,91 +284,68 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
             issue_state(ty);
             commit_cost();
             commit_state();
-            __syncthreads();
+            lds_barrier();
         }
 
         // ---- P1: x = relu(conv(cost)) on the whole region -------------------------------------------------------------------
         {
-            constexpr int NT1 = (RY * MG + GW - 1) / GW;
             f4 acc[NT1];
-            int base[NT1];
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) {
-                acc[t] = (f4){0, 0, 0, 0};
-                const int id = min(wave + GW * t, RY * MG - 1);
-                const int r = id / MG, g = id - r * MG;
-                base[t] = S == 2 ? (2 * r * SPX + 16 * g + m) * CS1 : (r * SPX + 16 * g + m) * CS1;
-            }
+            for (int t = 0; t < NT1; ++t) acc[t] = (f4){0, 0, 0, 0};
 #pragma unroll
-            for (int kb = 0; kb < ((D3D_GRU_X & 16) ? 1 : NKB1); ++kb) {
-                // K index k = 32 kb + 8 kgroup + j -> tap k / CP = (k_y, k_x), channel k % CP (padded taps: zero weights, any valid cell)
-                const int k0 = 32 * kb + 8 * kgroup;
-                const int t9 = k0 / CP, c = k0 % CP;
-                const int ky = t9 < 9 ? t9 / 3 : 0, kx = t9 < 9 ? t9 % 3 : 0;
-                const int aoff = S == 2 ? (ky * SPX + ((kx & 1) ? NEVEN : 0) + (kx >> 1)) * CS1 + (t9 < 9 ? c : 0) * 2
-                                        : (ky * SPX + kx) * CS1 + (t9 < 9 ? c : 0) * 2;
+            for (int kb = 0; kb < NKB1; ++kb) {
+                const unsigned char* ap = sim + a1base + a1off[kb];
                 const bf16x8 b = __builtin_bit_cast(bf16x8, w1l[kb * 64 + lane]);
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(sim + base[t] + aoff));
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + t * ((S == 2 ? 4 : 2) * SPX * CS1)));
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (the scheduler would hoist every K block's operand reads: ~100 registers)
             }
-            // D row (pixel) = 4 (lane >> 4) + register, column (channel) = lane & 15
+            if (xcol) {
 #pragma unroll
-            for (int t = 0; t < NT1; ++t) {
-                const int id = wave + GW * t;
-                if (id < RY * MG && m < HID) {
-                    const int r = id / MG, g = id - r * MG;
-                    const int gy = ry0 + r;
-                    const int cc = 16 * g + 4 * kgroup;
-                    const int gx = rx0 + cc;
-                    const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;   // (W % 4 == 0: a quad is inside or outside as a whole)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float y = fmaxf(acc[t][k] * 1.0f + 0.0f, 0.0f);
-                        *reinterpret_cast<unsigned short*>(XA + (r * PITCH + cc + k + 1) * XC + m * 2) = in ? bf16_bits(y) : (unsigned short)0;
-                    }
+                for (int t = 0; t < NT1; ++t) {
+                    const int gy = ry0 + wrow + 2 * t;
+                    const bool in = xin && gy >= 0 && gy < H;   // zero outside the image: the gates' own zero padding
+                    f4 y = acc[t] * 1.0f + 0.0f;
+                    y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+                    u2 pk = {pack_bf16_g(y[0], y[1]), pack_bf16_g(y[2], y[3])};
+                    if (!in) pk = (u2){0, 0};
+                    *reinterpret_cast<u2*>(XA + xwr + t * (2 * PITCH * XC)) = pk;
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (PREFETCH && more) {
             commit_cost();
             issue_state(ty + 1);        // in flight during P2 (committed behind it: the candidate reads x and r*h only)
         }
 
-        // ---- P2: gates.  Core tasks and one halo task; the fp32 state of the lane's pixel quads is requested first -----------
+        // ---- P2: gates.  The fp32 state of the lane's pixel quads is requested first ----------------------------------------
         f4 ukeep[NCT], hkeep[NCT];
         {
             constexpr int NT2 = NCT + 1;
             f4 acc[NT2][NTNG], hh[NT2];
-            int base[NT2], rr[NT2], gg[NT2];
+            const __amdgpu_buffer_rsrc_t rs = tensor_rsrc(p.h + ((long)ry0 * W + rx0));
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
 #pragma unroll
                 for (int nt = 0; nt < NTNG; ++nt) acc[t][nt] = (f4){0, 0, 0, 0};
-                rr[t] = t < NCT ? crow[t < NCT ? t : 0] : hrow;
-                gg[t] = t < NCT ? cgrp[t < NCT ? t : 0] : hgrp;
-                base[t] = (rr[t] * PITCH + 16 * gg[t] + m) * XC;
-                const int gy = ry0 + rr[t], gx = rx0 + 16 * gg[t] + 4 * kgroup;
-                const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-                const f4 v = (D3D_GRU_X & 2) ? (f4){0.125f, 0.125f, 0.125f, 0.125f}
-                                             : *reinterpret_cast<const f4*>(p.h + (size_t)hch * plane + (in ? (size_t)gy * W + gx : 0));
-                hh[t] = in ? v : (f4){0, 0, 0, 0};
+                const int gy = ry0 + (t < NCT ? 2 + wrow + 2 * t : hrow);   // (uniform)
+                const unsigned vo = t < NCT ? hq_c : hq_h;
+                hh[t] = buf_load4(rs, gy >= 0 && gy < H ? vo : OOB, t < NCT ? t * 2 * W * 4 : 0);
             }
 #pragma unroll
-            for (int kb = 0; kb < ((D3D_GRU_X & 16) ? 1 : NKBG); ++kb) {
-                int second;
-                const int aoff = a_off(kb, second);
-                const unsigned char* arr = second ? HA : XA;
+            for (int kb = 0; kb < NKBG; ++kb) {
+                const unsigned char* apc = XA + gbase + goff[kb];
+                const unsigned char* aph = XA + hbase + goff[kb];
                 bf16x8 b[NTNG];
 #pragma unroll
                 for (int nt = 0; nt < NTNG; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wgl[(kb * NTNG + nt) * 64 + lane]);
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(arr + base[t] + aoff));
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(t < NCT ? apc + t * (2 * PITCH * XC) : aph));
 #pragma unroll
                     for (int nt = 0; nt < NTNG; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[t][nt], 0, 0, 0);
                 }
@@ -340,74 +356,61 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
                 if (t == NCT && wave >= 2 * MG) continue;   // (no halo task for this wave)
                 f4 rgate, ugate;
                 if constexpr (HID == 8) {   // one N tile: channels 0-7 reset, 8-15 update
-                    const float bs = p.bg[m];
-                    f4 y = acc[t][0] * 1.0f + bs;
+                    f4 y = acc[t][0] * 1.0f + bgr;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = (D3D_GRU_X & 4) ? y[k] : 1.0f / (1.0f + __expf(-y[k]));
+                    for (int k = 0; k < 4; ++k) y[k] = gru_sigmoid(y[k]);
                     rgate = y;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ugate[k] = __shfl_down(y[k], 8, 16);   // u of channel m arrives from lane m + 8
+                    for (int k = 0; k < 4; ++k) ugate[k] = dpp_row_shl8(y[k]);   // u of channel m arrives from lane m + 8
                 } else {
-                    const float shr = p.bg[m], shu = p.bg[16 + m];
-                    f4 y = acc[t][0] * 1.0f + shr, z = acc[t][NTNG - 1] * 1.0f + shu;
+                    f4 y = acc[t][0] * 1.0f + bgr, z = acc[t][NTNG - 1] * 1.0f + bgu;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        y[k] = (D3D_GRU_X & 4) ? y[k] : 1.0f / (1.0f + __expf(-y[k]));
-                        z[k] = (D3D_GRU_X & 4) ? z[k] : 1.0f / (1.0f + __expf(-z[k]));
-                    }
+                    for (int k = 0; k < 4; ++k) { y[k] = gru_sigmoid(y[k]); z[k] = gru_sigmoid(z[k]); }
                     rgate = y; ugate = z;
                 }
-                if (m < HID) {
+                if (lane_h) {
                     const f4 rh = rgate * hh[t];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        *reinterpret_cast<unsigned short*>(RA + (rr[t] * PITCH + 16 * gg[t] + 4 * kgroup + k + 1) * XC + m * 2) = bf16_bits(rh[k]);
+                    const unsigned p01 = pack_bf16_g(rh[0], rh[1]), p23 = pack_bf16_g(rh[2], rh[3]);
+                    unsigned char* dst = XA + (t < NCT ? rwr_c + t * (2 * PITCH * XC) : rwr_h);
+                    *reinterpret_cast<unsigned short*>(dst) = (unsigned short)p01;
+                    *reinterpret_cast<unsigned short*>(dst + XC) = (unsigned short)(p01 >> 16);
+                    *reinterpret_cast<unsigned short*>(dst + 2 * XC) = (unsigned short)p23;
+                    *reinterpret_cast<unsigned short*>(dst + 3 * XC) = (unsigned short)(p23 >> 16);
                 }
                 if (t < NCT) { ukeep[t < NCT ? t : 0] = ugate; hkeep[t < NCT ? t : 0] = hh[t]; }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (PREFETCH && more) commit_state();
 
         // ---- P3: candidate and state update on the core tasks ---------------------------------------------------------------
         {
             f4 acc[NCT];
-            int base[NCT];
 #pragma unroll
-            for (int t = 0; t < NCT; ++t) {
-                acc[t] = (f4){0, 0, 0, 0};
-                base[t] = (crow[t] * PITCH + 16 * cgrp[t] + m) * XC;
-            }
+            for (int t = 0; t < NCT; ++t) acc[t] = (f4){0, 0, 0, 0};
 #pragma unroll
-            for (int kb = 0; kb < ((D3D_GRU_X & 16) ? 1 : NKBG); ++kb) {
-                int second;
-                const int aoff = a_off(kb, second);
-                const unsigned char* arr = second ? RA : XA;
+            for (int kb = 0; kb < NKBG; ++kb) {
+                const unsigned char* ap = XA + gbase + goff[kb] + csec[kb];   // second half of a tap: r*h instead of h
                 const bf16x8 b = __builtin_bit_cast(bf16x8, wcl[kb * 64 + lane]);
 #pragma unroll
                 for (int t = 0; t < NCT; ++t) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(arr + base[t] + aoff));
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + t * (2 * PITCH * XC)));
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (m < HID) {
-                const float bs = p.bc[m];
+            const __amdgpu_buffer_rsrc_t ro = tensor_rsrc(p.hout + ((long)ry0 * W + rx0));
 #pragma unroll
-                for (int t = 0; t < NCT; ++t) {
-                    const int gy = ry0 + crow[t];
-                    const int cc = 16 * cgrp[t] + 4 * kgroup;
-                    const int gx = rx0 + cc;
-                    f4 y = acc[t] * 1.0f + bs;
-                    const f4 u = ukeep[t], hq = hkeep[t];
+            for (int t = 0; t < NCT; ++t) {
+                const int gy = ry0 + 2 + wrow + 2 * t;   // (uniform; >= 0 always)
+                f4 y = acc[t] * 1.0f + bcm;
+                const f4 u = ukeep[t], hq = hkeep[t];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = u[k] * hq[k] + (1.0f - u[k]) * ((D3D_GRU_X & 4) ? y[k] : tanhf(y[k]));
-                    if (!(D3D_GRU_X & 8) || y[0] == 1234.5f)
-                        if (cc >= 4 && cc < RX - 4 && gx < W && gy < H) *reinterpret_cast<f4*>(p.hout + (size_t)m * plane + (size_t)gy * W + gx) = y;
-                }
+                for (int k = 0; k < 4; ++k) y[k] = u[k] * hq[k] + (1.0f - u[k]) * gru_tanh(y[k]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), ro, gy < H ? st_c : OOB, t * 2 * W * 4, 0);
             }
         }
-        __syncthreads();   // P3 has read X and R: the next tile's P1 may overwrite X
+        lds_barrier();   // P3 has read X and R: the next tile's P1 may overwrite X
     }
 }
 
@@ -435,17 +438,11 @@ static int launch_gru(const GruParams& p, hipStream_t stream) {
 // Non-default compile-time knobs of this translation unit (d3d_build_flags): empty for the production build.
 const char* gru_build_flags() {
     return ""
-#if D3D_GRU_X
-           " D3D_GRU_X"
-#endif
 #ifdef D3D_GRU_PREFETCH
            " D3D_GRU_PREFETCH"
 #endif
 #if D3D_GRU_WAVES2 != 4
            " D3D_GRU_WAVES2"
-#endif
-#ifdef D3D_GRU_TY_C8
-           " D3D_GRU_TY_C8"
 #endif
         ;
 }
@@ -467,9 +464,9 @@ extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI
     D3D_REQUIRE(stride == 1 || stride == 2, "bad stride %d", stride);
     if (stride == 1) D3D_REQUIRE(HI == H && WI == W, "stride 1: the cost map has the state's size");
     else D3D_REQUIRE(H == (HI - 1) / 2 + 1 && W == (WI - 1) / 2 + 1, "stride 2: state %dx%d does not belong to a %dx%d input", H, W, HI, WI);
-    if (W % 4 != 0 || WI % 4 != 0 ||
+    if (W % 4 != 0 || WI % 4 != 0 || (long)CP * HI * WI * 4 >= (1L << 31) || (long)HID * H * W * 4 >= (1L << 31) ||
         ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(hout) | reinterpret_cast<uintptr_t>(cost)) & 15)) {
-        set_error("d3d_gru_cell_fused_bf16: widths %d / %d (multiples of 4) with 16-byte aligned tensors needed", WI, W);
+        set_error("d3d_gru_cell_fused_bf16: widths %d / %d (multiples of 4) with 16-byte aligned tensors below 2 GiB needed", WI, W);
         return D3D_ERR_UNSUPPORTED;
     }
     GruParams p = {};
@@ -477,11 +474,7 @@ extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI
     p.wc = reinterpret_cast<const u4*>(wc); p.bg = bg; p.bc = bc; p.H = H; p.W = W; p.HI = HI; p.WI = WI;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1 && HID == 8) {
-#ifdef D3D_GRU_TY_C8
-        if (CP == 8) return launch_gru<8, 8, 1, 4, D3D_GRU_TY_C8>(p, st);
-#else
         if (CP == 8) return launch_gru<8, 8, 1, 4, 8>(p, st);
-#endif
         if (CP == 16) return launch_gru<16, 8, 1, 4, 8>(p, st);
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }

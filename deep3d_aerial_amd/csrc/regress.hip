@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict_
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long n = (long)Hc * plane;
     if (i >= n) return;
-    float r = 1.0f / (1.0f + __expf(-gates[i]));
-    float uu = 1.0f / (1.0f + __expf(-gates[n + i]));
+    float r = gru_sigmoid(gates[i]);
+    float uu = gru_sigmoid(gates[n + i]);
     rh[i] = r * h[i];
     u[i] = uu;
 }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void gru_update_kernel(const float* __restrict
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float uu = u[i];
-    h_out[i] = uu * h[i] + (1.0f - uu) * tanhf(convc[i]);
+    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh(convc[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -553,9 +553,9 @@ __global__ __launch_bounds__(256) void gru2_gates_kernel(const float* __restrict
     const GnAffine ar = gn_fold(st_r, n, eps), au = gn_fold(st_u, n, eps);
     const float rn = (gates[i] - ar.mean) * ar.rstd * g_r[c] + b_r[c];
     const float un = (gates[n + i] - au.mean) * au.rstd * g_u[c] + b_u[c];
-    const float r = 1.0f / (1.0f + __expf(-rn));
+    const float r = gru_sigmoid(rn);
     rh[i] = r * h[i];
-    u[i] = 1.0f / (1.0f + __expf(-un));
+    u[i] = gru_sigmoid(un);
 }
 
 // h' = u*h + (1-u)*tanh(gn_o(o))   (module.py:84-98)
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void gru2_update_kernel(const float* __restric
     const GnAffine a = gn_fold(st_o, n, eps);
     const float on = (o[i] - a.mean) * a.rstd * g_o[c] + b_o[c];
     const float uu = u[i];
-    h_out[i] = uu * h[i] + (1.0f - uu) * tanhf(on);
+    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh(on);
 }
 
 }  // namespace d3d
