@@ -53,6 +53,13 @@ struct Z2Params {
 __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
     return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
+// Global memory through buffer instructions: a raw buffer from `origin` on (which may lie before the tensor) + a 32-bit per-lane
+// byte offset + a scalar offset.  A lane whose pixels are outside the image carries OOBZ: the load returns zeros, the store is
+// dropped -- no address arithmetic and no select on the vector unit.
+constexpr unsigned OOBZ = 0xffffffffu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t z2_rsrc(const void* origin) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, (int)0xfffffffeu, 0x00020000);
+}
 
 // F32: the same tile scheme with exact fp32 operands (v_mfma_f32_16x16x4_f32, the default precision of the models): cells
 // of C_in floats + 16 bytes (20 | 36-dword pitches: the 16 pixels of an A operand, one dword each, fall in 16 different
@@ -133,39 +140,74 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     // A channel quad comes from `in` or from `in2` (C1 % 8 == 0).  Task order: channel quad fastest, then column quad, then row:
     // a load instruction still reads whole 128-byte runs (one per channel and row), and the lanes of a cell write of the
     // commit cover the C4 adjacent 8-byte (fp32: 16-byte) slots of one cell before moving 4 cells on.
+    // The kernel is bound by instruction issue (profiles/r04_t2p.txt, r04_gru_slice.txt), so what a task reads and writes is
+    // per-lane state computed once: its byte offset from the patch origin inside its source tensor (OOB where its column is
+    // outside the image: a buffer load then returns zeros), its patch row, its cell.  Per tile only the rows outside the image
+    // turn offsets OOB (inner tiles skip even that), and the values stay raw in registers until the commit -- a select behind
+    // the load would wait for it before the sweep it is meant to hide behind.
     constexpr int C4 = CI / 4, QX = TX / 4;
     constexpr int NQT = C4 * PYZ * QX, RQ = (NQT + NTZ - 1) / NTZ;
     constexpr int NST = C4 * PYZ * 2, RS = (NST + NTZ - 1) / NTZ;
     (void)G;
+    const unsigned plane4 = (unsigned)H * W * 4;   // bytes of a channel plane (host: every tensor < 2^31 bytes)
+    const int c14 = p.in2 ? p.C1 / 4 : C4;         // channel quads below it come from `in`
     f4 stq[RQ][4];      // [channel of the quad][4 pixels]
     float sts[RS][4];   // [channel of the quad]
+    unsigned qvo[RQ], svo[RS];
+    int qpy[RQ], spy[RS], qcell[RQ], scell[RS];
+    bool q2[RQ], s2[RS];   // the task's channels come from in2
     const int tid_e = NTZ - 1 - tid;
-    auto chan_base = [&](int c) { return c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane; };
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+        const int task = tid + r * NTZ;
+        const int c4 = task % C4, rest = task / C4, q = rest % QX, py = rest / QX;
+        q2[r] = c4 >= c14;
+        qvo[r] = task < NQT && x0 + 4 * q < W ? (unsigned)(4 * (q2[r] ? c4 - c14 : c4)) * plane4 + (unsigned)(py * W + 4 * q) * 4 : OOBZ;
+        qpy[r] = py;
+        qcell[r] = task < NQT ? (py * PX + 1 + 4 * q) * CS : -1;
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int task = tid_e + r * NTZ;
+        const int c4 = task % C4, rest = task / C4, side = rest & 1, py = rest >> 1;
+        const int gx = side ? x0 + TX : x0 - 1;
+        s2[r] = c4 >= c14;
+        svo[r] = task < NST && gx >= 0 && gx < W ? (unsigned)(4 * (s2[r] ? c4 - c14 : c4)) * plane4 + (unsigned)(py * W + gx - x0 + 1) * 4 : OOBZ;
+        spy[r] = py;
+        scell[r] = task < NST ? (py * PX + (side ? PX - 1 : 0)) * CS : -1;
+    }
+    int qc4[RQ], sc4[RS];
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) qc4[r] = (tid + r * NTZ) % C4;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) sc4[r] = (tid_e + r * NTZ) % C4;
     auto issue = [&](int ty) {
+        const int gy0 = ty * TYZ - 1;                                  // patch origin: row gy0, column x0 - 1 (edge tasks) | x0 (quads)
+        const bool inner = gy0 >= 0 && gy0 + PYZ <= H;
+        const __amdgpu_buffer_rsrc_t rq1 = z2_rsrc(p.in + ((long)gy0 * W + x0)), rs1 = z2_rsrc(p.in + ((long)gy0 * W + x0 - 1));
+        const __amdgpu_buffer_rsrc_t rq2 = z2_rsrc((p.in2 ? p.in2 : p.in) + ((long)gy0 * W + x0)), rs2 = z2_rsrc((p.in2 ? p.in2 : p.in) + ((long)gy0 * W + x0 - 1));
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
-            const int task = tid + r * NTZ;
-            const int c4 = task % C4, rest = task / C4, q = rest % QX, py = rest / QX;
-            const int gx = x0 + 4 * q, gy = ty * TYZ + py - 1;
-            const bool ok = task < NQT && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = ok ? chan_base(4 * c4) + (size_t)gy * W + gx : p.in;
+            unsigned vo = qvo[r];
+            if (!inner) vo = (unsigned)(qpy[r] + gy0) < (unsigned)H ? vo : OOBZ;
+            if (p.in2 && q2[r]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f4 v = *reinterpret_cast<const f4*>(src + (size_t)k * plane);
-                stq[r][k] = ok ? v : (f4){0, 0, 0, 0};
+                for (int k = 0; k < 4; ++k) stq[r][k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rq2, vo, k * plane4, 0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) stq[r][k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rq1, vo, k * plane4, 0));
             }
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
-            const int task = tid_e + r * NTZ;
-            const int c4 = task % C4, rest = task / C4, side = rest & 1, py = rest >> 1;
-            const int gx = side ? x0 + TX : x0 - 1, gy = ty * TYZ + py - 1;
-            const bool ok = task < NST && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = ok ? chan_base(4 * c4) + (size_t)gy * W + gx : p.in;
+            unsigned vo = svo[r];
+            if (!inner) vo = (unsigned)(spy[r] + gy0) < (unsigned)H ? vo : OOBZ;
+            if (p.in2 && s2[r]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = src[(size_t)k * plane];
-                sts[r][k] = ok ? v : 0.0f;
+                for (int k = 0; k < 4; ++k) sts[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, k * plane4, 0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sts[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, k * plane4, 0));
             }
         }
     };
@@ -187,44 +229,55 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     auto commit = [&](unsigned char* dst) {
 #pragma unroll
         for (int r = 0; r < RQ; ++r) {
-            const int task = tid + r * NTZ;
-            if (task < NQT) {
-                const int c4 = task % C4, rest = task / C4, q = rest % QX, py = rest / QX;
-                unsigned char* cell = dst + (py * PX + 1 + 4 * q) * CS;
+            if (qcell[r] >= 0) {
+                unsigned char* cell = dst + qcell[r];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) put4(cell + i * CS, c4, stq[r][0][i], stq[r][1][i], stq[r][2][i], stq[r][3][i]);
+                for (int i = 0; i < 4; ++i) put4(cell + i * CS, qc4[r], stq[r][0][i], stq[r][1][i], stq[r][2][i], stq[r][3][i]);
             }
         }
 #pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            const int task = tid_e + r * NTZ;
-            if (task < NST) {
-                const int c4 = task % C4, rest = task / C4, side = rest & 1, py = rest >> 1;
-                put4(dst + (py * PX + (side ? PX - 1 : 0)) * CS, c4, sts[r][0], sts[r][1], sts[r][2], sts[r][3]);
-            }
-        }
+        for (int r = 0; r < RS; ++r)
+            if (scell[r] >= 0) put4(dst + scell[r], sc4[r], sts[r][0], sts[r][1], sts[r][2], sts[r][3]);
     };
 
-    // K index k = 32 kb + 8 (lane >> 4) + j -> tap t = k / CI = (k_y, k_x), channel k % CI
-    auto a_offset = [&](int kb, int kgroup) {
-        const int k0 = 32 * kb + 8 * kgroup;
-        const int t = k0 / CI, c = k0 % CI;
-        const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
-        return (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
-    };
+    // K index k = 32 kb + 8 (lane >> 4) + j -> tap t = k / CI = (k_y, k_x), channel k % CI: one register per K block, computed once
     const int abase = (wave * PX + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);   // F32: K group = channel within the block of 4
+    int aoffs[F32 ? 1 : NKB];
+    if constexpr (!F32) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const int k0 = 32 * kb + 8 * (lane >> 4);
+            const int t = k0 / CI, c = k0 % CI;
+            const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
+            aoffs[kb] = abase + (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
+        }
+    }
+
+    // ---- epilogue state: D row (pixel) = (lane >> 4) * 4 + register, column (channel) = lane & 15.  Per lane and for good: the
+    //      affine of its channel per N tile, the byte offset of its pixel quad from the tile origin per (N tile, pixel group) --
+    //      OOB where the channel or the column does not exist, so loads return zeros and stores are dropped.
+    float esc[NTN], esh[NTN];
+    unsigned eoff[NTN][MGN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int co = nt * 16 + (lane & 15);
+        esc[nt] = p.scale && co < p.CO ? p.scale[co] : 1.0f;
+        esh[nt] = p.shift && co < p.CO ? p.shift[co] : 0.0f;
+#pragma unroll
+        for (int mg = 0; mg < MGN; ++mg) {
+            const int ox = x0 + mg * 16 + (lane >> 4) * 4;      // W % 4 == 0: a quad is inside or outside as a whole
+            eoff[nt][mg] = co < p.CO && ox < W ? (unsigned)co * plane4 + (unsigned)(wave * W + mg * 16 + (lane >> 4) * 4) * 4 : OOBZ;
+        }
+    }
 
     auto tile = [&](int ty, const unsigned char* buf) {
         f4 acc[AW];
 #pragma unroll
         for (int i = 0; i < AW; ++i) acc[i] = (f4){0, 0, 0, 0};
-        int kgroup = lane >> 4;
-        asm volatile("" : "+v"(kgroup));
         if constexpr (F32) {
             const float* wf = reinterpret_cast<const float*>(wlds);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {   // K block = channels 4 kb % CI .. + 3 of tap 4 kb / CI
-                constexpr int dummy = 0; (void)dummy;
                 const int t = (4 * kb) / CI, c = (4 * kb) % CI;
                 const int aoffk = ((t / 3) * PX + (t % 3)) * CS + c * 4;
                 float b[NTN];
@@ -241,7 +294,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         } else if constexpr (X3) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                const int aoffk = a_offset(kb, kgroup);
+                const unsigned char* ap = buf + aoffs[kb];
                 bf16x8 b[3][NTN];
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
@@ -253,7 +306,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
                     bf16x8 a[3];
 #pragma unroll
                     for (int s = 0; s < 3; ++s)
-                        a[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk + s * CI * 2));
+                        a[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS + s * CI * 2));
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt) {   // small terms first
                         f4 c = acc[mg * NTN + nt];
@@ -269,35 +322,32 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         } else
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const int aoffk = a_offset(kb, kgroup);
+            const unsigned char* ap = buf + aoffs[kb];
             bf16x8 b[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(kb * NTN + nt) * 64 + lane]);
 #pragma unroll
             for (int mg = 0; mg < MGN; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt)
                     acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
             }
         }
-        // ---- epilogue: D row (pixel) = (lane >> 4) * 4 + register, column (channel) = lane & 15 ---------------------
+        // ---- epilogue ------------------------------------------------------------------------------------------------------
         const int oy = ty * TYZ + wave;
         if (oy >= H) return;
+        if (p.sub2) {   // the stride-2 layer of a shape the stride-2 kernel has no room for: three quarters of the tile are dropped
+            if (oy & 1) return;
 #pragma unroll
-        for (int nt = 0; nt < NTN; ++nt) {
-            const int co = nt * 16 + (lane & 15);
-            if (co >= p.CO) continue;
-            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
-            const bool gate_h = p.act == 2 && co < p.ep_split;
+            for (int nt = 0; nt < NTN; ++nt) {
+                const int co = nt * 16 + (lane & 15);
+                if (co >= p.CO) continue;
 #pragma unroll
-            for (int mg = 0; mg < MGN; ++mg) {
-                const int ox = x0 + mg * 16 + (lane >> 4) * 4;
-                if (ox >= W) continue;                              // W % 4 == 0: a quad is inside or outside as a whole
-                const size_t o = (size_t)co * plane + (size_t)oy * W + ox;
-                f4 y = acc[mg * NTN + nt] * sc + sh;
-                if (p.sub2) {   // the stride-2 layer of a shape the stride-2 kernel has no room for: three quarters of the tile are dropped
-                    if (oy & 1) continue;
+                for (int mg = 0; mg < MGN; ++mg) {
+                    const int ox = x0 + mg * 16 + (lane >> 4) * 4;
+                    if (ox >= W) continue;
+                    const f4 y = acc[mg * NTN + nt] * esc[nt] + esh[nt];
                     const size_t o2 = ((size_t)co * ((H + 1) >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
                     float y0 = y[0], y2 = y[2];
                     if (p.skip && !p.skip_after_act) { y0 += p.skip[o2]; y2 += p.skip[o2 + 1]; }
@@ -305,23 +355,44 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
                     if (p.skip && p.skip_after_act) { y0 = p.skip[o2] + y0; y2 = p.skip[o2 + 1] + y2; }
                     p.out[o2] = y0;
                     p.out[o2 + 1] = y2;
-                    continue;
                 }
-                if (p.act == 2) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = gru_sigmoid(y[k]);
-                    if (gate_h) y *= *reinterpret_cast<const f4*>(p.skip + o);
-                } else if (p.act == 3) {
-                    const f4 u = *reinterpret_cast<const f4*>(p.aux1 + o), hh = *reinterpret_cast<const f4*>(p.skip + o);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * gru_tanh(y[k]);
-                } else {
-                    if (p.skip && !p.skip_after_act) y += *reinterpret_cast<const f4*>(p.skip + o);
-                    if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
-                    if (p.skip && p.skip_after_act) y = *reinterpret_cast<const f4*>(p.skip + o) + y;
-                }
-                *reinterpret_cast<f4*>(p.out + o) = y;
             }
+            return;
+        }
+        const long torg = (long)ty * TYZ * W + x0;   // tile origin (elements inside a channel plane)
+        const __amdgpu_buffer_rsrc_t ro = z2_rsrc(p.out + torg);
+        const __amdgpu_buffer_rsrc_t rk = z2_rsrc((p.skip ? p.skip : p.out) + torg), ra = z2_rsrc((p.aux1 ? p.aux1 : p.out) + torg);
+        // the epilogue's operands first (h, u, the skip tensor): all in flight at once, not one round trip per pixel quad
+        f4 ek[AW], ea[AW];
+#pragma unroll
+        for (int i = 0; i < AW; ++i) {
+            const unsigned o = eoff[i % NTN][i / NTN];
+            const bool gate_h = p.act == 2 && (i % NTN) * 16 + (lane & 15) < p.ep_split;
+            ek[i] = (f4){0, 0, 0, 0};
+            ea[i] = (f4){0, 0, 0, 0};
+            if (p.act == 2 ? true : p.skip != nullptr)
+                ek[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rk, p.act == 2 && !gate_h ? OOBZ : o, 0, 0));
+            if (p.act == 3) ea[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(ra, o, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < AW; ++i) {
+            const int nt = i % NTN, mg = i / NTN;
+            f4 y = acc[i] * esc[nt] + esh[nt];
+            if (p.act == 2) {
+                const bool gate_h = nt * 16 + (lane & 15) < p.ep_split;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = gru_sigmoid(y[k]);
+                if (gate_h) y *= ek[i];
+            } else if (p.act == 3) {
+                const f4 u = ea[i], hh = ek[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * gru_tanh(y[k]);
+            } else {
+                if (p.skip && !p.skip_after_act) y += ek[i];
+                if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+                if (p.skip && p.skip_after_act) y = ek[i] + y;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), ro, eoff[nt][mg], 0, 0);
         }
     };
 
@@ -336,12 +407,12 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         tile(ty, smem + cur * PATCH);
         if constexpr (NBUF == 2) {
             if (more) commit(smem + (cur ^ 1) * PATCH);
-            __syncthreads();
+            lds_barrier();
             cur ^= 1;
         } else {
-            __syncthreads();   // every wave has read the patch
+            lds_barrier();   // every wave has read the patch
             if (more) commit(smem);
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
