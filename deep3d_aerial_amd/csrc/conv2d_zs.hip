@@ -121,7 +121,6 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W;
-    const size_t plane = (size_t)H * W;
     const int x0 = blockIdx.x * TX;
     const int nty = (H + TYZ - 1) / TYZ;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
@@ -430,6 +429,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
         set_error("conv2d tile kernel: tensors must be 16-byte aligned (dwordx4 loads and stores)");
         return D3D_ERR_UNSUPPORTED;
     }
+    if ((long)(CI > p.CO ? CI : p.CO) * p.H * p.W * 4 * (1) >= (1L << 31)) return D3D_ERR_UNSUPPORTED;   // (32-bit buffer offsets)
     auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
@@ -465,7 +465,6 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const size_t plane = (size_t)H * W, oplane = (size_t)Ho * Wo;
     const int xo0 = blockIdx.x * TXO;
     const int nty = (Ho + TYZ - 1) / TYZ;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
@@ -478,42 +477,51 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         for (int i = tid; i < (X3 ? 3 : 1) * NKB * NTN * 64; i += NTZ) wlds[i] = p.wpk[i];   // X3: [hi | mid | lo][NKB][N tiles][lane]
     }
 
+    // task = (patch pixel, 8-channel group): eight dword loads, one cell slot.  Per lane and for good (see the stride-1 kernel):
+    // the task's byte offset from the patch origin (OOBZ where its column is outside the image), its patch row, its cell.
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
+    const unsigned plane4 = (unsigned)H * W * 4, oplane4 = (unsigned)Ho * Wo * 4;   // (host: every tensor < 2^31 bytes)
     float stg[ROUNDS][8];
+    unsigned svo[ROUNDS];
+    int spy[ROUNDS], scell[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int task = tid + r * NTZ;
+        const int pix = task / G, g = task - pix * G;
+        const int py = pix / PXI, px = pix - py * PXI;
+        const int gx = 2 * xo0 - ORG + px;
+        svo[r] = task < NTASK && gx >= 0 && gx < W ? (unsigned)(8 * g) * plane4 + (unsigned)(py * W + px) * 4 : OOBZ;
+        spy[r] = py;
+        const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
+        scell[r] = task < NTASK ? cell * CS + g * (F32 ? 32 : 16) : -1;
+    }
     auto issue = [&](int ty) {
+        const int gy0 = 2 * ty * TYZ - ORG;
+        const bool inner = gy0 >= 0 && gy0 + PYI <= H;
+        const __amdgpu_buffer_rsrc_t rs = z2_rsrc(p.in + ((long)gy0 * W + 2 * xo0 - ORG));
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NTZ;
-            const int pix = task / G, g = task - pix * G;
-            const int py = pix / PXI, px = pix - py * PXI;
-            const int gx = 2 * xo0 - ORG + px, gy = 2 * ty * TYZ - ORG + py;
-            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = p.in + (size_t)(8 * g) * plane + (ok ? (size_t)gy * W + gx : 0);
+            unsigned vo = svo[r];
+            if (!inner) vo = (unsigned)(spy[r] + gy0) < (unsigned)H ? vo : OOBZ;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * plane];
-                stg[r][k] = ok ? v : 0.0f;
-            }
+            for (int k = 0; k < 8; ++k) stg[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, k * plane4, 0));
         }
     };
     auto commit = [&](unsigned char* dst) {
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NTZ;
-            if (task < NTASK) {
-                const int pix = task / G, g = task - pix * G;
-                const int py = pix / PXI, px = pix - py * PXI;
-                const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
+            if (scell[r] >= 0) {
+                unsigned char* cell = dst + scell[r];
                 if constexpr (F32) {
-                    *reinterpret_cast<f4*>(dst + cell * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
-                    *reinterpret_cast<f4*>(dst + cell * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                    *reinterpret_cast<f4*>(cell) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
+                    *reinterpret_cast<f4*>(cell + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
                 } else if constexpr (X3) {
-                    put8_split3(dst + cell * CS + g * 16, CI, stg[r]);
+                    put8_split3(cell, CI, stg[r]);
                 } else {
                     const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
                                   pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
-                    *reinterpret_cast<u4*>(dst + cell * CS + g * 16) = v;
+                    *reinterpret_cast<u4*>(cell) = v;
                 }
             }
         }
@@ -526,13 +534,30 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         return (ky * PXI + col) * CS + (t < KS * KS ? c : 0) * 2;
     };
     const int abase = (2 * wave * PXI + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);
+    int aoffs[F32 ? 1 : NKB];   // one register per K block, computed once
+    if constexpr (!F32) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) aoffs[kb] = abase + a_offset(kb, lane >> 4);
+    }
+    // epilogue state (see the stride-1 kernel): affine per N tile, byte offset of the lane's pixel quad from the tile origin
+    float esc[NTN], esh[NTN];
+    unsigned eoff[NTN][MG];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int co = nt * 16 + (lane & 15);
+        esc[nt] = p.scale && co < p.CO ? p.scale[co] : 1.0f;
+        esh[nt] = p.shift && co < p.CO ? p.shift[co] : 0.0f;
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            const int ox = xo0 + mg * 16 + (lane >> 4) * 4;     // Wo % 4 == 0: a quad is inside or outside as a whole
+            eoff[nt][mg] = co < p.CO && ox < Wo ? (unsigned)co * oplane4 + (unsigned)(wave * Wo + mg * 16 + (lane >> 4) * 4) * 4 : OOBZ;
+        }
+    }
 
     auto tile = [&](int ty, const unsigned char* buf) {
         f4 acc[AW];
 #pragma unroll
         for (int i = 0; i < AW; ++i) acc[i] = (f4){0, 0, 0, 0};
-        int kgroup = lane >> 4;
-        asm volatile("" : "+v"(kgroup));
         if constexpr (F32) {
             const float* wf = reinterpret_cast<const float*>(wlds);
 #pragma unroll
@@ -554,7 +579,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         } else if constexpr (X3) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
-                const int aoffk = a_offset(kb, kgroup);
+                const unsigned char* ap = buf + aoffs[F32 ? 0 : kb];
                 bf16x8 b[3][NTN];
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp)
@@ -566,7 +591,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
                     bf16x8 a[3];
 #pragma unroll
                     for (int sp = 0; sp < 3; ++sp)
-                        a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk + sp * CI * 2));
+                        a[sp] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS + sp * CI * 2));
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt) acc[mg * NTN + nt] = mfma_split3(a, b[0][nt], b[1][nt], b[2][nt], acc[mg * NTN + nt]);
                 }
@@ -574,13 +599,13 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         } else
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const int aoffk = a_offset(kb, kgroup);
+            const unsigned char* ap = buf + aoffs[F32 ? 0 : kb];
             bf16x8 b[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(kb * NTN + nt) * 64 + lane]);
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt)
                     acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
@@ -588,22 +613,22 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         }
         const int oy = ty * TYZ + wave;
         if (oy >= Ho) return;
+        const long torg = (long)ty * TYZ * Wo + xo0;   // tile origin inside an output channel plane
+        const __amdgpu_buffer_rsrc_t ro = z2_rsrc(p.out + torg), rk = z2_rsrc((p.skip ? p.skip : p.out) + torg);
+        f4 ek[AW];
 #pragma unroll
-        for (int nt = 0; nt < NTN; ++nt) {
-            const int co = nt * 16 + (lane & 15);
-            if (co >= p.CO) continue;
-            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+        for (int i = 0; i < AW; ++i) {
+            ek[i] = (f4){0, 0, 0, 0};
+            if (p.skip) ek[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rk, eoff[i % NTN][i / NTN], 0, 0));
+        }
 #pragma unroll
-            for (int mg = 0; mg < MG; ++mg) {
-                const int ox = xo0 + mg * 16 + (lane >> 4) * 4;
-                if (ox >= Wo) continue;                             // Wo % 4 == 0
-                const size_t o = (size_t)co * oplane + (size_t)oy * Wo + ox;
-                f4 y = acc[mg * NTN + nt] * sc + sh;
-                if (p.skip && !p.skip_after_act) y += *reinterpret_cast<const f4*>(p.skip + o);
-                if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
-                if (p.skip && p.skip_after_act) y = *reinterpret_cast<const f4*>(p.skip + o) + y;
-                *reinterpret_cast<f4*>(p.out + o) = y;
-            }
+        for (int i = 0; i < AW; ++i) {
+            const int nt = i % NTN, mg = i / NTN;
+            f4 y = acc[i] * esc[nt] + esh[nt];
+            if (p.skip && !p.skip_after_act) y += ek[i];
+            if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+            if (p.skip && p.skip_after_act) y = ek[i] + y;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), ro, eoff[nt][mg], 0, 0);
         }
     };
 
@@ -617,12 +642,12 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
         tile(ty, smem + cur * PATCH);
         if constexpr (NBUF == 2) {
             if (more) commit(smem + (cur ^ 1) * PATCH);
-            __syncthreads();
+            lds_barrier();
             cur ^= 1;
         } else {
-            __syncthreads();
+            lds_barrier();
             if (more) commit(smem);
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -667,7 +692,6 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W, OW = 2 * W;
-    const size_t plane = (size_t)H * W, oplane = 4 * plane;
     const int ix0 = blockIdx.x * TXI;
     const int nty = (H + TYZ - 1) / TYZ;
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
@@ -680,52 +704,90 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         for (int i = tid; i < (X3 ? 3 : 1) * NFRAG * 64; i += NTZ) wlds[i] = p.wpk[i];   // X3: [hi | mid | lo][fragments][lane]
     }
 
+    // task = (patch pixel, 8-channel group): eight dword loads, one cell slot; offsets, rows and cells per lane and for good,
+    // OOBZ offsets for what lies outside the image (see the stride-1 kernel)
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NTZ - 1) / NTZ;
+    const unsigned plane4 = (unsigned)H * W * 4, oplane4 = 4 * plane4;   // (host: every tensor < 2^31 bytes)
     float stg[ROUNDS][8];
+    unsigned svo[ROUNDS];
+    int spy[ROUNDS], scell[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int task = tid + r * NTZ;
+        const int pix = task / G, g = task - pix * G;
+        const int py = pix / PXI, px = pix - py * PXI;
+        const int gx = ix0 + px - ORG;
+        svo[r] = task < NTASK && gx >= 0 && gx < W ? (unsigned)(8 * g) * plane4 + (unsigned)(py * W + px) * 4 : OOBZ;
+        spy[r] = py;
+        scell[r] = task < NTASK ? pix * CS + g * (F32 ? 32 : 16) : -1;
+    }
     auto issue = [&](int ty) {
+        const int gy0 = ty * TYZ - ORG;
+        const bool inner = gy0 >= 0 && gy0 + PYI <= H;
+        const __amdgpu_buffer_rsrc_t rs = z2_rsrc(p.in + ((long)gy0 * W + ix0 - ORG));
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NTZ;
-            const int pix = task / G, g = task - pix * G;
-            const int py = pix / PXI, px = pix - py * PXI;
-            const int gx = ix0 + px - ORG, gy = ty * TYZ + py - ORG;
-            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = p.in + (size_t)(8 * g) * plane + (ok ? (size_t)gy * W + gx : 0);
+            unsigned vo = svo[r];
+            if (!inner) vo = (unsigned)(spy[r] + gy0) < (unsigned)H ? vo : OOBZ;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * plane];
-                stg[r][k] = ok ? v : 0.0f;
-            }
+            for (int k = 0; k < 8; ++k) stg[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, k * plane4, 0));
         }
     };
     auto commit = [&](unsigned char* dst) {
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NTZ;
-            if (task < NTASK) {
-                const int pix = task / G, g = task - pix * G;
+            if (scell[r] >= 0) {
+                unsigned char* cell = dst + scell[r];
                 if constexpr (F32) {
-                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
-                    *reinterpret_cast<f4*>(dst + pix * CS + g * 32 + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
+                    *reinterpret_cast<f4*>(cell) = (f4){stg[r][0], stg[r][1], stg[r][2], stg[r][3]};
+                    *reinterpret_cast<f4*>(cell + 16) = (f4){stg[r][4], stg[r][5], stg[r][6], stg[r][7]};
                 } else if constexpr (X3) {
-                    put8_split3(dst + pix * CS + g * 16, CI, stg[r]);
+                    put8_split3(cell, CI, stg[r]);
                 } else {
                     const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
                                   pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
-                    *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                    *reinterpret_cast<u4*>(cell) = v;
                 }
             }
         }
     };
     const int abase = (wave * PXI + (lane & 15)) * CS + (F32 ? (lane >> 4) * 4 : 0);
+    // epilogue state: channel lane & 15 (XF: < 8), four input pixels = eight outputs from column 2 ix on; byte offset of output
+    // row 2 (ty TYZ + wave) from the tile origin, OOBZ where the channel or the columns do not exist
+    const int eco = lane & 15;
+    const bool ecin = eco < p.CO && (!XF || eco < 8);
+    const float esc = p.scale && ecin ? p.scale[eco] : 1.0f, esh = p.shift && ecin ? p.shift[eco] : 0.0f;
+    unsigned eoff[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        const int ix = ix0 + mg * 16 + (lane >> 4) * 4;             // W % 4 == 0: inside or outside as a whole
+        eoff[mg] = ecin && ix < W ? (unsigned)eco * oplane4 + (unsigned)(2 * wave * OW + 2 * (mg * 16 + (lane >> 4) * 4)) * 4 : OOBZ;
+    }
+    // both halves of the lane's eight outputs: skip operand in, result out
+    auto finish = [&](int ty, int PY, int mg, f4 e, f4 od) {
+        const long torg = ((long)(2 * ty * TYZ + PY)) * OW + 2 * ix0;   // tile origin inside an output channel plane
+        const __amdgpu_buffer_rsrc_t ro = z2_rsrc(p.out + torg), rk = z2_rsrc((p.skip ? p.skip : p.out) + torg);
+        const unsigned o = ty * TYZ + wave < H ? eoff[mg] : OOBZ;
+        f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
+        if (p.skip) {
+            const f4 k0 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rk, o, 0, 0));
+            const f4 k1 = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rk, o, 16, 0));
+            if (!p.skip_after_act) { lo += k0; hi += k1; }
+            if (p.act == 1) { lo = __builtin_elementwise_max(lo, (f4){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4){0, 0, 0, 0}); }
+            if (p.skip_after_act) { lo = k0 + lo; hi = k1 + hi; }
+        } else if (p.act == 1) {
+            lo = __builtin_elementwise_max(lo, (f4){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4){0, 0, 0, 0});
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, lo), ro, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, hi), ro, o, 16, 0);
+    };
 
     auto row = [&](auto pyc, int ty, const unsigned char* buf) {   // output row 2 iy + PY of this wave's input row: both column parities
         constexpr int PY = decltype(pyc)::value;
         if constexpr (XF) {
             f4 accf = {0, 0, 0, 0};
-            int kg = lane >> 4;
-            asm volatile("" : "+v"(kg));
+            const int kg = lane >> 4;   // (not opaque: the K offsets are tile-invariant, the compiler keeps or folds them)
 #pragma unroll
             for (int kb = 0; kb < NKBF; ++kb) {
                 const int k0 = 32 * kb + 8 * kg;
@@ -744,18 +806,7 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
             f4 oddf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) oddf[r] = dpp_row_ror8(accf[r]);   // columns 8..15 -> the lanes of columns 0..7
-            const int iy = ty * TYZ + wave, co = lane & 15;
-            const int ix = ix0 + (lane >> 4) * 4;
-            if (iy >= H || co >= 8 || co >= p.CO || ix >= W) return;
-            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
-            const size_t o = (size_t)co * oplane + (size_t)(2 * iy + PY) * OW + 2 * ix;
-            const f4 e = accf * sc + sh, od = oddf * sc + sh;
-            f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
-            if (p.skip && !p.skip_after_act) { lo += *reinterpret_cast<const f4*>(p.skip + o); hi += *reinterpret_cast<const f4*>(p.skip + o + 4); }
-            if (p.act == 1) { lo = __builtin_elementwise_max(lo, (f4){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4){0, 0, 0, 0}); }
-            if (p.skip && p.skip_after_act) { lo = *reinterpret_cast<const f4*>(p.skip + o) + lo; hi = *reinterpret_cast<const f4*>(p.skip + o + 4) + hi; }
-            *reinterpret_cast<f4*>(p.out + o) = lo;
-            *reinterpret_cast<f4*>(p.out + o + 4) = hi;
+            finish(ty, PY, 0, accf * esc + esh, oddf * esc + esh);
             return;
         }
         f4 acc[2][MG];
@@ -763,8 +814,7 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         for (int px = 0; px < 2; ++px)
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) acc[px][mg] = (f4){0, 0, 0, 0};
-        int kgroup = lane >> 4;
-        asm volatile("" : "+v"(kgroup));
+        const int kgroup = lane >> 4;
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
             const int NKB = nkb2(CI, PY, px, F32, K4);
@@ -814,25 +864,8 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
                 }
             }
         }
-        const int iy = ty * TYZ + wave;
-        if (iy >= H) return;
-        const int oy = 2 * iy + PY;
-        const int co = lane & 15;
-        if (co >= p.CO) return;
-        const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
 #pragma unroll
-        for (int mg = 0; mg < MG; ++mg) {
-            const int ix = ix0 + mg * 16 + (lane >> 4) * 4;
-            if (ix >= W) continue;                                  // W % 4 == 0: four input pixels = eight outputs, inside or outside as a whole
-            const size_t o = (size_t)co * oplane + (size_t)oy * OW + 2 * ix;
-            const f4 e = acc[0][mg] * sc + sh, od = acc[1][mg] * sc + sh;
-            f4 lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
-            if (p.skip && !p.skip_after_act) { lo += *reinterpret_cast<const f4*>(p.skip + o); hi += *reinterpret_cast<const f4*>(p.skip + o + 4); }
-            if (p.act == 1) { lo = __builtin_elementwise_max(lo, (f4){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4){0, 0, 0, 0}); }
-            if (p.skip && p.skip_after_act) { lo = *reinterpret_cast<const f4*>(p.skip + o) + lo; hi = *reinterpret_cast<const f4*>(p.skip + o + 4) + hi; }
-            *reinterpret_cast<f4*>(p.out + o) = lo;
-            *reinterpret_cast<f4*>(p.out + o + 4) = hi;
-        }
+        for (int mg = 0; mg < MG; ++mg) finish(ty, PY, mg, acc[0][mg] * esc + esh, acc[1][mg] * esc + esh);
     };
 
     issue(t0);
@@ -846,12 +879,12 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
         row(std::integral_constant<int, 1>{}, ty, smem + cur * PATCH);
         if constexpr (NBUF == 2) {
             if (more) commit(smem + (cur ^ 1) * PATCH);
-            __syncthreads();
+            lds_barrier();
             cur ^= 1;
         } else {
-            __syncthreads();
+            lds_barrier();
             if (more) commit(smem);
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -862,6 +895,7 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     constexpr int CS = z2_cell_bytes<F32, X3>(CI);
     constexpr int lds = (X3 ? 1 : 2) * (32 * MG + KS - 2) * (2 * TYZ + KS - 2) * CS + NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    if ((long)(CI > p.CO ? CI : p.CO) * p.H * p.W * 4 * (1) >= (1L << 31)) return D3D_ERR_UNSUPPORTED;   // (32-bit buffer offsets)
     auto kern = conv2d_s2_zs_bf16_kernel<CI, NTN, F32, X3, KS, MG>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
@@ -885,6 +919,7 @@ static int launch_tz(const Z2Params& p, hipStream_t stream) {
     constexpr int NFRAG = XF ? 2 * ((6 * CI + 31) / 32) : frag_base2(CI, 4, F32, K4);
     constexpr int lds = (X3 && CI > 8 ? 1 : 2) * (K4 ? (TXI + 2) * 10 : 33 * 9) * CS + NFRAG * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    if ((long)(CI > p.CO ? CI : p.CO) * p.H * p.W * 4 * (4) >= (1L << 31)) return D3D_ERR_UNSUPPORTED;   // (32-bit buffer offsets)
     auto kern = convt2d_zs_bf16_kernel<CI, F32, X3, K4, XF>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
