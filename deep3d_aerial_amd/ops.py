@@ -1211,13 +1211,16 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
         if y is not None:
             return y
-    if stride == 1 and act in (0, 1) and x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8), (48, 48)) and _use_mfma() \
+    # (the concat convolutions of AdaMVS's pyramid decoder, adamvs.py:104-113: 16 -> 8 at full, 32 -> 16 at half resolution --
+    #  228 / 148 us on the tile kernel against 272 / 194 us on the vector-unit kernel since the round-4 rebuild of the tile kernels)
+    fuse = x2 is not None and (Ci0 + Ci1, Co) in ((16, 8), (32, 16))
+    if stride == 1 and act in (0, 1) and ((x2 is None and (Ci0, Co) in ((32, 32), (16, 16), (8, 8), (48, 48))) or fuse) and _use_mfma() \
             and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128):
         # 32 -> 32, 16 -> 16 and 8 -> 8 (the trunks of the feature pyramids) in fp32 accuracy: the tile kernel beats the
         # row-streamed matrix-core form (140 -> 68 us at 464 x 688) and the vector-unit kernel (140 -> 68 us at 928 x 1376,
         # 180 -> 130 us at 1856 x 2752); 32 -> 8 | 16 (the FPN output layers) lose there and stay on the kernels below.
         # 48 -> 48 (the pair-visibility UNet of AdaMVS): fp32 instruction, one patch buffer (340 -> 90 us at 688 x 464)
-        y = conv2d_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
+        y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True)
         if y is not None:
             return y
     if stride == 1 and act in (0, 1):
