@@ -186,28 +186,26 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         const __amdgpu_buffer_rsrc_t rq1 = z2_rsrc(p.in + ((long)gy0 * W + x0)), rs1 = z2_rsrc(p.in + ((long)gy0 * W + x0 - 1));
         const __amdgpu_buffer_rsrc_t rq2 = z2_rsrc((p.in2 ? p.in2 : p.in) + ((long)gy0 * W + x0)), rs2 = z2_rsrc((p.in2 ? p.in2 : p.in) + ((long)gy0 * W + x0 - 1));
         // Two sources: the descriptor of a buffer instruction is scalar, and a per-lane choice between two of them is compiled
-        // into a loop over the distinct descriptors around EVERY load.  So with a second tensor each task asks both, with an OOB
-        // offset for the one its channels are not in, and ORs the answers (one of them is zeros); without it: one descriptor.
+        // into a loop over the distinct descriptors around every load (two passes when a wave's tasks straddle the tensors).  That
+        // is what the two-tensor layers get (asking both tensors with an OOB offset for the wrong one and OR-ing the answers was
+        // measured: 725 against 562 us for the three launches of an unfused stage-3 cell); a layer with ONE input must not pay
+        // for it, hence the uniform branch.
         if (p.in2) {
 #pragma unroll
             for (int r = 0; r < RQ; ++r) {
                 unsigned vo = qvo[r];
                 if (!inner) vo = (unsigned)(qpy[r] + gy0) < (unsigned)H ? vo : OOBZ;
-                const unsigned vo1 = q2[r] ? OOBZ : vo, vo2 = q2[r] ? vo : OOBZ;
+                const __amdgpu_buffer_rsrc_t rs = q2[r] ? rq2 : rq1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    stq[r][k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rq1, vo1, k * plane4, 0) |
-                                                           __builtin_amdgcn_raw_buffer_load_b128(rq2, vo2, k * plane4, 0));
+                for (int k = 0; k < 4; ++k) stq[r][k] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, k * plane4, 0));
             }
 #pragma unroll
             for (int r = 0; r < RS; ++r) {
                 unsigned vo = svo[r];
                 if (!inner) vo = (unsigned)(spy[r] + gy0) < (unsigned)H ? vo : OOBZ;
-                const unsigned vo1 = s2[r] ? OOBZ : vo, vo2 = s2[r] ? vo : OOBZ;
+                const __amdgpu_buffer_rsrc_t rs = s2[r] ? rs2 : rs1;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    sts[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vo1, k * plane4, 0) |
-                                                              __builtin_amdgcn_raw_buffer_load_b32(rs2, vo2, k * plane4, 0));
+                for (int k = 0; k < 4; ++k) sts[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, k * plane4, 0));
             }
             return;
         }

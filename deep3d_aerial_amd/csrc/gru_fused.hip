@@ -474,7 +474,7 @@ extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI
     p.wc = reinterpret_cast<const u4*>(wc); p.bg = bg; p.bc = bc; p.H = H; p.W = W; p.HI = HI; p.WI = WI;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1 && HID == 8) {
-        if (CP == 8) return launch_gru<8, 8, 1, 4, 8>(p, st);
+        if (CP == 8) return launch_gru<8, 8, 1, 4, 8>(p, st);   // (12- / 16-row tiles at one workgroup per CU: 306 / 283 against 244-254 us at stage 3)
         if (CP == 16) return launch_gru<16, 8, 1, 4, 8>(p, st);
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }
