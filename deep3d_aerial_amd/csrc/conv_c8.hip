@@ -84,10 +84,14 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
     constexpr int NKB = (9 * CI + 31) / 32;            // K blocks of 32 per k_z slice
     // bytes per pixel cell: an ODD number of 16-byte slots (1 | 3 | 5) -- split operands: 3 slots, 6 (16 channels: unpadded, so that
     // patch + weights stay under half the LDS and two workgroups share a CU; the A reads are a quarter of the LDS reads) or 13
-    constexpr int CS = X3 ? (CI == 16 ? 96 : 6 * CI + (CI > 8 ? 16 : 0)) : 2 * CI + (CI > 8 ? 16 : 0);
+    // bf16 cells: 16 | 32 bytes (8 | 16 channels); 32 | 64 channels as PLANES of 16-channel cells -- the bank-conflict-free pitch
+    // of common.h without the padding of a 96- | 160-byte cell (the 32 -> 32 layer's patch + weights would not fit)
+    constexpr bool PL = !X3 && CI == 32;              // (64 -> 64 at 1/512 of the voxels keeps its 144-byte cells: planes measured 0.27 -> 0.30 ms per view)
+    constexpr int CS = X3 ? (CI == 16 ? 96 : 6 * CI + (CI > 8 ? 16 : 0)) : PL ? 32 : CI == 64 ? 144 : bf16_cell_bytes(CI);
     constexpr int NBUF = X3 && CI >= 16 ? 1 : 2;   // split cells of 16 | 32 channels: ONE patch buffer (commit after every wave has read it)
     constexpr int G = CI / 8;                          // 8-channel groups per pixel
-    constexpr int PATCH = PX * PY * CS;
+    constexpr int PLANE = PX * PY * CS + 64;          // (planes: 64 mod 128 bytes apart, so a 16-byte staging store's eight lanes -- two pixels x two planes -- spread over the banks)
+    constexpr int PATCH = PL ? (CI / 16) * PLANE : PX * PY * CS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
         const int k0 = 32 * kb + 8 * kgroup;
         const int t = k0 / CI, c = k0 % CI;
         const int ky = t < 9 ? t / 3 : 0, kx = t < 9 ? t % 3 : 0;   // padded taps read a valid cell; their weights are zero
-        return (ky * PX + kx) * CS + (t < 9 ? c : 0) * 2;
+        const int cc = t < 9 ? c : 0;
+        return (ky * PX + kx) * CS + (PL ? (cc >> 4) * PLANE + (cc & 15) * 2 : cc * 2);
     };
     int aoffs[WG ? 1 : NKB];
     if constexpr (!WG) {
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             stok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const unsigned cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
             stoff[r] = p.in_cl8 ? ((g * H + cy) * W + cx) * 16 : (cy * W + cx) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes)
-            stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
+            stdst[r] = task < NTASK ? (PL ? (g >> 1) * PLANE + pix * CS + (g & 1) * 16 : pix * CS + g * 16) : -1;
         }
     }
     bool stzin = false;   // the plane in the staging registers is inside the volume
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                 if constexpr (INCL) v = stc[rr];
                 else v = (u4){pack_bf16(stg[rr][0], stg[rr][1]), pack_bf16(stg[rr][2], stg[rr][3]), pack_bf16(stg[rr][4], stg[rr][5]),
                               pack_bf16(stg[rr][6], stg[rr][7])};
-                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                *reinterpret_cast<u4*>(dst + (PL ? (g >> 1) * PLANE + pix * CS + (g & 1) * 16 : pix * CS + g * 16)) = v;
             }
         }
     };
@@ -495,9 +500,10 @@ static int launch(const C8Params& p, hipStream_t stream) {
     if constexpr (OUTCL && NTN == 1 && !KZF && !WG && !CO8)
         if (p.CO == 8) return launch<CI, NTN, INCL, OUTCL, MGN, WG, KZF, true>(p, stream);   // whole-cell stores (see store_plane)
     constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = X3 ? (CI == 16 ? 96 : 6 * CI + (CI > 8 ? 16 : 0)) : 2 * CI + (CI > 8 ? 16 : 0);
+    constexpr bool PL = !X3 && CI == 32;
+    constexpr int CS = X3 ? (CI == 16 ? 96 : 6 * CI + (CI > 8 ? 16 : 0)) : PL ? 32 : CI == 64 ? 144 : bf16_cell_bytes(CI);
     constexpr int TXk = 16 * MGN, PXk = TXk + 2;
-    constexpr int lds = (X3 && CI >= 16 ? 1 : 2) * PXk * PY * CS + (WG ? 0 : (X3 ? 3 : 1) * (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
+    constexpr int lds = (X3 && CI >= 16 ? 1 : 2) * (PL ? (CI / 16) * (PXk * PY * CS + 64) : PXk * PY * CS) + (WG ? 0 : (X3 ? 3 : 1) * (KZF ? 1 : 3) * NKB * NTN * 64 * 16);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = conv3d_c8_bf16_kernel<CI, NTN, INCL, OUTCL, MGN, WG, KZF, CO8, X3>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     constexpr int TXO = 16 * MGK, MG = MGK;          // output tile width, 16-pixel groups per wave (= output row)
     constexpr int PXI = 2 * TXO + 1, NEVEN = TXO + 1;   // staged patch columns; the even ones come first in a row, then the TXO odd ones
     constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);   // odd number of 16-byte slots
+    constexpr int CS = bf16_cell_bytes(CI);   // (bank-conflict-free pitch: common.h)
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
     constexpr int AW = MG * NTN;
@@ -255,7 +255,7 @@ auto kb_body = [&](int kb) {
 template <int CI, int NTN, int MGK = 2, bool WG = false>
 static int launch_s2(const S2Params& p, hipStream_t stream) {
     constexpr int NKB = (9 * CI + 31) / 32;
-    constexpr int CS = CI * 2 + (CI > 8 ? 16 : 0);
+    constexpr int CS = bf16_cell_bytes(CI);
     constexpr int TXOk = 16 * MGK, PXIk = 2 * TXOk + 1;
     const int lds = 2 * PXIk * PYI * CS + (WG ? 0 : 3 * NKB * NTN * 64 * 16);
     auto kern = conv3d_s2_cl_kernel<CI, NTN, MGK, WG>;

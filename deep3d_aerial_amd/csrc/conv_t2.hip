@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     constexpr int NT = 64 * TYI;
     constexpr int TXI = 16 * MG;
     constexpr int PXI = TXI + 1, PYI = TYI + 1;         // input patch: one more column / row for the d = 1 taps
-    constexpr int CS = (X3 ? 6 : 2) * CI + 16;          // bytes per cell: 3 | 5 | 9 sixteen-byte slots (odd); split: 7 | 13
+    constexpr int CS = X3 ? 6 * CI + 16 : CI == 64 ? 144 : bf16_cell_bytes(CI);   // bytes per cell (bank-conflict-free pitch: common.h; 64 channels: 160-byte cells measured 0.17 -> 0.21 ms per view)
     constexpr int G = CI / 8;
     constexpr int PATCH = PXI * PYI * CS;
     constexpr int NFRAG = FOLD ? fold_base(CI, 4) : frag_base(CI, 8);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
 template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false>
 static int launch(const T2Params& p, hipStream_t stream) {
     constexpr int TXI = 16 * MG;
-    constexpr int CS = (X3 ? 6 : 2) * CI + 16;
+    constexpr int CS = X3 ? 6 * CI + 16 : CI == 64 ? 144 : bf16_cell_bytes(CI);
     constexpr int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (X3 ? 3 : 1) * (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD, X3>;

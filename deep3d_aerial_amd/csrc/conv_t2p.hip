@@ -33,9 +33,10 @@ constexpr int NW = 8, NT = 64 * NW;
 constexpr int RXI = 32, RYI = 12;               // coarse cells whose y is computed per plane
 constexpr int OXI = RXI - 2, OYI = RYI - 2;     // coarse cells whose 2 x 2 outputs the workgroup finishes
 constexpr int PXI = RXI + 1, PYI = RYI + 1;     // staged coarse patch: one more column / row for the d = 1 taps
-constexpr int CS = 2 * CI + 16;                 // bytes per coarse cell: 3 sixteen-byte slots (odd)
+constexpr int CS = bf16_cell_bytes(CI);         // bytes per coarse cell: 32 (bank-conflict-free pitch: common.h)
 constexpr int PATCH = PXI * PYI * CS;
-constexpr int YP = 2 * RXI + 4, YR = 2 * RYI;   // y plane in LDS: 16-byte cells, rows of 68 (the last pixel group's lanes 12..15 read past column 63)
+constexpr int YP = 2 * RXI + 18, YR = 2 * RYI;  // y plane in LDS: 16-byte cells, rows of 82 -- the last pixel group's lanes 12..15 read past column 63, and
+                                                // taps (0, 2) | (1, 0) of one lane group sit a whole bank row apart (YP - 2 = 80 cells; tools/conv_bank_sim.py)
 constexpr int YBYTES = YP * YR * 16;
 constexpr int TTILES = RYI * (RXI / 16) / NW;   // conv11 tiles (coarse row, 16-cell group) per wave: 3
 constexpr int PTILES = 2 * OYI * 4 / NW;        // probability tiles (output row, 16-pixel group) per wave: 10

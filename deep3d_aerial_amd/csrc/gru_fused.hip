@@ -86,9 +86,9 @@ struct GruGeom {
     static constexpr int RX = 16 * MG, RY = TY + 4;          // region of x / h / r*h
     static constexpr int OX = RX - 8;                        // output tile width: region columns 4 .. RX - 5 (whole aligned quads)
     static constexpr int PITCH = RX + 2;                     // cells per region row (column c lives at c + 1)
-    static constexpr int XC = HID == 8 ? 16 : 48;            // bytes per region cell (an odd number of 16-byte slots)
-    static constexpr int REG = RY * PITCH * XC;              // one of X | H | R
-    static constexpr int CS1 = S == 2 ? 16 : CP * 2 + (CP > 8 ? 16 : 0);   // cost cell
+    static constexpr int XC = bf16_cell_bytes(HID);          // bytes per region cell (bank-conflict-free pitch: common.h)
+    static constexpr int REG = ((RY * PITCH * XC + 255) / 256) * 256;   // one of X | H | R: a K group of x and one of h / r*h share a lane group -- whole bank rows apart
+    static constexpr int CS1 = S == 2 ? 16 : bf16_cell_bytes(CP);   // cost cell
     static constexpr int SPX = S == 2 ? 2 * RX + 1 : RX + 2, SPY = S == 2 ? 2 * RY + 1 : RY + 2;
     static constexpr int NEVEN = RX + 1;                     // S = 2: even columns 0, 2, .. 2 RX first, then the odd ones
     static constexpr int SIMB = ((SPX * SPY * CS1 + 15) / 16) * 16;
