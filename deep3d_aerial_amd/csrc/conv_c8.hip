@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             const int gx = x0 + px - 1, gy = y0 + py - 1;
             stok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const unsigned cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-            stoff[r] = p.in_cl8 ? ((g * H + cy) * W + cx) * 16 : (cy * W + cx) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes)
+            stoff[r] = task >= NTASK ? 0 : p.in_cl8 ? ((g * H + cy) * W + cx) * 16 : (cy * W + cx) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes; no task: the plane's first bytes, one line)
             stdst[r] = task < NTASK ? (PL ? (g >> 1) * PLANE + pix * CS + (g & 1) * 16 : pix * CS + g * 16) : -1;
         }
     }
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
         const bool zin = zi >= 0 && zi < D;
         stzin = zin;
         if constexpr (INCL) {
+            if (!zin) return;   // (uniform) a plane outside the volume: nothing loaded, the commit writes zeros
             const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * plane * (CI * 2);
 #pragma unroll
             for (int rr = 0; rr < RH; ++rr) {
@@ -532,7 +533,7 @@ static int launch_fmt(const C8Params& p, int Ci, int Co, hipStream_t st) {
         case 16:
             // channel-last in and out: 32-wide tiles keep the kernel inside 128 registers (102), so two workgroups share a CU
             // (16 -> 8 at 32 x 928 x 1376: 1.09 -> 0.95 ms on the same box)
-            if constexpr (INCL && OUTCL) return launch<16, 1, true, true, 2>(p, st);
+            if constexpr (INCL && OUTCL) return launch<16, 1, true, true, 2>(p, st);   // (64-wide tiles, round 4 again: 0.675 -> 0.70-0.72 ms at stage 2)
             else return launch<16, 1, INCL, OUTCL>(p, st);
         default: return launch<32, 1, INCL, OUTCL>(p, st);
     }

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
         const int py = pix / PXI, px = pix - py * PXI;
         const int gx = 2 * xo0 - 1 + px, gy = 2 * yo0 - 1 + py;
         stok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-        stoff[r] = ((unsigned)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * (CI * 2) + g * 16;
+        stoff[r] = task >= NTASK ? 0 : ((unsigned)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * (CI * 2) + g * 16;   // (no task: every such lane reads the plane's first bytes -- one line -- instead of real cells beyond the patch)
         const int cell = py * PXI + ((px & 1) ? NEVEN + (px >> 1) : (px >> 1));
         stdst[r] = task < NTASK ? cell * CS + g * 16 : -1;
     }
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
     auto issue = [&](int zi) {
         const bool zin = zi >= 0 && zi < D;
         stzin = zin;
+        if (!zin) return;   // (uniform) a plane outside the volume: nothing loaded, the commit writes zeros
         const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * iplane;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             const int py = pix / PXI, px = pix - py * PXI;
             const int gx = ix0 + px, gy = iy0 + py;
             stok[r] = task < NTASK && gx < W && gy < H;
-            stoff[r] = ((unsigned)min(gy, H - 1) * W + min(gx, W - 1)) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes)
+            stoff[r] = task >= NTASK ? 0 : ((unsigned)min(gy, H - 1) * W + min(gx, W - 1)) * (CI * 2) + g * 16;   // (host: a plane is < 2^31 bytes; no task: the plane's first bytes, one line)
             stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
         }
     }
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
         const bool zin = zi >= 0 && zi < D;
         stzin = zin;
         if constexpr (CL) {
+            if (!zin) return;   // (uniform) a plane outside the volume: nothing loaded, the commit writes zeros
             const unsigned char* __restrict__ src = static_cast<const unsigned char*>(p.in) + (size_t)min(max(zi, 0), D - 1) * iplane * (CI * 2);
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {

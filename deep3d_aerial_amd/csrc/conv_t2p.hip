@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NT, 4) void convt3d_prob_kernel(T2PParams p) {
         const int py = pix / PXI, px = pix - py * PXI;
         const int gx = cx0 + px, gy = cy0 + py;
         stok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-        stoff[r] = ((unsigned)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * (CI * 2) + g * 16;
+        stoff[r] = task >= NTASK ? 0 : ((unsigned)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * (CI * 2) + g * 16;   // (no task: every such lane reads the plane's first bytes -- one line -- instead of real cells beyond the patch)
         stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
     }
     u4 stc[ROUNDS];
