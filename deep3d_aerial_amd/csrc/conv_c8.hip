@@ -168,6 +168,23 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             stdst[r] = task < NTASK ? (PL ? (g >> 1) * PLANE + pix * CS + (g & 1) * 16 : pix * CS + g * 16) : -1;
         }
     }
+    // planar fp32 input (fp32 mode and the first layer of bf16 mode without a CL8 volume): the same per-lane state -- element
+    // offset of the task's first channel inside a plane (clamped), whether it is inside the image, its cell
+    size_t poff[INCL ? 1 : ROUNDS];
+    int pdst[INCL ? 1 : ROUNDS];
+    bool pok[INCL ? 1 : ROUNDS];
+    if constexpr (!INCL) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PX, px = pix - py * PX;
+            const int gx = x0 + px - 1, gy = y0 + py - 1;
+            pok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            poff[r] = task < NTASK ? (size_t)(8 * g) * vol + (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1) : 0;
+            pdst[r] = task < NTASK ? (PL ? (g >> 1) * PLANE + pix * CS + (g & 1) * 16 : pix * CS + g * 16) : -1;
+        }
+    }
     bool stzin = false;   // the plane in the staging registers is inside the volume
     auto issue = [&](int zi, int r0, int r1) {   // global loads of input plane zi, rounds [r0, r1), into registers (zeros outside the volume)
         const bool zin = zi >= 0 && zi < D;
@@ -184,22 +201,15 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             }
             return;
         }
+        if (!zin) return;   // (uniform) a plane outside the volume: nothing loaded, the commit writes zeros
+        const float* __restrict__ srcp = static_cast<const float*>(p.in) + (size_t)zi * plane;
 #pragma unroll
         for (int rr = 0; rr < RH; ++rr) {
             const int r = r0 + rr;
             if (r >= r1) break;
-            const int task = tid + r * NT;
-            const int pix = task / G, g = task - pix * G;
-            const int py = pix / PX, px = pix - py * PX;
-            const int gx = x0 + px - 1, gy = y0 + py - 1;
-            const bool ok = zin && task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * vol + (size_t)(ok ? zi : 0) * plane +
-                (ok ? (size_t)gy * W + gx : 0);
+            const float* __restrict__ src = srcp + poff[INCL ? 0 : r];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * vol];
-                stg[rr][k] = ok ? v : 0.0f;
-            }
+            for (int k = 0; k < 8; ++k) stg[rr][k] = src[(size_t)k * vol];   // raw: zeroed when committed (a select here would wait for the load)
         }
     };
     auto commit = [&](unsigned char* dst, int r0, int r1) {   // registers -> bf16 cells
@@ -216,33 +226,31 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
         for (int rr = 0; rr < RH; ++rr) {
             const int r = r0 + rr;
             if (r >= r1) break;
-            const int task = tid + r * NT;
-            if (task < NTASK) {
-                const int pix = task / G, g = task - pix * G;
+            if (pdst[INCL ? 0 : r] >= 0) {
+                const bool ok = stzin && pok[INCL ? 0 : r];
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = ok ? stg[rr][k] : 0.0f;
+                unsigned char* cell = dst + pdst[INCL ? 0 : r];
                 if constexpr (X3) {   // hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the differences are exact in fp32
                     float r1[8], r2[8];
                     unsigned hi[4], mi[4], lo[4];
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) {
-                        hi[k >> 1] = pack_bf16(stg[rr][k], stg[rr][k + 1]);
-                        r1[k] = stg[rr][k] - __builtin_bit_cast(float, hi[k >> 1] << 16);
-                        r1[k + 1] = stg[rr][k + 1] - __builtin_bit_cast(float, hi[k >> 1] & 0xffff0000u);
+                        hi[k >> 1] = pack_bf16(x[k], x[k + 1]);
+                        r1[k] = x[k] - __builtin_bit_cast(float, hi[k >> 1] << 16);
+                        r1[k + 1] = x[k + 1] - __builtin_bit_cast(float, hi[k >> 1] & 0xffff0000u);
                         mi[k >> 1] = pack_bf16(r1[k], r1[k + 1]);
                         r2[k] = r1[k] - __builtin_bit_cast(float, mi[k >> 1] << 16);
                         r2[k + 1] = r1[k + 1] - __builtin_bit_cast(float, mi[k >> 1] & 0xffff0000u);
                         lo[k >> 1] = pack_bf16(r2[k], r2[k + 1]);
                     }
-                    unsigned char* cell = dst + pix * CS + g * 16;
                     *reinterpret_cast<u4*>(cell) = (u4){hi[0], hi[1], hi[2], hi[3]};
                     *reinterpret_cast<u4*>(cell + CI * 2) = (u4){mi[0], mi[1], mi[2], mi[3]};
                     *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
                     continue;
                 }
-                u4 v;
-                if constexpr (INCL) v = stc[rr];
-                else v = (u4){pack_bf16(stg[rr][0], stg[rr][1]), pack_bf16(stg[rr][2], stg[rr][3]), pack_bf16(stg[rr][4], stg[rr][5]),
-                              pack_bf16(stg[rr][6], stg[rr][7])};
-                *reinterpret_cast<u4*>(dst + (PL ? (g >> 1) * PLANE + pix * CS + (g & 1) * 16 : pix * CS + g * 16)) = v;
+                *reinterpret_cast<u4*>(cell) = (u4){pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
             }
         }
     };

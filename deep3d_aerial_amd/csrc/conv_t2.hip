@@ -128,6 +128,22 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             stdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
         }
     }
+    // planar fp32 input: the same per-lane state (element offset of the task's first channel inside a plane, clamped)
+    size_t poff[CL ? 1 : ROUNDS];
+    int pdst[CL ? 1 : ROUNDS];
+    bool pok[CL ? 1 : ROUNDS];
+    if constexpr (!CL) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int task = tid + r * NT;
+            const int pix = task / G, g = task - pix * G;
+            const int py = pix / PXI, px = pix - py * PXI;
+            const int gx = ix0 + px, gy = iy0 + py;
+            pok[r] = task < NTASK && gx < W && gy < H;
+            poff[r] = task < NTASK ? (size_t)(8 * g) * ivol + (size_t)min(gy, H - 1) * W + min(gx, W - 1) : 0;
+            pdst[r] = task < NTASK ? pix * CS + g * 16 : -1;
+        }
+    }
     bool stzin = false;   // the plane in the staging registers is inside the volume
     auto issue = [&](int zi) {
         const bool zin = zi >= 0 && zi < D;
@@ -142,20 +158,13 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
             }
             return;
         }
+        if (!zin) return;   // (uniform) a plane outside the volume: nothing loaded, the commit writes zeros
+        const float* __restrict__ srcp = static_cast<const float*>(p.in) + (size_t)zi * iplane;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NT;
-            const int pix = task / G, g = task - pix * G;
-            const int py = pix / PXI, px = pix - py * PXI;
-            const int gx = ix0 + px, gy = iy0 + py;
-            const bool ok = zin && task < NTASK && gx < W && gy < H;
-            const float* __restrict__ src = static_cast<const float*>(p.in) + (size_t)(8 * g) * ivol + (size_t)(ok ? zi : 0) * iplane +
-                (ok ? (size_t)gy * W + gx : 0);
+            const float* __restrict__ src = srcp + poff[CL ? 0 : r];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * ivol];
-                stg[r][k] = ok ? v : 0.0f;
-            }
+            for (int k = 0; k < 8; ++k) stg[r][k] = src[(size_t)k * ivol];   // raw: zeroed when committed
         }
     };
     auto commit = [&](unsigned char* dst) {
@@ -167,32 +176,30 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
         }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * NT;
-            if (task < NTASK) {
-                const int pix = task / G, g = task - pix * G;
+            if (pdst[CL ? 0 : r] >= 0) {
+                const bool ok = stzin && pok[CL ? 0 : r];
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = ok ? stg[r][k] : 0.0f;
+                unsigned char* cell = dst + pdst[CL ? 0 : r];
                 if constexpr (X3) {   // hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the differences are exact in fp32
                     unsigned hi[4], mi[4], lo[4];
 #pragma unroll
                     for (int k = 0; k < 8; k += 2) {
-                        hi[k >> 1] = pack_bf16_t2(stg[r][k], stg[r][k + 1]);
-                        const float a1 = stg[r][k] - __builtin_bit_cast(float, hi[k >> 1] << 16);
-                        const float b1 = stg[r][k + 1] - __builtin_bit_cast(float, hi[k >> 1] & 0xffff0000u);
+                        hi[k >> 1] = pack_bf16_t2(x[k], x[k + 1]);
+                        const float a1 = x[k] - __builtin_bit_cast(float, hi[k >> 1] << 16);
+                        const float b1 = x[k + 1] - __builtin_bit_cast(float, hi[k >> 1] & 0xffff0000u);
                         mi[k >> 1] = pack_bf16_t2(a1, b1);
                         const float a2 = a1 - __builtin_bit_cast(float, mi[k >> 1] << 16);
                         const float b2 = b1 - __builtin_bit_cast(float, mi[k >> 1] & 0xffff0000u);
                         lo[k >> 1] = pack_bf16_t2(a2, b2);
                     }
-                    unsigned char* cell = dst + pix * CS + g * 16;
                     *reinterpret_cast<u4*>(cell) = (u4){hi[0], hi[1], hi[2], hi[3]};
                     *reinterpret_cast<u4*>(cell + CI * 2) = (u4){mi[0], mi[1], mi[2], mi[3]};
                     *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
                     continue;
                 }
-                u4 v;
-                if constexpr (CL) v = stc[r];
-                else v = (u4){pack_bf16_t2(stg[r][0], stg[r][1]), pack_bf16_t2(stg[r][2], stg[r][3]), pack_bf16_t2(stg[r][4], stg[r][5]),
-                              pack_bf16_t2(stg[r][6], stg[r][7])};
-                *reinterpret_cast<u4*>(dst + pix * CS + g * 16) = v;
+                *reinterpret_cast<u4*>(cell) = (u4){pack_bf16_t2(x[0], x[1]), pack_bf16_t2(x[2], x[3]), pack_bf16_t2(x[4], x[5]), pack_bf16_t2(x[6], x[7])};
             }
         }
     };
