@@ -527,6 +527,22 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         if rc != _lib.ERR_UNSUPPORTED:
             _lib.check(rc, "d3d_conv3d_k3_c1_bf16x3")
             return out
+    if stride == 2 and (Ci, Co) in ((8, 16), (16, 32), (32, 64)) and ((W - 1) // 2 + 1) % 4 == 0 and _use_mfma() \
+            and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
+        # fp32 mode of conv1 / conv3 / conv5 (cas_mvsnet.py:86,89,92): the stride-2 z-streaming kernel on three-way bf16 splits
+        # (csrc/conv_s2x3.hip) instead of the vector-unit stream kernels
+        wp = derived_weight(weight, "c8bf16x3", _pack_c8_bf16x3)
+        o = lambda n: (n - 1) // 2 + 1
+        out = torch.empty((Co, o(D), o(H), o(W)), dtype=torch.float32, device=x.device)
+        if skip is not None and skip.shape != out.shape:
+            raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
+        rc = _lib.load().d3d_conv3d_k3s2_zs_bf16x3(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                   _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
+                                                   _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_conv3d_k3s2_zs_bf16x3")
+            dispatch_counts["conv3d_s2_x3"] += 1
+            return out
     co1 = Co == 1 and stride == 1 and Ci == 8 and not _cfg.off("co1")
     if _use_mfma() and Co <= 64 and not co1:
         y = conv_k3_mfma(x, weight, scale, shift, skip, act=1 if relu else 0, stride=stride)

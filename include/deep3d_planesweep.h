@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 4
+#define D3D_ABI_VERSION 5
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -300,6 +300,12 @@ int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const
                                      d3d_stream_t stream);
 /* ... and with fp32 accuracy from three-way bf16 splits of both operands (16 -> 8 | 16: conv11 of every CostRegNet in the
  * default precision); wpacked: [hi | mid | lo] x the layout above (ops._pack_t2_bf16x3). */
+/* Stride-2 3x3x3 convolution in fp32 accuracy on split bf16 operands (conv1 / conv3 / conv5 of a CostRegNet in fp32 mode,
+ * cas_mvsnet.py:86,89,92; csrc/conv_s2x3.hip): planar fp32 in [Ci,D,H,W] -> out [Co,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1];
+ * wpacked = ops._pack_c8_bf16x3.  8 -> 16, 16 -> 32, 32 -> 64 with an output width that is a multiple of 4;
+ * D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_conv3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+                              int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
 int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream);

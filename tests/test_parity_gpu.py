@@ -1762,6 +1762,32 @@ def test_convtranspose3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, mon
     assert np.abs(got - old).max() <= tol
 
 
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 16, 5, 20, 40), (8, 16, 8, 33, 71), (16, 32, 4, 9, 24), (16, 32, 7, 40, 63), (32, 64, 3, 10, 16),
+                                         (32, 64, 6, 17, 39), (8, 16, 1, 1, 8), (16, 32, 2, 16, 136)])
+def test_conv3d_stride2_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch, Ci, Co, D, H, W):
+    """d3d_conv3d_k3s2_zs_bf16x3 (fp32 mode of conv1 / conv3 / conv5, cas_mvsnet.py:86,89,92; csrc/conv_s2x3.hip): three-way
+    bf16 splits on the matrix cores against the fp32 oracle with affine / ReLU / skip, at the tolerance of the fp32-instruction
+    kernels, and against the kernel it replaces -- odd sizes, several z segments, tiles over every border."""
+    rng = np.random.default_rng(Ci * 10 + Co + D + W)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((Co, Ci, 3, 3, 3))).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.standard_normal(Co).astype(np.float32)
+    o = lambda n: (n - 1) // 2 + 1
+    sk = rng.standard_normal((Co, o(D), o(H), o(W))).astype(np.float32)
+    want = np.maximum(oracle.conv3d_k3(x, w, None, stride=2) * sc[:, None, None, None] + sh[:, None, None, None], 0.0) + sk
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "1")
+    before = ops.dispatch_counts["conv3d_s2_x3"]
+    got = host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True, stride=2))
+    assert ops.dispatch_counts["conv3d_s2_x3"] == before + 1
+    tol = 2e-6 * max(1.0, np.abs(want).max()) * 8
+    assert got.shape == want.shape and np.abs(got - want).max() <= tol
+    plain = host(ops.conv3d_k3(dev(x), dev(w), relu=False, stride=2))
+    set_switch(monkeypatch, "D3D_CONV_C8X3", "0")
+    assert np.abs(host(ops.conv3d_k3(dev(x), dev(w), dev(sc), dev(sh), dev(sk), relu=True, stride=2)) - got).max() <= tol
+    assert np.abs(host(ops.conv3d_k3(dev(x), dev(w), relu=False, stride=2)) - plain).max() <= tol
+    assert ops.dispatch_counts["conv3d_s2_x3"] == before + 2
+
+
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 8, 24, 40), (32, 8, 4, 16, 64), (8, 8, 3, 9, 36), (16, 16, 5, 17, 32), (32, 1, 6, 16, 48)])
 def test_conv0_takes_the_cl8_volume(ops, bf16_mode, Ci, Co, D, H, W):
     """d3d_conv3d_k3_cl_bf16 / d3d_conv3d_k3_c1_cl_bf16 with in_cl = 2: a CL8 input [D,Ci/8,H,W,8] gives bit for bit the
