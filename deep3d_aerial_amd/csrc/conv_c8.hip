@@ -615,8 +615,13 @@ extern "C" int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, con
                                         d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
-    if ((Ci != 8 && Ci != 16 && Ci != 32) || Co < 1 || Co > 16 || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
-        set_error("d3d_conv3d_k3_zs_bf16x3: C_in = %d (8 | 16 | 32), C_out = %d (<= 16), W = %d (a multiple of 4) not taken", Ci, Co, W);
+    const bool wide = (Ci == 32 && Co == 32) || (Ci == 64 && Co == 64);   // conv4 / conv6 (round 4): weight fragments from L2
+    if (((Ci != 8 && Ci != 16 && Ci != 32) || Co < 1 || Co > 16) && !wide) {
+        set_error("d3d_conv3d_k3_zs_bf16x3: C_in = %d (8 | 16 | 32), C_out = %d (<= 16; 32 -> 32, 64 -> 64) not taken", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    if (W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
+        set_error("d3d_conv3d_k3_zs_bf16x3: W = %d (a multiple of 4) not taken", W);
         return D3D_ERR_UNSUPPORTED;
     }
     C8Params p = {};
@@ -624,6 +629,8 @@ extern "C" int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, con
     p.D = D; p.H = H; p.W = W; p.relu = relu; p.CO = Co;
     hipStream_t st = (hipStream_t)stream;
     // 32-wide tiles (split cells are three times as wide); 16 | 32 input channels: one patch buffer beside the weights
+    if (Ci == 32 && Co == 32) return launch<32, 2, false, false, 2, true, false, false, true>(p, st);
+    if (Ci == 64) return launch<64, 4, false, false, 1, true, false, false, true>(p, st);
     switch (Ci) {
         case 8: return launch<8, 1, false, false, 2, false, false, false, true>(p, st);
         case 16: return launch<16, 1, false, false, 2, false, false, false, true>(p, st);

@@ -71,7 +71,9 @@ constexpr int fold_base(int CI, int c) {
 // groups of a pixel leave with the 32 contiguous bytes of the output cells (2 ix, 2 ix + 1) and every lane stores.
 // X3 (planar fp32 tensors, fp32 accuracy): cells hold the hi | mid | lo runs of the exact three-way bf16 split of their channels,
 // the weight fragments come in three parts, six products per K block (see conv_c8.hip).
-template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false>
+// WG: the weight fragments are read from global memory (L2) per use instead of living in LDS -- 64 -> 32 in split operands:
+// 324 KB of fragments, tiny volumes (as conv_c8.hip's 64 -> 64 layer).
+template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false, bool WG = false>
 __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     static_assert(!FOLD || (CL && NTN == 1), "x-folded form: channel-last, C_out = 8");
     static_assert(!X3 || (!CL && !FOLD), "split operands: planar fp32 tensors");
@@ -105,7 +107,9 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     const size_t oplane = 4 * iplane, ovol = (size_t)(2 * D) * oplane;
     const int OW = 2 * W;
 
-    for (int i = tid; i < (X3 ? 3 : 1) * NFRAG * NTN * 64; i += NT) wlds[i] = p.wpk[i];   // (split: [part][fragment])
+    if constexpr (!WG)
+        for (int i = tid; i < (X3 ? 3 : 1) * NFRAG * NTN * 64; i += NT) wlds[i] = p.wpk[i];   // (split: [part][fragment])
+    const u4* __restrict__ wsrc = WG ? p.wpk : wlds;
 
     constexpr int NTASK = PXI * PYI * G;
     constexpr int ROUNDS = (NTASK + NT - 1) / NT;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                 const int dx = real ? (t & 1) : 0, dy = real ? (t >> 1) % (1 + PY) : 0, dz = real ? (t >> 1) / (1 + PY) : 0;
                 const unsigned char* buf = dz ? b1 : b0;
                 const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, wlds[(FB + kb) * 64 + lane]);
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, wsrc[(FB + kb) * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
                     const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
@@ -306,9 +310,9 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
 #pragma unroll
                         for (int nt = 0; nt < NTN; ++nt) {
                             const int wi = ((FB + kb) * NTN + nt) * 64 + lane;
-                            const bf16x8 bh = __builtin_bit_cast(bf16x8, wlds[wi]);
-                            const bf16x8 bm = __builtin_bit_cast(bf16x8, wlds[WS + wi]);
-                            const bf16x8 bl = __builtin_bit_cast(bf16x8, wlds[2 * WS + wi]);
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, wsrc[wi]);
+                            const bf16x8 bm = __builtin_bit_cast(bf16x8, wsrc[WS + wi]);
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, wsrc[2 * WS + wi]);
                             f4 c = acc[px][mg][nt];   // small terms first
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], bh, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bl, c, 0, 0, 0);
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                 }
                 bf16x8 bfrag[NTN];
 #pragma unroll
-                for (int nt = 0; nt < NTN; ++nt) bfrag[nt] = __builtin_bit_cast(bf16x8, wlds[((FB + kb) * NTN + nt) * 64 + lane]);
+                for (int nt = 0; nt < NTN; ++nt) bfrag[nt] = __builtin_bit_cast(bf16x8, wsrc[((FB + kb) * NTN + nt) * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
                     const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
@@ -413,13 +417,13 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
     }
 }
 
-template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false>
+template <int CI, int NTN, int MG, bool CL, bool FOLD = false, bool X3 = false, bool WG = false>
 static int launch(const T2Params& p, hipStream_t stream) {
     constexpr int TXI = 16 * MG;
     constexpr int CS = X3 ? 6 * CI + 16 : CI == 64 ? 144 : bf16_cell_bytes(CI);
-    constexpr int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (X3 ? 3 : 1) * (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16;
+    constexpr int lds = 2 * (TXI + 1) * (TYI + 1) * CS + (WG ? 0 : (X3 ? 3 : 1) * (FOLD ? fold_base(CI, 4) : frag_base(CI, 8)) * NTN * 64 * 16);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD, X3>;
+    auto kern = convt3d_zs_bf16_kernel<CI, NTN, MG, CL, FOLD, X3, WG>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     T2Params q = p;
@@ -472,13 +476,16 @@ extern "C" int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* w
                                                   d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
-    if (Ci != 16 || (Co != 8 && Co != 16) || ceil_div(H, TYI) > 65535 || 2 * D > 65535) {
-        set_error("d3d_convtranspose3d_k3s2_zs_bf16x3: %d -> %d channels not taken (16 -> 8, 16 -> 16)", Ci, Co);
+    const bool shape = (Ci == 16 && (Co == 8 || Co == 16)) || (Ci == 32 && Co == 16) || (Ci == 64 && Co == 32);
+    if (!shape || ceil_div(H, TYI) > 65535 || 2 * D > 65535) {
+        set_error("d3d_convtranspose3d_k3s2_zs_bf16x3: %d -> %d channels not taken (16 -> 8, 16 -> 16, 32 -> 16, 64 -> 32)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }
     T2Params p = {};
     p.in = in; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.D = D; p.H = H; p.W = W; p.CO = Co; p.relu = relu;
+    if (Ci == 64) return launch<64, 2, 1, false, false, true, true>(p, (hipStream_t)stream);   // conv7 (round 4): fragments from L2
+    if (Ci == 32) return launch<32, 1, 1, false, false, true>(p, (hipStream_t)stream);   // conv9 (round 4): 16-wide tiles, two 17 x 9 patches of 208-byte split cells beside 81 KB of weights
     return launch<16, 1, 2, false, false, true>(p, (hipStream_t)stream);
 }
 

@@ -471,8 +471,8 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
     # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
-    if stride == 1 and Ci in (8, 16, 32) and Co in (8, 16) and W % 4 == 0 and _use_mfma() and conv_precision() != "bf16" \
-            and _cfg.get("D3D_CONV_C8X3") != "0":
+    if stride == 1 and ((Ci in (8, 16, 32) and Co in (8, 16)) or (Ci, Co) in ((32, 32), (64, 64))) and W % 4 == 0 and _use_mfma() \
+            and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
         # fp32 mode of conv0 and conv2 (cas_mvsnet.py:84,87): the z-streaming matrix-core kernel on three-way bf16 splits of both
         # operands -- fp32 accuracy (six products per K block), each plane staged once.  Against the kernels it replaces
         # (tools/x3_bench.py): conv0 32 -> 8 / 16 -> 8 / 8 -> 8 at the three stage volumes 2.65 / 3.22 / 1.85 -> 2.47 / 2.84 / 1.69 ms,
@@ -614,8 +614,8 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    if (Ci, Co) in ((16, 8), (16, 16)) and _use_mfma() and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
-        # fp32 mode of conv11 (cas_mvsnet.py:103: 16 -> 8 to the full-resolution volume): the per-parity matrix-core kernel on
+    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
+        # fp32 mode of conv11, conv9 and conv7 (cas_mvsnet.py:103, 100, 97: 16 -> 8 to the full-resolution volume, 32 -> 16, 64 -> 32): the per-parity matrix-core kernel on
         # three-way bf16 splits of both operands (fp32 accuracy, see conv3d_k3)
         wp = derived_weight(weight, "t2bf16x3", _pack_t2_bf16x3)
         out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)

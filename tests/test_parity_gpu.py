@@ -1720,7 +1720,8 @@ def test_variance_volume_channel_last_bf16_is_the_rounded_planar_volume(ops, V, 
 
 
 @pytest.mark.parametrize("Ci,Co,D,H,W", [(8, 8, 8, 24, 40), (16, 8, 5, 17, 68), (32, 8, 4, 16, 64), (8, 8, 1, 9, 36), (16, 16, 6, 33, 32),
-                                         (32, 16, 3, 8, 100), (8, 16, 9, 40, 24), (8, 1, 6, 19, 72), (8, 1, 1, 8, 132)])
+                                         (32, 16, 3, 8, 100), (8, 16, 9, 40, 24), (8, 1, 6, 19, 72), (8, 1, 1, 8, 132), (32, 32, 4, 12, 40),
+                                         (64, 64, 3, 9, 20), (32, 32, 1, 7, 36)])
 def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch, Ci, Co, D, H, W):
     """d3d_conv3d_k3_zs_bf16x3 (fp32 mode of conv0 / conv2, cas_mvsnet.py:84,87): three-way bf16 splits of both operands on the
     bf16 matrix cores against the fp32 oracle, with affine / ReLU / skip -- the tolerance of the fp32-instruction kernels --
@@ -1743,13 +1744,14 @@ def test_conv3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch,
     assert np.abs(host(ops.conv3d_k3(dev(x), dev(w), relu=False)) - plain).max() <= tol
 
 
-@pytest.mark.parametrize("Co,D,H,W", [(8, 4, 12, 20), (8, 1, 9, 33), (16, 3, 17, 16), (8, 5, 8, 70)])
-def test_convtranspose3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch, Co, D, H, W):
-    """d3d_convtranspose3d_k3s2_zs_bf16x3 (fp32 mode of conv11, cas_mvsnet.py:103): against the fp32 oracle with affine, ReLU
-    and skip, and against the kernel it replaces."""
-    rng = np.random.default_rng(Co + D + W)
-    x = rng.standard_normal((16, D, H, W)).astype(np.float32)
-    w = (0.2 * rng.standard_normal((16, Co, 3, 3, 3))).astype(np.float32)
+@pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 4, 12, 20), (16, 8, 1, 9, 33), (16, 16, 3, 17, 16), (16, 8, 5, 8, 70), (32, 16, 3, 9, 20),
+                                         (32, 16, 5, 17, 33), (32, 16, 1, 1, 1), (64, 32, 2, 9, 18), (64, 32, 3, 5, 33)])
+def test_convtranspose3d_split_operand_kernel_has_fp32_accuracy(ops, oracle, monkeypatch, Ci, Co, D, H, W):
+    """d3d_convtranspose3d_k3s2_zs_bf16x3 (fp32 mode of conv11, conv9 and conv7, cas_mvsnet.py:103, 100, 97): against the fp32 oracle with
+    affine, ReLU and skip, and against the kernel it replaces."""
+    rng = np.random.default_rng(Ci + Co + D + W)
+    x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((Ci, Co, 3, 3, 3))).astype(np.float32)
     sc, sh = rng.uniform(0.5, 1.5, Co).astype(np.float32), rng.standard_normal(Co).astype(np.float32)
     sk = rng.standard_normal((Co, 2 * D, 2 * H, 2 * W)).astype(np.float32)
     want = np.maximum(oracle.convtranspose3d_k3s2(x, w) * sc[:, None, None, None] + sh[:, None, None, None], 0.0) + sk
