@@ -270,7 +270,8 @@ int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* sca
                           int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
 /* The same kernel with fp32 ACCURACY (the default precision of the regularisers): both operands as exact three-way bf16
  * splits (hi + mid + lo), six v_mfma_f32_16x16x32_bf16 products per K block accumulated in fp32 -- the 3-D form of
- * d3d_conv2d_k3_zs_bf16x3.  C_in = 8 | 16 | 32, C_out <= 16, W % 4 == 0.  wpacked: [hi | mid | lo] x the layout above
+ * d3d_conv2d_k3_zs_bf16x3.  C_in = 8 | 16 | 32 with C_out <= 16; round 4: 32 -> 32 and 64 -> 64 (conv4 / conv6, fragments from
+ * L2); W % 4 == 0.  wpacked: [hi | mid | lo] x the layout above
  * (ops._pack_c8_bf16x3). */
 int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                             int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
@@ -299,16 +300,16 @@ int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream);
 /* ... and with fp32 accuracy from three-way bf16 splits of both operands (16 -> 8 | 16: conv11 of every CostRegNet in the
- * default precision); wpacked: [hi | mid | lo] x the layout above (ops._pack_t2_bf16x3). */
+ * default precision; round 4: 32 -> 16 and 64 -> 32, conv9 / conv7, the latter with its fragments read from L2); wpacked: [hi | mid | lo] x the layout above (ops._pack_t2_bf16x3). */
+int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
+                                     d3d_stream_t stream);
 /* Stride-2 3x3x3 convolution in fp32 accuracy on split bf16 operands (conv1 / conv3 / conv5 of a CostRegNet in fp32 mode,
  * cas_mvsnet.py:86,89,92; csrc/conv_s2x3.hip): planar fp32 in [Ci,D,H,W] -> out [Co,(D-1)/2+1,(H-1)/2+1,(W-1)/2+1];
  * wpacked = ops._pack_c8_bf16x3.  8 -> 16, 16 -> 32, 32 -> 64 with an output width that is a multiple of 4;
  * D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
 int d3d_conv3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                               int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
-int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
-                                     const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
-                                     d3d_stream_t stream);
 
 /* module.py:5-51 ConvGRUCell / adamvs.py:409-413 ConvReLU of the slice regularisers, bf16 mode: 3x3 stride-1 2-D convolution
  * over the channel concat of `in` [C1,H,W] and `in2` [C2,H,W] (may be NULL, C2 = 0) on v_mfma_f32_16x16x32_bf16, one 64 x 8
