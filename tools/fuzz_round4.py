@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random-shape cross-checks of round 4's kernels (bf16 mode): the fused conv-GRU cell against the three tile-kernel launches
 (bit for bit) and against float64 on rounded operands where the tile kernels do not take the shape; the wide convolution and
-the 24- / 40-channel tile kernel against float64 on rounded operands; the fused head + regression against the two launches.
+the 24- / 40-channel tile kernel against float64 on rounded operands; the fused head + regression against the two launches; conv11 + prob of a CostRegNet in one kernel against its two launches
+(bit for bit); fp32 mode: the stride-2 split-operand 3-D layer against float64.
     python tools/fuzz_round4.py [cases] [seed]"""
 import os
 import sys
@@ -97,5 +98,29 @@ with ops.bf16_convs():
             ops.online_regress_update(reg[0], dpl, *b)
             if ok and any(float((p - q).abs().max()) > 2e-5 * float(q.abs().max()) for p, q in zip(a, b)):
                 print("head case %d vs the two launches: transposed %s %dx%d mode %d differs" % (i, tr, hh, ww, mode)); bad += 1
+        # ---- conv11 + prob of a CostRegNet in one kernel against the two launches (bit for bit) ----
+        D3, H3, W3 = int(rng.integers(1, 10)), int(rng.integers(1, 40)), 2 * int(rng.integers(1, 50))
+        x3 = dev(rng.standard_normal((D3, H3, W3, 16))).to(torch.bfloat16)
+        sk3 = dev(rng.standard_normal((2 * D3, 2 * H3, 2 * W3, 8))).to(torch.bfloat16) if rng.integers(0, 4) else None
+        w11, wp3 = dev(0.1 * rng.standard_normal((16, 8, 3, 3, 3))), dev(0.1 * rng.standard_normal((1, 8, 3, 3, 3)))
+        sc3, sh3, bp3 = dev(rng.uniform(0.5, 1.5, 8)), dev(rng.standard_normal(8)), dev(rng.standard_normal(1))
+        one = ops.convtranspose3d_prob_cl(x3, w11, sc3, sh3, sk3, wp3, bp3)
+        y3 = ops.convtranspose3d_k3s2_cl(x3, w11, sc3, sh3, sk3, relu=True)
+        two = ops.conv3d_k3_cl(y3, wp3, None, bp3, None, relu=False, stride=1, out_cl=False)[0]
+        if one is None or not torch.equal(one, two):
+            print("conv11 + prob case %d: %dx%dx%d skip %s: %s" % (i, D3, H3, W3, sk3 is not None, "not taken" if one is None else
+                  "differs by %g" % float((one - two).abs().max()))); bad += 1
 print("%d cases, %d problems" % (cases, bad))
+# ---- fp32 mode: the stride-2 split-operand layer against float64 ----
+for i in range(max(cases // 3, 1)):
+    Ci, Co = [(8, 16), (16, 32), (32, 64)][int(rng.integers(0, 3))]
+    D3, H3, W3 = int(rng.integers(1, 9)), int(rng.integers(1, 40)), int(rng.integers(1, 20)) * 8 - int(rng.integers(0, 2))
+    x = dev(rng.standard_normal((Ci, D3, H3, W3)))
+    wt = dev(rng.standard_normal((Co, Ci, 3, 3, 3)) / np.sqrt(27 * Ci))
+    got = ops.conv3d_k3(x, wt, relu=False, stride=2)
+    want = F.conv3d(x.double()[None], wt.double(), stride=2, padding=1)[0]
+    err = float((got.double() - want).abs().max())
+    if err > 4e-6 * max(1.0, float(want.abs().max())):
+        print("stride-2 split case %d: %d -> %d %dx%dx%d max %g" % (i, Ci, Co, D3, H3, W3, err)); bad += 1
+print("fp32 stride-2 cases %d, problems so far %d" % (max(cases // 3, 1), bad))
 sys.exit(1 if bad else 0)
