@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: tools/gru_fused_bench.py on variants of csrc/gru_fused.hip built with the given -D flag sets (scratch libraries)
+# GPU box: tools/gru_fused_bench.py on variants of csrc/gru_fused.hip built with the given -D flag sets (scratch libraries;
+# -DD3D_GRU_PREFETCH=0|1, -DD3D_GRU_WAVES2=2 -- the timing-only -DD3D_GRU_X builds of the first half of round 4 are gone)
 cd "$GRAFT_REPO_ROOT" || exit 2
 CS=deep3d_aerial_amd/csrc
 OBJS=$(make -s -C $CS print-objs)
