@@ -1121,7 +1121,7 @@ extern "C" int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* w
     p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
     p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
     hipStream_t st = (hipStream_t)stream;
-    if (Co <= 8)   // both column parities in one tile (wpacked: ops._pack_t2d_k4fold_bf16 x 3)
+    if (Co <= 8)   // both column parities in one tile (wpacked: ops._pack_t2d_k4fold_bf16 x 3; round 4 again: 160 us folded, 188 us unfolded at 32 -> 8, 928 x 1376)
         return Ci == 8 ? launch_tz<8, false, true, true, true>(p, st) : Ci == 16 ? launch_tz<16, false, true, true, true>(p, st)
                                                                                    : launch_tz<32, false, true, true, true>(p, st);
     return Ci == 8 ? launch_tz<8, false, true, true>(p, st) : Ci == 16 ? launch_tz<16, false, true, true>(p, st)
