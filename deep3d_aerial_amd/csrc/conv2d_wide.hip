@@ -68,31 +68,43 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
     // ---- staging of one 32-channel chunk: a task = (pixel of the 66 x 10 patch, 8 channels) -> eight dword loads, one 16-byte chunk
     constexpr int NTASK = WPX * WPY * 4, ROUNDS = (NTASK + WNT - 1) / WNT;
     float stg[ROUNDS][8];
+    // per-lane state of a task, the same for every chunk: element offset of its pixel inside a channel plane (clamped into the
+    // image), whether it is inside, its cell -- and the values stay raw until they are committed: a select behind the loads would
+    // wait for them before the sweep they are meant to fly under
+    size_t poff[ROUNDS];
+    int pdst[ROUNDS], pg8[ROUNDS];
+    bool pok[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int task = tid + r * WNT;
+        const int pix = task >> 2, g = task & 3;
+        const int py = pix / WPX, px = pix - py * WPX;
+        const int gx = x0 + px - 1, gy = y0 + py - 1;
+        pok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        poff[r] = task < NTASK ? (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1) : 0;
+        pdst[r] = task < NTASK ? pix * WCS + g * 16 : -1;
+        pg8[r] = 8 * g;
+    }
     auto issue = [&](int j) {
         const int cbase = 32 * j;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * WNT;
-            const int pix = task >> 2, g = task & 3;
-            const int py = pix / WPX, px = pix - py * WPX;
-            const int gx = x0 + px - 1, gy = y0 + py - 1;
-            const bool ok = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
-            const int c = cbase + 8 * g;
-            const float* __restrict__ src = (c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane) + (ok ? (size_t)gy * W + gx : 0);
+            const int c = cbase + pg8[r];
+            const float* __restrict__ src = (c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane) + poff[r];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = src[(size_t)k * plane];
-                stg[r][k] = ok ? v : 0.0f;
-            }
+            for (int k = 0; k < 8; ++k) stg[r][k] = src[(size_t)k * plane];
         }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const int task = tid + r * WNT;
-            if (task < NTASK)
-                *reinterpret_cast<u4*>(patch + (task >> 2) * WCS + (task & 3) * 16) =
-                    (u4){pack_bf16_w(stg[r][0], stg[r][1]), pack_bf16_w(stg[r][2], stg[r][3]), pack_bf16_w(stg[r][4], stg[r][5]), pack_bf16_w(stg[r][6], stg[r][7])};
+            if (pdst[r] >= 0) {
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = pok[r] ? stg[r][k] : 0.0f;
+                *reinterpret_cast<u4*>(patch + pdst[r]) =
+                    (u4){pack_bf16_w(x[0], x[1]), pack_bf16_w(x[2], x[3]), pack_bf16_w(x[4], x[5]), pack_bf16_w(x[6], x[7])};
+            }
         }
     };
     auto load_weights = [&](int j) {   // the chunk's 9 x NW fragments: K block t * nkb_tap + j, output tiles nt0 ..
