@@ -164,9 +164,13 @@ class SliceCostRegNetRED(nn.Module):
         fused = ops.gru_cell_conv_fused(x, state, pre.conv.weight, g.weight, g.bias, c.weight, c.bias, stride)
         return fused if fused is not None else gru(pre(x), state)[0]
 
-    def _trunk(self, cost, state1, state2):
+    def _cells(self, cost, state1, state2):
         state1 = self._cell(self.conv1, self.conv_gru1, cost, state1, 1)
         state2 = self._cell(self.conv2, self.conv_gru2, state1, state2, 2)
+        return state1, state2
+
+    def _trunk(self, cost, state1, state2):
+        state1, state2 = self._cells(cost, state1, state2)
         # relu(upconv1(state2) + state1): skip added before the activation (adamvs.py:423-424)
         up = ops.convtranspose2d_k3s2(state2, self.upconv1.weight, None, self.upconv1.bias, state1,
                                       skip_after_act=False, act=1)
@@ -185,7 +189,15 @@ class SliceCostRegNetRED(nn.Module):
         """One slice AND its online-regression update (adamvs.py:512-525 around this module): in bf16 mode the head layer and
         the update are one kernel and `reg` never reaches memory (ops.slice_head_regress).  Returns the new states."""
         with ops.slice_tile_kernels():
-            up, state1, state2 = self._trunk(cost, state1, state2)
+            if self.up:   # (stages 1 / 2: upconv1 + head + update in one launch; `up` stays in LDS)
+                s1, s2 = self._cells(cost, state1, state2)
+                if ops.slice_tail_regress(s2, self.upconv1.weight, self.upconv1.bias, s1, self.upconv2d.weight, self.upconv2d.bias,
+                                          dplane, max_p, sum_d, sum_p):
+                    return s1, s2
+                up = ops.convtranspose2d_k3s2(s2, self.upconv1.weight, None, self.upconv1.bias, s1, skip_after_act=False, act=1)
+                state1, state2 = s1, s2
+            else:
+                up, state1, state2 = self._trunk(cost, state1, state2)
             if not ops.slice_head_regress(up, self.upconv2d.weight, self.upconv2d.bias, self.up, dplane, max_p, sum_d, sum_p):
                 ops.online_regress_update(self._head(up)[0], dplane, max_p, sum_d, sum_p)
         return state1, state2

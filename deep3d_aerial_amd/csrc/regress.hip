@@ -5,6 +5,9 @@
 // coalesced along x.  Reference citations are in include/deep3d_planesweep.h.
 #include "common.h"
 
+#include <cstdint>
+#include <type_traits>
+
 namespace d3d {
 
 // VEC consecutive pixels per thread: 16-byte loads / stores when VEC = 4 (the streaming kernels below are bound by the
@@ -412,6 +415,251 @@ __global__ __launch_bounds__(256) void slice_head_regress_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tail of a depth slice of SliceCostRegNetRED at the stages whose head up-samples (adamvs.py:413-418, 423-425, 514-525), ONE
+// kernel instead of two launches and a full-resolution 8-channel tensor:
+//     up  = relu(upconv1(state2) + b_up + state1)          ConvTranspose2d(16 -> 8, k 3, stride 2, pad 1, output_pad 1)
+//     reg = upconv2d(up) + b_head                           ConvTranspose2d(8 -> 1, k 3, stride 2, pad 1, output_pad 1)
+//     max_p, sum_d, sum_p <- online regression update with exp(reg) at the slice's depth plane
+// A workgroup (8 waves) takes 32 x 8 pixels of state2 per step: the 33 x 9 patch is staged as in conv2d_zs.hip's transposed
+// kernel (buffer loads, out-of-range offsets outside the image, bf16 cells), the four parity classes run on
+// v_mfma_f32_16x16x32_bf16 with the same packed weights (ops._pack_t2d_bf16) and the same epilogue expressions, and `up` --
+// 64 x 16 pixels, rounded to bf16 exactly as the head rounds its operands -- goes into LDS instead of HBM (zeros outside the
+// image).  Then a thread owns two neighbouring `up` pixels of the first 62 columns x 14 rows (the head reaches one pixel to the
+// right and below: tiles step by 31 x 7 state2 pixels) and runs slice_head_regress_kernel<true>'s arithmetic in its order:
+// the regression maps receive bit for bit what the two launches give them (tests/test_parity_gpu.py::
+// test_slice_tail_fused_is_the_two_launches).
+// ---------------------------------------------------------------------------------------------
+namespace tail {
+typedef float f4t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
+typedef unsigned u4t __attribute__((ext_vector_type(4)));
+constexpr int CI = 16, TXI = 32, TYI = 8, PXI = TXI + 1, PYI = TYI + 1, CS = 32;   // state2 tile, staged patch, bytes per cell
+constexpr int NT = 64 * TYI;
+constexpr int SX = TXI - 1, SY = TYI - 1;                    // tile step in state2 pixels
+constexpr int PATCH = PXI * PYI * CS;
+constexpr int UW = 2 * TXI, UH = 2 * TYI;                    // `up` region in LDS: 16-byte cells (8 channels)
+constexpr int UBYTES = UW * UH * 16;
+constexpr int ntaps(int py, int px) { return (1 + py) * (1 + px); }
+constexpr int nkb(int py, int px) { return (ntaps(py, px) * CI + 31) / 32; }
+constexpr int frag_base(int c) { int s = 0; for (int q = 0; q < c; ++q) s += nkb(q >> 1, q & 1); return s; }
+constexpr int NFRAG = frag_base(4);                          // 5
+constexpr int LDS_BYTES = 2 * PATCH + UBYTES + NFRAG * 64 * 16;
+constexpr unsigned OOB = 0xffffffffu;
+struct Params {
+    const float* s2;      // [16, h, w]
+    const u4t* wup;       // [NFRAG][64] B fragments (ops._pack_t2d_bf16)
+    const float* bup;     // [8]
+    const float* s1;      // [8, 2h, 2w]: added before the ReLU
+    const float* wh;      // [8][3][3] head weights, already rounded to bf16 (host)
+    const float* bh;      // [1]
+    const float* dplane;
+    float *max_p, *sum_d, *sum_p;   // [4h, 4w]
+    int hd, wd, h, w, tper;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* origin) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, (int)0xfffffffeu, 0x00020000);
+}
+}  // namespace tail
+
+__global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p) {
+    using namespace tail;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const ubuf = smem;                         // first: its cell offsets fit the DS instructions' immediates
+    unsigned char* const pbuf = smem + UBYTES;
+    u4t* const wlds = reinterpret_cast<u4t*>(pbuf + 2 * PATCH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = p.h, w = p.w, H = 2 * h, W = 2 * w;
+    const unsigned plane4 = (unsigned)h * w * 4, uplane4 = (unsigned)H * W * 4;   // (host: tensors < 2^31 bytes)
+    const int ix0 = blockIdx.x * SX;
+    const int nty = (h + SY - 1) / SY;
+    const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
+    for (int i = tid; i < NFRAG * 64; i += NT) wlds[i] = p.wup[i];
+
+    // ---- staging of the state2 patch: task = (patch pixel, 8-channel half) -> eight dword loads, one 16-byte slot ---------------
+    constexpr int NTASK = PXI * PYI * 2, ROUNDS = (NTASK + NT - 1) / NT;
+    float stg[ROUNDS][8];
+    unsigned svo[ROUNDS];
+    int spy[ROUNDS], scell[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int task = tid + r * NT;
+        const int pix = task >> 1, g = task & 1;
+        const int py = pix / PXI, px = pix - py * PXI;
+        svo[r] = task < NTASK && ix0 + px < w ? (unsigned)(8 * g) * plane4 + (unsigned)(py * w + px) * 4 : OOB;
+        spy[r] = py;
+        scell[r] = task < NTASK ? pix * CS + g * 16 : -1;
+    }
+    auto issue = [&](int ty) {
+        const int iy0 = ty * SY;
+        const bool inner = iy0 + PYI <= h;
+        const __amdgpu_buffer_rsrc_t rs = rsrc(p.s2 + ((long)iy0 * w + ix0));
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            unsigned vo = svo[r];
+            if (!inner) vo = spy[r] + iy0 < h ? vo : OOB;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) stg[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, k * plane4, 0));
+        }
+    };
+    auto commit = [&](unsigned char* dst) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (scell[r] >= 0)
+                *reinterpret_cast<u4t*>(dst + scell[r]) = (u4t){pack_bf16x2(stg[r][0], stg[r][1]), pack_bf16x2(stg[r][2], stg[r][3]),
+                                                                 pack_bf16x2(stg[r][4], stg[r][5]), pack_bf16x2(stg[r][6], stg[r][7])};
+    };
+
+    // ---- upconv1 on the matrix cores: wave = state2 row, two 16-pixel groups; K offsets per (parity class, K block) once -------
+    const int m = lane & 15, kg = lane >> 4;
+    int aoff[NFRAG];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kb = 0; kb < nkb(c >> 1, c & 1); ++kb) {
+            const int px = c & 1;
+            const int k0 = 32 * kb + 8 * kg, t = k0 / CI, ch = k0 % CI;
+            const bool real = t < ntaps(c >> 1, px);
+            const int dx = real ? t % (1 + px) : 0, dy = real ? t / (1 + px) : 0;
+            aoff[frag_base(c) + kb] = ((wave + dy) * PXI + m + dx) * CS + (real ? ch : 0) * 2;
+        }
+    // D row = state2 pixel 4 kg + register, column = channel m: the lane's eight `up` pixels 2 (16 mg + 4 kg) .. + 7 of rows 2 wave + PY
+    const bool chan = m < 8;
+    const float bup = chan ? p.bup[m] : 0.0f;
+    // state1 / `up` of the lane's pixels in PAIRS (tiles step by 31 state2 pixels, so a lane's eight pixels may straddle the right
+    // edge; W is even): byte offset of pair j from the tile origin of an `up` row pair, OOB where the pair does not exist
+    typedef float f2t __attribute__((ext_vector_type(2)));
+    unsigned kvo[2][4];
+    int uwr[2];         // the first pixel's cell in the LDS region (row 2 wave): + PY * UW * 16, + j * 16 per pixel
+#pragma unroll
+    for (int mg = 0; mg < 2; ++mg) {
+        const int xl = 2 * (16 * mg + 4 * kg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            kvo[mg][j] = chan && 2 * ix0 + xl + 2 * j < W ? (unsigned)m * uplane4 + (unsigned)(2 * wave * W + xl + 2 * j) * 4 : OOB;
+        uwr[mg] = ((2 * wave) * UW + xl) * 16 + m * 2;
+    }
+    // ---- head: thread = two `up` pixels (yy, 2 q), (yy, 2 q + 1) of the first 62 columns x 14 rows -----------------------------
+    const int hq = tid % (SX), hy = tid / SX;                 // 31 pairs per row
+    const bool htask = tid < SX * 2 * SY;                     // 31 x 14 = 434 tasks
+    const int urd = (hy * UW + 2 * hq) * 16;
+    const float bh = p.bh[0];
+
+    auto tile = [&](int ty, const unsigned char* buf) {
+        const int iy0 = ty * SY, Y0 = 2 * iy0;
+        const bool rowin = iy0 + wave < h;                    // this wave's state2 row (= two `up` rows) exists
+        const __amdgpu_buffer_rsrc_t rk = rsrc(p.s1 + ((long)Y0 * W + 2 * ix0));
+        f2t sk[2][2][4];                                      // [PY][mg][pair]: state1 of the lane's pixels, requested before the GEMMs
+#pragma unroll
+        for (int PY = 0; PY < 2; ++PY)
+#pragma unroll
+            for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sk[PY][mg][j] = __builtin_bit_cast(f2t, __builtin_amdgcn_raw_buffer_load_b64(rk, rowin ? kvo[mg][j] : OOB, PY * W * 4, 0));
+        auto rows = [&](auto pyc) {
+            constexpr int PY = decltype(pyc)::value;
+            f4t acc[2][2];
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int mg = 0; mg < 2; ++mg) acc[px][mg] = (f4t){0, 0, 0, 0};
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                constexpr int dummy = 0; (void)dummy;
+                const int NKB = nkb(PY, px), FB = frag_base(PY * 2 + px);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb >= NKB) break;
+                    const bf16x8t bw = __builtin_bit_cast(bf16x8t, wlds[(FB + kb) * 64 + lane]);
+#pragma unroll
+                    for (int mg = 0; mg < 2; ++mg) {
+                        const bf16x8t a = __builtin_bit_cast(bf16x8t, *reinterpret_cast<const u4t*>(buf + aoff[FB + kb] + mg * 16 * CS));
+                        acc[px][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[px][mg], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mg = 0; mg < 2; ++mg) {
+                const f4t e = acc[0][mg] * 1.0f + bup, od = acc[1][mg] * 1.0f + bup;
+                f4t lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
+                lo += (f4t){sk[PY][mg][0][0], sk[PY][mg][0][1], sk[PY][mg][1][0], sk[PY][mg][1][1]};
+                hi += (f4t){sk[PY][mg][2][0], sk[PY][mg][2][1], sk[PY][mg][3][0], sk[PY][mg][3][1]};
+                lo = __builtin_elementwise_max(lo, (f4t){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4t){0, 0, 0, 0});
+                // zeros outside the image: what the head's bounds tests read there
+                unsigned q0 = pack_bf16x2(lo[0], lo[1]), q1 = pack_bf16x2(lo[2], lo[3]), q2 = pack_bf16x2(hi[0], hi[1]), q3 = pack_bf16x2(hi[2], hi[3]);
+                if (!rowin || kvo[mg][0] == OOB) q0 = 0;
+                if (!rowin || kvo[mg][1] == OOB) q1 = 0;
+                if (!rowin || kvo[mg][2] == OOB) q2 = 0;
+                if (!rowin || kvo[mg][3] == OOB) q3 = 0;
+                if (chan) {
+                    unsigned char* dst = ubuf + uwr[mg] + PY * (UW * 16);
+                    *reinterpret_cast<unsigned short*>(dst) = (unsigned short)q0;
+                    *reinterpret_cast<unsigned short*>(dst + 16) = (unsigned short)(q0 >> 16);
+                    *reinterpret_cast<unsigned short*>(dst + 32) = (unsigned short)q1;
+                    *reinterpret_cast<unsigned short*>(dst + 48) = (unsigned short)(q1 >> 16);
+                    *reinterpret_cast<unsigned short*>(dst + 64) = (unsigned short)q2;
+                    *reinterpret_cast<unsigned short*>(dst + 80) = (unsigned short)(q2 >> 16);
+                    *reinterpret_cast<unsigned short*>(dst + 96) = (unsigned short)q3;
+                    *reinterpret_cast<unsigned short*>(dst + 112) = (unsigned short)(q3 >> 16);
+                }
+            }
+        };
+        rows(std::integral_constant<int, 0>{});
+        rows(std::integral_constant<int, 1>{});
+        lds_barrier();                                        // the `up` region is complete
+        if (htask) {
+            const int X = 2 * ix0 + 2 * hq, Y = Y0 + hy;      // the task's first `up` pixel
+            if (X < W && Y < H) {
+                // output 2 i + p per axis: p = 0 takes kernel tap 1 of input i; p = 1 takes tap 2 of input i and tap 0 of input i + 1
+                u4t c[2][3];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) c[rr][cc] = *reinterpret_cast<const u4t*>(ubuf + urd + (rr * UW + cc) * 16);
+                float e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};   // rows 2 Y and 2 Y + 1
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    auto val = [&](const u4t& v) {
+                        const unsigned d = v[ch >> 1];
+                        return __builtin_bit_cast(float, (ch & 1) ? (d & 0xffff0000u) : (d << 16));
+                    };
+                    const float x0 = val(c[0][0]), x1 = val(c[0][1]), x2 = val(c[0][2]);
+                    const float z0 = val(c[1][0]), z1 = val(c[1][1]), z2 = val(c[1][2]);
+                    const float* __restrict__ k = p.wh + ch * 9;   // [k_y][k_x]
+                    e[0] = fmaf(x0, k[4], e[0]);
+                    e[1] = fmaf(x1, k[3], fmaf(x0, k[5], e[1]));
+                    e[2] = fmaf(x1, k[4], e[2]);
+                    e[3] = fmaf(x2, k[3], fmaf(x1, k[5], e[3]));
+                    o[0] = fmaf(z0, k[1], fmaf(x0, k[7], o[0]));
+                    o[1] = fmaf(z1, k[0], fmaf(z0, k[2], fmaf(x1, k[6], fmaf(x0, k[8], o[1]))));
+                    o[2] = fmaf(z1, k[1], fmaf(x1, k[7], o[2]));
+                    o[3] = fmaf(z2, k[0], fmaf(z1, k[2], fmaf(x2, k[6], fmaf(x1, k[8], o[3]))));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { e[k] = e[k] * 1.0f + bh; o[k] = o[k] * 1.0f + bh; }
+                const int HH = 2 * H, WW = 2 * W;
+                const long i0 = (long)(2 * Y) * WW + 2 * X;
+                regress_row4(e, i0, 2 * X, 2 * Y, p.dplane, p.hd, p.wd, HH, WW, p.max_p, p.sum_d, p.sum_p);
+                regress_row4(o, i0 + WW, 2 * X, 2 * Y + 1, p.dplane, p.hd, p.wd, HH, WW, p.max_p, p.sum_d, p.sum_p);
+            }
+        }
+    };
+
+    issue(t0);
+    commit(pbuf);
+    __syncthreads();
+    int cur = 0;
+    for (int ty = t0; ty < t1; ++ty) {
+        const bool more = ty + 1 < t1;
+        if (more) issue(ty + 1);
+        tile(ty, pbuf + cur * PATCH);
+        if (more) commit(pbuf + (cur ^ 1) * PATCH);
+        lds_barrier();                                        // the `up` region is free, the next patch is there
+        cur ^= 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void online_regress_finalize_kernel(const float* __restrict__ max_p,
                                                                        const float* __restrict__ sum_d,
                                                                        const float* __restrict__ sum_p, long n,
@@ -681,6 +929,35 @@ int d3d_slice_head_regress_bf16(const float* up, const float* weight, const floa
         hipLaunchKernelGGL(slice_head_regress_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, up, weight, bias, dplane, hd, wd, h, w,
                            max_p, sum_d, sum_p);
     D3D_LAUNCH_CHECK("slice_head_regress_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_slice_tail_regress_bf16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
+                                const float* bhead, const float* dplane, int hd, int wd, int h, int w, float* max_p, float* sum_d,
+                                float* sum_p, d3d_stream_t stream) {
+    D3D_REQUIRE(state2 && wup_packed && bup && state1 && whead && bhead && dplane && max_p && sum_d && sum_p, "null pointer");
+    D3D_REQUIRE(hd > 0 && wd > 0 && h > 0 && w > 0, "bad dims %dx%d / %dx%d", hd, wd, h, w);
+    // (the depth plane is read in 16-byte quads only when it has the maps' resolution; a [1,1] plane is a 4-byte view of a table)
+    const bool dquad = hd == 4 * h && wd == 4 * w;
+    if (w % 4 != 0 || (long)h * w * 64 * 4 >= (1L << 31) ||
+        ((reinterpret_cast<uintptr_t>(max_p) | reinterpret_cast<uintptr_t>(sum_d) | reinterpret_cast<uintptr_t>(sum_p) |
+          (dquad ? reinterpret_cast<uintptr_t>(dplane) : 0)) & 15)) {
+        set_error("d3d_slice_tail_regress_bf16: w = %d (a multiple of 4), 16-byte aligned maps and tensors below 2 GiB needed", w);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(slice_tail_kernel), tail::LDS_BYTES);
+    if (rc != D3D_OK) return rc;
+    tail::Params p = {};
+    p.s2 = state2; p.wup = reinterpret_cast<const tail::u4t*>(wup_packed); p.bup = bup; p.s1 = state1; p.wh = whead; p.bh = bhead;
+    p.dplane = dplane; p.max_p = max_p; p.sum_d = sum_d; p.sum_p = sum_p; p.hd = hd; p.wd = wd; p.h = h; p.w = w;
+    const int gx = ceil_div(w, tail::SX), nty = ceil_div(h, tail::SY);
+    int tper = 8;
+    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    p.tper = tper;
+    const int gy = ceil_div(nty, tper);
+    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(slice_tail_kernel, dim3(gx, gy), dim3(tail::NT), tail::LDS_BYTES, (hipStream_t)stream, p);
+    D3D_LAUNCH_CHECK("slice_tail_kernel launch");
     return D3D_OK;
 }
 

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 5
+#define D3D_ABI_VERSION 6
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -210,6 +210,15 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
  * w % 4 == 0, else D3D_ERR_UNSUPPORTED.  `reg` never reaches memory. */
 int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
                                 int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream);
+/* Tail of a depth slice at the stages whose head up-samples (adamvs.py:413-418, 423-425, 514-525) in ONE kernel (round 4, ABI 6;
+ * csrc/regress.hip slice_tail_kernel): up = relu(ConvTranspose2d_16->8(state2) + bup + state1) stays in LDS,
+ * reg = ConvTranspose2d_8->1(up) + bhead, and the online regression update of (max_p, sum_d, sum_p) [4h, 4w] at `dplane`.
+ * state2 [16,h,w], state1 [8,2h,2w]; wup_packed = ops._pack_t2d_bf16, whead = the 72 head weights rounded to bf16 (fp32 values).
+ * Bit-identical to d3d_convtranspose2d_k3s2_zs_bf16 followed by d3d_slice_head_regress_bf16(transposed = 1).  w % 4 == 0,
+ * 16-byte aligned maps; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_slice_tail_regress_bf16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
+                                const float* bhead, const float* dplane, int hd, int wd, int h, int w, float* max_p, float* sum_d,
+                                float* sum_p, d3d_stream_t stream);
 int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const float* sum_p, int64_t n,
                                 float* depth_out, float* conf_out, d3d_stream_t stream);
 

@@ -1635,6 +1635,33 @@ def test_conv11_prob_fused_is_the_two_layers(ops, monkeypatch, D, H, W, skip):
     assert ops.convtranspose3d_prob_cl(xd, wd, scd, shd, sk, wpd, bpd) is None   # the switch takes it out of the dispatch
 
 
+@pytest.mark.parametrize("h,w,mode", [(8, 32, 0), (7, 31 * 4, 1), (15, 64, 2), (9, 36, 0), (30, 124, 1), (1, 4, 0), (58, 88, 2)])
+def test_slice_tail_fused_is_the_two_launches(ops, bf16_mode, monkeypatch, h, w, mode):
+    """d3d_slice_tail_regress_bf16 (upconv1 + skip + ReLU, the stride-2 head and the online regression update of a depth slice,
+    adamvs.py:413-418, 423-425, 514-525, in one kernel with `up` in LDS) against the two launches it replaces (transposed tile
+    kernel, then the fused head): the three regression maps bit for bit -- sizes over tile edges (31 x 7 state2 pixels per
+    workgroup step), every depth-plane form."""
+    rng = np.random.default_rng(h * 100 + w)
+    s2, s1 = dev(rng.standard_normal((16, h, w))), dev(rng.standard_normal((8, 2 * h, 2 * w)))
+    wu, bu = dev(0.2 * rng.standard_normal((16, 8, 3, 3))), dev(rng.standard_normal(8))
+    wh, bh = dev(0.3 * rng.standard_normal((8, 1, 3, 3))), dev(rng.standard_normal(1))
+    HH, WW = 4 * h, 4 * w
+    dpl = dev(600 + 50 * rng.standard_normal((1, 1) if mode == 0 else (2 * h, 2 * w) if mode == 1 else (HH, WW)))
+    acc0 = [dev(np.abs(rng.standard_normal((HH, WW)))) for _ in range(3)]
+    a = [t.clone() for t in acc0]
+    before = ops.dispatch_counts["slice_tail_regress"]
+    assert ops.slice_tail_regress(s2, wu, bu, s1, wh, bh, dpl, *a)
+    assert ops.dispatch_counts["slice_tail_regress"] == before + 1
+    b = [t.clone() for t in acc0]
+    up = ops.convtranspose2d_k3s2(s2, wu, None, bu, s1, skip_after_act=False, act=1)
+    assert ops.slice_head_regress(up, wh, bh, True, dpl, *b)
+    for name, p_, q_ in zip(("max_p", "sum_d", "sum_p"), a, b):
+        assert torch.isfinite(p_).all()
+        assert torch.equal(p_, q_), (name, float((p_ - q_).abs().max()))
+    set_kernel(monkeypatch, "tail_fused", False)
+    assert not ops.slice_tail_regress(s2, wu, bu, s1, wh, bh, dpl, *a)
+
+
 def test_conv11_prob_fused_odd_width_not_taken(ops):
     """W odd: rows of 2 W floats are not made of 16-byte quads -- the entry point declines and the model runs the two layers."""
     x = torch.zeros(2, 3, 5, 16, device="cuda", dtype=torch.bfloat16)

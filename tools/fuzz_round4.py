@@ -110,6 +110,22 @@ with ops.bf16_convs():
         if one is None or not torch.equal(one, two):
             print("conv11 + prob case %d: %dx%dx%d skip %s: %s" % (i, D3, H3, W3, sk3 is not None, "not taken" if one is None else
                   "differs by %g" % float((one - two).abs().max()))); bad += 1
+        # ---- upconv1 + skip + head + regression update in one kernel against the two launches (bit for bit) ----
+        h2, w2 = int(rng.integers(1, 60)), 4 * int(rng.integers(1, 30))
+        s2, s1 = dev(rng.standard_normal((16, h2, w2))), dev(rng.standard_normal((8, 2 * h2, 2 * w2)))
+        wu, bu = dev(0.2 * rng.standard_normal((16, 8, 3, 3))), dev(rng.standard_normal(8))
+        wh2, bh2 = dev(0.3 * rng.standard_normal((8, 1, 3, 3))), dev(rng.standard_normal(1))
+        mode = int(rng.integers(0, 3))
+        table = dev(600 + 50 * rng.standard_normal(8))
+        dpl = table[int(rng.integers(0, 8))].view(1, 1) if mode == 0 else \
+            dev(600 + 50 * rng.standard_normal((2 * h2, 2 * w2) if mode == 1 else (4 * h2, 4 * w2)))
+        acc0 = [dev(np.abs(rng.standard_normal((4 * h2, 4 * w2)))) for _ in range(3)]
+        a, b = [t.clone() for t in acc0], [t.clone() for t in acc0]
+        ok = ops.slice_tail_regress(s2, wu, bu, s1, wh2, bh2, dpl, *a)
+        upm = ops.convtranspose2d_k3s2(s2, wu, None, bu, s1, skip_after_act=False, act=1)
+        ok2 = ops.slice_head_regress(upm, wh2, bh2, True, dpl, *b)
+        if not ok or not ok2 or any(not torch.equal(p, q) for p, q in zip(a, b)):
+            print("slice tail case %d: %dx%d dplane mode %d: %s" % (i, h2, w2, mode, "not taken" if not (ok and ok2) else "differs")); bad += 1
 print("%d cases, %d problems" % (cases, bad))
 # ---- fp32 mode: the stride-2 split-operand layer against float64 ----
 for i in range(max(cases // 3, 1)):
