@@ -140,6 +140,10 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
     long long t_stage = 0, t_sweep = 0;
     const int h = p.h, w = p.w, D = p.D;
     const size_t plane = (size_t)h * w;
+#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_STAGGER)   // do the two workgroups of a CU run in lockstep?  the second wave of the dispatch starts late
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < D3D_WX_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
     // block -> (patch row, segment, patch column): blocks b, b + 8, ... share an XCD (and its L2); within an XCD's run vertically
     // adjacent patches come first (they share most of their source rows), as in the ring kernel
@@ -600,67 +604,72 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
             if (fit) {
                 const long long ts0 = D3D_WCLOCK();
                 D3D_WSTAT(1, 1); D3D_WSTAT(2, n);
-                // Stage.  A wave takes whole (quad, row) items of a view: the row is wave-uniform, the lane is the column.  Loads are
-                // buffer loads -- the view's descriptor and the row's byte offset in scalar registers, the column as a 32-bit lane
-                // offset, no 64-bit address registers -- and a lane or row outside the image gets an offset beyond the buffer, for
-                // which the hardware returns zeros: no clamps, no selects.  The loads of SU items (4 x SU per lane) are issued
-                // before the first 16-byte LDS write; the other workgroup of the CU sweeps meanwhile.
-                constexpr int SU = 4;
+                // Stage.  A wave takes whole rows of a view's window -- every quad of the row: the row's scalar arithmetic (range
+                // test, byte offset) is paid once for the group's channels -- the lane is the column.  Loads are buffer loads -- the
+                // view's descriptor and the row's byte offset in scalar registers, the column as a 32-bit lane offset, no 64-bit
+                // address registers -- and a lane or row outside the image gets an offset beyond the buffer, for which the hardware
+                // returns zeros: no clamps, no selects.  The loads of RPW rows (4 x Q x RPW per lane) are issued before the first
+                // 16-byte LDS write; the other workgroup of the CU sweeps meanwhile.
+                constexpr int RPW = Q > 2 ? 1 : (PH > 8 ? 3 : 2);
                 constexpr int OOB = 0x7ffffff0;   // (launch check: C * h * w * 4 < 2^31, so any offset from here on is out of range)
                 const int fbytes = p.C * (int)plane * 4;
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) {
+#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSTAGE)   // timing only (results wrong): the sweep without its staging
+                    if (p.n_src < 100) continue;
+#endif
                     if (i >= p.n_src) {   // the zero cells of an unused view
                         for (int idx = tid; idx < 4 * Q; idx += WTHREADS) lds_write4_abs(W[i].base + idx * 16, (f4){0, 0, 0, 0});
                         continue;
                     }
                     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats[i + 1]), 0, fbytes, 0x00020000);
-                    const int nitem = Q * W[i].wh;
                     for (int col0 = 0; col0 < W[i].ww; col0 += 64) {   // (windows wider than 64 cells: rare)
                         const int col = col0 + lane;
                         const int sx = W[i].wx0 + col;
                         const bool colin = col < W[i].ww;
                         const int voff = (colin && sx >= 0 && sx < w) ? sx * 4 : OOB;
                         const int cadr = W[i].base + col * 16;
-                        for (int it0 = wave; it0 < nitem; it0 += SU * WWAVES) {
-                            f4 v[SU];
+                        for (int row0 = wave; row0 < W[i].wh; row0 += RPW * WWAVES) {
+                            f4 v[RPW][Q];
 #pragma unroll
-                            for (int k = 0; k < SU; ++k) {
-                                const int it = min(it0 + k * WWAVES, nitem - 1);
-                                int q = 0;
-#pragma unroll
-                                for (int qq_ = 1; qq_ < Q; ++qq_) q += (it >= qq_ * W[i].wh) ? 1 : 0;
-                                const int sy = W[i].wy0 + (it - q * W[i].wh);
+                            for (int r = 0; r < RPW; ++r) {
+                                const int sy = W[i].wy0 + min(row0 + r * WWAVES, W[i].wh - 1);
                                 const bool yin = sy >= 0 && sy < h;
                                 // rows outside the image: the out-of-range marker travels in the VECTOR offset, which the hardware
                                 // range-checks against num_records (zeros come back); the scalar offset is documented as excluded
                                 // from that check, so it always stays inside the buffer
-                                const int soff = yin ? ((c0 + 4 * q) * (int)plane + sy * w) * 4 : 0;
+                                const int roff = yin ? (c0 * (int)plane + sy * w) * 4 : 0;
                                 const int pb = yin ? (int)plane * 4 : 0;
                                 const int vo = yin ? voff : OOB;
 #pragma unroll
-                                for (int c = 0; c < 4; ++c)
-                                    v[k][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, soff + c * pb, 0));
+                                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c)
+                                        v[r][q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, roff + (4 * q + c) * pb, 0));
                             }
 #pragma unroll
-                            for (int k = 0; k < SU; ++k) {
-                                const int it = it0 + k * WWAVES;
-                                int q = 0;
+                            for (int r = 0; r < RPW; ++r) {
+                                const int row = row0 + r * WWAVES;
+                                if (row < W[i].wh && colin) {
 #pragma unroll
-                                for (int qq_ = 1; qq_ < Q; ++qq_) q += (it >= qq_ * W[i].wh) ? 1 : 0;
-                                const int row = it - q * W[i].wh;
-                                if (it < nitem && colin) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[k]);
+                                    for (int q = 0; q < Q; ++q) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[r][q]);
+                                }
                             }
                             // every load of the batch is consumed here, written or not: a load left pending would be waited for
                             // where its register is next overwritten -- inside the plane loop, on the counter that also counts the
                             // planes' stores
 #pragma unroll
-                            for (int k = 0; k < SU; ++k) asm volatile("" : : "v"(v[k]));
+                            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                                for (int q = 0; q < Q; ++q) asm volatile("" : : "v"(v[r][q]));
                         }
                     }
                 }
                 __syncthreads();   // windows staged
                 const long long ts1 = D3D_WCLOCK();
+#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSWEEP)   // timing only (results wrong): the staging without the sweep
+                if (p.n_src > 100)
+#endif
                 for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, true);
                 __syncthreads();   // windows free (next chunk / next channel group)
                 t_stage += ts1 - ts0;
@@ -736,6 +745,13 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
+// Sweeps of at most this many planes take 32 x 16 patches (8 pixel waves, one plane sub-range) instead of 32 x 8 (4 x 2): what a
+// wave executes besides its planes -- rays, the depth-range table, the windows, its share of the staging: ~2100 of the ~3400
+// instructions of a wave at stage 3 -- is then spread over twice the planes (stage 3 0.77 -> 0.63 ms; stage 2, 32 planes: 1.19
+// -> 1.48 ms, the taller windows no longer fit beside each other -- profiles/r04_window_phases.txt).
+#ifndef D3D_WINDOW_PH16
+#define D3D_WINDOW_PH16 8
+#endif
 #ifndef D3D_WINDOW_PLANES
 #define D3D_WINDOW_PLANES 48   // sweeps of at most this many planes take the window kernel (0: never): every stage of the cascades
 #endif
@@ -755,6 +771,7 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
 #ifdef D3D_WINDOW_CG16
             if (cg16) return launch_window_one<MODE, NSRC, 16, true, 8>(p, stream);
 #endif
+            if (p.D <= D3D_WINDOW_PH16) return launch_window_one<MODE, NSRC, 8, true, 16>(p, stream);
             return launch_window_one<MODE, NSRC, 8, true, 8>(p, stream);
         }
     }
@@ -763,6 +780,7 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
     if (cg16) return launch_window_one<MODE, NSRC, 16, false, 8>(p, stream);
 #endif
     (void)cg16;
+    if (p.D <= D3D_WINDOW_PH16) return launch_window_one<MODE, NSRC, 8, false, 16>(p, stream);
     return launch_window_one<MODE, NSRC, 8, false, 8>(p, stream);
 }
 
@@ -774,6 +792,12 @@ int launch_window(int mode, const SweepParams& p, hipStream_t stream, bool force
     if (!forced && (D3D_WINDOW_PLANES == 0 || p.D > D3D_WINDOW_PLANES)) return D3D_ERR_UNSUPPORTED;
     if (mode == MODE_PAIR) {   // one source view, every channel in one pass
         if (p.n_src != 1 || p.out_cl) return D3D_ERR_UNSUPPORTED;
+        if (p.D <= D3D_WINDOW_PH16)
+            switch (p.C) {
+                case 8: return launch_window_one<MODE_PAIR, 1, 8, false, 16>(p, stream);
+                case 16: return launch_window_one<MODE_PAIR, 1, 16, false, 16>(p, stream);
+                case 32: return launch_window_one<MODE_PAIR, 1, 32, false, 16>(p, stream);
+            }
         switch (p.C) {
             case 8: return launch_window_one<MODE_PAIR, 1, 8, false, 8>(p, stream);
             case 16: return launch_window_one<MODE_PAIR, 1, 16, false, 8>(p, stream);
@@ -797,6 +821,9 @@ const char* window_build_flags() {
 #endif
 #ifdef D3D_WINDOW_CG16
            " D3D_WINDOW_CG16"
+#endif
+#if D3D_WINDOW_PH16 != 8
+           " D3D_WINDOW_PH16"
 #endif
 #if D3D_WINDOW_DSEG != 32
            " D3D_WINDOW_DSEG"
