@@ -371,324 +371,334 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
         }
     };
 
+    // ---- chunks of planes: as many of the planes that are left as have windows that fit; per chunk every channel group ------
+    // (the windows depend on the planes only: computed once per chunk, not once per chunk and group -- 23 -> 6 searches per
+    //  workgroup at stage 1)
     int guess = nplanes;   // planes to try first for the next chunk
-    for (int gi = 0; gi < a.ngroups; ++gi) {
-        const int c0 = gi * CH;
-        if constexpr (REF_LDS) {
-            for (int idx = tid; idx < Q * NPIX; idx += WTHREADS) {   // (read after the chunk's "windows staged" barrier)
-                const int q = idx / NPIX, pp = idx - q * NPIX;
-                const int qx = x0 + (pp & 31), qy = y0 + (pp >> 5);
-                const bool in = qx < w && qy < h;
-                const float* __restrict__ sq = p.feats[0] + (size_t)(c0 + 4 * q) * plane + (in ? (size_t)qy * w + qx : 0);
-                f4 v;
-                v[0] = sq[0]; v[1] = sq[plane]; v[2] = sq[2 * plane]; v[3] = sq[3 * plane];
-                if (!in) v = (f4){0, 0, 0, 0};
-                lds_write4_abs(ref0 + idx * 16, v);
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
-                    r[REF_LDS ? 0 : q][k] = valid ? t : 0.0f;
+    int done = 0;
+    while (done < nplanes) {
+        // first try: what fitted last time plus a quarter (a sweep with wide plane spacing settles at a few planes per chunk:
+        // searching down from "everything that is left" for every chunk cost seven window computations per chunk at stage 1)
+        const int first = min(nplanes - done, guess);
+        int n = first;
+        bool fit = windows(done, n);
+        while (!fit && n > NSUBW) {   // three quarters of the planes, in whole rounds of the sub-ranges
+            n = max((n * 3 / 4) / NSUBW * NSUBW, NSUBW);
+            fit = windows(done, n);
+        }
+        for (int gi = 0; gi < a.ngroups; ++gi) {
+            const int c0 = gi * CH;
+            if constexpr (REF_LDS) {
+                for (int idx = tid; idx < Q * NPIX; idx += WTHREADS) {   // (read after the chunk's "windows staged" barrier)
+                    const int q = idx / NPIX, pp = idx - q * NPIX;
+                    const int qx = x0 + (pp & 31), qy = y0 + (pp >> 5);
+                    const bool in = qx < w && qy < h;
+                    const float* __restrict__ sq = p.feats[0] + (size_t)(c0 + 4 * q) * plane + (in ? (size_t)qy * w + qx : 0);
+                    f4 v;
+                    v[0] = sq[0]; v[1] = sq[plane]; v[2] = sq[2 * plane]; v[3] = sq[3 * plane];
+                    if (!in) v = (f4){0, 0, 0, 0};
+                    lds_write4_abs(ref0 + idx * 16, v);
                 }
-            // The loads above are waited for HERE, once: a wait left to the first use would sit inside the plane loop, where the
-            // counter it waits on also counts the previous plane's stores -- every plane would wait for its predecessor's stores.
-#pragma unroll
-            for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(r[REF_LDS ? 0 : q]));
-        }
-        asm volatile("" : "+v"(aff_lo), "+v"(aff_step), "+v"(rden));
-        if (MODE == MODE_WEIGHTED) {
-#pragma unroll
-            for (int i = 0; i < NSRC; ++i) asm volatile("" : "+v"(vw[i]));
-        }
-        // one plane of the segment for this wave's pixels
-        auto sweep_plane = [&](const int dl_, const bool staged) {
-            const int d = ds + dl_;
-            float dv;
-            if (p.depth_mode == D3D_DEPTH_PER_PIXEL) {
-                const float t = p.depth[(size_t)d * plane + pix];
-                dv = valid ? t : 1.0f;
-            } else if (p.depth_mode == D3D_DEPTH_AFFINE) {
-                dv = __fadd_rn(aff_lo, __fmul_rn((float)d, aff_step));
             } else {
-                dv = lds[dl_];
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
+                        r[REF_LDS ? 0 : q][k] = valid ? t : 0.0f;
+                    }
+                // (waited for below, behind the staging loads: ref_wait)
             }
-            unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) +
-                                                      (p.out_cl == 2 ? ((size_t)d * (p.C / 8) + c0 / 8) * plane * 8 : (size_t)d * plane * p.C + c0))
-                                          : uniform64(p.out + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);
-            if (!valid) return;
-            if constexpr (MODE == MODE_PAIR) {
-                // adamvs.py:469-474: mean over the channels of reference x warped source, all C channels in one pass (quads in
-                // order, channels in order: the ring kernel's sum)
-                float pair_acc = 0.0f;
-                if (staged) {
+            asm volatile("" : "+v"(aff_lo), "+v"(aff_step), "+v"(rden));
+            if (MODE == MODE_WEIGHTED) {
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) asm volatile("" : "+v"(vw[i]));
+            }
+            // one plane of the segment for this wave's pixels
+            auto sweep_plane = [&](const int dl_, const bool staged) {
+                const int d = ds + dl_;
+                float dv;
+                if (p.depth_mode == D3D_DEPTH_PER_PIXEL) {
+                    const float t = p.depth[(size_t)d * plane + pix];
+                    dv = valid ? t : 1.0f;
+                } else if (p.depth_mode == D3D_DEPTH_AFFINE) {
+                    dv = __fadd_rn(aff_lo, __fmul_rn((float)d, aff_step));
+                } else {
+                    dv = lds[dl_];
+                }
+                unsigned long long ob = OUTCL ? uniform64(reinterpret_cast<unsigned short*>(p.out) +
+                                                          (p.out_cl == 2 ? ((size_t)d * (p.C / 8) + c0 / 8) * plane * 8 : (size_t)d * plane * p.C + c0))
+                                              : uniform64(p.out + (p.plane_major ? (size_t)d * p.C + c0 : (size_t)c0 * D + d) * plane);
+                if (!valid) return;
+                if constexpr (MODE == MODE_PAIR) {
+                    // adamvs.py:469-474: mean over the channels of reference x warped source, all C channels in one pass (quads in
+                    // order, channels in order: the ring kernel's sum)
+                    float pair_acc = 0.0f;
+                    if (staged) {
 #ifndef D3D_WINDOW_T_SGPR
-                    const f4 tv = *(volatile lds_f4_ptr)(unsigned)tadr;
-                    const TapL g = geo_win(ray[0], tv[0], tv[1], tv[2], dv, umax, vmax, W[0]);
+                        const f4 tv = *(volatile lds_f4_ptr)(unsigned)tadr;
+                        const TapL g = geo_win(ray[0], tv[0], tv[1], tv[2], dv, umax, vmax, W[0]);
 #else
-                    const TapL g = geo_win(ray[0], T0[0], T1[0], T2[0], dv, umax, vmax, W[0]);
+                        const TapL g = geo_win(ray[0], T0[0], T1[0], T2[0], dv, umax, vmax, W[0]);
 #endif
+                        f4 tp[2][4];
+                        auto request = [&](int q2, f4 (&dst)[4]) {
+                            const int n = g.a0 + q2 * W[0].qb, s_ = g.a1 + q2 * W[0].qb;
+                            dst[0] = lds_read4_abs(n);
+                            dst[1] = lds_read4_abs(n + 16);
+                            dst[2] = lds_read4_abs(s_);
+                            dst[3] = lds_read4_abs(s_ + 16);
+                        };
+                        request(0, tp[0]);
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            if (q + 1 < Q) request(q + 1, tp[(q + 1) & 1]);
+                            f4 (&c)[4] = tp[q & 1];
+                            asm volatile("" : "+v"(c[3]));
+                            const f4 val = blend(c[0], c[1], c[2], c[3], g.nw, g.ne, g.sw, g.se);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) pair_acc = fmaf(r[REF_LDS ? 0 : q][k], val[k], pair_acc);
+                        }
+                    } else {
+                        float u, v;
+                        project(ray[0], T0[0], T1[0], T2[0], dv, h, w, u, v);
+                        const TapG t = make_tap_glb(u, v, h, w);
+                        const float* __restrict__ gsrc = p.feats[1] + t.off;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const float* __restrict__ gk = gsrc + (size_t)(4 * q + kk) * plane;
+                                const float val = fmaf(gk[t.dyw + t.dx], t.se, fmaf(gk[t.dyw], t.sw, fmaf(gk[t.dx], t.ne, gk[0] * t.nw)));
+                                pair_acc = fmaf(r[REF_LDS ? 0 : q][kk], val, pair_acc);
+                            }
+                    }
+                    store_sbase(uniform64(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
+                    return;
+                }
+                if constexpr (Q > 2) { if (staged) {
+                    // Unit-major (16-channel groups): units u = (quad q, view i) in q-major order, one quad's accumulators live, the
+                    // four views' geometry kept for the whole plane (the ring kernel's order)
+                    TapL t[NSRC];
+#pragma unroll
+                    for (int i = 0; i < NSRC; ++i) t[i] = geo_win(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, W[i]);
+                    constexpr int NU = Q * NSRC;
                     f4 tp[2][4];
-                    auto request = [&](int q2, f4 (&dst)[4]) {
-                        const int n = g.a0 + q2 * W[0].qb, s_ = g.a1 + q2 * W[0].qb;
+                    auto request = [&](int u, f4 (&dst)[4]) {
+                        const int q2 = u / NSRC, i2 = u % NSRC;
+                        const int n = t[i2].a0 + q2 * W[i2].qb, s_ = t[i2].a1 + q2 * W[i2].qb;
                         dst[0] = lds_read4_abs(n);
                         dst[1] = lds_read4_abs(n + 16);
                         dst[2] = lds_read4_abs(s_);
                         dst[3] = lds_read4_abs(s_ + 16);
                     };
+                    f4 rq = lds_read4_abs(my_ref);
                     request(0, tp[0]);
+                    f4 s, qq;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int q = u / NSRC, i = u % NSRC;
+                        if (u + 1 < NU) request(u + 1, tp[(u + 1) & 1]);
+                        if (i == 0) {
+                            if (MODE == MODE_VARIANCE) { s = rq; qq = s * s; }
+                            else { s = (f4){0, 0, 0, 0}; qq = s; }
+                        }
+                        f4 (&c)[4] = tp[u & 1];
+                        asm volatile("" : "+v"(c[3]));   // one wait per unit (LDS returns in order)
+                        const f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
+                        accumulate(s, qq, val, rq, i);
+                        if (i == NSRC - 1 && q + 1 < Q) rq = lds_read4_abs(my_ref + (q + 1) * (NPIX * 16));   // (weighted mode reads rq until here)
+                        if (i == NSRC - 1) finalize_store(s, qq, ob, q);
+                    }
+                } }
+                if constexpr (Q <= 2) { if (staged) {
+                    // View-major (8-channel groups): ONE view's geometry is live at a time (the next view's is computed while this view's taps are in
+                    // flight) and the accumulators of the group's quads stay in registers until the last view -- the unit-major
+                    // order of the ring kernel keeps 4 x (2 addresses + 4 weights) alive and does not fit 128 registers.  Per channel
+                    // the views are still added in order 0, 1, ...: the same sums.
+                    f4 s[Q], qq[Q];
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
-                        if (q + 1 < Q) request(q + 1, tp[(q + 1) & 1]);
-                        f4 (&c)[4] = tp[q & 1];
-                        asm volatile("" : "+v"(c[3]));
-                        const f4 val = blend(c[0], c[1], c[2], c[3], g.nw, g.ne, g.sw, g.se);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) pair_acc = fmaf(r[REF_LDS ? 0 : q][k], val[k], pair_acc);
+                        if (MODE == MODE_VARIANCE) { s[q] = r[REF_LDS ? 0 : q]; qq[q] = s[q] * s[q]; }
+                        else { s[q] = (f4){0, 0, 0, 0}; qq[q] = s[q]; }
                     }
-                } else {
-                    float u, v;
-                    project(ray[0], T0[0], T1[0], T2[0], dv, h, w, u, v);
-                    const TapG t = make_tap_glb(u, v, h, w);
-                    const float* __restrict__ gsrc = p.feats[1] + t.off;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q)
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const float* __restrict__ gk = gsrc + (size_t)(4 * q + kk) * plane;
-                            const float val = fmaf(gk[t.dyw + t.dx], t.se, fmaf(gk[t.dyw], t.sw, fmaf(gk[t.dx], t.ne, gk[0] * t.nw)));
-                            pair_acc = fmaf(r[REF_LDS ? 0 : q][kk], val, pair_acc);
-                        }
-                }
-                store_sbase(uniform64(p.out + (size_t)d * plane), pixb, pair_acc / (float)CH);
-                return;
-            }
-            if constexpr (Q > 2) { if (staged) {
-                // Unit-major (16-channel groups): units u = (quad q, view i) in q-major order, one quad's accumulators live, the
-                // four views' geometry kept for the whole plane (the ring kernel's order)
-                TapL t[NSRC];
-#pragma unroll
-                for (int i = 0; i < NSRC; ++i) t[i] = geo_win(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, W[i]);
-                constexpr int NU = Q * NSRC;
-                f4 tp[2][4];
-                auto request = [&](int u, f4 (&dst)[4]) {
-                    const int q2 = u / NSRC, i2 = u % NSRC;
-                    const int n = t[i2].a0 + q2 * W[i2].qb, s_ = t[i2].a1 + q2 * W[i2].qb;
-                    dst[0] = lds_read4_abs(n);
-                    dst[1] = lds_read4_abs(n + 16);
-                    dst[2] = lds_read4_abs(s_);
-                    dst[3] = lds_read4_abs(s_ + 16);
-                };
-                f4 rq = lds_read4_abs(my_ref);
-                request(0, tp[0]);
-                f4 s, qq;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int q = u / NSRC, i = u % NSRC;
-                    if (u + 1 < NU) request(u + 1, tp[(u + 1) & 1]);
-                    if (i == 0) {
-                        if (MODE == MODE_VARIANCE) { s = rq; qq = s * s; }
-                        else { s = (f4){0, 0, 0, 0}; qq = s; }
-                    }
-                    f4 (&c)[4] = tp[u & 1];
-                    asm volatile("" : "+v"(c[3]));   // one wait per unit (LDS returns in order)
-                    const f4 val = blend(c[0], c[1], c[2], c[3], t[i].nw, t[i].ne, t[i].sw, t[i].se);
-                    accumulate(s, qq, val, rq, i);
-                    if (i == NSRC - 1 && q + 1 < Q) rq = lds_read4_abs(my_ref + (q + 1) * (NPIX * 16));   // (weighted mode reads rq until here)
-                    if (i == NSRC - 1) finalize_store(s, qq, ob, q);
-                }
-            } }
-            if constexpr (Q <= 2) { if (staged) {
-                // View-major (8-channel groups): ONE view's geometry is live at a time (the next view's is computed while this view's taps are in
-                // flight) and the accumulators of the group's quads stay in registers until the last view -- the unit-major
-                // order of the ring kernel keeps 4 x (2 addresses + 4 weights) alive and does not fit 128 registers.  Per channel
-                // the views are still added in order 0, 1, ...: the same sums.
-                f4 s[Q], qq[Q];
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    if (MODE == MODE_VARIANCE) { s[q] = r[REF_LDS ? 0 : q]; qq[q] = s[q] * s[q]; }
-                    else { s[q] = (f4){0, 0, 0, 0}; qq[q] = s[q]; }
-                }
-                f4 tp[Q][4];
-                auto request = [&](const TapL& g, int i2, int q2) {
-                    const int n = g.a0 + q2 * W[i2].qb, s_ = g.a1 + q2 * W[i2].qb;
-                    tp[q2][0] = lds_read4_abs(n);
-                    tp[q2][1] = lds_read4_abs(n + 16);
-                    tp[q2][2] = lds_read4_abs(s_);
-                    tp[q2][3] = lds_read4_abs(s_ + 16);
-                };
+                    f4 tp[Q][4];
+                    auto request = [&](const TapL& g, int i2, int q2) {
+                        const int n = g.a0 + q2 * W[i2].qb, s_ = g.a1 + q2 * W[i2].qb;
+                        tp[q2][0] = lds_read4_abs(n);
+                        tp[q2][1] = lds_read4_abs(n + 16);
+                        tp[q2][2] = lds_read4_abs(s_);
+                        tp[q2][3] = lds_read4_abs(s_ + 16);
+                    };
 #ifndef D3D_WINDOW_T_SGPR
-                auto geo_view = [&](int i) {
-                    const f4 tv = *(volatile lds_f4_ptr)(unsigned)(tadr + 16 * i);   // (volatile: not hoisted out of the plane loop)
-                    return geo_win(ray[i], tv[0], tv[1], tv[2], dv, umax, vmax, W[i]);
-                };
+                    auto geo_view = [&](int i) {
+                        const f4 tv = *(volatile lds_f4_ptr)(unsigned)(tadr + 16 * i);   // (volatile: not hoisted out of the plane loop)
+                        return geo_win(ray[i], tv[0], tv[1], tv[2], dv, umax, vmax, W[i]);
+                    };
 #else
-                auto geo_view = [&](int i) { return geo_win(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, W[i]); };
+                    auto geo_view = [&](int i) { return geo_win(ray[i], T0[i], T1[i], T2[i], dv, umax, vmax, W[i]); };
 #endif
-                TapL gc = geo_view(0);
+                    TapL gc = geo_view(0);
 #pragma unroll
-                for (int q = 0; q < Q; ++q) request(gc, 0, q);
+                    for (int q = 0; q < Q; ++q) request(gc, 0, q);
 #pragma unroll
-                for (int i = 0; i < NSRC; ++i) {
-                    __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every view's geometry to the top)
-                    TapL gn = gc;
-                    if (i + 1 < NSRC) gn = geo_view(i + 1);
+                    for (int i = 0; i < NSRC; ++i) {
+                        __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every view's geometry to the top)
+                        TapL gn = gc;
+                        if (i + 1 < NSRC) gn = geo_view(i + 1);
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        asm volatile("" : "+v"(tp[q][3]));   // one wait per quad (LDS returns in order)
-                        const f4 val = blend(tp[q][0], tp[q][1], tp[q][2], tp[q][3], gc.nw, gc.ne, gc.sw, gc.se);
-                        if (i + 1 < NSRC) request(gn, i + 1, q);   // the next view's taps of this quad, into the registers just read
-                        accumulate(s[q], qq[q], val, r[REF_LDS ? 0 : q], i);
-                    }
-                    gc = gn;
-                }
-#pragma unroll
-                for (int q = 0; q < Q; ++q) finalize_store(s[q], qq[q], ob, q);
-            } }
-            if (!staged) {   // taps from the planar maps in global memory (the ring kernel's fallback arithmetic), one view at a time
-                f4 s[Q], qq[Q], rf[Q];
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    if constexpr (REF_LDS) {   // (no barrier on this path: the reference features straight from global memory)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) rf[q][k] = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
-                    } else {
-                        rf[q] = r[REF_LDS ? 0 : q];
-                    }
-                    if (MODE == MODE_VARIANCE) { s[q] = rf[q]; qq[q] = s[q] * s[q]; }
-                    else { s[q] = (f4){0, 0, 0, 0}; qq[q] = s[q]; }
-                }
-                for (int i = 0; i < p.n_src; ++i) {
-                    const float* __restrict__ M = p.proj34 + 12 * i;
-                    const Ray rr = make_ray(M, xf, yf);
-                    float u, v;
-                    project(rr, M[3], M[7], M[11], dv, h, w, u, v);
-                    const TapG t = make_tap_glb(u, v, h, w);
-                    const float vwi = (MODE == MODE_WEIGHTED) ? p.weights[(size_t)i * plane + pix] : 0.0f;
-                    const float* __restrict__ g = p.feats[i + 1] + (size_t)c0 * plane + t.off;
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        f4 val;
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const float* __restrict__ gk = g + (size_t)(4 * q + kk) * plane;
-                            val[kk] = fmaf(gk[t.dyw + t.dx], t.se, fmaf(gk[t.dyw], t.sw, fmaf(gk[t.dx], t.ne, gk[0] * t.nw)));
+                        for (int q = 0; q < Q; ++q) {
+                            asm volatile("" : "+v"(tp[q][3]));   // one wait per quad (LDS returns in order)
+                            const f4 val = blend(tp[q][0], tp[q][1], tp[q][2], tp[q][3], gc.nw, gc.ne, gc.sw, gc.se);
+                            if (i + 1 < NSRC) request(gn, i + 1, q);   // the next view's taps of this quad, into the registers just read
+                            accumulate(s[q], qq[q], val, r[REF_LDS ? 0 : q], i);
                         }
-                        if (MODE == MODE_VARIANCE) {
-                            accumulate(s[q], qq[q], val, rf[q], 0);
+                        gc = gn;
+                    }
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) finalize_store(s[q], qq[q], ob, q);
+                } }
+                if (!staged) {   // taps from the planar maps in global memory (the ring kernel's fallback arithmetic), one view at a time
+                    f4 s[Q], qq[Q], rf[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        if constexpr (REF_LDS) {   // (no barrier on this path: the reference features straight from global memory)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) rf[q][k] = p.feats[0][(size_t)(c0 + 4 * q + k) * plane + pix];
                         } else {
+                            rf[q] = r[REF_LDS ? 0 : q];
+                        }
+                        if (MODE == MODE_VARIANCE) { s[q] = rf[q]; qq[q] = s[q] * s[q]; }
+                        else { s[q] = (f4){0, 0, 0, 0}; qq[q] = s[q]; }
+                    }
+                    for (int i = 0; i < p.n_src; ++i) {
+                        const float* __restrict__ M = p.proj34 + 12 * i;
+                        const Ray rr = make_ray(M, xf, yf);
+                        float u, v;
+                        project(rr, M[3], M[7], M[11], dv, h, w, u, v);
+                        const TapG t = make_tap_glb(u, v, h, w);
+                        const float vwi = (MODE == MODE_WEIGHTED) ? p.weights[(size_t)i * plane + pix] : 0.0f;
+                        const float* __restrict__ g = p.feats[i + 1] + (size_t)c0 * plane + t.off;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) s[q][k] = fmaf(val[k] * rf[q][k], vwi, s[q][k]);
+                        for (int q = 0; q < Q; ++q) {
+                            f4 val;
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const float* __restrict__ gk = g + (size_t)(4 * q + kk) * plane;
+                                val[kk] = fmaf(gk[t.dyw + t.dx], t.se, fmaf(gk[t.dyw], t.sw, fmaf(gk[t.dx], t.ne, gk[0] * t.nw)));
+                            }
+                            if (MODE == MODE_VARIANCE) {
+                                accumulate(s[q], qq[q], val, rf[q], 0);
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) s[q][k] = fmaf(val[k] * rf[q][k], vwi, s[q][k]);
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int q = 0; q < Q; ++q) finalize_store(s[q], qq[q], ob, q);
-            }
-        };
+                    for (int q = 0; q < Q; ++q) finalize_store(s[q], qq[q], ob, q);
+                }
+            };
 
-        // ---- chunks of planes: as many of the planes that are left as have windows that fit -----------------------------------
-        int done = 0;
-        while (done < nplanes) {
-            // first try: what fitted last time plus a quarter (a sweep with wide plane spacing settles at a few planes per chunk:
-            // searching down from "everything that is left" for every chunk cost seven window computations per chunk at stage 1)
-            const int first = min(nplanes - done, guess);
-            int n = first;
-            bool fit = windows(done, n);
-            while (!fit && n > NSUBW) {   // three quarters of the planes, in whole rounds of the sub-ranges
-                n = max((n * 3 / 4) / NSUBW * NSUBW, NSUBW);
-                fit = windows(done, n);
-            }
-            if (fit) {
-                const long long ts0 = D3D_WCLOCK();
-                D3D_WSTAT(1, 1); D3D_WSTAT(2, n);
-                // Stage.  A wave takes whole rows of a view's window -- every quad of the row: the row's scalar arithmetic (range
-                // test, byte offset) is paid once for the group's channels -- the lane is the column.  Loads are buffer loads -- the
-                // view's descriptor and the row's byte offset in scalar registers, the column as a 32-bit lane offset, no 64-bit
-                // address registers -- and a lane or row outside the image gets an offset beyond the buffer, for which the hardware
-                // returns zeros: no clamps, no selects.  The loads of RPW rows (4 x Q x RPW per lane) are issued before the first
-                // 16-byte LDS write; the other workgroup of the CU sweeps meanwhile.
-                constexpr int RPW = Q > 2 ? 1 : (PH > 8 ? 3 : 2);
-                constexpr int OOB = 0x7ffffff0;   // (launch check: C * h * w * 4 < 2^31, so any offset from here on is out of range)
-                const int fbytes = p.C * (int)plane * 4;
+                if (fit) {
+                    const long long ts0 = D3D_WCLOCK();
+                    D3D_WSTAT(1, 1); D3D_WSTAT(2, n);
+                    // Stage.  A wave takes whole rows of a view's window -- every quad of the row: the row's scalar arithmetic (range
+                    // test, byte offset) is paid once for the group's channels -- the lane is the column.  Loads are buffer loads -- the
+                    // view's descriptor and the row's byte offset in scalar registers, the column as a 32-bit lane offset, no 64-bit
+                    // address registers -- and a lane or row outside the image gets an offset beyond the buffer, for which the hardware
+                    // returns zeros: no clamps, no selects.  The loads of RPW rows (4 x Q x RPW per lane) are issued before the first
+                    // 16-byte LDS write; the other workgroup of the CU sweeps meanwhile.
+                    constexpr int RPW = Q > 2 ? 1 : (PH > 8 ? 3 : 2);
+                    constexpr int OOB = 0x7ffffff0;   // (launch check: C * h * w * 4 < 2^31, so any offset from here on is out of range)
+                    const int fbytes = p.C * (int)plane * 4;
 #pragma unroll
-                for (int i = 0; i < NSRC; ++i) {
+                    for (int i = 0; i < NSRC; ++i) {
 #if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSTAGE)   // timing only (results wrong): the sweep without its staging
-                    if (p.n_src < 100) continue;
+                        if (p.n_src < 100) continue;
 #endif
-                    if (i >= p.n_src) {   // the zero cells of an unused view
-                        for (int idx = tid; idx < 4 * Q; idx += WTHREADS) lds_write4_abs(W[i].base + idx * 16, (f4){0, 0, 0, 0});
-                        continue;
-                    }
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats[i + 1]), 0, fbytes, 0x00020000);
-                    for (int col0 = 0; col0 < W[i].ww; col0 += 64) {   // (windows wider than 64 cells: rare)
-                        const int col = col0 + lane;
-                        const int sx = W[i].wx0 + col;
-                        const bool colin = col < W[i].ww;
-                        const int voff = (colin && sx >= 0 && sx < w) ? sx * 4 : OOB;
-                        const int cadr = W[i].base + col * 16;
-                        for (int row0 = wave; row0 < W[i].wh; row0 += RPW * WWAVES) {
-                            f4 v[RPW][Q];
+                        if (i >= p.n_src) {   // the zero cells of an unused view
+                            for (int idx = tid; idx < 4 * Q; idx += WTHREADS) lds_write4_abs(W[i].base + idx * 16, (f4){0, 0, 0, 0});
+                            continue;
+                        }
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats[i + 1]), 0, fbytes, 0x00020000);
+                        for (int col0 = 0; col0 < W[i].ww; col0 += 64) {   // (windows wider than 64 cells: rare)
+                            const int col = col0 + lane;
+                            const int sx = W[i].wx0 + col;
+                            const bool colin = col < W[i].ww;
+                            const int voff = (colin && sx >= 0 && sx < w) ? sx * 4 : OOB;
+                            const int cadr = W[i].base + col * 16;
+                            for (int row0 = wave; row0 < W[i].wh; row0 += RPW * WWAVES) {
+                                f4 v[RPW][Q];
 #pragma unroll
-                            for (int r = 0; r < RPW; ++r) {
-                                const int sy = W[i].wy0 + min(row0 + r * WWAVES, W[i].wh - 1);
-                                const bool yin = sy >= 0 && sy < h;
-                                // rows outside the image: the out-of-range marker travels in the VECTOR offset, which the hardware
-                                // range-checks against num_records (zeros come back); the scalar offset is documented as excluded
-                                // from that check, so it always stays inside the buffer
-                                const int roff = yin ? (c0 * (int)plane + sy * w) * 4 : 0;
-                                const int pb = yin ? (int)plane * 4 : 0;
-                                const int vo = yin ? voff : OOB;
+                                for (int r = 0; r < RPW; ++r) {
+                                    const int sy = W[i].wy0 + min(row0 + r * WWAVES, W[i].wh - 1);
+                                    const bool yin = sy >= 0 && sy < h;
+                                    // rows outside the image: the out-of-range marker travels in the VECTOR offset, which the hardware
+                                    // range-checks against num_records (zeros come back); the scalar offset is documented as excluded
+                                    // from that check, so it always stays inside the buffer
+                                    const int roff = yin ? (c0 * (int)plane + sy * w) * 4 : 0;
+                                    const int pb = yin ? (int)plane * 4 : 0;
+                                    const int vo = yin ? voff : OOB;
 #pragma unroll
-                                for (int q = 0; q < Q; ++q)
+                                    for (int q = 0; q < Q; ++q)
 #pragma unroll
-                                    for (int c = 0; c < 4; ++c)
-                                        v[r][q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, roff + (4 * q + c) * pb, 0));
-                            }
-#pragma unroll
-                            for (int r = 0; r < RPW; ++r) {
-                                const int row = row0 + r * WWAVES;
-                                if (row < W[i].wh && colin) {
-#pragma unroll
-                                    for (int q = 0; q < Q; ++q) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[r][q]);
+                                        for (int c = 0; c < 4; ++c)
+                                            v[r][q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, roff + (4 * q + c) * pb, 0));
                                 }
+#pragma unroll
+                                for (int r = 0; r < RPW; ++r) {
+                                    const int row = row0 + r * WWAVES;
+                                    if (row < W[i].wh && colin) {
+#pragma unroll
+                                        for (int q = 0; q < Q; ++q) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[r][q]);
+                                    }
+                                }
+                                // every load of the batch is consumed here, written or not: a load left pending would be waited for
+                                // where its register is next overwritten -- inside the plane loop, on the counter that also counts the
+                                // planes' stores
+#pragma unroll
+                                for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                                    for (int q = 0; q < Q; ++q) asm volatile("" : : "v"(v[r][q]));
                             }
-                            // every load of the batch is consumed here, written or not: a load left pending would be waited for
-                            // where its register is next overwritten -- inside the plane loop, on the counter that also counts the
-                            // planes' stores
-#pragma unroll
-                            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                                for (int q = 0; q < Q; ++q) asm volatile("" : : "v"(v[r][q]));
                         }
                     }
-                }
-                __syncthreads();   // windows staged
-                const long long ts1 = D3D_WCLOCK();
-#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSWEEP)   // timing only (results wrong): the staging without the sweep
-                if (p.n_src > 100)
-#endif
-                for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, true);
-                __syncthreads();   // windows free (next chunk / next channel group)
-                t_stage += ts1 - ts0;
-                t_sweep += D3D_WCLOCK() - ts1;
-#ifdef D3D_EXPERIMENTS
-                { int cells = 0;
+                    // The reference loads are waited for HERE, once per chunk and group, with the staging loads in front of them: a
+                    // wait left to the first use would sit inside the plane loop, where the counter it waits on also counts the
+                    // previous plane's stores -- every plane would wait for its predecessor's stores.
+                    if constexpr (!REF_LDS) {
 #pragma unroll
-                  for (int i = 0; i < NSRC; ++i) cells += W[i].qb / 16 * Q;
-                  D3D_WSTAT(4, cells); }
+                        for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(r[q]));
+                    }
+                    __syncthreads();   // windows staged
+                    const long long ts1 = D3D_WCLOCK();
+#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSWEEP)   // timing only (results wrong): the staging without the sweep
+                    if (p.n_src > 100)
 #endif
-            } else {
-                D3D_WSTAT(3, n);
-                for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, false);
-            }
-            done += n;
-            if (!fit) guess = NSUBW;
-            else if (!(n == first && first < guess))   // (a chunk cut short by the end of the segment says nothing about what fits)
-                guess = max((n + n / 4 + NSUBW - 1) / NSUBW * NSUBW, n + NSUBW);
+                    for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, true);
+                    __syncthreads();   // windows free (next chunk / next channel group)
+                    t_stage += ts1 - ts0;
+                    t_sweep += D3D_WCLOCK() - ts1;
+#ifdef D3D_EXPERIMENTS
+                    { int cells = 0;
+#pragma unroll
+                      for (int i = 0; i < NSRC; ++i) cells += W[i].qb / 16 * Q;
+                      D3D_WSTAT(4, cells); }
+#endif
+                } else {
+                    D3D_WSTAT(3, n);
+                    if constexpr (!REF_LDS) {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) asm volatile("" : "+v"(r[q]));
+                    }
+                    for (int j = sub; j < n; j += NSUBW) sweep_plane(done + j, false);
+                }
         }
+        done += n;
+        if (!fit) guess = NSUBW;
+        else if (!(n == first && first < guess))   // (a chunk cut short by the end of the segment says nothing about what fits)
+            guess = max((n + n / 4 + NSUBW - 1) / NSUBW * NSUBW, n + NSUBW);
     }
     D3D_WSTAT(0, 1); D3D_WSTAT(5, t_stage); D3D_WSTAT(6, t_sweep); D3D_WSTAT(7, D3D_WCLOCK() - t_begin);
     (void)t_begin; (void)t_stage; (void)t_sweep;
