@@ -755,12 +755,13 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
     return D3D_OK;
 }
 
-// Sweeps of at most this many planes take 32 x 16 patches (8 pixel waves, one plane sub-range) instead of 32 x 8 (4 x 2): what a
-// wave executes besides its planes -- rays, the depth-range table, the windows, its share of the staging: ~2100 of the ~3400
-// instructions of a wave at stage 3 -- is then spread over twice the planes (stage 3 0.77 -> 0.63 ms; stage 2, 32 planes: 1.19
-// -> 1.48 ms, the taller windows no longer fit beside each other -- profiles/r04_window_phases.txt).
+// -DD3D_WINDOW_PH16=n: sweeps of at most n planes take 32 x 16 patches (8 pixel waves, one plane sub-range) instead of 32 x 8
+// (4 x 2): what a wave executes besides its planes -- rays, the depth-range table, the windows, its share of the staging: ~2000 of
+// the ~3300 instructions of a wave at stage 3 -- is then spread over twice the planes.  On the synthetic stage-3 sweep (flat
+// depth map) 0.77 -> 0.63 ms; inside a CasMVSNet view (random weights: a noisy stage-2 depth map) the taller patch's windows no
+// longer fit and the sweep takes 3.7 ms instead of 0.76 -- off (profiles/r04_window_phases.txt).
 #ifndef D3D_WINDOW_PH16
-#define D3D_WINDOW_PH16 8
+#define D3D_WINDOW_PH16 0
 #endif
 #ifndef D3D_WINDOW_PLANES
 #define D3D_WINDOW_PLANES 48   // sweeps of at most this many planes take the window kernel (0: never): every stage of the cascades
@@ -781,7 +782,9 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
 #ifdef D3D_WINDOW_CG16
             if (cg16) return launch_window_one<MODE, NSRC, 16, true, 8>(p, stream);
 #endif
+#if D3D_WINDOW_PH16 > 0
             if (p.D <= D3D_WINDOW_PH16) return launch_window_one<MODE, NSRC, 8, true, 16>(p, stream);
+#endif
             return launch_window_one<MODE, NSRC, 8, true, 8>(p, stream);
         }
     }
@@ -790,7 +793,9 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
     if (cg16) return launch_window_one<MODE, NSRC, 16, false, 8>(p, stream);
 #endif
     (void)cg16;
+#if D3D_WINDOW_PH16 > 0
     if (p.D <= D3D_WINDOW_PH16) return launch_window_one<MODE, NSRC, 8, false, 16>(p, stream);
+#endif
     return launch_window_one<MODE, NSRC, 8, false, 8>(p, stream);
 }
 
@@ -802,12 +807,14 @@ int launch_window(int mode, const SweepParams& p, hipStream_t stream, bool force
     if (!forced && (D3D_WINDOW_PLANES == 0 || p.D > D3D_WINDOW_PLANES)) return D3D_ERR_UNSUPPORTED;
     if (mode == MODE_PAIR) {   // one source view, every channel in one pass
         if (p.n_src != 1 || p.out_cl) return D3D_ERR_UNSUPPORTED;
+#if D3D_WINDOW_PH16 > 0
         if (p.D <= D3D_WINDOW_PH16)
             switch (p.C) {
                 case 8: return launch_window_one<MODE_PAIR, 1, 8, false, 16>(p, stream);
                 case 16: return launch_window_one<MODE_PAIR, 1, 16, false, 16>(p, stream);
                 case 32: return launch_window_one<MODE_PAIR, 1, 32, false, 16>(p, stream);
             }
+#endif
         switch (p.C) {
             case 8: return launch_window_one<MODE_PAIR, 1, 8, false, 8>(p, stream);
             case 16: return launch_window_one<MODE_PAIR, 1, 16, false, 8>(p, stream);
@@ -832,7 +839,7 @@ const char* window_build_flags() {
 #ifdef D3D_WINDOW_CG16
            " D3D_WINDOW_CG16"
 #endif
-#if D3D_WINDOW_PH16 != 8
+#if D3D_WINDOW_PH16 != 0
            " D3D_WINDOW_PH16"
 #endif
 #if D3D_WINDOW_DSEG != 32

@@ -364,7 +364,7 @@ WINDOW_CASES = [
     (4, 32, 50, 90, 48, 30.0, 3.0, False),     # three sources, two depth segments, per-plane depths
     (5, 8, 96, 160, 8, 260.0, 5.0, False),     # windows that do not fit: chunks of planes, then the gather fallback
     (2, 8, 33, 41, 3, 2.0, 0.0, True),         # one source view
-    (3, 32, 45, 70, 5, 4.0, 8.0, False),       # <= 8 planes: 32 x 16 patches (ragged), four channel groups, per-plane depths
+    (3, 32, 45, 70, 5, 4.0, 8.0, False),       # five planes of four channel groups: one chunk, the groups inside it (ragged patches)
 ]
 
 
