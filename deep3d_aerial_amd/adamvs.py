@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from .dataset import extract_features
 from . import ops
-from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, feature_conv, folded_bn,
+from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, feature_conv, folded_bn, trunk_conv0,
                      plane_depths)
 
 
@@ -82,7 +82,7 @@ class FeatureNet(nn.Module):
         return feature_conv(head, torch.cat((up(br_a(feat)), up(br_b(feat)), feat), 1))
 
     def forward(self, x):
-        c0 = self.conv0(x)
+        c0 = trunk_conv0(self.conv0, x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
         out = {"stage1": self._context(c2, self.branch1_1, self.branch1_2, self.out1)}

@@ -48,6 +48,12 @@ struct Z2Params {
     int skip_after_act;
     int tper;             // tiles per workgroup along y
     int sub2;             // stride-1 kernel: keep the even rows / columns only = the stride-2 layer (act 0 | 1; out, skip [CO,(H+1)/2,W/2])
+    // IMG3 form (d3d_conv2d_k3_pair3_bf16x3): `in` is not read -- the 8-channel input is the 3 -> 8 layer of the 3-channel image below
+    const float* img;     // [3, H, W]
+    const float* w0;      // [4][3][3][8] fp32: the 3 -> 8 layer's weights as d3d_conv2d_k3_stream packs them (channel 3 = zeros)
+    const float* scale0;  // [8] or null
+    const float* shift0;  // [8] or null
+    int act0;             // 0 | 1 (ReLU)
 };
 
 __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
@@ -103,9 +109,16 @@ __device__ __forceinline__ f4 mfma_split3(const bf16x8 (&a)[3], bf16x8 bh, bf16x
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], bh, c, 0, 0, 0);
 }
 
-template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false>
+// IMG3 (CI = 8, split operands): the first two layers of a feature trunk in one launch (module.py:663-666 conv0 = ConvBnReLU(3, 8)
+// + ConvBnReLU(8, 8) at full resolution).  The 8-channel input never exists in memory: the staging phase loads the 3-channel
+// image patch (12 x 68 per tile), the workgroup evaluates the first layer at the 10 x 66 patch positions with the vector-unit
+// arithmetic of conv2d_stream_kernel (conv.hip: same order c, k_y, k_x of the fused multiply-adds, scale, shift, ReLU) and writes
+// the split cells the matrix-core sweep reads -- what the two launches compute, bit for bit, without the 8 x H x W tensor's write
+// and read (326 of the pair's 550 MB at 2752 x 1856).
+template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     static_assert(!(F32 && X3), "one operand format");
+    static_assert(!IMG3 || (CI == 8 && X3 && NTN == 1), "image form: 3 -> 8 -> CO <= 16 on split operands");
     constexpr int TX = 16 * MGN, PX = TX + 2;
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
     constexpr int NSPL = X3 ? 3 : 1;
@@ -409,6 +422,115 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         }
     };
 
+    if constexpr (IMG3) {
+        constexpr int IPX = TX + 4, IPY = PYZ + 2, IPL = IPY * IPX;            // image patch: origin (tile row - 2, x0 - 2)
+        constexpr int NIL = (3 * IPL + NTZ - 1) / NTZ;
+        float* ipatch = reinterpret_cast<float*>(smem + NBUF * PATCH + NSPL * NKB * NTN * 64 * 16);
+        unsigned ivo[NIL];
+        int ipy[NIL], islot[NIL];
+        float iv[NIL];
+#pragma unroll
+        for (int i = 0; i < NIL; ++i) {
+            const int e = tid + NTZ * i;
+            const int c = e / IPL, r = e - c * IPL, iy = r / IPX, ix = r - iy * IPX;
+            const int gx = x0 - 2 + ix;
+            ivo[i] = e < 3 * IPL && gx >= 0 && gx < W ? (unsigned)c * plane4 + (unsigned)(iy * W + ix) * 4 : OOBZ;
+            ipy[i] = iy;
+            islot[i] = e < 3 * IPL ? e : -1;
+        }
+        auto issue_img = [&](int ty) {
+            const int gyo = ty * TYZ - 2;
+            const __amdgpu_buffer_rsrc_t ri = z2_rsrc(p.img + ((long)gyo * W + x0 - 2));
+#pragma unroll
+            for (int i = 0; i < NIL; ++i) {
+                const unsigned vo = (unsigned)(ipy[i] + gyo) < (unsigned)H ? ivo[i] : OOBZ;
+                iv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, vo, 0, 0));
+            }
+        };
+        auto commit_img = [&]() {
+#pragma unroll
+            for (int i = 0; i < NIL; ++i)
+                if (islot[i] >= 0) ipatch[islot[i]] = iv[i];
+        };
+        // items of the first layer: (64 patch positions, channel quad); the quad is the wave's (its weights are scalar operands)
+        constexpr int NPOS = PYZ * PX, NITEM = 2 * ((NPOS + 63) / 64), NRND = (NITEM + TYZ - 1) / TYZ;
+        typedef const float __attribute__((address_space(4))) cfloat;
+        const int wu = __builtin_amdgcn_readfirstlane(wave), hq = wu & 1;   // (scalar: the quad's weights are scalar loads)
+        float sc0[4], sh0[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            sc0[o] = p.scale0 ? p.scale0[4 * hq + o] : 1.0f;
+            sh0[o] = p.shift0 ? p.shift0[4 * hq + o] : 0.0f;
+        }
+        int ppy[NRND], ppx[NRND];
+#pragma unroll
+        for (int r = 0; r < NRND; ++r) {
+            const int pos = (r * (TYZ / 2) + (wu >> 1)) * 64 + lane;
+            ppy[r] = pos < NPOS ? pos / PX : -1;
+            ppx[r] = pos - (pos / PX) * PX;
+        }
+        auto produce = [&](int ty) {
+            const int gy0 = ty * TYZ - 1;
+            // the rounds of a wave side by side: a (c, k_y) row of the weights is loaded (scalar) once for all of them
+            float acc[NRND][4];
+            const float* __restrict__ pl[NRND];
+#pragma unroll
+            for (int r = 0; r < NRND; ++r) {
+                pl[r] = ipatch + max(ppy[r], 0) * IPX + ppx[r];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[r][o] = 0.0f;
+            }
+            cfloat* wt = (cfloat*)p.w0 + 4 * hq;
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                cfloat* w = wt + c * 72;
+                asm volatile("" : "+s"(w));
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int r = 0; r < NRND; ++r) {
+                            const float v = pl[r][c * IPL + dy * IPX + dx];
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) acc[r][o] = fmaf(v, w[dy * 24 + dx * 8 + o], acc[r][o]);
+                        }
+            }
+#pragma unroll
+            for (int r = 0; r < NRND; ++r) {
+                const int py = max(ppy[r], 0), px = ppx[r];
+                const bool inside = ppy[r] >= 0 && (unsigned)(gy0 + py) < (unsigned)H && (unsigned)(x0 - 1 + px) < (unsigned)W;
+                float y[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float t = acc[r][o];
+                    if (p.scale0) t *= sc0[o];
+                    if (p.shift0) t += sh0[o];
+                    if (p.act0 == 1) t = fmaxf(t, 0.0f);
+                    y[o] = inside ? t : 0.0f;   // outside the image: the second layer's zero padding
+                }
+                if (ppy[r] >= 0) put4(smem + (py * PX + px) * CS, hq, y[0], y[1], y[2], y[3]);
+            }
+        };
+        issue_img(t0);
+        commit_img();
+        __syncthreads();
+        produce(t0);
+        lds_barrier();
+        for (int ty = t0; ty < t1; ++ty) {
+            const bool more = ty + 1 < t1;
+            if (more) issue_img(ty + 1);
+            tile(ty, smem);
+            lds_barrier();   // every wave has read the cells
+            if (more) {
+                commit_img();
+                lds_barrier();
+                produce(ty + 1);
+                lds_barrier();
+            }
+        }
+        return;
+    }
     // ---- walk the tiles of this workgroup: the next patch's loads fly during the sweep -------------------------------
     issue(t0);
     commit(smem);
@@ -430,13 +552,13 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     }
 }
 
-template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false>
+template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false>
 static int launch_z2(const Z2Params& p, hipStream_t stream) {
     constexpr int TX = 16 * MGN, PX = TX + 2;
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
     constexpr int PATCH = PX * PYZ * z2_cell_bytes<F32, X3>(CI);
     constexpr int WBYTES = NKB * NTN * 64 * (F32 ? 4 : 16) * (X3 ? 3 : 1);
-    constexpr int lds = (X3 || (F32 && CI > 32) ? 1 : 2) * PATCH + WBYTES;
+    constexpr int lds = (X3 || (F32 && CI > 32) ? 1 : 2) * PATCH + WBYTES + (IMG3 ? 3 * (PYZ + 2) * (TX + 4) * 4 : 0);
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     if ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.in2) | reinterpret_cast<uintptr_t>(p.skip) |
          reinterpret_cast<uintptr_t>(p.aux1) | reinterpret_cast<uintptr_t>(p.out)) & 15) {
@@ -444,7 +566,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
         return D3D_ERR_UNSUPPORTED;
     }
     if ((long)(CI > p.CO ? CI : p.CO) * p.H * p.W * 4 * (1) >= (1L << 31)) return D3D_ERR_UNSUPPORTED;   // (32-bit buffer offsets)
-    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3>;
+    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3, IMG3>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
@@ -1023,6 +1145,25 @@ extern "C" int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2
     if (Ci == 32) return launch_z2<32, 1, 1, false, true>(p, st);   // 16-wide tiles: 65 KB, two workgroups per CU
     if (Ci == 16) return launch_z2<16, 1, 2, false, true>(p, st);
     return launch_z2<8, 1, 4, false, true>(p, st);
+}
+
+// conv0 of a feature trunk (3 -> 8 -> CO <= 16, both 3 x 3 stride 1 with affine + ReLU | none) in one launch: see IMG3 above.
+extern "C" int d3d_conv2d_k3_pair3_bf16x3(const float* img, const float* w0packed, const float* scale0, const float* shift0, int act0,
+                                          const void* wpacked, const float* scale, const float* shift, int act, int Co, int H, int W,
+                                          float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(img && w0packed && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE((act == 0 || act == 1) && (act0 == 0 || act0 == 1), "bad act %d / %d", act0, act);
+    if (Co > 16 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(img) & 3)) {
+        set_error("d3d_conv2d_k3_pair3_bf16x3: C_out = %d (<= 16), W = %d (multiple of 4) not taken", Co, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    Z2Params p = {};
+    p.in = out;   // (not read; the launcher checks its alignment)
+    p.C1 = 8; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
+    p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act;
+    p.img = img; p.w0 = w0packed; p.scale0 = scale0; p.shift0 = shift0; p.act0 = act0;
+    return launch_z2<8, 1, 4, false, true, true>(p, (hipStream_t)stream);
 }
 
 enum { PREC_BF16 = 0, PREC_F32 = 1, PREC_X3 = 2 };   // operand format of the stride-2 / transposed tile kernels

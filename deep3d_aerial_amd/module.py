@@ -382,6 +382,27 @@ class DeConv2dFuse(nn.Module):
         return self.conv(self.deconv(x), x2=x_pre)  # conv over cat((deconv(x), x_pre), 1) without the concat
 
 
+def trunk_conv0(conv0, x):
+    """conv0 of a feature trunk (two ConvBnReLU at full resolution, module.py:663-666) on a batch [B,3,H,W]: one launch per image
+    where ops.conv2d_k3_pair3 takes the shape (the 8-channel map between the layers is never written), else layer by layer."""
+    a, b = conv0[0], conv0[1]
+    if (x.is_cuda and x.dtype == torch.float32 and x.shape[1] == 3 and a.bn is not None and b.bn is not None
+            and not a.bn.training and not b.bn.training and _cfg.get("D3D_FEATURE_CONV") != "miopen"):
+        s0, t0 = folded_bn(a.bn)
+        s1, t1 = folded_bn(b.bn)
+        with _feature_precision():
+            outs = []
+            for i in range(x.shape[0]):
+                y = ops.conv2d_k3_pair3(x[i].contiguous(), a.conv.weight, s0, t0, 1 if a.relu else 0,
+                                        b.conv.weight, s1, t1, 1 if b.relu else 0)
+                if y is None:
+                    break
+                outs.append(y)
+            else:
+                return outs[0].unsqueeze(0) if len(outs) == 1 else torch.stack(outs)
+    return conv0(x)
+
+
 def _trunk(base):
     """conv0/conv1/conv2 of both feature nets (module.py:663-679, adamvs.py:59-75)."""
     conv0 = nn.Sequential(Conv2d(3, base, 3, 1, padding=1), Conv2d(base, base, 3, 1, padding=1))
@@ -415,7 +436,7 @@ class FeatureNet_mvsnet(nn.Module):
         self.out_channels = [4 * b, 2 * b, b]
 
     def forward(self, x):
-        c0 = self.conv0(x)
+        c0 = trunk_conv0(self.conv0, x)
         c1 = self.conv1(c0)
         c2 = self.conv2(c1)
         out = {"stage1": feature_conv(self.out1, c2)}

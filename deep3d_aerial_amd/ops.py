@@ -1095,6 +1095,36 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     return out
 
 
+def conv2d_k3_pair3(x, w0, scale0, shift0, act0, w1, scale1, shift1, act1):
+    """conv0 of a feature trunk -- Conv3x3(3 -> 8) + affine + act0, then Conv3x3(8 -> 8) + affine + act1 at full resolution
+    (module.py:663-666) -- in ONE launch of the tile kernel: the 8-channel map between the layers never reaches memory
+    (d3d_conv2d_k3_pair3_bf16x3; bit for bit what conv2d_stream followed by conv2d_zs give, which is what conv2d_k3 runs for the
+    two layers in the fp32 precision of the feature nets at these sizes).  x [3,H,W].  None when it does not apply."""
+    if x.dim() != 3 or x.shape[0] != 3 or conv_precision() == "bf16" or _z2_fp32_entry() != "x3" or not _use_mfma() \
+            or _cfg.off("conv0_pair") or _cfg.off("conv2d_zs") or _cfg.off("conv2d_stream"):
+        return None
+    _, H, W = x.shape
+    if tuple(w0.shape) != (8, 3, 3, 3) or tuple(w1.shape) != (8, 8, 3, 3) or W % 4 or H * W < _CONV2D_STREAM_MIN \
+            or 8 * H * W * 4 >= 2 ** 31 or act0 not in (0, 1) or act1 not in (0, 1):
+        return None
+
+    def pack0(w):
+        wp = w.new_zeros((8, 3, 3, 8))
+        wp[:3] = w.permute(1, 2, 3, 0)
+        return wp
+    wp0 = derived_weight(w0, "c2s", pack0)   # (the packing of conv2d_stream: same key, same tensor)
+    wp1 = derived_weight(w1, "z2bf16x3", _pack_z2_bf16x3)
+    out = torch.empty((8, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_conv2d_k3_pair3_bf16x3(_chk(x, "x", 3), _chk(wp0, "w0packed"), _opt(scale0, "scale0"), _opt(shift0, "shift0"),
+                                                int(act0), ctypes.c_void_p(wp1.data_ptr()), _opt(scale1, "scale1"),
+                                                _opt(shift1, "shift1"), int(act1), 8, H, W, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k3_pair3_bf16x3")
+    dispatch_counts["conv2d_pair3"] += 1
+    return out
+
+
 # In the default fp32 precision the tile kernels serve the slice regularisers only (the feature pyramids keep their tuned
 # vector-unit kernels: a FeatureNet forward is 2.12 ms on those, 2.19 ms on the fp32 tile kernel): the regulariser
 # modules switch them on around their forward.

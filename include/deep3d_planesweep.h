@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 6
+#define D3D_ABI_VERSION 7
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -210,6 +210,15 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
  * w % 4 == 0, else D3D_ERR_UNSUPPORTED.  `reg` never reaches memory. */
 int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
                                 int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream);
+/* conv0 of a feature trunk in ONE launch (round 4, ABI 7; csrc/conv2d_zs.hip, IMG3 form): out = act(scale * Conv3x3_8->Co(c) + shift)
+ * with c = act0(scale0 * Conv3x3_3->8(img) + shift0) evaluated per tile from the staged image patch and never written (module.py:
+ * 663-666: ConvBnReLU(3, 8) + ConvBnReLU(8, 8) at full resolution).  img [3,H,W]; w0packed [4][3][3][8] fp32 as
+ * d3d_conv2d_k3_stream takes it (input channel 3 = zeros); wpacked = the split B operands of d3d_conv2d_k3_zs_bf16x3.
+ * Bit-identical to d3d_conv2d_k3_stream followed by d3d_conv2d_k3_zs_bf16x3.  Co <= 16, W % 4 == 0, out 16-byte aligned;
+ * D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_conv2d_k3_pair3_bf16x3(const float* img, const float* w0packed, const float* scale0, const float* shift0, int act0,
+                               const void* wpacked, const float* scale, const float* shift, int act, int Co, int H, int W,
+                               float* out, d3d_stream_t stream);
 /* Tail of a depth slice at the stages whose head up-samples (adamvs.py:413-418, 423-425, 514-525) in ONE kernel (round 4, ABI 6;
  * csrc/regress.hip slice_tail_kernel): up = relu(ConvTranspose2d_16->8(state2) + bup + state1) stays in LDS,
  * reg = ConvTranspose2d_8->1(up) + bhead, and the online regression update of (max_p, sum_d, sum_p) [4h, 4w] at `dplane`.

@@ -1636,6 +1636,36 @@ def test_conv11_prob_fused_is_the_two_layers(ops, monkeypatch, D, H, W, skip):
     assert ops.convtranspose3d_prob_cl(xd, wd, scd, shd, sk, wpd, bpd) is None   # the switch takes it out of the dispatch
 
 
+@pytest.mark.parametrize("hw", [(256, 256), (264, 260), (300, 1028), (1856, 2752)], ids=lambda t: "%dx%d" % t)
+def test_trunk_conv0_pair_is_the_two_launches(ops, monkeypatch, hw):
+    """conv0 of a feature trunk in one launch (d3d_conv2d_k3_pair3_bf16x3: the 3 -> 8 layer evaluated per tile from the staged
+    image patch, the 8-channel map never written) against the two launches conv2d_k3 runs for the layers -- bit for bit, ragged
+    tiles and image borders included -- and against float64."""
+    H, W = hw
+    g = torch.Generator("cuda").manual_seed(H + W)
+    x = torch.rand(3, H, W, device="cuda", generator=g)
+    w0 = 0.4 * torch.randn(8, 3, 3, 3, device="cuda", generator=g)
+    w1 = 0.2 * torch.randn(8, 8, 3, 3, device="cuda", generator=g)
+    s0, t0, s1, t1 = [torch.randn(8, device="cuda", generator=g) * k + b for k, b in ((0.2, 1.0), (0.3, 0.0), (0.2, 1.0), (0.3, 0.0))]
+    with ops.fp32_convs():
+        before = ops.dispatch_counts["conv2d_pair3"]
+        one = ops.conv2d_k3_pair3(x, w0, s0, t0, 1, w1, s1, t1, 1)
+        assert one is not None and ops.dispatch_counts["conv2d_pair3"] == before + 1
+        set_kernel(monkeypatch, "conv0_pair", False)
+        assert ops.conv2d_k3_pair3(x, w0, s0, t0, 1, w1, s1, t1, 1) is None   # the switch takes it out of the dispatch
+        set_kernel(monkeypatch, "conv0_pair", True)
+        mid = ops.conv2d_k3(x, w0, s0, t0, None, act=1)
+        two = ops.conv2d_k3(mid, w1, s1, t1, None, act=1)
+    assert torch.equal(one, two)
+    if H * W <= 512 * 1024:
+        xd = x.double()[None]
+        m = torch.relu(torch.nn.functional.conv2d(xd, w0.double(), padding=1) * s0.double()[None, :, None, None] + t0.double()[None, :, None, None])
+        want = torch.relu(torch.nn.functional.conv2d(m, w1.double(), padding=1) * s1.double()[None, :, None, None] + t1.double()[None, :, None, None])[0]
+        assert float((one.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # widths that are not a multiple of four are not taken
+    assert ops.conv2d_k3_pair3(x[:, :, :W - 2].contiguous(), w0, s0, t0, 1, w1, s1, t1, 1) is None
+
+
 @pytest.mark.parametrize("h,w,mode", [(8, 32, 0), (7, 31 * 4, 1), (15, 64, 2), (9, 36, 0), (30, 124, 1), (1, 4, 0), (58, 88, 2)])
 def test_slice_tail_fused_is_the_two_launches(ops, bf16_mode, monkeypatch, h, w, mode):
     """d3d_slice_tail_regress_bf16 (upconv1 + skip + ReLU, the stride-2 head and the online regression update of a depth slice,
