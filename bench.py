@@ -217,7 +217,7 @@ def profiled_traffic():
     return (prof.get("hbm_bytes_per_launch") if info["matches_current_source"] else None), info
 
 
-def secondary_models(reps=2):
+def secondary_models(reps=5, warm=2):
     """BASELINE config 3 (not the headline metric): one reference view of the full cascades at 2752x1856, 5 views, bf16
     regulariser operands, seeded random weights -- ms per view and cost-volume Mvoxels/s (97.05 M voxels per view)."""
     from deep3d_aerial_amd import predict
@@ -235,7 +235,8 @@ def secondary_models(reps=2):
             pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}
             dv = torch.from_numpy(s["depth_values"])[None].cuda()
             with torch.no_grad():
-                net(imgs, pm, dv)
+                for _ in range(warm):   # (the first forward packs the weights; the second settles the allocator's pools)
+                    net(imgs, pm, dv)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(reps):
