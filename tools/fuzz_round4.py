@@ -139,4 +139,17 @@ for i in range(max(cases // 3, 1)):
     if err > 4e-6 * max(1.0, float(want.abs().max())):
         print("stride-2 split case %d: %d -> %d %dx%dx%d max %g" % (i, Ci, Co, D3, H3, W3, err)); bad += 1
 print("fp32 stride-2 cases %d, problems so far %d" % (max(cases // 3, 1), bad))
+# ---- conv0 of a feature trunk in one launch against the two launches (bit for bit; fp32 precision of the feature nets) ----
+with ops.fp32_convs():
+    for i in range(max(cases // 6, 1)):
+        H0, W0 = int(rng.integers(256, 420)), 4 * int(rng.integers(64, 130))
+        img = dev(rng.uniform(0, 1, (3, H0, W0)))
+        wa, wb = dev(0.4 * rng.standard_normal((8, 3, 3, 3))), dev(0.2 * rng.standard_normal((8, 8, 3, 3)))
+        sa, ta, sb, tb = [dev(rng.standard_normal(8) * 0.3 + o) for o in (1.0, 0.0, 1.0, 0.0)]
+        a0, a1 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        one = ops.conv2d_k3_pair3(img, wa, sa, ta, a0, wb, sb, tb, a1)
+        two = ops.conv2d_k3(ops.conv2d_k3(img, wa, sa, ta, None, act=a0), wb, sb, tb, None, act=a1)
+        if one is None or not torch.equal(one, two):
+            print("conv0 pair case %d: %dx%d act %d %d: %s" % (i, H0, W0, a0, a1, "not taken" if one is None else "differs by %g" % float((one - two).abs().max()))); bad += 1
+print("conv0 pair cases %d, problems so far %d" % (max(cases // 6, 1), bad))
 sys.exit(1 if bad else 0)
