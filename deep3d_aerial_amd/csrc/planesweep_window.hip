@@ -108,14 +108,32 @@ __device__ __forceinline__ void lds_write4_abs(int byte_addr, const f4& v) {
     *(__attribute__((address_space(3))) f4*)(unsigned)byte_addr = v;
 }
 
+// Lane exchanges of the reductions below as DPP operands (one vector instruction each; __shfl_xor is a ds_bpermute round trip
+// through the LDS pipe plus its address arithmetic): quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 // min / max over aligned groups of 8 lanes
 __device__ __forceinline__ float grp8_min(float v) {
-    v = fminf(v, __shfl_xor(v, 1)); v = fminf(v, __shfl_xor(v, 2)); v = fminf(v, __shfl_xor(v, 4));
+    v = fminf(v, dpp_get<0xB1>(v)); v = fminf(v, dpp_get<0x4E>(v)); v = fminf(v, dpp_get<0x141>(v));
     return v;
 }
 __device__ __forceinline__ float grp8_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, dpp_get<0xB1>(v)); v = fmaxf(v, dpp_get<0x4E>(v)); v = fmaxf(v, dpp_get<0x141>(v));
     return v;
+}
+// min / max over the wave (uniform result): rows of 16 by DPP, the four rows through scalar registers
+__device__ __forceinline__ float wave_min_dpp(float v) {
+    v = fminf(grp8_min(v), dpp_get<0x140>(grp8_min(v)));
+    return fminf(fminf(lane_value(v, 0), lane_value(v, 16)), fminf(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(grp8_max(v), dpp_get<0x140>(grp8_max(v)));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 }  // namespace
@@ -246,8 +264,8 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                 const float dv = __fadd_rn(blo[k], __fmul_rn((float)(ds + i), bst[k]));
                 if (bok[k]) { lo = fminf(lo, dv); hi = fmaxf(hi, dv); }
             }
-            lo = wave_min(lo);
-            hi = wave_max(hi);
+            lo = wave_min_dpp(lo);
+            hi = wave_max_dpp(hi);
             if (lane == 0) { lds[i] = lo; lds[WDSEG_MAX + i] = hi; }
         }
     } else {
@@ -263,8 +281,8 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                     hi = fmaxf(hi, dv);
                 }
             }
-            lo = wave_min(lo);
-            hi = wave_max(hi);
+            lo = wave_min_dpp(lo);
+            hi = wave_max_dpp(hi);
             if (lane == 0) { lds[i] = lo; lds[WDSEG_MAX + i] = hi; }
         }
     }
