@@ -791,7 +791,7 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
     //  once per 16 channels, but the windows are twice as large, nothing hides their staging, and chunks shrink: config 2 7.3 ms
     //  against 6.7 ms for the 8-channel form and 5.8 ms for the ring kernel; stage 2 of the cascade 1.33 against 1.31 ms)
 #ifdef D3D_WINDOW_CG16
-    const bool cg16 = p.C % 16 == 0 && p.D >= D3D_WINDOW_CG16;
+    const bool cg16 = p.C % 16 == 0 && p.D >= D3D_WINDOW_CG16 && p.out_cl != 2;   // (the CL8 store walks ONE plane of 8-channel groups)
 #else
     constexpr bool cg16 = false;
 #endif
