@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("D3D_LIBRARY") or os.path.join(CSRC, "libdeep3d_planesweep.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -75,6 +75,8 @@ SIGNATURES = {
     "d3d_conv3d_k3_c1_cl_bf16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3s2_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "d3d_conv2d_k3_zs_bf16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "d3d_conv2d_k3_wide_bf16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "d3d_conv2d_k3_pair3_bf16x3": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "d3d_slice_tail_regress_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_conv3d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],

@@ -20,6 +20,7 @@
 // chunk, chunks in channel order).
 #include <cstdint>
 #include "common.h"
+#include "gn_stats.h"
 
 namespace d3d {
 
@@ -46,13 +47,15 @@ struct WideParams {
     float* out;           // [CO, H, W]
     int H, W, CO, NTN;    // NTN = 16-channel output tiles of the layer
     int act;              // 0 none | 1 ReLU
+    double* gn;           // GN form: GroupNorm statistics of the output (gn_stats.h), zeroed by the caller; channels >= gn_split are group 1
+    int gn_split;
 };
 
 __device__ __forceinline__ unsigned pack_bf16_w(float a, float b) {
     return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
 }
 
-template <int NW>
+template <int NW, bool GN = false>
 __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* patch = smem;
@@ -145,36 +148,47 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
 
     // ---- epilogue: D row (pixel) = 4 (lane >> 4) + register, column (channel) = lane & 15 ------------------------------------
     const int oy = y0 + wave;
-    if (oy >= H) return;
+    GnAcc gacc;
+    gn_zero(gacc);
+    if (oy < H) {
 #pragma unroll
-    for (int nt = 0; nt < NW; ++nt) {
-        const int co = (nt0 + nt) * 16 + (lane & 15);
-        if (co >= p.CO) continue;
-        const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
+        for (int nt = 0; nt < NW; ++nt) {
+            const int co = (nt0 + nt) * 16 + (lane & 15);
+            if (co >= p.CO) continue;
+            const float sc = p.scale ? p.scale[co] : 1.0f, sh = p.shift ? p.shift[co] : 0.0f;
 #pragma unroll
-        for (int mg = 0; mg < 4; ++mg) {
-            const int ox = x0 + mg * 16 + (lane >> 4) * 4;
-            if (ox >= W) continue;
-            const size_t o = (size_t)co * plane + (size_t)oy * W + ox;
-            f4 y = acc[mg][nt] * sc + sh;
-            if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
-            if ((W & 3) == 0) {                                 // a quad is inside or outside as a whole, rows are 16-byte aligned
-                if (p.skip) y = *reinterpret_cast<const f4*>(p.skip + o) + y;
-                *reinterpret_cast<f4*>(p.out + o) = y;
-            } else {                                            // (the coarsest level of the first cascade stage: 86 x 58)
+            for (int mg = 0; mg < 4; ++mg) {
+                const int ox = x0 + mg * 16 + (lane >> 4) * 4;
+                if (ox >= W) continue;
+                const size_t o = (size_t)co * plane + (size_t)oy * W + ox;
+                f4 y = acc[mg][nt] * sc + sh;
+                if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+                if ((W & 3) == 0) {                                 // a quad is inside or outside as a whole, rows are 16-byte aligned
+                    if (p.skip) y = *reinterpret_cast<const f4*>(p.skip + o) + y;
+                    *reinterpret_cast<f4*>(p.out + o) = y;
+                    if constexpr (GN) gn_add(gacc, co >= p.gn_split, y);
+                } else {                                            // (the coarsest level of the first cascade stage: 86 x 58)
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (ox + k < W) p.out[o + k] = p.skip ? p.skip[o + k] + y[k] : y[k];
+                    for (int k = 0; k < 4; ++k)
+                        if (ox + k < W) p.out[o + k] = p.skip ? p.skip[o + k] + y[k] : y[k];
+                    if constexpr (GN) {   // (act 0, no skip: the stored values are y's)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (ox + k >= W) y[k] = 0.0f;   // a zero adds nothing to either sum
+                        gn_add(gacc, co >= p.gn_split, y);
+                    }
+                }
             }
         }
     }
+    if constexpr (GN) gn_flush(gacc, p.gn, p.gn_split < p.CO ? 2 : 1, reinterpret_cast<double*>(smem), tid, WNT / 64);
 }
 
-template <int NW>
+template <int NW, bool GN = false>
 static int launch_wide(const WideParams& p, hipStream_t stream) {
     constexpr int lds = WPATCH + 9 * NW * 64 * 16;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = conv2d_wide_bf16_kernel<NW>;
+    auto kern = conv2d_wide_bf16_kernel<NW, GN>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     const int gy = ceil_div(p.H, WW);
@@ -192,9 +206,9 @@ using namespace d3d;
 
 // out [Co,H,W] = act(conv3x3(cat(in, in2)) * scale + shift) (+ skip, added last); bf16 matrix-core operands, fp32 accumulation.
 // C1, C2 multiples of 32 with C1 + C2 = 64 | 128; Co = 32 | 64 | 128; wpacked = ops._pack_z2_bf16(weight).
-extern "C" int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
-                                       const float* shift, const float* skip, int act, int Co, int H, int W, float* out,
-                                       d3d_stream_t stream) {
+static int conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                              const float* shift, const float* skip, int act, int Co, int H, int W, float* out, double* gn_stats,
+                              int gn_split, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && C1 > 0 && C2 >= 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
@@ -209,9 +223,25 @@ extern "C" int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2
     WideParams p = {};
     p.in = in; p.in2 = in2; p.C1 = C1; p.CI = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
     p.skip = skip; p.out = out; p.H = H; p.W = W; p.CO = Co; p.NTN = Co / 16; p.act = act;
+    p.gn = gn_stats; p.gn_split = gn_split;
     hipStream_t st = (hipStream_t)stream;
     // four output tiles per workgroup; two where that leaves fewer than ~2 workgroups per CU (the coarse levels of the first stages)
     const long tiles = (long)ceil_div(W, WTX) * ceil_div(H, WW);
-    if (p.NTN % 4 == 0 && tiles * (p.NTN / 4) >= 512) return launch_wide<4>(p, st);
-    return launch_wide<2>(p, st);
+    const bool four = p.NTN % 4 == 0 && tiles * (p.NTN / 4) >= 512;
+    if (gn_stats) return four ? launch_wide<4, true>(p, st) : launch_wide<2, true>(p, st);
+    return four ? launch_wide<4>(p, st) : launch_wide<2>(p, st);
+}
+
+// out [Co,H,W] = act(conv3x3(cat(in, in2)) * scale + shift) (+ skip, added last); bf16 matrix-core operands, fp32 accumulation.
+// C1, C2 multiples of 32 with C1 + C2 = 64 | 128; Co = 32 | 64 | 128; wpacked = ops._pack_z2_bf16(weight).
+extern "C" int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                                       const float* shift, const float* skip, int act, int Co, int H, int W, float* out,
+                                       d3d_stream_t stream) {
+    return conv2d_k3_wide_bf16(in, C1, in2, C2, wpacked, scale, shift, skip, act, Co, H, W, out, nullptr, 0, stream);
+}
+// The same layer (act 0, no skip) + the GroupNorm(1, C) statistics of its output (see d3d_conv2d_k3_zs_bf16_gn).
+extern "C" int d3d_conv2d_k3_wide_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift,
+                                          int Co, int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream) {
+    D3D_REQUIRE(gn_stats && gn_split > 0 && gn_split <= Co, "bad statistics arguments");
+    return conv2d_k3_wide_bf16(in, C1, in2, C2, wpacked, nullptr, shift, nullptr, 0, Co, H, W, out, gn_stats, gn_split, stream);
 }

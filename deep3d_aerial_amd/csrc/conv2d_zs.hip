@@ -16,6 +16,7 @@
 // h / u and 16-byte stores.
 #include <cstdint>
 #include "common.h"
+#include "gn_stats.h"
 
 #include <type_traits>
 
@@ -54,6 +55,9 @@ struct Z2Params {
     const float* scale0;  // [8] or null
     const float* shift0;  // [8] or null
     int act0;             // 0 | 1 (ReLU)
+    // GroupNorm statistics of the output (gn_stats.h; act 0, no skip): fp64 pairs, zeroed by the caller; channels >= gn_split are group 1
+    double* gn;
+    int gn_split;
 };
 
 __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
@@ -115,7 +119,7 @@ __device__ __forceinline__ f4 mfma_split3(const bf16x8 (&a)[3], bf16x8 bh, bf16x
 // arithmetic of conv2d_stream_kernel (conv.hip: same order c, k_y, k_x of the fused multiply-adds, scale, shift, ReLU) and writes
 // the split cells the matrix-core sweep reads -- what the two launches compute, bit for bit, without the 8 x H x W tensor's write
 // and read (326 of the pair's 550 MB at 2752 x 1856).
-template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false>
+template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false, bool GN = false>
 __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     static_assert(!(F32 && X3), "one operand format");
     static_assert(!IMG3 || (CI == 8 && X3 && NTN == 1), "image form: 3 -> 8 -> CO <= 16 on split operands");
@@ -296,6 +300,8 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
         }
     }
 
+    GnAcc gacc;
+    gn_zero(gacc);
     auto tile = [&](int ty, const unsigned char* buf) {
         f4 acc[AW];
 #pragma unroll
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
                 if (p.skip && !p.skip_after_act) y += ek[i];
                 if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
                 if (p.skip && p.skip_after_act) y = ek[i] + y;
+                if constexpr (GN) { if (eoff[nt][mg] != OOBZ) gn_add(gacc, nt * 16 + (lane & 15) >= p.gn_split, y); }   // (what is stored, and only that)
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), ro, eoff[nt][mg], 0, 0);
         }
@@ -550,9 +557,10 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
             lds_barrier();
         }
     }
+    if constexpr (GN) gn_flush(gacc, p.gn, p.gn_split < p.CO ? 2 : 1, reinterpret_cast<double*>(smem), tid, TYZ);
 }
 
-template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false>
+template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false, bool GN = false>
 static int launch_z2(const Z2Params& p, hipStream_t stream) {
     constexpr int TX = 16 * MGN, PX = TX + 2;
     constexpr int NKB = F32 ? 9 * CI / 4 : (9 * CI + 31) / 32;
@@ -566,7 +574,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
         return D3D_ERR_UNSUPPORTED;
     }
     if ((long)(CI > p.CO ? CI : p.CO) * p.H * p.W * 4 * (1) >= (1L << 31)) return D3D_ERR_UNSUPPORTED;   // (32-bit buffer offsets)
-    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3, IMG3>;
+    auto kern = conv2d_zs_bf16_kernel<CI, NTN, MGN, F32, X3, IMG3, GN>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
@@ -1308,9 +1316,25 @@ static int convtranspose2d_k3s2_zs(int prec, const float* in, const void* wpacke
     return Ci == 8 ? launch_tz<8>(p, st) : Ci == 16 ? launch_tz<16>(p, st) : launch_tz<32>(p, st);
 }
 
+static int conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                            const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                            int skip_after_act, int Co, int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
 extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                                      const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                                      int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    return conv2d_k3_zs_bf16(in, C1, in2, C2, wpacked, scale, shift, skip, aux1, act, ep_split, skip_after_act, Co, H, W, out, nullptr, 0, stream);
+}
+// The same layer (act 0, no skip) + the GroupNorm(1, C) statistics of its output for the normalisation that follows (module.py:62-67,
+// 71-99 ConvGRUCell2): gn_stats [ngroups][2] fp64 (sum, sum of squares), ZEROED by the caller; channels >= gn_split form the second
+// group (gn_split = Co: one group).  What d3d_groupnorm_stats computes from the stored tensor, without the pass over it.
+extern "C" int d3d_conv2d_k3_zs_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co,
+                                        int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream) {
+    D3D_REQUIRE(gn_stats && gn_split > 0 && gn_split <= Co, "bad statistics arguments");
+    return conv2d_k3_zs_bf16(in, C1, in2, C2, wpacked, nullptr, shift, nullptr, nullptr, 0, 0, 0, Co, H, W, out, gn_stats, gn_split, stream);
+}
+static int conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+                            const float* shift, const float* skip, const float* aux1, int act, int ep_split,
+                            int skip_after_act, int Co, int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && C1 > 0 && C2 >= 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act >= 0 && act <= 3, "bad act %d", act);
@@ -1332,7 +1356,16 @@ extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, 
     p.in = in; p.in2 = in2; p.C1 = C1; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
     p.skip = skip; p.aux1 = aux1; p.out = out; p.H = H; p.W = W; p.CO = Co; p.act = act; p.ep_split = ep_split;
     p.skip_after_act = skip_after_act;
+    p.gn = gn_stats; p.gn_split = gn_split;
     hipStream_t st = (hipStream_t)stream;
+    if (gn_stats) {   // the layers of ConvGRUCell2's finest levels (msrednet.py:337-370): 16 | 24 | 32 | 40 -> 8 | 16 | 32
+        if (Ci == 40 && Co <= 16) return launch_z2<40, 1, 2, false, false, false, true>(p, st);
+        if (Ci == 24 && Co <= 16) return launch_z2<24, 1, 4, false, false, false, true>(p, st);
+        if (Ci == 32) return Co > 16 ? launch_z2<32, 2, 2, false, false, false, true>(p, st) : launch_z2<32, 1, 2, false, false, false, true>(p, st);
+        if (Ci == 16) return Co > 16 ? launch_z2<16, 2, 4, false, false, false, true>(p, st) : launch_z2<16, 1, 4, false, false, false, true>(p, st);
+        set_error("d3d_conv2d_k3_zs_bf16_gn: C_in = %d, C_out = %d not taken", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
     if (Ci == 48) return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);
     if (Ci == 40) return launch_z2<40, 1, 2>(p, st);
     if (Ci == 24) return launch_z2<24, 1, 4>(p, st);

@@ -207,12 +207,15 @@ class ConvGRUCell2(nn.Module):
     def forward(self, x, h=None, negate_x=False):
         if h is None:
             h = torch.zeros((self.output_channel,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
-        f = ops.conv2d_k3(x, self._w(self.gate_conv, negate_x), None, self.gate_conv.bias, None, act=0, stride=1, x2=h)
+        # (the GroupNorm statistics ride on the convolutions' epilogues where the kernel has that form: ops.GnStats)
+        gs = ops.GnStats(2)
+        f = ops.conv2d_k3(x, self._w(self.gate_conv, negate_x), None, self.gate_conv.bias, None, act=0, stride=1, x2=h, gn=gs)
         rn, un = self.reset_gate_norm, self.update_gate_norm
-        rh, u = ops.gru_gates_gn(f, h, rn.weight, rn.bias, un.weight, un.bias, rn.eps)
+        rh, u = ops.gru_gates_gn(f, h, rn.weight, rn.bias, un.weight, un.bias, rn.eps, stats=gs.stats(f))
+        go = ops.GnStats(1)
         o = ops.conv2d_k3(x, self._w(self.output_conv, negate_x), None, self.output_conv.bias, None, act=0, stride=1,
-                          x2=rh)
-        out = ops.gru_update_gn(o, u, h, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps)
+                          x2=rh, gn=go)
+        out = ops.gru_update_gn(o, u, h, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps, stats=go.stats(o))
         return out, out
 
 

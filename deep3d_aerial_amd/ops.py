@@ -1057,7 +1057,7 @@ def _z2_fp32_entry():
     return "f32" if _cfg.get("D3D_CONV2D_FP32") == "f32" else "x3"
 
 
-def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False):
+def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False, gn=None):
     """3x3 stride-1 conv over cat(x, x2) on the tile kernel with the fused epilogues of the slice regularisers (act 0 | 1 |
     2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16) -- bf16 matrix-core operands in bf16 mode; fp32 accuracy otherwise
     (d3d_conv2d_k3_zs_bf16x3: three-way bf16 splits, or with D3D_CONV2D_FP32=f32 the fp32 instruction of d3d_conv2d_k3_zs_f32).  Returns None for shapes the kernel does not take."""
@@ -1078,6 +1078,20 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
     if tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci0 + Ci1, tuple(weight.shape)))
     lib = _lib.load()
+    if bf16 and gn is not None and aux1 is None and Ci in (16, 24, 32, 40) and shift is not None:
+        ga = _gn_args(gn, Co, act, scale, skip, x.device)
+        if ga is not None:   # the layer and the GroupNorm statistics of its output in one launch
+            wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+            out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+            rc = lib.d3d_conv2d_k3_zs_bf16_gn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()), _chk(shift, "shift"),
+                                              Co, H, W, _chk(out, "out"), ctypes.c_void_p(ga[0].data_ptr()), int(ga[1]), _stream())
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "d3d_conv2d_k3_zs_bf16_gn")
+                dispatch_counts["conv2d_tile"] += 1
+                dispatch_counts["conv2d_gn_fused"] += 1
+                return out
+            gn.slot = None   # (not taken: nothing was launched, the slot stays zero for the next request of this lap)
+            _gn_arenas[(x.device.index, torch.cuda.current_stream(x.device).cuda_stream)][1] -= 1
     if bf16:
         name, wp = "d3d_conv2d_k3_zs_bf16", derived_weight(weight, "z2bf16", _pack_z2_bf16)
     elif _z2_fp32_entry() == "x3" and Ci != 48:   # (split cells of 48 channels + their weights do not fit the LDS)
@@ -1235,7 +1249,7 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
     return out
 
 
-def conv2d_wide(x, weight, scale=None, shift=None, skip=None, act=0, x2=None):
+def conv2d_wide(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, gn=None):
     """3x3 stride-1 conv over cat(x, x2) with 64 | 128 input channels (parts of 32) and 32 | 64 | 128 output channels on the
     bf16 matrix cores, K walked in chunks of 32 channels (d3d_conv2d_k3_wide_bf16, csrc/conv2d_wide.hip: the coarse conv-GRU
     levels of the RED-Net slice regulariser).  bf16 mode only; None for other shapes."""
@@ -1247,6 +1261,18 @@ def conv2d_wide(x, weight, scale=None, shift=None, skip=None, act=0, x2=None):
         return None
     wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+    ga = _gn_args(gn, Co, act, scale, skip, x.device) if shift is not None else None
+    if ga is not None:   # the layer and the GroupNorm statistics of its output in one launch
+        rc = _lib.load().d3d_conv2d_k3_wide_bf16_gn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
+                                                    _chk(shift, "shift"), Co, H, W, _chk(out, "out"), ctypes.c_void_p(ga[0].data_ptr()),
+                                                    int(ga[1]), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_conv2d_k3_wide_bf16_gn")
+            dispatch_counts["conv2d_wide"] += 1
+            dispatch_counts["conv2d_gn_fused"] += 1
+            return out
+        gn.slot = None
+        _gn_arenas[(x.device.index, torch.cuda.current_stream(x.device).cuda_stream)][1] -= 1
     rc = _lib.load().d3d_conv2d_k3_wide_bf16(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
                                              _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), int(act), Co, H, W,
                                              _chk(out, "out"), _stream())
@@ -1257,8 +1283,9 @@ def conv2d_wide(x, weight, scale=None, shift=None, skip=None, act=0, x2=None):
     return out
 
 
-def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None):
-    """3x3 conv over cat(x, x2) channels. x [Ci0,H,W], x2 [Ci1,H,W]|None, weight [Co,Ci0+Ci1,3,3]."""
+def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=None, gn=None):
+    """3x3 conv over cat(x, x2) channels. x [Ci0,H,W], x2 [Ci1,H,W]|None, weight [Co,Ci0+Ci1,3,3].  gn: an optional GnStats request
+    for the GroupNorm statistics of the output, served in the layer's epilogue where the kernel has that form."""
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
@@ -1270,11 +1297,11 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
             (conv_precision() == "bf16" or _cfg.state.tile_kernels):
         # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
         # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
-        y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True)   # conv2d_k3: the skip is added last
+        y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True, gn=gn)   # conv2d_k3: the skip is added last
         if y is not None:
             return y
     if stride == 1 and act in (0, 1) and (Ci0 + Ci1) in (64, 128):
-        y = conv2d_wide(x, weight, scale, shift, skip, act, x2=x2)   # (bf16 mode: the wide conv-GRU levels of RED-Net)
+        y = conv2d_wide(x, weight, scale, shift, skip, act, x2=x2, gn=gn)   # (bf16 mode: the wide conv-GRU levels of RED-Net)
         if y is not None:
             return y
     zs_any = conv_precision() == "bf16" or _cfg.state.tile_kernels or Ci0 == 48
@@ -1380,6 +1407,45 @@ def gru_update(u, h, convc):
     return out
 
 
+_gn_arenas = {}
+_GN_SLOTS = 2048
+
+
+class GnStats:
+    """Request for the GroupNorm(1, C) statistics of a convolution's output (ConvGRUCell2, module.py:62-99): `ngroups` (1 | 2) equal
+    consecutive channel groups.  conv2d_k3(..., gn=req) fills `req` in the convolution's epilogue where the kernel has that form
+    (bf16 mode: d3d_conv2d_k3_zs_bf16_gn / d3d_conv2d_k3_wide_bf16_gn); `req.stats(y)` returns the fp64 (sum, sum of squares) pairs
+    -- the epilogue's, or those of d3d_groupnorm_stats over the stored tensor y.  The pairs live in a zeroed arena of slots per
+    (device, stream): one fill per _GN_SLOTS requests instead of one per layer."""
+
+    def __init__(self, ngroups):
+        self.ngroups, self.slot = int(ngroups), None
+
+    def take_slot(self, device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ar = _gn_arenas.get(key)
+        if ar is None or ar[1] >= _GN_SLOTS:
+            buf = ar[0] if ar is not None else torch.empty((_GN_SLOTS, 2, 2), dtype=torch.float64, device=device)
+            buf.zero_()   # (stream order: behind every kernel that used the slots of the previous lap)
+            ar = [buf, 0]
+            _gn_arenas[key] = ar
+        self.slot = ar[0][ar[1]]
+        ar[1] += 1
+        return self.slot
+
+    def stats(self, y):
+        if self.slot is None:
+            return groupnorm_stats(y, self.ngroups)
+        return self.slot[0] if self.ngroups == 1 else self.slot
+
+
+def _gn_args(gn, Co, act, scale, skip, device):
+    """(stats pointer, split) for the _gn entries, or None when the request cannot ride on this layer."""
+    if gn is None or _cfg.off("gn_fused") or act != 0 or scale is not None or skip is not None or (gn.ngroups == 2 and Co % 2):
+        return None
+    return gn.take_slot(device), (Co // 2 if gn.ngroups == 2 else Co)
+
+
 def groupnorm_stats(x, ngroups=1):
     """(sum, sum of squares) of each of `ngroups` equal consecutive parts of x as device fp64 pairs [ngroups,2],
     for GroupNorm(1, C) (module.py:62-67); ngroups = 1 returns the single pair [2]."""
@@ -1396,13 +1462,13 @@ def _dptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def gru_gates_gn(gates, h, gamma_r, beta_r, gamma_u, beta_u, eps=1e-5):
+def gru_gates_gn(gates, h, gamma_r, beta_r, gamma_u, beta_u, eps=1e-5, stats=None):
     """ConvGRUCell2 gates (module.py:71-82): gates [2Hc,H,W] pre-norm, h [Hc,H,W] -> (r*h, u)."""
     Hc = h.shape[0]
     plane = h[0].numel()
     if gates.shape[0] != 2 * Hc or gates[0].numel() != plane:
         raise ValueError("gates must be [2*Hc,H,W]")
-    st = groupnorm_stats(gates, 2)  # reset-gate half, update-gate half: one launch
+    st = groupnorm_stats(gates, 2) if stats is None else stats  # reset-gate half, update-gate half: one launch (or the convolution's own)
     st_r, st_u = st[0], st[1]
     rh = torch.empty_like(h)
     u = torch.empty_like(h)
@@ -1413,11 +1479,11 @@ def gru_gates_gn(gates, h, gamma_r, beta_r, gamma_u, beta_u, eps=1e-5):
     return rh, u
 
 
-def gru_update_gn(o, u, h, gamma, beta, eps=1e-5):
+def gru_update_gn(o, u, h, gamma, beta, eps=1e-5, stats=None):
     """ConvGRUCell2 state update (module.py:84-98): h' = u*h + (1-u)*tanh(GroupNorm(o))."""
     Hc = h.shape[0]
     plane = h[0].numel()
-    st = groupnorm_stats(o)
+    st = groupnorm_stats(o) if stats is None else stats
     out = torch.empty_like(h)
     rc = _lib.load().d3d_gru_update_gn(_chk(o, "o"), _dptr(st), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(u, "u"),
                                        _chk(h, "h"), Hc, plane, float(eps), _chk(out, "out"), _stream())

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 7
+#define D3D_ABI_VERSION 8
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -210,6 +210,17 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
  * w % 4 == 0, else D3D_ERR_UNSUPPORTED.  `reg` never reaches memory. */
 int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
                                 int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream);
+/* A 3 x 3 convolution of ConvGRUCell2 (module.py:71-99: gate_conv / output_conv over cat(x, h), bias, no activation) that also
+ * accumulates the GroupNorm(1, C) statistics of its output (round 4, ABI 8; csrc/gn_stats.h): gn_stats [ngroups][2] fp64 =
+ * (sum, sum of squares) per channel group, ZEROED by the caller before the launch (stream order); channels >= gn_split are the second
+ * group (the update half of the gate convolution), gn_split = Co means one group.  The sums are those d3d_groupnorm_stats computes
+ * from the stored tensor (same operands, fp64; the order of the additions differs) -- that launch and its pass over the tensor go.
+ * _zs: the tile kernel of d3d_conv2d_k3_zs_bf16 for C1 + C2 = 16 | 24 | 32 | 40 (24 | 40: Co <= 16; else Co <= 32), W % 4 == 0;
+ * _wide: d3d_conv2d_k3_wide_bf16's shapes.  D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_conv2d_k3_zs_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
+                             int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
+int d3d_conv2d_k3_wide_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
+                               int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
 /* conv0 of a feature trunk in ONE launch (round 4, ABI 7; csrc/conv2d_zs.hip, IMG3 form): out = act(scale * Conv3x3_8->Co(c) + shift)
  * with c = act0(scale0 * Conv3x3_3->8(img) + shift0) evaluated per tile from the staged image patch and never written (module.py:
  * 663-666: ConvBnReLU(3, 8) + ConvBnReLU(8, 8) at full resolution).  img [3,H,W]; w0packed [4][3][3][8] fp32 as

@@ -1640,6 +1640,34 @@ def test_conv11_prob_fused_is_the_two_layers(ops, monkeypatch, D, H, W, skip):
     assert ops.convtranspose3d_prob_cl(xd, wd, scd, shd, sk, wpd, bpd) is None   # the switch takes it out of the dispatch
 
 
+@pytest.mark.parametrize("ci0,ci1,co,h,w", [(16, 8, 16, 130, 132), (32, 8, 16, 67, 260), (8, 8, 16, 129, 256), (16, 16, 32, 140, 136),
+                                            (8, 8, 8, 131, 128), (32, 32, 64, 58, 88), (32, 32, 32, 57, 86), (64, 64, 128, 30, 44), (64, 64, 64, 29, 43)])
+def test_groupnorm_statistics_ride_on_the_convolution(ops, bf16_mode, monkeypatch, ci0, ci1, co, h, w):
+    """ConvGRUCell2's convolutions with the GroupNorm(1, C) statistics of their output accumulated in the epilogue
+    (d3d_conv2d_k3_zs_bf16_gn / d3d_conv2d_k3_wide_bf16_gn, csrc/gn_stats.h): the output is the plain layer's, bit for bit, and the
+    fp64 sums are those d3d_groupnorm_stats computes from the stored tensor (same operands; only the order of the fp64 additions
+    differs) -- one and two channel groups, ragged tiles, widths that are not a multiple of 4 on the wide kernel."""
+    g = torch.Generator("cuda").manual_seed(ci0 + co + h)
+    x, x2 = torch.randn(ci0, h, w, device="cuda", generator=g), torch.randn(ci1, h, w, device="cuda", generator=g)
+    wt = torch.randn(co, ci0 + ci1, 3, 3, device="cuda", generator=g) / (3.0 * (ci0 + ci1) ** 0.5)
+    bias = torch.randn(co, device="cuda", generator=g)
+    for ngroups in (2, 1):
+        conv = ops.conv2d_wide if ci0 + ci1 >= 64 else ops.conv2d_zs   # (conv2d_k3's choices for these layers at production sizes)
+        req = ops.GnStats(ngroups)
+        before = ops.dispatch_counts["conv2d_gn_fused"]
+        y = conv(x, wt, None, bias, None, 0, x2=x2, gn=req)
+        assert ops.dispatch_counts["conv2d_gn_fused"] == before + 1 and req.slot is not None
+        set_kernel(monkeypatch, "gn_fused", False)
+        plain_req = ops.GnStats(ngroups)
+        plain = conv(x, wt, None, bias, None, 0, x2=x2, gn=plain_req)
+        set_kernel(monkeypatch, "gn_fused", True)
+        assert plain_req.slot is None and torch.equal(y, plain)
+        got, want = req.stats(y).reshape(-1), plain_req.stats(plain).reshape(-1)
+        assert float(((got - want).abs() / want.abs().clamp_min(1e-300)).max()) <= 1e-11, (got, want)
+        exact = torch.stack([torch.stack([part.double().sum(), (part.double() ** 2).sum()]) for part in y.chunk(ngroups, 0)]).reshape(-1)
+        assert float(((got - exact).abs() / exact.abs().clamp_min(1e-300)).max()) <= 1e-11
+
+
 @pytest.mark.parametrize("hw", [(256, 256), (264, 260), (300, 1028), (1856, 2752)], ids=lambda t: "%dx%d" % t)
 def test_trunk_conv0_pair_is_the_two_launches(ops, monkeypatch, hw):
     """conv0 of a feature trunk in one launch (d3d_conv2d_k3_pair3_bf16x3: the 3 -> 8 layer evaluated per tile from the staged
