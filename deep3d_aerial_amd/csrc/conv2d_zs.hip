@@ -119,8 +119,9 @@ __device__ __forceinline__ f4 mfma_split3(const bf16x8 (&a)[3], bf16x8 bh, bf16x
 // arithmetic of conv2d_stream_kernel (conv.hip: same order c, k_y, k_x of the fused multiply-adds, scale, shift, ReLU) and writes
 // the split cells the matrix-core sweep reads -- what the two launches compute, bit for bit, without the 8 x H x W tensor's write
 // and read (326 of the pair's 550 MB at 2752 x 1856).
+// (GN instance of 40 channels: 124 registers without the statistics' fp64 partial sums -- held to 128, i.e. to two workgroups per CU)
 template <int CI, int NTN, int MGN, bool F32 = false, bool X3 = false, bool IMG3 = false, bool GN = false>
-__global__ __launch_bounds__(NTZ, 2) void conv2d_zs_bf16_kernel(Z2Params p) {
+__global__ __launch_bounds__(NTZ, GN && CI == 40 ? 4 : 2) void conv2d_zs_bf16_kernel(Z2Params p) {
     static_assert(!(F32 && X3), "one operand format");
     static_assert(!IMG3 || (CI == 8 && X3 && NTN == 1), "image form: 3 -> 8 -> CO <= 16 on split operands");
     constexpr int TX = 16 * MGN, PX = TX + 2;

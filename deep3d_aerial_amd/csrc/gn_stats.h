@@ -20,8 +20,9 @@ __device__ __forceinline__ void gn_add(GnAcc& a, bool second, const V4& y) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const double v = (double)y[k];
-        if (second) { a.s[1] += v; a.q[1] += v * v; }
-        else        { a.s[0] += v; a.q[0] += v * v; }
+        // (v * v is exact in fp64 -- 24 x 24 significand bits -- so the fused form rounds once, as the product-then-sum does)
+        if (second) { a.s[1] += v; a.q[1] = __builtin_fma(v, v, a.q[1]); }
+        else        { a.s[0] += v; a.q[0] = __builtin_fma(v, v, a.q[0]); }
     }
 }
 

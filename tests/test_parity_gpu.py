@@ -1076,6 +1076,8 @@ def test_model_forward_at_production_kernel_size_matches_reference(ops, name, mo
             assert counts.get("gru_cell_fused", 0) == 2 * (48 + 32 + 8), counts   # both cells of every slice of every stage
             # upconv1 + skip + head + regression update of every slice of the up-sampling stages in one kernel, the last stage's head fused
             assert counts.get("slice_tail_regress", 0) == 48 + 32 and counts.get("slice_head_regress", 0) == 8, counts
+    if name == "msrednet" and mode == "bf16":   # GroupNorm statistics of the conv-GRU levels on the tile / wide kernels ride on the convolutions
+        assert counts.get("conv2d_gn_fused", 0) >= 2 * 2 * (48 + 32 + 8), counts   # (at least the two wide levels of every slice)
     if name in ("casmvsnet", "adamvs"):   # conv0 of the feature trunk of every view in one launch (both precisions: the feature nets are fp32)
         assert counts.get("conv2d_pair3", 0) == imgs.shape[1], counts
     # ---- and what they produced is the reference's
