@@ -821,6 +821,67 @@ __global__ __launch_bounds__(256) void gru2_update_kernel(const float* __restric
     h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh(on);
 }
 
+// The two kernels above, four pixels of one channel per thread (plane % 4 == 0, 16-byte aligned tensors; grid.y = channel: no
+// division), the folded statistics -- an fp64 division and a square root -- evaluated by ONE thread of the workgroup instead of
+// every thread.  The same fp32 operations per element, in the same order.
+typedef float f4g __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gru2_gates_kernel4(const float* __restrict__ gates, const double* __restrict__ st_r,
+                                                           const double* __restrict__ st_u, const float* __restrict__ g_r,
+                                                           const float* __restrict__ b_r, const float* __restrict__ g_u,
+                                                           const float* __restrict__ b_u, const float* __restrict__ h,
+                                                           int Hc, long plane, float eps, float* __restrict__ rh,
+                                                           float* __restrict__ u) {
+    __shared__ float aff[4];
+    const long n = (long)Hc * plane;
+    if (threadIdx.x == 0) {
+        const GnAffine ar = gn_fold(st_r, n, eps), au = gn_fold(st_u, n, eps);
+        aff[0] = ar.mean; aff[1] = ar.rstd; aff[2] = au.mean; aff[3] = au.rstd;
+    }
+    __syncthreads();
+    const long q = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (q >= plane) return;
+    const int c = blockIdx.y;
+    const long i = (long)c * plane + q;
+    const float gr = g_r[c], br = b_r[c], gu = g_u[c], bu = b_u[c];
+    const f4g vr = *reinterpret_cast<const f4g*>(gates + i), vu = *reinterpret_cast<const f4g*>(gates + n + i);
+    const f4g hv = *reinterpret_cast<const f4g*>(h + i);
+    f4g orh, ou;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float rn = (vr[k] - aff[0]) * aff[1] * gr + br;
+        const float un = (vu[k] - aff[2]) * aff[3] * gu + bu;
+        orh[k] = gru_sigmoid(rn) * hv[k];
+        ou[k] = gru_sigmoid(un);
+    }
+    *reinterpret_cast<f4g*>(rh + i) = orh;
+    *reinterpret_cast<f4g*>(u + i) = ou;
+}
+
+__global__ __launch_bounds__(256) void gru2_update_kernel4(const float* __restrict__ o, const double* __restrict__ st_o,
+                                                            const float* __restrict__ g_o, const float* __restrict__ b_o,
+                                                            const float* __restrict__ u, const float* __restrict__ h,
+                                                            int Hc, long plane, float eps, float* __restrict__ h_out) {
+    __shared__ float aff[2];
+    if (threadIdx.x == 0) {
+        const GnAffine a = gn_fold(st_o, (long)Hc * plane, eps);
+        aff[0] = a.mean; aff[1] = a.rstd;
+    }
+    __syncthreads();
+    const long q = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (q >= plane) return;
+    const int c = blockIdx.y;
+    const long i = (long)c * plane + q;
+    const float go = g_o[c], bo = b_o[c];
+    const f4g ov = *reinterpret_cast<const f4g*>(o + i), uv = *reinterpret_cast<const f4g*>(u + i), hv = *reinterpret_cast<const f4g*>(h + i);
+    f4g out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float on = (ov[k] - aff[0]) * aff[1] * go + bo;
+        out[k] = uv[k] * hv[k] + (1.0f - uv[k]) * gru_tanh(on);
+    }
+    *reinterpret_cast<f4g*>(h_out + i) = out;
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -1043,6 +1104,10 @@ int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* st
     D3D_REQUIRE(gates && stats_r && stats_u && gamma_r && beta_r && gamma_u && beta_u && h && rh && u, "null pointer");
     D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
     const long n = (long)Hc * plane;
+    if (plane % 4 == 0 && Hc <= 65535 && aligned16(gates) && aligned16(h) && aligned16(rh) && aligned16(u))
+        hipLaunchKernelGGL(gru2_gates_kernel4, dim3(ceil_div(plane / 4, 256), Hc), dim3(256), 0, (hipStream_t)stream, gates, stats_r,
+                           stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
+    else
     hipLaunchKernelGGL(gru2_gates_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, gates, stats_r,
                        stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
     D3D_LAUNCH_CHECK("gru2_gates_kernel launch");
@@ -1054,6 +1119,10 @@ int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma,
     D3D_REQUIRE(o && stats_o && gamma && beta && u && h && h_out, "null pointer");
     D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
     const long n = (long)Hc * plane;
+    if (plane % 4 == 0 && Hc <= 65535 && aligned16(o) && aligned16(u) && aligned16(h) && aligned16(h_out))
+        hipLaunchKernelGGL(gru2_update_kernel4, dim3(ceil_div(plane / 4, 256), Hc), dim3(256), 0, (hipStream_t)stream, o, stats_o, gamma,
+                           beta, u, h, Hc, (long)plane, eps, h_out);
+    else
     hipLaunchKernelGGL(gru2_update_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, o, stats_o, gamma,
                        beta, u, h, Hc, (long)plane, eps, h_out);
     D3D_LAUNCH_CHECK("gru2_update_kernel launch");
