@@ -36,6 +36,7 @@ SIGNATURES = {
     "d3d_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],  # returns size_t
     "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_variance_volume_planes": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_f16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_cl_bf16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_cl8_bf16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],

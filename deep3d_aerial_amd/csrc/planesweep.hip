@@ -493,6 +493,18 @@ int d3d_variance_volume(const float* const* feats, const float* proj34, const fl
     return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
 }
 
+// The same volume with plane d as one contiguous [C,h,w] block -- out [D,C,h,w] -- for the models that walk the depth slices one at a
+// time (msrednet.py:400-437: the recurrent regulariser then reads a slice where it lies, no per-slice copy).
+int d3d_variance_volume_planes(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                               int n_views, int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
+                               d3d_stream_t stream) {
+    SweepParams p = {};
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes);
+    if (rc) return rc;
+    p.plane_major = 1;
+    return sweep_dispatch(MODE_VARIANCE, p, (hipStream_t)stream);
+}
+
 static int variance_volume_cl_any(int layout, const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                 d3d_stream_t stream) {

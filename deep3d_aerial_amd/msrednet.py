@@ -74,13 +74,13 @@ class InferDepthNet(nn.Module):
             # The reference warps plane by plane (msrednet.py:400-414) because it holds one slice at a time; the
             # whole variance volume of a stage is at most 2.6 GB here, so it is swept in ONE fused launch and the
             # recurrent regulariser then walks its depth slices.
-            var = ops.variance_volume(feats, p34, dvb.contiguous())                    # [C,D,h,w]
+            var = ops.variance_volume(feats, p34, dvb.contiguous(), plane_major=True)  # [D,C,h,w]: a slice is one contiguous block
             for d in range(num_depth):
-                if dvb.dim() == 1:   # [D] uniform planes
-                    dplane = dvb[d:d + 1].expand(h * w).reshape(h, w).contiguous()
+                if dvb.dim() == 1:   # [D] uniform planes: a [1,1] map (the update resamples it to the image, a constant)
+                    dplane = dvb[d:d + 1].view(1, 1)
                 else:                # [D,h,w] per-pixel hypotheses
                     dplane = dvb[d]
-                reg, *states = cost_regularization(var[:, d].contiguous(), *states)
+                reg, *states = cost_regularization(var[d], *states)
                 ops.online_regress_update(reg[0], dplane, max_p, sum_d, sum_p)
             dep, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
             depths.append(dep)

@@ -189,10 +189,23 @@ def _chk16(t, name):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def variance_volume(feats, proj34, depth, out=None):
-    """feats: list of V tensors [C,h,w] (feats[0] = reference); -> [C,D,h,w] (cas_mvsnet.py:45-60).
+def variance_volume(feats, proj34, depth, out=None, plane_major=False):
+    """feats: list of V tensors [C,h,w] (feats[0] = reference); -> [C,D,h,w] (cas_mvsnet.py:45-60), or [D,C,h,w] with
+    plane_major=True (fp32: plane d is one contiguous block for the slice loops).
     float16 feature maps give a float16 volume (fp32 arithmetic, BASELINE config 5)."""
     C, h, w = _check_feats(feats, proj34)
+    if plane_major and feats[0].dtype == torch.float32:
+        dp, mode, D = _depth(depth, h, w)
+        if out is None:
+            out = torch.empty((D, C, h, w), dtype=torch.float32, device=feats[0].device)
+        arr = _ptr_array(feats, "feats")
+        ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
+        rc = _lib.load().d3d_variance_volume_planes(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
+                                                    _chk(out, "out", 4), wp, wn, _stream())
+        _lib.check(rc, "d3d_variance_volume_planes")
+        return out
+    if plane_major:
+        raise ValueError("plane_major volumes are fp32")
     if feats[0].dtype == torch.float16:
         dp, mode, D = _depth(depth, h, w)
         if out is None:

@@ -139,6 +139,11 @@ int d3d_homo_warp_f64coord(const float* src, const double* proj34, const float* 
 int d3d_variance_volume(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                         int n_views, int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
                         d3d_stream_t stream);
+/* d3d_variance_volume with plane d as one contiguous block: out [D,C,h,w] (round 4, ABI 8) -- the layout the slice-recurrent
+ * regularisers read (msrednet.py:400-437), as d3d_weighted_corr(plane_major = 1) is for adamvs.py:492-512.  Same values. */
+int d3d_variance_volume_planes(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+                               int n_views, int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
+                               d3d_stream_t stream);
 
 /* d3d_variance_volume with the result as a channel-last bf16 volume [D,h,w,C] (RNE at the store; fp32 features and fp32
  * arithmetic as above): the form conv0 of the 3-D regulariser takes in bf16 mode (d3d_conv3d_k3_cl_bf16, in_cl = 1), which

@@ -406,6 +406,24 @@ def test_window_kernel_repeats_the_ring_kernel_bit_for_bit(ops, oracle, case):
         assert rel_l1(host(outs["window"][0]), want) <= REL_VOLUME
 
 
+@pytest.mark.parametrize("path_", ["", "window", "tiled", "direct"])
+def test_variance_volume_plane_major_is_the_same_volume(ops, path_):
+    """d3d_variance_volume_planes (out [D,C,h,w]: the slice loop of msrednet.py:400-437 reads plane d where it lies) holds the
+    values of d3d_variance_volume, on every kernel family."""
+    V, C, h, w, D = 4, 16, 70, 132, 12
+    proj, dv = S.make_scene(V, h, w, D, sweep_px=6.0, seed=7, yaw_deg=3.0)
+    fd = [dev(f) for f in S.make_features(V, C, h, w, seed=7)]
+    p34 = ops.compose_projections(dev(proj))
+    depth = dev(S.uniform_depths(dv, D))
+    config.switches["D3D_FORCE_PATH"] = path_
+    try:
+        a = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, depth), path_)
+        b = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, depth, plane_major=True), path_)
+    finally:
+        config.switches["D3D_FORCE_PATH"] = ""
+    assert tuple(b.shape) == (D, C, h, w) and torch.equal(b, a.permute(1, 0, 2, 3))
+
+
 def test_window_kernel_full_size_last_stage(ops):
     """The shape the dispatcher sends to the window kernel inside a cascade view: 8 channels x 8 per-pixel hypotheses at
     1856 x 2752, five views -- dispatcher's choice against the ring kernel, bit for bit, all three products."""
