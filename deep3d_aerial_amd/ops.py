@@ -321,10 +321,12 @@ def softargmin_conf4_var(cost, depth, lamb):
     return dep, conf, var
 
 
-def uncertainty_aware_samples(cur_depth, exp_var, ndepth, shape=None):
+def uncertainty_aware_samples(cur_depth, exp_var, ndepth, shape=None, affine=False):
     """ucsnet.py:30-53.  First stage: cur_depth [2+] = (min, ..., max) -> uniform hypotheses [ndepth] (the reference tiles
     them to [ndepth,h,w]; the sweep kernels take the per-plane form).  Later stages: cur_depth, exp_var [h,w] ->
-    [ndepth,h,w] hypotheses between cur - var and cur + var."""
+    [ndepth,h,w] hypotheses between cur - var and cur + var -- or, affine=True, the two maps (low, step) that generate them as an
+    AffineDepth: plane k = low + k * step with the kernel's two roundings; the reference's `+ 1e-12` is the identity on any
+    depth above 2e-5 (half an ulp there), so for real scenes the planes are the volume's, bit for bit."""
     if cur_depth.dim() == 1:
         return depth_range_samples(cur_depth, ndepth, 0.0)
     if ndepth <= 1:
@@ -332,6 +334,13 @@ def uncertainty_aware_samples(cur_depth, exp_var, ndepth, shape=None):
     h, w = cur_depth.shape
     if exp_var is None or tuple(exp_var.shape) != (h, w):
         raise ValueError("exp_var must be [%d,%d]" % (h, w))
+    if affine:
+        maps = torch.empty((2, h, w), dtype=torch.float32, device=cur_depth.device)
+        torch.sub(cur_depth, exp_var, out=maps[0])                                  # low
+        torch.sub(cur_depth + exp_var, maps[0], out=maps[1])                        # high - low
+        # step: the kernel's fp32 DIVISION (a tensor divisor: torch turns a scalar divisor into a multiplication by its reciprocal)
+        maps[1].div_(torch.full((1,), float(ndepth) - 1.0, dtype=torch.float32, device=cur_depth.device))
+        return AffineDepth(maps, ndepth)
     out = torch.empty((ndepth, h, w), dtype=torch.float32, device=cur_depth.device)
     rc = _lib.load().d3d_uncertainty_samples(_chk(cur_depth, "cur_depth", 2), _chk(exp_var, "exp_var", 2), ndepth, h, w,
                                              _chk(out, "out"), _stream())

@@ -23,6 +23,12 @@ from .dataset import extract_features
 from .module import FeatureNet_mvsnet
 
 
+# Stages 2 and 3 hand the sweep and the regression the two maps (low, step) their hypotheses are generated from instead of the
+# [D,h,w] volume (ops.AffineDepth, as cas_mvsnet.AFFINE_DEPTH): no D-plane volume is written or read, the window kernel bounds its
+# windows from two maps.  False restores the volumes.
+AFFINE_DEPTH = True
+
+
 def compute_depth(feats, proj_mats, depth_samps, cost_reg, lamb):
     """ucsnet.py:99-151 for one batch item: feats list of [C,h,w], proj_mats [V,4,4], depth_samps [D] or [D,h,w]."""
     assert len(feats) == proj_mats.shape[0], "Different number of images and projection matrices"
@@ -65,7 +71,7 @@ class Infer_UCSNet(nn.Module):
                 else:
                     cur = ops.resize_bilinear(depth[b:b + 1].contiguous(), cur_h, cur_w)[0]
                     var = ops.resize_bilinear(exp_var[b:b + 1].contiguous(), cur_h, cur_w)[0]
-                    samples = ops.uncertainty_aware_samples(cur, var, self.ndepths[stage_idx])
+                    samples = ops.uncertainty_aware_samples(cur, var, self.ndepths[stage_idx], affine=AFFINE_DEPTH)
                 d, c, v = compute_depth([f[b].contiguous() for f in feats], proj_matrices[key][b], samples,
                                         self.cost_regularization[stage_idx], self.lamb)
                 deps.append(d)

@@ -985,6 +985,27 @@ def test_ucsnet_forward_matches_reference(ops, tag):
     assert out["variance"].shape == (1,) + g["variance"].shape
 
 
+def test_ucsnet_affine_hypotheses_equal_the_volume_path(ops, monkeypatch):
+    """Infer_UCSNet hands stages 2 and 3 the (low, step) maps of its uncertainty-aware hypotheses (ucsnet.AFFINE_DEPTH, ops.AffineDepth)
+    instead of the [D,h,w] volume: the planes are the volume's bit for bit (the reference's + 1e-12 is the identity at these depths),
+    so the whole forward is."""
+    from deep3d_aerial_amd import ucsnet
+
+    g = load_golden("model_ucsnet_v5")
+    net = _fill(ucsnet.Infer_UCSNet(num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    outs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ucsnet, "AFFINE_DEPTH", flag)
+        with torch.no_grad():
+            outs[flag] = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
+    for st in ("stage1", "stage2", "stage3"):
+        for key in ("depth", "photometric_confidence", "variance"):
+            assert torch.equal(outs[True][st][key], outs[False][st][key]), (st, key)
+    cur, var = outs[True]["stage2"]["depth"][0], outs[True]["stage2"]["variance"][0]
+    assert torch.equal(ops.uncertainty_aware_samples(cur, var, 8, affine=True).volume(), ops.uncertainty_aware_samples(cur, var, 8))
+
+
 @pytest.mark.parametrize("tag", ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "model_adamvs_v5",
                                  "model_msrednet_v3", "model_msrednet_v5"])
 def test_model_forward_matches_reference(ops, tag):
