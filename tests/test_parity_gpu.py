@@ -1107,17 +1107,20 @@ def test_model_forward_at_production_kernel_size_matches_reference(ops, name, mo
         if mode == "bf16":   # ... the regularisers on channel-last bf16 volumes fed by CL8 variance volumes
             assert counts.get("variance_cl8", 0) == 3 and counts.get("conv3d_cl8_in", 0) == 3 and counts.get("conv3d_cl", 0) >= 18, counts
             # conv11 + prob of the three stages in one kernel each (the full-resolution 8-channel volume stays in LDS)
-            assert counts.get("convtranspose3d_prob_cl", 0) == 3 and counts.get("convtranspose3d_cl", 0) == 6, counts
+            if not config.off("t2prob"):
+                assert counts.get("convtranspose3d_prob_cl", 0) == 3 and counts.get("convtranspose3d_cl", 0) == 6, counts
             assert counts.get("conv3d_cl_fallback", 0) == 0 and counts.get("variance_cl_fallback", 0) == 0, counts
     else:                    # ... the slice regularisers' finest level on the 2-D tile kernels (and, bf16 AdaMVS, the fused cell)
         assert counts.get("conv2d_tile", 0) + counts.get("gru_cell_fused", 0) > 0 and counts.get("convtranspose2d_tile", 0) > 0, counts
         if name == "adamvs" and mode == "bf16":
             assert counts.get("gru_cell_fused", 0) == 2 * (48 + 32 + 8), counts   # both cells of every slice of every stage
             # upconv1 + skip + head + regression update of every slice of the up-sampling stages in one kernel, the last stage's head fused
-            assert counts.get("slice_tail_regress", 0) == 48 + 32 and counts.get("slice_head_regress", 0) == 8, counts
-    if name == "msrednet" and mode == "bf16":   # GroupNorm statistics of the conv-GRU levels on the tile / wide kernels ride on the convolutions
+            if not config.off("tail_fused"):
+                assert counts.get("slice_tail_regress", 0) == 48 + 32 and counts.get("slice_head_regress", 0) == 8, counts
+    # (the asserts on this round's fused kernels hold for the default dispatch: D3D_KERNELS_OFF=<name> takes a kernel out on purpose)
+    if name == "msrednet" and mode == "bf16" and not config.off("gn_fused"):   # GroupNorm statistics ride on the convolutions
         assert counts.get("conv2d_gn_fused", 0) >= 2 * 2 * (48 + 32 + 8), counts   # (at least the two wide levels of every slice)
-    if name in ("casmvsnet", "adamvs"):   # conv0 of the feature trunk of every view in one launch (both precisions: the feature nets are fp32)
+    if name in ("casmvsnet", "adamvs") and not config.off("conv0_pair"):   # conv0 of the feature trunk of every view in one launch (the feature nets are fp32 in both modes)
         assert counts.get("conv2d_pair3", 0) == imgs.shape[1], counts
     # ---- and what they produced is the reference's
     interval = float(dv[0, -1] - dv[0, 0]) / nd
