@@ -63,6 +63,7 @@ int launch_tiled(int mode, const struct SweepParams& p, hipStream_t stream);
 // D3D_ERR_UNSUPPORTED outside its shapes
 int launch_window(int mode, const struct SweepParams& p, hipStream_t stream, bool forced);
 size_t tiled_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes);
+size_t window_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes);
 // non-default compile-time knobs of the translation units that have any (d3d_build_flags)
 const char* tiled_build_flags();
 const char* window_build_flags();
@@ -415,7 +416,8 @@ int d3d_debug_force_path(int path) {
 
 size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes) {
     if (n_views < 2 || C <= 0 || D <= 0 || h <= 1 || w <= 1 || (elem_bytes != 4 && elem_bytes != 2)) return 0;
-    return tiled_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes);
+    const size_t a = tiled_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes), b = window_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes);
+    return a > b ? a : b;
 }
 
 int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int depth_mode, int C, int D, int h,

@@ -1345,6 +1345,18 @@ __global__ __launch_bounds__(256) void pack_channel_last_kernel(PackArgs pa, int
     reinterpret_cast<f4*>(out + ((size_t)vg * plane + pos) * CW)[q] = x;
 }
 
+// The fp32 source maps of a sweep as [view][C / 8][h * w][8] in p.workspace (for the window kernel's gather path, planesweep_window.hip)
+int pack_channel_last_g8(const SweepParams& p, hipStream_t stream) {
+    PackArgs pa = {};
+    for (int i = 0; i < p.n_src; ++i) pa.src[i] = p.feats[i + 1];
+    const long plane = (long)p.h * p.w;
+    const int ngroups = p.C / 8;
+    hipLaunchKernelGGL((pack_channel_last_kernel<8, float>), dim3((unsigned)ceil_div(plane * 2, 256), p.n_src * ngroups), dim3(256), 0, stream, pa,
+                       ngroups, plane, reinterpret_cast<float*>(p.workspace));
+    D3D_LAUNCH_CHECK("pack_channel_last_kernel launch (window gather path)");
+    return D3D_OK;
+}
+
 static int group_channels(int C, int n_src, int elem_bytes);
 
 // depth planes per workgroup segment and the number of segments (shared by the launcher and the workspace query)

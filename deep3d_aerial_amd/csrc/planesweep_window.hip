@@ -31,6 +31,8 @@
 
 namespace d3d {
 
+int pack_channel_last_g8(const SweepParams& p, hipStream_t stream);   // planesweep_tiled.hip
+
 namespace {
 
 constexpr int WTW = 32;               // patch width: one 128-byte output row segment per lane row
@@ -56,6 +58,7 @@ constexpr int WTOFF = 2 * WDSEG_MAX;      // where the translations start
 struct WindowArgs {
     int tiles_x, tiles_y, nseg, dseg, ngroups;
     int cap_bytes;   // LDS bytes available for windows
+    const float* cl; // channel-last copy of the source maps [view][C / 8][h * w][8] (pack_channel_last_g8) for the gather path, or null
     unsigned long long* stats;   // -DD3D_EXPERIMENTS + D3D_WINDOW_STATS: [0] workgroups [1] staged chunks [2] planes in them [3] gathered planes
                                  // [4] staged bytes / 16 [5] cycles staging (wave 0) [6] cycles sweeping (wave 0) [7] cycles total (wave 0)
 };
@@ -597,9 +600,17 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                         const TapG t = make_tap_glb(u, v, h, w);
                         const float vwi = (MODE == MODE_WEIGHTED) ? p.weights[(size_t)i * plane + pix] : 0.0f;
                         const float* __restrict__ g = p.feats[i + 1] + (size_t)c0 * plane + t.off;
+                        // with the channel-last copy (hypothesis volumes: the caller did not vouch for a smooth map) a tap's eight channels
+                        // are 32 contiguous bytes -- two 16-byte loads instead of eight 4-byte loads in eight planes; same values
+                        const f4* __restrict__ gc = CH == 8 && a.cl ? reinterpret_cast<const f4*>(a.cl + (((size_t)i * a.ngroups + gi) * plane + t.off) * 8) : nullptr;
 #pragma unroll
                         for (int q = 0; q < Q; ++q) {
                             f4 val;
+                            if (CH == 8 && gc) {
+                                const f4 nw = gc[q], ne = gc[2 * t.dx + q], sw = gc[2 * t.dyw + q], se = gc[2 * (t.dyw + t.dx) + q];
+#pragma unroll
+                                for (int kk = 0; kk < 4; ++kk) val[kk] = fmaf(se[kk], t.se, fmaf(sw[kk], t.sw, fmaf(ne[kk], t.ne, nw[kk] * t.nw)));
+                            } else
 #pragma unroll
                             for (int kk = 0; kk < 4; ++kk) {
                                 const float* __restrict__ gk = g + (size_t)(4 * q + kk) * plane;
@@ -749,6 +760,15 @@ static int launch_window_one(const SweepParams& p, hipStream_t stream) {
     a.nseg = ceil_div(p.D, a.dseg);
     a.cap_bytes = WLDS_BYTES - WTAB * 4;
     a.stats = nullptr;
+    a.cl = nullptr;
+    if (MODE != MODE_PAIR && CH == 8 && p.depth_mode == D3D_DEPTH_PER_PIXEL && p.workspace &&
+        p.workspace_bytes >= (size_t)p.n_src * p.C * p.h * p.w * 4) {
+        // Hypothesis VOLUMES (the models that have a smooth map hand over its two generating maps, D3D_DEPTH_AFFINE): patches whose
+        // hypotheses no window bounds gather their taps from global memory, and that path wants the channel-last copy
+        rc = pack_channel_last_g8(p, stream);
+        if (rc != D3D_OK) return rc;
+        a.cl = reinterpret_cast<const float*>(p.workspace);
+    }
     const long nblk = (long)a.tiles_x * a.tiles_y * a.nseg;
     if (nblk > 0x7fffffffL) return D3D_ERR_UNSUPPORTED;
 #ifdef D3D_EXPERIMENTS
@@ -815,6 +835,12 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
     if (p.D <= D3D_WINDOW_PH16) return launch_window_one<MODE, NSRC, 8, false, 16>(p, stream);
 #endif
     return launch_window_one<MODE, NSRC, 8, false, 8>(p, stream);
+}
+
+// scratch of the gather path's channel-last copy (d3d_sweep_workspace_bytes takes the larger of this and the ring kernel's)
+size_t window_workspace_bytes(int n_src, int C, int D, int h, int w, int elem_bytes) {
+    if (elem_bytes != 4 || C % 8 != 0 || n_src > 4 || n_src < 1 || D3D_WINDOW_PLANES == 0 || D > D3D_WINDOW_PLANES) return 0;
+    return (size_t)n_src * C * h * w * 4;
 }
 
 // Returns D3D_ERR_UNSUPPORTED for shapes outside what the window kernel is built for (the caller then takes the ring kernel).

@@ -406,6 +406,33 @@ def test_window_kernel_repeats_the_ring_kernel_bit_for_bit(ops, oracle, case):
         assert rel_l1(host(outs["window"][0]), want) <= REL_VOLUME
 
 
+@pytest.mark.parametrize("C,V", [(8, 5), (16, 4), (32, 3)])
+def test_window_kernel_gather_path_reads_the_channel_last_copy(ops, C, V):
+    """Hypothesis VOLUMES whose planes no window bounds (a noisy depth map: what a random-weight RED-Net hands stages 2 / 3): the
+    window kernel's patches gather their taps from global memory -- from the channel-last copy of the source maps packed into the
+    call's workspace (32 contiguous bytes per tap and 8-channel group instead of eight planes) -- and the volume is the ring
+    kernel's and the direct kernel's planar gather, bit for bit; variance and weighted correlation, planar and channel-last."""
+    h, w, D = 70, 132, 8
+    proj, dv = S.make_scene(V, h, w, 64, sweep_px=300.0, seed=C + V, yaw_deg=4.0)   # (no window of a 32 x 8 patch fits: every plane is gathered)
+    fd = [dev(f) for f in S.make_features(V, C, h, w, seed=C)]
+    p34 = ops.compose_projections(dev(proj))
+    rng = np.random.default_rng(C)
+    depth = dev(np.sort(rng.uniform(dv[0], dv[1], (D, h, w)).astype(np.float32), 0))   # every pixel anywhere in the range
+    vw = dev(rng.uniform(0.02, 1.0, (V - 1, h, w)))
+    outs = {}
+    for path_ in ("window", "tiled", "direct"):
+        config.switches["D3D_FORCE_PATH"] = path_
+        try:
+            outs[path_] = (ops.variance_volume(fd, p34, depth), ops.weighted_corr(fd, p34, vw, depth),
+                           ops.variance_volume_cl(fd, p34, depth, layout="cl8") if path_ != "direct" else None)
+        finally:
+            config.switches["D3D_FORCE_PATH"] = ""
+    for k in range(3):
+        assert torch.equal(outs["window"][k], outs["tiled"][k])
+    assert rel_l1(host(outs["window"][0]), host(outs["direct"][0])) <= 1e-6
+    assert int(ops._lib.load().d3d_sweep_workspace_bytes(V, C, D, h, w, 4)) >= (V - 1) * C * h * w * 4
+
+
 @pytest.mark.parametrize("path_", ["", "window", "tiled", "direct"])
 def test_variance_volume_plane_major_is_the_same_volume(ops, path_):
     """d3d_variance_volume_planes (out [D,C,h,w]: the slice loop of msrednet.py:400-437 reads plane d where it lies) holds the
