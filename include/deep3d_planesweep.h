@@ -104,7 +104,9 @@ const char* d3d_build_flags(void);
  * [C,h,w] elements of elem_bytes (4 = fp32, 2 = fp16) swept over D planes: room for a channel-last staging
  * copy of the source maps.  0 = the shape takes none.  The buffer is the caller's (device memory, 16-byte
  * aligned, private to the call until it completes on its stream); passing NULL / fewer bytes is valid and
- * selects a slower staging form (fp32) or the direct-gather kernel (fp16).
+ * selects a slower staging form (fp32) or the direct-gather kernel (fp16).  Sweeps of at most 48 planes (the window kernel) use it
+ * only when the hypotheses are a [D,h,w] VOLUME (D3D_DEPTH_PER_PIXEL): patches whose planes no window bounds then gather their
+ * taps from the channel-last copy instead of the planar maps (round 4, ABI 8); (lo, step) maps and per-plane depths leave it unused.
  * Replaces nothing in the reference: torch's caching allocator plays this role there.
  */
 size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes);
