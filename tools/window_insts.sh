@@ -2,6 +2,7 @@
 # GPU box: dynamic instruction counts per wave of the window kernel's phases -- -DD3D_EXPERIMENTS variants with the staging and / or
 # the sweep left out (results wrong), one rocprofv3 counter pass each over tools/stage_sweep_case.py <stage>:
 #   tools/window_insts.sh stage3 ["extra -D flags"]
+[ -n "$GRAFT_REPO_ROOT" ] || { echo "GRAFT_REPO_ROOT is not set"; exit 2; }
 cd "$GRAFT_REPO_ROOT" || exit 2
 STAGE=${1:-stage3}; EXTRA=$2
 CS=deep3d_aerial_amd/csrc
