@@ -1012,6 +1012,32 @@ def test_ucsnet_forward_matches_reference(ops, tag):
     assert out["variance"].shape == (1,) + g["variance"].shape
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_msrednet_slice_levels_on_streams_equal_one_stream(ops, monkeypatch, mode):
+    """The four conv-GRU levels of a RED-Net depth slice run on four HIP streams (msrednet.slice_RED_Regularization: they depend on
+    the encoder's maps only, the decoder joins them): the same kernels on the same operands -- the forward equals the one-stream
+    forward (to the order of the fp64 atomics of the GroupNorm statistics), twice in a row."""
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
+
+    g = load_golden("model_msrednet_v5")
+    net = _fill(Infer_CascadeREDNet(num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    ops.set_conv_precision(mode)
+    try:
+        outs = []
+        for off in (False, True, False):
+            set_kernel(monkeypatch, "red_streams", not off)
+            with torch.no_grad():
+                outs.append(net(dev(g["imgs"]), pm, dev(g["depth_values"])))
+            torch.cuda.synchronize()
+    finally:
+        ops.set_conv_precision(None)
+    for st in ("stage1", "stage2", "stage3"):
+        for key in ("depth", "photometric_confidence"):
+            a, b, c = (host(o[st][key]) for o in outs)
+            assert rel_l1(a, b) <= 1e-6 and rel_l1(a, c) <= 1e-6, (st, key)
+
+
 def test_ucsnet_affine_hypotheses_equal_the_volume_path(ops, monkeypatch):
     """Infer_UCSNet hands stages 2 and 3 the (low, step) maps of its uncertainty-aware hypotheses (ucsnet.AFFINE_DEPTH, ops.AffineDepth)
     instead of the [D,h,w] volume: the planes are the volume's bit for bit (the reference's + 1e-12 is the identity at these depths),
