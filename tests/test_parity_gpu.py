@@ -1038,6 +1038,27 @@ def test_msrednet_slice_levels_on_streams_equal_one_stream(ops, monkeypatch, mod
             assert rel_l1(a, b) <= 1e-6 and rel_l1(a, c) <= 1e-6, (st, key)
 
 
+@pytest.mark.parametrize("name", ["casmvsnet", "adamvs"])
+def test_feature_pyramids_on_streams_equal_one_stream(ops, monkeypatch, name):
+    """The feature pyramids of a view set go round-robin over three HIP streams (dataset._pyramids: the images are independent, the
+    caller's stream waits for the side streams before anything reads a pyramid): the forward is the one-stream forward, bit for bit."""
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+    from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+
+    g = load_golden("model_%s_v5" % name)
+    net = _fill({"casmvsnet": Infer_CascadeMVSNet, "adamvs": Infer_AdaMVSNet}[name](num_depth=int(g["num_depth"])), int(g["seed"]))
+    pm = {s: dev(g["proj_" + s]) for s in ("stage1", "stage2", "stage3")}
+    outs = []
+    for on in (True, False, True):
+        set_kernel(monkeypatch, "fpn_streams", on)
+        with torch.no_grad():
+            outs.append(net(dev(g["imgs"]), pm, dev(g["depth_values"])))
+        torch.cuda.synchronize()
+    for st in ("stage1", "stage2", "stage3"):
+        for key in ("depth", "photometric_confidence"):
+            assert torch.equal(outs[0][st][key], outs[1][st][key]) and torch.equal(outs[0][st][key], outs[2][st][key]), (st, key)
+
+
 def test_ucsnet_affine_hypotheses_equal_the_volume_path(ops, monkeypatch):
     """Infer_UCSNet hands stages 2 and 3 the (low, step) maps of its uncertainty-aware hypotheses (ucsnet.AFFINE_DEPTH, ops.AffineDepth)
     instead of the [D,h,w] volume: the planes are the volume's bit for bit (the reference's + 1e-12 is the identity at these depths),
