@@ -222,14 +222,13 @@ class InferDepthNet(nn.Module):
         p34 = ops.compose_projections(proj44)
         pair_results = []
         if conf_in is None:  # stage 1: per-pair visibility (adamvs.py:465-489)
-            vws = []
-            for i in range(1, len(feats)):
+            def one_pair(i):   # (the pairs are independent chains of small launches: three of them in flight, ops.on_streams)
                 corr = ops.pair_corr_mean(feats[0], feats[i], p34[i - 1], dv)
-                score = self.reg(corr)
-                vw, pd = ops.pair_softmax_max(score, dv)
-                vws.append(vw)
-                pair_results.append(pd)
-            weights = torch.stack(vws)
+                return ops.pair_softmax_max(self.reg(corr), dv)
+
+            res = ops.on_streams([(lambda i=i: one_pair(i)) for i in range(1, len(feats))], dev, "pair_streams")
+            pair_results = [pd for _, pd in res]
+            weights = torch.stack([vw for vw, _ in res])
         elif tuple(conf_in.shape[1:]) == (h, w):
             weights = conf_in
         else:  # adamvs.py:502, once per stage instead of once per plane

@@ -46,6 +46,7 @@ KERNELS = {
     "conv2d_k5": "5x5 stride-2 tile kernel of the feature trunks",
     "conv2d_wide": "bf16 tile kernel for 64 | 128 input channels (RED-Net's coarse conv-GRU levels; the generic fp32 matrix-core kernel instead)",
     "gru_fused": "one-launch conv-GRU cell of bf16 mode (three tile-kernel launches instead)",
+    "pair_streams": "the per-pair visibility passes of AdaMVS's first stage on three HIP streams (independent pairs; one stream instead)",
     "fpn_streams": "the feature pyramids of a view set on three HIP streams (the images are independent; one stream instead)",
     "red_streams": "the four conv-GRU levels of a RED-Net depth slice on four HIP streams (they depend on the encoder only; one stream instead)",
     "gn_fused": "GroupNorm statistics of ConvGRUCell2's convolutions accumulated in their epilogues (bf16 mode; d3d_groupnorm_stats over the stored tensor instead)",

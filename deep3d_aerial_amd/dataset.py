@@ -206,36 +206,13 @@ def _by_content(feature_net, x, cache):
     return pyr
 
 
-_fpn_side = {}   # device index -> two side streams
-
-
 def _pyramids(feature_net, xs):
     """feature_net(x) for every [B,3,H,W] tensor of xs.  On the GPU the images go round-robin over the caller's stream and two side
-    streams (the pyramids are independent; the half- and quarter-resolution layers of one image leave most of the chip idle) and
-    the caller's stream waits for the side streams before anything reads a pyramid.  Same kernels, same operands."""
-    from . import config as _cfg
+    streams (ops.on_streams: the pyramids are independent; the half- and quarter-resolution layers of one image leave most of the
+    chip idle) and the caller's stream waits for the side streams before anything reads a pyramid.  Same kernels, same operands."""
+    from . import ops
 
-    if len(xs) < 2 or not xs[0].is_cuda or _cfg.off("fpn_streams"):
-        return [feature_net(x) for x in xs]
-    dev = xs[0].device
-    main = torch.cuda.current_stream(dev)
-    side = _fpn_side.get(dev.index)
-    if side is None:
-        side = _fpn_side[dev.index] = [torch.cuda.Stream(dev) for _ in range(2)]
-    fork = main.record_event()
-    outs, joins = [], []
-    for v, x in enumerate(xs):
-        st = (None, side[0], side[1])[v % 3]
-        if st is None:
-            outs.append(feature_net(x))
-            continue
-        with torch.cuda.stream(st):
-            st.wait_event(fork)
-            outs.append(feature_net(x))
-            joins.append(st.record_event())
-    for e in joins:
-        main.wait_event(e)
-    return outs
+    return ops.on_streams([(lambda x=x: feature_net(x)) for x in xs], xs[0].device, "fpn_streams")
 
 
 def extract_features(feature_net, imgs, image_keys=None, cache=None):

@@ -82,6 +82,7 @@ def folded_bn(bn):
         with torch.no_grad():
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
             shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        ops.publish_prepared(scale)   # (read from every stream the forwards use)
         cache = (key, scale, shift)
         bn._d3d_fold = cache
     return cache[1], cache[2]

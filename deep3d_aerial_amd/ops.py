@@ -1516,6 +1516,43 @@ def gru_update_gn(o, u, h, gamma, beta, eps=1e-5, stats=None):
 _derived_cache = {}
 
 
+_side_streams = {}
+
+
+def on_streams(thunks, device, switch):
+    """[f() for f in thunks] with the INDEPENDENT pieces of work going round-robin over the caller's stream and two side streams
+    (fork event before, one join event per side piece after): chains of small launches that leave most of the chip idle overlap.
+    Same kernels, same operands; `switch` (a key of config.KERNELS) in D3D_KERNELS_OFF keeps everything on the caller's stream."""
+    if len(thunks) < 2 or device.type != "cuda" or _cfg.off(switch):
+        return [f() for f in thunks]
+    main = torch.cuda.current_stream(device)
+    side = _side_streams.get(device.index)
+    if side is None:
+        side = _side_streams[device.index] = [torch.cuda.Stream(device) for _ in range(2)]
+    fork = main.record_event()
+    outs, joins = [], []
+    for i, f in enumerate(thunks):
+        st = (None, side[0], side[1])[i % 3]
+        if st is None:
+            outs.append(f())
+            continue
+        with torch.cuda.stream(st):
+            st.wait_event(fork)
+            outs.append(f())
+            joins.append(st.record_event())
+    for e in joins:
+        main.wait_event(e)
+    return outs
+
+
+def publish_prepared(weight):
+    """A freshly prepared (packed / folded) operand goes into a cache that EVERY stream reads: the forwards run some layers on
+    side streams (feature pyramids, RED-Net's conv-GRU levels), so the stream that prepared it waits for the preparation once --
+    a cache miss happens at the first forward after a weight changes -- and whoever finds the entry later finds finished data."""
+    if isinstance(weight, torch.Tensor) and weight.is_cuda:
+        torch.cuda.current_stream(weight.device).synchronize()
+
+
 def derived_weight(weight, tag, fn):
     """A tensor computed from a parameter (negated / flipped / re-laid-out weights), cached per parameter
     version like the packed GEMM operands; host-side weight preparation, not data-path arithmetic."""
@@ -1526,6 +1563,7 @@ def derived_weight(weight, tag, fn):
     with torch.no_grad():
         out = fn(weight.detach())
         out = tuple(t.contiguous() for t in out) if isinstance(out, tuple) else out.contiguous()
+    publish_prepared(weight)
     if len(_derived_cache) > 4096:
         _derived_cache.clear()
     _derived_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), out)
@@ -1635,6 +1673,7 @@ def _packed(weight, transposed):
                         pad = torch.zeros((wp.shape[0], _mpad(Co)), dtype=torch.float32, device=w.device)
                         pad[:, :Co] = wp
                         out.append(((pz, py, px), pad.contiguous(), _np.array(taps, _np.int8).tobytes(), len(taps)))
+    publish_prepared(weight)
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
     _pack_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), out)
@@ -1821,6 +1860,7 @@ def _packed_fold(weight, transposed, stride):
                     for p2 in sets[2]:
                         dims = tuple(_dim_convT(ks0[d], pp) for d, pp in enumerate((p0, p1, p2)))
                         launches.append(_fold_pack(wk, dims, Co, ks))
+    publish_prepared(weight)
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
     _pack_cache[key] = (_weakref.ref(weight), (weight.data_ptr(), weight._version), launches)
