@@ -33,20 +33,26 @@ class slice_RED_Regularization(nn.Module):
         self.upconv1 = ConvTransReLU(b * 2, b, 3, 2, 1, 1)
         self.upconv2d = nn.ConvTranspose2d(b, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
 
-    _side = {}   # device index -> three side streams (the conv-GRU levels 2-4 of a slice)
+    _side = {}   # device index -> three side streams (conv-GRU levels 2, 3 and 1 of a slice)
 
     def forward(self, cost, state1, state2, state3, state4):
         w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
-        c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)             # conv1(-cost)
         if cost.is_cuda and not _cfg.off("red_streams"):
             # The four recurrent cells of a slice depend on the encoder's maps only (msrednet.py:352-367), and at the first two
-            # stages their kernels are tens of workgroups each: levels 2-4 run on side streams beside level 1, the decoder joins
-            # them.  Same kernels on the same operands; every tensor that crosses streams is ordered by an event, and a block
-            # freed on a side stream is reused there only behind the next slice's fork, i.e. behind this slice's decoder.
+            # stages their kernels are tens of workgroups each: level 1 starts on a side stream beside the encoder, levels 2 / 3
+            # on two more as soon as their encoder map exists, level 4 follows the encoder on the caller's stream; the decoder
+            # joins them.  Same kernels on the same operands; every tensor that crosses streams is ordered by an event, and a
+            # block freed on a side stream is reused there only behind the next slice's fork, i.e. behind this slice's decoder.
             main = torch.cuda.current_stream(cost.device)
             side = self._side.get(cost.device.index)
             if side is None:
                 side = self._side[cost.device.index] = [torch.cuda.Stream(cost.device) for _ in range(3)]
+            e0 = main.record_event()                                                  # (the cost slice and the states exist)
+            with torch.cuda.stream(side[2]):                                          # level 1 -- the largest -- beside the encoder
+                side[2].wait_event(e0)
+                state1, _ = self.conv_gru1(cost, state1, negate_x=True)               # conv_gru1(-cost)
+                d1 = side[2].record_event()
+            c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)           # conv1(-cost)
             e1 = main.record_event()
             with torch.cuda.stream(side[0]):
                 side[0].wait_event(e1)
@@ -59,21 +65,17 @@ class slice_RED_Regularization(nn.Module):
                 state3, _ = self.conv_gru3(c2, state3)
                 d3 = side[1].record_event()
             c3 = self.conv3(c2)
-            e3 = main.record_event()
-            with torch.cuda.stream(side[2]):
-                side[2].wait_event(e3)
-                state4, _ = self.conv_gru4(c3, state4)
-                d4 = side[2].record_event()
-            state1, _ = self.conv_gru1(cost, state1, negate_x=True)                   # conv_gru1(-cost)
-            main.wait_event(d4)
+            state4, _ = self.conv_gru4(c3, state4)
             main.wait_event(d3)
             up33 = self.upconv3(state4, skip=state3)                                  # relu(convT) + reg_cost3
             main.wait_event(d2)
             up22 = self.upconv2(up33, skip=state2)
+            main.wait_event(d1)
             up11 = self.upconv1(up22, skip=state1)
             wc = ops.derived_weight(self.upconv2d.weight, "flipT", lambda w: w.flip(2, 3).transpose(0, 1))
             reg = ops.conv2d_k3(up11, wc, None, self.upconv2d.bias, None, act=0)
             return reg, state1, state2, state3, state4
+        c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)             # conv1(-cost)
         c2 = self.conv2(c1)
         c3 = self.conv3(c2)
         state4, _ = self.conv_gru4(c3, state4)
