@@ -224,7 +224,7 @@ def secondary_models(reps=5, warm=2):
 
     res = {}
     old = ops.conv_precision()
-    ops.set_conv_precision("bf16")
+    ops.set_conv_precision("h16")
     try:
         for name in ("casmvsnet", "adamvs", "msrednet"):
             net = predict.build_model(name, 384)
@@ -314,7 +314,7 @@ def regulariser_leg(reps=5):
     for C, D, h, w in ((32, 48, 464, 688), (16, 32, 928, 1376), (8, 8, 1856, 2752)):
         net = CostRegNet(C).cuda().eval()
         S.fill_state_dict_(net.state_dict(), 3)
-        vol = ops.cl_to_cl8(torch.randn(D, h, w, C, device="cuda").to(torch.bfloat16))   # [D,C/8,h,w,8]: as the sweep kernels write it
+        vol = ops.cl_to_cl8(torch.randn(D, h, w, C, device="cuda").to(ops.h16_dtype()))   # [D,C/8,h,w,8]: as the sweep kernels write it
         with torch.no_grad():
             net.forward_one(vol)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

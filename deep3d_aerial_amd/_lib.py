@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("D3D_LIBRARY") or os.path.join(CSRC, "libdeep3d_planesweep.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -31,6 +31,7 @@ SIGNATURES = {
     "d3d_debug_force_path": [_i],
     "d3d_debug_dispatch_counts": [_vp, _i],
     "d3d_build_flags": [],
+    "d3d_h16_format": [],
     "d3d_compose_projections_f64": [_vp, _i, _vp, _vp],
     "d3d_homo_warp_f64coord": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],  # returns size_t
@@ -38,8 +39,8 @@ SIGNATURES = {
     "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_planes": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_f16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
-    "d3d_variance_volume_cl_bf16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
-    "d3d_variance_volume_cl8_bf16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_variance_volume_cl_h16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
+    "d3d_variance_volume_cl8_h16": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_pair_corr_mean": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_weighted_corr": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_softargmin_conf4": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
@@ -49,41 +50,41 @@ SIGNATURES = {
     "d3d_resize_bilinear": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3_co8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv3d_k3_c8_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv3d_k3_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv3d_k3_c8_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv3d_k3_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv3d_k3_c1_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_convtranspose3d_k3s2_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_convtranspose3d_k3s2_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv2d_k3_zs_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3_zs_h16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3_zs_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3_zs_bf16x3": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_avgpool2d_4_8": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "d3d_conv3x3_bias_border": [_vp, _vp, _i, _i, _i, _vp],
     "d3d_conv1x1_context": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv2d_k3s2_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv2d_k3_wide_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
-    "d3d_slice_head_regress_bf16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "d3d_gru_cell_fused_bf16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "d3d_convtranspose2d_k3s2_zs_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3s2_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3_wide_h16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "d3d_slice_head_regress_h16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "d3d_gru_cell_fused_h16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "d3d_convtranspose2d_k3s2_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k4s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k5s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2_zs_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv3d_k3_cl_bf16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
-    "d3d_conv3d_k3_c1_cl_bf16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_conv3d_k3s2_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_convtranspose3d_k3s2_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
-    "d3d_conv2d_k3_zs_bf16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
-    "d3d_conv2d_k3_wide_bf16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "d3d_conv3d_k3_cl_h16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "d3d_conv3d_k3_c1_cl_h16": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv3d_k3s2_cl_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_convtranspose3d_k3s2_cl_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "d3d_conv2d_k3_zs_h16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "d3d_conv2d_k3_wide_h16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "d3d_conv2d_k3_pair3_bf16x3": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
-    "d3d_slice_tail_regress_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "d3d_slice_tail_regress_h16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_conv3d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "d3d_convtranspose3d_prob_cl_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "d3d_volume_planar_to_cl_bf16": [_vp, _i, _sz, _vp, _vp],
-    "d3d_volume_cl_bf16_to_planar": [_vp, _i, _sz, _vp, _vp],
+    "d3d_convtranspose3d_prob_cl_h16": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "d3d_volume_planar_to_cl_h16": [_vp, _i, _sz, _vp, _vp],
+    "d3d_volume_cl_h16_to_planar": [_vp, _i, _sz, _vp, _vp],
     "d3d_convtranspose3d_k3s2_co8": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_k3s2": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv1x1_upskip": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -94,7 +95,7 @@ SIGNATURES = {
                           _i, _i, _i, _i, _i, ctypes.c_char_p, _vp, _vp],
     "d3d_conv_fold_f32": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                           ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
-    "d3d_conv_fold_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+    "d3d_conv_fold_h16": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                            ctypes.POINTER(ctypes.c_int), _i, ctypes.c_char_p, _vp, _vp],
     "d3d_gru_gates": [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     "d3d_gru_update": [_vp, _vp, _vp, _i64, _vp, _vp],
@@ -152,7 +153,7 @@ def load():
         except AttributeError as e:
             raise LibraryMissing("symbol %s missing from %s" % (name, SO_PATH)) from e
         fn.argtypes = argtypes
-        fn.restype = (ctypes.c_char_p if name in ("d3d_last_error", "d3d_build_flags") else
+        fn.restype = (ctypes.c_char_p if name in ("d3d_last_error", "d3d_build_flags", "d3d_h16_format") else
                       ctypes.c_size_t if name in ("d3d_sweep_workspace_bytes", "d3d_fusion_points_scratch_bytes") else ctypes.c_int)
     if lib.d3d_version() != ABI_VERSION:
         raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))
@@ -161,6 +162,11 @@ def load():
 
 
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP = -1, -2, -3
+
+
+def h16_format():
+    """"f16" | "bf16": the 16-bit operand format the loaded library was built with (d3d_h16_format, ABI 9)."""
+    return load().d3d_h16_format().decode("ascii")
 
 
 def check(rc, what):

@@ -56,10 +56,10 @@ class CostRegNet(nn.Module):
     @staticmethod
     def channel_last():
         """bf16 mode with channel-last bf16 activations between the layers (ops.conv3d_k3_cl)."""
-        return ops.conv_precision() == "bf16" and ops.channel_last_enabled()
+        return ops.conv_precision() == "h16" and ops.channel_last_enabled()
 
     def forward_one(self, x):  # [C,D,H,W] fp32 (or channel-last bf16 [D,H,W,C] in bf16 mode) -> [D,H,W]
-        cl_in = x.dtype == torch.bfloat16   # [D,H,W,C], or the sweep kernels' CL8 form [D,C/8,H,W,8]
+        cl_in = x.dtype == ops.h16_dtype()   # [D,H,W,C], or the sweep kernels' CL8 form [D,C/8,H,W,8]
         D, H, W = ((x.shape[0], x.shape[2], x.shape[3]) if x.dim() == 5 else x.shape[:3]) if cl_in else x.shape[1:]
         if D % 8 or H % 8 or W % 8:
             raise ValueError("CostRegNet needs D,H,W divisible by 8 (got %s)" % ((D, H, W),))

@@ -20,7 +20,7 @@ import threading
 SWITCHES = {
     "D3D_FORCE_PATH": ("", "sweep kernels: 'direct' | 'tiled' | 'window' forces one kernel family (tests, profiling); '' = dispatcher"),
     "D3D_CONV": ("mfma", "3-D / 2-D convolutions: 'mfma' (matrix cores) | 'mfma_slice' | 'direct' (vector-unit cross-check)"),
-    "D3D_CONV_PRECISION": ("fp32", "default operand precision of the regularisers: 'fp32' | 'bf16' (ops.set_conv_precision overrides)"),
+    "D3D_CONV_PRECISION": ("fp32", "default operand precision of the regularisers: 'fp32' | 'h16' (16-bit operands in the library's format; ops.set_conv_precision overrides)"),
     "D3D_CONV_C8X3": ("1", "fp32 mode of conv0 / conv2 / conv11 on the split-operand (3 x bf16) matrix-core kernels: '1' | '0' off | 'all' also the probability layer (slower there)"),
     "D3D_CONV2D_FP32": ("x3", "fp32 mode of the 2-D tile kernels: 'x3' (three-way bf16 split) | 'f32' (fp32 MFMA)"),
     "D3D_FEATURE_PRECISION": ("fp32", "feature pyramids: 'fp32' | 'follow' (the regularisers' precision)"),
@@ -105,7 +105,7 @@ def override(**values):
 
 
 class _State(threading.local):
-    conv_precision = None    # None: follow the D3D_CONV_PRECISION switch | "fp32" | "bf16"
+    conv_precision = None    # None: follow the D3D_CONV_PRECISION switch | "fp32" | "h16"
     tile_kernels = False     # inside a slice regulariser's plane loop (ops.slice_tile_kernels)
 
 

@@ -41,6 +41,55 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
 }
 
+// ---------------------------------------------------------------------------------------
+// "h16": the 16-bit operand format of the fast mode (BASELINE config 3) -- one format for the whole library, fixed at build
+// time and reported by d3d_h16_format().  IEEE half ("f16", 11 significand bits) by default; -DD3D_H16_BF16 builds the
+// bfloat16 form (8 bits) rounds 2-4 shipped.  Why: on the arg-max-sensitive model fixtures EVERY rounding site of a regulariser
+// (input volume, each layer's weights, each stored activation: 23 sites in a CostRegNet) carries 0.1 - 0.7 stage-3 depth
+// intervals of error on its own in bf16 and they add in quadrature to 0.9 - 1.4 -- against the 0.25 the parity bar allows; no
+// subset of sites kept in fp32 helps (profiles/r05_bf16_ablation.txt).  Half has the same bytes, the same matrix-core rate
+// (v_mfma_f32_16x16x32_f16), single-instruction conversions both ways (v_cvt_pk_f16_f32, v_cvt_f32_f16) and an eighth of the
+// rounding error.  Its range (6e-8 .. 65504) covers BN-normalised activations and weights; the one operand whose magnitude the
+// data decides, the variance volume, saturates instead of overflowing (sweep_device.h).  The split-operand kernels (fp32 mode,
+// "bf16x3") keep their three bf16 pieces: 24 significand bits need bf16's exponent range in the low pieces.
+// ---------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifdef D3D_H16_BF16
+#define D3D_H16_FORMAT "bf16"
+typedef __bf16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_h16x2(float a, float b) { return pack_bf16x2(a, b); }
+__device__ __forceinline__ float h16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float h16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ f32x4_t mfma_h16(h16x8 a, h16x8 b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+typedef __bf16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma_h16_k16(h16x4 a, h16x4 b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+#else
+#define D3D_H16_FORMAT "f16"
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_h16x2(float a, float b) {   // one v_cvt_pk_f16_f32 (RNE)
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, f16x2_t));
+}
+__device__ __forceinline__ float h16_lo(unsigned u) {   // v_cvt_f32_f16
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(f16x2_t, u)[0];
+}
+__device__ __forceinline__ float h16_hi(unsigned u) {   // v_cvt_f32_f16 ... src0_sel:WORD_1
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(f16x2_t, u)[1];
+}
+__device__ __forceinline__ f32x4_t mfma_h16(h16x8 a, h16x8 b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma_h16_k16(h16x4 a, h16x4 b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+#endif
+__device__ __forceinline__ h16x4 cvt_h16x4(float a, float b, float c, float d) {   // two packed conversions
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(h16x4, (u32x2_t){pack_h16x2(a, b), pack_h16x2(c, d)});
+}
+// one value rounded to the format and back (what a kernel that keeps fp32 values "as the matrix cores see them" applies)
+__device__ __forceinline__ float round_h16(float v) { return h16_lo(pack_h16x2(v, 0.0f)); }
+
 // sigmoid and tanh of the conv-GRU epilogues (adamvs.py:60-72 / module.py ConvGRUCell: torch.sigmoid, torch.tanh): one v_exp_f32
 // and one v_rcp_f32 each, ~2e-7 of the exact value (relative for the sigmoid, absolute for the tanh) -- far inside what the
 // state's own fp32 rounding moves.  The IEEE division and tanhf they replace expand to ~12 and ~35 instructions per value, a

@@ -27,7 +27,6 @@ namespace d3d {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int WW = 8;                 // waves = output rows of a tile
@@ -51,8 +50,8 @@ struct WideParams {
     int gn_split;
 };
 
-__device__ __forceinline__ unsigned pack_bf16_w(float a, float b) {
-    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+__device__ __forceinline__ unsigned pack_h16_w(float a, float b) {
+    return pack_h16x2(a, b);   // one packed conversion (common.h: pack_h16x2)
 }
 
 template <int NW, bool GN = false>
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) x[k] = pok[r] ? stg[r][k] : 0.0f;
                 *reinterpret_cast<u4*>(patch + pdst[r]) =
-                    (u4){pack_bf16_w(x[0], x[1]), pack_bf16_w(x[2], x[3]), pack_bf16_w(x[4], x[5]), pack_bf16_w(x[6], x[7])};
+                    (u4){pack_h16_w(x[0], x[1]), pack_h16_w(x[2], x[3]), pack_h16_w(x[4], x[5]), pack_h16_w(x[6], x[7])};
             }
         }
     };
@@ -133,14 +132,14 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int aoff = ((t / 3) * WPX + (t % 3)) * WCS;
-            bf16x8 b[NW];
+            h16x8 b[NW];
 #pragma unroll
-            for (int nt = 0; nt < NW; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(t * NW + nt) * 64 + lane]);
+            for (int nt = 0; nt < NW; ++nt) b[nt] = __builtin_bit_cast(h16x8, wlds[(t * NW + nt) * 64 + lane]);
 #pragma unroll
             for (int mg = 0; mg < 4; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(patch + abase + mg * 16 * WCS + aoff));
+                const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(patch + abase + mg * 16 * WCS + aoff));
 #pragma unroll
-                for (int nt = 0; nt < NW; ++nt) acc[mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg][nt], 0, 0, 0);
+                for (int nt = 0; nt < NW; ++nt) acc[mg][nt] = mfma_h16(a, b[nt], acc[mg][nt]);
             }
         }
         __syncthreads();   // every wave has read the patch and the weights of this chunk
@@ -216,7 +215,7 @@ static int conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2
     const int Ci = C1 + C2;
     if ((Ci != 64 && Ci != 128) || C1 % 32 || C2 % 32 || (Co != 32 && Co != 64 && Co != 128) ||
         ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(skip)) & 15)) {
-        set_error("d3d_conv2d_k3_wide_bf16: C_in = %d + %d (64 | 128 in parts of 32), C_out = %d (32 | 64 | 128) with 16-byte aligned tensors not taken",
+        set_error("d3d_conv2d_k3_wide_h16: C_in = %d + %d (64 | 128 in parts of 32), C_out = %d (32 | 64 | 128) with 16-byte aligned tensors not taken",
                   C1, C2, Co);
         return D3D_ERR_UNSUPPORTED;
     }
@@ -234,13 +233,13 @@ static int conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2
 
 // out [Co,H,W] = act(conv3x3(cat(in, in2)) * scale + shift) (+ skip, added last); bf16 matrix-core operands, fp32 accumulation.
 // C1, C2 multiples of 32 with C1 + C2 = 64 | 128; Co = 32 | 64 | 128; wpacked = ops._pack_z2_bf16(weight).
-extern "C" int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+extern "C" int d3d_conv2d_k3_wide_h16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                                        const float* shift, const float* skip, int act, int Co, int H, int W, float* out,
                                        d3d_stream_t stream) {
     return conv2d_k3_wide_bf16(in, C1, in2, C2, wpacked, scale, shift, skip, act, Co, H, W, out, nullptr, 0, stream);
 }
-// The same layer (act 0, no skip) + the GroupNorm(1, C) statistics of its output (see d3d_conv2d_k3_zs_bf16_gn).
-extern "C" int d3d_conv2d_k3_wide_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift,
+// The same layer (act 0, no skip) + the GroupNorm(1, C) statistics of its output (see d3d_conv2d_k3_zs_h16_gn).
+extern "C" int d3d_conv2d_k3_wide_h16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift,
                                           int Co, int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream) {
     D3D_REQUIRE(gn_stats && gn_split > 0 && gn_split <= Co, "bad statistics arguments");
     return conv2d_k3_wide_bf16(in, C1, in2, C2, wpacked, nullptr, shift, nullptr, 0, Co, H, W, out, gn_stats, gn_split, stream);

@@ -60,8 +60,11 @@ struct Z2Params {
     int gn_split;
 };
 
-__device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {
+__device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {   // the split (fp32-mode) operands: three bf16 pieces
     return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+}
+__device__ __forceinline__ unsigned pack_h16_z2(float a, float b) {    // the single 16-bit operand (common.h)
+    return pack_h16x2(a, b);
 }
 // Global memory through buffer instructions: a raw buffer from `origin` on (which may lie before the tensor) + a 32-bit per-lane
 // byte offset + a scalar offset.  A lane whose pixels are outside the image carries OOBZ: the load returns zeros, the store is
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(NTZ, GN && CI == 40 ? 4 : 2) void conv2d_zs_bf16_ke
             *reinterpret_cast<u2*>(cell + CI * 2 + c4 * 8) = (u2){m0, m1};
             *reinterpret_cast<u2*>(cell + CI * 4 + c4 * 8) = (u2){l0, l1};
         } else {
-            *reinterpret_cast<u2*>(cell + c4 * 8) = (u2){pack_bf16_z2(v0, v1), pack_bf16_z2(v2, v3)};
+            *reinterpret_cast<u2*>(cell + c4 * 8) = (u2){pack_h16_z2(v0, v1), pack_h16_z2(v2, v3)};
         }
     };
     auto commit = [&](unsigned char* dst) {
@@ -356,15 +359,15 @@ __global__ __launch_bounds__(NTZ, GN && CI == 40 ? 4 : 2) void conv2d_zs_bf16_ke
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const unsigned char* ap = buf + aoffs[kb];
-            bf16x8 b[NTN];
+            h16x8 b[NTN];
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(kb * NTN + nt) * 64 + lane]);
+            for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(h16x8, wlds[(kb * NTN + nt) * 64 + lane]);
 #pragma unroll
             for (int mg = 0; mg < MGN; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS));
+                const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt)
-                    acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+                    acc[mg * NTN + nt] = mfma_h16(a, b[nt], acc[mg * NTN + nt]);
             }
         }
         // ---- epilogue ------------------------------------------------------------------------------------------------------
@@ -664,8 +667,8 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
                 } else if constexpr (X3) {
                     put8_split3(cell, CI, stg[r]);
                 } else {
-                    const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
-                                  pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                    const u4 v = {pack_h16_z2(stg[r][0], stg[r][1]), pack_h16_z2(stg[r][2], stg[r][3]),
+                                  pack_h16_z2(stg[r][4], stg[r][5]), pack_h16_z2(stg[r][6], stg[r][7])};
                     *reinterpret_cast<u4*>(cell) = v;
                 }
             }
@@ -745,15 +748,15 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             const unsigned char* ap = buf + aoffs[F32 ? 0 : kb];
-            bf16x8 b[NTN];
+            h16x8 b[NTN];
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wlds[(kb * NTN + nt) * 64 + lane]);
+            for (int nt = 0; nt < NTN; ++nt) b[nt] = __builtin_bit_cast(h16x8, wlds[(kb * NTN + nt) * 64 + lane]);
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS));
+                const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(ap + mg * 16 * CS));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt)
-                    acc[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[mg * NTN + nt], 0, 0, 0);
+                    acc[mg * NTN + nt] = mfma_h16(a, b[nt], acc[mg * NTN + nt]);
             }
         }
         const int oy = ty * TYZ + wave;
@@ -890,8 +893,8 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
                 } else if constexpr (X3) {
                     put8_split3(cell, CI, stg[r]);
                 } else {
-                    const u4 v = {pack_bf16_z2(stg[r][0], stg[r][1]), pack_bf16_z2(stg[r][2], stg[r][3]),
-                                  pack_bf16_z2(stg[r][4], stg[r][5]), pack_bf16_z2(stg[r][6], stg[r][7])};
+                    const u4 v = {pack_h16_z2(stg[r][0], stg[r][1]), pack_h16_z2(stg[r][2], stg[r][3]),
+                                  pack_h16_z2(stg[r][4], stg[r][5]), pack_h16_z2(stg[r][6], stg[r][7])};
                     *reinterpret_cast<u4*>(cell) = v;
                 }
             }
@@ -1001,11 +1004,11 @@ __global__ __launch_bounds__(NTZ, 2) void convt2d_zs_bf16_kernel(Z2Params p) {
                     }
                     continue;
                 }
-                const bf16x8 bw = __builtin_bit_cast(bf16x8, wlds[(FB + kb) * 64 + lane]);
+                const h16x8 bw = __builtin_bit_cast(h16x8, wlds[(FB + kb) * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
-                    acc[px][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[px][mg], 0, 0, 0);
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
+                    acc[px][mg] = mfma_h16(a, bw, acc[px][mg]);
                 }
             }
         }
@@ -1205,7 +1208,7 @@ extern "C" int d3d_conv2d_k3s2_zs_bf16x3(const float* in, const void* wpacked, c
     return conv2d_k3s2_zs(PREC_X3, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
-extern "C" int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_conv2d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                        const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                        d3d_stream_t stream) {
     return conv2d_k3s2_zs(PREC_BF16, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
@@ -1284,7 +1287,7 @@ extern "C" int d3d_convtranspose2d_k3s2_zs_bf16x3(const float* in, const void* w
     return convtranspose2d_k3s2_zs(PREC_X3, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
-extern "C" int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_convtranspose2d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                                 const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W,
                                                 float* out, d3d_stream_t stream) {
     return convtranspose2d_k3s2_zs(PREC_BF16, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
@@ -1304,7 +1307,7 @@ static int convtranspose2d_k3s2_zs(int prec, const float* in, const void* wpacke
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
     D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
     if ((Ci != 8 && Ci != 16 && Ci != 32) || Co > 16 || W % 4 != 0) {
-        set_error("d3d_convtranspose2d_k3s2_zs_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16), W = %d (multiple of 4) not taken", Ci, Co, W);
+        set_error("d3d_convtranspose2d_k3s2_zs_h16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16), W = %d (multiple of 4) not taken", Ci, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
     Z2Params p = {};
@@ -1320,7 +1323,7 @@ static int convtranspose2d_k3s2_zs(int prec, const float* in, const void* wpacke
 static int conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                             const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                             int skip_after_act, int Co, int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
-extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+extern "C" int d3d_conv2d_k3_zs_h16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                                      const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                                      int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream) {
     return conv2d_k3_zs_bf16(in, C1, in2, C2, wpacked, scale, shift, skip, aux1, act, ep_split, skip_after_act, Co, H, W, out, nullptr, 0, stream);
@@ -1328,7 +1331,7 @@ extern "C" int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, 
 // The same layer (act 0, no skip) + the GroupNorm(1, C) statistics of its output for the normalisation that follows (module.py:62-67,
 // 71-99 ConvGRUCell2): gn_stats [ngroups][2] fp64 (sum, sum of squares), ZEROED by the caller; channels >= gn_split form the second
 // group (gn_split = Co: one group).  What d3d_groupnorm_stats computes from the stored tensor, without the pass over it.
-extern "C" int d3d_conv2d_k3_zs_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co,
+extern "C" int d3d_conv2d_k3_zs_h16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co,
                                         int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream) {
     D3D_REQUIRE(gn_stats && gn_split > 0 && gn_split <= Co, "bad statistics arguments");
     return conv2d_k3_zs_bf16(in, C1, in2, C2, wpacked, nullptr, shift, nullptr, nullptr, 0, 0, 0, Co, H, W, out, gn_stats, gn_split, stream);
@@ -1349,7 +1352,7 @@ static int conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, 
     const bool shape = (((Ci == 8 || Ci == 16 || Ci == 32) && Co <= 32) || (Ci == 48 && Co <= 48) || ((Ci == 24 || Ci == 40) && Co <= 16)) &&
                        C1 % 8 == 0 && C2 % 8 == 0 && W % 4 == 0;
     if (!shape) {
-        set_error("d3d_conv2d_k3_zs_bf16: C_in = %d + %d (8 | 16 | 32 | 48 in groups of 8; 24 | 40 with C_out <= 16), C_out = %d (<= 32; <= 48 with C_in = 48), "
+        set_error("d3d_conv2d_k3_zs_h16: C_in = %d + %d (8 | 16 | 32 | 48 in groups of 8; 24 | 40 with C_out <= 16), C_out = %d (<= 32; <= 48 with C_in = 48), "
                   "W = %d (multiple of 4) not taken", C1, C2, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
@@ -1364,7 +1367,7 @@ static int conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, 
         if (Ci == 24 && Co <= 16) return launch_z2<24, 1, 4, false, false, false, true>(p, st);
         if (Ci == 32) return Co > 16 ? launch_z2<32, 2, 2, false, false, false, true>(p, st) : launch_z2<32, 1, 2, false, false, false, true>(p, st);
         if (Ci == 16) return Co > 16 ? launch_z2<16, 2, 4, false, false, false, true>(p, st) : launch_z2<16, 1, 4, false, false, false, true>(p, st);
-        set_error("d3d_conv2d_k3_zs_bf16_gn: C_in = %d, C_out = %d not taken", Ci, Co);
+        set_error("d3d_conv2d_k3_zs_h16_gn: C_in = %d, C_out = %d not taken", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }
     if (Ci == 48) return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);

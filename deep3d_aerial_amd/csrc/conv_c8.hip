@@ -49,15 +49,18 @@ struct C8Params {
     int in_cl8;           // CL input in planes of 8-channel groups [D, CI/8, H, W, 8] (the sweep kernels' CL8 volume) instead of [D, H, W, CI]
 };
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // the split (fp32-mode) operands: three bf16 pieces
     return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+}
+__device__ __forceinline__ unsigned pack_h16(float a, float b) {    // the single 16-bit operand / stored activation (common.h)
+    return pack_h16x2(a, b);
 }
 
 // waves per SIMD the register budget is sized for: two workgroups per CU (the second one's loads and stores fly while the
 // first one sweeps) where the staging registers allow it
-__device__ __forceinline__ f4 unpack_bf16x4(uint2 u) {
-    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+__device__ __forceinline__ f4 unpack_h16x4(uint2 u) {
+    return (f4){h16_lo(u.x), h16_hi(u.x),
+                h16_lo(u.y), h16_hi(u.y)};
 }
 
 // NTN: 16-channel output tiles (1: C_out <= 16, 2: C_out = 32, 4: C_out = 64); INCL / OUTCL: channel-last bf16 input / output;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                     *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
                     continue;
                 }
-                *reinterpret_cast<u4*>(cell) = (u4){pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7])};
+                *reinterpret_cast<u4*>(cell) = (u4){pack_h16(x[0], x[1]), pack_h16(x[2], x[3]), pack_h16(x[4], x[5]), pack_h16(x[6], x[7])};
             }
         }
     };
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                     const size_t o = ob + c8s.oo[mg];
                     f4 v = a[mg] * c8s.sc + c8s.sh;
                     if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                    if (p.skip && c8s.live) v += unpack_bf16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
-                    const unsigned px = pack_bf16(v[0], v[1]), py = pack_bf16(v[2], v[3]);
+                    if (p.skip && c8s.live) v += unpack_h16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                    const unsigned px = pack_h16(v[0], v[1]), py = pack_h16(v[2], v[3]);
                     const auto qx = __builtin_amdgcn_permlane16_swap(px, px, false, false);
                     const auto qy = __builtin_amdgcn_permlane16_swap(py, py, false, false);
                     if (c8s.st[mg]) {
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                                 const size_t o = (((size_t)zo * H + oy) * W + ox) * p.CO + cb;   // bf16 element index
                                 f4 v = a[mg * NTN + nt] * sc + sh;
                                 if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                                if (p.skip) v += unpack_bf16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
-                                const uint2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                                if (p.skip) v += unpack_h16x4(*reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(p.skip) + o));
+                                const uint2 pk = {pack_h16(v[0], v[1]), pack_h16(v[2], v[3])};
                                 *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.out) + o) = pk;
                             }
                         }
@@ -387,11 +390,11 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                 return;
             }
             if constexpr (KZF) {
-                const bf16x8 bw = __builtin_bit_cast(bf16x8, wsrc[kb * 64 + lane]);
+                const h16x8 bw = __builtin_bit_cast(h16x8, wsrc[kb * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MGN; ++mg) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
-                    up[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, up[mg], 0, 0, 0);
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                    up[mg] = mfma_h16(a, bw, up[mg]);
                 }
                 return;
             }
@@ -425,27 +428,27 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
                 }
                 return;
             }
-            bf16x8 b0[NTN], b1[NTN], b2[NTN];
+            h16x8 b0[NTN], b1[NTN], b2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                b0[nt] = __builtin_bit_cast(bf16x8, wsrc[((0 * NKB + kb) * NTN + nt) * 64 + lane]);
-                b1[nt] = __builtin_bit_cast(bf16x8, wsrc[((1 * NKB + kb) * NTN + nt) * 64 + lane]);
-                b2[nt] = __builtin_bit_cast(bf16x8, wsrc[((2 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b0[nt] = __builtin_bit_cast(h16x8, wsrc[((0 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b1[nt] = __builtin_bit_cast(h16x8, wsrc[((1 * NKB + kb) * NTN + nt) * 64 + lane]);
+                b2[nt] = __builtin_bit_cast(h16x8, wsrc[((2 * NKB + kb) * NTN + nt) * 64 + lane]);
             }
 #pragma unroll
             for (int mg = 0; mg < MGN; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) {
                     // (the A and B fragment layouts are the same, so D^T costs nothing: weights first = channel rows)
                     if constexpr (OUTCL) {
-                        up[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[nt], a, up[mg * NTN + nt], 0, 0, 0);
-                        mid[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[nt], a, mid[mg * NTN + nt], 0, 0, 0);
-                        down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2[nt], a, down[mg * NTN + nt], 0, 0, 0);
+                        up[mg * NTN + nt] = mfma_h16(b0[nt], a, up[mg * NTN + nt]);
+                        mid[mg * NTN + nt] = mfma_h16(b1[nt], a, mid[mg * NTN + nt]);
+                        down[mg * NTN + nt] = mfma_h16(b2[nt], a, down[mg * NTN + nt]);
                     } else {
-                        up[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0[nt], up[mg * NTN + nt], 0, 0, 0);
-                        mid[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1[nt], mid[mg * NTN + nt], 0, 0, 0);
-                        down[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2[nt], down[mg * NTN + nt], 0, 0, 0);
+                        up[mg * NTN + nt] = mfma_h16(a, b0[nt], up[mg * NTN + nt]);
+                        mid[mg * NTN + nt] = mfma_h16(a, b1[nt], mid[mg * NTN + nt]);
+                        down[mg * NTN + nt] = mfma_h16(a, b2[nt], down[mg * NTN + nt]);
                     }
                 }
             }
@@ -547,7 +550,7 @@ static int launch_fmt(const C8Params& p, int Ci, int Co, hipStream_t st) {
     }
 }
 
-extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_conv3d_k3_cl_h16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
                                      const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out, int out_cl,
                                      d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
@@ -555,7 +558,7 @@ extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpac
     const bool wide = Ci == 64 && Co == 64 && in_cl && out_cl;   // conv6: channel-last only, weights streamed from L2
     const bool shape = ((Ci == 8 || Ci == 16 || Ci == 32) && Co >= 1 && (Co <= 16 || (Co == 32 && Ci == 32))) || wide;
     if (!shape || (out_cl ? Co % 4 != 0 : W % 4 != 0) || ceil_div(H, TY) > 65535 || D > 65535) {
-        set_error("d3d_conv3d_k3_cl_bf16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16, or 32 with C_in = 32; a multiple of 4 for "
+        set_error("d3d_conv3d_k3_cl_h16: C_in = %d (8 | 16 | 32), C_out = %d (<= 16, or 32 with C_in = 32; a multiple of 4 for "
                   "channel-last output; 64 -> 64 channel-last), W = %d (a multiple of 4 for planar output) not taken", Ci, Co, W);
         return D3D_ERR_UNSUPPORTED;
     }
@@ -569,12 +572,12 @@ extern "C" int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpac
     return out_cl ? launch_fmt<false, true>(p, Ci, Co, st) : launch_fmt<false, false>(p, Ci, Co, st);
 }
 
-extern "C" int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_conv3d_k3_c1_cl_h16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
                                         const float* skip, int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     if ((Ci != 8 && Ci != 16 && Ci != 32) || W % 4 != 0 || ceil_div(H, TY) > 65535 || D > 65535) {
-        set_error("d3d_conv3d_k3_c1_cl_bf16: C_in = %d (8 | 16 | 32), W = %d (a multiple of 4) not taken", Ci, W);
+        set_error("d3d_conv3d_k3_c1_cl_h16: C_in = %d (8 | 16 | 32), W = %d (a multiple of 4) not taken", Ci, W);
         return D3D_ERR_UNSUPPORTED;
     }
     C8Params p = {};
@@ -638,14 +641,14 @@ extern "C" int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, con
     }
 }
 
-extern "C" int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_conv3d_k3_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream) {
-    return d3d_conv3d_k3_cl_bf16(in, 0, wpacked, scale, shift, skip, relu, Ci, Co, D, H, W, out, 0, stream);
+    return d3d_conv3d_k3_cl_h16(in, 0, wpacked, scale, shift, skip, relu, Ci, Co, D, H, W, out, 0, stream);
 }
 
-extern "C" int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_conv3d_k3_c8_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int D, int H, int W, float* out,
                                      d3d_stream_t stream) {
-    return d3d_conv3d_k3_cl_bf16(in, 0, wpacked, scale, shift, skip, relu, Ci, 8, D, H, W, out, 0, stream);
+    return d3d_conv3d_k3_cl_h16(in, 0, wpacked, scale, shift, skip, relu, Ci, 8, D, H, W, out, 0, stream);
 }

@@ -20,7 +20,6 @@ namespace d3d {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int TYO = 8;                 // output rows of a workgroup = waves (output columns: 16 * MGK)
@@ -40,12 +39,12 @@ struct S2Params {
     int zper;             // output planes per workgroup
 };
 
-__device__ __forceinline__ unsigned pack_bf16_cl(float a, float b) {
-    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+__device__ __forceinline__ unsigned pack_h16_cl(float a, float b) {
+    return pack_h16x2(a, b);   // one packed conversion (common.h: pack_h16x2)
 }
-__device__ __forceinline__ f4 unpack_bf16x4_cl(uint2 u) {
-    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+__device__ __forceinline__ f4 unpack_h16x4_cl(uint2 u) {
+    return (f4){h16_lo(u.x), h16_hi(u.x),
+                h16_lo(u.y), h16_hi(u.y)};
 }
 
 // MGK: 16-pixel groups per wave (output tile width 16 * MGK); WG: weight fragments read from global memory (L2) per use
@@ -174,8 +173,8 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
                         const unsigned o = eoff[mg] + nt * 16;
                         f4 v = a[mg * NTN + nt] * esc[nt] + esh[nt];
                         if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                        if (p.skip) v += unpack_bf16x4_cl(*reinterpret_cast<const uint2*>(sk + o));
-                        const uint2 pk = {pack_bf16_cl(v[0], v[1]), pack_bf16_cl(v[2], v[3])};
+                        if (p.skip) v += unpack_h16x4_cl(*reinterpret_cast<const uint2*>(sk + o));
+                        const uint2 pk = {pack_h16_cl(v[0], v[1]), pack_h16_cl(v[2], v[3])};
                         *reinterpret_cast<uint2*>(dst + o) = pk;
                     }
                 }
@@ -191,19 +190,19 @@ __global__ __launch_bounds__(NT) void conv3d_s2_cl_kernel(S2Params p) {
         asm volatile("" : "+v"(kgroup));
 auto kb_body = [&](int kb) {
             const int aoffk = WG ? a_offset(kb, kgroup) : aoffs[WG ? 0 : kb];
-            bf16x8 w1[NTN], w2[NTN];
+            h16x8 w1[NTN], w2[NTN];
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) {
-                w1[nt] = __builtin_bit_cast(bf16x8, wsrc[((kz1 * NKB + kb) * NTN + nt) * 64 + lane]);
-                if (two) w2[nt] = __builtin_bit_cast(bf16x8, wsrc[((kz2 * NKB + kb) * NTN + nt) * 64 + lane]);
+                w1[nt] = __builtin_bit_cast(h16x8, wsrc[((kz1 * NKB + kb) * NTN + nt) * 64 + lane]);
+                if (two) w2[nt] = __builtin_bit_cast(h16x8, wsrc[((kz2 * NKB + kb) * NTN + nt) * 64 + lane]);
             }
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
+                const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoffk));
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt) {
-                    d1[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[nt], a, d1[mg * NTN + nt], 0, 0, 0);
-                    if (two) d2[mg * NTN + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[nt], a, d2[mg * NTN + nt], 0, 0, 0);
+                    d1[mg * NTN + nt] = mfma_h16(w1[nt], a, d1[mg * NTN + nt]);
+                    if (two) d2[mg * NTN + nt] = mfma_h16(w2[nt], a, d2[mg * NTN + nt]);
                 }
             }
         };
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restri
     float f[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = src[(size_t)k * n];
-    out[v * G + g] = (u4){pack_bf16_cl(f[0], f[1]), pack_bf16_cl(f[2], f[3]), pack_bf16_cl(f[4], f[5]), pack_bf16_cl(f[6], f[7])};
+    out[v * G + g] = (u4){pack_h16_cl(f[0], f[1]), pack_h16_cl(f[2], f[3]), pack_h16_cl(f[4], f[5]), pack_h16_cl(f[6], f[7])};
 }
 
 __global__ __launch_bounds__(256) void cl_to_planar_kernel(const u4* __restrict__ in, int C, size_t n, float* __restrict__ out) {
@@ -293,8 +292,8 @@ __global__ __launch_bounds__(256) void cl_to_planar_kernel(const u4* __restrict_
     const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        dst[(size_t)(2 * k) * n] = __builtin_bit_cast(float, w[k] << 16);
-        dst[(size_t)(2 * k + 1) * n] = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+        dst[(size_t)(2 * k) * n] = h16_lo(w[k]);
+        dst[(size_t)(2 * k + 1) * n] = h16_hi(w[k]);
     }
 }
 
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(256) void cl_to_planar_kernel(const u4* __restrict_
 
 using namespace d3d;
 
-extern "C" int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
+extern "C" int d3d_conv3d_k3s2_cl_h16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
                                        int relu, int Ci, int Co, int D, int H, int W, void* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
@@ -314,7 +313,7 @@ extern "C" int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, cons
     const bool shape = (Ci == 8 && Co == 16) || (Ci == 16 && Co == 32) || (Ci == 8 && Co == 8) || (Ci == 16 && Co == 16) ||
                        (Ci == 32 && Co == 64);
     if (!shape || ceil_div(p.Ho, TYO) > 65535 || p.Do > 65535 || (long)H * W * Ci * 2 >= (1L << 31)) {   // (32-bit offsets inside a plane)
-        set_error("d3d_conv3d_k3s2_cl_bf16: %d -> %d channels not taken (8->8, 8->16, 16->16, 16->32, 32->64)", Ci, Co);
+        set_error("d3d_conv3d_k3s2_cl_h16: %d -> %d channels not taken (8->8, 8->16, 16->16, 16->32, 32->64)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -323,7 +322,7 @@ extern "C" int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, cons
     return Co > 16 ? launch_s2<16, 2>(p, st) : launch_s2<16, 1>(p, st);
 }
 
-extern "C" int d3d_volume_planar_to_cl_bf16(const float* in, int C, size_t n, void* out, d3d_stream_t stream) {
+extern "C" int d3d_volume_planar_to_cl_h16(const float* in, int C, size_t n, void* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && out, "null pointer");
     D3D_REQUIRE(C > 0 && C % 8 == 0 && C <= 8 * 65535 && n > 0 && n < ((size_t)1 << 39), "C = %d (multiple of 8), n = %zu", C, n);
     hipLaunchKernelGGL(planar_to_cl_kernel, dim3((unsigned)((n + 255) / 256), C / 8), dim3(256), 0, (hipStream_t)stream, in, C, n,
@@ -332,7 +331,7 @@ extern "C" int d3d_volume_planar_to_cl_bf16(const float* in, int C, size_t n, vo
     return D3D_OK;
 }
 
-extern "C" int d3d_volume_cl_bf16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream) {
+extern "C" int d3d_volume_cl_h16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && out, "null pointer");
     D3D_REQUIRE(C > 0 && C % 8 == 0 && C <= 8 * 65535 && n > 0 && n < ((size_t)1 << 39), "C = %d (multiple of 8), n = %zu", C, n);
     hipLaunchKernelGGL(cl_to_planar_kernel, dim3((unsigned)((n + 255) / 256), C / 8), dim3(256), 0, (hipStream_t)stream,

@@ -71,7 +71,7 @@ __device__ unsigned long long g_conv_stats[8];
 #define ZS_ADD(i, a, b)
 #endif
 
-typedef __bf16 bf4v __attribute__((ext_vector_type(4)));
+typedef h16x4 bf4v;   // four operands of the library's 16-bit format (common.h)
 
 // BF16 = true: the same kernel with bf16 MFMA operands (v_mfma_f32_16x16x16_bf16, fp32 accumulate) -- the
 // precision BASELINE's config 3 names.  Activations are rounded (RNE, v_cvt_pk_bf16_f32) as they are staged: the
@@ -146,15 +146,15 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                         if (t >= p.tzstart[i] && t < p.tzstart[i + 1]) te = p.tzstart[i + 1];
                     live = tt < te;
                 }
-                bf4v v;
+                float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ci = cb + q;
                     const bool ok = live && ci < Ci;
                     const float w = p.wpack[((long)(ok ? tt : 0) * Ci + (ok ? ci : 0)) * MP + m];
-                    v[q] = (__bf16)(ok ? w : 0.0f);
+                    v[q] = ok ? w : 0.0f;
                 }
-                wl16[r1 * WS + m] = v;
+                wl16[r1 * WS + m] = cvt_h16x4(v[0], v[1], v[2], v[3]);
             }
         }
         const int rows = BF16 ? 0 : p.ntaps * CiP;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
         asm volatile("" : "+v"(grpo), "+v"(xso), "+s"(nit));
         if constexpr (BF16) {
             bf4v* xw8 = reinterpret_cast<bf4v*>(xw);
-            auto pack = [](float a0, float a1, float a2, float a3) { return (bf4v){(__bf16)a0, (__bf16)a1, (__bf16)a2, (__bf16)a3}; };
+            auto pack = [](float a0, float a1, float a2, float a3) { return cvt_h16x4(a0, a1, a2, a3); };
 #pragma unroll
             for (int b = 0; b < PF / 16; ++b) {
                 if (b < nit) {
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                         const bf4v av = wa[m * 16];
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            acc[s][m][n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, b[n], acc[s][m][n], 0, 0, 0);
+                            acc[s][m][n] = mfma_h16_k16(av, b[n], acc[s][m][n]);
                     }
                 }
                 continue;
@@ -1002,7 +1002,7 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
                           Co, D, H, W, Do, Ho, Wo, geom, ntaps, taps_zyx, out, stream);
 }
 
-int d3d_conv_fold_bf16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
+int d3d_conv_fold_h16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                        const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
                        const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo,
                        const int* geom, int ntaps, const signed char* taps_zyx, float* out, d3d_stream_t stream) {

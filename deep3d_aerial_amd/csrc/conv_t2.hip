@@ -40,8 +40,11 @@ struct T2Params {
     int ozper;           // output planes per workgroup (even)
 };
 
-__device__ __forceinline__ unsigned pack_bf16_t2(float a, float b) {
+__device__ __forceinline__ unsigned pack_bf16_t2(float a, float b) {   // the split (fp32-mode) operands: three bf16 pieces
     return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+}
+__device__ __forceinline__ unsigned pack_h16_t2(float a, float b) {    // the single 16-bit operand / stored activation (common.h)
+    return pack_h16x2(a, b);
 }
 
 constexpr int ntaps(int pz, int py, int px) { return (1 + pz) * (1 + py) * (1 + px); }
@@ -53,9 +56,9 @@ constexpr int frag_base(int CI, int p) {
     return s;
 }
 
-__device__ __forceinline__ f4 unpack_bf16x4_t2(uint2 u) {
-    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+__device__ __forceinline__ f4 unpack_h16x4_t2(uint2 u) {
+    return (f4){h16_lo(u.x), h16_hi(u.x),
+                h16_lo(u.y), h16_hi(u.y)};
 }
 
 // first fragment of the x-folded packing: class (pz, py) holds the K blocks of its px = 1 tap set
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                     *reinterpret_cast<u4*>(cell + CI * 4) = (u4){lo[0], lo[1], lo[2], lo[3]};
                     continue;
                 }
-                *reinterpret_cast<u4*>(cell) = (u4){pack_bf16_t2(x[0], x[1]), pack_bf16_t2(x[2], x[3]), pack_bf16_t2(x[4], x[5]), pack_bf16_t2(x[6], x[7])};
+                *reinterpret_cast<u4*>(cell) = (u4){pack_h16_t2(x[0], x[1]), pack_h16_t2(x[2], x[3]), pack_h16_t2(x[4], x[5]), pack_h16_t2(x[6], x[7])};
             }
         }
     };
@@ -253,11 +256,11 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                 const int dx = real ? (t & 1) : 0, dy = real ? (t >> 1) % (1 + PY) : 0, dz = real ? (t >> 1) / (1 + PY) : 0;
                 const unsigned char* buf = dz ? b1 : b0;
                 const int aoff = (dy * PXI + dx) * CS + (real ? c : 0) * 2;
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, wsrc[(FB + kb) * 64 + lane]);
+                const h16x8 wf = __builtin_bit_cast(h16x8, wsrc[(FB + kb) * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
-                    accf[mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a, accf[mg], 0, 0, 0);
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
+                    accf[mg] = mfma_h16(wf, a, accf[mg]);
                 }
             }
             // D row (lane >> 4) * 4 + r = (column parity, channel), column = input pixel lane & 15
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                     if (est[0][mg]) {
                         f4 v = accf[mg] * esc[0] + esh[0];
                         if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                        if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(sk + eoff[mg]));
-                        const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
+                        if (p.skip) v += unpack_h16x4_t2(*reinterpret_cast<const uint2*>(sk + eoff[mg]));
+                        const uint2 pk = {pack_h16_t2(v[0], v[1]), pack_h16_t2(v[2], v[3])};
                         *reinterpret_cast<uint2*>(dst + eoff[mg]) = pk;
                     }
                 }
@@ -324,16 +327,16 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                     }
                     continue;
                 }
-                bf16x8 bfrag[NTN];
+                h16x8 bfrag[NTN];
 #pragma unroll
-                for (int nt = 0; nt < NTN; ++nt) bfrag[nt] = __builtin_bit_cast(bf16x8, wsrc[((FB + kb) * NTN + nt) * 64 + lane]);
+                for (int nt = 0; nt < NTN; ++nt) bfrag[nt] = __builtin_bit_cast(h16x8, wsrc[((FB + kb) * NTN + nt) * 64 + lane]);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(buf + abase + mg * 16 * CS + aoff));
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt) {
-                        if constexpr (CL) acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[nt], a, acc[px][mg][nt], 0, 0, 0);
-                        else acc[px][mg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[nt], acc[px][mg][nt], 0, 0, 0);
+                        if constexpr (CL) acc[px][mg][nt] = mfma_h16(bfrag[nt], a, acc[px][mg][nt]);
+                        else acc[px][mg][nt] = mfma_h16(a, bfrag[nt], acc[px][mg][nt]);
                     }
                 }
             }
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(64 * TYI) void convt3d_zs_bf16_kernel(T2Params p) {
                             const unsigned o = eoff[mg] + px * p.CO + nt * 16;
                             f4 v = acc[px][mg][nt] * esc[nt] + esh[nt];
                             if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                            if (p.skip) v += unpack_bf16x4_t2(*reinterpret_cast<const uint2*>(sk + o));
-                            const uint2 pk = {pack_bf16_t2(v[0], v[1]), pack_bf16_t2(v[2], v[3])};
+                            if (p.skip) v += unpack_h16x4_t2(*reinterpret_cast<const uint2*>(sk + o));
+                            const uint2 pk = {pack_h16_t2(v[0], v[1]), pack_h16_t2(v[2], v[3])};
                             *reinterpret_cast<uint2*>(dst + o) = pk;
                         }
                     }
@@ -442,14 +445,14 @@ static int launch(const T2Params& p, hipStream_t stream) {
 
 using namespace d3d;
 
-extern "C" int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_convtranspose3d_k3s2_cl_h16(const void* in, const void* wpacked, const float* scale, const float* shift,
                                                 const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out,
                                                 int channel_last, d3d_stream_t stream) {
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     const bool shape = (Ci == 16 && Co == 8) || (Ci == 16 && Co == 16) || (Ci == 32 && Co == 16) || (Ci == 64 && Co == 32);
     if (!shape || ceil_div(H, TYI) > 65535 || 2 * D > 65535 || (channel_last && (long)H * W * 4 * (Ci > Co ? Ci : Co) * 2 >= (1L << 31))) {   // (32-bit offsets inside a plane)
-        set_error("d3d_convtranspose3d_k3s2_cl_bf16: %d -> %d channels not taken (16->8, 16->16, 32->16, 64->32)", Ci, Co);
+        set_error("d3d_convtranspose3d_k3s2_cl_h16: %d -> %d channels not taken (16->8, 16->16, 32->16, 64->32)", Ci, Co);
         return D3D_ERR_UNSUPPORTED;
     }
     T2Params p = {};
@@ -458,7 +461,7 @@ extern "C" int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpac
     hipStream_t st = (hipStream_t)stream;
     if (channel_last == 2) {   // x-folded weight packing
         if (Ci == 16 && Co == 8) return launch<16, 1, 2, true, true>(p, st);
-        set_error("d3d_convtranspose3d_k3s2_cl_bf16: the x-folded form takes 16 -> 8 channels only");
+        set_error("d3d_convtranspose3d_k3s2_cl_h16: the x-folded form takes 16 -> 8 channels only");
         return D3D_ERR_UNSUPPORTED;
     }
     if (channel_last) {
@@ -489,8 +492,8 @@ extern "C" int d3d_convtranspose3d_k3s2_zs_bf16x3(const float* in, const void* w
     return launch<16, 1, 2, false, false, true>(p, (hipStream_t)stream);
 }
 
-extern "C" int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+extern "C" int d3d_convtranspose3d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                                 const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                                 d3d_stream_t stream) {
-    return d3d_convtranspose3d_k3s2_cl_bf16(in, wpacked, scale, shift, skip, relu, Ci, Co, D, H, W, out, 0, stream);
+    return d3d_convtranspose3d_k3s2_cl_h16(in, wpacked, scale, shift, skip, relu, Ci, Co, D, H, W, out, 0, stream);
 }

@@ -25,7 +25,6 @@ namespace d3d {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int CI = 16;                          // channels of x
@@ -67,13 +66,13 @@ struct T2PParams {
     int ozper;            // output planes per workgroup (even)
 };
 
-__device__ __forceinline__ unsigned pack_bf16_p(float a, float b) {
-    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+__device__ __forceinline__ unsigned pack_h16_p(float a, float b) {
+    return pack_h16x2(a, b);   // one packed conversion (common.h: pack_h16x2)
 }
 
-__device__ __forceinline__ f4 unpack_bf16x4_p(uint2 u) {
-    return (f4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+__device__ __forceinline__ f4 unpack_h16x4_p(uint2 u) {
+    return (f4){h16_lo(u.x), h16_hi(u.x),
+                h16_lo(u.y), h16_hi(u.y)};
 }
 
 __device__ __forceinline__ float dpp_row_shr1_p(float v) {
@@ -199,14 +198,14 @@ __global__ __launch_bounds__(NT, 4) void convt3d_prob_kernel(T2PParams p) {
                 for (int kb = 0; kb < NKB; ++kb) {
                     const unsigned char* abuf = kb / (1 + PY) ? ab1 : ab0;
                     const int ao = aoff[FB + kb];
-                    const bf16x8 wf = __builtin_bit_cast(bf16x8, wt[(FB + kb) * 64 + lane]);
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(abuf + t * (4 * PXI * CS) + ao));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a, acc, 0, 0, 0);
+                    const h16x8 wf = __builtin_bit_cast(h16x8, wt[(FB + kb) * 64 + lane]);
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(abuf + t * (4 * PXI * CS) + ao));
+                    acc = mfma_h16(wf, a, acc);
                 }
                 f4 v = acc * sc + sh;
                 if (p.relu) v = __builtin_elementwise_max(v, (f4){0, 0, 0, 0});
-                if constexpr (SKIP) v += unpack_bf16x4_p(sk[t][PY]);
-                uint2 pk = {pack_bf16_p(v[0], v[1]), pack_bf16_p(v[2], v[3])};
+                if constexpr (SKIP) v += unpack_h16x4_p(sk[t][PY]);
+                uint2 pk = {pack_h16_p(v[0], v[1]), pack_h16_p(v[2], v[3])};
                 if (!ins[t][PY]) pk = (uint2){0, 0};                 // the zero padding of the probability layer
                 *reinterpret_cast<uint2*>(ybuf + ywr + (8 * t + PY) * (YP * 16)) = pk;
             };
@@ -232,11 +231,11 @@ __global__ __launch_bounds__(NT, 4) void convt3d_prob_kernel(T2PParams p) {
     auto sweep = [&]() {
 #pragma unroll
         for (int kb = 0; kb < NFP; ++kb) {
-            const bf16x8 bw = __builtin_bit_cast(bf16x8, wp[kb * 64 + lane]);
+            const h16x8 bw = __builtin_bit_cast(h16x8, wp[kb * 64 + lane]);
 #pragma unroll
             for (int j = 0; j < PTILES; ++j) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ybuf + sbase[kb] + j * (2 * YP * 16)));
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[j], 0, 0, 0);
+                const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(ybuf + sbase[kb] + j * (2 * YP * 16)));
+                acc[j] = mfma_h16(a, bw, acc[j]);
                 if (j % 5 == 4) __builtin_amdgcn_sched_barrier(0);   // five operand loads in flight, not thirty (registers)
             }
         }
@@ -302,14 +301,14 @@ __global__ __launch_bounds__(NT, 4) void convt3d_prob_kernel(T2PParams p) {
 
 using namespace d3d;
 
-extern "C" int d3d_convtranspose3d_prob_cl_bf16(const void* in, const void* wt_folded, const float* scale, const float* shift,
+extern "C" int d3d_convtranspose3d_prob_cl_h16(const void* in, const void* wt_folded, const float* scale, const float* shift,
                                                 const void* skip, int relu, const void* wprob_kzfolded, const float* prob_bias,
                                                 int D, int H, int W, float* out, d3d_stream_t stream) {
     D3D_REQUIRE(in && wt_folded && wprob_kzfolded && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     const int gx = ceil_div(W, OXI), gy = ceil_div(H, OYI);
     if (W % 2 != 0 || gy > 65535 || 2 * D > 65535 || (long)H * W * 64 >= (1L << 31)) {   // (32-bit offsets inside a plane)
-        set_error("d3d_convtranspose3d_prob_cl_bf16: W = %d (even: rows of 2 W floats in 16-byte quads), plane %d x %d not taken", W, H, W);
+        set_error("d3d_convtranspose3d_prob_cl_h16: W = %d (even: rows of 2 W floats in 16-byte quads), plane %d x %d not taken", W, H, W);
         return D3D_ERR_UNSUPPORTED;
     }
     auto kern = skip ? convt3d_prob_kernel<true> : convt3d_prob_kernel<false>;

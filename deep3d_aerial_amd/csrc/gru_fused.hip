@@ -36,7 +36,6 @@ namespace d3d {
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 // The cell is bound by instruction issue (profiles/r04_gru_slice.txt, second part): a tile of the first build was 1650 vector
@@ -67,8 +66,8 @@ struct GruParams {
     int tper;            // tiles per workgroup along y
 };
 
-__device__ __forceinline__ unsigned pack_bf16_g(float a, float b) {
-    return pack_bf16x2(a, b);   // one v_cvt_pk_bf16_f32 (common.h)
+__device__ __forceinline__ unsigned pack_h16_g(float a, float b) {
+    return pack_h16x2(a, b);   // one packed conversion (common.h: pack_h16x2)
 }
 // raw buffer over a tensor from `origin` on (which may lie before the tensor: lanes that would read there carry OOB offsets)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tensor_rsrc(const void* origin) {
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
                 constexpr int dummy = 0; (void)dummy;
                 const int off = S == 2 ? ((i & 1) ? ((i + 1) >> 1) - NEVEN : (i >> 1)) * CS1 : i * CS1;
                 if (ckeep[r][i])
-                    *reinterpret_cast<u2*>(sim + ccell[r] + off) = (u2){pack_bf16_g(sc[r][0][i], sc[r][1][i]), pack_bf16_g(sc[r][2][i], sc[r][3][i])};
+                    *reinterpret_cast<u2*>(sim + ccell[r] + off) = (u2){pack_h16_g(sc[r][0][i], sc[r][1][i]), pack_h16_g(sc[r][2][i], sc[r][3][i])};
             }
         }
     };
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
             if (hcell[r] < 0) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<u2*>(XA + hcell[r] + i * XC) = (u2){pack_bf16_g(sh[r][0][i], sh[r][1][i]), pack_bf16_g(sh[r][2][i], sh[r][3][i])};
+                *reinterpret_cast<u2*>(XA + hcell[r] + i * XC) = (u2){pack_h16_g(sh[r][0][i], sh[r][1][i]), pack_h16_g(sh[r][2][i], sh[r][3][i])};
         }
     };
 
@@ -295,11 +294,11 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
 #pragma unroll
             for (int kb = 0; kb < NKB1; ++kb) {
                 const unsigned char* ap = sim + a1base + a1off[kb];
-                const bf16x8 b = __builtin_bit_cast(bf16x8, w1l[kb * 64 + lane]);
+                const h16x8 b = __builtin_bit_cast(h16x8, w1l[kb * 64 + lane]);
 #pragma unroll
                 for (int t = 0; t < NT1; ++t) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + t * ((S == 2 ? 4 : 2) * SPX * CS1)));
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc[t], 0, 0, 0);
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(ap + t * ((S == 2 ? 4 : 2) * SPX * CS1)));
+                    acc[t] = mfma_h16(b, a, acc[t]);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // (the scheduler would hoist every K block's operand reads: ~100 registers)
             }
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
                     const bool in = xin && gy >= 0 && gy < H;   // zero outside the image: the gates' own zero padding
                     f4 y = acc[t] * 1.0f + 0.0f;
                     y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
-                    u2 pk = {pack_bf16_g(y[0], y[1]), pack_bf16_g(y[2], y[3])};
+                    u2 pk = {pack_h16_g(y[0], y[1]), pack_h16_g(y[2], y[3])};
                     if (!in) pk = (u2){0, 0};
                     *reinterpret_cast<u2*>(XA + xwr + t * (2 * PITCH * XC)) = pk;
                 }
@@ -340,14 +339,14 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
             for (int kb = 0; kb < NKBG; ++kb) {
                 const unsigned char* apc = XA + gbase + goff[kb];
                 const unsigned char* aph = XA + hbase + goff[kb];
-                bf16x8 b[NTNG];
+                h16x8 b[NTNG];
 #pragma unroll
-                for (int nt = 0; nt < NTNG; ++nt) b[nt] = __builtin_bit_cast(bf16x8, wgl[(kb * NTNG + nt) * 64 + lane]);
+                for (int nt = 0; nt < NTNG; ++nt) b[nt] = __builtin_bit_cast(h16x8, wgl[(kb * NTNG + nt) * 64 + lane]);
 #pragma unroll
                 for (int t = 0; t < NT2; ++t) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(t < NCT ? apc + t * (2 * PITCH * XC) : aph));
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(t < NCT ? apc + t * (2 * PITCH * XC) : aph));
 #pragma unroll
-                    for (int nt = 0; nt < NTNG; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[nt], acc[t][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTNG; ++nt) acc[t][nt] = mfma_h16(a, b[nt], acc[t][nt]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
                 }
                 if (lane_h) {
                     const f4 rh = rgate * hh[t];
-                    const unsigned p01 = pack_bf16_g(rh[0], rh[1]), p23 = pack_bf16_g(rh[2], rh[3]);
+                    const unsigned p01 = pack_h16_g(rh[0], rh[1]), p23 = pack_h16_g(rh[2], rh[3]);
                     unsigned char* dst = XA + (t < NCT ? rwr_c + t * (2 * PITCH * XC) : rwr_h);
                     *reinterpret_cast<unsigned short*>(dst) = (unsigned short)p01;
                     *reinterpret_cast<unsigned short*>(dst + XC) = (unsigned short)(p01 >> 16);
@@ -391,11 +390,11 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
 #pragma unroll
             for (int kb = 0; kb < NKBG; ++kb) {
                 const unsigned char* ap = XA + gbase + goff[kb] + csec[kb];   // second half of a tap: r*h instead of h
-                const bf16x8 b = __builtin_bit_cast(bf16x8, wcl[kb * 64 + lane]);
+                const h16x8 b = __builtin_bit_cast(h16x8, wcl[kb * 64 + lane]);
 #pragma unroll
                 for (int t = 0; t < NCT; ++t) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4*>(ap + t * (2 * PITCH * XC)));
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+                    const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4*>(ap + t * (2 * PITCH * XC)));
+                    acc[t] = mfma_h16(a, b, acc[t]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -455,7 +454,7 @@ using namespace d3d;
 //   stride 1: cost [CP,H,W] (CP = 8 | 16 | 32), HID = 8 (adamvs.py:409-410 conv1 + conv_gru1)
 //   stride 2: cost [8,HI,WI] with H = (HI - 1) / 2 + 1, W = (WI - 1) / 2 + 1, HID = 16 (adamvs.py:411-412 conv2 + conv_gru2)
 // w1 / wg / wc: ops._pack_z2_bf16 of the three nn.Conv2d weights; bg [2 HID], bc [HID] their biases (conv1 / conv2 have none).
-extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
+extern "C" int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
                                        const void* w1, const void* wg, const float* bg, const void* wc, const float* bc, float* hout,
                                        d3d_stream_t stream) {
     D3D_REQUIRE(cost && h && hout && w1 && wg && wc && bg && bc, "null pointer");
@@ -466,7 +465,7 @@ extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI
     else D3D_REQUIRE(H == (HI - 1) / 2 + 1 && W == (WI - 1) / 2 + 1, "stride 2: state %dx%d does not belong to a %dx%d input", H, W, HI, WI);
     if (W % 4 != 0 || WI % 4 != 0 || (long)CP * HI * WI * 4 >= (1L << 31) || (long)HID * H * W * 4 >= (1L << 31) ||
         ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(hout) | reinterpret_cast<uintptr_t>(cost)) & 15)) {
-        set_error("d3d_gru_cell_fused_bf16: widths %d / %d (multiples of 4) with 16-byte aligned tensors below 2 GiB needed", WI, W);
+        set_error("d3d_gru_cell_fused_h16: widths %d / %d (multiples of 4) with 16-byte aligned tensors below 2 GiB needed", WI, W);
         return D3D_ERR_UNSUPPORTED;
     }
     GruParams p = {};
@@ -479,6 +478,6 @@ extern "C" int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }
     if (stride == 2 && HID == 16 && CP == 8) return launch_gru<8, 16, 2, 4, 4>(p, st);
-    set_error("d3d_gru_cell_fused_bf16: C = %d, hidden = %d, stride = %d not taken (8 | 16 | 32 -> 8 at stride 1; 8 -> 16 at stride 2)", CP, HID, stride);
+    set_error("d3d_gru_cell_fused_h16: C = %d, hidden = %d, stride = %d not taken (8 | 16 | 32 -> 8 at stride 1; 8 -> 16 at stride 2)", CP, HID, stride);
     return D3D_ERR_UNSUPPORTED;
 }

@@ -394,6 +394,8 @@ int d3d_debug_dispatch_counts(unsigned long long* out4, int reset) {
     return D3D_OK;
 }
 
+const char* d3d_h16_format(void) { return D3D_H16_FORMAT; }
+
 const char* d3d_build_flags(void) {
     static char buf[512];
     static std::atomic<int> done{0};
@@ -516,7 +518,7 @@ static int variance_volume_cl_any(int layout, const float* const* feats, const f
     if (rc) return rc;
     p.out_cl = layout;
     if (forced_path() == 1) {
-        set_error("d3d_variance_volume_cl_bf16: only the LDS-ring and window kernels write channel-last volumes");
+        set_error("d3d_variance_volume_cl_h16: only the LDS-ring and window kernels write channel-last volumes");
         return D3D_ERR_UNSUPPORTED;
     }
     if (forced_path() != 2) {
@@ -526,13 +528,13 @@ static int variance_volume_cl_any(int layout, const float* const* feats, const f
     return counted(2, launch_tiled(MODE_VARIANCE, p, (hipStream_t)stream));
 }
 
-int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+int d3d_variance_volume_cl_h16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                 d3d_stream_t stream) {
     return variance_volume_cl_any(1, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes, stream);
 }
 
-int d3d_variance_volume_cl8_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+int d3d_variance_volume_cl8_h16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                  int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                  d3d_stream_t stream) {
     return variance_volume_cl_any(2, feats, proj34, depth, depth_mode, n_views, C, D, h, w, out, workspace, workspace_bytes, stream);

@@ -940,9 +940,9 @@ __global__ __launch_bounds__(64 * (NPIXW_T * NSUB_T + NLOAD_T), 3) void sweep_ti
         }
         if constexpr (OUTCL) {
             if ((q & 1) == 0) {
-                even_quad = pack_bf16x4(o);
+                even_quad = pack_h16x4(o);
             } else {
-                store_sbase_bf16x8(ob, pixo, even_quad, pack_bf16x4(o));
+                store_sbase_h16x8(ob, pixo, even_quad, pack_h16x4(o));
                 ob += cl_step;   // the next 8 channels: the next 16 bytes of the cell, or the next group plane (CL8)
             }
         } else {

@@ -364,13 +364,13 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
         }
         if constexpr (OUTCL) {
             if ((q & 1) == 0) {
-                even_quad = pack_bf16x4(o);
+                even_quad = pack_h16x4(o);
             } else {
-#ifdef D3D_CL_PARTIAL_DEFAULT_POLICY   // experiment: see store_sbase_bf16x8
-                if (a.ngroups > 1) store_sbase_bf16x8<true>(ob, pixo, even_quad, pack_bf16x4(o));
+#ifdef D3D_CL_PARTIAL_DEFAULT_POLICY   // experiment: see store_sbase_h16x8
+                if (a.ngroups > 1) store_sbase_h16x8<true>(ob, pixo, even_quad, pack_h16x4(o));
                 else
 #endif
-                store_sbase_bf16x8(ob, pixo, even_quad, pack_bf16x4(o));
+                store_sbase_h16x8(ob, pixo, even_quad, pack_h16x4(o));
                 ob += 16;
             }
         } else {

@@ -291,10 +291,7 @@ __global__ __launch_bounds__(256) void online_regress_update_kernel(const float*
 // kernel with 15 of its 16 output columns idle and four storing lanes per wave, and `reg` made a round trip through HBM; here
 // a thread owns one input pixel (= 2 x 2 outputs) resp. one output pixel, the 72 weights are wave-uniform, operands are
 // rounded to bf16 (RNE) as the matrix cores' are, products and sums are fp32.
-__device__ __forceinline__ float bf16_round(float v) {
-    const __bf16 b = (__bf16)v;
-    return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
+__device__ __forceinline__ float bf16_round(float v) { return round_h16(v); }   // (the library's 16-bit format: common.h)
 // four consecutive outputs of one row (X % 4 == 0, W % 4 == 0): the accumulators move as 16-byte accesses
 __device__ __forceinline__ void regress_row4(const float (&reg)[4], long i, int X, int Y, const float* __restrict__ dplane, int hd, int wd,
                                              int H, int W, float* __restrict__ max_p, float* __restrict__ sum_d, float* __restrict__ sum_p) {
@@ -432,7 +429,6 @@ __global__ __launch_bounds__(256) void slice_head_regress_kernel(const float* __
 // ---------------------------------------------------------------------------------------------
 namespace tail {
 typedef float f4t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
 typedef unsigned u4t __attribute__((ext_vector_type(4)));
 constexpr int CI = 16, TXI = 32, TYI = 8, PXI = TXI + 1, PYI = TYI + 1, CS = 32;   // state2 tile, staged patch, bytes per cell
 constexpr int NT = 64 * TYI;
@@ -506,8 +502,8 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r)
             if (scell[r] >= 0)
-                *reinterpret_cast<u4t*>(dst + scell[r]) = (u4t){pack_bf16x2(stg[r][0], stg[r][1]), pack_bf16x2(stg[r][2], stg[r][3]),
-                                                                 pack_bf16x2(stg[r][4], stg[r][5]), pack_bf16x2(stg[r][6], stg[r][7])};
+                *reinterpret_cast<u4t*>(dst + scell[r]) = (u4t){pack_h16x2(stg[r][0], stg[r][1]), pack_h16x2(stg[r][2], stg[r][3]),
+                                                                 pack_h16x2(stg[r][4], stg[r][5]), pack_h16x2(stg[r][6], stg[r][7])};
     };
 
     // ---- upconv1 on the matrix cores: wave = state2 row, two 16-pixel groups; K offsets per (parity class, K block) once -------
@@ -571,11 +567,11 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     if (kb >= NKB) break;
-                    const bf16x8t bw = __builtin_bit_cast(bf16x8t, wlds[(FB + kb) * 64 + lane]);
+                    const h16x8 bw = __builtin_bit_cast(h16x8, wlds[(FB + kb) * 64 + lane]);
 #pragma unroll
                     for (int mg = 0; mg < 2; ++mg) {
-                        const bf16x8t a = __builtin_bit_cast(bf16x8t, *reinterpret_cast<const u4t*>(buf + aoff[FB + kb] + mg * 16 * CS));
-                        acc[px][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[px][mg], 0, 0, 0);
+                        const h16x8 a = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4t*>(buf + aoff[FB + kb] + mg * 16 * CS));
+                        acc[px][mg] = mfma_h16(a, bw, acc[px][mg]);
                     }
                 }
             }
@@ -587,7 +583,7 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
                 hi += (f4t){sk[PY][mg][2][0], sk[PY][mg][2][1], sk[PY][mg][3][0], sk[PY][mg][3][1]};
                 lo = __builtin_elementwise_max(lo, (f4t){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4t){0, 0, 0, 0});
                 // zeros outside the image: what the head's bounds tests read there
-                unsigned q0 = pack_bf16x2(lo[0], lo[1]), q1 = pack_bf16x2(lo[2], lo[3]), q2 = pack_bf16x2(hi[0], hi[1]), q3 = pack_bf16x2(hi[2], hi[3]);
+                unsigned q0 = pack_h16x2(lo[0], lo[1]), q1 = pack_h16x2(lo[2], lo[3]), q2 = pack_h16x2(hi[0], hi[1]), q3 = pack_h16x2(hi[2], hi[3]);
                 if (!rowin || kvo[mg][0] == OOB) q0 = 0;
                 if (!rowin || kvo[mg][1] == OOB) q1 = 0;
                 if (!rowin || kvo[mg][2] == OOB) q2 = 0;
@@ -622,7 +618,7 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
                 for (int ch = 0; ch < 8; ++ch) {
                     auto val = [&](const u4t& v) {
                         const unsigned d = v[ch >> 1];
-                        return __builtin_bit_cast(float, (ch & 1) ? (d & 0xffff0000u) : (d << 16));
+                        return (ch & 1) ? h16_hi(d) : h16_lo(d);
                     };
                     const float x0 = val(c[0][0]), x1 = val(c[0][1]), x2 = val(c[0][2]);
                     const float z0 = val(c[1][0]), z1 = val(c[1][1]), z2 = val(c[1][2]);
@@ -973,12 +969,12 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
     return D3D_OK;
 }
 
-int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
+int d3d_slice_head_regress_h16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
                                 int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream) {
     D3D_REQUIRE(up && weight && bias && dplane && max_p && sum_d && sum_p, "null pointer");
     D3D_REQUIRE(hd > 0 && wd > 0 && h > 0 && w > 0, "bad dims %dx%d / %dx%d", hd, wd, h, w);
     if (w % (transposed ? 2 : 4) != 0) {
-        set_error("d3d_slice_head_regress_bf16: w = %d must be a multiple of %d", w, transposed ? 2 : 4);
+        set_error("d3d_slice_head_regress_h16: w = %d must be a multiple of %d", w, transposed ? 2 : 4);
         return D3D_ERR_UNSUPPORTED;
     }
     dim3 grid(ceil_div(w / (transposed ? 2 : 4), 64), ceil_div(h, 4));
@@ -993,7 +989,7 @@ int d3d_slice_head_regress_bf16(const float* up, const float* weight, const floa
     return D3D_OK;
 }
 
-int d3d_slice_tail_regress_bf16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
+int d3d_slice_tail_regress_h16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
                                 const float* bhead, const float* dplane, int hd, int wd, int h, int w, float* max_p, float* sum_d,
                                 float* sum_p, d3d_stream_t stream) {
     D3D_REQUIRE(state2 && wup_packed && bup && state1 && whead && bhead && dplane && max_p && sum_d && sum_p, "null pointer");
@@ -1003,7 +999,7 @@ int d3d_slice_tail_regress_bf16(const float* state2, const void* wup_packed, con
     if (w % 4 != 0 || (long)h * w * 64 * 4 >= (1L << 31) ||
         ((reinterpret_cast<uintptr_t>(max_p) | reinterpret_cast<uintptr_t>(sum_d) | reinterpret_cast<uintptr_t>(sum_p) |
           (dquad ? reinterpret_cast<uintptr_t>(dplane) : 0)) & 15)) {
-        set_error("d3d_slice_tail_regress_bf16: w = %d (a multiple of 4), 16-byte aligned maps and tensors below 2 GiB needed", w);
+        set_error("d3d_slice_tail_regress_h16: w = %d (a multiple of 4), 16-byte aligned maps and tensors below 2 GiB needed", w);
         return D3D_ERR_UNSUPPORTED;
     }
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(slice_tail_kernel), tail::LDS_BYTES);

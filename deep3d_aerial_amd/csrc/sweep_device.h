@@ -102,11 +102,17 @@ __device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte
     asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(byte_off), "v"(v), "s"(sb));
 }
 
-// channel-last bf16 output: four consecutive channels of the lane's voxel, RNE, as two dwords ...
-__device__ __forceinline__ unsigned long long pack_bf16x4(const float __attribute__((ext_vector_type(4)))& v) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    const bf2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};   // v_cvt_pk_bf16_f32
-    return (unsigned long long)__builtin_bit_cast(unsigned, a) | ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32);
+// channel-last 16-bit output (the library's h16 format, common.h): four consecutive channels of the lane's voxel, RNE, as two
+// dwords ...  The variance volume is the one operand of the regularisers whose magnitude the data decides (feature maps leave
+// their nets without a normalisation): in the half format it SATURATES at the largest finite value instead of becoming inf
+// (one v_min_f32 per value; a variance is never far below zero -- E[x^2] - E[x]^2 cancels to a few ulp).
+__device__ __forceinline__ unsigned long long pack_h16x4(const float __attribute__((ext_vector_type(4)))& v) {
+#ifdef D3D_H16_BF16
+    const unsigned a = pack_h16x2(v[0], v[1]), b = pack_h16x2(v[2], v[3]);
+#else
+    const unsigned a = pack_h16x2(fminf(v[0], 65504.0f), fminf(v[1], 65504.0f)), b = pack_h16x2(fminf(v[2], 65504.0f), fminf(v[3], 65504.0f));
+#endif
+    return (unsigned long long)a | ((unsigned long long)b << 32);
 }
 // ... and EIGHT of them (two finished quads) as one 16-byte store: a lane's stores are 64 cells apart from its
 // neighbours' (cell = C * 2 bytes), so every store instruction is 64 separate memory transactions whatever its width --
@@ -116,7 +122,7 @@ __device__ __forceinline__ unsigned long long pack_bf16x4(const float __attribut
 // 2.66 GB for a 1.31 GB volume, the planar volume's bytes).  Dropping `nt` so that the halves could merge in L2 / the
 // Infinity Cache left WRITE_SIZE unchanged and moved the time by -5 % (window kernel, stage 2) to +20 % (ring kernel, stage 1).
 template <bool PARTIAL = false>
-__device__ __forceinline__ void store_sbase_bf16x8(unsigned long long sb, unsigned byte_off, unsigned long long lo, unsigned long long hi) {
+__device__ __forceinline__ void store_sbase_h16x8(unsigned long long sb, unsigned byte_off, unsigned long long lo, unsigned long long hi) {
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     const u4v bits = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
     // (a store of more than 8 bytes reads its data registers late: the next VALU write of one of them needs wait states, and

@@ -16,6 +16,7 @@ neighbouring reference views share most of their images, and then every image go
 import collections
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -458,6 +459,15 @@ class MVSDataset(object):
         item["ref_image_path"] = self.image_paths[ids[0]]
         return item
 
+    def view_records(self, fusion_num=10):
+        """The view list the fusion step works from (fuse/fusion_3d_normal.py:98-99, 227-249: viewpair.txt read again with
+        fusion_num sources -- not predict's view_num): per item {"name": the reference view's product name, "src": the names of
+        ALL its listed sources up to fusion_num, "id": the 1-based position of the image in the block's image list (what
+        Fuse_Depth_Map.read_ImageID counts, :284-303; 0 means "not visible" in the visibility planes)}.  No image is read."""
+        name = lambda i: os.path.splitext(str(self.image_params_dict[i].name))[0]
+        return [{"name": name(s[0]), "src": [name(j) for j in s[1:1 + fusion_num]], "id": int(s[0]) + 1, "image": int(s[0])}
+                for s in self.sample_list]
+
     def device_item(self, idx):
         ids = self.sample_list[idx][:self.view_num]
         views = [self._view(i) for i in ids]
@@ -482,3 +492,6 @@ class DeviceItems(object):
 
     def __getitem__(self, idx):
         return self.dataset.device_item(idx)
+
+    def view_records(self, fusion_num=10):
+        return self.dataset.view_records(fusion_num)

@@ -330,7 +330,7 @@ def fpn_output(lateral, x, coarse, head, wide=None):
 
 
 def _feature_precision_is_fp32():
-    return _cfg.get("D3D_FEATURE_PRECISION") != "follow" or ops.conv_precision() != "bf16"
+    return _cfg.get("D3D_FEATURE_PRECISION") != "follow" or ops.conv_precision() != "h16"
 
 
 class Conv2d(nn.Module):

@@ -238,10 +238,10 @@ def variance_volume_cl(feats, proj34, depth, layout="cl"):
     C, h, w = _check_feats(feats, proj34)
     dp, mode, D = _depth(depth, h, w)
     if C % 8 == 0:
-        out = torch.empty((D, C // 8, h, w, 8) if layout == "cl8" else (D, h, w, C), dtype=torch.bfloat16, device=feats[0].device)
+        out = torch.empty((D, C // 8, h, w, 8) if layout == "cl8" else (D, h, w, C), dtype=h16_dtype(), device=feats[0].device)
         arr = _ptr_array(feats, "feats")
         ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
-        name = "d3d_variance_volume_cl8_bf16" if layout == "cl8" else "d3d_variance_volume_cl_bf16"
+        name = "d3d_variance_volume_cl8_h16" if layout == "cl8" else "d3d_variance_volume_cl_h16"
         rc = getattr(_lib.load(), name)(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
                                         ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
@@ -377,7 +377,7 @@ def slice_head_regress(up, weight, bias, transposed, dplane, max_p, sum_d, sum_p
     the online regression update of that plane (adamvs.py:514-525) in ONE streaming kernel: `reg` never reaches memory.  bf16
     mode only (operands rounded to bf16 as the matrix cores round them).  Returns False when the fused kernel does not apply
     (the caller then runs the layer and online_regress_update)."""
-    if conv_precision() != "bf16" or _cfg.off("head_fused") or up.dim() != 3 or up.shape[0] != 8 or bias is None:
+    if conv_precision() != "h16" or _cfg.off("head_fused") or up.dim() != 3 or up.shape[0] != 8 or bias is None:
         return False
     _, h, w = up.shape
     H, W = (2 * h, 2 * w) if transposed else (h, w)
@@ -386,20 +386,20 @@ def slice_head_regress(up, weight, bias, transposed, dplane, max_p, sum_d, sum_p
     if w % (2 if transposed else 4):
         return False
     hd, wd = dplane.shape
-    wr = derived_weight(weight, "bf16round", lambda t: t.to(torch.bfloat16).float().contiguous())   # the matrix cores' rounding, once
-    rc = _lib.load().d3d_slice_head_regress_bf16(_chk(up, "up", 3), _chk(wr, "weight"), _chk(bias, "bias"), int(bool(transposed)),
+    wr = derived_weight(weight, "h16round", lambda t: t.to(h16_dtype()).float().contiguous())   # the matrix cores' rounding, once
+    rc = _lib.load().d3d_slice_head_regress_h16(_chk(up, "up", 3), _chk(wr, "weight"), _chk(bias, "bias"), int(bool(transposed)),
                                                  _chk(dplane, "dplane", 2), hd, wd, h, w, _chk(max_p, "max_p", 2),
                                                  _chk(sum_d, "sum_d", 2), _chk(sum_p, "sum_p", 2), _stream())
-    _lib.check(rc, "d3d_slice_head_regress_bf16")
+    _lib.check(rc, "d3d_slice_head_regress_h16")
     dispatch_counts["slice_head_regress"] += 1
     return True
 
 
 def slice_tail_regress(state2, w_up, b_up, state1, w_head, b_head, dplane, max_p, sum_d, sum_p):
     """relu(upconv1(state2) + state1) -> upconv2d -> online regression update (adamvs.py:413-418, 423-425, 514-525) in ONE kernel
-    for the stages whose head is the stride-2 ConvTranspose2d: `up` and `reg` never reach memory (d3d_slice_tail_regress_bf16; bit
+    for the stages whose head is the stride-2 ConvTranspose2d: `up` and `reg` never reach memory (d3d_slice_tail_regress_h16; bit
     for bit what convtranspose2d_k3s2 + slice_head_regress give).  bf16 mode only; False when it does not apply."""
-    if conv_precision() != "bf16" or _cfg.off("tail_fused") or _cfg.off("head_fused") or state2.dim() != 3 or state2.shape[0] != 16 \
+    if conv_precision() != "h16" or _cfg.off("tail_fused") or _cfg.off("head_fused") or state2.dim() != 3 or state2.shape[0] != 16 \
             or b_up is None or b_head is None:
         return False
     _, h, w = state2.shape
@@ -408,14 +408,14 @@ def slice_tail_regress(state2, w_up, b_up, state1, w_head, b_head, dplane, max_p
         return False
     hd, wd = dplane.shape
     wp = derived_weight(w_up, "t2dbf16", _pack_t2d_bf16)
-    wr = derived_weight(w_head, "bf16round", lambda t: t.to(torch.bfloat16).float().contiguous())
-    rc = _lib.load().d3d_slice_tail_regress_bf16(_chk(state2, "state2", 3), ctypes.c_void_p(wp.data_ptr()), _chk(b_up, "b_up"),
+    wr = derived_weight(w_head, "h16round", lambda t: t.to(h16_dtype()).float().contiguous())
+    rc = _lib.load().d3d_slice_tail_regress_h16(_chk(state2, "state2", 3), ctypes.c_void_p(wp.data_ptr()), _chk(b_up, "b_up"),
                                                  _chk(state1, "state1", 3), _chk(wr, "w_head"), _chk(b_head, "b_head"),
                                                  _chk(dplane, "dplane", 2), hd, wd, h, w, _chk(max_p, "max_p", 2),
                                                  _chk(sum_d, "sum_d", 2), _chk(sum_p, "sum_p", 2), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return False
-    _lib.check(rc, "d3d_slice_tail_regress_bf16")
+    _lib.check(rc, "d3d_slice_tail_regress_h16")
     dispatch_counts["slice_tail_regress"] += 1
     return True
 
@@ -467,8 +467,8 @@ def resize_bilinear(x, H, W):
     return out
 
 
-def _pack_c8_bf16(w):
-    """[8,Ci,3,3,3] -> the B operands of v_mfma_f32_16x16x32_bf16 for d3d_conv3d_k3_c8_bf16: [kz][K block][lane][8] bf16
+def _pack_c8_bf16(w, dt=None):
+    """[8,Ci,3,3,3] -> the B operands of v_mfma_f32_16x16x32_bf16 for d3d_conv3d_k3_c8_h16: [kz][K block][lane][8] bf16
     with K = (ky, kx, ci) padded to a multiple of 32 and the 8 output channels in columns 0..7 of 16 (rest zero);
     lane l holds column l & 15, rows 8 * (l >> 4) .. + 7 of its block.  Returned as int16 bits."""
     Co, Ci = w.shape[0], w.shape[1]
@@ -479,26 +479,26 @@ def _pack_c8_bf16(w):
     # w[n, ci, kz, ky, kx] -> b[kz, (ky*3+kx)*Ci + ci, n]
     b[:, :K, :Co] = w.permute(2, 3, 4, 1, 0).reshape(3, K, Co)
     b = b.reshape(3, nkb, 4, 8, ntn, 16).permute(0, 1, 4, 2, 5, 3)      # [kz][kb][ntile][kgroup][n][j]
-    return b.reshape(3, nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+    return b.reshape(3, nkb, ntn, 64, 8).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
 def _pack_c8_kzfold_bf16x3(w):
     """[1,Ci,3,3,3] -> the B operands of d3d_conv3d_k3_c1_bf16x3: [hi | mid | lo] x _pack_c8_kzfold_bf16."""
-    return torch.stack([_pack_c8_kzfold_bf16(part) for part in _split3_bf16(w)]).contiguous()
+    return torch.stack([_pack_c8_kzfold_bf16(part, torch.bfloat16) for part in _split3_bf16(w)]).contiguous()
 
 
 def _pack_t2_bf16x3(w):
     """nn.ConvTranspose3d weight [Ci,Co,3,3,3] -> the B operands of d3d_convtranspose3d_k3s2_zs_bf16x3: [hi | mid | lo] x _pack_t2_bf16."""
-    return torch.stack([_pack_t2_bf16(part) for part in _split3_bf16(w)]).contiguous()
+    return torch.stack([_pack_t2_bf16(part, torch.bfloat16) for part in _split3_bf16(w)]).contiguous()
 
 
 def _pack_c8_bf16x3(w):
     """[Co,Ci,3,3,3] -> the B operands of d3d_conv3d_k3_zs_bf16x3: [hi | mid | lo] x _pack_c8_bf16 (the exact three-way bf16 split)."""
-    return torch.stack([_pack_c8_bf16(part) for part in _split3_bf16(w)]).contiguous()
+    return torch.stack([_pack_c8_bf16(part, torch.bfloat16) for part in _split3_bf16(w)]).contiguous()
 
 
-def _pack_c8_kzfold_bf16(w):
-    """nn.Conv3d weight [1,Ci,3,3,3] -> B operands of d3d_conv3d_k3_c1_cl_bf16: ONE tile per K block whose columns 0, 1, 2 are
+def _pack_c8_kzfold_bf16(w, dt=None):
+    """nn.Conv3d weight [1,Ci,3,3,3] -> B operands of d3d_conv3d_k3_c1_cl_h16: ONE tile per K block whose columns 0, 1, 2 are
     the k_z = 0, 1, 2 slices (K = (k_y, k_x, c_in), padded to a multiple of 32); [K block][lane][8], lane l = column l & 15,
     K rows 8 * (l >> 4) .. + 7.  int16 bits (bf16)."""
     Ci = w.shape[1]
@@ -507,7 +507,7 @@ def _pack_c8_kzfold_bf16(w):
     b = torch.zeros((nkb * 32, 16), dtype=torch.float32, device=w.device)
     b[:K, :3] = w[0].permute(2, 3, 0, 1).reshape(K, 3)          # [ci, kz, ky, kx] -> [ky, kx, ci, kz] -> rows (ky*3+kx)*Ci + ci, column kz
     b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)            # [kb][kgroup][n][j]
-    return b.reshape(nkb, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+    return b.reshape(nkb, 64, 8).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
 def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1):
@@ -519,7 +519,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
     # C_out = 1 (the probability layer, cas_mvsnet.py:110) has its own streaming VALU kernel behind d3d_conv3d_k3: a
     # single output channel fills 1/16 of a matrix-core tile (D3D_CONV_CO1=0 sends it through the folded MFMA form)
     if stride == 1 and ((Ci in (8, 16, 32) and Co in (8, 16)) or (Ci, Co) in ((32, 32), (64, 64))) and W % 4 == 0 and _use_mfma() \
-            and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
+            and conv_precision() != "h16" and _cfg.get("D3D_CONV_C8X3") != "0":
         # fp32 mode of conv0 and conv2 (cas_mvsnet.py:84,87): the z-streaming matrix-core kernel on three-way bf16 splits of both
         # operands -- fp32 accuracy (six products per K block), each plane staged once.  Against the kernels it replaces
         # (tools/x3_bench.py): conv0 32 -> 8 / 16 -> 8 / 8 -> 8 at the three stage volumes 2.65 / 3.22 / 1.85 -> 2.47 / 2.84 / 1.69 ms,
@@ -535,7 +535,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
             _lib.check(rc, "d3d_conv3d_k3_zs_bf16x3")
             return out
     if Co == 8 and stride == 1 and Ci % 8 == 0 and _use_mfma() and not _cfg.off("co8") \
-            and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
+            and conv_precision() != "h16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv0 of every CostRegNet): z-streaming kernel on the fp32 vector units (same peak as the fp32 matrix
         # cores, which an 8-row GEMM half fills); weights re-laid out [Ci][ky][kx][kz][8] once per parameter version
         wp = derived_weight(weight, "co8", lambda w: w.permute(1, 3, 4, 2, 0))
@@ -547,19 +547,19 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
         _lib.check(rc, "d3d_conv3d_k3_co8")
         return out
     if stride == 1 and Ci in (8, 16, 32) and (Co in (8, 16) or (Co == 32 and Ci == 32)) and W % 4 == 0 and _use_mfma() \
-            and conv_precision() == "bf16" and not _cfg.off("c8"):
+            and conv_precision() == "h16" and not _cfg.off("c8"):
         # conv0 / conv2 / conv4 of every CostRegNet with bf16 operands: z-streaming matrix-core kernel (each plane read once)
         wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
         out = torch.empty((Co, D, H, W), dtype=torch.float32, device=x.device)
         if skip is not None and skip.shape != out.shape:
             raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
-        rc = _lib.load().d3d_conv3d_k3_zs_bf16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+        rc = _lib.load().d3d_conv3d_k3_zs_h16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
                                                _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
                                                _chk(out, "out"), _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_conv3d_k3_zs_bf16")
+            _lib.check(rc, "d3d_conv3d_k3_zs_h16")
             return out
-    if Co == 1 and stride == 1 and Ci == 8 and W % 4 == 0 and _use_mfma() and conv_precision() != "bf16" \
+    if Co == 1 and stride == 1 and Ci == 8 and W % 4 == 0 and _use_mfma() and conv_precision() != "h16" \
             and _cfg.get("D3D_CONV_C8X3") == "all":
         # fp32 mode of the probability layer (cas_mvsnet.py:110) on the k_z-folded matrix-core kernel with split operands: built
         # and tested, but SLOWER than the vector-unit kernel it would replace (0.25 / 0.59 / 0.61 -> 0.34 / 0.87 / 0.85 ms at the
@@ -575,7 +575,7 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
             _lib.check(rc, "d3d_conv3d_k3_c1_bf16x3")
             return out
     if stride == 2 and (Ci, Co) in ((8, 16), (16, 32), (32, 64)) and ((W - 1) // 2 + 1) % 4 == 0 and _use_mfma() \
-            and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
+            and conv_precision() != "h16" and _cfg.get("D3D_CONV_C8X3") != "0":
         # fp32 mode of conv1 / conv3 / conv5 (cas_mvsnet.py:86,89,92): the stride-2 z-streaming kernel on three-way bf16 splits
         # (csrc/conv_s2x3.hip) instead of the vector-unit stream kernels
         wp = derived_weight(weight, "c8bf16x3", _pack_c8_bf16x3)
@@ -606,8 +606,8 @@ def conv3d_k3(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1)
     return out
 
 
-def _pack_t2_bf16(w):
-    """nn.ConvTranspose3d weight [Ci,Co,3,3,3] -> B operands of v_mfma_f32_16x16x32_bf16 for d3d_convtranspose3d_k3s2_zs_bf16.
+def _pack_t2_bf16(w, dt=None):
+    """nn.ConvTranspose3d weight [Ci,Co,3,3,3] -> B operands of v_mfma_f32_16x16x32_bf16 for d3d_convtranspose3d_k3s2_zs_h16.
     Output parity class (pz,py,px), in the order pz*4 + py*2 + px: taps (dz,dy,dx), d <= p per dimension, enumerated dz-major;
     an even output coordinate uses kernel index 1 (d = 0), an odd one index 2 (d = 0) and 0 (d = 1).  K = (tap, ci) padded to
     a multiple of 32, output channels padded to a multiple of 16; per class [K block][N tile][lane][8] with lane l holding
@@ -627,11 +627,11 @@ def _pack_t2_bf16(w):
         # [kb][kgroup][j][nt][n] -> [kb][nt][kgroup][n][j]
         b = b.reshape(nkb, 4, 8, ntn, 16).permute(0, 3, 1, 4, 2)
         parts.append(b.reshape(nkb * ntn * 64, 8))
-    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+    return torch.cat(parts).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
-def _pack_t2_fold_bf16(w):
-    """ConvTranspose3d weight [Ci,8,3,3,3] -> A operands of the x-folded form of d3d_convtranspose3d_k3s2_cl_bf16: per output
+def _pack_t2_fold_bf16(w, dt=None):
+    """ConvTranspose3d weight [Ci,8,3,3,3] -> A operands of the x-folded form of d3d_convtranspose3d_k3s2_cl_h16: per output
     parity class (pz,py), K = (taps (dz,dy,dx) with dx in {0,1}, dz-major) x ci, GEMM row r = px * 8 + channel: the even
     column (px = 0) uses kernel column 1 of the dx = 0 taps (its dx = 1 entries are zero), the odd one column 2 (dx = 0)
     and 0 (dx = 1).  [class][K block][lane][8], lane l = row l & 15, K rows 8 * (l >> 4) .. + 7.  int16 bits (bf16)."""
@@ -652,7 +652,7 @@ def _pack_t2_fold_bf16(w):
             b[t * Ci:(t + 1) * Ci, 8:16] = w[:, :, kz, ky, kmap[(1, dx)]]
         b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)      # [kb][kgroup][row][j]
         parts.append(b.reshape(nkb * 64, 8))
-    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+    return torch.cat(parts).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
 def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True):
@@ -661,7 +661,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
     Co = weight.shape[1]
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() != "bf16" and _cfg.get("D3D_CONV_C8X3") != "0":
+    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() != "h16" and _cfg.get("D3D_CONV_C8X3") != "0":
         # fp32 mode of conv11, conv9 and conv7 (cas_mvsnet.py:103, 100, 97: 16 -> 8 to the full-resolution volume, 32 -> 16, 64 -> 32): the per-parity matrix-core kernel on
         # three-way bf16 splits of both operands (fp32 accuracy, see conv3d_k3)
         wp = derived_weight(weight, "t2bf16x3", _pack_t2_bf16x3)
@@ -675,7 +675,7 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
             _lib.check(rc, "d3d_convtranspose3d_k3s2_zs_bf16x3")
             return out
     if Co == 8 and Ci % 8 == 0 and _use_mfma() and not _cfg.off("co8") \
-            and conv_precision() != "bf16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
+            and conv_precision() != "h16" and 7 * D * H * W * 4 + H * W * 4 < 2 ** 31:
         # C_out = 8 (conv11 of every CostRegNet): z-streaming kernel on the fp32 vector units, weights [Ci][kz][ky][kx][8]
         wp = derived_weight(weight, "coT8", lambda w: w.permute(0, 2, 3, 4, 1))
         out = torch.empty((8, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
@@ -686,18 +686,18 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
                                                       _chk(out, "out"), _stream())
         _lib.check(rc, "d3d_convtranspose3d_k3s2_co8")
         return out
-    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() == "bf16" \
+    if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)) and _use_mfma() and conv_precision() == "h16" \
             and not _cfg.off("t2"):
         # decoder layers of CostRegNet with bf16 operands: eight per-parity dense convolutions on the matrix cores, z-streaming
         wp = derived_weight(weight, "t2bf16", _pack_t2_bf16)
         out = torch.empty((Co, 2 * D, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
         if skip is not None and skip.shape != out.shape:
             raise ValueError("skip shape %s != output shape %s" % (tuple(skip.shape), tuple(out.shape)))
-        rc = _lib.load().d3d_convtranspose3d_k3s2_zs_bf16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+        rc = _lib.load().d3d_convtranspose3d_k3s2_zs_h16(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
                                                           _opt(shift, "shift"), _opt(skip, "skip"), int(relu), Ci, Co, D, H, W,
                                                           _chk(out, "out"), _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_convtranspose3d_k3s2_zs_bf16")
+            _lib.check(rc, "d3d_convtranspose3d_k3s2_zs_h16")
             return out
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=1 if relu else 0)
@@ -715,16 +715,16 @@ def convtranspose3d_k3s2(x, weight, scale=None, shift=None, skip=None, relu=True
 
 # ----------------------------------------------------------------------------------------
 # Channel-last bf16 volumes: what the CostRegNet layers hand to each other in bf16 mode (BASELINE config 3).
-# A "CL" volume is a torch.bfloat16 tensor [D,H,W,C]; a planar one the usual float32 [C,D,H,W].
+# A "CL" volume is a 16-bit tensor (h16_dtype(): torch.float16 unless the library was built for bfloat16) [D,H,W,C]; a planar one the usual float32 [C,D,H,W].
 # ----------------------------------------------------------------------------------------
 def channel_last_enabled():
     return not _cfg.off("cl")
 
 
 def _chk_cl(t, name, cl8=False):
-    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == h16_dtype() and t.is_contiguous()
             and (t.dim() == 4 or (cl8 and t.dim() == 5 and t.shape[4] == 8))):
-        raise TypeError("%s must be a contiguous CUDA bfloat16 tensor [D,H,W,C]%s" % (name, " or [D,C/8,H,W,8]" if cl8 else ""))
+        raise TypeError("%s must be a contiguous CUDA 16-bit (ops.h16_dtype()) tensor [D,H,W,C]%s" % (name, " or [D,C/8,H,W,8]" if cl8 else ""))
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -733,9 +733,9 @@ def to_cl(x):
     C, D, H, W = x.shape
     if C % 8:
         raise ValueError("channel-last volumes need C % 8 == 0 (got %d)" % C)
-    out = torch.empty((D, H, W, C), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().d3d_volume_planar_to_cl_bf16(_chk(x, "x", 4), C, D * H * W, _chk_cl(out, "out"), _stream()),
-               "d3d_volume_planar_to_cl_bf16")
+    out = torch.empty((D, H, W, C), dtype=h16_dtype(), device=x.device)
+    _lib.check(_lib.load().d3d_volume_planar_to_cl_h16(_chk(x, "x", 4), C, D * H * W, _chk_cl(out, "out"), _stream()),
+               "d3d_volume_planar_to_cl_h16")
     return out
 
 
@@ -745,20 +745,20 @@ def from_cl(x):
     if C % 8:
         raise ValueError("channel-last volumes need C % 8 == 0 (got %d)" % C)
     out = torch.empty((C, D, H, W), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().d3d_volume_cl_bf16_to_planar(_chk_cl(x, "x"), C, D * H * W, _chk(out, "out"), _stream()),
-               "d3d_volume_cl_bf16_to_planar")
+    _lib.check(_lib.load().d3d_volume_cl_h16_to_planar(_chk_cl(x, "x"), C, D * H * W, _chk(out, "out"), _stream()),
+               "d3d_volume_cl_h16_to_planar")
     return out
 
 
 def _planar(t):
-    return None if t is None else (from_cl(t) if t.dtype == torch.bfloat16 else t)
+    return None if t is None else (from_cl(t) if t.dtype == h16_dtype() else t)
 
 
 def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride=1, out_cl=True):
     """conv3d_k3 with bf16 operands on either activation format: x planar fp32 [Ci,D,H,W] or CL bf16 [D,H,W,Ci];
     returns CL [Do,Ho,Wo,Co] (out_cl) or planar fp32 [Co,Do,Ho,Wo]; `skip` comes in the output's format.  Shapes the
     channel-last kernels do not take go through the planar kernels and the two format conversions."""
-    in_cl = x.dtype == torch.bfloat16
+    in_cl = x.dtype == h16_dtype()
     cl8 = in_cl and x.dim() == 5   # [D,Ci/8,H,W,8]: the sweep kernels' CL8 volume (stride-1 layers on the conv0 kernel family)
     if cl8 and (stride != 1 or x.shape[4] != 8):
         raise ValueError("a CL8 input [D,Ci/8,H,W,8] is taken by the stride-1 layers only")
@@ -769,38 +769,38 @@ def conv3d_k3_cl(x, weight, scale=None, shift=None, skip=None, relu=True, stride
         raise ValueError("weight must be [Co,%d,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     o = lambda n: (n - 1) // stride + 1
     oshape = (o(D), o(H), o(W), Co) if out_cl else (Co, o(D), o(H), o(W))
-    if skip is not None and (tuple(skip.shape) != oshape or (skip.dtype == torch.bfloat16) != bool(out_cl)):
+    if skip is not None and (tuple(skip.shape) != oshape or (skip.dtype == h16_dtype()) != bool(out_cl)):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
     xp = _chk_cl(x, "x", cl8=True) if in_cl else _chk(x, "x", 4)
     fmt = 2 if cl8 else int(in_cl)
     sp = None if skip is None else (_chk_cl(skip, "skip") if out_cl else _chk(skip, "skip"))
     wp = derived_weight(weight, "c8bf16", _pack_c8_bf16)
     wptr = ctypes.c_void_p(wp.data_ptr())
-    out = torch.empty(oshape, dtype=torch.bfloat16 if out_cl else torch.float32, device=x.device)
+    out = torch.empty(oshape, dtype=h16_dtype() if out_cl else torch.float32, device=x.device)
     optr = ctypes.c_void_p(out.data_ptr())
     rc = _lib.ERR_UNSUPPORTED
     if stride == 1 and Co == 1 and not out_cl and not _cfg.off("kzfold"):
         # the probability layer: k_z folded into the columns of one operand tile
         wf = derived_weight(weight, "c8kzfold", _pack_c8_kzfold_bf16)
-        rc = _lib.load().d3d_conv3d_k3_c1_cl_bf16(xp, fmt, ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
+        rc = _lib.load().d3d_conv3d_k3_c1_cl_h16(xp, fmt, ctypes.c_void_p(wf.data_ptr()), _opt(scale, "scale"),
                                                   _opt(shift, "shift"), sp, int(relu), Ci, D, H, W, optr, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_conv3d_k3_c1_cl_bf16")
+            _lib.check(rc, "d3d_conv3d_k3_c1_cl_h16")
             dispatch_counts["conv3d_cl"] += 1
             return out
     if stride == 1:
-        rc = _lib.load().d3d_conv3d_k3_cl_bf16(xp, fmt, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
+        rc = _lib.load().d3d_conv3d_k3_cl_h16(xp, fmt, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu),
                                                Ci, Co, D, H, W, optr, int(out_cl), _stream())
     elif stride == 2 and in_cl and out_cl:
-        rc = _lib.load().d3d_conv3d_k3s2_cl_bf16(xp, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu), Ci, Co,
+        rc = _lib.load().d3d_conv3d_k3s2_cl_h16(xp, wptr, _opt(scale, "scale"), _opt(shift, "shift"), sp, int(relu), Ci, Co,
                                                  D, H, W, optr, _stream())
     if rc != _lib.ERR_UNSUPPORTED:
-        _lib.check(rc, "d3d_conv3d_k3_cl_bf16" if stride == 1 else "d3d_conv3d_k3s2_cl_bf16")
+        _lib.check(rc, "d3d_conv3d_k3_cl_h16" if stride == 1 else "d3d_conv3d_k3s2_cl_h16")
         dispatch_counts["conv3d_cl8_in" if cl8 else "conv3d_cl"] += 1
         return out
     dispatch_counts["conv3d_cl_fallback"] += 1
     saved = _cfg.state.conv_precision
-    _cfg.state.conv_precision = "bf16"
+    _cfg.state.conv_precision = "h16"
     try:
         y = conv3d_k3(_planar(cl8_to_cl(x) if cl8 else x), weight, scale, shift, _planar(skip), relu=relu, stride=stride)
     finally:
@@ -815,23 +815,23 @@ def convtranspose3d_k3s2_cl(x, weight, scale=None, shift=None, skip=None, relu=T
     if tuple(weight.shape) != (Ci, Co, 3, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     oshape = (2 * D, 2 * H, 2 * W, Co)
-    if skip is not None and (tuple(skip.shape) != oshape or skip.dtype != torch.bfloat16):
+    if skip is not None and (tuple(skip.shape) != oshape or skip.dtype != h16_dtype()):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape))
     if (Ci, Co) in ((16, 8), (16, 16), (32, 16), (64, 32)):
         fold = (Ci, Co) == (16, 8) and not _cfg.off("t2fold")   # conv11: both column parities in one GEMM
         wp = derived_weight(weight, "t2foldbf16", _pack_t2_fold_bf16) if fold else derived_weight(weight, "t2bf16", _pack_t2_bf16)
-        out = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
-        rc = _lib.load().d3d_convtranspose3d_k3s2_cl_bf16(_chk_cl(x, "x"), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+        out = torch.empty(oshape, dtype=h16_dtype(), device=x.device)
+        rc = _lib.load().d3d_convtranspose3d_k3s2_cl_h16(_chk_cl(x, "x"), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
                                                           _opt(shift, "shift"), None if skip is None else _chk_cl(skip, "skip"),
                                                           int(relu), Ci, Co, D, H, W, ctypes.c_void_p(out.data_ptr()),
                                                           2 if fold else 1, _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_convtranspose3d_k3s2_cl_bf16")
+            _lib.check(rc, "d3d_convtranspose3d_k3s2_cl_h16")
             dispatch_counts["convtranspose3d_cl"] += 1
             return out
     dispatch_counts["conv3d_cl_fallback"] += 1
     saved = _cfg.state.conv_precision
-    _cfg.state.conv_precision = "bf16"
+    _cfg.state.conv_precision = "h16"
     try:
         y = convtranspose3d_k3s2(from_cl(x), weight, scale, shift, _planar(skip), relu=relu)
     finally:
@@ -843,24 +843,24 @@ def convtranspose3d_prob_cl(x, weight, scale, shift, skip, prob_weight, prob_bia
     """conv11 + prob of a CostRegNet (cas_mvsnet.py:103-105,118-119) in one launch: x CL [D,H,W,16] bf16, skip CL
     [2D,2H,2W,8] bf16 -> planar fp32 [2D,2H,2W] = Conv3d_8->1(skip + act(scale * ConvTranspose3d_16->8(x) + shift)) + bias,
     the 8-channel volume rounded to bf16 as between the two unfused layers (bit-identical to them) but kept in LDS
-    (d3d_convtranspose3d_prob_cl_bf16).  None for shapes the kernel does not take."""
+    (d3d_convtranspose3d_prob_cl_h16).  None for shapes the kernel does not take."""
     D, H, W, Ci = x.shape
     if _cfg.off("t2prob") or _cfg.off("t2fold") or _cfg.off("kzfold") or Ci != 16 or W % 2 \
             or tuple(weight.shape) != (16, 8, 3, 3, 3) or tuple(prob_weight.shape) != (1, 8, 3, 3, 3):
         return None
     oshape = (2 * D, 2 * H, 2 * W)
-    if skip is not None and (tuple(skip.shape) != oshape + (8,) or skip.dtype != torch.bfloat16):
+    if skip is not None and (tuple(skip.shape) != oshape + (8,) or skip.dtype != h16_dtype()):
         raise ValueError("skip %s %s does not match the output %s" % (skip.dtype, tuple(skip.shape), oshape + (8,)))
     wt = derived_weight(weight, "t2foldbf16", _pack_t2_fold_bf16)
     wp = derived_weight(prob_weight, "c8kzfold", _pack_c8_kzfold_bf16)
     out = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    rc = _lib.load().d3d_convtranspose3d_prob_cl_bf16(
+    rc = _lib.load().d3d_convtranspose3d_prob_cl_h16(
         _chk_cl(x, "x"), ctypes.c_void_p(wt.data_ptr()), _opt(scale, "scale"), _opt(shift, "shift"),
         None if skip is None else _chk_cl(skip, "skip"), int(relu), ctypes.c_void_p(wp.data_ptr()), _opt(prob_bias, "prob_bias"),
         D, H, W, ctypes.c_void_p(out.data_ptr()), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_convtranspose3d_prob_cl_bf16")
+    _lib.check(rc, "d3d_convtranspose3d_prob_cl_h16")
     dispatch_counts["convtranspose3d_prob_cl"] += 1
     return out
 
@@ -891,7 +891,7 @@ def conv2d_stream(x, weight, scale, shift, skip, act, x2=None, aux1=None, ep_spl
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
-    if (Co not in (8, 16) or not _use_mfma() or conv_precision() == "bf16" or H * W < _CONV2D_STREAM_MIN
+    if (Co not in (8, 16) or not _use_mfma() or conv_precision() == "h16" or H * W < _CONV2D_STREAM_MIN
             or 8 * H * W * 4 >= 2 ** 31 or _cfg.off("conv2d_stream")
             or (x2 is not None and Ci0 % 8 != 0) or tuple(weight.shape) != (Co, Ci0 + Ci1, 3, 3)):
         return None
@@ -912,8 +912,8 @@ def conv2d_stream(x, weight, scale, shift, skip, act, x2=None, aux1=None, ep_spl
     return out  # pixels from which the vector-unit streaming form of conv2d_k3 is used
 
 
-def _pack_z2_bf16(w):
-    """nn.Conv2d weight [Co,Ci,3,3] -> B operands of v_mfma_f32_16x16x32_bf16 for d3d_conv2d_k3_zs_bf16: K = (k_y, k_x, c_in)
+def _pack_z2_bf16(w, dt=None):
+    """nn.Conv2d weight [Co,Ci,3,3] -> B operands of v_mfma_f32_16x16x32_bf16 for d3d_conv2d_k3_zs_h16: K = (k_y, k_x, c_in)
     padded to a multiple of 32, output channels to a multiple of 16; [K block][N tile][lane][8], lane l = column l & 15,
     K rows 8 * (l >> 4) .. + 7 of its block.  int16 bits (bf16)."""
     Co, Ci = w.shape[0], w.shape[1]
@@ -923,7 +923,7 @@ def _pack_z2_bf16(w):
     b = torch.zeros((nkb * 32, ntn * 16), dtype=torch.float32, device=w.device)
     b[:K, :Co] = w.permute(2, 3, 1, 0).reshape(K, Co)                  # [ky, kx, ci, co]
     b = b.reshape(nkb, 4, 8, ntn, 16).permute(0, 3, 1, 4, 2)           # [kb][ntile][kgroup][n][j]
-    return b.reshape(nkb, ntn, 64, 8).to(torch.bfloat16).view(torch.int16).contiguous()
+    return b.reshape(nkb, ntn, 64, 8).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
 def _pack_z2_f32(w):
@@ -991,15 +991,15 @@ def _split3_bf16(w):
 
 def _pack_z2_bf16x3(w):
     """nn.Conv2d weight [Co,Ci,3,3] -> the B operands of d3d_conv2d_k3_zs_bf16x3: [hi | mid | lo] x _pack_z2_bf16."""
-    return torch.stack([_pack_z2_bf16(part) for part in _split3_bf16(w)]).contiguous()
+    return torch.stack([_pack_z2_bf16(part, torch.bfloat16) for part in _split3_bf16(w)]).contiguous()
 
 
 def _pack_t2d_bf16x3(w):
     """nn.ConvTranspose2d weight [Ci,Co,3,3] -> the B operands of d3d_convtranspose2d_k3s2_zs_bf16x3: [hi | mid | lo] x _pack_t2d_bf16."""
-    return torch.stack([_pack_t2d_bf16(part) for part in _split3_bf16(w)]).contiguous()
+    return torch.stack([_pack_t2d_bf16(part, torch.bfloat16) for part in _split3_bf16(w)]).contiguous()
 
 
-def _pack_t2d_k4_bf16(w):
+def _pack_t2d_k4_bf16(w, dt=None):
     """nn.ConvTranspose2d weight [Ci,Co,4,4] (stride 2, padding 1) -> B operands of the k = 4 transposed tile kernel: per output
     parity class (py,px), order py*2 + px, taps (dy,dx) in {0,1}^2 dy-major; output 2i + p reads input i - 1 + p + d through
     kernel index 3 - p - 2d.  K = (tap, ci), 16 output columns; [K block][lane][8] (bf16 bits)."""
@@ -1014,10 +1014,10 @@ def _pack_t2d_k4_bf16(w):
             b[t * Ci:(t + 1) * Ci, :Co] = w[:, :, 3 - py - 2 * dy, 3 - px - 2 * dx]
         b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)                 # [kb][kgroup][n][j]
         parts.append(b.reshape(nkb * 64, 8))
-    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+    return torch.cat(parts).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
-def _pack_t2d_k4fold_bf16(w):
+def _pack_t2d_k4fold_bf16(w, dt=None):
     """The k = 4 transposed weight [Ci,Co<=8,4,4] with both column parities in one 16-column tile: per row parity py, K =
     (dy in {0,1}, patch column dxx in {0,1,2}, ci); columns 0..7 = even output column (dxx = dx), 8..15 = odd one (dxx = 1 + dx)."""
     Ci, Co = w.shape[0], w.shape[1]
@@ -1034,13 +1034,13 @@ def _pack_t2d_k4fold_bf16(w):
                         b[t * Ci:(t + 1) * Ci, px * 8:px * 8 + Co] = w[:, :, 3 - py - 2 * dy, 3 - px - 2 * dx]
         b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)
         parts.append(b.reshape(nkb * 64, 8))
-    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+    return torch.cat(parts).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
 def _pack_t2d_k4_bf16x3(w):
     """[hi | mid | lo] x the k = 4 packing d3d_convtranspose2d_k4s2_zs_bf16x3 takes: column-folded for C_out <= 8."""
     pack = _pack_t2d_k4fold_bf16 if w.shape[1] <= 8 else _pack_t2d_k4_bf16
-    return torch.stack([pack(part) for part in _split3_bf16(w)]).contiguous()
+    return torch.stack([pack(part, torch.bfloat16) for part in _split3_bf16(w)]).contiguous()
 
 
 def upsampled_conv_weight(w3):
@@ -1081,12 +1081,12 @@ def _z2_fp32_entry():
 
 def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1=None, ep_split=0, skip_after_act=False, gn=None):
     """3x3 stride-1 conv over cat(x, x2) on the tile kernel with the fused epilogues of the slice regularisers (act 0 | 1 |
-    2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_bf16) -- bf16 matrix-core operands in bf16 mode; fp32 accuracy otherwise
+    2 GRU gates | 3 GRU update: see d3d_conv2d_k3_zs_h16) -- bf16 matrix-core operands in bf16 mode; fp32 accuracy otherwise
     (d3d_conv2d_k3_zs_bf16x3: three-way bf16 splits, or with D3D_CONV2D_FP32=f32 the fp32 instruction of d3d_conv2d_k3_zs_f32).  Returns None for shapes the kernel does not take."""
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
-    Ci, bf16 = Ci0 + Ci1, conv_precision() == "bf16"
+    Ci, bf16 = Ci0 + Ci1, conv_precision() == "h16"
     ok = (Ci in (8, 16, 32) and Co <= 32) or (Ci == 48 and Co <= 48) or (bf16 and Ci in (24, 40) and Co <= 16)   # 48 -> 48: the pair-visibility UNet; 24 | 40: RED-Net's conv_gru1 at stages 2 / 1
     if ok and W % 4 and x2 is None and aux1 is None and act in (0, 1) and H * W <= 256 * 256 and Ci0 % 8 == 0:
         # small images whose width is not a multiple of 4 (the coarsest UNet level, 58 x 86): zero columns on the right are the
@@ -1105,17 +1105,17 @@ def conv2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, aux1
         if ga is not None:   # the layer and the GroupNorm statistics of its output in one launch
             wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
             out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
-            rc = lib.d3d_conv2d_k3_zs_bf16_gn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()), _chk(shift, "shift"),
+            rc = lib.d3d_conv2d_k3_zs_h16_gn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()), _chk(shift, "shift"),
                                               Co, H, W, _chk(out, "out"), ctypes.c_void_p(ga[0].data_ptr()), int(ga[1]), _stream())
             if rc != _lib.ERR_UNSUPPORTED:
-                _lib.check(rc, "d3d_conv2d_k3_zs_bf16_gn")
+                _lib.check(rc, "d3d_conv2d_k3_zs_h16_gn")
                 dispatch_counts["conv2d_tile"] += 1
                 dispatch_counts["conv2d_gn_fused"] += 1
                 return out
             gn.slot = None   # (not taken: nothing was launched, the slot stays zero for the next request of this lap)
             _gn_arenas[(x.device.index, torch.cuda.current_stream(x.device).cuda_stream)][1] -= 1
     if bf16:
-        name, wp = "d3d_conv2d_k3_zs_bf16", derived_weight(weight, "z2bf16", _pack_z2_bf16)
+        name, wp = "d3d_conv2d_k3_zs_h16", derived_weight(weight, "z2bf16", _pack_z2_bf16)
     elif _z2_fp32_entry() == "x3" and Ci != 48:   # (split cells of 48 channels + their weights do not fit the LDS)
         name, wp = "d3d_conv2d_k3_zs_bf16x3", derived_weight(weight, "z2bf16x3", _pack_z2_bf16x3)
     else:
@@ -1136,7 +1136,7 @@ def conv2d_k3_pair3(x, w0, scale0, shift0, act0, w1, scale1, shift1, act1):
     (module.py:663-666) -- in ONE launch of the tile kernel: the 8-channel map between the layers never reaches memory
     (d3d_conv2d_k3_pair3_bf16x3; bit for bit what conv2d_stream followed by conv2d_zs give, which is what conv2d_k3 runs for the
     two layers in the fp32 precision of the feature nets at these sizes).  x [3,H,W].  None when it does not apply."""
-    if x.dim() != 3 or x.shape[0] != 3 or conv_precision() == "bf16" or _z2_fp32_entry() != "x3" or not _use_mfma() \
+    if x.dim() != 3 or x.shape[0] != 3 or conv_precision() == "h16" or _z2_fp32_entry() != "x3" or not _use_mfma() \
             or _cfg.off("conv0_pair") or _cfg.off("conv2d_zs") or _cfg.off("conv2d_stream"):
         return None
     _, H, W = x.shape
@@ -1182,7 +1182,7 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     Ci, H, W = x.shape
     Co = weight.shape[0]
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    bf16 = conv_precision() == "bf16"
+    bf16 = conv_precision() == "h16"
     x3 = not bf16 and _z2_fp32_entry() == "x3" and Ci != 48
     wide = Ci == 48 and Co <= 48 and W % 4 == 0   # the pair-visibility UNet: the stride-1 kernel with a subsampled store
     if not wide and (Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4) or act not in (0, 1) \
@@ -1191,7 +1191,7 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     if tuple(weight.shape) != (Co, Ci, 3, 3):
         raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
     if bf16:
-        fn, wp = _lib.load().d3d_conv2d_k3s2_zs_bf16, derived_weight(weight, "z2bf16", _pack_z2_bf16)
+        fn, wp = _lib.load().d3d_conv2d_k3s2_zs_h16, derived_weight(weight, "z2bf16", _pack_z2_bf16)
     elif x3:
         fn, wp = _lib.load().d3d_conv2d_k3s2_zs_bf16x3, derived_weight(weight, "z2bf16x3", _pack_z2_bf16x3)
     else:
@@ -1207,8 +1207,8 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     return out
 
 
-def _pack_t2d_bf16(w):
-    """nn.ConvTranspose2d weight [Ci,Co,3,3] -> B operands for d3d_convtranspose2d_k3s2_zs_bf16: per output parity class
+def _pack_t2d_bf16(w, dt=None):
+    """nn.ConvTranspose2d weight [Ci,Co,3,3] -> B operands for d3d_convtranspose2d_k3s2_zs_h16: per output parity class
     (py,px), order py*2 + px, taps (dy,dx) with d <= p per dimension, dy-major; an even output coordinate uses kernel index 1
     (d = 0), an odd one index 2 (d = 0) and 0 (d = 1).  K = (tap, ci) padded to 32, 16 output columns; [K block][lane][8]."""
     Ci, Co = w.shape[0], w.shape[1]
@@ -1224,7 +1224,7 @@ def _pack_t2d_bf16(w):
             b[t * Ci:(t + 1) * Ci, :Co] = w[:, :, kmap[(py, dy)], kmap[(px, dx)]]
         b = b.reshape(nkb, 4, 8, 16).permute(0, 1, 3, 2)                 # [kb][kgroup][n][j]
         parts.append(b.reshape(nkb * 64, 8))
-    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous()
+    return torch.cat(parts).to(dt or h16_dtype()).view(torch.int16).contiguous()
 
 
 def _pack_t2d_f32(w):
@@ -1253,8 +1253,8 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
         return None
     if tuple(weight.shape) != (Ci, Co, 3, 3):
         raise ValueError("weight must be [%d,Co,3,3] (got %s)" % (Ci, tuple(weight.shape)))
-    if conv_precision() == "bf16":
-        fn, wp = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16, derived_weight(weight, "t2dbf16", _pack_t2d_bf16)
+    if conv_precision() == "h16":
+        fn, wp = _lib.load().d3d_convtranspose2d_k3s2_zs_h16, derived_weight(weight, "t2dbf16", _pack_t2d_bf16)
     elif _z2_fp32_entry() == "x3":
         fn, wp = _lib.load().d3d_convtranspose2d_k3s2_zs_bf16x3, derived_weight(weight, "t2dbf16x3", _pack_t2d_bf16x3)
     else:
@@ -1273,34 +1273,34 @@ def convtranspose2d_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip
 
 def conv2d_wide(x, weight, scale=None, shift=None, skip=None, act=0, x2=None, gn=None):
     """3x3 stride-1 conv over cat(x, x2) with 64 | 128 input channels (parts of 32) and 32 | 64 | 128 output channels on the
-    bf16 matrix cores, K walked in chunks of 32 channels (d3d_conv2d_k3_wide_bf16, csrc/conv2d_wide.hip: the coarse conv-GRU
+    bf16 matrix cores, K walked in chunks of 32 channels (d3d_conv2d_k3_wide_h16, csrc/conv2d_wide.hip: the coarse conv-GRU
     levels of the RED-Net slice regulariser).  bf16 mode only; None for other shapes."""
     Ci0, H, W = x.shape
     Ci1 = 0 if x2 is None else x2.shape[0]
     Co = weight.shape[0]
-    if conv_precision() != "bf16" or _cfg.off("conv2d_wide") or (Ci0 + Ci1) not in (64, 128) or Ci0 % 32 or Ci1 % 32 \
+    if conv_precision() != "h16" or _cfg.off("conv2d_wide") or (Ci0 + Ci1) not in (64, 128) or Ci0 % 32 or Ci1 % 32 \
             or Co not in (32, 64, 128) or act not in (0, 1) or not _use_mfma():
         return None
     wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
     out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
     ga = _gn_args(gn, Co, act, scale, skip, x.device) if shift is not None else None
     if ga is not None:   # the layer and the GroupNorm statistics of its output in one launch
-        rc = _lib.load().d3d_conv2d_k3_wide_bf16_gn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
+        rc = _lib.load().d3d_conv2d_k3_wide_h16_gn(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
                                                     _chk(shift, "shift"), Co, H, W, _chk(out, "out"), ctypes.c_void_p(ga[0].data_ptr()),
                                                     int(ga[1]), _stream())
         if rc != _lib.ERR_UNSUPPORTED:
-            _lib.check(rc, "d3d_conv2d_k3_wide_bf16_gn")
+            _lib.check(rc, "d3d_conv2d_k3_wide_h16_gn")
             dispatch_counts["conv2d_wide"] += 1
             dispatch_counts["conv2d_gn_fused"] += 1
             return out
         gn.slot = None
         _gn_arenas[(x.device.index, torch.cuda.current_stream(x.device).cuda_stream)][1] -= 1
-    rc = _lib.load().d3d_conv2d_k3_wide_bf16(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
+    rc = _lib.load().d3d_conv2d_k3_wide_h16(_chk(x, "x", 3), Ci0, _opt(x2, "x2"), Ci1, ctypes.c_void_p(wp.data_ptr()),
                                              _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"), int(act), Co, H, W,
                                              _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_conv2d_k3_wide_bf16")
+    _lib.check(rc, "d3d_conv2d_k3_wide_h16")
     dispatch_counts["conv2d_wide"] += 1
     return out
 
@@ -1316,7 +1316,7 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
     if x2 is not None and tuple(x2.shape[1:]) != (H, W):
         raise ValueError("x2 spatial size mismatch")
     if stride == 1 and act in (0, 1) and _use_mfma() and H * W >= CONV2D_ZS_MINPIX and \
-            (conv_precision() == "bf16" or _cfg.state.tile_kernels):
+            (conv_precision() == "h16" or _cfg.state.tile_kernels):
         # bf16 mode, and the ConvReLU of a slice regulariser in fp32 mode (three-way bf16 splits: 65.2 -> 63.9 ms per AdaMVS
         # view; on the fp32 instruction the vector-unit kernel won, 71.7 vs 73.1 ms): one tile per step on the matrix cores
         y = conv2d_zs(x, weight, scale, shift, skip, act, x2=x2, skip_after_act=True, gn=gn)   # conv2d_k3: the skip is added last
@@ -1326,7 +1326,7 @@ def conv2d_k3(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         y = conv2d_wide(x, weight, scale, shift, skip, act, x2=x2, gn=gn)   # (bf16 mode: the wide conv-GRU levels of RED-Net)
         if y is not None:
             return y
-    zs_any = conv_precision() == "bf16" or _cfg.state.tile_kernels or Ci0 == 48
+    zs_any = conv_precision() == "h16" or _cfg.state.tile_kernels or Ci0 == 48
     if stride == 2 and x2 is None and act in (0, 1) and zs_any and _use_mfma() and H * W >= (64 * 64 if Ci0 == 48 else 128 * 128):
         y = conv2d_s2_zs(x, weight, scale, shift, skip, act, skip_after_act=True)
         if y is not None:
@@ -1436,7 +1436,7 @@ _GN_SLOTS = 2048
 class GnStats:
     """Request for the GroupNorm(1, C) statistics of a convolution's output (ConvGRUCell2, module.py:62-99): `ngroups` (1 | 2) equal
     consecutive channel groups.  conv2d_k3(..., gn=req) fills `req` in the convolution's epilogue where the kernel has that form
-    (bf16 mode: d3d_conv2d_k3_zs_bf16_gn / d3d_conv2d_k3_wide_bf16_gn); `req.stats(y)` returns the fp64 (sum, sum of squares) pairs
+    (bf16 mode: d3d_conv2d_k3_zs_h16_gn / d3d_conv2d_k3_wide_h16_gn); `req.stats(y)` returns the fp64 (sum, sum of squares) pairs
     -- the epilogue's, or those of d3d_groupnorm_stats over the stored tensor y.  The pairs live in a zeroed arena of slots per
     (device, stream): one fill per _GN_SLOTS requests instead of one per layer."""
 
@@ -1588,19 +1588,40 @@ def _mpad(co):
 
 
 
+H16_NAMES = ("h16", "f16", "bf16")
+
+
+def h16_dtype():
+    """torch dtype of the library's 16-bit operand format (d3d_h16_format: "f16" by default, "bf16" in a -DD3D_H16_BF16 build):
+    what channel-last "h16" volumes and packed 16-bit weight fragments are made of."""
+    return torch.float16 if _lib.h16_format() == "f16" else torch.bfloat16
+
+
+def _norm_precision(mode):
+    """"h16" is the fast mode in whatever 16-bit format the library was built with; "f16" / "bf16" name a format and are
+    accepted only when the loaded library IS that format -- asking an f16 build for bf16 must not silently run f16."""
+    if mode in (None, "fp32", "h16"):
+        return mode
+    if mode in ("f16", "bf16"):
+        if _lib.h16_format() != mode:
+            raise ValueError("precision %r asked of a library whose 16-bit operand format is %r (d3d_h16_format; rebuild with "
+                             "`make -C deep3d_aerial_amd/csrc H16=%s` or ask for 'h16')" % (mode, _lib.h16_format(), mode))
+        return "h16"
+    raise ValueError("precision must be 'fp32' or 'h16' (or the library's format by name: %r)" % _lib.h16_format())
+
+
 def set_conv_precision(mode):
-    """"fp32" (default; exact fp32 MFMA) or "bf16" (bf16 MFMA operands, fp32 accumulate: BASELINE config 3) for
-    the convolutions that go through d3d_conv_fold_*.  None = follow the environment (D3D_CONV_PRECISION).
+    """"fp32" (default; fp32 accuracy: exact fp32 MFMA or split bf16x3 operands) or "h16" (16-bit matrix-core operands in the
+    library's format -- IEEE half unless built otherwise, see _lib.h16_format() -- with fp32 accumulation: BASELINE config 3's
+    fast mode) for the regularisers' convolutions.  None = follow the switch table (D3D_CONV_PRECISION).
     PER THREAD (config.state is a threading.local): a forward run in a worker thread follows the switch table's
     D3D_CONV_PRECISION unless that thread calls this itself; to change the process-wide default set
     config.switches["D3D_CONV_PRECISION"]."""
-    if mode not in (None, "fp32", "bf16"):
-        raise ValueError("precision must be 'fp32' or 'bf16'")
-    _cfg.state.conv_precision = mode
+    _cfg.state.conv_precision = _norm_precision(mode)
 
 
 def conv_precision():
-    return _cfg.state.conv_precision or _cfg.get("D3D_CONV_PRECISION")
+    return _cfg.state.conv_precision or _norm_precision(_cfg.get("D3D_CONV_PRECISION"))
 
 
 class fp32_convs:
@@ -1615,12 +1636,12 @@ class fp32_convs:
         return False
 
 
-class bf16_convs(fp32_convs):
-    """Context manager: bf16 matrix-core operands inside (BASELINE config 3's precision), whatever the global precision."""
+class h16_convs(fp32_convs):
+    """Context manager: 16-bit matrix-core operands inside (BASELINE config 3's fast mode), whatever the global precision."""
 
     def __enter__(self):
         self.saved = _cfg.state.conv_precision
-        _cfg.state.conv_precision = "bf16"
+        _cfg.state.conv_precision = "h16"
 
 
 def _use_mfma():
@@ -1896,12 +1917,12 @@ def conv_fold(x, weight, scale=None, shift=None, skip=None, act=0, stride=1, x2=
         else:
             G = tuple((od[i] + (fz, fy, fx)[i] - 1) // (fz, fy, fx)[i] for i in range(3))
         geom = (ctypes.c_int * 15)(G[0], G[1], G[2], cz, cy, cx, sz, sy, sx, bz, by, bx, fz, fy, fx)
-        fold = lib.d3d_conv_fold_bf16 if conv_precision() == "bf16" else lib.d3d_conv_fold_f32
+        fold = lib.d3d_conv_fold_h16 if conv_precision() == "h16" else lib.d3d_conv_fold_f32
         rc = fold(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
                                    _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
                                    int(skip_after_act), int(act), _opt(aux1, "aux1"), int(ep_split), Co, D, H, W,
                                    od[0], od[1], od[2], geom, T, taps, _chk(out, "out"), _stream())
-        if rc == _lib.ERR_UNSUPPORTED and fold is lib.d3d_conv_fold_bf16:
+        if rc == _lib.ERR_UNSUPPORTED and fold is lib.d3d_conv_fold_h16:
             # shape outside the bf16 kernels (e.g. image width not a multiple of 4): the exact fp32 kernel instead
             rc = lib.d3d_conv_fold_f32(_chk(x, "x"), Ci0, _opt(x2, "x2"), Ci1, _chk(wpack, "wpack"), mpad, M,
                                        _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
@@ -1920,7 +1941,7 @@ def conv2d_same(x, weight, scale=None, shift=None, skip=None, act=0, stride=1):
     Co, Ci = weight.shape[0], weight.shape[1]
     if x.shape[0] != Ci or Co > 64 or not _use_mfma():
         return None
-    if weight.shape[2] == 5 and stride == 2 and conv_precision() != "bf16":
+    if weight.shape[2] == 5 and stride == 2 and conv_precision() != "h16":
         y = conv2d_k5s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
@@ -1951,11 +1972,11 @@ def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_aft
 
 
 def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride=1):
-    """relu(conv3x3(cost, stride)) followed by the conv-GRU cell on it, ONE launch (d3d_gru_cell_fused_bf16, csrc/gru_fused.hip;
+    """relu(conv3x3(cost, stride)) followed by the conv-GRU cell on it, ONE launch (d3d_gru_cell_fused_h16, csrc/gru_fused.hip;
     adamvs.py:409-412: conv1 + conv_gru1 at stride 1, conv2 + conv_gru2 at stride 2).  bf16 mode only (the operands are bf16, the
     state stays fp32): bit-identical to conv2d_zs + gru_cell_fused.  Returns the new state, or None for shapes / modes the
     kernel does not take (the caller then runs the separate launches)."""
-    if conv_precision() != "bf16" or not _use_mfma() or _cfg.off("gru_fused") or cost.dim() != 3:
+    if conv_precision() != "h16" or not _use_mfma() or _cfg.off("gru_fused") or cost.dim() != 3:
         return None
     CP, HI, WI = cost.shape
     HID, H, W = h.shape
@@ -1971,12 +1992,12 @@ def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride
     wg = derived_weight(w_gates, "z2bf16", _pack_z2_bf16)
     wc = derived_weight(w_cand, "z2bf16", _pack_z2_bf16)
     out = torch.empty_like(h)
-    rc = _lib.load().d3d_gru_cell_fused_bf16(_chk(cost, "cost", 3), CP, HI, WI, int(stride), _chk(h, "h", 3), HID, H, W,
+    rc = _lib.load().d3d_gru_cell_fused_h16(_chk(cost, "cost", 3), CP, HI, WI, int(stride), _chk(h, "h", 3), HID, H, W,
                                              ctypes.c_void_p(w1.data_ptr()), ctypes.c_void_p(wg.data_ptr()), _chk(b_gates, "b_gates"),
                                              ctypes.c_void_p(wc.data_ptr()), _chk(b_cand, "b_cand"), _chk(out, "out"), _stream())
     if rc == _lib.ERR_UNSUPPORTED:
         return None
-    _lib.check(rc, "d3d_gru_cell_fused_bf16")
+    _lib.check(rc, "d3d_gru_cell_fused_h16")
     dispatch_counts["gru_cell_fused"] += 1
     return out
 

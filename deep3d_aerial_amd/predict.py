@@ -308,6 +308,11 @@ class SyntheticStrip:
         win = dataset.crop_window(self.h0, self.w0, self.h, self.w)
         return dataset.crop_camera(cam, win[0], win[1]), dataset.slice_window(self.h0, self.w0, win)
 
+    def view_records(self, fusion_num=10):
+        """pipeline.view_records: reference view i lists images i + 1, i + 2, ... (the ring) as its sources."""
+        return [{"name": "view_%04d" % i, "src": ["view_%04d" % ((i + k) % self.n) for k in range(1, min(self.n, 1 + fusion_num))],
+                 "id": i + 1, "image": i} for i in range(self.n)]
+
     def __getitem__(self, idx):
         from . import dataset
 
@@ -345,13 +350,15 @@ def _item_views(s, model, device):
 # the per-view loop of predict.py:126-183, sharded over ranks
 # ----------------------------------------------------------------------------------------
 def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="cuda", keep_maps=False,
-                  feature_cache_bytes=0, display=False, partition="block", stats=None):
+                  feature_cache_bytes=0, display=False, partition="block", stats=None, cams=None):
     """Returns the names of the views this rank produced; with keep_maps=True a dict name -> (depth, confidence)
     of device tensors instead, so the fusion step (fuse.ViewFusion) can start without re-reading the PFM files.
     feature_cache_bytes > 0 keeps the feature pyramids of that many bytes of images resident across views (items must
     carry "image_keys"); results do not change.  partition: how the views are dealt to the ranks (sharding.shard_views;
     "block" keeps neighbouring views -- which share source images -- on one rank, so its cache keeps hitting).
-    stats: a dict that receives this rank's view count, cache hits / misses and feature pyramids computed per view."""
+    stats: a dict that receives this rank's view count, cache hits / misses and feature pyramids computed per view.
+    cams: a dict that receives name -> the view's [2,4,4] camera (`outcam`: what write_red_cam puts into {name}.txt), for the
+    fusion step that follows in the same process (pipeline.predict_and_fuse)."""
     from .dataset import FeatureCache
 
     os.makedirs(output_folder, exist_ok=True)
@@ -387,6 +394,8 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
                 writer.submit([depth, prob], paths, display=(output_folder, name) if display else None)
                 write_red_cam(os.path.join(output_folder, "%s.txt" % name), s["outcam"], s["outlocation"],
                               s["ref_image_path"])
+                if cams is not None:
+                    cams[name] = np.array(s["outcam"], dtype=np.float32)
                 if keep_maps:
                     done[name] = (depth, prob)
                 else:
@@ -444,6 +453,18 @@ def parse_args(argv=None):
     ap.add_argument("--feature_cache_gb", type=float, default=8.0, help="HBM kept for feature pyramids of shared images (0 = off)")
     ap.add_argument("--partition", default="block", choices=list(sharding.POLICIES),
                     help="views per rank: contiguous blocks (neighbouring views share images: the cache keeps hitting) or round_robin")
+    # --fuse: BASELINE config 5's pipeline in one launch (pipeline.predict_and_fuse): the ranks all-gather their maps and every
+    # rank fuses the reference views it swept.  Thresholds and counts are Fuse_Depth_Map's (fusion_3d_normal.py:56-57, run.py:176).
+    ap.add_argument("--fuse", action="store_true", help="all-gather the depth / confidence maps and fuse this rank's reference views")
+    ap.add_argument("--fusion_num", type=int, default=10)
+    ap.add_argument("--geo_consist_num", type=int, default=4)
+    ap.add_argument("--photometric_threshold", type=float, default=0.2)
+    ap.add_argument("--position_threshold", type=float, default=1.0)
+    ap.add_argument("--depth_threshold", type=float, default=0.01)
+    ap.add_argument("--normal_threshold", type=float, default=90.0)
+    ap.add_argument("--fuse_filter_sources", type=int, default=1,
+                    help="1: confirmed samples leave the source maps (the reference's save_temp chain, kept per rank); 0: order-free")
+    ap.add_argument("--fusion_output", default=None, help="folder of the fused arrays (default <output_folder>/fused)")
     return ap.parse_args(argv)
 
 
@@ -501,9 +522,22 @@ def main(argv=None):
         synthetic.fill_state_dict_(model.state_dict(), 0)
     model = model.cuda()
     st = {}
+    cache_bytes = int(a.feature_cache_gb * (1 << 30)) if a.synthetic_items <= 0 else 0
+    if a.fuse:
+        from . import fuse, pipeline
+
+        tm = {}
+        checker = fuse.ConsistencyChecker(a.position_threshold, a.depth_threshold, a.normal_threshold, a.photometric_threshold)
+        res = pipeline.predict_and_fuse(model, ds, a.output_folder, rank, world, checker=checker, fusion_num=a.fusion_num,
+                                        min_geo_consist_num=a.geo_consist_num, filter_sources=bool(a.fuse_filter_sources),
+                                        partition=a.partition, feature_cache_bytes=cache_bytes, timings=tm, display=_truthy(a.display))
+        pipeline.save_fused(res, a.fusion_output or os.path.join(a.output_folder, "fused"))
+        print("rank %d/%d: %d views in %.2f s, all-gather of %.1f MB in %.2f ms (%s), fusion of its %d reference views %.2f s, "
+              "%d vertices" % (rank, world, tm["views"], tm["predict_s"], tm["allgather_bytes"] / 1e6, tm["allgather_ms"], tm["backend"],
+                               len(res), tm["fuse_s"], sum(int(r["points"]["xyz"].shape[0]) for r in res)))
+        return [r["ref"] for r in res]
     names = predict_views(model, ds, a.output_folder, rank, world, display=_truthy(a.display),
-                          feature_cache_bytes=int(a.feature_cache_gb * (1 << 30)) if a.synthetic_items <= 0 else 0,
-                          partition=a.partition, stats=st)
+                          feature_cache_bytes=cache_bytes, partition=a.partition, stats=st)
     acc = st.get("cache_hits", 0) + st.get("cache_misses", 0)
     print("rank %d/%d wrote %d views (%s partition): feature cache %d hits / %d lookups (%.0f %%), %.2f pyramids computed per view"
           % (rank, world, len(names), st.get("partition"), st.get("cache_hits", 0), acc,

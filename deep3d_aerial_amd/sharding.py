@@ -93,8 +93,15 @@ def all_gather_maps(local_maps, n_views, rank=None, world_size=None, policy="blo
     per = (n_views + world_size - 1) // world_size
     padded = local_maps.new_zeros((per,) + tuple(local_maps.shape[1:]))
     padded[: local_maps.shape[0]] = local_maps
-    gathered = local_maps.new_empty((world_size * per,) + tuple(local_maps.shape[1:]))
-    dist.all_gather_into_tensor(gathered, padded.contiguous())
+    if dist.get_backend() == "gloo" and padded.is_cuda:
+        # ranks that share one card rendezvous over gloo (init_from_env): the maps travel through host memory
+        host = padded.cpu()
+        gathered = host.new_empty((world_size * per,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(gathered, host.contiguous())
+        gathered = gathered.to(local_maps.device)
+    else:
+        gathered = local_maps.new_empty((world_size * per,) + tuple(local_maps.shape[1:]))
+        dist.all_gather_into_tensor(gathered, padded.contiguous())
     # gathered[r*per + j] is the j-th view of rank r's list
     out = local_maps.new_empty((n_views,) + tuple(local_maps.shape[1:]))
     for r in range(world_size):

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 8
+#define D3D_ABI_VERSION 9
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -97,6 +97,20 @@ int d3d_debug_dispatch_counts(unsigned long long* out4, int reset);
  * shapes or select measured-and-dropped variants; one of them set by accident in the Makefile must not ship silently.
  */
 const char* d3d_build_flags(void);
+
+/*
+ * The 16-bit operand format of this build's fast mode ("h16": every entry point named *_h16 below, BASELINE config 3): "f16"
+ * (IEEE half, 11 significand bits; the default) or "bf16" (a -DD3D_H16_BF16 build).  One format per library: "h16" volumes,
+ * packed weight fragments and stored activations are in it, and a caller creates them accordingly (torch.float16 /
+ * torch.bfloat16).  Accumulation is fp32 either way.  Half is the default because bfloat16's 8 significand bits put the
+ * regressed depth 0.9 - 1.4 stage-3 intervals from the reference's on the arg-max-sensitive model fixtures against a bar of
+ * 0.25 (north_star: 1e-3 relative L1), with every rounding site of a regulariser contributing; half at the same bytes and
+ * matrix-core rate stays below 0.25 (profiles/r05_h16_ablation.txt).  The variance volume, the one operand whose
+ * magnitude the data decides, saturates at 65504 in the half format.  The *_bf16x3 entry points (fp32 mode: an fp32 operand as
+ * the exact sum of three bfloat16 pieces) are bfloat16 in every build.
+ * Replaces nothing in the reference (fp32 throughout).  ABI 9.
+ */
+const char* d3d_h16_format(void);
 
 /*
  * Scratch bytes the plane-sweep entry points below (d3d_homo_warp, d3d_variance_volume[_f16],
@@ -148,18 +162,18 @@ int d3d_variance_volume_planes(const float* const* feats, const float* proj34, c
                                d3d_stream_t stream);
 
 /* d3d_variance_volume with the result as a channel-last bf16 volume [D,h,w,C] (RNE at the store; fp32 features and fp32
- * arithmetic as above): the form conv0 of the 3-D regulariser takes in bf16 mode (d3d_conv3d_k3_cl_bf16, in_cl = 1), which
+ * arithmetic as above): the form conv0 of the 3-D regulariser takes in bf16 mode (d3d_conv3d_k3_cl_h16, in_cl = 1), which
  * rounds its input to bf16 anyway -- so the regularised result is bit-identical to the planar fp32 route, the volume is
  * written once at half the bytes and read with 16-byte loads.  C % 8 == 0, h*w*C < 2^31, at most 6 source views;
- * D3D_ERR_UNSUPPORTED otherwise (nothing is launched; callers use d3d_variance_volume + d3d_volume_planar_to_cl_bf16). */
-int d3d_variance_volume_cl_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+ * D3D_ERR_UNSUPPORTED otherwise (nothing is launched; callers use d3d_variance_volume + d3d_volume_planar_to_cl_h16). */
+int d3d_variance_volume_cl_h16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                 d3d_stream_t stream);
 /* The same volume in planes of 8-channel groups, "CL8": out [D, C/8, h, w, 8] bf16 -- the 16 bytes a lane stores per voxel
  * and group are then a WHOLE cell (with C > 8 the [D,h,w,C] form above makes every store a partial 32-byte write: the
- * write traffic of a C = 16 volume was that of the planar fp32 one).  d3d_conv3d_k3_cl_bf16 / d3d_conv3d_k3_c1_cl_bf16 take
+ * write traffic of a C = 16 volume was that of the planar fp32 one).  d3d_conv3d_k3_cl_h16 / d3d_conv3d_k3_c1_cl_h16 take
  * it with in_cl = 2.  For C = 8 the two layouts coincide. */
-int d3d_variance_volume_cl8_bf16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
+int d3d_variance_volume_cl8_h16(const float* const* feats, const float* proj34, const float* depth, int depth_mode,
                                 int n_views, int C, int D, int h, int w, void* out, void* workspace, size_t workspace_bytes,
                                 d3d_stream_t stream);
 
@@ -215,18 +229,18 @@ int d3d_online_regress_update(const float* reg, const float* dplane, int hd, int
  * with dplane [hd,wd] resampled as d3d_online_regress_update resamples it.  up [8,h,w], weight 72 floats [c][k_y][k_x] (the
  * nn.ConvTranspose2d [8,1,3,3] / nn.Conv2d [1,8,3,3] tensor, ALREADY rounded to bf16 values), bias [1]; w % 2 == 0 (transposed) /
  * w % 4 == 0, else D3D_ERR_UNSUPPORTED.  `reg` never reaches memory. */
-int d3d_slice_head_regress_bf16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
+int d3d_slice_head_regress_h16(const float* up, const float* weight, const float* bias, int transposed, const float* dplane, int hd,
                                 int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream);
 /* A 3 x 3 convolution of ConvGRUCell2 (module.py:71-99: gate_conv / output_conv over cat(x, h), bias, no activation) that also
  * accumulates the GroupNorm(1, C) statistics of its output (round 4, ABI 8; csrc/gn_stats.h): gn_stats [ngroups][2] fp64 =
  * (sum, sum of squares) per channel group, ZEROED by the caller before the launch (stream order); channels >= gn_split are the second
  * group (the update half of the gate convolution), gn_split = Co means one group.  The sums are those d3d_groupnorm_stats computes
  * from the stored tensor (same operands, fp64; the order of the additions differs) -- that launch and its pass over the tensor go.
- * _zs: the tile kernel of d3d_conv2d_k3_zs_bf16 for C1 + C2 = 16 | 24 | 32 | 40 (24 | 40: Co <= 16; else Co <= 32), W % 4 == 0;
- * _wide: d3d_conv2d_k3_wide_bf16's shapes.  D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
-int d3d_conv2d_k3_zs_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
+ * _zs: the tile kernel of d3d_conv2d_k3_zs_h16 for C1 + C2 = 16 | 24 | 32 | 40 (24 | 40: Co <= 16; else Co <= 32), W % 4 == 0;
+ * _wide: d3d_conv2d_k3_wide_h16's shapes.  D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_conv2d_k3_zs_h16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
                              int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
-int d3d_conv2d_k3_wide_bf16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
+int d3d_conv2d_k3_wide_h16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
                                int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
 /* conv0 of a feature trunk in ONE launch (round 4, ABI 7; csrc/conv2d_zs.hip, IMG3 form): out = act(scale * Conv3x3_8->Co(c) + shift)
  * with c = act0(scale0 * Conv3x3_3->8(img) + shift0) evaluated per tile from the staged image patch and never written (module.py:
@@ -241,9 +255,9 @@ int d3d_conv2d_k3_pair3_bf16x3(const float* img, const float* w0packed, const fl
  * csrc/regress.hip slice_tail_kernel): up = relu(ConvTranspose2d_16->8(state2) + bup + state1) stays in LDS,
  * reg = ConvTranspose2d_8->1(up) + bhead, and the online regression update of (max_p, sum_d, sum_p) [4h, 4w] at `dplane`.
  * state2 [16,h,w], state1 [8,2h,2w]; wup_packed = ops._pack_t2d_bf16, whead = the 72 head weights rounded to bf16 (fp32 values).
- * Bit-identical to d3d_convtranspose2d_k3s2_zs_bf16 followed by d3d_slice_head_regress_bf16(transposed = 1).  w % 4 == 0,
+ * Bit-identical to d3d_convtranspose2d_k3s2_zs_h16 followed by d3d_slice_head_regress_h16(transposed = 1).  w % 4 == 0,
  * 16-byte aligned maps; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
-int d3d_slice_tail_regress_bf16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
+int d3d_slice_tail_regress_h16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
                                 const float* bhead, const float* dplane, int hd, int wd, int h, int w, float* max_p, float* sum_d,
                                 float* sum_p, d3d_stream_t stream);
 int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const float* sum_p, int64_t n,
@@ -298,11 +312,11 @@ int d3d_conv3d_k3_co8(const float* in, const float* wpacked, const float* scale,
  * rounded to bf16 (RNE) while it is staged, each input plane is read once and feeds three output planes.
  * wpacked: the weight [8,Ci,3,3,3] rounded to bf16 and laid out in the instruction's B-operand order,
  * [k_z][K block of 32][lane 0..63][8 values], K = (k_y, k_x, c_in) (ops.conv3d_k3 packs it once per parameter version). */
-int d3d_conv3d_k3_c8_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+int d3d_conv3d_k3_c8_h16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
 /* The same kernel for C_out <= 16 (C_in = 8 | 16 | 32) and 32 -> 32: conv2 / conv4 of CostRegNet (cas_mvsnet.py:87,90).
  * wpacked: [k_z][K block][N tile of 16 channels][lane][8 values]. */
-int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+int d3d_conv3d_k3_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                           int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
 /* The same kernel with fp32 ACCURACY (the default precision of the regularisers): both operands as exact three-way bf16
  * splits (hi + mid + lo), six v_mfma_f32_16x16x32_bf16 products per K block accumulated in fp32 -- the 3-D form of
@@ -311,7 +325,7 @@ int d3d_conv3d_k3_zs_bf16(const float* in, const void* wpacked, const float* sca
  * (ops._pack_c8_bf16x3). */
 int d3d_conv3d_k3_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                             int relu, int Ci, int Co, int D, int H, int W, float* out, d3d_stream_t stream);
-/* C_out = 1 (the probability layer) the same way: k_z folded into the columns of one tile (d3d_conv3d_k3_c1_cl_bf16's form),
+/* C_out = 1 (the probability layer) the same way: k_z folded into the columns of one tile (d3d_conv3d_k3_c1_cl_h16's form),
  * planar fp32 in [8,D,H,W] and out [D,H,W]; wpacked: [hi | mid | lo] x ops._pack_c8_kzfold_bf16. */
 int d3d_conv3d_k3_c1_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                             int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
@@ -332,7 +346,7 @@ int d3d_convtranspose3d_k3s2_co8(const float* in, const float* wpacked, const fl
  * convolutions over one staged input (no multiplications by inserted zeros), each input plane read once per tile.
  * wpacked: the weight [Ci,Co,3,3,3] rounded to bf16, per output parity class in B-operand lane order
  * (ops.convtranspose3d_k3s2 packs it once per parameter version). */
-int d3d_convtranspose3d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+int d3d_convtranspose3d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int relu, int Ci, int Co, int D, int H, int W, float* out,
                                      d3d_stream_t stream);
 /* ... and with fp32 accuracy from three-way bf16 splits of both operands (16 -> 8 | 16: conv11 of every CostRegNet in the
@@ -357,19 +371,19 @@ int d3d_conv3d_k3s2_zs_bf16x3(const float* in, const void* wpacked, const float*
  * W % 4 == 0; D3D_ERR_UNSUPPORTED otherwise (nothing launched).
  * wpacked: the weight [Co,C1+C2,3,3] rounded to bf16 in B-operand lane order, [K block][N tile][lane][8], K = (k_y,k_x,c_in)
  * (ops._pack_z2_bf16). */
-int d3d_conv2d_k3_zs_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+int d3d_conv2d_k3_zs_h16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                           const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                           int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
 /* The same layer in the models' default precision: exact fp32 operands on v_mfma_f32_16x16x4_f32 (weights fp32 in the same
- * [K block of 4][N tile][lane] order, ops._pack_z2_f32); arguments and shapes as d3d_conv2d_k3_zs_bf16. */
+ * [K block of 4][N tile][lane] order, ops._pack_z2_f32); arguments and shapes as d3d_conv2d_k3_zs_h16. */
 int d3d_conv2d_k3_zs_f32(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                          const float* shift, const float* skip, const float* aux1, int act, int ep_split,
                          int skip_after_act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
 /* The same layer with fp32 accuracy on the bf16 matrix cores: every fp32 operand is the exact sum of three bf16 numbers
  * (hi + mid + lo); the activations are split while a tile is staged, the weights on the host (wpacked: the three
- * d3d_conv2d_k3_zs_bf16 packings of hi | mid | lo one after the other, ops._pack_z2_bf16x3), and a K block takes the six
+ * d3d_conv2d_k3_zs_h16 packings of hi | mid | lo one after the other, ops._pack_z2_bf16x3), and a K block takes the six
  * products down to 2^-16 of the leading one on v_mfma_f32_16x16x32_bf16, accumulated in fp32 -- what is dropped is below
  * fp32's own rounding of a product.  Arguments and shapes as d3d_conv2d_k3_zs_f32 (C1 + C2 = 8 | 16 | 32, Co <= 32). */
 int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
@@ -397,9 +411,9 @@ int d3d_conv1x1_context(const float* f, int Ci, const float* weight, const float
  * in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1] resp. [Co,2H,2W]; act 0 | 1 (ReLU); skip (shape of out, may be NULL) added before
  * the activation or, skip_after_act, after it.  Stride 2: C_in = 8 | 16, C_out <= 32, output width % 4 == 0; transposed:
  * C_in = 8 | 16 | 32, C_out <= 16, W % 4 == 0.  wpacked: ops._pack_z2_bf16 / ops._pack_t2d_bf16 (per output parity class, as the 3-D form). */
-int d3d_conv2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
+int d3d_conv2d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                             int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
-int d3d_convtranspose2d_k3s2_zs_bf16(const float* in, const void* wpacked, const float* scale, const float* shift,
+int d3d_convtranspose2d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                      d3d_stream_t stream);
 /* ... and in exact fp32 (v_mfma_f32_16x16x4_f32; weights ops._pack_z2_f32 / ops._pack_t2d_f32): stride 2 takes C_in = 8 only
@@ -433,7 +447,7 @@ int d3d_convtranspose2d_k4s2_zs_bf16x3(const float* in, const void* wpacked, con
  * Co = 32 | 64 | 128; out [Co,H,W] = act(conv * scale + shift) (+ skip, added last); act 0 | 1 (ReLU).  K is walked in
  * chunks of 32 input channels (the tile kernels above keep a whole layer in LDS, which ends at 48 channels).  wpacked:
  * ops._pack_z2_bf16(weight [Co,C1+C2,3,3]).  D3D_ERR_UNSUPPORTED for other shapes. */
-int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
+int d3d_conv2d_k3_wide_h16(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* scale,
                             const float* shift, const float* skip, int act, int Co, int H, int W, float* out, d3d_stream_t stream);
 
 /* One conv-GRU cell of the slice regularisers in ONE launch (csrc/gru_fused.hip; replaces adamvs.py:409-412 conv1 + conv_gru1 resp.
@@ -445,13 +459,13 @@ int d3d_conv2d_k3_wide_bf16(const float* in, int C1, const float* in2, int C2, c
  * operands, fp32 accumulation, the state stays fp32); bg [2 HID], bc [HID].  Bit-identical to the three-launch form.
  * W, WI multiples of 4, 16-byte aligned tensors.
  * D3D_ERR_UNSUPPORTED for other channel counts. */
-int d3d_gru_cell_fused_bf16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
+int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
                             const void* w1, const void* wg, const float* bg, const void* wc, const float* bc, float* hout,
                             d3d_stream_t stream);
 
 /* Conv2d(kernel 5, stride 2, padding 2) -- the downsampling layers of the feature trunks (module.py:669, 675; adamvs.py:64, 70 of the reference) --
  * on the stride-2 tile kernel with split operands (fp32 accuracy): in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1]; wpacked:
- * ops._pack_z2_bf16x3 of the weight [Co,Ci,5,5] (K = (k_y,k_x,c_in)); scale / shift / skip / act as d3d_conv2d_k3s2_zs_bf16.
+ * ops._pack_z2_bf16x3 of the weight [Co,Ci,5,5] (K = (k_y,k_x,c_in)); scale / shift / skip / act as d3d_conv2d_k3s2_zs_h16.
  * Ci 8 with Co <= 16 | Ci 16 with Co <= 32, output width % 4 == 0; D3D_ERR_UNSUPPORTED otherwise. */
 int d3d_conv2d_k5s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                               int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
@@ -463,39 +477,39 @@ int d3d_conv2d_k5s2_zs_bf16x3(const float* in, const void* wpacked, const float*
  * staging task is one 16-byte load.  Same layers and weight packings as the *_zs_bf16 entry points above
  * (cas_mvsnet.py:84-118: conv0 planar -> CL, conv1 .. conv11 CL -> CL with CL skips, prob CL -> planar).
  *
- * d3d_conv3d_k3_cl_bf16: stride 1; in_cl / out_cl select the format of `in` (also 2: CL8 [D,Ci/8,H,W,8], see
- * d3d_variance_volume_cl8_bf16) and of `out` + `skip` (0: planar fp32
+ * d3d_conv3d_k3_cl_h16: stride 1; in_cl / out_cl select the format of `in` (also 2: CL8 [D,Ci/8,H,W,8], see
+ * d3d_variance_volume_cl8_h16) and of `out` + `skip` (0: planar fp32
  *   [C,D,H,W], 1: CL).  C_in = 8 | 16 | 32, C_out <= 16 or 32 -> 32; C_out % 4 == 0 for CL output, W % 4 == 0 for planar.
- * d3d_conv3d_k3s2_cl_bf16: stride 2, pad 1; CL in [D,H,W,Ci] -> CL out [(D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Co];
+ * d3d_conv3d_k3s2_cl_h16: stride 2, pad 1; CL in [D,H,W,Ci] -> CL out [(D-1)/2+1, (H-1)/2+1, (W-1)/2+1, Co];
  *   8->8, 8->16, 16->16, 16->32.
- * d3d_convtranspose3d_k3s2_cl_bf16: channel_last = 1: CL in / skip / out ([2D,2H,2W,Co]); 0: the planar form above;
+ * d3d_convtranspose3d_k3s2_cl_h16: channel_last = 1: CL in / skip / out ([2D,2H,2W,Co]); 0: the planar form above;
  *   2: CL with the x-folded weight packing (16 -> 8 only: both output-column parities in one GEMM, ops._pack_t2_fold_bf16).
- * d3d_volume_planar_to_cl_bf16 / d3d_volume_cl_bf16_to_planar: format conversion of a volume of n voxels, C % 8 == 0 (RNE;
+ * d3d_volume_planar_to_cl_h16 / d3d_volume_cl_h16_to_planar: format conversion of a volume of n voxels, C % 8 == 0 (RNE;
  *   the way back is exact) -- for the layers that stay on the planar kernels (conv5 / conv6) and for tests.
  * D3D_ERR_UNSUPPORTED for other shapes; nothing is launched then. */
-int d3d_conv3d_k3_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+int d3d_conv3d_k3_cl_h16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
                           const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out, int out_cl,
                           d3d_stream_t stream);
 /* C_out = 1 (the probability layer, cas_mvsnet.py:110): in planar fp32 or CL (in_cl), out planar fp32 [D,H,W]; the three k_z
  * slices of the weight are columns 0..2 of ONE operand tile (ops._pack_c8_kzfold_bf16), a third of the matrix work of the
  * generic entry point.  C_in = 8 | 16 | 32, W % 4 == 0. */
-int d3d_conv3d_k3_c1_cl_bf16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
+int d3d_conv3d_k3_c1_cl_h16(const void* in, int in_cl, const void* wpacked, const float* scale, const float* shift,
                              const float* skip, int relu, int Ci, int D, int H, int W, float* out, d3d_stream_t stream);
-int d3d_conv3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
+int d3d_conv3d_k3s2_cl_h16(const void* in, const void* wpacked, const float* scale, const float* shift, const void* skip,
                             int relu, int Ci, int Co, int D, int H, int W, void* out, d3d_stream_t stream);
-int d3d_convtranspose3d_k3s2_cl_bf16(const void* in, const void* wpacked, const float* scale, const float* shift,
+int d3d_convtranspose3d_k3s2_cl_h16(const void* in, const void* wpacked, const float* scale, const float* shift,
                                      const void* skip, int relu, int Ci, int Co, int D, int H, int W, void* out,
                                      int channel_last, d3d_stream_t stream);
 /* conv11 + prob of a CostRegNet in one kernel (cas_mvsnet.py:103-105,118-119; csrc/conv_t2p.hip):
  *   y = skip + ReLU(scale * ConvTranspose3d_16->8(in) + shift) rounded to bf16, out = Conv3d_8->1(y) + prob_bias[0];
  * y lives in LDS only.  in CL [D,H,W,16], skip CL [2D,2H,2W,8] (or null), out planar fp32 [2D,2H,2W]; wt_folded as for
- * d3d_convtranspose3d_k3s2_cl_bf16(channel_last = 2), wprob_kzfolded as for d3d_conv3d_k3_c1_cl_bf16.  Bit-identical to
+ * d3d_convtranspose3d_k3s2_cl_h16(channel_last = 2), wprob_kzfolded as for d3d_conv3d_k3_c1_cl_h16.  Bit-identical to
  * those two calls in sequence.  W even; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
-int d3d_convtranspose3d_prob_cl_bf16(const void* in, const void* wt_folded, const float* scale, const float* shift,
+int d3d_convtranspose3d_prob_cl_h16(const void* in, const void* wt_folded, const float* scale, const float* shift,
                                      const void* skip, int relu, const void* wprob_kzfolded, const float* prob_bias,
                                      int D, int H, int W, float* out, d3d_stream_t stream);
-int d3d_volume_planar_to_cl_bf16(const float* in, int C, size_t n, void* out, d3d_stream_t stream);
-int d3d_volume_cl_bf16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream);
+int d3d_volume_planar_to_cl_h16(const float* in, int C, size_t n, void* out, d3d_stream_t stream);
+int d3d_volume_cl_h16_to_planar(const void* in, int C, size_t n, float* out, d3d_stream_t stream);
 
 
 /* 3x3 stride-1 nn.Conv2d with C_out = 8 | 16 (the full- / half-resolution layers of the feature pyramids,
@@ -588,7 +602,7 @@ int d3d_conv_fold_f32(const float* in0, int Ci0, const float* in1, int Ci1, cons
 /* Same contract with bf16 MFMA operands (v_mfma_f32_16x16x16_bf16; inputs and weights rounded to nearest-even
  * bf16 as the operands are formed, fp32 accumulation, fp32 tensors in memory): the precision BASELINE.json's
  * config 3 asks for.  Depth stays within the 1e-3 relative-L1 budget of the fp32 reference (tests/test_parity_gpu.py). */
-int d3d_conv_fold_bf16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
+int d3d_conv_fold_h16(const float* in0, int Ci0, const float* in1, int Ci1, const float* wpack, int mpad, int M,
                        const float* scale, const float* shift, const float* skip, int skip_after_act, int act,
                        const float* aux1, int ep_split, int Co, int D, int H, int W, int Do, int Ho, int Wo,
                        const int* geom, int ntaps, const signed char* taps_zyx, float* out, d3d_stream_t stream);

@@ -15,9 +15,10 @@ def bf16_exact(rng, shape):
     return (rng.integers(-32, 33, shape) / 64.0).astype(np.float32)
 
 
-def dense_from_fragments(frag, kblock):
-    """[nkb][ntn][64][krows] fragments (bf16 bits or fp32) -> dense B [K, ntn * 16]."""
-    f = frag.view(torch.bfloat16).float().numpy() if frag.dtype == torch.int16 else frag.numpy()
+def dense_from_fragments(frag, kblock, dt=None):
+    """[nkb][ntn][64][krows] fragments (16-bit bits or fp32) -> dense B [K, ntn * 16].  16-bit fragments are in the library's h16
+    format (ops.h16_dtype()) unless `dt` says otherwise (the pieces of a three-way split are bfloat16 in every build)."""
+    f = frag.view(dt or ops.h16_dtype()).float().numpy() if frag.dtype == torch.int16 else frag.numpy()
     if f.ndim == 3:                                    # fp32 fragments: one K row per lane
         f = f[..., None]
     nkb, ntn, _, kr = f.shape
@@ -44,7 +45,7 @@ def conv_from_B(x, B, taps, Co, out_shape, stride=1):
 
 @pytest.mark.parametrize("Ci,Co", [(8, 8), (16, 8), (32, 8), (16, 16), (32, 32), (64, 64), (8, 16)])
 def test_pack_conv3d_fragments(Ci, Co):
-    """ops._pack_c8_bf16 (d3d_conv3d_k3_zs_bf16 / _cl_bf16, stride 1 and 2): per k_z slice K = (k_y, k_x, c_in)."""
+    """ops._pack_c8_bf16 (d3d_conv3d_k3_zs_h16 / _cl_bf16, stride 1 and 2): per k_z slice K = (k_y, k_x, c_in)."""
     rng = np.random.default_rng(Ci + Co)
     w = bf16_exact(rng, (Co, Ci, 3, 3, 3))
     x = rng.standard_normal((Ci, 3, 4, 5)).astype(np.float32)
@@ -60,7 +61,7 @@ def test_pack_conv3d_fragments(Ci, Co):
 
 
 def test_pack_probability_layer_kz_folded():
-    """ops._pack_c8_kzfold_bf16 (d3d_conv3d_k3_c1_cl_bf16): the k_z slices are columns 0..2 of one tile."""
+    """ops._pack_c8_kzfold_bf16 (d3d_conv3d_k3_c1_cl_h16): the k_z slices are columns 0..2 of one tile."""
     rng = np.random.default_rng(3)
     w = bf16_exact(rng, (1, 8, 3, 3, 3))
     x = rng.standard_normal((8, 4, 3, 6)).astype(np.float32)
@@ -85,7 +86,7 @@ def _transposed_from_classes(x, classes, Co, nd):
 
 @pytest.mark.parametrize("Ci,Co", [(16, 8), (32, 16), (64, 32), (16, 16)])
 def test_pack_convtranspose3d_parity_classes(Ci, Co):
-    """ops._pack_t2_bf16 (d3d_convtranspose3d_k3s2_zs_bf16 / _cl_bf16): eight parity classes, taps (dz,dy,dx) dz-major."""
+    """ops._pack_t2_bf16 (d3d_convtranspose3d_k3s2_zs_h16 / _cl_bf16): eight parity classes, taps (dz,dy,dx) dz-major."""
     rng = np.random.default_rng(Ci * 3 + Co)
     w = bf16_exact(rng, (Ci, Co, 3, 3, 3))
     x = rng.standard_normal((Ci, 2, 3, 4)).astype(np.float32)
@@ -151,7 +152,7 @@ def test_pack_conv2d_three_way_bf16_split(Ci, Co):
     frag = ops._pack_z2_bf16x3(torch.from_numpy(w))
     assert frag.shape[0] == 3
     taps = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
-    B = [dense_from_fragments(frag[s], 32) for s in range(3)]
+    B = [dense_from_fragments(frag[s], 32, torch.bfloat16) for s in range(3)]
     got = np.zeros((Co, 6, 9), np.float64)
     for sa, sb in [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]:
         got += conv_from_B(xs[sa], B[sb], taps, Co, (6, 9)).astype(np.float64)
@@ -170,7 +171,7 @@ def test_pack_convtranspose2d_three_way_split_is_three_bf16_packings():
     parts = ops._split3_bf16(w)
     assert frag.shape[0] == 3 and torch.equal(parts[0] + parts[1] + parts[2], w)
     for s_, part in enumerate(parts):
-        assert torch.equal(frag[s_], ops._pack_t2d_bf16(part))
+        assert torch.equal(frag[s_], ops._pack_t2d_bf16(part, torch.bfloat16))
 
 
 @pytest.mark.parametrize("Ci,Co,packer,kblock", [(16, 8, "_pack_t2d_bf16", 32), (8, 1, "_pack_t2d_bf16", 32), (32, 16, "_pack_t2d_f32", 4),

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from deep3d_aerial_amd import ops
 from conv_bench import timeit
-ops.set_conv_precision("bf16")
+ops.set_conv_precision("h16")
 shapes = [(32, 48, 464, 688), (16, 32, 928, 1376), (8, 8, 1856, 2752)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0] == int(sys.argv[1])]

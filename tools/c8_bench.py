@@ -1,5 +1,5 @@
 """conv0 of the three CostRegNets (C_in -> 8, stride 1) at the cascade's full-size shapes: the bf16 matrix-core
-z-streaming kernel (d3d_conv3d_k3_c8_bf16) next to the round-1 bf16 stream kernel and the fp32 vector-unit kernel."""
+z-streaming kernel (d3d_conv3d_k3_c8_h16) next to the round-1 bf16 stream kernel and the fp32 vector-unit kernel."""
 import os
 import sys
 
@@ -22,7 +22,7 @@ for tag, Ci, D, h, w in SHAPES:
     #  D3D_CONV_C8X3=0)
     for mode, env in (("bf16 c8 mfma", {}), ("bf16 stream (r1)", {"D3D_KERNELS_OFF": "c8"}),
                       ("fp32 x3 mfma", None), ("fp32 co8 valu", {"D3D_CONV_C8X3": "0"})):
-        ops.set_conv_precision("bf16" if mode.startswith("bf16") else "fp32")
+        ops.set_conv_precision("h16" if mode.startswith("bf16") else "fp32")
         with config.override(**(env or {})):
             ms = timeit(fn, 5)
         res.append("%s %7.3f ms (%5.0f GB/s, %4.2f of 8 TB/s)" % (mode, ms, gb / ms * 1e3, gb / ms / 8.0))

@@ -70,7 +70,7 @@ def layer3d_cl(tag, Ci, Co, D, h, w, stride=1, transposed=False, in_cl=True, out
     if transposed:
         wt = torch.randn(Ci, Co, 3, 3, 3, device="cuda") * 0.1
         outv = 8 * D * h * w
-        sk = torch.randn(2 * D, 2 * h, 2 * w, Co, device="cuda").to(torch.bfloat16) if skip else None
+        sk = torch.randn(2 * D, 2 * h, 2 * w, Co, device="cuda").to(ops.h16_dtype()) if skip else None
         fn = lambda: ops.convtranspose3d_k3s2_cl(x, wt, skip=sk, relu=True)
         flop = 2 * 27 * Ci * Co * D * h * w
     else:
@@ -126,7 +126,7 @@ if __name__ == "__main__":
         costreg3d("cas s2", 16, 32, H // 2, W // 2)
         costreg3d("cas s1", 32, 48, H // 4, W // 4)
     if which in ("all", "3dcl"):
-        ops.set_conv_precision("bf16")
+        ops.set_conv_precision("h16")
         costreg3d_cl("cas s3", 8, 8, H, W)
         costreg3d_cl("cas s2", 16, 32, H // 2, W // 2)
         costreg3d_cl("cas s1", 32, 48, H // 4, W // 4)

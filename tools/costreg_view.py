@@ -4,11 +4,11 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep3d_aerial_amd import ops, synthetic as S
 from deep3d_aerial_amd.cas_mvsnet import CostRegNet
-ops.set_conv_precision("bf16")
+ops.set_conv_precision("h16")
 for C, D, h, w in ((32, 48, 464, 688), (16, 32, 928, 1376), (8, 8, 1856, 2752)):
     net = CostRegNet(C).cuda().eval()
     S.fill_state_dict_(net.state_dict(), 3)
-    vol = torch.randn(D, h, w, C, device="cuda").to(torch.bfloat16)
+    vol = torch.randn(D, h, w, C, device="cuda").to(ops.h16_dtype())
     with torch.no_grad():
         for _ in range(2):
             net.forward_one(vol)

@@ -13,7 +13,7 @@ orig = ops.variance_volume_cl
 def checked(f, p, d):
     got = orig(f, p, d)
     planar = ops.variance_volume(f, p, d)
-    want = planar.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
+    want = planar.to(ops.h16_dtype()).permute(1, 2, 3, 0).contiguous()
     bad = got.view(torch.int16) != want.view(torch.int16)
     nanp = ~torch.isfinite(planar)
     print("variance volume", tuple(got.shape), "mismatching:", int(bad.sum()), "non-finite CL:", int((~torch.isfinite(got.float())).sum()),
@@ -26,7 +26,7 @@ def checked(f, p, d):
         print("  got", got[i0[0], i0[1], i0[2]].float().tolist(), "\n  want", want[i0[0], i0[1], i0[2]].float().tolist())
     return got
 ops.variance_volume_cl = checked
-ops.set_conv_precision("bf16")
+ops.set_conv_precision("h16")
 with torch.no_grad():
     o = net(imgs, pm, dv)
 for st in ("stage1", "stage2", "stage3"):

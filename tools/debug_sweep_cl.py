@@ -13,7 +13,7 @@ for stage, C, D, sc in (("stage2", 16, 32, 2), ("stage1", 32, 48, 4), ("stage3",
     base = torch.full((h, w), 0.5 * (lo + hi), device="cuda") + 3.0 * torch.randn(h, w, device="cuda")
     depth = ops.depth_range_samples(base, D, (hi - lo) / 384 * sc) if stage != "stage1" else ops.depth_range_samples(dv, D, 0.0)
     planar = ops.variance_volume(feats, p34, depth)
-    want = planar.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
+    want = planar.to(ops.h16_dtype()).permute(1, 2, 3, 0).contiguous()
     got = ops.variance_volume_cl(feats, p34, depth)
     bad = (got.view(torch.int16) != want.view(torch.int16))
     nb = int(bad.sum())

@@ -9,9 +9,9 @@ from deep3d_aerial_amd import ops
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 n_cases = int(os.environ.get("FUZZ_CASES", "80"))
-ops.set_conv_precision(os.environ.get("FUZZ_PRECISION", "bf16"))
+ops.set_conv_precision(os.environ.get("FUZZ_PRECISION", "h16"))
 torch.backends.cudnn.allow_tf32 = False
-bf = (lambda t: t.to(torch.bfloat16).float()) if os.environ.get("FUZZ_PRECISION", "bf16") == "bf16" else (lambda t: t)   # fp32 mode: exact operands
+bf = (lambda t: t.to(ops.h16_dtype()).float()) if os.environ.get("FUZZ_PRECISION", "h16") == "h16" else (lambda t: t)   # fp32 mode: exact operands
 nbad, worst = 0, 0.0
 for case in range(n_cases):
     kind = str(rng.choice(["s1", "gates", "update", "s2", "t2"]))

@@ -10,14 +10,14 @@ from deep3d_aerial_amd import ops
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 n_cases = int(os.environ.get("FUZZ_CASES", "60"))
 torch.backends.cudnn.allow_tf32 = False
-bf = lambda t: t.to(torch.bfloat16).float()
-cl = lambda t: t.permute(1, 2, 3, 0).contiguous().to(torch.bfloat16)      # planar fp32 [C,D,H,W] -> CL bf16
+bf = lambda t: t.to(ops.h16_dtype()).float()
+cl = lambda t: t.permute(1, 2, 3, 0).contiguous().to(ops.h16_dtype())      # planar fp32 [C,D,H,W] -> CL bf16
 uncl = lambda t: t.float().permute(3, 0, 1, 2).contiguous()
 S1 = [(8, 8), (16, 8), (32, 8), (16, 16), (32, 32), (64, 64), (8, 16), (32, 16), (8, 1), (16, 1), (32, 1)]
 S2 = [(8, 16), (16, 32), (32, 64), (8, 8), (16, 16)]
 T2 = [(16, 8), (32, 16), (64, 32), (16, 16)]
 worst, nbad = 0.0, 0
-ops.set_conv_precision("bf16")
+ops.set_conv_precision("h16")
 for case in range(n_cases):
     kind = str(rng.choice(["s1", "s2", "t2"]))
     Ci, Co = [S1, S2, T2][["s1", "s2", "t2"].index(kind)][int(rng.integers(0, [len(S1), len(S2), len(T2)][["s1", "s2", "t2"].index(kind)]))]

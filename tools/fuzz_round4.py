@@ -17,7 +17,7 @@ from deep3d_aerial_amd import ops  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
-bf = lambda t: t.to(torch.bfloat16).double()
+bf = lambda t: t.to(ops.h16_dtype()).double()
 bad = 0
 
 
@@ -30,7 +30,7 @@ def cell64(cost, state, w1, wg, bg, wc, bc, stride, hid):
     return (u * state.double()[None] + (1 - u) * c)[0]
 
 
-with ops.bf16_convs():
+with ops.h16_convs():
     for i in range(cases):
         # ---- fused conv-GRU cell ----
         stride = int(rng.integers(1, 3))
@@ -100,8 +100,8 @@ with ops.bf16_convs():
                 print("head case %d vs the two launches: transposed %s %dx%d mode %d differs" % (i, tr, hh, ww, mode)); bad += 1
         # ---- conv11 + prob of a CostRegNet in one kernel against the two launches (bit for bit) ----
         D3, H3, W3 = int(rng.integers(1, 10)), int(rng.integers(1, 40)), 2 * int(rng.integers(1, 50))
-        x3 = dev(rng.standard_normal((D3, H3, W3, 16))).to(torch.bfloat16)
-        sk3 = dev(rng.standard_normal((2 * D3, 2 * H3, 2 * W3, 8))).to(torch.bfloat16) if rng.integers(0, 4) else None
+        x3 = dev(rng.standard_normal((D3, H3, W3, 16))).to(ops.h16_dtype())
+        sk3 = dev(rng.standard_normal((2 * D3, 2 * H3, 2 * W3, 8))).to(ops.h16_dtype()) if rng.integers(0, 4) else None
         w11, wp3 = dev(0.1 * rng.standard_normal((16, 8, 3, 3, 3))), dev(0.1 * rng.standard_normal((1, 8, 3, 3, 3)))
         sc3, sh3, bp3 = dev(rng.uniform(0.5, 1.5, 8)), dev(rng.standard_normal(8)), dev(rng.standard_normal(1))
         one = ops.convtranspose3d_prob_cl(x3, w11, sc3, sh3, sk3, wp3, bp3)

@@ -51,7 +51,7 @@ for case in range(n_cases):
     if mode == "variance" and C % 8 == 0:   # the channel-last bf16 volume must be the rounding of the ring kernel's planar one
         config.switches["D3D_FORCE_PATH"] = "tiled"
         cl = ops.variance_volume_cl(feats, p34, depth)
-        want = a.to(torch.bfloat16).permute(1, 2, 3, 0).contiguous()
+        want = a.to(ops.h16_dtype()).permute(1, 2, 3, 0).contiguous()
         nbad = int((cl.view(torch.int16) != want.view(torch.int16)).sum())
         cl8 = ops.variance_volume_cl(feats, p34, depth, layout="cl8")
         nbad += int((ops.cl8_to_cl(cl8).view(torch.int16) != want.view(torch.int16)).sum())
@@ -64,7 +64,7 @@ for case in range(n_cases):
         if mode == "variance" and C % 8 == 0:
             config.switches["D3D_FORCE_PATH"] = "window"
             clw = ops.variance_volume_cl(feats, p34, depth)
-            wantw = outs["window"].to(torch.bfloat16).permute(1, 2, 3, 0).contiguous().view(torch.int16)
+            wantw = outs["window"].to(ops.h16_dtype()).permute(1, 2, 3, 0).contiguous().view(torch.int16)
             nwc = int((clw.view(torch.int16) != wantw).sum())
             nwc += int((ops.cl8_to_cl(ops.variance_volume_cl(feats, p34, depth, layout="cl8")).view(torch.int16) != wantw).sum())
             cl_note += ", its channel-last form %d" % nwc

@@ -3,7 +3,7 @@ tools/run_pmc_script.sh).  argv[1]: bf16 (default) | fp32 -- the precision mode 
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep3d_aerial_amd import ops
-ops.set_conv_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
+ops.set_conv_precision(sys.argv[1] if len(sys.argv) > 1 else "h16")
 H, W = 1856, 2752
 x = torch.randn(8, H, W, device="cuda"); h8 = torch.randn(8, H, W, device="cuda")
 wg = torch.randn(16, 16, 3, 3, device="cuda") * 0.1; bg = torch.randn(16, device="cuda")

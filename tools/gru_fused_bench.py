@@ -34,7 +34,7 @@ def timed(fn):
 cases = [("stage 1 gru1", 32, 1, 688, 464), ("stage 1 gru2", 8, 2, 688, 464), ("stage 2 gru1", 16, 1, 1376, 928),
          ("stage 2 gru2", 8, 2, 1376, 928), ("stage 3 gru1", 8, 1, 2752, 1856), ("stage 3 gru2", 8, 2, 2752, 1856)]
 print("%-14s %10s %10s %8s %10s %8s" % ("cell", "fused us", "3 launches", "ratio", "min MB", "fused TB/s"))
-with ops.bf16_convs():
+with ops.h16_convs():
     for label, C, s, h, w in cases:
         hid = 8 if s == 1 else 16
         H, W = (h, w) if s == 1 else ((h - 1) // 2 + 1, (w - 1) // 2 + 1)

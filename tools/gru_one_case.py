@@ -11,7 +11,7 @@ w1 = dev(rng.standard_normal((hid, C, 3, 3)) / np.sqrt(9 * C))
 wg = dev(rng.standard_normal((2 * hid, 2 * hid, 3, 3)) / np.sqrt(18 * hid))
 wc = dev(rng.standard_normal((hid, 2 * hid, 3, 3)) / np.sqrt(18 * hid))
 bg, bc = dev(rng.standard_normal(2 * hid)), dev(rng.standard_normal(hid))
-with ops.bf16_convs():
+with ops.h16_convs():
     for _ in range(3):
         ops.gru_cell_conv_fused(cost, st, w1, wg, bg, wc, bc, 1)
 torch.cuda.synchronize()

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep3d_aerial_amd import config, predict, synthetic as S
 
 model = sys.argv[1] if len(sys.argv) > 1 else "casmvsnet"
-prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+prec = sys.argv[2] if len(sys.argv) > 2 else "h16"
 config.switches["D3D_CONV_PRECISION"] = prec
 from deep3d_aerial_amd import ops
 net = predict.build_model(model, 384)

@@ -17,7 +17,7 @@ for tag in ["model_casmvsnet_v3", "model_casmvsnet_v5", "model_adamvs_v3", "mode
     res = []
     for feat in ("fp32", "follow"):
         config.switches["D3D_FEATURE_PRECISION"] = feat
-        ops.set_conv_precision("bf16")
+        ops.set_conv_precision("h16")
         with torch.no_grad():
             out = net(dev(g["imgs"]), pm, dev(g["depth_values"]))
         ops.set_conv_precision(None)

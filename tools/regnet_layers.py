@@ -12,12 +12,12 @@ from deep3d_aerial_amd.cas_mvsnet import CostRegNet  # noqa: E402
 from deep3d_aerial_amd.module import folded_bn  # noqa: E402
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-ops.set_conv_precision("bf16")
+ops.set_conv_precision("h16")
 total = {}
 for tag, C, D, h, w in (("stage1", 32, 48, 464, 688), ("stage2", 16, 32, 928, 1376), ("stage3", 8, 8, 1856, 2752)):
     net = CostRegNet(C).cuda().eval()
     S.fill_state_dict_(net.state_dict(), 3)
-    vol = ops.cl_to_cl8(torch.randn(D, h, w, C, device="cuda").to(torch.bfloat16))
+    vol = ops.cl_to_cl8(torch.randn(D, h, w, C, device="cuda").to(ops.h16_dtype()))
     times = {}
 
     def run(name, fn):

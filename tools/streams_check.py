@@ -4,7 +4,7 @@ pyramids of a view set) against the one-stream forward and against itself -- rel
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from deep3d_aerial_amd import config, predict, synthetic as S, ops
-ops.set_conv_precision("bf16")
+ops.set_conv_precision("h16")
 model, switch = (sys.argv[1], sys.argv[2]) if len(sys.argv) > 2 else ("msrednet", "red_streams")
 net = predict.build_model(model, 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
 s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]

@@ -3,7 +3,7 @@ and direct kernels forced: python tools/sweep_in_model.py casmvsnet|adamvs|msred
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep3d_aerial_amd import config, predict, synthetic as S, ops
-config.switches["D3D_CONV_PRECISION"] = "bf16"
+config.switches["D3D_CONV_PRECISION"] = "h16"
 model = sys.argv[1] if len(sys.argv) > 1 else "msrednet"
 net = predict.build_model(model, 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
 s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]

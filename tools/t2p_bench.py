@@ -1,4 +1,4 @@
-"""conv11 + prob of the three CostRegNets at the cascade's full-size shapes: the fused kernel (d3d_convtranspose3d_prob_cl_bf16)
+"""conv11 + prob of the three CostRegNets at the cascade's full-size shapes: the fused kernel (d3d_convtranspose3d_prob_cl_h16)
 next to the two launches it replaces (x-folded transposed layer, k_z-folded probability layer)."""
 import os
 import sys
@@ -11,8 +11,8 @@ from conv_bench import timeit  # noqa: E402
 
 SHAPES = [("stage1", 24, 232, 344), ("stage2", 16, 464, 688), ("stage3", 4, 928, 1376)]   # coarse [D, H, W] (W = the long side)
 for tag, D, H, W in SHAPES:
-    x = torch.randn(D, H, W, 16, device="cuda").to(torch.bfloat16)
-    sk = torch.randn(2 * D, 2 * H, 2 * W, 8, device="cuda").to(torch.bfloat16)
+    x = torch.randn(D, H, W, 16, device="cuda").to(ops.h16_dtype())
+    sk = torch.randn(2 * D, 2 * H, 2 * W, 8, device="cuda").to(ops.h16_dtype())
     wt = torch.randn(16, 8, 3, 3, 3, device="cuda") * 0.1
     wp = torch.randn(1, 8, 3, 3, 3, device="cuda") * 0.1
     sc, sh, bp = torch.rand(8, device="cuda") + 0.5, torch.randn(8, device="cuda"), torch.randn(1, device="cuda")

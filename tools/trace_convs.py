@@ -23,7 +23,7 @@ for n in ("conv_k3_mfma", "convtranspose_k3s2_mfma", "conv_fold", "conv2d_stream
 net = predict.build_model("adamvs", 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
 s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
 imgs = torch.from_numpy(s["imgs"])[None].cuda(); pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}; dv = torch.from_numpy(s["depth_values"])[None].cuda()
-ops.set_conv_precision(os.environ.get("TRACE_PRECISION", "bf16"))
+ops.set_conv_precision(os.environ.get("TRACE_PRECISION", "h16"))
 with torch.no_grad():
     if timed:
         net(imgs, pm, dv); cnt.clear(); ms.clear()   # warm-up: packed weights, kernel attributes
