@@ -465,8 +465,13 @@ class MVSDataset(object):
         ALL its listed sources up to fusion_num, "id": the 1-based position of the image in the block's image list (what
         Fuse_Depth_Map.read_ImageID counts, :284-303; 0 means "not visible" in the visibility planes)}.  No image is read."""
         name = lambda i: os.path.splitext(str(self.image_params_dict[i].name))[0]
-        return [{"name": name(s[0]), "src": [name(j) for j in s[1:1 + fusion_num]], "id": int(s[0]) + 1, "image": int(s[0])}
-                for s in self.sample_list]
+        recs = []
+        for s in self.sample_list:
+            src = list(s[1:])
+            if len(src) < fusion_num:   # :241-244: short lists are filled up with their first source (it is then checked again)
+                src += [src[0]] * (fusion_num - len(src))
+            recs.append({"name": name(s[0]), "src": [name(j) for j in src[:fusion_num]], "id": int(s[0]) + 1, "image": int(s[0])})
+        return recs
 
     def device_item(self, idx):
         ids = self.sample_list[idx][:self.view_num]

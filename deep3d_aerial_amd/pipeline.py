@@ -19,8 +19,8 @@ sharding.shard_views), against the gathered maps of ALL views.  What this preser
   a source map loses the samples a reference view has confirmed before the NEXT reference view reads it -- a chain through
   the whole view list of a scene block.  A rank runs that chain over its own reference views in list order, starting from
   the unfiltered gathered maps: inside a rank's block of views the reference's behaviour is kept exactly; samples confirmed
-  by reference views of LOWER ranks are still offered (a few more duplicate points along the seams between rank blocks,
-  never fewer points).  One rank reproduces the reference's chain over the whole list.
+  by reference views of LOWER ranks are still offered (duplicate points along the seams between rank blocks).  One rank
+  reproduces the reference's chain over the whole list.
 
 The view list, the sources of a view (all the sources viewpair.txt lists, up to `fusion_num` -- the fusion step does not stop
 at predict's view_num: fusion_3d_normal.py:98, 476) and the 1-based image ids of the visibility lists come from the dataset

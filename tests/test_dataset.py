@@ -215,3 +215,21 @@ def test_feature_cache_hit_survives_eviction_by_an_earlier_miss():
     assert calls == [1.0, 2.0]
     feats = DS.extract_features(net, [b, None, None], ["B", "B", "B"], cache)   # padded source lists repeat an image
     assert len(calls) == 2 and all(float(f["stage1"][0, 0, 0, 0]) == 4.0 for f in feats)
+
+
+def test_view_records_list_the_fusion_sources(tmp_path):
+    """dataset.view_records (pipeline.predict_and_fuse): the view list of the fusion step as fuse/fusion_3d_normal.py:227-249 reads
+    it -- every listed source up to fusion_num (not predict's view_num), short lists filled with their first source, views without
+    sources dropped, 1-based image positions as visibility ids."""
+    from deep3d_aerial_amd import dataset as D, predict as P
+
+    BF, folder = _block(tmp_path)
+    ds = D.MVSDataset(folder, "val", BF.VIEW_NUM, "mean", BF.Args())
+    recs = D.DeviceItems(ds).view_records(4)
+    assert [r["name"] for r in recs] == ["img_00", "img_01", "img_02", "img_03"] and [r["id"] for r in recs] == [1, 2, 3, 4]
+    assert recs[0]["src"] == ["img_01", "img_02", "img_03", "img_01"]          # 3 listed, filled to 4
+    assert recs[2]["src"] == ["img_01", "img_03", "img_00", "img_04"]          # all 4 listed (predict uses the first view_num - 1)
+    assert recs[3]["src"] == ["img_04"] * 4
+    assert [r["src"] for r in ds.view_records(2)] == [["img_01", "img_02"], ["img_00", "img_02"], ["img_01", "img_03"], ["img_04", "img_04"]]
+    strip = P.SyntheticStrip(5, 3, 32, 32, 64).view_records(10)
+    assert strip[4] == {"name": "view_0004", "src": ["view_0000", "view_0001", "view_0002", "view_0003"], "id": 5, "image": 4}

@@ -69,7 +69,11 @@ def test_bench_two_ranks(tmp_path):
     assert len(lines) == 1                                       # rank 0 alone prints
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["roofline"]["bound"] == "hbm" and "cpu_baseline" not in d and "secondary" not in d
+    assert d["roofline"]["bound"] == "valu+lds" and d["roofline"]["priced_against"] == "hbm" and "cpu_baseline" not in d and "secondary" not in d
+    # BASELINE config 5's exchange: the all-gather of the maps ahead of fusion, timed outside the step loop
+    ex = d["exchange"]
+    assert ex["allgather_ms"] > 0 and ex["content_ok"] and ex["shape_per_rank"][1:] == [2, 3712, 2752]
+    assert ex["backend"] == ("gloo" if torch.cuda.device_count() < 2 else "nccl")
     assert d["config"].get("ranks_share_one_gpu", False) == (torch.cuda.device_count() < 2)
     # every rank reports its own kernel time, wall time and device, so a first multi-GPU run can be read rank by rank
     pr = d["per_rank"]

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round measurement on the GPU box for the headline kernel: bench line, rocprofv3 kernel-trace stats, HBM traffic
 # (separate FETCH_SIZE / WRITE_SIZE passes) and SQ counters.  Usage: tools/profile_round.sh r02
-# Outputs under gpurun_out/<round>/ ; the summary (with the SHA-256 of the kernel source it was taken from) is what gets
-# copied to profiles/pmc_latest.json -- bench.py reports `roofline.traffic` only while that hash matches the tree.
+# Outputs under gpurun_out/<round>/ ; the summary (with the SHA-256 of the kernel's machine code it was taken from) is what gets
+# copied to profiles/pmc_latest.json -- bench.py reports `roofline.traffic` only while the kernel's machine code in the built
+# library hashes to what this profile recorded (_lib.kernel_code_sha256).  Make this the LAST GPU action of a round.
 R=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $out
@@ -18,9 +19,12 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_
 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq2 -- $B --steps 3 --warmup 1 > $out/pmc_sq2.log 2>&1
 cp $out/trace/*/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
 python3 - <<PY
-import csv, glob, collections, json, hashlib
+import csv, glob, collections, json, hashlib, sys
 out = "$out"
 root = "$GRAFT_REPO_ROOT"
+sys.path.insert(0, root)
+from deep3d_aerial_amd import _lib
+PREFIX = "_ZN3d3d18sweep_tiled_kernelILi1ELi4ELi16EfLb0ELi4ELi4ELi2EEE"   # bench.HEADLINE_KERNEL_PREFIX
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -31,7 +35,7 @@ for f in glob.glob(out + "/pmc_*/*/*counter_collection.csv"):
 avg = {k: {c: sum(v) / len(v) for c, v in d.items() if c != "_name"} for k, d in per.items()}
 res = {"round": "$R", "command": "python bench.py --steps 20 --warmup 5 (rocprofv3 passes: --steps 3 --warmup 1 --no-cpu-baseline --no-secondary); tools/profile_round.sh",
        "kernel": per["sweep"].get("_name"), "staging_copy_kernel": per["staging_copy"].get("_name"),
-       "kernel_source_sha256": hashlib.sha256(open(root + "/deep3d_aerial_amd/csrc/planesweep_tiled.hip", "rb").read()).hexdigest()}
+       "kernel_symbol_prefix": PREFIX, "kernel_code_sha256": _lib.kernel_code_sha256(PREFIX)}
 for f in glob.glob(out + "/trace/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if "sweep_tiled" in r["Name"]:
