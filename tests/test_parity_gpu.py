@@ -44,28 +44,50 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.fixture(params=["auto", "direct", "tiled", "window"])
+PATHS = ["auto", "direct", "tiled", "window"]
+
+
+@pytest.fixture(autouse=True)
+def _dispatcher_chooses_again():
+    """No test leaves a kernel family forced behind it."""
+    yield
+    config.switches["D3D_FORCE_PATH"] = ""
+
+
+def _force(name):
+    old = config.switches.get("D3D_FORCE_PATH")
+    config.switches["D3D_FORCE_PATH"] = "" if name == "auto" else name
+    return old
+
+
+@pytest.fixture(params=PATHS)
 def path(request):
     """Runs a test on the dispatcher's choice and with each kernel family forced."""
-    old = config.switches.get("D3D_FORCE_PATH")
-    if request.param == "auto":
-        config.switches["D3D_FORCE_PATH"] = ""
-    else:
-        config.switches["D3D_FORCE_PATH"] = request.param
+    old = _force(request.param)
     yield request.param
-    if old is None:
-        config.switches["D3D_FORCE_PATH"] = ""
-    else:
-        config.switches["D3D_FORCE_PATH"] = old
+    config.switches["D3D_FORCE_PATH"] = old or ""
 
 
-def _run_or_skip_unsupported(fn, path):
-    try:
-        return fn()
-    except RuntimeError as e:
-        if path in ("tiled", "window") and "unsupported" in str(e):
-            pytest.skip("shape outside the %s kernel's domain (the dispatcher takes another kernel)" % path)
-        raise
+@pytest.fixture(params=["auto", "direct", "tiled"])
+def warp_path(request):
+    """The kernel families that have a warp mode (d3d_homo_warp): the window kernel has none -- no model calls the bare warp, every
+    sweep it serves is an aggregation (csrc/planesweep_window.hip launch_window) -- so it is not a parameter here instead of a skip."""
+    old = _force(request.param)
+    yield request.param
+    config.switches["D3D_FORCE_PATH"] = old or ""
+
+
+def _takes(path, V, C, pair=False):
+    """Does the forced kernel family take an fp32 sweep of V views and C channels?  Mirrors launch_window
+    (csrc/planesweep_window.hip: C % 8 == 0, at most 4 source views) and launch_tiled (csrc/planesweep_tiled.hip: C % 8 == 0, at
+    most 6); the pair pass of both is built for 8 / 16 / 32 channels.  The dispatcher ("auto") and the direct kernel take anything.
+    A forced family REFUSES shapes outside its domain (D3D_ERR_UNSUPPORTED): the tests below are parametrised over the domain, so
+    an "unsupported" inside it is a failure, not a skip."""
+    if path in ("auto", "direct"):
+        return True
+    if C % 8 or (pair and C not in (8, 16, 32)):
+        return False
+    return V - 1 <= (4 if path == "window" else 6)
 
 
 # ----------------------------------------------------------------------------------------
@@ -85,41 +107,45 @@ def test_compose_projections(ops, oracle):
         assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max()
 
 
-def test_homo_warp_golden(ops, path):
+def test_homo_warp_golden(ops, warp_path):
     g = load_golden("ops_warp")
+    ran = 0
     for i in range(int(g["n_cases"])):
         k = "c%d_" % i
-        got = _run_or_skip_unsupported(
-            lambda: host(ops.homo_warp(dev(g[k + "src"]), dev(g[k + "proj34"]).reshape(12), dev(g[k + "depth"]))), path)
+        if not _takes(warp_path, 2, g[k + "src"].shape[0]):
+            continue   # (C = 4 fixtures: outside the ring kernel's 8-channel groups; the dispatcher and the direct kernel run them)
+        got = host(ops.homo_warp(dev(g[k + "src"]), dev(g[k + "proj34"]).reshape(12), dev(g[k + "depth"])))
         want = g[k + "out"]
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= ABS_GATHER, i
         # zero padding must be exact zeros, not small numbers
         far = np.abs(want) == 0
         assert np.abs(got[far]).max(initial=0.0) <= ABS_GATHER
+        ran += 1
+    assert ran >= 10, ran
 
 
-def test_homo_warp_identity_is_copy(ops, path):
+def test_homo_warp_identity_is_copy(ops, warp_path):
     src = S.make_features(1, 8, 40, 72, seed=3)[0]
     p34 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(12)
     depth = np.array([1.0, 2.0, 7.5], np.float32)
-    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(p34), dev(depth))), path)
+    got = host(ops.homo_warp(dev(src), dev(p34), dev(depth)))
     for d in range(3):
         assert np.array_equal(got[:, d], src)
 
 
-def test_homo_warp_out_of_frustum_and_nonfinite(ops, path):
-    src = np.ones((4, 16, 64), np.float32)
+def test_homo_warp_out_of_frustum_and_nonfinite(ops, warp_path):
+    src = np.ones((8, 16, 64), np.float32)
     depth = np.array([1.0, 2.0], np.float32)
     shift = np.array([[1, 0, 0, 5000], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(12)  # far right
-    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(shift), dev(depth))), path)
+    got = host(ops.homo_warp(dev(src), dev(shift), dev(depth)))
     assert np.count_nonzero(got) == 0
     zero_z = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 0]], np.float32).reshape(12)  # p.z == 0 -> inf/nan
-    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(zero_z), dev(depth))), path)
+    got = host(ops.homo_warp(dev(src), dev(zero_z), dev(depth)))
     assert np.isfinite(got).all() and np.count_nonzero(got) == 0
     # half-pixel shift at the border: partial taps (zero padding per tap)
     half = np.array([[1, 0, 0, -0.5], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(12)
-    got = _run_or_skip_unsupported(lambda: host(ops.homo_warp(dev(src), dev(half), dev(np.array([1.0], np.float32)))), path)
+    got = host(ops.homo_warp(dev(src), dev(half), dev(np.array([1.0], np.float32))))
     assert np.allclose(got[:, 0, :, 0], 0.5) and np.allclose(got[:, 0, :, 1:], 1.0)
 
 
@@ -128,19 +154,25 @@ def test_homo_warp_out_of_frustum_and_nonfinite(ops, path):
 # ----------------------------------------------------------------------------------------
 def test_aggregation_golden(ops, path):
     g = load_golden("ops_aggregate")
+    ran = 0
     for i in range(int(g["n_cases"])):
         k = "c%d_" % i
+        V, C = len(g[k + "feats"]), g[k + "feats"][0].shape[0]
+        if not _takes(path, V, C, pair=True):
+            continue   # (a fixture outside the forced family's domain -- see _takes; "auto" and "direct" run every fixture)
         feats = [dev(f) for f in g[k + "feats"]]
         p34 = dev(g[k + "proj34"]).reshape(-1, 12)
         depth = dev(g[k + "depth"])
-        var = _run_or_skip_unsupported(lambda: host(ops.variance_volume(feats, p34, depth)), path)
+        var = host(ops.variance_volume(feats, p34, depth))
         assert np.abs(var - g[k + "variance"]).max() <= 2 * ABS_GATHER, i
         assert rel_l1(var, g[k + "variance"]) <= REL_VOLUME, i
-        wc = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(feats, p34, dev(g[k + "weights"]), depth)), path)
+        wc = host(ops.weighted_corr(feats, p34, dev(g[k + "weights"]), depth))
         assert rel_l1(wc, g[k + "weighted"]) <= REL_VOLUME, i
         for j in range(len(feats) - 1):
-            pm = _run_or_skip_unsupported(lambda: host(ops.pair_corr_mean(feats[0], feats[j + 1], p34[j], depth)), path)
+            pm = host(ops.pair_corr_mean(feats[0], feats[j + 1], p34[j], depth))
             assert np.abs(pm - g[k + "pair_mean"][j]).max() <= ABS_GATHER, (i, j)
+        ran += 1
+    assert ran >= 1, "no golden case inside the %s kernel's domain" % path
 
 
 CASES = [
@@ -153,11 +185,19 @@ CASES = [
     (2, 32, 37, 53, 5, "plane", 3.0, 1.0),      # ragged sizes: not multiples of any tile
     (4, 12, 33, 70, 3, "pixel", 3.0, 25.0),     # odd channel count multiple of 4, big yaw
     (3, 5, 20, 30, 2, "plane", 2.0, 1.0),       # C not a multiple of 4
+    # (round 5) the window kernel's own corners -- it serves every sweep of the cascades: ragged with a big yaw, the cascade
+    # stages' channel counts on per-pixel hypotheses, its plane limit
+    (4, 16, 33, 70, 3, "pixel", 3.0, 25.0),
+    (5, 24, 41, 67, 7, "pixel", 5.0, 6.0),      # three 8-channel groups (RED-Net's 24-channel level)
+    (5, 8, 50, 90, 48, "plane", 20.0, 2.0),     # 48 planes: the largest sweep the dispatcher hands the window kernel
+    (3, 32, 29, 47, 32, "pixel", 10.0, 12.0),
 ]
+_case_id = lambda c: "V%d_C%d_%dx%d_D%d_%s" % c[:6]
+AGG_PARAMS = [pytest.param(p, c, id="%s-%s" % (p, _case_id(c))) for p in PATHS for c in CASES if _takes(p, c[0], c[1])]
+WARP_PARAMS = [pytest.param(p, c, id="%s-%s" % (p, _case_id(c))) for p in ("auto", "direct", "tiled") for c in CASES if _takes(p, c[0], c[1])]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "V%d_C%d_%dx%d_D%d_%s" % c[:6])
-def test_aggregation_vs_oracle(ops, oracle, path, case):
+def _agg_case(case):
     V, C, h, w, D, kind, sweep, yaw = case
     proj, dv = S.make_scene(V, h, w, D, sweep_px=sweep, seed=V * 100 + C, yaw_deg=yaw)
     feats = S.make_features(V, C, h, w, seed=C + D)
@@ -166,31 +206,58 @@ def test_aggregation_vs_oracle(ops, oracle, path, case):
         depth = S.uniform_depths(dv, D)
     else:
         depth = np.sort(rng.uniform(dv[0], dv[1], (D, h, w)).astype(np.float32), 0)
-    fd = [dev(f) for f in feats]
-    p34 = ops.compose_projections(dev(proj))
-    p34_host = host(p34).reshape(-1, 3, 4)
-    dd = dev(depth)
+    return proj, feats, depth, rng
 
-    var = _run_or_skip_unsupported(lambda: host(ops.variance_volume(fd, p34, dd)), path)
-    want = oracle.variance_volume(feats[0], feats[1:], p34_host, depth)
-    assert np.abs(var - want).max() <= 2 * ABS_GATHER
-    assert rel_l1(var, want) <= REL_VOLUME
 
-    vw = rng.uniform(0.02, 1.0, (V - 1, h, w)).astype(np.float32)
-    wc = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(fd, p34, dev(vw), dd)), path)
-    # plane-major output [D,C,h,w] (what the slice loop of the AdaMVS driver reads): the same values, transposed
-    wc_pm = _run_or_skip_unsupported(lambda: host(ops.weighted_corr(fd, p34, dev(vw), dd, plane_major=True)), path)
-    assert np.array_equal(wc_pm.transpose(1, 0, 2, 3), wc)
-    want = oracle.weighted_corr(feats[0], feats[1:], p34_host, vw, depth)
-    assert rel_l1(wc, want) <= REL_VOLUME
+@pytest.mark.parametrize("forced,case", AGG_PARAMS)
+def test_aggregation_vs_oracle(ops, oracle, forced, case):
+    """Variance, weighted correlation (both output orders) and the pair pass of every kernel family against the oracle, over
+    the shapes inside the family's domain (_takes): a case listed here PASSES or FAILS, it is never skipped."""
+    V, C, h, w, D, kind, sweep, yaw = case
+    proj, feats, depth, rng = _agg_case(case)
+    old = _force(forced)
+    try:
+        fd = [dev(f) for f in feats]
+        p34 = ops.compose_projections(dev(proj))
+        p34_host = host(p34).reshape(-1, 3, 4)
+        dd = dev(depth)
 
-    pm = _run_or_skip_unsupported(lambda: host(ops.pair_corr_mean(fd[0], fd[1], p34[0], dd)), path)
-    want = oracle.pair_corr_mean(feats[0], feats[1], p34_host[0], depth)
-    assert np.abs(pm - want).max() <= ABS_GATHER
+        var = host(ops.variance_volume(fd, p34, dd))
+        want = oracle.variance_volume(feats[0], feats[1:], p34_host, depth)
+        assert np.abs(var - want).max() <= 2 * ABS_GATHER
+        assert rel_l1(var, want) <= REL_VOLUME
 
-    wp = _run_or_skip_unsupported(lambda: host(ops.homo_warp(fd[1], p34[0], dd)), path)
-    want = oracle.homo_warp(feats[1], p34_host[0], depth)
-    assert np.abs(wp - want).max() <= ABS_GATHER
+        vw = rng.uniform(0.02, 1.0, (V - 1, h, w)).astype(np.float32)
+        wc = host(ops.weighted_corr(fd, p34, dev(vw), dd))
+        # plane-major output [D,C,h,w] (what the slice loop of the AdaMVS driver reads): the same values, transposed
+        wc_pm = host(ops.weighted_corr(fd, p34, dev(vw), dd, plane_major=True))
+        assert np.array_equal(wc_pm.transpose(1, 0, 2, 3), wc)
+        want = oracle.weighted_corr(feats[0], feats[1:], p34_host, vw, depth)
+        assert rel_l1(wc, want) <= REL_VOLUME
+
+        if _takes(forced, 2, C, pair=True):   # (the pair pass of the forced families exists for 8 / 16 / 32 channels)
+            pm = host(ops.pair_corr_mean(fd[0], fd[1], p34[0], dd))
+            want = oracle.pair_corr_mean(feats[0], feats[1], p34_host[0], depth)
+            assert np.abs(pm - want).max() <= ABS_GATHER
+        if forced != "auto":   # the family asked for is the family that ran
+            counts = ops.sweep_dispatch_counts()
+            assert counts[forced] > 0, counts
+    finally:
+        config.switches["D3D_FORCE_PATH"] = old or ""
+
+
+@pytest.mark.parametrize("forced,case", WARP_PARAMS)
+def test_homo_warp_vs_oracle(ops, oracle, forced, case):
+    """d3d_homo_warp (module.py:516-557 on its own) on the aggregation cases, for the families that have a warp mode."""
+    proj, feats, depth, _ = _agg_case(case)
+    old = _force(forced)
+    try:
+        p34 = ops.compose_projections(dev(proj))
+        wp = host(ops.homo_warp(dev(feats[1]), p34[0], dev(depth)))
+        want = oracle.homo_warp(feats[1], host(p34).reshape(-1, 3, 4)[0], depth)
+        assert np.abs(wp - want).max() <= ABS_GATHER
+    finally:
+        config.switches["D3D_FORCE_PATH"] = old or ""
 
 
 def test_variance_volume_fp16_storage_7_views(ops, oracle):
@@ -215,8 +282,7 @@ def test_variance_of_identical_views_is_zero(ops, path):
     f = S.make_features(1, 16, 48, 64, seed=9)[0]
     eye = np.tile(np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32).reshape(1, 12), (3, 1))
     fd = dev(f)
-    var = _run_or_skip_unsupported(
-        lambda: host(ops.variance_volume([fd, fd, fd, fd], dev(eye), dev(np.array([1.0, 3.0], np.float32)))), path)
+    var = host(ops.variance_volume([fd, fd, fd, fd], dev(eye), dev(np.array([1.0, 3.0], np.float32))))
     assert np.abs(var).max() <= 2e-6 * float((f ** 2).max())
 
 
@@ -315,11 +381,15 @@ AFFINE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", AFFINE_CASES, ids=lambda c: "V%d_C%d_%dx%d_D%d" % c[:5])
+AFFINE_PARAMS = [pytest.param(p, c, id="%s-V%d_C%d_%dx%d_D%d" % ((p,) + c[:5])) for p in PATHS for c in AFFINE_CASES if _takes(p, c[0], c[1])]
+
+
+@pytest.mark.parametrize("path,case", AFFINE_PARAMS)
 def test_affine_depth_mode_is_the_per_pixel_mode_without_the_volume(ops, oracle, path, case):
     """D3D_DEPTH_AFFINE (hypotheses lo + k * step per pixel, module.py:616-631, given as two maps): every op that takes a
     [D,h,w] hypothesis volume gives bit-identical results from the two maps that generate it, and both match the oracle."""
     V, C, h, w, D, sweep, yaw = case
+    _force(path)
     proj, dv = S.make_scene(V, h, w, D, sweep_px=sweep, seed=V * 10 + C, yaw_deg=yaw)
     feats = S.make_features(V, C, h, w, seed=C + D)
     rng = np.random.default_rng(D + C)
@@ -332,14 +402,13 @@ def test_affine_depth_mode_is_the_per_pixel_mode_without_the_volume(ops, oracle,
     p34 = ops.compose_projections(dev(proj))
     p34_host = host(p34).reshape(-1, 3, 4)
 
-    va = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, aff), path)
-    vv = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, vol), path)
+    va = ops.variance_volume(fd, p34, aff)
+    vv = ops.variance_volume(fd, p34, vol)
     assert torch.equal(va, vv)
     want = oracle.variance_volume(feats[0], feats[1:], p34_host, host(vol))
     assert rel_l1(host(va), want) <= REL_VOLUME
     vw = dev(rng.uniform(0.02, 1.0, (V - 1, h, w)))
-    assert torch.equal(_run_or_skip_unsupported(lambda: ops.weighted_corr(fd, p34, vw, aff), path),
-                       _run_or_skip_unsupported(lambda: ops.weighted_corr(fd, p34, vw, vol), path))
+    assert torch.equal(ops.weighted_corr(fd, p34, vw, aff), ops.weighted_corr(fd, p34, vw, vol))
     if C % 8 == 0 and path != "direct":
         assert torch.equal(ops.variance_volume_cl(fd, p34, aff), ops.variance_volume_cl(fd, p34, vol))
     cost = dev(rng.standard_normal((D, h, w)) * 3.0)
@@ -444,8 +513,8 @@ def test_variance_volume_plane_major_is_the_same_volume(ops, path_):
     depth = dev(S.uniform_depths(dv, D))
     config.switches["D3D_FORCE_PATH"] = path_
     try:
-        a = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, depth), path_)
-        b = _run_or_skip_unsupported(lambda: ops.variance_volume(fd, p34, depth, plane_major=True), path_)
+        a = ops.variance_volume(fd, p34, depth)
+        b = ops.variance_volume(fd, p34, depth, plane_major=True)
     finally:
         config.switches["D3D_FORCE_PATH"] = ""
     assert tuple(b.shape) == (D, C, h, w) and torch.equal(b, a.permute(1, 0, 2, 3))
