@@ -33,7 +33,6 @@ class slice_RED_Regularization(nn.Module):
         self.upconv1 = ConvTransReLU(b * 2, b, 3, 2, 1, 1)
         self.upconv2d = nn.ConvTranspose2d(b, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
 
-    _side = {}   # device index -> three side streams (conv-GRU levels 2, 3 and 1 of a slice)
 
     def forward(self, cost, state1, state2, state3, state4):
         w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
@@ -44,26 +43,27 @@ class slice_RED_Regularization(nn.Module):
             # joins them.  Same kernels on the same operands; every tensor that crosses streams is ordered by an event, and a
             # block freed on a side stream is reused there only behind the next slice's fork, i.e. behind this slice's decoder.
             main = torch.cuda.current_stream(cost.device)
-            side = self._side.get(cost.device.index)
-            if side is None:
-                side = self._side[cost.device.index] = [torch.cuda.Stream(cost.device) for _ in range(3)]
+            side = ops.side_streams(cost.device, 3, "red")   # three per caller stream: conv-GRU levels 2, 3 and 1 of a slice
             e0 = main.record_event()                                                  # (the cost slice and the states exist)
             with torch.cuda.stream(side[2]):                                          # level 1 -- the largest -- beside the encoder
                 side[2].wait_event(e0)
                 state1, _ = self.conv_gru1(cost, state1, negate_x=True)               # conv_gru1(-cost)
                 d1 = side[2].record_event()
+            ops.hand_over(state1, main)
             c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)           # conv1(-cost)
             e1 = main.record_event()
             with torch.cuda.stream(side[0]):
                 side[0].wait_event(e1)
                 state2, _ = self.conv_gru2(c1, state2)
                 d2 = side[0].record_event()
+            ops.hand_over(state2, main)
             c2 = self.conv2(c1)
             e2 = main.record_event()
             with torch.cuda.stream(side[1]):
                 side[1].wait_event(e2)
                 state3, _ = self.conv_gru3(c2, state3)
                 d3 = side[1].record_event()
+            ops.hand_over(state3, main)
             c3 = self.conv3(c2)
             state4, _ = self.conv_gru4(c3, state4)
             main.wait_event(d3)

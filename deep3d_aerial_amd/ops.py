@@ -1516,19 +1516,47 @@ def gru_update_gn(o, u, h, gamma, beta, eps=1e-5, stats=None):
 _derived_cache = {}
 
 
-_side_streams = {}
+_side_streams = {}   # (device index, caller stream, owner) -> side streams
+_side_lock = __import__("threading").Lock()
+
+
+def side_streams(device, n, owner="ops"):
+    """`n` side streams for the forward that runs on the CALLER'S CURRENT stream of `device` -- one set per (device, caller stream,
+    owner), created on first use.  Two forwards in flight on different streams (two host threads) therefore never
+    share a side stream: their forks / joins do not serialise on each other, the GroupNorm slot arenas (keyed by stream) are
+    not shared, and a block the caching allocator frees on a side stream is reused behind THAT caller's next fork only."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, owner)
+    with _side_lock:
+        side = _side_streams.get(key)
+        if side is None or len(side) < n:
+            side = _side_streams[key] = [torch.cuda.Stream(device) for _ in range(n)]
+    return side[:n]
+
+
+def hand_over(outs, stream):
+    """Tensors produced on a side stream and consumed on `stream` from now on: tell the caching allocator (record_stream), so
+    that their blocks -- allocated in the side stream's pool -- are not handed out again on the side stream while `stream` still
+    reads them.  Walks lists / tuples / dicts.  (Ordering is the join event's job; this is the allocator's bookkeeping.)"""
+    if isinstance(outs, torch.Tensor):
+        if outs.is_cuda:
+            outs.record_stream(stream)
+    elif isinstance(outs, (list, tuple)):
+        for o in outs:
+            hand_over(o, stream)
+    elif isinstance(outs, dict):
+        for o in outs.values():
+            hand_over(o, stream)
 
 
 def on_streams(thunks, device, switch):
     """[f() for f in thunks] with the INDEPENDENT pieces of work going round-robin over the caller's stream and two side streams
     (fork event before, one join event per side piece after): chains of small launches that leave most of the chip idle overlap.
-    Same kernels, same operands; `switch` (a key of config.KERNELS) in D3D_KERNELS_OFF keeps everything on the caller's stream."""
+    Same kernels, same operands; `switch` (a key of config.KERNELS) in D3D_KERNELS_OFF keeps everything on the caller's stream.
+    The side streams belong to the caller's stream (side_streams), and what the side pieces return is handed over to it."""
     if len(thunks) < 2 or device.type != "cuda" or _cfg.off(switch):
         return [f() for f in thunks]
     main = torch.cuda.current_stream(device)
-    side = _side_streams.get(device.index)
-    if side is None:
-        side = _side_streams[device.index] = [torch.cuda.Stream(device) for _ in range(2)]
+    side = side_streams(device, 2)
     fork = main.record_event()
     outs, joins = [], []
     for i, f in enumerate(thunks):
@@ -1540,6 +1568,7 @@ def on_streams(thunks, device, switch):
             st.wait_event(fork)
             outs.append(f())
             joins.append(st.record_event())
+        hand_over(outs[-1], main)
     for e in joins:
         main.wait_event(e)
     return outs

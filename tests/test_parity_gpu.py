@@ -1789,15 +1789,14 @@ def test_conv3d_stride2_channel_last_bf16(ops, oracle, Ci, Co, D, H, W):
     _assert_bf16_of(_cl_host(got), want, tol)
 
 
-@pytest.mark.parametrize("Ci,Co,D,H,W", [(16, 8, 2, 3, 5), (16, 8, 4, 9, 70), (32, 16, 3, 5, 64), (64, 32, 2, 9, 18), (16, 16, 5, 20, 33),
-                                         (16, 8, 1, 1, 1), (32, 16, 9, 4, 130)])
-@pytest.mark.parametrize("fold", ["1", "0"])
+_T3_SHAPES = [(16, 8, 2, 3, 5), (16, 8, 4, 9, 70), (32, 16, 3, 5, 64), (64, 32, 2, 9, 18), (16, 16, 5, 20, 33), (16, 8, 1, 1, 1), (32, 16, 9, 4, 130)]
+
+
+@pytest.mark.parametrize("Ci,Co,D,H,W,fold", [c + (f,) for f in ("1", "0") for c in _T3_SHAPES if f == "1" or c[:2] == (16, 8)])   # (only 16 -> 8 has two forms)
 def test_convtranspose3d_channel_last_bf16(ops, oracle, monkeypatch, Ci, Co, D, H, W, fold):
     """conv7 / conv9 / conv11 of CostRegNet (cas_mvsnet.py:97-103,116-118) on d3d_convtranspose3d_k3s2_cl_h16 with
     channel-last bf16 input, skip and output; 16 -> 8 both in the x-folded form (one GEMM for both column parities) and in
     the per-parity form."""
-    if fold == "0" and (Ci, Co) != (16, 8):
-        pytest.skip("only 16 -> 8 has two forms")
     set_kernel(monkeypatch, "t2fold", fold != "0")
     rng = np.random.default_rng(Ci * 1000 + W + D)
     x = rng.standard_normal((Ci, D, H, W)).astype(np.float32)
@@ -2509,3 +2508,70 @@ def test_stride2_and_transposed_tile_kernels_fp32(ops, oracle, monkeypatch, flav
             assert got is not None and np.abs(host(got) - np.maximum(conv + sk, 0)).max() <= 2e-5 * max(1.0, np.abs(conv).max())
     finally:
         ops.set_conv_precision(None)
+
+
+# ----------------------------------------------------------------------------------------
+# host re-entrancy (the boundary is re-entrant and stream-ordered)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["adamvs", "msrednet", "casmvsnet"])
+def test_two_threads_on_two_streams_equal_the_serial_forward(ops, name):
+    """Two reference views in flight: two host threads, each on its own HIP stream, run the same module object at the same time
+    (h16 mode, the multi-stream forms of the forwards on: feature pyramids / pair passes / RED-Net's conv-GRU levels on side
+    streams) -- every result is bit for bit the serial one, three rounds in a row.  What makes that hold: the side streams belong
+    to the caller's stream (ops.side_streams), tensors that cross streams are handed over to the allocator (ops.hand_over), the
+    GroupNorm slot arenas are per stream, and the conv precision is per-thread state that each thread sets for itself
+    (config.state is a threading.local: a worker does NOT inherit the main thread's set_conv_precision -- round 4's "results
+    differed" was a worker running fp32 beside a main thread in bf16 mode)."""
+    import threading
+
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+    from deep3d_aerial_amd.cas_mvsnet import Infer_CascadeMVSNet
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet
+
+    ctor = {"casmvsnet": Infer_CascadeMVSNet, "adamvs": Infer_AdaMVSNet, "msrednet": Infer_CascadeREDNet}[name]
+    V, H, W, nd = 5, 128, 192, 384
+    net = ctor(num_depth=nd)
+    S.fill_state_dict_(net.state_dict(), 77)
+    net = net.cuda().eval()
+    items = []
+    for seed in (11, 12):
+        imgs, pm, dv = S.model_inputs(V, H, W, nd, seed)
+        items.append((dev(imgs), {k: dev(v) for k, v in pm.items()}, dev(dv)))
+
+    def forward(item):
+        with torch.no_grad():
+            out = net(*item)
+        return out["depth"].clone(), out["photometric_confidence"].clone()
+
+    ops.set_conv_precision("h16")
+    try:
+        serial = [forward(it) for it in items]
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_precision(None)
+
+    results, errors = {}, []
+
+    def worker(k, rounds):
+        try:
+            ops.set_conv_precision("h16")            # per-thread state: a worker sets its own
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.default_stream())
+            outs = []
+            with torch.cuda.stream(st):
+                for _ in range(rounds):
+                    outs.append(forward(items[k]))
+            st.synchronize()
+            results[k] = outs
+        except Exception as e:   # surfaced below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k, 3)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for d, c in results[k]:
+            assert torch.equal(d, serial[k][0]) and torch.equal(c, serial[k][1]), (name, k)
