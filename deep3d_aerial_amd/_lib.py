@@ -35,6 +35,7 @@ SIGNATURES = {
     "d3d_compose_projections_f64": [_vp, _i, _vp, _vp],
     "d3d_homo_warp_f64coord": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_sweep_workspace_bytes": [_i, _i, _i, _i, _i, _i],  # returns size_t
+    "d3d_sweep_workspace_bytes_for": [_i, _i, _i, _i, _i, _i, _i],  # returns size_t
     "d3d_homo_warp": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_variance_volume_planes": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
@@ -154,7 +155,7 @@ def load():
             raise LibraryMissing("symbol %s missing from %s" % (name, SO_PATH)) from e
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name in ("d3d_last_error", "d3d_build_flags", "d3d_h16_format") else
-                      ctypes.c_size_t if name in ("d3d_sweep_workspace_bytes", "d3d_fusion_points_scratch_bytes") else ctypes.c_int)
+                      ctypes.c_size_t if name in ("d3d_sweep_workspace_bytes", "d3d_sweep_workspace_bytes_for", "d3d_fusion_points_scratch_bytes") else ctypes.c_int)
     if lib.d3d_version() != ABI_VERSION:
         raise LibraryMissing("ABI version mismatch: library %d, binding %d" % (lib.d3d_version(), ABI_VERSION))
     _lib = lib

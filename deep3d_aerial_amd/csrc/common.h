@@ -96,6 +96,14 @@ __device__ __forceinline__ float round_h16(float v) { return h16_lo(pack_h16x2(v
 // quarter of the fused cell's instruction stream.  Every kernel family uses these two, so fused and unfused cells agree bit for bit.
 __device__ __forceinline__ float gru_sigmoid(float y) { return __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
 __device__ __forceinline__ float gru_tanh(float y) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * y)); }
+// The fast forms above belong to the instruction-bound h16 kernels (whose operands carry 2^-12 of rounding anyway).  The fp32-mode
+// kernels -- exact fp32 / split-operand convolutions, the elementwise gate and update kernels -- take torch's own expressions
+// (IEEE division, tanhf: no cancellation near 0), so fp32 mode reproduces torch.sigmoid / torch.tanh to their last bits and
+// nothing compounds over the 48+ recurrent slices.
+template <bool FAST>
+__device__ __forceinline__ float gru_sigmoid_as(float y) { return FAST ? gru_sigmoid(y) : 1.0f / (1.0f + expf(-y)); }
+template <bool FAST>
+__device__ __forceinline__ float gru_tanh_as(float y) { return FAST ? gru_tanh(y) : tanhf(y); }
 
 // Bytes of a channel-last bf16 cell of C channels in LDS, read as the A operand of v_mfma_f32_16x16x32_bf16 (one ds_read_b128 per
 // lane: pixel lane & 15, K group lane >> 4).  gfx950 services that read in four NON-contiguous 16-lane groups -- {0-3, 12-15,

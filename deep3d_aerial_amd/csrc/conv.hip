@@ -675,11 +675,11 @@ __global__ __launch_bounds__(256) void conv2d_stream_kernel(ConvParams p) {
                     if (p.scale) yv *= p.scale[o];
                     if (p.shift) yv += p.shift[o];
                     if (p.act == 2) {
-                        yv = gru_sigmoid(yv);
+                        yv = gru_sigmoid_as<false>(yv);
                         if (o < p.ep_split) yv *= p.skip[oidx];
                     } else {
                         const float u = p.aux1[oidx], hv = p.skip[oidx];
-                        yv = u * hv + (1.0f - u) * gru_tanh(yv);
+                        yv = u * hv + (1.0f - u) * gru_tanh_as<false>(yv);
                     }
                     p.out[oidx] = yv;
                 }

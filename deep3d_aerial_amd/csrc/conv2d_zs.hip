@@ -417,12 +417,12 @@ __global__ __launch_bounds__(NTZ, GN && CI == 40 ? 4 : 2) void conv2d_zs_bf16_ke
             if (p.act == 2) {
                 const bool gate_h = nt * 16 + (lane & 15) < p.ep_split;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = gru_sigmoid(y[k]);
+                for (int k = 0; k < 4; ++k) y[k] = gru_sigmoid_as<!(F32 || X3)>(y[k]);   // (fp32 mode: torch's own expression, common.h)
                 if (gate_h) y *= ek[i];
             } else if (p.act == 3) {
                 const f4 u = ea[i], hh = ek[i];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * gru_tanh(y[k]);
+                for (int k = 0; k < 4; ++k) y[k] = u[k] * hh[k] + (1.0f - u[k]) * gru_tanh_as<!(F32 || X3)>(y[k]);
             } else {
                 if (p.skip && !p.skip_after_act) y += ek[i];
                 if (p.act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});

@@ -313,11 +313,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256) void conv_stream_kernel(ConvZPar
                             float skv = 0.0f;
                             if (skp && (!gru_gate || co < p.ep_split)) skv = sk[BATCH_SKIP ? mt : 0][r][n];
                             if (gru_gate) {
-                                y = gru_sigmoid(y);
+                                y = gru_sigmoid_as<BF16>(y);
                                 if (co < p.ep_split) y *= skv;
                             } else if (gru_upd) {
                                 const float u = sk2[(SPLIT && MT == 1) ? r : 0][n];
-                                y = u * skv + (1.0f - u) * gru_tanh(y);
+                                y = u * skv + (1.0f - u) * gru_tanh_as<BF16>(y);
                             } else {
                                 if (skp && !p.skip_after_act) y += skv;
                                 if (p.act == 1) y = fmaxf(y, 0.0f);

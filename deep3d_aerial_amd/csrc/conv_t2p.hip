@@ -15,6 +15,7 @@
 // Same K order, same epilogue expressions and the same rounding points as the two kernels it replaces: the result is
 // bit-identical to theirs (tests/test_parity_gpu.py::test_conv11_prob_fused_is_the_two_layers).
 // HBM per full-resolution voxel: 4 B (x, 1/8 of the voxels x 32 B) + 16 B x 1.28 (conv0, halo) + 4 B (prob) = 28.5 B for 60.
+#include <cstdint>
 #include "common.h"
 
 #include <type_traits>
@@ -307,8 +308,9 @@ extern "C" int d3d_convtranspose3d_prob_cl_h16(const void* in, const void* wt_fo
     D3D_REQUIRE(in && wt_folded && wprob_kzfolded && out, "null pointer");
     D3D_REQUIRE(D > 0 && H > 0 && W > 0, "bad dims %dx%dx%d", D, H, W);
     const int gx = ceil_div(W, OXI), gy = ceil_div(H, OYI);
-    if (W % 2 != 0 || gy > 65535 || 2 * D > 65535 || (long)H * W * 64 >= (1L << 31)) {   // (32-bit offsets inside a plane)
-        set_error("d3d_convtranspose3d_prob_cl_h16: W = %d (even: rows of 2 W floats in 16-byte quads), plane %d x %d not taken", W, H, W);
+    if (W % 2 != 0 || gy > 65535 || 2 * D > 65535 || (long)H * W * 64 >= (1L << 31) ||   // (32-bit offsets inside a plane)
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(skip) | reinterpret_cast<uintptr_t>(out)) & 15)) {
+        set_error("d3d_convtranspose3d_prob_cl_h16: W = %d (even: rows of 2 W floats in 16-byte quads), plane %d x %d, 16-byte aligned volumes needed", W, H, W);
         return D3D_ERR_UNSUPPORTED;
     }
     auto kern = skip ? convt3d_prob_kernel<true> : convt3d_prob_kernel<false>;

@@ -416,10 +416,16 @@ int d3d_debug_force_path(int path) {
     return D3D_OK;
 }
 
-size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes) {
+size_t d3d_sweep_workspace_bytes_for(int n_views, int C, int D, int h, int w, int elem_bytes, int depth_mode) {
     if (n_views < 2 || C <= 0 || D <= 0 || h <= 1 || w <= 1 || (elem_bytes != 4 && elem_bytes != 2)) return 0;
-    const size_t a = tiled_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes), b = window_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes);
+    const size_t a = tiled_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes);
+    // the window kernel's channel-last copy serves its gather path, which exists for [D,h,w] hypothesis volumes only
+    const size_t b = depth_mode == D3D_DEPTH_PER_PIXEL ? window_workspace_bytes(n_views - 1, C, D, h, w, elem_bytes) : 0;
     return a > b ? a : b;
+}
+
+size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes) {
+    return d3d_sweep_workspace_bytes_for(n_views, C, D, h, w, elem_bytes, D3D_DEPTH_PER_PIXEL);   // the largest any depth mode uses
 }
 
 int d3d_homo_warp(const float* src, const float* proj34, const float* depth, int depth_mode, int C, int D, int h,

@@ -719,8 +719,8 @@ __global__ __launch_bounds__(256) void gru_gates_kernel(const float* __restrict_
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long n = (long)Hc * plane;
     if (i >= n) return;
-    float r = gru_sigmoid(gates[i]);
-    float uu = gru_sigmoid(gates[n + i]);
+    float r = gru_sigmoid_as<false>(gates[i]);
+    float uu = gru_sigmoid_as<false>(gates[n + i]);
     rh[i] = r * h[i];
     u[i] = uu;
 }
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void gru_update_kernel(const float* __restrict
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float uu = u[i];
-    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh(convc[i]);
+    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh_as<false>(convc[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -797,9 +797,9 @@ __global__ __launch_bounds__(256) void gru2_gates_kernel(const float* __restrict
     const GnAffine ar = gn_fold(st_r, n, eps), au = gn_fold(st_u, n, eps);
     const float rn = (gates[i] - ar.mean) * ar.rstd * g_r[c] + b_r[c];
     const float un = (gates[n + i] - au.mean) * au.rstd * g_u[c] + b_u[c];
-    const float r = gru_sigmoid(rn);
+    const float r = gru_sigmoid_as<false>(rn);
     rh[i] = r * h[i];
-    u[i] = gru_sigmoid(un);
+    u[i] = gru_sigmoid_as<false>(un);
 }
 
 // h' = u*h + (1-u)*tanh(gn_o(o))   (module.py:84-98)
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256) void gru2_update_kernel(const float* __restric
     const GnAffine a = gn_fold(st_o, n, eps);
     const float on = (o[i] - a.mean) * a.rstd * g_o[c] + b_o[c];
     const float uu = u[i];
-    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh(on);
+    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh_as<false>(on);
 }
 
 // The two kernels above, four pixels of one channel per thread (plane % 4 == 0, 16-byte aligned tensors; grid.y = channel: no
@@ -846,8 +846,8 @@ __global__ __launch_bounds__(256) void gru2_gates_kernel4(const float* __restric
     for (int k = 0; k < 4; ++k) {
         const float rn = (vr[k] - aff[0]) * aff[1] * gr + br;
         const float un = (vu[k] - aff[2]) * aff[3] * gu + bu;
-        orh[k] = gru_sigmoid(rn) * hv[k];
-        ou[k] = gru_sigmoid(un);
+        orh[k] = gru_sigmoid_as<false>(rn) * hv[k];
+        ou[k] = gru_sigmoid_as<false>(un);
     }
     *reinterpret_cast<f4g*>(rh + i) = orh;
     *reinterpret_cast<f4g*>(u + i) = ou;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void gru2_update_kernel4(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float on = (ov[k] - aff[0]) * aff[1] * go + bo;
-        out[k] = uv[k] * hv[k] + (1.0f - uv[k]) * gru_tanh(on);
+        out[k] = uv[k] * hv[k] + (1.0f - uv[k]) * gru_tanh_as<false>(on);
     }
     *reinterpret_cast<f4g*>(h_out + i) = out;
 }
@@ -973,8 +973,13 @@ int d3d_slice_head_regress_h16(const float* up, const float* weight, const float
                                 int wd, int h, int w, float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream) {
     D3D_REQUIRE(up && weight && bias && dplane && max_p && sum_d && sum_p, "null pointer");
     D3D_REQUIRE(hd > 0 && wd > 0 && h > 0 && w > 0, "bad dims %dx%d / %dx%d", hd, wd, h, w);
-    if (w % (transposed ? 2 : 4) != 0) {
-        set_error("d3d_slice_head_regress_h16: w = %d must be a multiple of %d", w, transposed ? 2 : 4);
+    // (16-byte accesses to the accumulators and, at the maps' own resolution, to the depth plane; 8- / 16-byte ones to `up`)
+    const int Ho = transposed ? 2 * h : h, Wo = transposed ? 2 * w : w;
+    const bool dquad = hd == Ho && wd == Wo;
+    if (w % (transposed ? 2 : 4) != 0 ||
+        ((reinterpret_cast<uintptr_t>(up) | reinterpret_cast<uintptr_t>(max_p) | reinterpret_cast<uintptr_t>(sum_d) | reinterpret_cast<uintptr_t>(sum_p) |
+          (dquad ? reinterpret_cast<uintptr_t>(dplane) : 0)) & 15)) {
+        set_error("d3d_slice_head_regress_h16: w = %d (a multiple of %d) and 16-byte aligned maps needed", w, transposed ? 2 : 4);
         return D3D_ERR_UNSUPPORTED;
     }
     dim3 grid(ceil_div(w / (transposed ? 2 : 4), 64), ceil_div(h, 4));

@@ -231,16 +231,23 @@ def extract_features(feature_net, imgs, image_keys=None, cache=None):
     # two passes: take (and so hold a reference to) every cached pyramid of the item FIRST; a put() for an uncached view
     # may evict any key, including one of this item's that the caller did not upload because it was cached
     feats = [cache.get(k) for k in image_keys]
+    # the misses of the item -- each image once (padded source lists repeat an image) -- are featurised TOGETHER on the three
+    # streams of _pyramids, as an item without a cache is (the first view of a strip misses all V), then stored
+    first = {}
     for v in range(V):
-        if feats[v] is None:
-            dup = next((u for u in range(v) if image_keys[u] == image_keys[v]), None)
-            if dup is not None:            # the same image twice in one item (padded source lists)
-                feats[v] = feats[dup]
-                continue
-            x = view(v)
-            if x is None:
+        if feats[v] is None and image_keys[v] not in first:
+            if view(v) is None:
                 raise KeyError("image %r is neither cached nor supplied" % (image_keys[v],))
-            feats[v] = feature_net(x)
+            first[image_keys[v]] = v
+    if first:
+        order = sorted(first.values())
+        pyrs = _pyramids(feature_net, [view(v) for v in order])
+        for v, pyr in zip(order, pyrs):
+            feats[v] = pyr
+        for v in range(V):
+            if feats[v] is None:
+                feats[v] = feats[first[image_keys[v]]]
+        for v in order:
             cache.put(image_keys[v], feats[v])
     return feats
 

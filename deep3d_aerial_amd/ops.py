@@ -89,11 +89,13 @@ def _sync_force_path():
         _forced[0] = want
 
 
-def _workspace(n_views, C, D, h, w, elem_bytes, device):
-    """Scratch for one sweep call, sized by the library and owned by torch's caching allocator: the allocator hands the
-    block back only after the work queued on the current stream (this call) has been ordered, so calls never share it."""
+def _workspace(n_views, C, D, h, w, elem_bytes, device, mode=PER_PIXEL):
+    """Scratch for one sweep call, sized by the library FOR THE CALL'S DEPTH MODE (the window kernel's channel-last copy -- 650 MB
+    at the last cascade stage -- serves hypothesis volumes only: (lo, step) maps and per-plane depths do not ask for it) and owned
+    by torch's caching allocator: the allocator hands the block back only after the work queued on the current stream (this call)
+    has been ordered, so calls never share it."""
     _sync_force_path()
-    n = int(_lib.load().d3d_sweep_workspace_bytes(n_views, C, D, h, w, elem_bytes))
+    n = int(_lib.load().d3d_sweep_workspace_bytes_for(n_views, C, D, h, w, elem_bytes, mode))
     if n == 0:
         return None, ctypes.c_void_p(0), 0
     buf = torch.empty((n,), dtype=torch.uint8, device=device)
@@ -144,7 +146,7 @@ def homo_warp(src, proj34, depth, out=None):
     dp, mode, D = _depth(depth, h, w, affine_ok=False, op="homo_warp")
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=src.device)
-    ws, wp, wn = _workspace(2, C, D, h, w, 4, src.device)
+    ws, wp, wn = _workspace(2, C, D, h, w, 4, src.device, mode)
     rc = _lib.load().d3d_homo_warp(_chk(src, "src", 3), _chk(proj34, "proj34"), dp, mode, C, D, h, w,
                                    _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_homo_warp")
@@ -199,7 +201,7 @@ def variance_volume(feats, proj34, depth, out=None, plane_major=False):
         if out is None:
             out = torch.empty((D, C, h, w), dtype=torch.float32, device=feats[0].device)
         arr = _ptr_array(feats, "feats")
-        ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
+        ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device, mode)
         rc = _lib.load().d3d_variance_volume_planes(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
                                                     _chk(out, "out", 4), wp, wn, _stream())
         _lib.check(rc, "d3d_variance_volume_planes")
@@ -211,7 +213,7 @@ def variance_volume(feats, proj34, depth, out=None, plane_major=False):
         if out is None:
             out = torch.empty((C, D, h, w), dtype=torch.float16, device=feats[0].device)
         arr = (ctypes.c_void_p * len(feats))(*[_chk16(f, "feats[%d]" % i).value for i, f in enumerate(feats)])
-        ws, wp, wn = _workspace(len(feats), C, D, h, w, 2, feats[0].device)
+        ws, wp, wn = _workspace(len(feats), C, D, h, w, 2, feats[0].device, mode)
         rc = _lib.load().d3d_variance_volume_f16(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
                                                  _chk16(out, "out"), wp, wn, _stream())
         _lib.check(rc, "d3d_variance_volume_f16")
@@ -220,7 +222,7 @@ def variance_volume(feats, proj34, depth, out=None, plane_major=False):
     if out is None:
         out = torch.empty((C, D, h, w), dtype=torch.float32, device=feats[0].device)
     arr = _ptr_array(feats, "feats")
-    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
+    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device, mode)
     rc = _lib.load().d3d_variance_volume(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
                                          _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_variance_volume")
@@ -240,7 +242,7 @@ def variance_volume_cl(feats, proj34, depth, layout="cl"):
     if C % 8 == 0:
         out = torch.empty((D, C // 8, h, w, 8) if layout == "cl8" else (D, h, w, C), dtype=h16_dtype(), device=feats[0].device)
         arr = _ptr_array(feats, "feats")
-        ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
+        ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device, mode)
         name = "d3d_variance_volume_cl8_h16" if layout == "cl8" else "d3d_variance_volume_cl_h16"
         rc = getattr(_lib.load(), name)(arr, _chk(proj34, "proj34"), dp, mode, len(feats), C, D, h, w,
                                         ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
@@ -273,7 +275,7 @@ def weighted_corr(feats, proj34, weights, depth, out=None, plane_major=False):
     if out is None:
         out = torch.empty((D, C, h, w) if plane_major else (C, D, h, w), dtype=torch.float32, device=feats[0].device)
     arr = _ptr_array(feats, "feats")
-    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device)
+    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device, mode)
     rc = _lib.load().d3d_weighted_corr(arr, _chk(proj34, "proj34"), _chk(weights, "weights", 3), dp, mode,
                                        len(feats), C, D, h, w, int(bool(plane_major)), _chk(out, "out", 4), wp, wn, _stream())
     _lib.check(rc, "d3d_weighted_corr")
@@ -286,7 +288,7 @@ def pair_corr_mean(ref, src, proj34, depth, out=None):
     dp, mode, D = _depth(depth, h, w)
     if out is None:
         out = torch.empty((D, h, w), dtype=torch.float32, device=ref.device)
-    ws, wp, wn = _workspace(2, C, D, h, w, 4, ref.device)
+    ws, wp, wn = _workspace(2, C, D, h, w, 4, ref.device, mode)
     rc = _lib.load().d3d_pair_corr_mean(_chk(ref, "ref", 3), _chk(src, "src", 3), _chk(proj34, "proj34"), dp, mode,
                                         C, D, h, w, _chk(out, "out", 3), wp, wn, _stream())
     _lib.check(rc, "d3d_pair_corr_mean")

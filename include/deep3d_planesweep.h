@@ -124,6 +124,9 @@ const char* d3d_h16_format(void);
  * Replaces nothing in the reference: torch's caching allocator plays this role there.
  */
 size_t d3d_sweep_workspace_bytes(int n_views, int C, int D, int h, int w, int elem_bytes);
+/* The same for a call whose depth mode is known (ABI 9): (lo, step) maps and per-plane depths never use the window kernel's
+ * channel-last copy (650 MB at the last cascade stage), so their figure is the ring kernel's alone. */
+size_t d3d_sweep_workspace_bytes_for(int n_views, int C, int D, int h, int w, int elem_bytes, int depth_mode);
 
 /*
  * module.py:516-557 homo_warping_float -- warp ONE source feature map onto D planes.

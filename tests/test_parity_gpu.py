@@ -2574,4 +2574,7 @@ def test_two_threads_on_two_streams_equal_the_serial_forward(ops, name):
     assert not errors, errors
     for k in range(2):
         for d, c in results[k]:
-            assert torch.equal(d, serial[k][0]) and torch.equal(c, serial[k][1]), (name, k)
+            if name == "msrednet":   # (its GroupNorm statistics are fp64 atomic sums: equal to the order of the additions)
+                assert rel_l1(host(d), host(serial[k][0])) <= 1e-6 and rel_l1(host(c), host(serial[k][1])) <= 1e-5, (name, k)
+            else:
+                assert torch.equal(d, serial[k][0]) and torch.equal(c, serial[k][1]), (name, k)
