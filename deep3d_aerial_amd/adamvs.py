@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .dataset import extract_features
+from . import config as _cfg
 from . import ops
 from .module import (Conv2d, ConvBnReLU, ConvGRUCell, ConvReLU, DeConv2dFuse, _no_train, _trunk, feature_conv, folded_bn, trunk_conv0,
                      plane_depths)
@@ -185,6 +186,28 @@ class SliceCostRegNetRED(nn.Module):
         up, state1, state2 = self._trunk(cost, state1, state2)
         return self._head(up), state1, state2
 
+    def loop_graph(self, C, h, w, D, dv):
+        """The captured slice loop for this shape on the caller's stream (SliceLoopGraph), or None where it does not apply: h16
+        mode with the fused cell / tail kernels only, not while somebody else is capturing, D3D_KERNELS_OFF=slice_graph."""
+        import threading
+
+        if (not dv.is_cuda or ops.conv_precision() != "h16" or _cfg.off("slice_graph") or _cfg.off("gru_fused") or D < 4 or h % 2 or w % 2
+                or (_cfg.off("tail_fused") if self.up else _cfg.off("head_fused")) or torch.cuda.is_current_stream_capturing()
+                or threading.current_thread() is not threading.main_thread()):
+            # (worker threads run the launch loop: with two threads capturing and replaying their own graphs side by side the
+            #  results were not bit-stable on this stack -- round 5, tests/test_parity_gpu.py::test_two_threads_... -- and a
+            #  capture is a process-wide event in the HIP runtime; the main thread's forwards are where the gain is)
+            return None
+        return SliceLoopGraph.get(self, C, h, w, D, dv)
+
+    def _tail(self, s2, s1, dplane, max_p, sum_d, sum_p):
+        """upconv1 + skip + head + regression update of one slice from its two new states (the second half of step_regress)."""
+        if self.up:
+            return ops.slice_tail_regress(s2, self.upconv1.weight, self.upconv1.bias, s1, self.upconv2d.weight, self.upconv2d.bias,
+                                          dplane, max_p, sum_d, sum_p)
+        up = ops.convtranspose2d_k3s2(s2, self.upconv1.weight, None, self.upconv1.bias, s1, skip_after_act=False, act=1)
+        return ops.slice_head_regress(up, self.upconv2d.weight, self.upconv2d.bias, self.up, dplane, max_p, sum_d, sum_p)
+
     def step_regress(self, cost, state1, state2, dplane, max_p, sum_d, sum_p):
         """One slice AND its online-regression update (adamvs.py:512-525 around this module): in bf16 mode the head layer and
         the update are one kernel and `reg` never reaches memory (ops.slice_head_regress).  Returns the new states."""
@@ -201,6 +224,196 @@ class SliceCostRegNetRED(nn.Module):
             if not ops.slice_head_regress(up, self.upconv2d.weight, self.upconv2d.bias, self.up, dplane, max_p, sum_d, sum_p):
                 ops.online_regress_update(self._head(up)[0], dplane, max_p, sum_d, sum_p)
         return state1, state2
+
+
+class SliceLoopGraph(object):
+    """The slice loop of one cascade stage (adamvs.py:492-525: D times cell 1 -> cell 2 -> upconv1 + skip + head + regression
+    update) captured ONCE as a HIP graph and replayed per reference view.
+
+    Why: the loop is 3 D launches of 30 - 200 us kernels of a few hundred workgroups each.  Across slices each of the three
+    depends on ITS OWN predecessor only -- state1(d) needs state1(d - 1); state2(d) needs state2(d - 1) and state1(d); the
+    accumulators need tail(d - 1) -- so cell 1 of slice d + 2, cell 2 of slice d + 1 and the tail of slice d can be in flight
+    together and fill each other's launch / drain gaps and partial last rounds.  Issued eagerly from three streams that form
+    is SLOWER than the serial loop (29.3 against 27.7 ms per view): Python cannot issue three launches and seven event
+    operations in the 43 us a stage-1 kernel lasts.  Captured, the host issues ONE graph launch per stage.
+
+    What is captured: three streams (the capture stream = chain 1; two side streams = chains 2 and 3), the states in rings of
+    three buffers each (slice d + 3 reuses slice d's buffers behind an event of slice d's tail: nothing depends on the caching
+    allocator inside the graph), the zeroing of the first states and of the accumulators.  Same kernels on the same operands
+    as the serial loop: bit-identical (tests/test_parity_gpu.py::test_adamvs_slice_graph_is_the_serial_loop).
+    Static inputs: `sim` [D,C,h,w] (the weighted sweep writes it in place: ops.weighted_corr(out=)) and `dv` (copied in, < 0.1 ms).
+    One graph per (module, shape, caller stream, packed weights): two forwards in flight on two streams own separate graphs
+    and buffers.  The first call of a shape runs the serial loop (it packs the weights and sets the kernels' LDS attributes --
+    neither may happen inside a capture), the second captures."""
+
+    _cache = {}
+    _lock = __import__("threading").Lock()
+    MAX_GRAPHS = 12
+    CHAINS = 3   # 1: the serial order on one captured stream; 2: cells on one stream, tails on another
+    UP_ONLY = False
+
+    @classmethod
+    def get(cls, mod, C, h, w, D, dv):
+        dev = dv.device
+        # (the kernel-selection switches are part of the key: a graph replays the kernels that were dispatched when it was captured)
+        key = (id(mod), C, h, w, D, tuple(dv.shape), dev.index, torch.cuda.current_stream(dev).cuda_stream, ops.h16_dtype(),
+               tuple(sorted(_cfg.switches.items())))
+        with cls._lock:
+            for k in [k for k, v in cls._cache.items() if v.mod() is None]:   # graphs of modules that are gone (and their buffers)
+                del cls._cache[k]
+            g = cls._cache.get(key)
+            if g is None or g.mod() is not mod:
+                if len(cls._cache) >= cls.MAX_GRAPHS:
+                    cls._cache.pop(next(iter(cls._cache)))
+                g = cls._cache[key] = cls(mod, C, h, w, D, dv)
+        return g
+
+    def __init__(self, mod, C, h, w, D, dv):
+        import weakref
+
+        self.mod = weakref.ref(mod)
+        self.C, self.h, self.w, self.D, self.up = C, h, w, D, mod.up
+        self.dev = dv.device
+        self.calls, self.graph, self.counts, self.wkey, self.failed = 0, None, None, None, None
+        self.sim = self.dv = None
+        self.dv_shape = tuple(dv.shape)
+
+    def _weights_key(self, mod):
+        ps = [mod.conv1.conv.weight, mod.conv2.conv.weight, mod.upconv1.weight, mod.upconv2d.weight]
+        for gru in (mod.conv_gru1, mod.conv_gru2):
+            ps += [gru.conv_gates[0].weight, gru.convc[0].weight]
+        return tuple((p.data_ptr(), p._version) for p in ps)
+
+    def usable(self):
+        """True from the second call on (the first one of a shape runs the serial loop); a changed weight starts over."""
+        mod = self.mod()
+        k = self._weights_key(mod)
+        if k != self.wkey:
+            self.wkey, self.calls, self.graph = k, 0, None
+        self.calls += 1
+        return self.calls >= 2 and self.failed is None
+
+    def _alloc(self):
+        dev, f32 = self.dev, torch.float32
+        H, W = (2 * self.h, 2 * self.w) if self.up else (self.h, self.w)
+        self.sim = torch.empty((self.D, self.C, self.h, self.w), dtype=f32, device=dev)
+        self.dv = torch.empty(self.dv_shape, dtype=f32, device=dev)
+        self.s1 = [torch.empty((8, self.h, self.w), dtype=f32, device=dev) for _ in range(4)]
+        self.s2 = [torch.empty((16, self.h // 2, self.w // 2), dtype=f32, device=dev) for _ in range(4)]
+        self.max_p = torch.empty((H, W), dtype=f32, device=dev)
+        self.sum_d, self.sum_p = torch.empty_like(self.max_p), torch.empty_like(self.max_p)
+        self.streams = [torch.cuda.Stream(dev) for _ in range(3)]   # capture stream (chain 1), chains 2 and 3
+
+    def _capture(self):
+        mod = self.mod()
+        D = self.D
+        dplane = (lambda d: self.dv[d].reshape(1, 1)) if self.dv.dim() == 1 else (lambda d: self.dv[d])
+        g1, c1 = mod.conv_gru1.conv_gates[0], mod.conv_gru1.convc[0]
+        g2, c2 = mod.conv_gru2.conv_gates[0], mod.conv_gru2.convc[0]
+        sa, sb, sc = self.streams
+        chains = SliceLoopGraph.CHAINS if (self.up or not SliceLoopGraph.UP_ONLY) else 1
+        if chains == 1:   # (probe / fallback form: the serial order inside one captured stream)
+            sb = sc = sa
+        elif chains == 2:
+            sb = sa
+        before = dict(ops.dispatch_counts)
+        # One slice eagerly first, on the ring buffers (the capture overwrites them): whatever the three kernels prepare on first
+        # use -- packed weights in the caches, the kernels' LDS attributes -- exists afterwards, so the capture meets no operation
+        # that cannot be captured even if a cache was emptied since the serial call.
+        with ops.slice_tile_kernels():
+            ops.gru_cell_conv_fused(self.sim[0], self.s1[3], mod.conv1.conv.weight, g1.weight, g1.bias, c1.weight, c1.bias, 1, out=self.s1[0])
+            ops.gru_cell_conv_fused(self.s1[0], self.s2[3], mod.conv2.conv.weight, g2.weight, g2.bias, c2.weight, c2.bias, 2, out=self.s2[0])
+            mod._tail(self.s2[0], self.s1[0], dplane(0), self.max_p, self.sum_d, self.sum_p)
+        ops.dispatch_counts.clear()
+        ops.dispatch_counts.update(before)
+        graph = torch.cuda.CUDAGraph()
+        sa.wait_stream(torch.cuda.current_stream(self.dev))
+        keep = []   # every event of the capture stays alive until the capture has ended
+        def rec(st):
+            keep.append(st.record_event())
+            return keep[-1]
+        def wait(st, ev):
+            if chains != 1:
+                st.wait_event(ev)
+        failure = None
+        with torch.cuda.graph(graph, stream=sa, capture_error_mode="thread_local"), ops.slice_tile_kernels():
+          try:
+            # ring slot 3 holds the zero states of slice 0; slots 0 .. 2 take the slices' states in turn
+            self.s1[3].zero_(); self.s2[3].zero_()
+            self.max_p.zero_(); self.sum_d.zero_(); self.sum_p.zero_()
+            if chains != 1:
+                fork = rec(sa)
+                if sb is not sa:
+                    sb.wait_event(fork)
+                sc.wait_event(fork)
+            ec = [None] * D
+            eb = None
+            for d in range(D):
+                a_in, a_out = self.s1[3 if d == 0 else (d - 1) % 3], self.s1[d % 3]
+                b_in, b_out = self.s2[3 if d == 0 else (d - 1) % 3], self.s2[d % 3]
+                if d >= 3:
+                    wait(sa, ec[d - 3])   # the slot's previous occupant has been read by its cell 2 and its tail
+                ok = ops.gru_cell_conv_fused(self.sim[d], a_in, mod.conv1.conv.weight, g1.weight, g1.bias, c1.weight, c1.bias, 1, out=a_out)
+                ea = rec(sa)
+                with torch.cuda.stream(sb):
+                    wait(sb, ea)   # (cell 1 of this slice waited for tail(d - 3): the state-2 slot is free as well)
+                    ok2 = ops.gru_cell_conv_fused(a_out, b_in, mod.conv2.conv.weight, g2.weight, g2.bias, c2.weight, c2.bias, 2, out=b_out)
+                    eb = rec(sb)
+                with torch.cuda.stream(sc):
+                    wait(sc, eb)          # (behind cell 2 of this slice, hence behind its cell 1)
+                    ok3 = mod._tail(b_out, a_out, dplane(d), self.max_p, self.sum_d, self.sum_p)
+                    ec[d] = rec(sc)
+                if ok is None or ok2 is None or not ok3:
+                    raise RuntimeError("a fused slice kernel refused a shape the serial loop ran it on")
+            wait(sa, eb)
+            wait(sa, ec[D - 1])
+          except Exception as e:
+            # leave the capture in an orderly way -- every stream that joined it is joined back to the capture stream, so that
+            # ending the capture releases all of them -- and report the failure afterwards
+            failure = e
+            try:
+                if sb is not sa:
+                    sa.wait_stream(sb)
+                if sc is not sa:
+                    sa.wait_stream(sc)
+            except Exception:
+                pass
+        self._events = keep
+        if failure is not None:
+            raise failure
+        after = dict(ops.dispatch_counts)
+        self.counts = {k: v - before.get(k, 0) for k, v in after.items() if v != before.get(k, 0)}
+        for k, v in self.counts.items():   # (the capture launched nothing: it does not count; every replay does)
+            ops.dispatch_counts[k] -= v
+        self.graph = graph
+
+    def run(self, dv):
+        """Replays the loop on the caller's stream over what the sweep has written into self.sim.  Returns (max_p, sum_d, sum_p)."""
+        if self.graph is None:
+            with SliceLoopGraph._lock:
+                if self.sim is None:
+                    raise RuntimeError("SliceLoopGraph.run before buffers()")
+                before = dict(ops.dispatch_counts)
+                try:
+                    self._capture()
+                except Exception as e:
+                    # On this stack (ROCm 7.2) an invalidated capture leaves the thread's HIP state unusable ("operation failed due
+                    # to a previous error during capture" on every later call), so there is no falling back to the launch loop:
+                    # say what happened and how to run without the graph.
+                    self.failed = repr(e)[:300]
+                    raise RuntimeError("capturing the slice loop as a HIP graph failed (%s); run with D3D_KERNELS_OFF=slice_graph"
+                                       % self.failed) from e
+                torch.cuda.current_stream(self.dev).wait_stream(self.streams[0])
+        self.dv.copy_(dv)
+        self.graph.replay()
+        for k, v in self.counts.items():
+            ops.dispatch_counts[k] += v
+        return self.max_p, self.sum_d, self.sum_p
+
+    def buffers(self):
+        if self.sim is None:
+            self._alloc()
+        return self
 
 
 class InferDepthNet(nn.Module):
@@ -234,16 +447,27 @@ class InferDepthNet(nn.Module):
         else:  # adamvs.py:502, once per stage instead of once per plane
             weights = ops.resize_bilinear(conf_in, h, w)
 
-        sim = ops.weighted_corr(feats, p34, weights, dv if dv_sweep is None else dv_sweep, plane_major=True)  # [D,C,h,w]: plane d is one contiguous block
-        H, W = (2 * h, 2 * w) if self.in_up else (h, w)
-        s1 = torch.zeros((8, h, w), dtype=torch.float32, device=dev)
-        s2 = torch.zeros((16, h // 2, w // 2), dtype=torch.float32, device=dev)
-        max_p = torch.zeros((H, W), dtype=torch.float32, device=dev)
-        sum_d = torch.zeros_like(max_p)
-        sum_p = torch.zeros_like(max_p)
-        for d in range(D):
-            dplane = dv[d].reshape(1, 1) if dv.dim() == 1 else dv[d]
-            s1, s2 = self.reg_fuse.step_regress(sim[d], s1, s2, dplane, max_p, sum_d, sum_p)
+        loop = self.reg_fuse.loop_graph(C, h, w, D, dv)
+        acc = None
+        if loop is not None and loop.usable():
+            # the slice loop as one HIP graph (SliceLoopGraph): the sweep writes the graph's static volume, the graph is replayed
+            sim = loop.buffers().sim
+            ops.weighted_corr(feats, p34, weights, dv if dv_sweep is None else dv_sweep, plane_major=True, out=sim)
+            acc = loop.run(dv)
+        else:
+            sim = ops.weighted_corr(feats, p34, weights, dv if dv_sweep is None else dv_sweep, plane_major=True)  # [D,C,h,w]: plane d is one contiguous block
+        if acc is None:   # the launch loop
+            H, W = (2 * h, 2 * w) if self.in_up else (h, w)
+            s1 = torch.zeros((8, h, w), dtype=torch.float32, device=dev)
+            s2 = torch.zeros((16, h // 2, w // 2), dtype=torch.float32, device=dev)
+            max_p = torch.zeros((H, W), dtype=torch.float32, device=dev)
+            sum_d = torch.zeros_like(max_p)
+            sum_p = torch.zeros_like(max_p)
+            for d in range(D):
+                dplane = dv[d].reshape(1, 1) if dv.dim() == 1 else dv[d]
+                s1, s2 = self.reg_fuse.step_regress(sim[d], s1, s2, dplane, max_p, sum_d, sum_p)
+        else:
+            max_p, sum_d, sum_p = acc
         depth, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
         return depth, conf, weights, pair_results
 

@@ -199,7 +199,13 @@ __global__ __launch_bounds__(NT, X3 ? (CI <= 16 ? 4 : 2) : NTN > 1 ? 1 : (CI <= 
             for (int rr = 0; rr < RH; ++rr) {
                 const int r = r0 + rr;
                 if (r >= r1) break;
+#ifdef D3D_X_CONV0_NOLOAD   // timing-only build (wrong results): the channel-last input is not read -- what a layer whose input tile was already
+                            // in the CU would cost (profiles/r05_sweep_conv0_fusion_bound.txt); reported by d3d_build_flags() (planesweep_window.hip)
+                const u4 v = {stoff[r], (unsigned)r, (unsigned)zi, 0x3c003c00u};
+                (void)src;
+#else
                 const u4 v = *reinterpret_cast<const u4*>(src + stoff[r]);
+#endif
                 stc[rr] = v;   // raw: zeroed for cells outside the volume when it is committed -- a select here would wait for the load
             }
             return;

@@ -370,7 +370,16 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                 if (a.ngroups > 1) store_sbase_h16x8<true>(ob, pixo, even_quad, pack_h16x4(o));
                 else
 #endif
+#ifdef D3D_X_SWEEP_NOSTORE   // timing-only build (wrong results): the channel-last volume is computed and NOT written -- what a sweep whose
+                             // output stayed in the CU would cost (profiles/r05_sweep_conv0_fusion_bound.txt); reported by d3d_build_flags()
+                {
+                    const unsigned long long hq = pack_h16x4(o);
+                    if (a.cap_bytes < 0) store_sbase_h16x8(ob, pixo, even_quad, hq);   // (a uniform test that never holds: the values stay live)
+                    else asm volatile("" : : "v"(hq), "v"(even_quad));
+                }
+#else
                 store_sbase_h16x8(ob, pixo, even_quad, pack_h16x4(o));
+#endif
                 ob += 16;
             }
         } else {
@@ -891,6 +900,12 @@ const char* window_build_flags() {
 #endif
 #ifdef D3D_CL_PARTIAL_DEFAULT_POLICY
            " D3D_CL_PARTIAL_DEFAULT_POLICY"
+#endif
+#ifdef D3D_X_SWEEP_NOSTORE
+           " D3D_X_SWEEP_NOSTORE"
+#endif
+#ifdef D3D_X_CONV0_NOLOAD
+           " D3D_X_CONV0_NOLOAD"
 #endif
         ;
 }

@@ -1540,7 +1540,7 @@ def hand_over(outs, stream):
     that their blocks -- allocated in the side stream's pool -- are not handed out again on the side stream while `stream` still
     reads them.  Walks lists / tuples / dicts.  (Ordering is the join event's job; this is the allocator's bookkeeping.)"""
     if isinstance(outs, torch.Tensor):
-        if outs.is_cuda:
+        if outs.is_cuda and not _cfg.off("hand_over"):
             outs.record_stream(stream)
     elif isinstance(outs, (list, tuple)):
         for o in outs:
@@ -2002,7 +2002,7 @@ def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_aft
     return out
 
 
-def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride=1):
+def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride=1, out=None):
     """relu(conv3x3(cost, stride)) followed by the conv-GRU cell on it, ONE launch (d3d_gru_cell_fused_h16, csrc/gru_fused.hip;
     adamvs.py:409-412: conv1 + conv_gru1 at stride 1, conv2 + conv_gru2 at stride 2).  bf16 mode only (the operands are bf16, the
     state stays fp32): bit-identical to conv2d_zs + gru_cell_fused.  Returns the new state, or None for shapes / modes the
@@ -2022,7 +2022,10 @@ def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride
     w1 = derived_weight(w_pre, "z2bf16", _pack_z2_bf16)
     wg = derived_weight(w_gates, "z2bf16", _pack_z2_bf16)
     wc = derived_weight(w_cand, "z2bf16", _pack_z2_bf16)
-    out = torch.empty_like(h)
+    if out is None:
+        out = torch.empty_like(h)
+    elif out.shape != h.shape or out.dtype != h.dtype or out.data_ptr() == h.data_ptr():
+        raise ValueError("out must be a separate tensor of the state's shape")
     rc = _lib.load().d3d_gru_cell_fused_h16(_chk(cost, "cost", 3), CP, HI, WI, int(stride), _chk(h, "h", 3), HID, H, W,
                                              ctypes.c_void_p(w1.data_ptr()), ctypes.c_void_p(wg.data_ptr()), _chk(b_gates, "b_gates"),
                                              ctypes.c_void_p(wc.data_ptr()), _chk(b_cand, "b_cand"), _chk(out, "out"), _stream())

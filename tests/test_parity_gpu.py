@@ -2578,3 +2578,49 @@ def test_two_threads_on_two_streams_equal_the_serial_forward(ops, name):
                 assert rel_l1(host(d), host(serial[k][0])) <= 1e-6 and rel_l1(host(c), host(serial[k][1])) <= 1e-5, (name, k)
             else:
                 assert torch.equal(d, serial[k][0]) and torch.equal(c, serial[k][1]), (name, k)
+
+
+def test_adamvs_slice_graph_is_the_serial_loop(ops, monkeypatch):
+    """The slice loop of an AdaMVS stage captured as one HIP graph of three chains on three streams (adamvs.SliceLoopGraph: cell 1
+    of slice d + 2, cell 2 of slice d + 1 and the tail of slice d in flight together; first call of a shape serial, second captures,
+    later ones replay) runs the serial loop's kernels on the serial loop's operands: every output of the forward is bit for bit
+    the serial forward's -- on the capturing call, on replays, and after new weights have been loaded -- and the kernels counted
+    are the same."""
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+
+    V, H, W, nd = 5, 256, 384, 384
+    net = Infer_AdaMVSNet(num_depth=nd)
+    S.fill_state_dict_(net.state_dict(), 7204)
+    net = net.cuda().eval()
+    imgs, pm, dv = S.model_inputs(V, H, W, nd, 7204)
+    args = (dev(imgs), {k: dev(v) for k, v in pm.items()}, dev(dv))
+    ops.set_conv_precision("h16")
+    try:
+        outs, counts = [], []
+        for on in (True, True, True, False, True):   # serial (first call of the shapes), capture + replay, replay, switched off, replay
+            set_kernel(monkeypatch, "slice_graph", on)
+            ops.dispatch_counts.clear()
+            with torch.no_grad():
+                o = net(*args)
+            torch.cuda.synchronize()
+            outs.append([o[s][k].clone() for s in ("stage1", "stage2", "stage3") for k in ("depth", "photometric_confidence")])
+            counts.append({k: ops.dispatch_counts[k] for k in ("gru_cell_fused", "slice_tail_regress", "slice_head_regress")})
+    finally:
+        ops.set_conv_precision(None)
+    assert all(c == {"gru_cell_fused": 176, "slice_tail_regress": 80, "slice_head_regress": 8} for c in counts), counts
+    for per_output in zip(*outs):
+        assert all(torch.equal(per_output[0], o) for o in per_output[1:])
+    from deep3d_aerial_amd.adamvs import SliceLoopGraph
+    assert sum(g.graph is not None for g in SliceLoopGraph._cache.values()) >= 3   # the three stages were captured
+    # new weights (in place, as load_state_dict does): the graphs start over, results follow the weights
+    ops.set_conv_precision("h16")
+    try:
+        S.fill_state_dict_(net.state_dict(), 99)
+        fresh = []
+        for on in (False, True, True, True):
+            set_kernel(monkeypatch, "slice_graph", on)
+            with torch.no_grad():
+                fresh.append(net(*args)["depth"].clone())
+    finally:
+        ops.set_conv_precision(None)
+    assert not torch.equal(fresh[0], outs[0][4]) and all(torch.equal(fresh[0], f) for f in fresh[1:])
