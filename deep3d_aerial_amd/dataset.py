@@ -331,6 +331,19 @@ def read_view_pair_text(pair_path, view_num):
     return metas
 
 
+def read_scene_blocks(path):
+    """blocks.txt (IO/params_io.py:430-444, read by fuse/fusion_3d_normal.py:252-272): `N`, then per scene block a line with its
+    range `x_min x_max y_min y_max z_min z_max` and a line with the image ids of its reference views.
+    -> [{"scene_range": [6 floats], "refs": [image ids]}]."""
+    blocks = []
+    with open(path) as f:
+        for _ in range(int(f.readline())):
+            rng = [float(x) for x in f.readline().split()]
+            refs = [int(x) for x in f.readline().split()]
+            blocks.append({"scene_range": rng, "refs": refs})
+    return blocks
+
+
 def scale_image(image, scale=1.0):
     """preprocess.py:41-46 scale_image -> cv2.resize(image, None, fx=scale, fy=scale, INTER_LINEAR).
     scale == 1 (the pipeline's setting: mvs_dl.py never passes --resize_scale) returns the image as cv2 does.  Other

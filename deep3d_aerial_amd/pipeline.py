@@ -22,6 +22,13 @@ sharding.shard_views), against the gathered maps of ALL views.  What this preser
   by reference views of LOWER ranks are still offered (duplicate points along the seams between rank blocks).  One rank
   reproduces the reference's chain over the whole list.
 
+* `fuse_partition="scene_blocks"` (with the scene blocks of blocks.txt, dataset.read_scene_blocks): the reference fuses scene
+  block by scene block and starts the chain afresh for each (fusion_3d_normal.py:593-608; the tmp folder is emptied at the end
+  of fuse_depths, :586-587).  Scene blocks are therefore the units whose chains are INDEPENDENT: dealt whole to the ranks
+  (block b to rank b mod N -- fusion ownership then differs from sweep ownership, which costs nothing: every rank holds every
+  map after the gather) they reproduce the reference's result exactly for any N, filtering on, vertices clipped to each block's
+  scene range as :557 does.  Balanced only when there are at least N blocks; the default partition ("views") always is.
+
 The view list, the sources of a view (all the sources viewpair.txt lists, up to `fusion_num` -- the fusion step does not stop
 at predict's view_num: fusion_3d_normal.py:98, 476) and the 1-based image ids of the visibility lists come from the dataset
 (`view_records`); cameras are the `outcam` of the item whose reference view the image is -- what the reference reads back from
@@ -60,7 +67,7 @@ def _gather_objects(obj, world_size):
 
 def predict_and_fuse(model, dataset, output_folder, rank=0, world_size=1, checker=None, fusion_num=10, min_geo_consist_num=4,
                      filter_sources=True, partition="block", scene_range=None, skip_line=2, feature_cache_bytes=0,
-                     device="cuda", timings=None, display=False):
+                     device="cuda", timings=None, display=False, fuse_partition="views", scene_blocks=None):
     """Runs the three steps above for this rank.  Returns a list, one entry per reference view this rank owns, of
     {"ref", "final_mask" [H,W] bool, "avg_xyz_world" [3,H,W], "points": fuse.extract_points(...) dict} (device tensors).
     timings: dict that receives predict_s, allgather_ms (the collective alone, synchronised on both sides), fuse_s."""
@@ -105,14 +112,33 @@ def predict_and_fuse(model, dataset, output_folder, rank=0, world_size=1, checke
     for i, r in enumerate(recs):
         views[r["name"]] = {"depth": all_maps[i, 0], "confidence": all_maps[i, 1], "K": all_cams[i, 1, :3, :3].copy(),
                             "E": all_cams[i, 0].copy(), "id": int(r["id"])}
-    pairs = [{"ref": recs[i]["name"], "src": list(recs[i]["src"])[:fusion_num]} for i in mine]
-    fused = fuse.fuse_block(views, pairs, checker, fusion_num=fusion_num, min_geo_consist_num=min_geo_consist_num,
-                            filter_sources=filter_sources)
-    sr = scene_range if scene_range is not None else [-np.inf, np.inf, -np.inf, np.inf]
+    if fuse_partition not in ("views", "scene_blocks"):
+        raise ValueError("fuse_partition must be 'views' or 'scene_blocks'")
+    pair_of = lambda i: {"ref": recs[i]["name"], "src": list(recs[i]["src"])[:fusion_num]}
     out = []
-    for f in fused:
-        pts = fuse.extract_points(f["avg_xyz_world"], f["final_mask"], f["vis_infos"], None, f["normal_world"], sr, skip_line)
-        out.append({"ref": f["ref"], "final_mask": f["final_mask"], "avg_xyz_world": f["avg_xyz_world"], "points": pts})
+    if fuse_partition == "scene_blocks":
+        if not scene_blocks:
+            raise ValueError("fuse_partition='scene_blocks' needs the scene blocks (dataset.read_scene_blocks(blocks.txt))")
+        by_image = {int(r.get("image", i)): i for i, r in enumerate(recs)}
+        for b, blk in enumerate(scene_blocks):
+            if b % world_size != rank:
+                continue
+            # (a reference view listed in a block but absent from the view list -- it had no sources -- has no maps: skipped with the
+            #  warning the reference gives for a missing PFM, fusion_3d_normal.py:420-422)
+            pairs = [pair_of(by_image[i]) for i in blk["refs"] if i in by_image]
+            fused = fuse.fuse_block(views, pairs, checker, fusion_num=fusion_num, min_geo_consist_num=min_geo_consist_num,
+                                    filter_sources=filter_sources)
+            for f in fused:
+                pts = fuse.extract_points(f["avg_xyz_world"], f["final_mask"], f["vis_infos"], None, f["normal_world"],
+                                          blk["scene_range"], skip_line)
+                out.append({"ref": f["ref"], "scene": b, "final_mask": f["final_mask"], "avg_xyz_world": f["avg_xyz_world"], "points": pts})
+    else:
+        fused = fuse.fuse_block(views, [pair_of(i) for i in mine], checker, fusion_num=fusion_num,
+                                min_geo_consist_num=min_geo_consist_num, filter_sources=filter_sources)
+        sr = scene_range if scene_range is not None else [-np.inf, np.inf, -np.inf, np.inf]
+        for f in fused:
+            pts = fuse.extract_points(f["avg_xyz_world"], f["final_mask"], f["vis_infos"], None, f["normal_world"], sr, skip_line)
+            out.append({"ref": f["ref"], "final_mask": f["final_mask"], "avg_xyz_world": f["avg_xyz_world"], "points": pts})
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     if timings is not None:
@@ -130,7 +156,9 @@ def save_fused(results, folder):
     paths = []
     for r in results:
         p = r["points"]
-        path = os.path.join(folder, r["ref"] + ".npz")
+        sub = os.path.join(folder, "scene_%d" % r["scene"]) if "scene" in r else folder   # (a view can belong to several scene blocks)
+        os.makedirs(sub, exist_ok=True)
+        path = os.path.join(sub, r["ref"] + ".npz")
         fm = r["final_mask"].cpu().numpy()
         np.savez(path, mask_shape=np.array(fm.shape), final_mask=np.packbits(fm, axis=1), xyz=p["xyz"].cpu().numpy(),
                  normal=p["normal"].cpu().numpy() if p["normal"] is not None else np.zeros((0, 3), np.float32),

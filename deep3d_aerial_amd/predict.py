@@ -465,6 +465,10 @@ def parse_args(argv=None):
     ap.add_argument("--fuse_filter_sources", type=int, default=1,
                     help="1: confirmed samples leave the source maps (the reference's save_temp chain, kept per rank); 0: order-free")
     ap.add_argument("--fusion_output", default=None, help="folder of the fused arrays (default <output_folder>/fused)")
+    ap.add_argument("--fuse_partition", default="views", choices=["views", "scene_blocks"],
+                    help="who fuses what: every rank the reference views it swept (balanced; the filtering chain restarts at rank seams), or "
+                         "whole scene blocks of blocks.txt per rank (the reference's chains exactly, for any number of ranks)")
+    ap.add_argument("--blocks_file", default=None, help="scene blocks (default <data_folder>/blocks.txt) for --fuse_partition scene_blocks")
     return ap.parse_args(argv)
 
 
@@ -528,9 +532,15 @@ def main(argv=None):
 
         tm = {}
         checker = fuse.ConsistencyChecker(a.position_threshold, a.depth_threshold, a.normal_threshold, a.photometric_threshold)
+        blocks = None
+        if a.fuse_partition == "scene_blocks":
+            from . import dataset as _ds
+
+            blocks = _ds.read_scene_blocks(a.blocks_file or os.path.join(a.data_folder, "blocks.txt"))
         res = pipeline.predict_and_fuse(model, ds, a.output_folder, rank, world, checker=checker, fusion_num=a.fusion_num,
                                         min_geo_consist_num=a.geo_consist_num, filter_sources=bool(a.fuse_filter_sources),
-                                        partition=a.partition, feature_cache_bytes=cache_bytes, timings=tm, display=_truthy(a.display))
+                                        partition=a.partition, feature_cache_bytes=cache_bytes, timings=tm, display=_truthy(a.display),
+                                        fuse_partition=a.fuse_partition, scene_blocks=blocks)
         pipeline.save_fused(res, a.fusion_output or os.path.join(a.output_folder, "fused"))
         print("rank %d/%d: %d views in %.2f s, all-gather of %.1f MB in %.2f ms (%s), fusion of its %d reference views %.2f s, "
               "%d vertices" % (rank, world, tm["views"], tm["predict_s"], tm["allgather_bytes"] / 1e6, tm["allgather_ms"], tm["backend"],

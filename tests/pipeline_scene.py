@@ -7,7 +7,7 @@ view, found through the marker the dataset writes into depth_values.  Everything
 all-gather, the ownership rule, fuse_block, extract_points -- is the production code.
 
 Run as a script it is one rank of a torch.distributed.run launch:
-    python -m torch.distributed.run --nproc-per-node 2 tests/pipeline_scene.py <out_dir> <filter_sources 0|1>
+    python -m torch.distributed.run --nproc-per-node 2 tests/pipeline_scene.py <out_dir> <filter_sources 0|1> [views|scene_blocks]
 """
 import os
 import sys
@@ -72,7 +72,12 @@ def checker():
     return fuse.ConsistencyChecker(1.0, 0.01, 10.0, 0.2)
 
 
-def main(out_dir, filter_sources):
+SCENE_BLOCKS = [{"scene_range": [-1e9, 1e9, -1e9, 1e9, -1e9, 1e9], "refs": [0, 1, 2]},
+                {"scene_range": [-60.0, 40.0, -1e9, 1e9, -1e9, 1e9], "refs": [2, 3, 4]},          # (clips vertices in x; shares view 2)
+                {"scene_range": [-1e9, 1e9, -1e9, 1e9, -1e9, 1e9], "refs": [4, 5, 6]}]
+
+
+def main(out_dir, filter_sources, fuse_partition="views"):
     from deep3d_aerial_amd import pipeline, sharding
 
     rank, world = sharding.init_from_env()
@@ -80,7 +85,8 @@ def main(out_dir, filter_sources):
     scene = SceneViews()
     tm = {}
     res = pipeline.predict_and_fuse(SceneModel(scene), scene, os.path.join(out_dir, "MVS"), rank, world, checker=checker(),
-                                    fusion_num=FUSION_NUM, min_geo_consist_num=3, filter_sources=bool(filter_sources), timings=tm)
+                                    fusion_num=FUSION_NUM, min_geo_consist_num=3, filter_sources=bool(filter_sources), timings=tm,
+                                    fuse_partition=fuse_partition, scene_blocks=SCENE_BLOCKS if fuse_partition == "scene_blocks" else None)
     pipeline.save_fused(res, os.path.join(out_dir, "fused"))
     print("rank %d/%d fused %s: all-gather %.2f ms over %s" % (rank, world, [r["ref"] for r in res], tm["allgather_ms"], tm["backend"]))
     if world > 1:
@@ -89,4 +95,4 @@ def main(out_dir, filter_sources):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]))
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "views")

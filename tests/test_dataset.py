@@ -233,3 +233,14 @@ def test_view_records_list_the_fusion_sources(tmp_path):
     assert [r["src"] for r in ds.view_records(2)] == [["img_01", "img_02"], ["img_00", "img_02"], ["img_01", "img_03"], ["img_04", "img_04"]]
     strip = P.SyntheticStrip(5, 3, 32, 32, 64).view_records(10)
     assert strip[4] == {"name": "view_0004", "src": ["view_0000", "view_0001", "view_0002", "view_0003"], "id": 5, "image": 4}
+
+
+def test_read_scene_blocks(tmp_path):
+    """blocks.txt as IO/params_io.py:430-444 writes it and fuse/fusion_3d_normal.py:252-272 reads it."""
+    from deep3d_aerial_amd import dataset as D
+
+    p = tmp_path / "blocks.txt"
+    p.write_text("2\n-10.5000 20.0000 -3.0000 4.0000 100.0000 200.0000 \n0 1 2 \n0.0000 1.0000 0.0000 1.0000 0.0000 1.0000 \n2 3 \n")
+    b = D.read_scene_blocks(str(p))
+    assert b == [{"scene_range": [-10.5, 20.0, -3.0, 4.0, 100.0, 200.0], "refs": [0, 1, 2]},
+                 {"scene_range": [0.0, 1.0, 0.0, 1.0, 0.0, 1.0], "refs": [2, 3]}]

@@ -18,14 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _launch(n_ranks, out_dir, filter_sources):
+def _launch(n_ranks, out_dir, filter_sources, fuse_partition="views"):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "pipeline_scene.py"), str(out_dir), str(int(filter_sources))]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "pipeline_scene.py"), str(out_dir), str(int(filter_sources)), fuse_partition]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, (res.stdout[-2000:], res.stderr[-3000:])
     return res.stdout
@@ -33,9 +33,10 @@ def _launch(n_ranks, out_dir, filter_sources):
 
 def _load(folder):
     out = {}
-    for f in sorted(os.listdir(folder)):
-        d = np.load(os.path.join(folder, f))
-        out[f[:-4]] = {k: d[k] for k in d.files}
+    for root, _, files in sorted(os.walk(folder)):
+        for f in sorted(files):
+            d = np.load(os.path.join(root, f))
+            out[os.path.relpath(os.path.join(root, f[:-4]), folder)] = {k: d[k] for k in d.files}
     return out
 
 
@@ -101,6 +102,35 @@ def test_source_filtering_chain_is_kept_inside_a_rank(tmp_path):
     _launch(1, tmp_path / "off", False)
     noff = sum(len(v["xyz"]) for v in _load(tmp_path / "off" / "fused").values())
     assert noff > n1
+
+
+def test_scene_blocks_keep_the_reference_chain_for_any_number_of_ranks(tmp_path):
+    """fuse_partition="scene_blocks": whole scene blocks of blocks.txt per rank.  The reference starts the source-filtering chain
+    afresh for every scene block (fusion_3d_normal.py:586-587, 593-608), so with FILTERING ON two ranks produce the single-rank
+    arrays bit for bit -- and those are fuse_block over each block's view list from the unfiltered maps, clipped to the block's range."""
+    from deep3d_aerial_amd import fuse
+
+    _launch(1, tmp_path / "one", True, "scene_blocks")
+    _launch(2, tmp_path / "two", True, "scene_blocks")
+    one, two = _load(tmp_path / "one" / "fused"), _load(tmp_path / "two" / "fused")
+    assert sorted(one) == sorted("scene_%d/scene_%02d" % (b, i) for b, blk in enumerate(PS.SCENE_BLOCKS) for i in blk["refs"])
+    _same(one, two)
+    scene = PS.SceneViews()
+    recs = scene.view_records(PS.FUSION_NUM)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    views = {r["name"]: {"depth": dev(v["depth"]), "confidence": dev(v["confidence"]), "K": v["K"], "E": v["E"], "id": r["id"]}
+             for r, v in zip(recs, scene.views)}
+    for b, blk in enumerate(PS.SCENE_BLOCKS):
+        pairs = [{"ref": recs[i]["name"], "src": recs[i]["src"][:PS.FUSION_NUM]} for i in blk["refs"]]
+        for f in fuse.fuse_block(views, pairs, PS.checker(), fusion_num=PS.FUSION_NUM, min_geo_consist_num=3, filter_sources=True):
+            got = one["scene_%d/%s" % (b, f["ref"])]
+            assert np.array_equal(np.unpackbits(got["final_mask"], axis=1)[:, :PS.W].astype(bool), f["final_mask"].cpu().numpy())
+            pts = fuse.extract_points(f["avg_xyz_world"], f["final_mask"], f["vis_infos"], None, f["normal_world"], blk["scene_range"], 2)
+            assert np.array_equal(got["xyz"], pts["xyz"].cpu().numpy())
+    # view 2 is fused in two blocks: unfiltered at the head of block 1, behind views 0 and 1 in block 0; block 1 clips in x
+    assert not np.array_equal(one["scene_0/scene_02"]["final_mask"], one["scene_1/scene_02"]["final_mask"])
+    x = one["scene_1/scene_03"]["xyz"][:, 0]
+    assert len(x) > 100 and x.min() > -60.0 and x.max() < 40.0
 
 
 def test_predict_main_fuse_flag_two_ranks(tmp_path):
