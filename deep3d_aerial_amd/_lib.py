@@ -67,6 +67,8 @@ SIGNATURES = {
     "d3d_conv2d_k3_wide_h16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "d3d_slice_head_regress_h16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_gru_cell_fused_h16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "d3d_gru_cell_fused_cl8_h16": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "d3d_weighted_corr_cl8_h16": [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp],
     "d3d_convtranspose2d_k3s2_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose2d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],

@@ -163,6 +163,8 @@ class SliceCostRegNetRED(nn.Module):
         """relu(pre(x)) -> gru: one launch in bf16 mode (ops.gru_cell_conv_fused), the separate layers otherwise."""
         g, c = gru.conv_gates[0], gru.convc[0]
         fused = ops.gru_cell_conv_fused(x, state, pre.conv.weight, g.weight, g.bias, c.weight, c.bias, stride)
+        if fused is None and x.dim() == 4:   # a CL8 cost plane the fused kernel refused after all: its planar fp32 form (exact)
+            x = ops.from_cl(ops.cl8_to_cl(x[None]))[:, 0].contiguous()
         return fused if fused is not None else gru(pre(x), state)[0]
 
     def _cells(self, cost, state1, state2):
@@ -185,6 +187,14 @@ class SliceCostRegNetRED(nn.Module):
     def _forward(self, cost, state1, state2):
         up, state1, state2 = self._trunk(cost, state1, state2)
         return self._head(up), state1, state2
+
+    def takes_cl8(self, C, h, w):
+        """Will the first cell of a slice run as the fused kernel on a CL8 cost plane?  (Only then may the sweep write that form:
+        the unfused layers read planar fp32 planes.)"""
+        # (8 channels -- the last stage -- stay planar: one 16-byte cell per pixel makes twice the staging tasks of the planar quads and
+        #  the cell measures 255 against 233 us there; at 16 / 32 channels it is 80 / 36 against 98 / 48 us, tools/cl8_cell_bench.py)
+        return (ops.conv_precision() == "h16" and not _cfg.off("gru_fused") and not _cfg.off("corr_cl8") and _cfg.get("D3D_CONV") != "direct"
+                and C in (16, 32) and w % 4 == 0 and self.base_channels == 8)
 
     def loop_graph(self, C, h, w, D, dv):
         """The captured slice loop for this shape on the caller's stream (SliceLoopGraph), or None where it does not apply: h16
@@ -296,7 +306,10 @@ class SliceLoopGraph(object):
     def _alloc(self):
         dev, f32 = self.dev, torch.float32
         H, W = (2 * self.h, 2 * self.w) if self.up else (self.h, self.w)
-        self.sim = torch.empty((self.D, self.C, self.h, self.w), dtype=f32, device=dev)
+        # the volume the sweep writes: CL8 16-bit cells where the cell takes them (ops.weighted_corr_cl8), the planar fp32 volume otherwise
+        self.cl8 = self.mod().takes_cl8(self.C, self.h, self.w)
+        self.sim = torch.empty((self.D, self.C // 8, self.h, self.w, 8), dtype=ops.h16_dtype(), device=dev) if self.cl8 else \
+            torch.empty((self.D, self.C, self.h, self.w), dtype=f32, device=dev)
         self.dv = torch.empty(self.dv_shape, dtype=f32, device=dev)
         self.s1 = [torch.empty((8, self.h, self.w), dtype=f32, device=dev) for _ in range(4)]
         self.s2 = [torch.empty((16, self.h // 2, self.w // 2), dtype=f32, device=dev) for _ in range(4)]
@@ -449,13 +462,21 @@ class InferDepthNet(nn.Module):
 
         loop = self.reg_fuse.loop_graph(C, h, w, D, dv)
         acc = None
+        dsweep = dv if dv_sweep is None else dv_sweep
         if loop is not None and loop.usable():
             # the slice loop as one HIP graph (SliceLoopGraph): the sweep writes the graph's static volume, the graph is replayed
             sim = loop.buffers().sim
-            ops.weighted_corr(feats, p34, weights, dv if dv_sweep is None else dv_sweep, plane_major=True, out=sim)
+            if loop.cl8:
+                if ops.weighted_corr_cl8(feats, p34, weights, dsweep, out=sim) is None:
+                    raise RuntimeError("the sweep refused the CL8 volume it wrote on the previous call of this shape")
+            else:
+                ops.weighted_corr(feats, p34, weights, dsweep, plane_major=True, out=sim)
             acc = loop.run(dv)
         else:
-            sim = ops.weighted_corr(feats, p34, weights, dv if dv_sweep is None else dv_sweep, plane_major=True)  # [D,C,h,w]: plane d is one contiguous block
+            # fast mode: the volume as CL8 16-bit cells (plane d = what the fused cell stages with 16-byte loads); else [D,C,h,w] fp32
+            sim = ops.weighted_corr_cl8(feats, p34, weights, dsweep) if self.reg_fuse.takes_cl8(C, h, w) else None
+            if sim is None:
+                sim = ops.weighted_corr(feats, p34, weights, dsweep, plane_major=True)  # plane d is one contiguous block
         if acc is None:   # the launch loop
             H, W = (2 * h, 2 * w) if self.in_up else (h, w)
             s1 = torch.zeros((8, h, w), dtype=torch.float32, device=dev)

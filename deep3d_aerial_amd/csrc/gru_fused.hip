@@ -53,7 +53,8 @@ constexpr int GNT = 64 * GW;
 constexpr unsigned OOB = 0xffffffffu;   // a buffer offset outside every tensor: loads return zeros, stores are dropped
 
 struct GruParams {
-    const float* cost;   // [CP, HI, WI]: input of the leading convolution (HI, WI = H, W for S = 1; the finer level for S = 2)
+    const void* cost;    // [CP, HI, WI] fp32: input of the leading convolution (HI, WI = H, W for S = 1; the finer level for S = 2);
+                         // CL instances: [CP / 8, HI, WI, 8] cells of the library's 16-bit format (the sweep's CL8 plane, sweep_params.h)
     const float* h;      // [HID, H, W] state in
     float* hout;         // [HID, H, W] state out (must not alias h: neighbouring tiles read its halo)
     const u4* w1;        // leading convolution, [NKB1][1][64] B fragments (ops._pack_z2_bf16)
@@ -80,6 +81,10 @@ __device__ __forceinline__ float dpp_row_shl8(float v) {   // lane m of a 16-lan
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x108, 0xf, 0xf, true));
 }
 
+// CL (S = 1 only): the cost plane arrives as 16-bit channel-last cells in 8-channel groups -- what d3d_weighted_corr_cl8_h16 writes:
+// the values the planar form rounds while it stages, rounded once by the sweep instead.  A staging task is then (row, pixel, group):
+// ONE 16-byte load and ONE 16-byte LDS write, no conversion (planar fp32: four 16-byte loads, eight packed conversions and four
+// 8-byte writes per 16 values) and half the bytes.
 template <int CP, int HID, int S, int MG, int TY>
 struct GruGeom {
     static constexpr int RX = 16 * MG, RY = TY + 4;          // region of x / h / r*h
@@ -98,8 +103,9 @@ struct GruGeom {
 
 // A workgroup walks `tper` tiles down the image: the weights are loaded once, and (PREFETCH) the next tile's cost / state
 // patches are in flight -- raw, in registers -- while the current tile is swept.
-template <int CP, int HID, int S, int MG, int TY>
+template <int CP, int HID, int S, int MG, int TY, bool CL = false>
 __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024 ? D3D_GRU_WAVES2 : 2)) void gru_cell_fused_kernel(GruParams p) {
+    static_assert(!CL || S == 1, "channel-last cost planes feed the stride-1 cell (the stride-2 cell reads the fp32 state of the first)");
     using G = GruGeom<CP, HID, S, MG, TY>;
     constexpr int RX = G::RX, RY = G::RY, PITCH = G::PITCH, XC = G::XC, REG = G::REG, CS1 = G::CS1, SPX = G::SPX, SPY = G::SPY;
     constexpr int NEVEN = G::NEVEN, NKB1 = G::NKB1, NKBG = G::NKBG, NTNG = G::NTNG;
@@ -138,23 +144,40 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
     //      gxc0 - 3 (a multiple of 4) and the columns outside the patch are dropped at the commit.
     //      Per task and for good: its byte offset from the patch origin (OOB where the column is outside the image), its patch
     //      row, its first cell; per tile: rows outside the image turn the offset OOB (a uniform test skips that for inner tiles).
-    constexpr int NQC = (SPX + 3 + 3) / 4, C4C = CP / 4, NTC = SPY * NQC * C4C, RC = (NTC + GNT - 1) / GNT;
+    constexpr int NQC = (SPX + 3 + 3) / 4, C4C = CP / 4, NTC = CL ? 1 : SPY * NQC * C4C, RC = CL ? 1 : (NTC + GNT - 1) / GNT;
     constexpr int NQH = RX / 4, C4H = HID / 4, NTH = RY * NQH * C4H, RH = (NTH + GNT - 1) / GNT;
     const int qx0 = (S == 2 ? 2 * rx0 : rx0) - 4;
     unsigned cvo[RC];    // cost task: offset | OOB
     int cpy[RC], ccell[RC];
     bool ckeep[RC][4];   // the pixel's column lies inside the patch
+    if constexpr (!CL) {
 #pragma unroll
-    for (int r = 0; r < RC; ++r) {
-        const int task = r * GNT + tid;
-        const int q = task % NQC, rest = task / NQC, c4 = rest % C4C, py = rest / C4C;
-        const int gx = qx0 + 4 * q;
-        cvo[r] = task < NTC && gx >= 0 && gx < WI ? (unsigned)(4 * c4) * iplane4 + (unsigned)(py * WI + 4 * q) * 4 : OOB;
-        cpy[r] = py;
-        const int px0 = 4 * q - 3;   // patch column of the quad's first pixel (odd)
-        ccell[r] = task < NTC ? (S == 2 ? py * SPX + NEVEN + ((px0 - 1) >> 1) : py * SPX + px0) * CS1 + c4 * 8 : -1;
+        for (int r = 0; r < RC; ++r) {
+            const int task = r * GNT + tid;
+            const int q = task % NQC, rest = task / NQC, c4 = rest % C4C, py = rest / C4C;
+            const int gx = qx0 + 4 * q;
+            cvo[r] = task < NTC && gx >= 0 && gx < WI ? (unsigned)(4 * c4) * iplane4 + (unsigned)(py * WI + 4 * q) * 4 : OOB;
+            cpy[r] = py;
+            const int px0 = 4 * q - 3;   // patch column of the quad's first pixel (odd)
+            ccell[r] = task < NTC ? (S == 2 ? py * SPX + NEVEN + ((px0 - 1) >> 1) : py * SPX + px0) * CS1 + c4 * 8 : -1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ckeep[r][i] = task < NTC && px0 + i >= 0 && px0 + i < SPX;
+            for (int i = 0; i < 4; ++i) ckeep[r][i] = task < NTC && px0 + i >= 0 && px0 + i < SPX;
+        }
+    }
+    // channel-last cost plane: task = (patch row py, patch column px, 8-channel group g); patch column px is image column rx0 - 1 + px
+    constexpr int G8 = CP / 8, NTL = CL ? SPY * SPX * G8 : 1, RL = CL ? (NTL + GNT - 1) / GNT : 1;
+    unsigned lvo[RL];    // offset from the patch origin (row 0, column 0 of the patch, group 0) | OOB
+    int lpy[RL], lcell[RL];
+    if constexpr (CL) {
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int task = r * GNT + tid;
+            const int px = task % SPX, rest = task / SPX, g = rest % G8, py = rest / G8;
+            const int gx = rx0 - 1 + px;
+            lvo[r] = task < NTL && gx >= 0 && gx < WI ? ((unsigned)g * (unsigned)(HI * WI) + (unsigned)(py * WI + px)) * 16u : OOB;
+            lpy[r] = py;
+            lcell[r] = task < NTL ? (py * SPX + px) * CS1 + g * 16 : -1;
+        }
     }
     unsigned hvo[RH];
     int hpy[RH], hcell[RH];
@@ -168,9 +191,23 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
         hcell[r] = task < NTH ? REG + (py * PITCH + 4 * q + 1) * XC + c4 * 8 : -1;   // (H region = XA + REG)
     }
     f4 sc[RC][4], sh[RH][4];
+    u4 sl[RL];
     auto issue_cost = [&](int ty) {
+        if constexpr (CL) {
+            const int gy0 = ty * TY - 3;
+            // (the origin may lie before the tensor: the lanes that would read there carry OOB offsets)
+            const __amdgpu_buffer_rsrc_t rs = tensor_rsrc(static_cast<const unsigned char*>(p.cost) + ((long)gy0 * WI + (rx0 - 1)) * 16);
+            const bool inner = gy0 >= 0 && gy0 + SPY <= HI;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                unsigned vo = lvo[r];
+                if (!inner) vo = (unsigned)(lpy[r] + gy0) < (unsigned)HI ? vo : OOB;
+                sl[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+            }
+            return;
+        }
         const int gy0 = S == 2 ? 2 * (ty * TY - 2) - 1 : ty * TY - 3;
-        const __amdgpu_buffer_rsrc_t rs = tensor_rsrc(p.cost + ((long)gy0 * WI + qx0));
+        const __amdgpu_buffer_rsrc_t rs = tensor_rsrc(static_cast<const float*>(p.cost) + ((long)gy0 * WI + qx0));
         const bool inner = gy0 >= 0 && gy0 + SPY <= HI;
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
@@ -194,6 +231,12 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
     };
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     auto commit_cost = [&]() {
+        if constexpr (CL) {
+#pragma unroll
+            for (int r = 0; r < RL; ++r)
+                if (lcell[r] >= 0) *reinterpret_cast<u4*>(sim + lcell[r]) = sl[r];   // (outside the image the load returned zeros)
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < RC; ++r) {
             if (ccell[r] < 0) continue;
@@ -413,11 +456,11 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
     }
 }
 
-template <int CP, int HID, int S, int MG, int TY>
+template <int CP, int HID, int S, int MG, int TY, bool CL = false>
 static int launch_gru(const GruParams& p, hipStream_t stream) {
     using G = GruGeom<CP, HID, S, MG, TY>;
     static_assert(G::LDS <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = gru_cell_fused_kernel<CP, HID, S, MG, TY>;
+    auto kern = gru_cell_fused_kernel<CP, HID, S, MG, TY, CL>;
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS);
     if (rc != D3D_OK) return rc;
     GruParams q = p;
@@ -479,5 +522,32 @@ extern "C" int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI,
     }
     if (stride == 2 && HID == 16 && CP == 8) return launch_gru<8, 16, 2, 4, 4>(p, st);
     set_error("d3d_gru_cell_fused_h16: C = %d, hidden = %d, stride = %d not taken (8 | 16 | 32 -> 8 at stride 1; 8 -> 16 at stride 2)", CP, HID, stride);
+    return D3D_ERR_UNSUPPORTED;
+}
+
+// The stride-1 cell with its cost plane as channel-last 16-bit cells in 8-channel groups, cost [CP / 8, H, W, 8] in the library's h16
+// format: one plane of the volume d3d_weighted_corr_cl8_h16 writes.  The planar entry rounds the fp32 plane to that format while it
+// stages; here the sweep has done the same rounding once, so the new state is bit for bit the planar entry's on the planar form of
+// the same volume.  CP = 8 | 16 | 32, HID = 8; W a multiple of 4, 16-byte aligned tensors, else D3D_ERR_UNSUPPORTED.
+extern "C" int d3d_gru_cell_fused_cl8_h16(const void* cost_cl8, int CP, const float* h, int HID, int H, int W, const void* w1, const void* wg,
+                                          const float* bg, const void* wc, const float* bc, float* hout, d3d_stream_t stream) {
+    D3D_REQUIRE(cost_cl8 && h && hout && w1 && wg && wc && bg && bc, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0, "bad dims");
+    D3D_REQUIRE(h != hout, "the state is updated out of place (neighbouring tiles read the old halo)");
+    if (W % 4 != 0 || (long)CP * H * W * 2 >= (1L << 31) || (long)HID * H * W * 4 >= (1L << 31) ||
+        ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(hout) | reinterpret_cast<uintptr_t>(cost_cl8)) & 15)) {
+        set_error("d3d_gru_cell_fused_cl8_h16: width %d (a multiple of 4) with 16-byte aligned tensors below 2 GiB needed", W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    GruParams p = {};
+    p.cost = cost_cl8; p.h = h; p.hout = hout; p.w1 = reinterpret_cast<const u4*>(w1); p.wg = reinterpret_cast<const u4*>(wg);
+    p.wc = reinterpret_cast<const u4*>(wc); p.bg = bg; p.bc = bc; p.H = H; p.W = W; p.HI = H; p.WI = W;
+    hipStream_t st = (hipStream_t)stream;
+    if (HID == 8) {
+        if (CP == 8) return launch_gru<8, 8, 1, 4, 8, true>(p, st);
+        if (CP == 16) return launch_gru<16, 8, 1, 4, 8, true>(p, st);
+        if (CP == 32) return launch_gru<32, 8, 1, 4, 8, true>(p, st);
+    }
+    set_error("d3d_gru_cell_fused_cl8_h16: C = %d, hidden = %d not taken (8 | 16 | 32 -> 8)", CP, HID);
     return D3D_ERR_UNSUPPORTED;
 }

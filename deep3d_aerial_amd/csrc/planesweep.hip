@@ -570,6 +570,26 @@ int d3d_weighted_corr(const float* const* feats, const float* proj34, const floa
     return sweep_dispatch(MODE_WEIGHTED, p, (hipStream_t)stream);
 }
 
+// adamvs.py:492-509 with the volume leaving as 16-bit cells in planes of 8-channel groups [D, C/8, h, w, 8] (the library's h16
+// format, RNE of the fp32 value d3d_weighted_corr stores): plane d is one contiguous block whose cells the fused conv-GRU cell
+// stages with 16-byte loads (d3d_gru_cell_fused_cl8_h16).  Window kernel only (C % 8 == 0, at most 4 source views, D <= 48: every
+// stage of the cascades); D3D_ERR_UNSUPPORTED otherwise -- the caller then takes d3d_weighted_corr.
+int d3d_weighted_corr_cl8_h16(const float* const* feats, const float* proj34, const float* weights, const float* depth,
+                              int depth_mode, int n_views, int C, int D, int h, int w, void* out, void* workspace,
+                              size_t workspace_bytes, d3d_stream_t stream) {
+    SweepParams p = {};
+    D3D_REQUIRE(weights, "null weights");
+    int rc = fill_multi(p, feats, proj34, depth, depth_mode, n_views, C, D, h, w, reinterpret_cast<float*>(out), workspace, workspace_bytes);
+    if (rc) return rc;
+    p.weights = weights;
+    p.out_cl = 2;
+    if (forced_path() == 1 || forced_path() == 2) {
+        set_error("d3d_weighted_corr_cl8_h16: only the window kernel writes the channel-last correlation volume");
+        return D3D_ERR_UNSUPPORTED;
+    }
+    return counted(3, launch_window(MODE_WEIGHTED, p, (hipStream_t)stream, forced_path() == 3));
+}
+
 int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, const float* depth, int depth_mode,
                        int C, int D, int h, int w, float* out, void* workspace, size_t workspace_bytes,
                        d3d_stream_t stream) {

@@ -147,10 +147,17 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
     constexpr int WWAVES = window_waves(MODE, CH), WTHREADS = 64 * WWAVES;
     static_assert(MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED || (MODE == MODE_PAIR && NSRC == 1),
                   "window kernel: variance, weighted correlation, and the channel mean of one pair's correlation");
-    static_assert(!OUTCL || MODE == MODE_VARIANCE, "channel-last bf16 output is the variance volume's");
+    static_assert(!OUTCL || MODE == MODE_VARIANCE || MODE == MODE_WEIGHTED, "channel-last 16-bit output: the variance volume and the weighted correlation");
     static_assert(NSRC <= 8, "one lane per (corner, view): 8 x NSRC <= 64");
     constexpr int NPW = PH / 2, NSUBW = WWAVES / NPW;   // pixel waves, plane sub-ranges
     constexpr int Q = CH / 4;
+    // The weighted correlation leaving as CL8 16-bit cells (round 5: the slice regularisers' fast mode): with the four view weights
+    // of a pixel and the four views' rays in registers for the whole kernel this instance does not fit 128 registers (18 spills in
+    // the plane loop even with the packed accumulate below; 148 and a 6.7 ms sweep instead of 1.7 ms before it).  The weights live in
+    // LDS instead ([pixel][4] floats, 4 KB), read where they are used -- one ds_read_b32 per (quad, view, plane) -- and so do the
+    // views' matrices, from which a view's ray is rebuilt per plane: 123 registers, no spill.
+    constexpr bool VW_LDS = OUTCL && MODE == MODE_WEIGHTED;
+    static_assert(!VW_LDS || NSRC <= 4, "four view weights per LDS cell");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
@@ -224,6 +231,22 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
             den += vw[i];
         }
         rden = 1.0f / den;
+        if constexpr (VW_LDS) {
+            if (sub == 0) {
+                f4 wv = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < NSRC; ++i) wv[i] = vw[i];
+                lds_write4_abs(lds_base_bytes(lds) + WTAB * 4 + (pw * 64 + lane) * 16, wv);   // (read behind the range table's barrier)
+            }
+            // ... and so do the views' 3 x 4 matrices (rows [r0 r1 r2 t]; an unused view: every sample at (-1, -1)): the lane's
+            // ray of a view is rebuilt from them per plane (make_ray's own expression) instead of living in three registers per view
+            if (tid < 3 * NSRC) {
+                const int i = tid / 3, row = tid - 3 * i;
+                f4 m = {0.0f, 0.0f, 0.0f, row == 2 ? 1.0f : -1.0f};
+                if (i < p.n_src) { const float* __restrict__ M = p.proj34 + 12 * i + 4 * row; m = (f4){M[0], M[1], M[2], M[3]}; }
+                lds_write4_abs(lds_base_bytes(lds) + WTAB * 4 + WTW * PH * 16 + tid * 16, m);
+            }
+        }
     }
     float aff_lo = 1.0f, aff_step = 0.0f;
     if (p.depth_mode == D3D_DEPTH_AFFINE && valid) {
@@ -296,10 +319,13 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
     constexpr bool REF_LDS = Q > 2 && MODE != MODE_PAIR;   // (a pair sweep has one view's geometry live: room for the reference in registers)
     constexpr int NPIX = WTW * PH;
     constexpr int REF_BYTES = REF_LDS ? CH * NPIX * 4 : 0;
-    const int ref0 = lds_base_bytes(lds) + WTAB * 4;
+    constexpr int VW_BYTES = VW_LDS ? WTW * PH * 16 + 3 * NSRC * 16 : 0;   // view weights per pixel + the views' matrices
+    const int my_mat = lds_base_bytes(lds) + WTAB * 4 + WTW * PH * 16;
+    const int my_vw = lds_base_bytes(lds) + WTAB * 4 + (pw * 64 + lane) * 16;
+    const int ref0 = lds_base_bytes(lds) + WTAB * 4 + VW_BYTES;
     const int my_ref = ref0 + (pw * 64 + lane) * 16;
     const int lds0 = ref0 + REF_BYTES;
-    const int cap_bytes = a.cap_bytes - REF_BYTES;
+    const int cap_bytes = a.cap_bytes - REF_BYTES - VW_BYTES;
     const float umax = (float)w, vmax = (float)h;
     const float invV = 1.0f / (float)(p.n_src + 1);
     const size_t cstride_b = (p.plane_major ? plane : (size_t)D * plane) * 4;   // bytes between channels
@@ -362,7 +388,10 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
         } else {
             o = s * rden;
         }
-        if constexpr (OUTCL) {
+        if constexpr (OUTCL && MODE == MODE_WEIGHTED) {
+            store_sbase_h16x4(ob, pixo, pack_h16x4(o));   // (quad by quad: sweep_device.h)
+            ob += 8;
+        } else if constexpr (OUTCL) {
             if ((q & 1) == 0) {
                 even_quad = pack_h16x4(o);
             } else {
@@ -396,8 +425,14 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
             s = cat2(lo2(s) + vl, hi2(s) + vh);
             qq = cat2(pk_fma(vl, vl, lo2(qq)), pk_fma(vh, vh, hi2(qq)));
         } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s[k] = fmaf(val[k] * rq[k], vw[i], s[k]);
+            float wv;
+            if constexpr (VW_LDS) wv = *(volatile __attribute__((address_space(3))) float*)(unsigned)(my_vw + 4 * i);
+            else wv = vw[i];
+            // per channel: the product val * ref rounded, then one fused multiply-add with the view weight -- two channels per
+            // instruction (v_pk_mul_f32, v_pk_fma_f32: the scalar form's results bit for bit, half its instructions; written as four
+            // scalar chains the channel-last instance spilled 148 registers)
+            const f2 w2 = {wv, wv};
+            s = cat2(pk_fma(lo2(val) * lo2(rq), w2, lo2(s)), pk_fma(hi2(val) * hi2(rq), w2, hi2(s)));
         }
     };
 
@@ -440,7 +475,7 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                 // (waited for below, behind the staging loads: ref_wait)
             }
             asm volatile("" : "+v"(aff_lo), "+v"(aff_step), "+v"(rden));
-            if (MODE == MODE_WEIGHTED) {
+            if (MODE == MODE_WEIGHTED && !VW_LDS) {
 #pragma unroll
                 for (int i = 0; i < NSRC; ++i) asm volatile("" : "+v"(vw[i]));
             }
@@ -562,6 +597,15 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                     };
 #ifndef D3D_WINDOW_T_SGPR
                     auto geo_view = [&](int i) {
+                        if constexpr (VW_LDS) {   // (matrix rows from LDS, broadcast reads; the ray as make_ray computes it)
+                            const f4 m0 = *(volatile lds_f4_ptr)(unsigned)(my_mat + 48 * i), m1 = *(volatile lds_f4_ptr)(unsigned)(my_mat + 48 * i + 16),
+                                     m2 = *(volatile lds_f4_ptr)(unsigned)(my_mat + 48 * i + 32);
+                            Ray rr;
+                            rr.rx = fmaf(m0[0], xf, fmaf(m0[1], yf, m0[2]));
+                            rr.ry = fmaf(m1[0], xf, fmaf(m1[1], yf, m1[2]));
+                            rr.rz = fmaf(m2[0], xf, fmaf(m2[1], yf, m2[2]));
+                            return geo_win(rr, m0[3], m1[3], m2[3], dv, umax, vmax, W[i]);
+                        }
                         const f4 tv = *(volatile lds_f4_ptr)(unsigned)(tadr + 16 * i);   // (volatile: not hoisted out of the plane loop)
                         return geo_win(ray[i], tv[0], tv[1], tv[2], dv, umax, vmax, W[i]);
                     };
@@ -834,6 +878,9 @@ static int launch_window_ch(const SweepParams& p, hipStream_t stream) {
 #endif
             return launch_window_one<MODE, NSRC, 8, true, 8>(p, stream);
         }
+    }
+    if constexpr (MODE == MODE_WEIGHTED) {   // (round 5: the slice regularisers' cost planes as CL8 16-bit cells -- d3d_weighted_corr_cl8_h16)
+        if (p.out_cl == 2) return launch_window_one<MODE, NSRC, 8, true, 8>(p, stream);
     }
     if (p.out_cl) return D3D_ERR_UNSUPPORTED;
 #ifdef D3D_WINDOW_CG16

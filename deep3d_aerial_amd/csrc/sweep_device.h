@@ -104,13 +104,14 @@ __device__ __forceinline__ void store_sbase(unsigned long long sb, unsigned byte
 
 // channel-last 16-bit output (the library's h16 format, common.h): four consecutive channels of the lane's voxel, RNE, as two
 // dwords ...  The variance volume is the one operand of the regularisers whose magnitude the data decides (feature maps leave
-// their nets without a normalisation): in the half format it SATURATES at the largest finite value instead of becoming inf
-// (one v_min_f32 per value; a variance is never far below zero -- E[x^2] - E[x]^2 cancels to a few ulp).
+// their nets without a normalisation), and so is the weighted correlation of the slice models: in the half format they SATURATE
+// at the largest finite magnitude instead of becoming inf (one v_med3_f32 per value).
 __device__ __forceinline__ unsigned long long pack_h16x4(const float __attribute__((ext_vector_type(4)))& v) {
 #ifdef D3D_H16_BF16
     const unsigned a = pack_h16x2(v[0], v[1]), b = pack_h16x2(v[2], v[3]);
 #else
-    const unsigned a = pack_h16x2(fminf(v[0], 65504.0f), fminf(v[1], 65504.0f)), b = pack_h16x2(fminf(v[2], 65504.0f), fminf(v[3], 65504.0f));
+    auto sat = [](float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); };   // (a correlation can be negative)
+    const unsigned a = pack_h16x2(sat(v[0]), sat(v[1])), b = pack_h16x2(sat(v[2]), sat(v[3]));
 #endif
     return (unsigned long long)a | ((unsigned long long)b << 32);
 }
@@ -129,6 +130,14 @@ __device__ __forceinline__ void store_sbase_h16x8(unsigned long long sb, unsigne
     //  the compiler's hazard recognizer does not see inside the string -- without the s_nop some lanes stored garbage)
     if constexpr (PARTIAL) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
     else asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(byte_off), "v"(bits), "s"(sb));
+}
+// one finished quad of a CL8 cell on its own: 8 bytes at byte_off (+ 8 for the cell's second quad).  The weighted-correlation
+// instance of the window kernel has no registers left for holding the first quad until the second is finished (148 spills with
+// the 16-byte form); a wave's two 8-byte stores still cover one contiguous kilobyte between them.
+__device__ __forceinline__ void store_sbase_h16x4(unsigned long long sb, unsigned byte_off, unsigned long long quad) {
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const u2v bits = {(unsigned)quad, (unsigned)(quad >> 32)};
+    asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(byte_off), "v"(bits), "s"(sb));
 }
 }  // namespace
 }  // namespace d3d

@@ -282,6 +282,34 @@ def weighted_corr(feats, proj34, weights, depth, out=None, plane_major=False):
     return out
 
 
+def weighted_corr_cl8(feats, proj34, weights, depth, out=None):
+    """weighted_corr for the fast mode of the slice regularisers: the volume leaves the sweep as 16-bit cells in planes of
+    8-channel groups, [D, C/8, h, w, 8] in the library's h16 format (d3d_weighted_corr_cl8_h16) -- plane d is what the fused
+    conv-GRU cell stages with 16-byte loads (gru_cell_conv_fused on a 4-d cost).  The values are the fp32 volume's, rounded
+    once (the rounding the cell applies to the planar plane anyway).  None where the window kernel does not take the shape or
+    D3D_KERNELS_OFF=corr_cl8: the caller then takes weighted_corr(plane_major=True)."""
+    C, h, w = _check_feats(feats, proj34)
+    if tuple(weights.shape) != (len(feats) - 1, h, w):
+        raise ValueError("weights must be [%d,%d,%d]" % (len(feats) - 1, h, w))
+    if C % 8 or _cfg.off("corr_cl8"):
+        return None
+    dp, mode, D = _depth(depth, h, w)
+    shape = (D, C // 8, h, w, 8)
+    if out is None:
+        out = torch.empty(shape, dtype=h16_dtype(), device=feats[0].device)
+    elif tuple(out.shape) != shape or out.dtype != h16_dtype() or not out.is_contiguous():
+        raise ValueError("out must be a contiguous %s tensor of ops.h16_dtype()" % (shape,))
+    arr = _ptr_array(feats, "feats")
+    ws, wp, wn = _workspace(len(feats), C, D, h, w, 4, feats[0].device, mode)
+    rc = _lib.load().d3d_weighted_corr_cl8_h16(arr, _chk(proj34, "proj34"), _chk(weights, "weights", 3), dp, mode, len(feats), C, D, h, w,
+                                               ctypes.c_void_p(out.data_ptr()), wp, wn, _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_weighted_corr_cl8_h16")
+    dispatch_counts["weighted_corr_cl8"] += 1
+    return out
+
+
 def pair_corr_mean(ref, src, proj34, depth, out=None):
     """adamvs.py:469-474. -> [D,h,w]."""
     C, h, w = _check_feats([ref, src], proj34)
@@ -2007,8 +2035,30 @@ def gru_cell_conv_fused(cost, h, w_pre, w_gates, b_gates, w_cand, b_cand, stride
     adamvs.py:409-412: conv1 + conv_gru1 at stride 1, conv2 + conv_gru2 at stride 2).  bf16 mode only (the operands are bf16, the
     state stays fp32): bit-identical to conv2d_zs + gru_cell_fused.  Returns the new state, or None for shapes / modes the
     kernel does not take (the caller then runs the separate launches)."""
-    if conv_precision() != "h16" or not _use_mfma() or _cfg.off("gru_fused") or cost.dim() != 3:
+    if conv_precision() != "h16" or not _use_mfma() or _cfg.off("gru_fused") or cost.dim() not in (3, 4):
         return None
+    if cost.dim() == 4:   # a CL8 plane [C/8, H, W, 8] of 16-bit cells (weighted_corr_cl8): the stride-1 cell's own entry point
+        G8, HI, WI, _ = cost.shape
+        HID, H, W = h.shape
+        CP = 8 * G8
+        if cost.dtype != h16_dtype() or cost.shape[3] != 8 or not cost.is_contiguous() or stride != 1 or (HI, WI) != (H, W) \
+                or CP not in (8, 16, 32) or HID != 8 or b_gates is None or b_cand is None:
+            return None
+        w1 = derived_weight(w_pre, "z2bf16", _pack_z2_bf16)
+        wg = derived_weight(w_gates, "z2bf16", _pack_z2_bf16)
+        wc = derived_weight(w_cand, "z2bf16", _pack_z2_bf16)
+        if out is None:
+            out = torch.empty_like(h)
+        elif out.shape != h.shape or out.dtype != h.dtype or out.data_ptr() == h.data_ptr():
+            raise ValueError("out must be a separate tensor of the state's shape")
+        rc = _lib.load().d3d_gru_cell_fused_cl8_h16(ctypes.c_void_p(cost.data_ptr()), CP, _chk(h, "h", 3), HID, H, W,
+                                                    ctypes.c_void_p(w1.data_ptr()), ctypes.c_void_p(wg.data_ptr()), _chk(b_gates, "b_gates"),
+                                                    ctypes.c_void_p(wc.data_ptr()), _chk(b_cand, "b_cand"), _chk(out, "out"), _stream())
+        if rc == _lib.ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, "d3d_gru_cell_fused_cl8_h16")
+        dispatch_counts["gru_cell_fused"] += 1
+        return out
     CP, HI, WI = cost.shape
     HID, H, W = h.shape
     if stride == 1:

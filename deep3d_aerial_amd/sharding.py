@@ -103,6 +103,8 @@ def all_gather_maps(local_maps, n_views, rank=None, world_size=None, policy="blo
         gathered = local_maps.new_empty((world_size * per,) + tuple(local_maps.shape[1:]))
         dist.all_gather_into_tensor(gathered, padded.contiguous())
     # gathered[r*per + j] is the j-th view of rank r's list
+    if policy == "block" and n_views == world_size * per:
+        return gathered   # equal contiguous blocks: rank-major order IS the global view order (no second 5 GB pass at config 5's size)
     out = local_maps.new_empty((n_views,) + tuple(local_maps.shape[1:]))
     for r in range(world_size):
         idx = shard_views(n_views, r, world_size, policy)

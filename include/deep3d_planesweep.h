@@ -206,6 +206,14 @@ int d3d_pair_corr_mean(const float* ref, const float* src, const float* proj34, 
 int d3d_weighted_corr(const float* const* feats, const float* proj34, const float* weights, const float* depth,
                       int depth_mode, int n_views, int C, int D, int h, int w, int plane_major, float* out, void* workspace,
                       size_t workspace_bytes, d3d_stream_t stream);
+/* adamvs.py:492-509 with the volume leaving as 16-bit cells in planes of 8-channel groups, out [D, C/8, h, w, 8] in the library's h16
+ * format (RNE of the fp32 value d3d_weighted_corr stores; saturating at +-65504 in the half format): what the fused conv-GRU cell
+ * stages with 16-byte loads (d3d_gru_cell_fused_cl8_h16).  Window kernel only -- C % 8 == 0, at most 4 source views, D <= 48: every
+ * stage of the cascades -- D3D_ERR_UNSUPPORTED otherwise (the caller then takes d3d_weighted_corr).  ABI 9. */
+int d3d_weighted_corr_cl8_h16(const float* const* feats, const float* proj34, const float* weights, const float* depth,
+                              int depth_mode, int n_views, int C, int D, int h, int w, void* out, void* workspace,
+                              size_t workspace_bytes, d3d_stream_t stream);
+
 
 /*
  * cas_mvsnet.py:69-76 + module.py:605-613 -- softmax over D, soft-argmin depth and the
@@ -465,6 +473,13 @@ int d3d_conv2d_k3_wide_h16(const float* in, int C1, const float* in2, int C2, co
 int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI, int stride, const float* h, int HID, int H, int W,
                             const void* w1, const void* wg, const float* bg, const void* wc, const float* bc, float* hout,
                             d3d_stream_t stream);
+/* The stride-1 cell on a cost plane of channel-last 16-bit cells in 8-channel groups, cost_cl8 [CP / 8, H, W, 8] in the library's h16
+ * format (one plane of d3d_weighted_corr_cl8_h16's volume): a staging task is one 16-byte load and one 16-byte LDS write, no
+ * conversion, half the bytes.  Bit-identical to d3d_gru_cell_fused_h16 on the planar fp32 plane of the same values (the planar entry
+ * applies the same rounding while it stages).  CP = 8 | 16 | 32, HID = 8.  ABI 9.  adamvs.py:409-410, module.py:24-51. */
+int d3d_gru_cell_fused_cl8_h16(const void* cost_cl8, int CP, const float* h, int HID, int H, int W, const void* w1, const void* wg,
+                               const float* bg, const void* wc, const float* bc, float* hout, d3d_stream_t stream);
+
 
 /* Conv2d(kernel 5, stride 2, padding 2) -- the downsampling layers of the feature trunks (module.py:669, 675; adamvs.py:64, 70 of the reference) --
  * on the stride-2 tile kernel with split operands (fp32 accuracy): in [Ci,H,W] -> out [Co,(H-1)/2+1,(W-1)/2+1]; wpacked:

@@ -2624,3 +2624,77 @@ def test_adamvs_slice_graph_is_the_serial_loop(ops, monkeypatch):
     finally:
         ops.set_conv_precision(None)
     assert not torch.equal(fresh[0], outs[0][4]) and all(torch.equal(fresh[0], f) for f in fresh[1:])
+
+
+@pytest.mark.parametrize("V,C,h,w,D,kind", [(5, 32, 44, 72, 12, "plane"), (5, 16, 70, 100, 8, "affine"), (3, 8, 96, 132, 8, "pixel"),
+                                            (4, 32, 37, 52, 5, "pixel")])
+def test_weighted_corr_cl8_is_the_rounded_planar_volume(ops, V, C, h, w, D, kind):
+    """d3d_weighted_corr_cl8_h16 (adamvs.py:492-509 leaving the sweep as 16-bit cells in planes of 8-channel groups): exactly the
+    fp32 volume of d3d_weighted_corr rounded once to the library's 16-bit format, in the CL8 arrangement [D, C/8, h, w, 8]."""
+    proj, dv = S.make_scene(V, h, w, D, sweep_px=5.0, seed=V * 7 + C, yaw_deg=3.0)
+    fd = [dev(f) for f in S.make_features(V, C, h, w, seed=C + D)]
+    rng = np.random.default_rng(C + h)
+    p34 = ops.compose_projections(dev(proj))
+    vw = dev(rng.uniform(0.02, 1.0, (V - 1, h, w)))
+    if kind == "plane":
+        depth = dev(S.uniform_depths(dv, D))
+    else:
+        cur = dev((0.5 * (dv[0] + dv[1]) + 0.2 * float(dv[1] - dv[0]) * rng.uniform(-1, 1, (h, w))).astype(np.float32))
+        depth = ops.depth_range_affine(cur, D, float(dv[1] - dv[0]) / 4.0 / D)
+        if kind == "pixel":
+            depth = depth.volume()
+    planar = ops.weighted_corr(fd, p34, vw, depth, plane_major=True)              # [D,C,h,w] fp32
+    got = ops.weighted_corr_cl8(fd, p34, vw, depth)
+    assert got is not None and got.dtype == _h16_dtype() and tuple(got.shape) == (D, C // 8, h, w, 8)
+    want = planar.view(D, C // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous().to(_h16_dtype())
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("C,h,w", [(32, 44, 72), (16, 70, 100), (8, 96, 132), (8, 9, 4), (32, 130, 68)])
+def test_gru_cell_on_a_cl8_cost_plane_is_the_planar_cell(ops, bf16_mode, C, h, w):
+    """d3d_gru_cell_fused_cl8_h16: the fused conv-GRU cell staging its cost plane from 16-bit CL8 cells equals, bit for bit, the
+    planar entry on the fp32 plane holding the same (already rounded) values -- the planar entry's own rounding is then exact."""
+    rng = np.random.default_rng(C * 3 + h)
+    cost = torch.from_numpy(rng.standard_normal((C, h, w)).astype(np.float32)).cuda().to(_h16_dtype())   # values of the 16-bit format
+    planar = cost.float().contiguous()
+    cl8 = cost.view(C // 8, 8, h, w).permute(0, 2, 3, 1).contiguous()                                      # [C/8, h, w, 8]
+    h0 = dev(rng.standard_normal((8, h, w)))
+    w1 = dev(rng.standard_normal((8, C, 3, 3)) / (3.0 * np.sqrt(C)))
+    wg, bg = dev(rng.standard_normal((16, 16, 3, 3)) / 12.0), dev(rng.standard_normal(16))
+    wc, bc = dev(rng.standard_normal((8, 16, 3, 3)) / 12.0), dev(rng.standard_normal(8))
+    a = ops.gru_cell_conv_fused(planar, h0, w1, wg, bg, wc, bc, 1)
+    b = ops.gru_cell_conv_fused(cl8, h0, w1, wg, bg, wc, bc, 1)
+    assert a is not None and b is not None
+    assert torch.equal(a, b)
+
+
+def test_adamvs_cl8_correlation_volume_is_the_planar_forward(ops, monkeypatch):
+    """Infer_AdaMVSNet in the fast mode with the weighted-correlation volume as CL8 16-bit cells (sweep -> fused cell, no fp32
+    volume in between) against the planar fp32 volume: bit-identical outputs, in the launch loop and in the captured loop."""
+    from deep3d_aerial_amd.adamvs import Infer_AdaMVSNet
+
+    V, H, W, nd = 5, 256, 384, 384
+    net = Infer_AdaMVSNet(num_depth=nd)
+    S.fill_state_dict_(net.state_dict(), 7204)
+    net = net.cuda().eval()
+    imgs, pm, dv = S.model_inputs(V, H, W, nd, 7204)
+    args = (dev(imgs), {k: dev(v) for k, v in pm.items()}, dev(dv))
+    ops.set_conv_precision("h16")
+    try:
+        outs = {}
+        for graph in (False, True):
+            for cl8 in (True, False):
+                set_kernel(monkeypatch, "slice_graph", graph)
+                set_kernel(monkeypatch, "corr_cl8", cl8)
+                ops.dispatch_counts.clear()
+                with torch.no_grad():
+                    for _ in range(3 if graph else 1):
+                        o = net(*args)
+                torch.cuda.synchronize()
+                assert (ops.dispatch_counts.get("weighted_corr_cl8", 0) > 0) == cl8
+                outs[(graph, cl8)] = [o[s][k].clone() for s in ("stage1", "stage2", "stage3") for k in ("depth", "photometric_confidence")]
+    finally:
+        ops.set_conv_precision(None)
+    base = outs[(False, False)]
+    for key, val in outs.items():
+        assert all(torch.equal(a, b) for a, b in zip(base, val)), key
