@@ -486,6 +486,9 @@ const char* gru_build_flags() {
 #if D3D_GRU_WAVES2 != 4
            " D3D_GRU_WAVES2"
 #endif
+#if defined(D3D_GRU2_TY) && D3D_GRU2_TY != 4
+           " D3D_GRU2_TY"
+#endif
         ;
 }
 
@@ -520,7 +523,15 @@ extern "C" int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI,
         if (CP == 16) return launch_gru<16, 8, 1, 4, 8>(p, st);
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }
-    if (stride == 2 && HID == 16 && CP == 8) return launch_gru<8, 16, 2, 4, 4>(p, st);
+#ifndef D3D_GRU2_TY
+#define D3D_GRU2_TY 4   // tile rows of the stride-2 cell.  OPEN LEAD (round 5): 8-row tiles are 10 - 24 % faster (the 2 x stride input patch
+                        // makes the halo expensive: 129 x 17 input pixels per 56 x 4 outputs = 2.45 x, 129 x 25 per 56 x 8 = 1.8 x) -- 20.1 ->
+                        // 15.3 / 57.2 -> 49.4 / 175.5 -> 158.5 us at the three stages, tools/cl8_cell_bench.py -- but NOT bit-identical to
+                        // the three launches: with more than two core tasks per wave (TY = 6 | 8) the middle tasks' second pixel of every
+                        // quad is wrong in output channels 12 - 15, a little differently from run to run (tools/gru2_debug.py); no spill,
+                        // not the prefetch, not addresses beyond 64 KB.  Unresolved: production stays at 4.
+#endif
+    if (stride == 2 && HID == 16 && CP == 8) return launch_gru<8, 16, 2, 4, D3D_GRU2_TY>(p, st);
     set_error("d3d_gru_cell_fused_h16: C = %d, hidden = %d, stride = %d not taken (8 | 16 | 32 -> 8 at stride 1; 8 -> 16 at stride 2)", CP, HID, stride);
     return D3D_ERR_UNSUPPORTED;
 }

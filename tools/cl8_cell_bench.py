@@ -37,4 +37,12 @@ for tag, C, D, sc in (("stage1", 32, 48, 4), ("stage2", 16, 32, 2), ("stage3", 8
     out = torch.empty_like(h0)
     c_planar = timeit(lambda: ops.gru_cell_conv_fused(planar[D // 2], h0, w1, wg, bg, wc, bc, 1, out=out))
     c_cl8 = timeit(lambda: ops.gru_cell_conv_fused(cl8[D // 2], h0, w1, wg, bg, wc, bc, 1, out=out))
+    s1 = dev(rng.standard_normal((8, h, w)))
+    h2 = dev(rng.standard_normal((16, h // 2, w // 2)))
+    w2 = dev(rng.standard_normal((16, 8, 3, 3)) / 8.5)
+    wg2, bg2 = dev(rng.standard_normal((32, 32, 3, 3)) / 17.0), dev(rng.standard_normal(32))
+    wc2, bc2 = dev(rng.standard_normal((16, 32, 3, 3)) / 17.0), dev(rng.standard_normal(16))
+    out2 = torch.empty_like(h2)
+    c2 = timeit(lambda: ops.gru_cell_conv_fused(s1, h2, w2, wg2, bg2, wc2, bc2, 2, out=out2))
+    print("%s   stride-2 cell (8 -> 16 at %dx%d): %.1f us" % (tag, h // 2, w // 2, c2 * 1e3), flush=True)
     print("%s C=%d D=%d %dx%d: sweep planar %.3f ms, CL8 %.3f ms | cell planar %.1f us, CL8 %.1f us" % (tag, C, D, h, w, t_planar, t_cl8, c_planar * 1e3, c_cl8 * 1e3), flush=True)
