@@ -49,6 +49,7 @@ KERNELS = {
     "pair_streams": "the per-pair visibility passes of AdaMVS's first stage on three HIP streams (independent pairs; one stream instead)",
     "fpn_streams": "the feature pyramids of a view set on three HIP streams (the images are independent; one stream instead)",
     "hand_over": "record_stream on tensors that cross the streams of a multi-stream forward (measurement only: off is unsafe with two forwards in flight)",
+    "convt_wide": "RED-Net's 64 -> 32 transposed layer as the wide stride-1 tile kernel over the zero-stuffed input (round-1 stream kernel instead)",
     "corr_cl8": "AdaMVS's weighted-correlation volume written by the sweep as CL8 16-bit cells and staged by the fused conv-GRU cell with 16-byte loads (planar fp32 volume instead)",
     "slice_graph": "AdaMVS's slice loop of a stage as ONE captured HIP graph of three chains on three streams -- cell 1 of slice d + 2, cell 2 of slice d + 1, head / regression of slice d in flight together (the serial launch loop instead)",
     "red_streams": "the four conv-GRU levels of a RED-Net depth slice on four HIP streams (they depend on the encoder only; one stream instead)",

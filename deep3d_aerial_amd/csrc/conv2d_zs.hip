@@ -1237,6 +1237,16 @@ static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const 
         if (f32) return Co > 32 ? launch_z2<48, 3, 2, true>(p, st) : Co > 16 ? launch_z2<48, 2, 2, true>(p, st) : launch_z2<48, 1, 2, true>(p, st);
         return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);
     }
+    if (Ci == 32 && Co <= 64 && W % 4 == 0 && prec == PREC_BF16) {
+        // RED-Net's conv3 (msrednet.py:346: ConvReLU(32, 64, stride 2) at the third level of a slice -- 172 x 116 pixels and up): 32-channel
+        // cells leave no room for a stride-2 patch either; the stride-1 tile kernel with a subsampled store again (three quarters of its
+        // products are dropped, at these image sizes the layer is latency: 87 us on the round-1 stream kernel, 88 calls per view)
+        Z2Params p = {};
+        p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
+        p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.sub2 = 1;
+        hipStream_t st = (hipStream_t)stream;
+        return Co > 48 ? launch_z2<32, 4, 2>(p, st) : Co > 32 ? launch_z2<32, 3, 2>(p, st) : Co > 16 ? launch_z2<32, 2, 2>(p, st) : launch_z2<32, 1, 2>(p, st);
+    }
     // (two 65 x 17 patches must fit the LDS: bf16 cells up to C_in = 16, fp32 cells C_in = 8)
     if ((Ci != 8 && (Ci != 16 || f32)) || Co > 32 || Wo % 4 != 0) {
         set_error("d3d_conv2d_k3s2_zs_%s: C_in = %d (8%s), C_out = %d (<= 32), output width %d (multiple of 4) not taken",

@@ -784,6 +784,7 @@ __device__ __forceinline__ GnAffine gn_fold(const double* __restrict__ stats, lo
 }
 
 // gates [2Hc,plane] -> r = sigmoid(gn_r(gates[:Hc])), u = sigmoid(gn_u(gates[Hc:])); rh = r*h (module.py:71-82,85)
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru2_gates_kernel(const float* __restrict__ gates, const double* __restrict__ st_r,
                                                           const double* __restrict__ st_u, const float* __restrict__ g_r,
                                                           const float* __restrict__ b_r, const float* __restrict__ g_u,
@@ -797,12 +798,13 @@ __global__ __launch_bounds__(256) void gru2_gates_kernel(const float* __restrict
     const GnAffine ar = gn_fold(st_r, n, eps), au = gn_fold(st_u, n, eps);
     const float rn = (gates[i] - ar.mean) * ar.rstd * g_r[c] + b_r[c];
     const float un = (gates[n + i] - au.mean) * au.rstd * g_u[c] + b_u[c];
-    const float r = gru_sigmoid_as<false>(rn);
+    const float r = gru_sigmoid_as<FAST>(rn);
     rh[i] = r * h[i];
-    u[i] = gru_sigmoid_as<false>(un);
+    u[i] = gru_sigmoid_as<FAST>(un);
 }
 
 // h' = u*h + (1-u)*tanh(gn_o(o))   (module.py:84-98)
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru2_update_kernel(const float* __restrict__ o, const double* __restrict__ st_o,
                                                            const float* __restrict__ g_o, const float* __restrict__ b_o,
                                                            const float* __restrict__ u, const float* __restrict__ h,
@@ -814,13 +816,14 @@ __global__ __launch_bounds__(256) void gru2_update_kernel(const float* __restric
     const GnAffine a = gn_fold(st_o, n, eps);
     const float on = (o[i] - a.mean) * a.rstd * g_o[c] + b_o[c];
     const float uu = u[i];
-    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh_as<false>(on);
+    h_out[i] = uu * h[i] + (1.0f - uu) * gru_tanh_as<FAST>(on);
 }
 
 // The two kernels above, four pixels of one channel per thread (plane % 4 == 0, 16-byte aligned tensors; grid.y = channel: no
 // division), the folded statistics -- an fp64 division and a square root -- evaluated by ONE thread of the workgroup instead of
 // every thread.  The same fp32 operations per element, in the same order.
 typedef float f4g __attribute__((ext_vector_type(4)));
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru2_gates_kernel4(const float* __restrict__ gates, const double* __restrict__ st_r,
                                                            const double* __restrict__ st_u, const float* __restrict__ g_r,
                                                            const float* __restrict__ b_r, const float* __restrict__ g_u,
@@ -846,13 +849,14 @@ __global__ __launch_bounds__(256) void gru2_gates_kernel4(const float* __restric
     for (int k = 0; k < 4; ++k) {
         const float rn = (vr[k] - aff[0]) * aff[1] * gr + br;
         const float un = (vu[k] - aff[2]) * aff[3] * gu + bu;
-        orh[k] = gru_sigmoid_as<false>(rn) * hv[k];
-        ou[k] = gru_sigmoid_as<false>(un);
+        orh[k] = gru_sigmoid_as<FAST>(rn) * hv[k];
+        ou[k] = gru_sigmoid_as<FAST>(un);
     }
     *reinterpret_cast<f4g*>(rh + i) = orh;
     *reinterpret_cast<f4g*>(u + i) = ou;
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru2_update_kernel4(const float* __restrict__ o, const double* __restrict__ st_o,
                                                             const float* __restrict__ g_o, const float* __restrict__ b_o,
                                                             const float* __restrict__ u, const float* __restrict__ h,
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(256) void gru2_update_kernel4(const float* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float on = (ov[k] - aff[0]) * aff[1] * go + bo;
-        out[k] = uv[k] * hv[k] + (1.0f - uv[k]) * gru_tanh_as<false>(on);
+        out[k] = uv[k] * hv[k] + (1.0f - uv[k]) * gru_tanh_as<FAST>(on);
     }
     *reinterpret_cast<f4g*>(h_out + i) = out;
 }
@@ -1101,31 +1105,31 @@ int d3d_groupnorm_stats(const float* x, int64_t n, int ngroups, double* stats, d
 
 int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* stats_u, const float* gamma_r,
                      const float* beta_r, const float* gamma_u, const float* beta_u, const float* h, int Hc,
-                     int64_t plane, float eps, float* rh, float* u, d3d_stream_t stream) {
+                     int64_t plane, float eps, int fast, float* rh, float* u, d3d_stream_t stream) {
     D3D_REQUIRE(gates && stats_r && stats_u && gamma_r && beta_r && gamma_u && beta_u && h && rh && u, "null pointer");
     D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
     const long n = (long)Hc * plane;
     if (plane % 4 == 0 && Hc <= 65535 && aligned16(gates) && aligned16(h) && aligned16(rh) && aligned16(u))
-        hipLaunchKernelGGL(gru2_gates_kernel4, dim3(ceil_div(plane / 4, 256), Hc), dim3(256), 0, (hipStream_t)stream, gates, stats_r,
-                           stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
+        hipLaunchKernelGGL(fast ? gru2_gates_kernel4<true> : gru2_gates_kernel4<false>, dim3(ceil_div(plane / 4, 256), Hc), dim3(256), 0,
+                           (hipStream_t)stream, gates, stats_r, stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
     else
-    hipLaunchKernelGGL(gru2_gates_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, gates, stats_r,
-                       stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
+        hipLaunchKernelGGL(fast ? gru2_gates_kernel<true> : gru2_gates_kernel<false>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           gates, stats_r, stats_u, gamma_r, beta_r, gamma_u, beta_u, h, Hc, (long)plane, eps, rh, u);
     D3D_LAUNCH_CHECK("gru2_gates_kernel launch");
     return D3D_OK;
 }
 
 int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* u,
-                      const float* h, int Hc, int64_t plane, float eps, float* h_out, d3d_stream_t stream) {
+                      const float* h, int Hc, int64_t plane, float eps, int fast, float* h_out, d3d_stream_t stream) {
     D3D_REQUIRE(o && stats_o && gamma && beta && u && h && h_out, "null pointer");
     D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
     const long n = (long)Hc * plane;
     if (plane % 4 == 0 && Hc <= 65535 && aligned16(o) && aligned16(u) && aligned16(h) && aligned16(h_out))
-        hipLaunchKernelGGL(gru2_update_kernel4, dim3(ceil_div(plane / 4, 256), Hc), dim3(256), 0, (hipStream_t)stream, o, stats_o, gamma,
-                           beta, u, h, Hc, (long)plane, eps, h_out);
+        hipLaunchKernelGGL(fast ? gru2_update_kernel4<true> : gru2_update_kernel4<false>, dim3(ceil_div(plane / 4, 256), Hc), dim3(256), 0,
+                           (hipStream_t)stream, o, stats_o, gamma, beta, u, h, Hc, (long)plane, eps, h_out);
     else
-    hipLaunchKernelGGL(gru2_update_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, o, stats_o, gamma,
-                       beta, u, h, Hc, (long)plane, eps, h_out);
+        hipLaunchKernelGGL(fast ? gru2_update_kernel<true> : gru2_update_kernel<false>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           o, stats_o, gamma, beta, u, h, Hc, (long)plane, eps, h_out);
     D3D_LAUNCH_CHECK("gru2_update_kernel launch");
     return D3D_OK;
 }

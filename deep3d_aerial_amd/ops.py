@@ -1214,7 +1214,8 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     bf16 = conv_precision() == "h16"
     x3 = not bf16 and _z2_fp32_entry() == "x3" and Ci != 48
-    wide = Ci == 48 and Co <= 48 and W % 4 == 0   # the pair-visibility UNet: the stride-1 kernel with a subsampled store
+    # the stride-1 kernel with a subsampled store: the pair-visibility UNet's 48 channels, RED-Net's 32 -> 64 layer (fast mode)
+    wide = ((Ci == 48 and Co <= 48) or (bf16 and Ci == 32 and Co <= 64)) and W % 4 == 0
     if not wide and (Ci not in ((8, 16) if bf16 or x3 else (8,)) or Co > 32 or Wo % 4) or act not in (0, 1) \
             or _cfg.off("conv2d_zs"):
         return None
@@ -1423,6 +1424,18 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
         y = conv2d_zs(z, wf, scale, shift, skip, act, skip_after_act=skip_after_act)
         if y is not None:
             return y
+    if Ci == 64 and Co in (32, 64) and conv_precision() == "h16" and _use_mfma() and act in (0, 1) and (skip is None or skip_after_act) \
+            and not _cfg.off("convt_wide") and H * W <= 512 * 512:
+        # RED-Net's upconv3 (msrednet.py:348: ConvTransReLU(64, 32) from the coarsest level, 86 x 58 pixels at stage 1): the same
+        # zero-stuffed form on the wide tile kernel (64 input channels in two chunks of 32; ReLU, then the skip: ConvTransReLU's
+        # order).  167 / 102 us per call on the round-1 stream kernel -- 12.6 ms of a 66 ms view
+        z = x.new_zeros((Ci, 2 * H, 2 * W))
+        z[:, ::2, ::2] = x
+        wf = derived_weight(weight, "t2flip", lambda w: w.flip(2, 3).transpose(0, 1))
+        y = conv2d_wide(z, wf, scale, shift, skip, act)
+        if y is not None:
+            dispatch_counts["convtranspose2d_wide"] += 1
+            return y
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:
@@ -1526,7 +1539,7 @@ def gru_gates_gn(gates, h, gamma_r, beta_r, gamma_u, beta_u, eps=1e-5, stats=Non
     u = torch.empty_like(h)
     rc = _lib.load().d3d_gru_gates_gn(_chk(gates, "gates"), _dptr(st_r), _dptr(st_u), _chk(gamma_r, "gamma_r"),
                                       _chk(beta_r, "beta_r"), _chk(gamma_u, "gamma_u"), _chk(beta_u, "beta_u"),
-                                      _chk(h, "h"), Hc, plane, float(eps), _chk(rh, "rh"), _chk(u, "u"), _stream())
+                                      _chk(h, "h"), Hc, plane, float(eps), int(conv_precision() == "h16"), _chk(rh, "rh"), _chk(u, "u"), _stream())
     _lib.check(rc, "d3d_gru_gates_gn")
     return rh, u
 
@@ -1538,7 +1551,7 @@ def gru_update_gn(o, u, h, gamma, beta, eps=1e-5, stats=None):
     st = groupnorm_stats(o) if stats is None else stats
     out = torch.empty_like(h)
     rc = _lib.load().d3d_gru_update_gn(_chk(o, "o"), _dptr(st), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(u, "u"),
-                                       _chk(h, "h"), Hc, plane, float(eps), _chk(out, "out"), _stream())
+                                       _chk(h, "h"), Hc, plane, float(eps), int(conv_precision() == "h16"), _chk(out, "out"), _stream())
     _lib.check(rc, "d3d_gru_update_gn")
     return out
 

@@ -644,13 +644,15 @@ int d3d_gru_update(const float* u, const float* h, const float* convc, int64_t n
  *     tensor are two segments of one call.
  *   d3d_gru_gates_gn:  r = sigmoid(gn_r(gates[:Hc])); u = sigmoid(gn_u(gates[Hc:])); rh = r*h.
  *   d3d_gru_update_gn: h' = u*h + (1-u)*tanh(gn_o(o)).
+ * fast (ABI 9): 0 = torch's own expressions (IEEE division, tanhf: the fp32 mode), 1 = the one-exp-one-rcp forms the h16 kernels
+ * use (about 2e-7 from the exact value; these launches are ~15 us each, 2816 of them per RED-Net view).
  */
 int d3d_groupnorm_stats(const float* x, int64_t n, int ngroups, double* stats, d3d_stream_t stream);
 int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* stats_u, const float* gamma_r,
                      const float* beta_r, const float* gamma_u, const float* beta_u, const float* h, int Hc,
-                     int64_t plane, float eps, float* rh, float* u, d3d_stream_t stream);
+                     int64_t plane, float eps, int fast, float* rh, float* u, d3d_stream_t stream);
 int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* u,
-                      const float* h, int Hc, int64_t plane, float eps, float* h_out, d3d_stream_t stream);
+                      const float* h, int Hc, int64_t plane, float eps, int fast, float* h_out, d3d_stream_t stream);
 
 /* ucsnet.py:137-151 (compute_depth of UCS-Net): d3d_softargmin_conf4 plus the spread of the per-pixel distribution,
  * var_out = lamb * sqrt(sum_d softmax(cost)_d * (depth_d - depth_out)^2)  [h,w]. */

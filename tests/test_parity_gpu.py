@@ -2187,7 +2187,7 @@ def test_gru_cell_bf16_tile_kernels_match_the_stream_kernels(ops, monkeypatch):
 
 
 @pytest.mark.parametrize("Ci,Co,H,W,act", [(8, 16, 16, 64, 1), (8, 16, 9, 72, 1), (16, 32, 33, 40, 0), (16, 8, 5, 16, 1), (8, 16, 70, 263, 1),
-                                           (8, 1, 12, 24, 0)])
+                                           (8, 1, 12, 24, 0), (32, 64, 43, 116, 1), (32, 64, 9, 8, 0), (32, 40, 30, 52, 1)])
 def test_conv2d_stride2_tile_kernel_bf16(ops, oracle, bf16_mode, Ci, Co, H, W, act):
     """d3d_conv2d_k3s2_zs_h16 (adamvs.py:411 ConvReLU(8, 16, 3, 2, 1)): the fp32 oracle on bf16-rounded operands, bias, ReLU and
     a skip before / after the activation; odd sizes and ragged tiles included (output width a multiple of 4)."""
@@ -2204,8 +2204,9 @@ def test_conv2d_stride2_tile_kernel_bf16(ops, oracle, bf16_mode, Ci, Co, H, W, a
         y = conv + (0 if after else sk)
         y = np.maximum(y, 0) if act == 1 else y
         assert np.abs(host(got) - (y + (sk if after else 0))).max() <= 2 * tol, after
-    assert ops.conv2d_s2_zs(dev(x[:, :, :W - 2]), dev(w), None, dev(b), None, act) is None or ((W - 3) // 2 + 1) % 4 == 0   # ragged widths: not taken
-    assert ops.conv2d_s2_zs(dev(np.zeros((32, 8, 16), np.float32)), dev(np.zeros((8, 32, 3, 3), np.float32))) is None       # C_in = 32: not taken
+    if Ci != 32:   # (32 channels run on the stride-1 kernel with a subsampled store: any width that is a multiple of 4)
+        assert ops.conv2d_s2_zs(dev(x[:, :, :W - 2]), dev(w), None, dev(b), None, act) is None or ((W - 3) // 2 + 1) % 4 == 0   # ragged widths: not taken
+    assert ops.conv2d_s2_zs(dev(np.zeros((24, 8, 16), np.float32)), dev(np.zeros((8, 24, 3, 3), np.float32))) is None       # C_in = 24: not taken
 
 
 @pytest.mark.parametrize("Ci,Co,H,W,act", [(16, 8, 8, 32, 1), (16, 8, 9, 36, 1), (8, 1, 17, 68, 0), (32, 16, 5, 8, 1), (16, 8, 40, 132, 1),
@@ -2698,3 +2699,19 @@ def test_adamvs_cl8_correlation_volume_is_the_planar_forward(ops, monkeypatch):
     base = outs[(False, False)]
     for key, val in outs.items():
         assert all(torch.equal(a, b) for a, b in zip(base, val)), key
+
+
+@pytest.mark.parametrize("Co,H,W", [(32, 43, 29), (32, 86, 58), (64, 9, 12), (32, 1, 1)])
+def test_transposed_64_channels_as_the_wide_convolution_of_the_zero_stuffed_input(ops, oracle, bf16_mode, Co, H, W):
+    """ops.convtranspose2d_k3s2 at 64 input channels in the fast mode (RED-Net's upconv3, msrednet.py:348): the wide stride-1 tile
+    kernel over the zero-stuffed input with the flipped kernel, against the oracle's transposed convolution on rounded operands;
+    ReLU, then the skip (ConvTransReLU's order)."""
+    rng = np.random.default_rng(H * 5 + W + Co)
+    x = rng.standard_normal((64, H, W)).astype(np.float32)
+    w = (0.05 * rng.standard_normal((64, Co, 3, 3))).astype(np.float32)
+    sk = rng.standard_normal((Co, 2 * H, 2 * W)).astype(np.float32)
+    want = np.maximum(oracle.convtranspose2d_k3s2(_h16_round(x), _h16_round(w), None), 0) + sk
+    ops.dispatch_counts.clear()
+    got = ops.convtranspose2d_k3s2(dev(x), dev(w), None, None, dev(sk), skip_after_act=True, act=1)
+    assert ops.dispatch_counts.get("convtranspose2d_wide", 0) == 1
+    assert np.abs(host(got) - want).max() <= 6e-5 * max(1.0, np.abs(want).max())

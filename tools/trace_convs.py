@@ -20,7 +20,7 @@ def wrap(name):
     setattr(ops, name, g)
 for n in ("conv_k3_mfma", "convtranspose_k3s2_mfma", "conv_fold", "conv2d_stream", "conv2d_zs", "conv2d_s2_zs", "convtranspose2d_zs", "conv2d_same", "conv1x1_upskip"):
     if hasattr(ops, n): wrap(n)
-net = predict.build_model("adamvs", 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
+net = predict.build_model(os.environ.get("TRACE_MODEL", "adamvs"), 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
 s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
 imgs = torch.from_numpy(s["imgs"])[None].cuda(); pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}; dv = torch.from_numpy(s["depth_values"])[None].cuda()
 ops.set_conv_precision(os.environ.get("TRACE_PRECISION", "h16"))
