@@ -106,8 +106,15 @@ class InferDepthNet(nn.Module):
         for b in range(B):
             feats = [f[b].contiguous() for f in features]
             p34 = ops.compose_projections(proj_matrices[b].contiguous())
-            dvb = depth_values[b]
+            dvb = depth_values[b].contiguous()
             dev = feats[0].device
+            loop = RedLoopGraph.get(cost_regularization, C, h, w, num_depth, dvb)
+            if loop is not None and loop.usable():   # the slice loop as one captured HIP graph (RedLoopGraph)
+                ops.variance_volume(feats, p34, dvb, out=loop.buffers().var, plane_major=True)
+                dep, conf = ops.online_regress_finalize(*loop.run(dvb))
+                depths.append(dep)
+                confs.append(conf)
+                continue
             states = [torch.zeros((8 << i, h >> i, w >> i), dtype=torch.float32, device=dev) for i in range(4)]
             max_p = torch.zeros((h, w), dtype=torch.float32, device=dev)
             sum_d = torch.zeros_like(max_p)
@@ -115,7 +122,7 @@ class InferDepthNet(nn.Module):
             # The reference warps plane by plane (msrednet.py:400-414) because it holds one slice at a time; the
             # whole variance volume of a stage is at most 2.6 GB here, so it is swept in ONE fused launch and the
             # recurrent regulariser then walks its depth slices.
-            var = ops.variance_volume(feats, p34, dvb.contiguous(), plane_major=True)  # [D,C,h,w]: a slice is one contiguous block
+            var = ops.variance_volume(feats, p34, dvb, plane_major=True)  # [D,C,h,w]: a slice is one contiguous block
             for d in range(num_depth):
                 if dvb.dim() == 1:   # [D] uniform planes: a [1,1] map (the update resamples it to the image, a constant)
                     dplane = dvb[d:d + 1].view(1, 1)
@@ -127,6 +134,122 @@ class InferDepthNet(nn.Module):
             depths.append(dep)
             confs.append(conf)
         return {"depth": torch.stack(depths), "photometric_confidence": torch.stack(confs)}
+
+
+class RedLoopGraph(object):
+    """The slice loop of one RED-Net cascade stage (msrednet.py:400-437: D times the four-level conv-GRU encoder-decoder and the
+    online regression update, ~33 launches per slice) captured once as a HIP graph and replayed per reference view.
+
+    Why: a RED-Net view is ~2 900 launches of 10 - 90 us kernels; the host thread, not the card, paces it (22 us per launch;
+    taking 9 ms of kernel time out of it did not move the view -- DESIGN.md 4.3).  Captured, the host issues one graph launch per
+    stage.  What is captured is the forward as it runs eagerly, including the four-stream form of a slice
+    (slice_RED_Regularization.forward: ops.side_streams / events / ops.hand_over -- tensors that cross streams are recorded, which
+    keeps the capture's allocator from handing their blocks to another stream before the capture ends), the GroupNorm slot arenas
+    (created and zeroed INSIDE the capture, per captured stream: every replay zeroes them again) and the zeroing of the states and
+    accumulators.  Static inputs: the variance volume [D,C,h,w] (the sweep writes it in place) and the hypotheses (copied in).
+    Same kernels, same operands as the eager loop; equal to it to the order of the fp64 atomics of the GroupNorm statistics
+    (tests/test_parity_gpu.py::test_msrednet_loop_graph_is_the_eager_loop).  Same protocol as adamvs.SliceLoopGraph: first call of
+    a shape eager, second captures (after one eager slice that prepares what first-use code would), main thread only, a failed
+    capture raises (D3D_KERNELS_OFF=red_graph)."""
+
+    _cache = {}
+    _lock = __import__("threading").Lock()
+    MAX_GRAPHS = 12
+
+    @classmethod
+    def get(cls, cr, C, h, w, D, dvb):
+        import threading
+
+        if (not dvb.is_cuda or ops.conv_precision() != "h16" or _cfg.off("red_graph") or D < 4 or torch.cuda.is_current_stream_capturing()
+                or threading.current_thread() is not threading.main_thread()):
+            return None
+        dev = dvb.device
+        key = (id(cr), C, h, w, D, tuple(dvb.shape), dev.index, torch.cuda.current_stream(dev).cuda_stream, ops.h16_dtype(),
+               tuple(sorted(_cfg.switches.items())))
+        with cls._lock:
+            for k in [k for k, v in cls._cache.items() if v.cr() is None]:
+                del cls._cache[k]
+            g = cls._cache.get(key)
+            if g is None or g.cr() is not cr:
+                if len(cls._cache) >= cls.MAX_GRAPHS:
+                    cls._cache.pop(next(iter(cls._cache)))
+                g = cls._cache[key] = cls(cr, C, h, w, D, dvb)
+        return g
+
+    def __init__(self, cr, C, h, w, D, dvb):
+        import weakref
+
+        self.cr = weakref.ref(cr)
+        self.C, self.h, self.w, self.D, self.dev = C, h, w, D, dvb.device
+        self.dv_shape = tuple(dvb.shape)
+        self.calls, self.graph, self.counts, self.wkey, self.failed, self.var = 0, None, None, None, None, None
+
+    def usable(self):
+        k = tuple((p.data_ptr(), p._version) for p in self.cr().parameters())
+        if k != self.wkey:
+            self.wkey, self.calls, self.graph = k, 0, None
+        self.calls += 1
+        return self.calls >= 2 and self.failed is None
+
+    def buffers(self):
+        if self.var is None:
+            f32, dev = torch.float32, self.dev
+            self.var = torch.empty((self.D, self.C, self.h, self.w), dtype=f32, device=dev)
+            self.dv = torch.empty(self.dv_shape, dtype=f32, device=dev)
+            self.max_p = torch.empty((self.h, self.w), dtype=f32, device=dev)
+            self.sum_d, self.sum_p = torch.empty_like(self.max_p), torch.empty_like(self.max_p)
+            self.stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(self.stream):     # the captured forward's side streams exist before the capture begins
+                self.side = ops.side_streams(dev, 3, "red")
+        return self
+
+    def _dplane(self, d):
+        return self.dv[d:d + 1].view(1, 1) if self.dv.dim() == 1 else self.dv[d]
+
+    def _zero_states(self):
+        return [torch.zeros((8 << i, self.h >> i, self.w >> i), dtype=torch.float32, device=self.dev) for i in range(4)]
+
+    def _capture(self):
+        cr = self.cr()
+        before = dict(ops.dispatch_counts)
+        states = self._zero_states()          # one eager slice first: packed weights, LDS attributes, slot arenas of the eager streams
+        reg, *states = cr(self.var[0], *states)
+        ops.online_regress_update(reg[0], self._dplane(0), self.max_p, self.sum_d, self.sum_p)
+        del reg, states
+        ops.dispatch_counts.clear()
+        ops.dispatch_counts.update(before)
+        graph = torch.cuda.CUDAGraph()
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        for st in [self.stream] + list(self.side):   # the captured streams' GroupNorm slot arenas are born (and zeroed) in the capture
+            ops._gn_arenas.pop((self.dev.index, st.cuda_stream), None)
+        with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+            states = self._zero_states()
+            self.max_p.zero_(); self.sum_d.zero_(); self.sum_p.zero_()
+            for d in range(self.D):
+                reg, *states = cr(self.var[d], *states)
+                ops.online_regress_update(reg[0], self._dplane(d), self.max_p, self.sum_d, self.sum_p)
+            del reg, states
+        after = dict(ops.dispatch_counts)
+        self.counts = {k: v - before.get(k, 0) for k, v in after.items() if v != before.get(k, 0)}
+        for k, v in self.counts.items():
+            ops.dispatch_counts[k] -= v
+        self.graph = graph
+
+    def run(self, dvb):
+        if self.graph is None:
+            with RedLoopGraph._lock:
+                try:
+                    self._capture()
+                except Exception as e:
+                    self.failed = repr(e)[:300]
+                    raise RuntimeError("capturing RED-Net's slice loop as a HIP graph failed (%s); run with D3D_KERNELS_OFF=red_graph"
+                                       % self.failed) from e
+                torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+        self.dv.copy_(dvb)
+        self.graph.replay()
+        for k, v in self.counts.items():
+            ops.dispatch_counts[k] += v
+        return self.max_p, self.sum_d, self.sum_p
 
 
 class Infer_CascadeREDNet(nn.Module):

@@ -2627,6 +2627,49 @@ def test_adamvs_slice_graph_is_the_serial_loop(ops, monkeypatch):
     assert not torch.equal(fresh[0], outs[0][4]) and all(torch.equal(fresh[0], f) for f in fresh[1:])
 
 
+def test_msrednet_loop_graph_is_the_eager_loop(ops, monkeypatch):
+    """The slice loop of a RED-Net stage captured as one HIP graph (msrednet.RedLoopGraph: the four-stream slice, the GroupNorm
+    slot arenas and the zeroing of the states all inside the capture; first call of a shape eager, second captures, later ones
+    replay) runs the eager loop's kernels on the eager loop's operands.  The GroupNorm statistics are fp64 atomic sums, so two
+    runs agree to the order of those additions (as two eager runs do): relative L1 <= 1e-6 on the depth maps -- on the capturing
+    call, on replays (the arenas are zeroed again by the graph: a stale slot would be off by a factor), with the switch off, and
+    after new weights have been loaded.  The kernels counted are the same."""
+    from deep3d_aerial_amd.msrednet import Infer_CascadeREDNet, RedLoopGraph
+
+    V, H, W, nd = 3, 256, 384, 96
+    net = Infer_CascadeREDNet(num_depth=nd)
+    S.fill_state_dict_(net.state_dict(), 7301)
+    net = net.cuda().eval()
+    imgs, pm, dv = S.model_inputs(V, H, W, nd, 7301)
+    args = (dev(imgs), {k: dev(v) for k, v in pm.items()}, dev(dv))
+    keys = [(s, k) for s in ("stage1", "stage2", "stage3") for k in ("depth", "photometric_confidence")]
+    ops.set_conv_precision("h16")
+    try:
+        outs, counts = [], []
+        for on in (True, True, True, False, True):   # eager (first call of the shapes), capture + replay, replay, switched off, replay
+            set_kernel(monkeypatch, "red_graph", on)
+            ops.dispatch_counts.clear()
+            with torch.no_grad():
+                o = net(*args)
+            torch.cuda.synchronize()
+            outs.append([host(o[s][k]) for s, k in keys])
+            counts.append(dict(ops.dispatch_counts))
+        assert all(c == counts[0] for c in counts[1:]), counts
+        for (s, k), per_output in zip(keys, zip(*outs)):
+            for i, o in enumerate(per_output[1:]):
+                assert rel_l1(o, per_output[0]) <= (1e-6 if k == "depth" else 1e-5), (s, k, i + 1)
+        assert sum(g.graph is not None for g in RedLoopGraph._cache.values()) >= 3   # the three stages were captured
+        S.fill_state_dict_(net.state_dict(), 98)   # new weights in place, as load_state_dict does: the graphs start over
+        fresh = []
+        for on in (False, True, True, True):
+            set_kernel(monkeypatch, "red_graph", on)
+            with torch.no_grad():
+                fresh.append(host(net(*args)["depth"]))
+        assert rel_l1(fresh[0], outs[0][4]) > 1e-4 and all(rel_l1(f, fresh[0]) <= 1e-6 for f in fresh[1:])
+    finally:
+        ops.set_conv_precision(None)
+
+
 @pytest.mark.parametrize("V,C,h,w,D,kind", [(5, 32, 44, 72, 12, "plane"), (5, 16, 70, 100, 8, "affine"), (3, 8, 96, 132, 8, "pixel"),
                                             (4, 32, 37, 52, 5, "pixel")])
 def test_weighted_corr_cl8_is_the_rounded_planar_volume(ops, V, C, h, w, D, kind):

@@ -18,7 +18,7 @@ def wrap(name):
             e1.record(); torch.cuda.synchronize(); ms[key] += e0.elapsed_time(e1)
         return y
     setattr(ops, name, g)
-for n in ("conv_k3_mfma", "convtranspose_k3s2_mfma", "conv_fold", "conv2d_stream", "conv2d_zs", "conv2d_s2_zs", "convtranspose2d_zs", "conv2d_same", "conv1x1_upskip"):
+for n in ("conv_k3_mfma", "convtranspose_k3s2_mfma", "conv_fold", "conv2d_stream", "conv2d_zs", "conv2d_s2_zs", "convtranspose2d_zs", "conv2d_same", "conv1x1_upskip", "conv2d_wide"):
     if hasattr(ops, n): wrap(n)
 net = predict.build_model(os.environ.get("TRACE_MODEL", "adamvs"), 384); S.fill_state_dict_(net.state_dict(), 1); net = net.cuda().eval()
 s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
