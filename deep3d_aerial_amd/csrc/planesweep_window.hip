@@ -51,6 +51,12 @@ constexpr int window_lds_bytes(int MODE, int CH) { return window_big(MODE, CH) ?
 #ifndef D3D_WINDOW_DSEG
 #define D3D_WINDOW_DSEG 32
 #endif
+#ifndef D3D_WINDOW_RPW
+#define D3D_WINDOW_RPW 0   // window rows per wave and view in one staging batch (0: the built-in choice)
+#endif
+#ifndef D3D_WINDOW_VB
+#define D3D_WINDOW_VB 0    // views whose rows are requested together in one staging batch (0 = 1: view by view)
+#endif
 constexpr int WDSEG_MAX = D3D_WINDOW_DSEG;   // planes per workgroup segment (upper bound)
 constexpr int WTAB = 2 * WDSEG_MAX + 32;   // floats: per-plane depth range of the patch (pmin, pmax) + the views' translations (4 each)
 constexpr int WTOFF = 2 * WDSEG_MAX;      // where the translations start
@@ -691,58 +697,84 @@ __global__ __launch_bounds__(64 * window_waves(MODE, CH), !window_big(MODE, CH) 
                     // address registers -- and a lane or row outside the image gets an offset beyond the buffer, for which the hardware
                     // returns zeros: no clamps, no selects.  The loads of RPW rows (4 x Q x RPW per lane) are issued before the first
                     // 16-byte LDS write; the other workgroup of the CU sweeps meanwhile.
-                    constexpr int RPW = Q > 2 ? 1 : (PH > 8 ? 3 : 2);
+                    // Views per batch (VB): round 5 measured requesting the rows of SEVERAL views' windows before the first LDS write of a
+                    // batch (one memory round trip per batch instead of one per view).  The extra descriptors / offsets in flight push the
+                    // kernel over its 128 registers (80 - 180 bytes of scratch per lane, reloaded in the plane loop): stage 1 1.68 -> 2.28 ms
+                    // with all four views, 1.94 with two; and halving the rows per batch (twice the round trips) costs only 5 % -- the staging
+                    // is not a latency chain.  View by view stays (profiles/r05_window_staging.txt).
+                    constexpr int VB = D3D_WINDOW_VB > 0 ? (D3D_WINDOW_VB < NSRC ? D3D_WINDOW_VB : NSRC) : 1;
+                    constexpr int RPW = D3D_WINDOW_RPW > 0 ? D3D_WINDOW_RPW : (Q > 2 ? 1 : (VB > 2 ? 1 : (PH > 8 ? 3 : 2)));
                     constexpr int OOB = 0x7ffffff0;   // (launch check: C * h * w * 4 < 2^31, so any offset from here on is out of range)
                     const int fbytes = p.C * (int)plane * 4;
 #pragma unroll
                     for (int i = 0; i < NSRC; ++i) {
-#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSTAGE)   // timing only (results wrong): the sweep without its staging
-                        if (p.n_src < 100) continue;
-#endif
-                        if (i >= p.n_src) {   // the zero cells of an unused view
+                        if (i >= p.n_src)   // the zero cells of an unused view
                             for (int idx = tid; idx < 4 * Q; idx += WTHREADS) lds_write4_abs(W[i].base + idx * 16, (f4){0, 0, 0, 0});
-                            continue;
+                    }
+#pragma unroll
+                    for (int i0 = 0; i0 < NSRC; i0 += VB) {
+                        int maxw = 0, maxh = 0;
+#pragma unroll
+                        for (int i = i0; i < i0 + VB && i < NSRC; ++i) {
+                            if (i < p.n_src) {
+                                maxw = max(maxw, W[i].ww);
+                                maxh = max(maxh, W[i].wh);
+                            }
                         }
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats[i + 1]), 0, fbytes, 0x00020000);
-                        for (int col0 = 0; col0 < W[i].ww; col0 += 64) {   // (windows wider than 64 cells: rare)
+#if defined(D3D_EXPERIMENTS) && defined(D3D_WX_NOSTAGE)   // timing only (results wrong): the sweep without its staging
+                        if (p.n_src < 100) maxw = 0;
+#endif
+                        for (int col0 = 0; col0 < maxw; col0 += 64) {   // (windows wider than 64 cells: rare)
                             const int col = col0 + lane;
-                            const int sx = W[i].wx0 + col;
-                            const bool colin = col < W[i].ww;
-                            const int voff = (colin && sx >= 0 && sx < w) ? sx * 4 : OOB;
-                            const int cadr = W[i].base + col * 16;
-                            for (int row0 = wave; row0 < W[i].wh; row0 += RPW * WWAVES) {
-                                f4 v[RPW][Q];
+                            for (int row0 = wave; row0 < maxh; row0 += RPW * WWAVES) {
+                                f4 v[VB][RPW][Q];
 #pragma unroll
-                                for (int r = 0; r < RPW; ++r) {
-                                    const int sy = W[i].wy0 + min(row0 + r * WWAVES, W[i].wh - 1);
-                                    const bool yin = sy >= 0 && sy < h;
-                                    // rows outside the image: the out-of-range marker travels in the VECTOR offset, which the hardware
-                                    // range-checks against num_records (zeros come back); the scalar offset is documented as excluded
-                                    // from that check, so it always stays inside the buffer
-                                    const int roff = yin ? (c0 * (int)plane + sy * w) * 4 : 0;
-                                    const int pb = yin ? (int)plane * 4 : 0;
-                                    const int vo = yin ? voff : OOB;
+                                for (int i = i0; i < i0 + VB && i < NSRC; ++i) {
+                                    if (i >= p.n_src) continue;
+                                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.feats[i + 1]), 0, fbytes, 0x00020000);
+                                    const int sx = W[i].wx0 + col;
+                                    const int voff = (col < W[i].ww && sx >= 0 && sx < w) ? sx * 4 : OOB;
 #pragma unroll
-                                    for (int q = 0; q < Q; ++q)
+                                    for (int r = 0; r < RPW; ++r) {
+                                        const int sy = W[i].wy0 + min(row0 + r * WWAVES, W[i].wh - 1);
+                                        const bool yin = sy >= 0 && sy < h;
+                                        // rows outside the image: the out-of-range marker travels in the VECTOR offset, which the hardware
+                                        // range-checks against num_records (zeros come back); the scalar offset is documented as excluded
+                                        // from that check, so it always stays inside the buffer
+                                        const int roff = yin ? (c0 * (int)plane + sy * w) * 4 : 0;
+                                        const int pb = yin ? (int)plane * 4 : 0;
+                                        const int vo = yin ? voff : OOB;
 #pragma unroll
-                                        for (int c = 0; c < 4; ++c)
-                                            v[r][q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, roff + (4 * q + c) * pb, 0));
+                                        for (int q = 0; q < Q; ++q)
+#pragma unroll
+                                            for (int c = 0; c < 4; ++c)
+                                                v[i - i0][r][q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, roff + (4 * q + c) * pb, 0));
+                                    }
                                 }
 #pragma unroll
-                                for (int r = 0; r < RPW; ++r) {
-                                    const int row = row0 + r * WWAVES;
-                                    if (row < W[i].wh && colin) {
+                                for (int i = i0; i < i0 + VB && i < NSRC; ++i) {
+                                    if (i >= p.n_src) continue;
+                                    const int cadr = W[i].base + col * 16;
 #pragma unroll
-                                        for (int q = 0; q < Q; ++q) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[r][q]);
+                                    for (int r = 0; r < RPW; ++r) {
+                                        const int row = row0 + r * WWAVES;
+                                        if (row < W[i].wh && col < W[i].ww) {
+#pragma unroll
+                                            for (int q = 0; q < Q; ++q) lds_write4_abs(cadr + q * W[i].qb + row * W[i].rowb, v[i - i0][r][q]);
+                                        }
                                     }
                                 }
                                 // every load of the batch is consumed here, written or not: a load left pending would be waited for
                                 // where its register is next overwritten -- inside the plane loop, on the counter that also counts the
                                 // planes' stores
 #pragma unroll
-                                for (int r = 0; r < RPW; ++r)
+                                for (int i = i0; i < i0 + VB && i < NSRC; ++i) {
+                                    if (i >= p.n_src) continue;
 #pragma unroll
-                                    for (int q = 0; q < Q; ++q) asm volatile("" : : "v"(v[r][q]));
+                                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                                        for (int q = 0; q < Q; ++q) asm volatile("" : : "v"(v[i - i0][r][q]));
+                                }
                             }
                         }
                     }
@@ -944,6 +976,12 @@ const char* window_build_flags() {
 #endif
 #if D3D_WINDOW_DSEG != 32
            " D3D_WINDOW_DSEG"
+#endif
+#if D3D_WINDOW_RPW != 0
+           " D3D_WINDOW_RPW"
+#endif
+#if D3D_WINDOW_VB != 0
+           " D3D_WINDOW_VB"
 #endif
 #ifdef D3D_CL_PARTIAL_DEFAULT_POLICY
            " D3D_CL_PARTIAL_DEFAULT_POLICY"
