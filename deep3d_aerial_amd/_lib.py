@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("D3D_LIBRARY") or os.path.join(CSRC, "libdeep3d_planesweep.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deep3d_planesweep.h")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -82,6 +82,7 @@ SIGNATURES = {
     "d3d_convtranspose3d_k3s2_cl_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "d3d_conv2d_k3_zs_h16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
     "d3d_conv2d_k3_wide_h16_gn": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "d3d_convtranspose2d_k3s2_wide_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3_pair3_bf16x3": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "d3d_slice_tail_regress_h16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_conv3d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
@@ -105,6 +106,8 @@ SIGNATURES = {
     "d3d_groupnorm_stats": [_vp, _i64, _i, _vp, _vp],
     "d3d_gru_gates_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp, _vp],
     "d3d_gru_update_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp],
+    "d3d_gru_reset_gn": [_vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp],
+    "d3d_gru_update_gates_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp],
     "d3d_softargmin_conf4_var": [_vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _vp, _vp],
     "d3d_uncertainty_samples": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "d3d_pair_softmax_max": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

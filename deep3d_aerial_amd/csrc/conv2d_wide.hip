@@ -48,6 +48,8 @@ struct WideParams {
     int act;              // 0 none | 1 ReLU
     double* gn;           // GN form: GroupNorm statistics of the output (gn_stats.h), zeroed by the caller; channels >= gn_split are group 1
     int gn_split;
+    int stuffed;          // 1: `in` is [CI, H/2, W/2] and stands for its zero-stuffed image (in at the even rows / columns, zeros elsewhere):
+                          // the stride-2 transposed convolution as a stride-1 one, without the stuffed tensor (d3d_convtranspose2d_k3s2_wide_h16)
 };
 
 __device__ __forceinline__ unsigned pack_h16_w(float a, float b) {
@@ -63,6 +65,7 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
+    const size_t iplane = p.stuffed ? (size_t)(H >> 1) * (W >> 1) : plane;   // a channel plane of the input
     const int x0 = blockIdx.x * WTX, y0 = blockIdx.y * WW;
     const int nt0 = blockIdx.z * NW;            // first output tile of this workgroup
     const int nchunk = p.CI / 32, nkb_tap = nchunk;   // K blocks per tap in the packed weights
@@ -84,6 +87,10 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
         const int gx = x0 + px - 1, gy = y0 + py - 1;
         pok[r] = task < NTASK && gx >= 0 && gx < W && gy >= 0 && gy < H;
         poff[r] = task < NTASK ? (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1) : 0;
+        if (p.stuffed) {   // odd rows / columns of the stuffed image are zeros; an even one is input pixel (gy / 2, gx / 2)
+            pok[r] = pok[r] && !((gx | gy) & 1);
+            poff[r] = task < NTASK ? (size_t)(min(max(gy, 0), H - 1) >> 1) * (W >> 1) + (min(max(gx, 0), W - 1) >> 1) : 0;
+        }
         pdst[r] = task < NTASK ? pix * WCS + g * 16 : -1;
         pg8[r] = 8 * g;
     }
@@ -92,9 +99,9 @@ __global__ __launch_bounds__(WNT, 2) void conv2d_wide_bf16_kernel(WideParams p) 
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             const int c = cbase + pg8[r];
-            const float* __restrict__ src = (c < p.C1 ? p.in + (size_t)c * plane : p.in2 + (size_t)(c - p.C1) * plane) + poff[r];
+            const float* __restrict__ src = (c < p.C1 ? p.in + (size_t)c * iplane : p.in2 + (size_t)(c - p.C1) * iplane) + poff[r];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) stg[r][k] = src[(size_t)k * plane];
+            for (int k = 0; k < 8; ++k) stg[r][k] = src[(size_t)k * iplane];
         }
     };
     auto commit = [&]() {
@@ -243,4 +250,24 @@ extern "C" int d3d_conv2d_k3_wide_h16_gn(const float* in, int C1, const float* i
                                           int Co, int H, int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream) {
     D3D_REQUIRE(gn_stats && gn_split > 0 && gn_split <= Co, "bad statistics arguments");
     return conv2d_k3_wide_bf16(in, C1, in2, C2, wpacked, nullptr, shift, nullptr, 0, Co, H, W, out, gn_stats, gn_split, stream);
+}
+
+// module.py:287-294 with 64 input channels (msrednet.py:348 upconv3): out [Co,2H,2W] = act(convT3x3_s2(in) * scale + shift) (+ skip, added
+// last) as the stride-1 convolution of the zero-stuffed input with the flipped, transposed kernel (wpacked = ops._pack_z2_bf16 of it)
+// -- the stuffed image exists only in the kernel's staging.  in [64,H,W]; Co = 32 | 64.
+extern "C" int d3d_convtranspose2d_k3s2_wide_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                                  const float* skip, int act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wpacked && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    if (Ci != 64 || (Co != 32 && Co != 64) || ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(skip)) & 15)) {
+        set_error("d3d_convtranspose2d_k3s2_wide_h16: C_in = %d (64), C_out = %d (32 | 64) with 16-byte aligned tensors not taken", Ci, Co);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    WideParams p = {};
+    p.in = in; p.in2 = nullptr; p.C1 = Ci; p.CI = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift;
+    p.skip = skip; p.out = out; p.H = 2 * H; p.W = 2 * W; p.CO = Co; p.NTN = Co / 16; p.act = act; p.stuffed = 1;
+    const long tiles = (long)ceil_div(p.W, WTX) * ceil_div(p.H, WW);
+    const bool four = p.NTN % 4 == 0 && tiles * (p.NTN / 4) >= 512;
+    return four ? launch_wide<4>(p, (hipStream_t)stream) : launch_wide<2>(p, (hipStream_t)stream);
 }

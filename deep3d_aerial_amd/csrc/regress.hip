@@ -882,6 +882,97 @@ __global__ __launch_bounds__(256) void gru2_update_kernel4(const float* __restri
     *reinterpret_cast<f4g*>(h_out + i) = out;
 }
 
+
+// Round 5: the cell in three passes over 104 channel planes instead of 128.  The reset half alone -- rh = sigmoid(gn_r(gates[:Hc])) * h
+// -- and the update gate evaluated where it is used: h' = u*h + (1-u)*tanh(gn_o(o)) with u = sigmoid(gn_u(gates[Hc:])) computed from
+// the pre-norm gate in the update pass (one plane read either way) instead of being written by one kernel and read by the next.
+// Per element the fp32 operations of the two kernels above, in their order: the same bits.  A thread takes up to GRU2_F4 quads a
+// workgroup-stride apart, so the folded statistics (an fp64 division and a square root on one thread, a barrier) are paid once
+// per 4096 elements instead of once per 1024.
+constexpr int GRU2_F4 = 4;
+template <bool FAST>
+__global__ __launch_bounds__(256) void gru2_reset_kernel4(const float* __restrict__ gates, const double* __restrict__ st_r,
+                                                           const float* __restrict__ g_r, const float* __restrict__ b_r,
+                                                           const float* __restrict__ h, int Hc, long plane, float eps,
+                                                           float* __restrict__ rh) {
+    __shared__ float aff[2];
+    if (threadIdx.x == 0) {
+        const GnAffine ar = gn_fold(st_r, (long)Hc * plane, eps);
+        aff[0] = ar.mean; aff[1] = ar.rstd;
+    }
+    const int c = blockIdx.y;
+    const float gr = g_r[c], br = b_r[c];
+    const long q0 = ((long)blockIdx.x * (256 * GRU2_F4) + threadIdx.x) * 4;
+    f4g vr[GRU2_F4], hv[GRU2_F4];
+#pragma unroll
+    for (int j = 0; j < GRU2_F4; ++j) {
+        const long q = q0 + j * 1024;
+        if (q < plane) {
+            vr[j] = *reinterpret_cast<const f4g*>(gates + (long)c * plane + q);
+            hv[j] = *reinterpret_cast<const f4g*>(h + (long)c * plane + q);
+        }
+    }
+    __syncthreads();
+    const float mean = aff[0], rstd = aff[1];
+#pragma unroll
+    for (int j = 0; j < GRU2_F4; ++j) {
+        const long q = q0 + j * 1024;
+        if (q < plane) {
+            f4g orh;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float rn = (vr[j][k] - mean) * rstd * gr + br;
+                orh[k] = gru_sigmoid_as<FAST>(rn) * hv[j][k];
+            }
+            *reinterpret_cast<f4g*>(rh + (long)c * plane + q) = orh;
+        }
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void gru2_update_gates_kernel4(const float* __restrict__ o, const double* __restrict__ st_o,
+                                                                  const float* __restrict__ g_o, const float* __restrict__ b_o,
+                                                                  const float* __restrict__ gates_u, const double* __restrict__ st_u,
+                                                                  const float* __restrict__ g_u, const float* __restrict__ b_u,
+                                                                  const float* __restrict__ h, int Hc, long plane, float eps,
+                                                                  float* __restrict__ h_out) {
+    __shared__ float aff[4];
+    if (threadIdx.x == 0) {
+        const GnAffine a = gn_fold(st_o, (long)Hc * plane, eps), au = gn_fold(st_u, (long)Hc * plane, eps);
+        aff[0] = a.mean; aff[1] = a.rstd; aff[2] = au.mean; aff[3] = au.rstd;
+    }
+    const int c = blockIdx.y;
+    const float go = g_o[c], bo = b_o[c], gu = g_u[c], bu = b_u[c];
+    const long q0 = ((long)blockIdx.x * (256 * GRU2_F4) + threadIdx.x) * 4;
+    f4g ov[GRU2_F4], uv[GRU2_F4], hv[GRU2_F4];
+#pragma unroll
+    for (int j = 0; j < GRU2_F4; ++j) {
+        const long q = q0 + j * 1024;
+        if (q < plane) {
+            ov[j] = *reinterpret_cast<const f4g*>(o + (long)c * plane + q);
+            uv[j] = *reinterpret_cast<const f4g*>(gates_u + (long)c * plane + q);
+            hv[j] = *reinterpret_cast<const f4g*>(h + (long)c * plane + q);
+        }
+    }
+    __syncthreads();
+    const float mo = aff[0], ro = aff[1], mu = aff[2], ru = aff[3];
+#pragma unroll
+    for (int j = 0; j < GRU2_F4; ++j) {
+        const long q = q0 + j * 1024;
+        if (q < plane) {
+            f4g out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float on = (ov[j][k] - mo) * ro * go + bo;
+                const float un = (uv[j][k] - mu) * ru * gu + bu;
+                const float uu = gru_sigmoid_as<FAST>(un);
+                out[k] = uu * hv[j][k] + (1.0f - uu) * gru_tanh_as<FAST>(on);
+            }
+            *reinterpret_cast<f4g*>(h_out + (long)c * plane + q) = out;
+        }
+    }
+}
+
 }  // namespace d3d
 
 using namespace d3d;
@@ -1131,6 +1222,30 @@ int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma,
         hipLaunchKernelGGL(fast ? gru2_update_kernel<true> : gru2_update_kernel<false>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
                            o, stats_o, gamma, beta, u, h, Hc, (long)plane, eps, h_out);
     D3D_LAUNCH_CHECK("gru2_update_kernel launch");
+    return D3D_OK;
+}
+
+int d3d_gru_reset_gn(const float* gates, const double* stats_r, const float* gamma_r, const float* beta_r, const float* h, int Hc,
+                     int64_t plane, float eps, int fast, float* rh, d3d_stream_t stream) {
+    D3D_REQUIRE(gates && stats_r && gamma_r && beta_r && h && rh, "null pointer");
+    D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
+    if (plane % 4 != 0 || Hc > 65535 || !aligned16(gates) || !aligned16(h) || !aligned16(rh)) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fast ? gru2_reset_kernel4<true> : gru2_reset_kernel4<false>, dim3(ceil_div(plane / 4, 256 * GRU2_F4), Hc), dim3(256), 0,
+                       (hipStream_t)stream, gates, stats_r, gamma_r, beta_r, h, Hc, (long)plane, eps, rh);
+    D3D_LAUNCH_CHECK("gru2_reset_kernel4 launch");
+    return D3D_OK;
+}
+
+int d3d_gru_update_gates_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* gates,
+                            const double* stats_u, const float* gamma_u, const float* beta_u, const float* h, int Hc, int64_t plane,
+                            float eps, int fast, float* h_out, d3d_stream_t stream) {
+    D3D_REQUIRE(o && stats_o && gamma && beta && gates && stats_u && gamma_u && beta_u && h && h_out, "null pointer");
+    D3D_REQUIRE(Hc > 0 && plane > 0 && eps >= 0.0f, "bad dims");
+    const float* gates_u = gates + (long)Hc * plane;
+    if (plane % 4 != 0 || Hc > 65535 || !aligned16(o) || !aligned16(gates_u) || !aligned16(h) || !aligned16(h_out)) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(fast ? gru2_update_gates_kernel4<true> : gru2_update_gates_kernel4<false>, dim3(ceil_div(plane / 4, 256 * GRU2_F4), Hc),
+                       dim3(256), 0, (hipStream_t)stream, o, stats_o, gamma, beta, gates_u, stats_u, gamma_u, beta_u, h, Hc, (long)plane, eps, h_out);
+    D3D_LAUNCH_CHECK("gru2_update_gates_kernel4 launch");
     return D3D_OK;
 }
 

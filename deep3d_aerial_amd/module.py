@@ -212,11 +212,24 @@ class ConvGRUCell2(nn.Module):
         gs = ops.GnStats(2)
         f = ops.conv2d_k3(x, self._w(self.gate_conv, negate_x), None, self.gate_conv.bias, None, act=0, stride=1, x2=h, gn=gs)
         rn, un = self.reset_gate_norm, self.update_gate_norm
-        rh, u = ops.gru_gates_gn(f, h, rn.weight, rn.bias, un.weight, un.bias, rn.eps, stats=gs.stats(f))
+        st = gs.stats(f)
+        # the reset half alone, the update gate evaluated inside the state update (104 channel planes per cell instead of 128, the
+        # same bits): ops.gru_reset_gn / gru_update_gates_gn; the two-output form where the kernel does not take the shape
+        rh = None
+        if f.is_cuda and rn.eps == un.eps == self.output_norm.eps and not _cfg.off("gru_gates_split"):
+            rh = ops.gru_reset_gn(f, h, rn.weight, rn.bias, rn.eps, st[0])
+        if rh is None:
+            rh, u = ops.gru_gates_gn(f, h, rn.weight, rn.bias, un.weight, un.bias, rn.eps, stats=st)
+        else:
+            u = None
         go = ops.GnStats(1)
         o = ops.conv2d_k3(x, self._w(self.output_conv, negate_x), None, self.output_conv.bias, None, act=0, stride=1,
                           x2=rh, gn=go)
-        out = ops.gru_update_gn(o, u, h, self.output_norm.weight, self.output_norm.bias, self.output_norm.eps, stats=go.stats(o))
+        on = self.output_norm
+        if u is None:
+            out = ops.gru_update_gates_gn(o, f, h, on.weight, on.bias, un.weight, un.bias, on.eps, go.stats(o), st[1])
+        else:
+            out = ops.gru_update_gn(o, u, h, on.weight, on.bias, on.eps, stats=go.stats(o))
         return out, out
 
 

@@ -1429,13 +1429,20 @@ def convtranspose2d_k3s2(x, weight, scale=None, shift=None, skip=None, skip_afte
         # RED-Net's upconv3 (msrednet.py:348: ConvTransReLU(64, 32) from the coarsest level, 86 x 58 pixels at stage 1): the same
         # zero-stuffed form on the wide tile kernel (64 input channels in two chunks of 32; ReLU, then the skip: ConvTransReLU's
         # order).  167 / 102 us per call on the round-1 stream kernel -- 12.6 ms of a 66 ms view
-        z = x.new_zeros((Ci, 2 * H, 2 * W))
-        z[:, ::2, ::2] = x
+        # -- the stuffed image formed in the kernel's staging: no fill + strided copy of a [64,2H,2W] tensor per call (two of a
+        # slice's 33 launches; stage 1 replays its captured loop at ~9 us per node)
         wf = derived_weight(weight, "t2flip", lambda w: w.flip(2, 3).transpose(0, 1))
-        y = conv2d_wide(z, wf, scale, shift, skip, act)
-        if y is not None:
+        wp = derived_weight(wf, "z2bf16", _pack_z2_bf16)
+        if skip is not None and tuple(skip.shape) != (Co, 2 * H, 2 * W):
+            raise ValueError("skip shape mismatch")
+        out = torch.empty((Co, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        rc = _lib.load().d3d_convtranspose2d_k3s2_wide_h16(_chk(x, "x", 3), ctypes.c_void_p(wp.data_ptr()), _opt(scale, "scale"),
+                                                            _opt(shift, "shift"), _opt(skip, "skip"), int(act), Ci, Co, H, W,
+                                                            _chk(out, "out"), _stream())
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "d3d_convtranspose2d_k3s2_wide_h16")
             dispatch_counts["convtranspose2d_wide"] += 1
-            return y
+            return out
     if _use_mfma() and Co <= 64:
         y = convtranspose_k3s2_mfma(x, weight, scale, shift, skip, act=act, skip_after_act=skip_after_act)
         if y is not None:
@@ -1519,6 +1526,31 @@ def groupnorm_stats(x, ngroups=1):
                                          _stream())
     _lib.check(rc, "d3d_groupnorm_stats")
     return st[0] if ngroups == 1 else st
+
+
+def gru_reset_gn(gates, h, gamma_r, beta_r, eps, stats_r):
+    """The reset half of ConvGRUCell2's gates alone (module.py:71-76,85): rh = sigmoid(GroupNorm(gates[:Hc])) * h.  None when the
+    kernel does not take the shape (the caller then runs gru_gates_gn)."""
+    Hc, plane = h.shape[0], h[0].numel()
+    rh = torch.empty_like(h)
+    rc = _lib.load().d3d_gru_reset_gn(_chk(gates, "gates"), _dptr(stats_r), _chk(gamma_r, "gamma_r"), _chk(beta_r, "beta_r"), _chk(h, "h"),
+                                      Hc, plane, float(eps), int(conv_precision() == "h16"), _chk(rh, "rh"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_gru_reset_gn")
+    return rh
+
+
+def gru_update_gates_gn(o, gates, h, gamma, beta, gamma_u, beta_u, eps, stats_o, stats_u):
+    """ConvGRUCell2's state update with the update gate evaluated in place (module.py:77-82,84-98): u = sigmoid(GroupNorm(gates[Hc:])),
+    h' = u*h + (1-u)*tanh(GroupNorm(o)) -- gru_gates_gn's u followed by gru_update_gn, bit for bit, without u's write and read."""
+    Hc, plane = h.shape[0], h[0].numel()
+    out = torch.empty_like(h)
+    rc = _lib.load().d3d_gru_update_gates_gn(_chk(o, "o"), _dptr(stats_o), _chk(gamma, "gamma"), _chk(beta, "beta"), _chk(gates, "gates"),
+                                             _dptr(stats_u), _chk(gamma_u, "gamma_u"), _chk(beta_u, "beta_u"), _chk(h, "h"), Hc, plane,
+                                             float(eps), int(conv_precision() == "h16"), _chk(out, "out"), _stream())
+    _lib.check(rc, "d3d_gru_update_gates_gn")
+    return out
 
 
 def _dptr(t):

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define D3D_ABI_VERSION 9
+#define D3D_ABI_VERSION 10
 
 #define D3D_OK 0
 #define D3D_ERR_INVALID_ARG (-1)
@@ -253,6 +253,11 @@ int d3d_conv2d_k3_zs_h16_gn(const float* in, int C1, const float* in2, int C2, c
                              int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
 int d3d_conv2d_k3_wide_h16_gn(const float* in, int C1, const float* in2, int C2, const void* wpacked, const float* shift, int Co, int H,
                                int W, float* out, double* gn_stats, int gn_split, d3d_stream_t stream);
+/* module.py:287-294 at 64 input channels (msrednet.py:348 upconv3, ABI 10): out [Co,2H,2W] = act(convT3x3_s2(in) * scale + shift)
+ * (+ skip, added last) as the stride-1 convolution of the zero-stuffed input with the flipped, transposed kernel (wpacked =
+ * ops._pack_z2_bf16 of it); the stuffed image exists only in the kernel's staging.  in [64,H,W]; Co = 32 | 64; 16-bit operands. */
+int d3d_convtranspose2d_k3s2_wide_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
+                                      const float* skip, int act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
 /* conv0 of a feature trunk in ONE launch (round 4, ABI 7; csrc/conv2d_zs.hip, IMG3 form): out = act(scale * Conv3x3_8->Co(c) + shift)
  * with c = act0(scale0 * Conv3x3_3->8(img) + shift0) evaluated per tile from the staged image patch and never written (module.py:
  * 663-666: ConvBnReLU(3, 8) + ConvBnReLU(8, 8) at full resolution).  img [3,H,W]; w0packed [4][3][3][8] fp32 as
@@ -653,6 +658,17 @@ int d3d_gru_gates_gn(const float* gates, const double* stats_r, const double* st
                      int64_t plane, float eps, int fast, float* rh, float* u, d3d_stream_t stream);
 int d3d_gru_update_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* u,
                       const float* h, int Hc, int64_t plane, float eps, int fast, float* h_out, d3d_stream_t stream);
+/* The same cell in two elementwise passes over 104 channel planes instead of 128 (ABI 10): the reset half alone, and the update
+ * gate evaluated where it is used --
+ *   d3d_gru_reset_gn:        rh = sigmoid(gn_r(gates[:Hc])) * h
+ *   d3d_gru_update_gates_gn: h' = u*h + (1-u)*tanh(gn_o(o)),  u = sigmoid(gn_u(gates[Hc:]))   (gates: the whole [2Hc,plane] tensor)
+ * Per element the operations of the pair above in their order: the same bits.  plane % 4 == 0 and 16-byte aligned tensors, else
+ * D3D_ERR_UNSUPPORTED (nothing launched). */
+int d3d_gru_reset_gn(const float* gates, const double* stats_r, const float* gamma_r, const float* beta_r, const float* h, int Hc,
+                     int64_t plane, float eps, int fast, float* rh, d3d_stream_t stream);
+int d3d_gru_update_gates_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* gates,
+                            const double* stats_u, const float* gamma_u, const float* beta_u, const float* h, int Hc, int64_t plane,
+                            float eps, int fast, float* h_out, d3d_stream_t stream);
 
 /* ucsnet.py:137-151 (compute_depth of UCS-Net): d3d_softargmin_conf4 plus the spread of the per-pixel distribution,
  * var_out = lamb * sqrt(sum_d softmax(cost)_d * (depth_d - depth_out)^2)  [h,w]. */

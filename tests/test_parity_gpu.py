@@ -1036,6 +1036,37 @@ def test_groupnorm_stats_and_gates_vs_oracle(ops, oracle):
     assert np.abs(got - want).max() <= 2e-6
 
 
+@pytest.mark.parametrize("mode", ["fp32", "h16"])
+@pytest.mark.parametrize("Hc,h,w", [(16, 9, 12), (8, 70, 100), (32, 33, 1028), (8, 7, 5)])
+def test_gru2_split_passes_are_the_two_output_pair(ops, oracle, mode, Hc, h, w):
+    """d3d_gru_reset_gn + d3d_gru_update_gates_gn (module.py:71-98 in two elementwise passes: the update gate is evaluated inside
+    the state update instead of being written and read back) against the oracle, and bit for bit what d3d_gru_gates_gn followed by
+    d3d_gru_update_gn give, in both activation forms; widths that are not a multiple of 4 are declined (the pair runs)."""
+    rng = np.random.default_rng(Hc * 31 + w)
+    f = (1.0 + 2.0 * rng.standard_normal((2 * Hc, h, w))).astype(np.float32)
+    hh = rng.standard_normal((Hc, h, w)).astype(np.float32)
+    o = rng.standard_normal((Hc, h, w)).astype(np.float32)
+    gr, br, gu, bu, go, bo = (dev(rng.uniform(0.5, 1.5, Hc).astype(np.float32)) for _ in range(6))
+    ops.set_conv_precision(mode)
+    try:
+        st = ops.groupnorm_stats(dev(f), 2)
+        so = ops.groupnorm_stats(dev(o))
+        rh0, u0 = ops.gru_gates_gn(dev(f), dev(hh), gr, br, gu, bu, 1e-5, stats=st)
+        out0 = ops.gru_update_gn(dev(o), u0, dev(hh), go, bo, 1e-5, stats=so)
+        rh1 = ops.gru_reset_gn(dev(f), dev(hh), gr, br, 1e-5, st[0])
+        if (h * w) % 4:
+            assert rh1 is None
+            return
+        out1 = ops.gru_update_gates_gn(dev(o), dev(f), dev(hh), go, bo, gu, bu, 1e-5, so, st[1])
+    finally:
+        ops.set_conv_precision(None)
+    assert torch.equal(rh0, rh1) and torch.equal(out0, out1)
+    r_want = oracle.sigmoid(oracle.groupnorm1(f[:Hc], host(gr), host(br)))
+    u_want = oracle.sigmoid(oracle.groupnorm1(f[Hc:], host(gu), host(bu)))
+    assert np.abs(host(rh1) - r_want * hh).max() <= 2e-6
+    assert np.abs(host(out1) - oracle.gru_update(u_want, hh, oracle.groupnorm1(o, host(go), host(bo)))).max() <= 4e-6
+
+
 def test_pairnet_golden(ops, convpath):
     from deep3d_aerial_amd.adamvs import CostRegNet2D
 
