@@ -14,7 +14,8 @@ from .module import ConvGRUCell2, ConvReLU, ConvTransReLU, FeatureNet_mvsnet, pl
 
 
 class slice_RED_Regularization(nn.Module):
-    """msrednet.py:337-370.  forward(cost [C,h,w], state1..4) -> (reg [1,h,w], state1..4).
+    """msrednet.py:337-370.  forward(cost [C,h,w], state1..4) -> (reg [1,h,w], state1..4); with regress = (dplane, max_p, sum_d,
+    sum_p) the online regression update of the slice is applied as well (reg is None when it was fused into the head).
     The reference feeds -cost to conv1 and conv_gru1; here the sign is folded into their weights."""
 
     def __init__(self, in_channels, base_channels=8):
@@ -34,7 +35,21 @@ class slice_RED_Regularization(nn.Module):
         self.upconv2d = nn.ConvTranspose2d(b, 1, kernel_size=3, stride=1, padding=1, output_padding=0)
 
 
-    def forward(self, cost, state1, state2, state3, state4):
+    def _head(self, up11, regress):
+        """upconv2d: ConvTranspose2d(stride 1, pad 1) = correlation with the spatially flipped, transposed kernel.  With
+        regress = (dplane, max_p, sum_d, sum_p) the layer and the online regression update of msrednet.py:418-437 are one kernel
+        where it applies (h16 mode: ops.slice_head_regress) and None is returned: `reg` never reaches memory."""
+        wc = ops.derived_weight(self.upconv2d.weight, "flipT", lambda w: w.flip(2, 3).transpose(0, 1))
+        if regress is not None:
+            dplane, max_p, sum_d, sum_p = regress
+            if ops.slice_head_regress(up11, wc, self.upconv2d.bias, False, dplane, max_p, sum_d, sum_p):
+                return None
+        reg = ops.conv2d_k3(up11, wc, None, self.upconv2d.bias, None, act=0)
+        if regress is not None:
+            ops.online_regress_update(reg[0], *regress)
+        return reg
+
+    def forward(self, cost, state1, state2, state3, state4, regress=None):
         w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
         if cost.is_cuda and not _cfg.off("red_streams"):
             # The four recurrent cells of a slice depend on the encoder's maps only (msrednet.py:352-367), and at the first two
@@ -72,9 +87,7 @@ class slice_RED_Regularization(nn.Module):
             up22 = self.upconv2(up33, skip=state2)
             main.wait_event(d1)
             up11 = self.upconv1(up22, skip=state1)
-            wc = ops.derived_weight(self.upconv2d.weight, "flipT", lambda w: w.flip(2, 3).transpose(0, 1))
-            reg = ops.conv2d_k3(up11, wc, None, self.upconv2d.bias, None, act=0)
-            return reg, state1, state2, state3, state4
+            return self._head(up11, regress), state1, state2, state3, state4
         c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)             # conv1(-cost)
         c2 = self.conv2(c1)
         c3 = self.conv3(c2)
@@ -85,10 +98,7 @@ class slice_RED_Regularization(nn.Module):
         up22 = self.upconv2(up33, skip=state2)
         state1, _ = self.conv_gru1(cost, state1, negate_x=True)                       # conv_gru1(-cost)
         up11 = self.upconv1(up22, skip=state1)
-        # ConvTranspose2d(stride 1, pad 1) = correlation with the spatially flipped, transposed kernel
-        wc = ops.derived_weight(self.upconv2d.weight, "flipT", lambda w: w.flip(2, 3).transpose(0, 1))
-        reg = ops.conv2d_k3(up11, wc, None, self.upconv2d.bias, None, act=0)
-        return reg, state1, state2, state3, state4
+        return self._head(up11, regress), state1, state2, state3, state4
 
 
 class InferDepthNet(nn.Module):
@@ -128,8 +138,7 @@ class InferDepthNet(nn.Module):
                     dplane = dvb[d:d + 1].view(1, 1)
                 else:                # [D,h,w] per-pixel hypotheses
                     dplane = dvb[d]
-                reg, *states = cost_regularization(var[d], *states)
-                ops.online_regress_update(reg[0], dplane, max_p, sum_d, sum_p)
+                _, *states = cost_regularization(var[d], *states, regress=(dplane, max_p, sum_d, sum_p))
             dep, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
             depths.append(dep)
             confs.append(conf)
@@ -155,7 +164,9 @@ class RedLoopGraph(object):
     Measured and not kept (profiles/r05_red_pipeline_ab.txt): the D slices as six chains across the slices (encoder of slice d + 2,
     the four levels' cells of d + 1, the decoder of d in flight together, 2-dependency nodes only) -- stage 1 14.7 -> 17.0 ms, stages
     2 / 3 unchanged.  Stage 1 replays 1 584 nodes in 14.7 ms, 9 us per node whatever the branches: the node rate bounds it, not the
-    slices' dependency chain; stages 2 / 3 are bound by their kernels' durations."""
+    slices' dependency chain; stages 2 / 3 are bound by their kernels' durations.  The lighter variant -- only the decoder of slice d
+    on its own stream beside the encoder and cells of slice d + 1 -- is slower as well (58.3 -> 63.3 ms per view): more branches in
+    flight cost this graph executor more than the overlap returns."""
 
     _cache = {}
     _lock = __import__("threading").Lock()
@@ -218,9 +229,8 @@ class RedLoopGraph(object):
         cr = self.cr()
         before = dict(ops.dispatch_counts)
         states = self._zero_states()          # one eager slice first: packed weights, LDS attributes, slot arenas of the eager streams
-        reg, *states = cr(self.var[0], *states)
-        ops.online_regress_update(reg[0], self._dplane(0), self.max_p, self.sum_d, self.sum_p)
-        del reg, states
+        _, *states = cr(self.var[0], *states, regress=(self._dplane(0), self.max_p, self.sum_d, self.sum_p))
+        del states
         ops.dispatch_counts.clear()
         ops.dispatch_counts.update(before)
         graph = torch.cuda.CUDAGraph()
@@ -231,9 +241,8 @@ class RedLoopGraph(object):
             states = self._zero_states()
             self.max_p.zero_(); self.sum_d.zero_(); self.sum_p.zero_()
             for d in range(self.D):
-                reg, *states = cr(self.var[d], *states)
-                ops.online_regress_update(reg[0], self._dplane(d), self.max_p, self.sum_d, self.sum_p)
-            del reg, states
+                _, *states = cr(self.var[d], *states, regress=(self._dplane(d), self.max_p, self.sum_d, self.sum_p))
+            del states
         after = dict(ops.dispatch_counts)
         self.counts = {k: v - before.get(k, 0) for k, v in after.items() if v != before.get(k, 0)}
         for k, v in self.counts.items():

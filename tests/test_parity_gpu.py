@@ -1303,6 +1303,8 @@ def test_model_forward_at_production_kernel_size_matches_reference(ops, name, mo
     # (the asserts on this round's fused kernels hold for the default dispatch: D3D_KERNELS_OFF=<name> takes a kernel out on purpose)
     if name == "msrednet" and mode == "h16" and not config.off("gn_fused"):   # GroupNorm statistics ride on the convolutions
         assert counts.get("conv2d_gn_fused", 0) >= 2 * 2 * (48 + 32 + 8), counts   # (at least the two wide levels of every slice)
+        if not config.off("head_fused"):   # upconv2d + the online regression update of every slice in one kernel
+            assert counts.get("slice_head_regress", 0) == 48 + 32 + 8, counts
     if name in ("casmvsnet", "adamvs") and not config.off("conv0_pair"):   # conv0 of the feature trunk of every view in one launch (the feature nets are fp32 in both modes)
         assert counts.get("conv2d_pair3", 0) == imgs.shape[1], counts
     # ---- and what they produced is the reference's
