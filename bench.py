@@ -508,7 +508,12 @@ def main():
                 "in_frame_fraction": round(in_frame, 4)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
-    exchange = exchange_leg(dist, rank, world, shared) if dist else None
+    exchange = None
+    if dist:
+        try:
+            exchange = exchange_leg(dist, rank, world, shared)
+        except Exception as e:   # the scaling line must survive a failure of the add-on leg (reported, not hidden)
+            exchange = {"error": repr(e)[:300]}
     voxels = D * H_FEAT * W_FEAT
     value = world * args.steps * voxels / elapsed / 1e6
     achieved = algorithmic_bytes() / (kern_ms * 1e-3) / 1e9
