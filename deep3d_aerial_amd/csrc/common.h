@@ -115,6 +115,64 @@ __device__ __forceinline__ float gru_tanh_as(float y) { return FAST ? gru_tanh(y
 // of the fused conv-GRU cell).  8-channel cells are 16 bytes: K groups are then taps, and neighbouring taps share their cell.
 __host__ __device__ constexpr int bf16_cell_bytes(int C) { return C <= 8 ? 16 : ((2 * C - 32 + 63) / 64) * 64 + 32; }
 
+// Tiles per workgroup along y.  A workgroup pays its prologue once (the weights into LDS, the per-lane task state): more tiles per
+// workgroup amortise it and let the next tile's patch fly under the sweep -- but the launch should still cover the chip, and a
+// grid a little above a whole number of rounds of resident workgroups leaves most of the last round's slots idle (a 2-D tile kernel at 688 x 464, 32
+// channels: 1290 one-tile workgroups on 512 slots = three rounds, the last half empty; 430 three-tile workgroups = one).  Round 5
+// picks the count that minimises  rounds x (tiles + prologue)  with the prologue priced in tiles from the bytes it moves;
+// -DD3D_Z2_TPER_MODEL=0 is the rule of rounds 2-4 (halve from 8 until there are 1024 workgroups).
+#ifndef D3D_Z2_TPER_MODEL
+#define D3D_Z2_TPER_MODEL 1
+#endif
+inline int pick_tper(int gx, int nty, int lds_bytes, int weight_bytes, int patch_bytes, int max_per_cu = 2) {
+#if D3D_Z2_TPER_MODEL
+    const int per_cu = lds_bytes > 0 ? (160 * 1024 / lds_bytes < max_per_cu ? (160 * 1024 / lds_bytes > 0 ? 160 * 1024 / lds_bytes : 1) : max_per_cu) : max_per_cu;
+    const long slots = 256L * per_cu;
+    const double prologue = 0.25 + 0.5 * (double)weight_bytes / (double)(patch_bytes > 0 ? patch_bytes : 1);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int t = 1; t <= 8; ++t) {
+        const long wgs = (long)gx * ceil_div(nty, t);
+        const long rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * ((double)t + prologue);
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = t; }
+    }
+    return best;
+#else
+    (void)lds_bytes; (void)weight_bytes; (void)patch_bytes; (void)max_per_cu;
+    int tper = 8;   // every tile re-reads two halo rows of its neighbour; enough workgroups for 256 CUs come first
+    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    return tper;
+#endif
+}
+
+// The same question for the z-streaming 3-D kernels: into how many depth segments to cut a volume whose (x, y) tiles alone do not
+// cover the chip.  A segment pays `halo` planes it shares with its neighbour plus a prologue; the count that minimises
+// rounds x (planes per segment + halo + prologue) wins (rounds 2-4: double until there are 1024 workgroups).  Returns planes per segment.
+inline int pick_zper(long tiles_xy, int D, int min_planes, int halo, int lds_bytes, int max_per_cu = 2, long old_target = 1024) {
+#if D3D_Z2_TPER_MODEL
+    const int fit = lds_bytes > 0 ? 160 * 1024 / lds_bytes : max_per_cu;
+    const long slots = 256L * (fit < 1 ? 1 : (fit < max_per_cu ? fit : max_per_cu));
+    int best = D;
+    double best_cost = 1e30;
+    for (int nz = 1; nz <= D; ++nz) {
+        const int zper = ceil_div(D, nz);
+        if (zper < min_planes && nz > 1) break;
+        if (nz > 1 && zper == ceil_div(D, nz - 1)) continue;   // (the same segments as the previous count)
+        const long wgs = tiles_xy * ceil_div(D, zper);
+        const long rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * ((double)zper + (double)halo + 1.0);
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = zper; }
+    }
+    return best;
+#else
+    (void)halo; (void)lds_bytes; (void)max_per_cu;
+    int nz = 1;
+    while (tiles_xy * nz < old_target && D / (nz * 2) >= min_planes) nz *= 2;
+    return ceil_div(D, nz);
+#endif
+}
+
 // Workgroup barrier for data handed over through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the
 // fence waits for EVERY memory operation the wave has in flight (s_waitcnt vmcnt(0)): the global stores of the plane just
 // finished and the global loads issued ahead for a later plane -- a z-streaming kernel then pays a store's round trip per

@@ -583,8 +583,7 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int gx = ceil_div(p.W, TX), nty = ceil_div(p.H, TYZ);
-    int tper = 8;   // every tile re-reads two halo rows of its neighbour; enough workgroups for 256 CUs come first
-    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    const int tper = pick_tper(gx, nty, lds, WBYTES, PATCH, GN && CI == 40 ? 4 : 2);
     q.tper = tper;
     const int gy = ceil_div(nty, tper);
     if (gy > 65535) return D3D_ERR_UNSUPPORTED;
@@ -1050,8 +1049,8 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     Z2Params q = p;
     const int Ho = (p.H - 1) / 2 + 1, Wo = (p.W - 1) / 2 + 1;
     const int gx = ceil_div(Wo, 16 * MG), nty = ceil_div(Ho, TYZ);
-    int tper = 8;
-    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    constexpr int PATCH_S2 = (32 * MG + KS - 2) * (2 * TYZ + KS - 2) * CS;
+    const int tper = pick_tper(gx, nty, lds, lds - (X3 ? 1 : 2) * PATCH_S2, PATCH_S2);
     q.tper = tper;
     const int gy = ceil_div(nty, tper);
     if (gy > 65535) return D3D_ERR_UNSUPPORTED;
@@ -1073,8 +1072,8 @@ static int launch_tz(const Z2Params& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int gx = ceil_div(p.W, TXI), nty = ceil_div(p.H, TYZ);
-    int tper = 8;
-    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    constexpr int PATCH_T = (K4 ? (TXI + 2) * 10 : 33 * 9) * CS;
+    const int tper = pick_tper(gx, nty, lds, lds - (X3 && CI > 8 ? 1 : 2) * PATCH_T, PATCH_T);
     q.tper = tper;
     const int gy = ceil_div(nty, tper);
     if (gy > 65535) return D3D_ERR_UNSUPPORTED;

@@ -528,9 +528,7 @@ static int launch(const C8Params& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     C8Params q = p;
     const int gx = ceil_div(p.W, TXk), gy = ceil_div(p.H, TY);
-    int nz = 1;   // enough workgroups for 256 CUs; every z segment re-reads two halo planes
-    while ((long)gx * gy * nz < 1024 && p.D / (nz * 2) >= 4) nz *= 2;
-    q.zper = ceil_div(p.D, nz);
+    q.zper = pick_zper((long)gx * gy, p.D, 4, 2, lds);   // (every z segment re-reads two halo planes; common.h)
     hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(p.D, q.zper)), dim3(NT), lds, stream, q);
     D3D_LAUNCH_CHECK("conv3d_c8_bf16_kernel launch");
     return D3D_OK;

@@ -263,9 +263,7 @@ static int launch_s2(const S2Params& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     S2Params q = p;
     const int gx = ceil_div(p.Wo, TXOk), gy = ceil_div(p.Ho, TYO);
-    int nz = 1;   // every z segment re-reads one halo plane
-    while ((long)gx * gy * nz < 1024 && p.Do / (nz * 2) >= 2) nz *= 2;
-    q.zper = ceil_div(p.Do, nz);
+    q.zper = pick_zper((long)gx * gy, p.Do, 2, 1, lds);   // (every z segment re-reads one halo plane)
     hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(p.Do, q.zper)), dim3(NT), lds, stream, q);
     D3D_LAUNCH_CHECK("conv3d_s2_cl_kernel launch");
     return D3D_OK;

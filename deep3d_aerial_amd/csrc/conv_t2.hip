@@ -431,9 +431,7 @@ static int launch(const T2Params& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     T2Params q = p;
     const int gx = ceil_div(p.W, TXI), gy = ceil_div(p.H, TYI);
-    int nz = 1;
-    while ((long)gx * gy * nz < 1024 && p.D / (nz * 2) >= 2) nz *= 2;
-    q.ozper = 2 * ceil_div(p.D, nz);
+    q.ozper = 2 * pick_zper((long)gx * gy, p.D, 2, 1, lds);
     hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(2 * p.D, q.ozper)), dim3(64 * TYI), lds, stream, q);
     D3D_LAUNCH_CHECK("convt3d_zs_bf16_kernel launch");
     return D3D_OK;

@@ -320,9 +320,8 @@ extern "C" int d3d_convtranspose3d_prob_cl_h16(const void* in, const void* wt_fo
     p.in = in; p.wt = reinterpret_cast<const u4*>(wt_folded); p.scale = scale; p.shift = shift; p.skip = skip;
     p.wp = reinterpret_cast<const u4*>(wprob_kzfolded); p.pbias = prob_bias; p.out = out;
     p.D = D; p.H = H; p.W = W; p.relu = relu;
-    int nz = 1;   // enough workgroups for 2 x 256 slots; every z segment recomputes two y planes
-    while ((long)gx * gy * nz < 1536 && (2 * D) / (nz * 2) >= 8) nz *= 2;   // (1024 | 3072: the same to 3 %, profiles/r04_t2p.txt)
-    p.ozper = 2 * ceil_div(D, nz);
+    // (every z segment recomputes two y planes; rounds 2-4: doubled until 1536 workgroups -- 1024 | 3072: the same to 3 %, profiles/r04_t2p.txt)
+    p.ozper = 2 * pick_zper((long)gx * gy, D, 4, 2, LDS_BYTES, 2, 1536);
     hipLaunchKernelGGL(kern, dim3(gx, gy, ceil_div(2 * D, p.ozper)), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
     D3D_LAUNCH_CHECK("convt3d_prob_kernel launch");
     return D3D_OK;

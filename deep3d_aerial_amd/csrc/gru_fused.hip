@@ -465,8 +465,9 @@ static int launch_gru(const GruParams& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     GruParams q = p;
     const int gx = ceil_div(p.W, G::OX), nty = ceil_div(p.H, TY);
-    int tper = 8;   // tiles a workgroup walks down the image: enough workgroups for 256 CUs come first
-    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    // tiles a workgroup walks down the image (common.h pick_tper: whole rounds of resident workgroups, the prologue -- weights and
+    // per-lane task state -- amortised; with two tiles or more the next patch is in flight under the sweep)
+    const int tper = pick_tper(gx, nty, G::LDS, G::WB + 16 * 1024, G::SIMB + 2 * G::REG, G::LDS <= 80 * 1024 ? 2 : 1);
     q.tper = tper;
     const int gy = ceil_div(nty, tper);
     if (gy > 65535) return D3D_ERR_UNSUPPORTED;

@@ -1108,8 +1108,7 @@ int d3d_slice_tail_regress_h16(const float* state2, const void* wup_packed, cons
     p.s2 = state2; p.wup = reinterpret_cast<const tail::u4t*>(wup_packed); p.bup = bup; p.s1 = state1; p.wh = whead; p.bh = bhead;
     p.dplane = dplane; p.max_p = max_p; p.sum_d = sum_d; p.sum_p = sum_p; p.hd = hd; p.wd = wd; p.h = h; p.w = w;
     const int gx = ceil_div(w, tail::SX), nty = ceil_div(h, tail::SY);
-    int tper = 8;
-    while (tper > 1 && (long)gx * ceil_div(nty, tper) < 1024) tper >>= 1;
+    const int tper = pick_tper(gx, nty, tail::LDS_BYTES, tail::NFRAG * 64 * 16 + 8 * 1024, 2 * tail::PATCH);
     p.tper = tper;
     const int gy = ceil_div(nty, tper);
     if (gy > 65535) return D3D_ERR_UNSUPPORTED;
