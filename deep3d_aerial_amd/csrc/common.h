@@ -128,7 +128,13 @@ inline int pick_tper(int gx, int nty, int lds_bytes, int weight_bytes, int patch
 #if D3D_Z2_TPER_MODEL
     const int per_cu = lds_bytes > 0 ? (160 * 1024 / lds_bytes < max_per_cu ? (160 * 1024 / lds_bytes > 0 ? 160 * 1024 / lds_bytes : 1) : max_per_cu) : max_per_cu;
     const long slots = 256L * per_cu;
-    const double prologue = 0.25 + 0.5 * (double)weight_bytes / (double)(patch_bytes > 0 ? patch_bytes : 1);
+#ifndef D3D_TPER_P0
+#define D3D_TPER_P0 0.25
+#endif
+#ifndef D3D_TPER_P1
+#define D3D_TPER_P1 0.5
+#endif
+    const double prologue = D3D_TPER_P0 + D3D_TPER_P1 * (double)weight_bytes / (double)(patch_bytes > 0 ? patch_bytes : 1);
     int best = 1;
     double best_cost = 1e30;
     for (int t = 1; t <= 8; ++t) {
