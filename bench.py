@@ -293,6 +293,7 @@ def secondary_models(reps=5, warm=2):
             imgs = torch.from_numpy(s["imgs"])[None].cuda()
             pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}
             dv = torch.from_numpy(s["depth_values"])[None].cuda()
+            ops.note_depth_range(dv, s["depth_values"][0], s["depth_values"][-1])   # as predict.predict_views hands it over: no host sync per view
             with torch.no_grad():
                 for _ in range(warm):   # (the first forward packs the weights; the second settles the allocator's pools)
                     net(imgs, pm, dv)

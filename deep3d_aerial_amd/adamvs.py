@@ -541,7 +541,7 @@ class Infer_AdaMVSNet(nn.Module):
     def forward(self, imgs, proj_matrices, depth_values, image_keys=None):
         """image_keys (optional, with self.feature_cache set): one hashable key per view; the feature pyramid of a
         key seen before is reused instead of recomputed, and imgs may then be a list whose cached entries are None."""
-        dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())
+        dmin, dmax = ops.depth_range_host(depth_values)   # (host numbers: no device access when the caller noted them)
         depth_interval = (dmax - dmin) / self.num_depth
         features = extract_features(self.feature, imgs, image_keys, self.feature_cache)
         V = len(features)

@@ -295,7 +295,7 @@ class Infer_CascadeREDNet(nn.Module):
         key seen before is reused instead of recomputed, and imgs may then be a list whose cached entries are None."""
         if self.training:
             raise RuntimeError("inference only: call .eval()")
-        dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())   # msrednet.py:477-478 (one host sync)
+        dmin, dmax = ops.depth_range_host(depth_values)   # (host numbers: no device access when the caller noted them)
         depth_interval = (dmax - dmin) / self.num_depth
         features = extract_features(self.feature, imgs, image_keys, self.feature_cache)
         V = len(features)

@@ -1649,6 +1649,34 @@ def on_streams(thunks, device, switch):
     return outs
 
 
+# The drivers need the depth range (depth_values[0, 0], depth_values[0, -1]) as host numbers (adamvs.py:565-566 and its siblings
+# read it with .item()): on a device tensor that is a device -> host copy, i.e. the host waits for every kernel of the PREVIOUS
+# view before it launches the first one of this view.  A caller that built the tensor from host data says so once
+# (note_depth_range: predict_views, bench.py) and the forward then never touches the device for it.
+_depth_ranges = {}
+
+
+def note_depth_range(depth_values, dmin, dmax):
+    """`depth_values` (a device tensor about to be passed to an Infer_* forward) holds [dmin .. dmax] in its first row: keep the
+    host copy of the two numbers (until the tensor is written to or dies)."""
+    import weakref
+
+    key = id(depth_values)
+    ref = weakref.ref(depth_values, lambda _r, key=key: _depth_ranges.pop(key, None))
+    _depth_ranges[key] = (ref, depth_values._version, float(dmin), float(dmax))
+    return depth_values
+
+
+def depth_range_host(depth_values):
+    """(dmin, dmax) of an Infer_* forward's depth_values [B,2] | [B,D] as host floats: the noted pair if the caller left one
+    (no device access), else read from the tensor (one host sync)."""
+    hit = _depth_ranges.get(id(depth_values))
+    if hit is not None and hit[0]() is depth_values and hit[1] == depth_values._version:
+        return hit[2], hit[3]
+    dmin, dmax = (float(v) for v in depth_values[0, [0, -1]].tolist())
+    return dmin, dmax
+
+
 def publish_prepared(weight):
     """A freshly prepared (packed / folded) operand goes into a cache that EVERY stream reads: the forwards run some layers on
     side streams (feature pyramids, RED-Net's conv-GRU levels), so the stream that prepared it waits for the preparation once --

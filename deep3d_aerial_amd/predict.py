@@ -379,7 +379,10 @@ def predict_views(model, dataset, output_folder, rank=0, world_size=1, device="c
                 imgs, keys = _item_views(s, model, device)
                 pm = {k: torch.from_numpy(np.ascontiguousarray(v))[None].to(device)
                       for k, v in s["proj_matrices"].items()}
-                dv = torch.from_numpy(np.ascontiguousarray(s["depth_values"]))[None].to(device)
+                dvh = np.ascontiguousarray(s["depth_values"])
+                dv = torch.from_numpy(dvh)[None].to(device)
+                from . import ops as _ops
+                _ops.note_depth_range(dv, dvh.reshape(-1)[0], dvh.reshape(-1)[-1])   # the forward then never waits for the previous view
                 out = model(imgs, pm, dv, image_keys=keys)
                 depth = out["depth"].squeeze().float().contiguous()
                 prob = out["photometric_confidence"].squeeze().float().contiguous()

@@ -251,3 +251,24 @@ def test_pack_conv2d_5x5_fragments():
     taps = [(ky - 2, kx - 2) for ky in range(5) for kx in range(5)]
     want = F.conv2d(torch.from_numpy(x).double()[None], torch.from_numpy(w).double(), stride=2, padding=2)[0].numpy()
     assert np.abs(conv_from_B(x, B, taps, 16, (5, 6), stride=2) - want).max() <= 1e-4
+
+
+def test_noted_depth_range_is_used_until_the_tensor_changes():
+    """ops.note_depth_range / depth_range_host: the drivers take (dmin, dmax) from the host pair a caller left for THIS tensor
+    (predict_views, bench.py: no device -> host copy per view), and read the tensor again once it was written to, or for any
+    other tensor."""
+    import torch
+    from deep3d_aerial_amd import ops
+
+    dv = torch.tensor([[400.0, 800.0]])
+    assert ops.depth_range_host(dv) == (400.0, 800.0)            # nothing noted: read from the tensor
+    ops.note_depth_range(dv, 1.0, 2.0)
+    assert ops.depth_range_host(dv) == (1.0, 2.0)                # the noted pair (deliberately not the tensor's: proves which one is used)
+    other = dv.clone()
+    assert ops.depth_range_host(other) == (400.0, 800.0)         # another tensor: its own values
+    dv[0, 0] = 500.0                                             # written to: the note is stale
+    assert ops.depth_range_host(dv) == (500.0, 800.0)
+    n = len(ops._depth_ranges)
+    ops.note_depth_range(other, 3.0, 4.0)
+    del other
+    assert len(ops._depth_ranges) <= n                           # a dead tensor's note goes with it

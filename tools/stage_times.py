@@ -16,6 +16,8 @@ s = predict.SyntheticBlock(1, 5, 2752, 1856, 384)[0]
 imgs = torch.from_numpy(s["imgs"])[None].cuda()
 pm = {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()}
 dv = torch.from_numpy(s["depth_values"])[None].cuda()
+if os.environ.get("STAGE_NO_NOTE") != "1":   # as predict.predict_views hands the range over (no host sync per view); STAGE_NO_NOTE=1: the forward reads it back
+    ops.note_depth_range(dv, s["depth_values"][0], s["depth_values"][-1])
 ops.set_conv_precision("h16")
 marks, open_ = [], []
 mods = list(net.DepthNet) if isinstance(net.DepthNet, torch.nn.ModuleList) else [net.DepthNet]
