@@ -62,6 +62,7 @@ SIGNATURES = {
     "d3d_conv2d_k3_zs_bf16x3": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_avgpool2d_4_8": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "d3d_conv3x3_bias_border": [_vp, _vp, _i, _i, _i, _vp],
+    "d3d_conv2d_k1_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv1x1_context": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3_wide_h16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],

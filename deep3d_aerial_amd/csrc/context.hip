@@ -148,6 +148,44 @@ __global__ __launch_bounds__(256) void conv3x3_bias_border_kernel(float* __restr
     out[((size_t)co * H + y) * W + x] -= miss;
 }
 
+// Plain 1 x 1 convolution in exact fp32 (the output layers of the feature pyramids, module.py:677-679 / 701-703 and their UNet
+// siblings): a streaming kernel -- a thread owns four consecutive pixels of the flattened plane and a block of 8 output channels
+// (blockIdx.y), reads the CI input planes with 16-byte loads (re-read per block of 8, from L2) and keeps 32 accumulators; weights
+// [CI][CO8 blocks] arrive through scalar loads.  out = act(scale * conv + shift) (+ skip, added last).  Round 5: these three layers
+// per image were the last users of round 1's conv_stream_kernel in a RED-Net / CasMVSNet view (0.9 - 2.2 TB/s there).
+template <int CI>
+__global__ __launch_bounds__(256) void conv1x1_f32_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ skip, int act, int Co, long plane,
+                                                          float* __restrict__ out) {
+    const long o = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (o >= plane) return;
+    const int co0 = blockIdx.y * 8;
+    cfloat* w = (cfloat*)wt + (size_t)blockIdx.y * CI * 8;   // [block][CI][8]: uniform indices -> scalar loads
+    f4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (f4){0, 0, 0, 0};
+#pragma unroll 8
+    for (int ci = 0; ci < CI; ++ci) {
+        const f4 v = *reinterpret_cast<const f4*>(in + ci * plane + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float wj = w[ci * 8 + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[j][k] = fmaf(wj, v[k], acc[j][k]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = co0 + j;
+        if (co >= Co) break;
+        f4 y = acc[j] * (scale ? scale[co] : 1.0f) + (shift ? shift[co] : 0.0f);
+        if (act == 1) y = __builtin_elementwise_max(y, (f4){0, 0, 0, 0});
+        if (skip) y = y + *reinterpret_cast<const f4*>(skip + co * plane + o);
+        *reinterpret_cast<f4*>(out + co * plane + o) = y;
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -189,6 +227,28 @@ extern "C" int d3d_conv1x1_context(const float* f, int Ci, const float* weight, 
     else if (Ci == 16) hipLaunchKernelGGL((conv1x1_context_kernel<16, 8>), grid, dim3(256), 0, st, f, weight, a, Ha, Wa, b, Hb, Wb, H, W, out);
     else hipLaunchKernelGGL((conv1x1_context_kernel<32, 8>), grid, dim3(256), 0, st, f, weight, a, Ha, Wa, b, Hb, Wb, H, W, out);
     D3D_LAUNCH_CHECK("conv1x1_context_kernel launch");
+    return D3D_OK;
+}
+
+// out [Co,H,W] = act(scale * Conv1x1(in) + shift) (+ skip, added last) in exact fp32.  in [Ci,H,W], Ci = 8 | 16 | 32; wt = the weight
+// as [ceil(Co / 8)][Ci][8] (ops._pack_k1: blocks of 8 output channels, zero-padded); H * W a multiple of 4, 16-byte aligned tensors,
+// else D3D_ERR_UNSUPPORTED (nothing launched).
+extern "C" int d3d_conv2d_k1_f32(const float* in, const float* wt, const float* scale, const float* shift, const float* skip, int act,
+                                 int Ci, int Co, int H, int W, float* out, d3d_stream_t stream) {
+    D3D_REQUIRE(in && wt && out, "null pointer");
+    D3D_REQUIRE(H > 0 && W > 0 && Co > 0, "bad dims");
+    D3D_REQUIRE(act == 0 || act == 1, "bad act %d", act);
+    const long plane = (long)H * W;
+    if ((Ci != 8 && Ci != 16 && Ci != 32) || Co > 64 * 8 || plane % 4 != 0 || !aligned16(in) || !aligned16(out) || (skip && !aligned16(skip))) {
+        set_error("d3d_conv2d_k1_f32: C_in = %d (8 | 16 | 32), H * W = %ld (a multiple of 4), 16-byte aligned tensors: not taken", Ci, plane);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)ceil_div(plane / 4, 256), (unsigned)ceil_div(Co, 8));
+    hipStream_t st = (hipStream_t)stream;
+    if (Ci == 8) hipLaunchKernelGGL((conv1x1_f32_kernel<8>), grid, dim3(256), 0, st, in, wt, scale, shift, skip, act, Co, plane, out);
+    else if (Ci == 16) hipLaunchKernelGGL((conv1x1_f32_kernel<16>), grid, dim3(256), 0, st, in, wt, scale, shift, skip, act, Co, plane, out);
+    else hipLaunchKernelGGL((conv1x1_f32_kernel<32>), grid, dim3(256), 0, st, in, wt, scale, shift, skip, act, Co, plane, out);
+    D3D_LAUNCH_CHECK("conv1x1_f32_kernel launch");
     return D3D_OK;
 }
 

@@ -2073,11 +2073,44 @@ def conv2d_same(x, weight, scale=None, shift=None, skip=None, act=0, stride=1):
     Co, Ci = weight.shape[0], weight.shape[1]
     if x.shape[0] != Ci or Co > 64 or not _use_mfma():
         return None
+    if weight.shape[2] == 1 and stride == 1 and conv_precision() != "h16" and not _cfg.off("conv2d_k1"):
+        y = conv2d_k1(x, weight, scale, shift, skip, act)
+        if y is not None:
+            return y
     if weight.shape[2] == 5 and stride == 2 and conv_precision() != "h16":
         y = conv2d_k5s2_zs(x, weight, scale, shift, skip, act)
         if y is not None:
             return y
     return conv_fold(x, weight, scale, shift, skip, act, stride, None, True, transposed=False)
+
+
+def _pack_k1(w):
+    """[Co,Ci,1,1] -> [ceil(Co / 8)][Ci][8]: blocks of 8 output channels, zero-padded (d3d_conv2d_k1_f32)."""
+    Co, Ci = w.shape[0], w.shape[1]
+    nb = (Co + 7) // 8
+    wp = w.new_zeros((nb * 8, Ci))
+    wp[:Co] = w.reshape(Co, Ci)
+    return wp.reshape(nb, 8, Ci).permute(0, 2, 1).contiguous()
+
+
+def conv2d_k1(x, weight, scale=None, shift=None, skip=None, act=0):
+    """Conv2d(k 1) in exact fp32 as a streaming kernel (d3d_conv2d_k1_f32: the 1 x 1 output layers of the feature pyramids);
+    act(scale * conv + shift) + skip.  None for shapes it does not take."""
+    Ci, H, W = x.shape
+    Co = weight.shape[0]
+    if Ci not in (8, 16, 32) or (H * W) % 4 or act not in (0, 1) or tuple(weight.shape) != (Co, Ci, 1, 1):
+        return None
+    wp = derived_weight(weight, "k1f32", _pack_k1)
+    out = torch.empty((Co, H, W), dtype=torch.float32, device=x.device)
+    if skip is not None and skip.shape != out.shape:
+        raise ValueError("skip shape mismatch")
+    rc = _lib.load().d3d_conv2d_k1_f32(_chk(x, "x", 3), _chk(wp, "wpacked"), _opt(scale, "scale"), _opt(shift, "shift"), _opt(skip, "skip"),
+                                       int(act), Ci, Co, H, W, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k1_f32")
+    dispatch_counts["conv2d_k1"] += 1
+    return out
 
 
 def conv2d_k5s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after_act=True):

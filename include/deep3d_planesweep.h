@@ -415,6 +415,13 @@ int d3d_conv2d_k3_zs_bf16x3(const float* in, int C1, const float* in2, int C2, c
  * convolution commutes with the resize), so neither the upsampled branches nor the concat reach HBM.
  * Ci == Co in 8 | 16 | 32, W % 4 == 0, 3 Wa <= W, 3 Wb <= W; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
 int d3d_avgpool2d_4_8(const float* in, int C, int H, int W, float* out4, float* out8, d3d_stream_t stream);
+/* module.py:677-679, 701-703 (the 1 x 1 output layers of the feature pyramids) as a streaming kernel in exact fp32 (ABI 10):
+ * out [Co,H,W] = act(scale * Conv1x1(in) + shift) (+ skip, added last).  in [Ci,H,W], Ci = 8 | 16 | 32; wt = the nn.Conv2d weight
+ * re-laid as [ceil(Co / 8)][Ci][8] (blocks of 8 output channels, zero-padded: ops._pack_k1); act 0 | 1 (ReLU); scale / shift / skip
+ * may be null.  H * W a multiple of 4 and 16-byte aligned tensors, else D3D_ERR_UNSUPPORTED (nothing launched). */
+int d3d_conv2d_k1_f32(const float* in, const float* wt, const float* scale, const float* shift, const float* skip, int act,
+                      int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+
 /* out [Co,H,W] -= sum over the 3x3 taps whose source pixel lies OUTSIDE the image of taps[Co,3,3]: the border correction of a
  * bias that was added to the input of a zero-padded 3x3 convolution and folded into the layer's constant (module.fpn_output:
  * the lateral bias of the last FPN level, module.py:745-747 of the reference).  In place, border pixels only. */

@@ -1067,6 +1067,33 @@ def test_gru2_split_passes_are_the_two_output_pair(ops, oracle, mode, Hc, h, w):
     assert np.abs(host(out1) - oracle.gru_update(u_want, hh, oracle.groupnorm1(o, host(go), host(bo)))).max() <= 4e-6
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,act,skip,affine", [(8, 8, 64, 96, 0, False, False), (16, 16, 37, 52, 1, True, True), (32, 32, 58, 86, 0, False, True),
+                                                        (32, 16, 9, 12, 1, False, True), (16, 8, 21, 20, 0, True, False), (8, 4, 30, 44, 1, False, True),
+                                                        (8, 8, 7, 5, 0, False, False)])
+def test_conv1x1_streaming_kernel(ops, Ci, Co, H, W, act, skip, affine):
+    """d3d_conv2d_k1_f32 (the 1 x 1 output layers of the feature pyramids, module.py:677-679, 701-703, in exact fp32 as a streaming
+    kernel): against float64 on the same operands, through the route the pyramids take (ops.conv2d_same); planes that are not a
+    multiple of 4 pixels are declined and served by the kernel of rounds 1-4."""
+    rng = np.random.default_rng(Ci * 100 + Co + H)
+    x = rng.standard_normal((Ci, H, W)).astype(np.float32)
+    w = (0.3 * rng.standard_normal((Co, Ci, 1, 1))).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Co).astype(np.float32) if affine else None
+    sh = rng.standard_normal(Co).astype(np.float32) if affine else None
+    sk = rng.standard_normal((Co, H, W)).astype(np.float32) if skip else None
+    want = np.einsum("oc,chw->ohw", w[:, :, 0, 0].astype(np.float64), x.astype(np.float64))
+    if affine:
+        want = want * sc[:, None, None].astype(np.float64) + sh[:, None, None]
+    if act:
+        want = np.maximum(want, 0)
+    if skip:
+        want = want + sk
+    ops.dispatch_counts.clear()
+    with ops.fp32_convs():
+        got = ops.conv2d_same(dev(x), dev(w), None if sc is None else dev(sc), None if sh is None else dev(sh), None if sk is None else dev(sk), act)
+    assert ops.dispatch_counts.get("conv2d_k1", 0) == (0 if (H * W) % 4 else 1)
+    assert np.abs(host(got) - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+
+
 def test_pairnet_golden(ops, convpath):
     from deep3d_aerial_amd.adamvs import CostRegNet2D
 
