@@ -176,17 +176,12 @@ def h16_format():
     return load().d3d_h16_format().decode("ascii")
 
 
-def kernel_code_sha256(symbol_prefix, path=None):
-    """SHA-256 of the gfx950 machine code of ONE kernel in the built library: the bytes of the (unique) function symbol whose
-    mangled name starts with `symbol_prefix`, read from the code objects bundled in the .so's .hip_fatbin section.  A counter
-    profile of a kernel stays valid exactly as long as this hash does -- an edit elsewhere in the same source file does not
-    invalidate it, a change of compiler flags does (bench.profiled_traffic, tools/profile_round.sh).  None if not found."""
-    import hashlib
+def code_objects(path=None):
+    """The gfx950 code objects (ELF images, as bytes) bundled in the built library's .hip_fatbin section."""
     import struct
 
     data = open(path or SO_PATH, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    found = []
     pos = data.find(magic)
     while pos >= 0:
         n = struct.unpack_from("<Q", data, pos + 24)[0]
@@ -198,25 +193,37 @@ def kernel_code_sha256(symbol_prefix, path=None):
             if b"amdgcn" not in triple or size == 0:
                 continue
             elf = data[pos + off:pos + off + size]
-            if elf[:4] != b"\x7fELF":
-                continue
-            shoff, = struct.unpack_from("<Q", elf, 0x28)
-            shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
-            secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
-            for sh in secs:
-                if sh[1] != 2:   # SHT_SYMTAB
-                    continue
-                strtab = secs[sh[6]]
-                for k in range(sh[5] // sh[9]):
-                    st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, sh[4] + k * sh[9])
-                    if (st_info & 0xF) != 2 or st_size == 0 or st_shndx >= len(secs):   # STT_FUNC
-                        continue
-                    end = elf.index(b"\0", strtab[4] + st_name)
-                    if elf[strtab[4] + st_name:end].decode("ascii", "replace").startswith(symbol_prefix):
-                        sec = secs[st_shndx]
-                        o = sec[4] + (st_value - sec[3])
-                        found.append(hashlib.sha256(elf[o:o + st_size]).hexdigest())
+            if elf[:4] == b"\x7fELF":
+                yield elf
         pos = data.find(magic, pos + len(magic))
+
+
+def kernel_code_sha256(symbol_prefix, path=None):
+    """SHA-256 of the gfx950 machine code of ONE kernel in the built library: the bytes of the (unique) function symbol whose
+    mangled name starts with `symbol_prefix`, read from the code objects bundled in the .so's .hip_fatbin section.  A counter
+    profile of a kernel stays valid exactly as long as this hash does -- an edit elsewhere in the same source file does not
+    invalidate it, a change of compiler flags does (bench.profiled_traffic, tools/profile_round.sh).  None if not found."""
+    import hashlib
+    import struct
+
+    found = []
+    for elf in code_objects(path):
+        shoff, = struct.unpack_from("<Q", elf, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + i * shentsize) for i in range(shnum)]
+        for sh in secs:
+            if sh[1] != 2:   # SHT_SYMTAB
+                continue
+            strtab = secs[sh[6]]
+            for k in range(sh[5] // sh[9]):
+                st_name, st_info, _, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", elf, sh[4] + k * sh[9])
+                if (st_info & 0xF) != 2 or st_size == 0 or st_shndx >= len(secs):   # STT_FUNC
+                    continue
+                end = elf.index(b"\0", strtab[4] + st_name)
+                if elf[strtab[4] + st_name:end].decode("ascii", "replace").startswith(symbol_prefix):
+                    sec = secs[st_shndx]
+                    o = sec[4] + (st_value - sec[3])
+                    found.append(hashlib.sha256(elf[o:o + st_size]).hexdigest())
     return found[0] if len(found) == 1 else None
 
 

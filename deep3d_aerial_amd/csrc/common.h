@@ -179,6 +179,20 @@ inline int pick_zper(long tiles_xy, int D, int min_planes, int halo, int lds_byt
 #endif
 }
 
+// gfx950: the data registers of a 12- / 16-byte buffer store are still being read when the NEXT vector instructions issue.  LLVM's
+// hazard recognizer inserts the wait states only when the store's soffset is an immediate (GCNHazardRecognizer::createsVALUHazard:
+// "this hazard only exists if the instruction is not using a register in the soffset field"); with an SGPR soffset nothing is
+// inserted, and on this chip a store followed at once by an instruction that overwrites its data registers puts the NEW values of
+// lanes 12-15 of each row of 16 (second dword) into memory -- found in round 5 as the "nondeterministic" stride-2 fused conv-GRU
+// cell with 8-row tiles (tools/gru2_debug.py; the stride-1 cells had the same sequence, on lanes whose stores are dropped).  The
+// empty asm keeps the stored registers alive behind two wait states; tools/store_hazard_scan.py (a CPU test runs it on the built
+// library) looks for the pattern in every kernel.
+typedef unsigned d3d_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buffer_store_b128_guarded(d3d_u4 data, __amdgpu_buffer_rsrc_t rsrc, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, 0);
+    asm volatile("s_nop 1" : : "v"(data) : "memory");
+}
+
 // Workgroup barrier for data handed over through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the
 // fence waits for EVERY memory operation the wave has in flight (s_waitcnt vmcnt(0)): the global stores of the plane just
 // finished and the global loads issued ahead for a later plane -- a z-streaming kernel then pays a store's round trip per

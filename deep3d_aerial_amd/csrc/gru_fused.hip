@@ -449,7 +449,7 @@ __global__ __launch_bounds__(GNT, (GruGeom<CP, HID, S, MG, TY>::LDS <= 80 * 1024
                 const f4 u = ukeep[t], hq = hkeep[t];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) y[k] = u[k] * hq[k] + (1.0f - u[k]) * gru_tanh(y[k]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, y), ro, gy < H ? st_c : OOB, t * 2 * W * 4, 0);
+                buffer_store_b128_guarded(__builtin_bit_cast(u4, y), ro, gy < H ? st_c : OOB, t * 2 * W * 4);   // (common.h: gfx950 store-data hazard)
             }
         }
         lds_barrier();   // P3 has read X and R: the next tile's P1 may overwrite X
@@ -487,7 +487,7 @@ const char* gru_build_flags() {
 #if D3D_GRU_WAVES2 != 4
            " D3D_GRU_WAVES2"
 #endif
-#if defined(D3D_GRU2_TY) && D3D_GRU2_TY != 4
+#if defined(D3D_GRU2_TY) && D3D_GRU2_TY != 8
            " D3D_GRU2_TY"
 #endif
         ;
@@ -525,12 +525,12 @@ extern "C" int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI,
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }
 #ifndef D3D_GRU2_TY
-#define D3D_GRU2_TY 4   // tile rows of the stride-2 cell.  OPEN LEAD (round 5): 8-row tiles are 10 - 24 % faster (the 2 x stride input patch
-                        // makes the halo expensive: 129 x 17 input pixels per 56 x 4 outputs = 2.45 x, 129 x 25 per 56 x 8 = 1.8 x) -- 20.1 ->
-                        // 15.3 / 57.2 -> 49.4 / 175.5 -> 158.5 us at the three stages, tools/cl8_cell_bench.py -- but NOT bit-identical to
-                        // the three launches: with more than two core tasks per wave (TY = 6 | 8) the middle tasks' second pixel of every
-                        // quad is wrong in output channels 12 - 15, a little differently from run to run (tools/gru2_debug.py); no spill,
-                        // not the prefetch, not addresses beyond 64 KB.  Unresolved: production stays at 4.
+#define D3D_GRU2_TY 8   // tile rows of the stride-2 cell: the 2 x stride input patch makes the halo expensive (129 x 17 input pixels per 56 x 4
+                        // outputs = 2.45 x, 129 x 25 per 56 x 8 = 1.8 x): 8 rows are 10 - 24 % faster than 4 (20.1 -> 15.3 / 57.2 -> 49.4 /
+                        // 175.5 -> 158.5 us at the three stages).  Rounds 4-5 ran 4 rows because 8 were "not bit-identical, a little
+                        // differently from run to run" in output channels 12-15: the store-data hazard of gfx950 that LLVM does not
+                        // guard when the store's soffset is a register (common.h buffer_store_b128_guarded) -- with more than two core
+                        // tasks per wave the next task's first packed add overwrote the registers of the store just issued.
 #endif
     if (stride == 2 && HID == 16 && CP == 8) return launch_gru<8, 16, 2, 4, D3D_GRU2_TY>(p, st);
     set_error("d3d_gru_cell_fused_h16: C = %d, hidden = %d, stride = %d not taken (8 | 16 | 32 -> 8 at stride 1; 8 -> 16 at stride 2)", CP, HID, stride);

@@ -34,3 +34,31 @@ def test_asm_mix_counts_a_listing(tmp_path):
     out = subprocess.run([sys.executable, tool, str(listing), "kern"], capture_output=True, text=True, check=True).stdout
     assert "kernel: 2 vector (1 mfma) 3 scalar 1 ds 1 global" in out
     assert "after the first barrier: 1 vector (1 mfma) 2 scalar 1 ds 1 global" in out
+
+
+def test_store_hazard_scan_finds_the_pattern_and_the_library_is_clean():
+    """tools/store_hazard_scan.py (round 5): gfx950 still reads the data registers of a 12- / 16-byte buffer store with an SGPR
+    soffset when the next vector instructions issue, LLVM guards only an immediate soffset, and an overwrite right behind such a
+    store stored garbage in lanes 12-15 (the stride-2 fused conv-GRU cell with 8-row tiles; csrc/common.h
+    buffer_store_b128_guarded).  The scanner flags the sequence in a listing -- not the guarded, the immediate-soffset or the
+    unrelated ones -- and the production library does not contain it in any kernel."""
+    import pytest
+    import store_hazard_scan as H
+
+    bad = ["0000 <_Zk1>:", "\tbuffer_store_dwordx4 v[106:109], v110, s[24:27], s66 offen", "\tv_pk_add_f32 v[106:107], v[142:143], v[200:201]", "\ts_endpgm"]
+    n, hits = H.scan_listing(bad)
+    assert n == 1 and len(hits) == 1 and hits[0][0] == "_Zk1" and hits[0][3] == 0
+    one_slot = ["0000 <_Zk2>:", "\tbuffer_store_dwordx3 v[4:6], v9, s[0:3], s7 offen offset:16", "\tv_mov_b32_e32 v20, v21", "\tv_exp_f32_e32 v5, v30"]
+    assert len(H.scan_listing(one_slot)[1]) == 1 and H.scan_listing(one_slot)[1][0][3] == 1
+    fine = ["0000 <_Zk3>:",
+            "\tbuffer_store_dwordx4 v[106:109], v110, s[24:27], s66 offen", "\ts_nop 1", "\tv_pk_add_f32 v[106:107], v[142:143], v[200:201]",   # guarded
+            "\tbuffer_store_dwordx4 v[10:13], v14, s[24:27], 0 offen", "\tv_mov_b32_e32 v10, 0",                # immediate soffset: LLVM's own wait states
+            "\tbuffer_store_dwordx4 v[20:23], v24, s[24:27], s5 offen", "\tv_mov_b32_e32 v30, 0", "\tv_mov_b32_e32 v31, 0", "\tv_mov_b32_e32 v20, 0",
+            "\tbuffer_store_dwordx2 v[40:41], v24, s[24:27], s5 offen", "\tv_mov_b32_e32 v40, 0",              # 8 bytes: no hazard
+            "\tbuffer_store_dwordx4 v[50:53], v54, s[24:27], s5 offen", "\tds_write_b64 v50, v[60:61]", "\tv_cmp_gt_u32_e32 vcc, v50, v51", "\ts_endpgm"]
+    n, hits = H.scan_listing(fine)
+    assert n == 3 and hits == []
+    if not os.path.exists(H.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    n, hits = H.scan_library()
+    assert n > 0 and hits == [], hits

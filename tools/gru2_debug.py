@@ -4,6 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deep3d_aerial_amd import ops
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+MODE = os.environ.get("GRU2_MODE", "")   # "" | "nocand" (wc = 0, bc = 0: h' = u h) | "nostate" (h = 0: h' = (1 - u) tanh(c)) | "nogate" (wg = 0: r = u = sigmoid(bg))
 for (h, w) in [(272, 264), (135, 248), (64, 64)]:
     rng = np.random.default_rng(802)
     C, hid = 8, 16
@@ -12,6 +13,9 @@ for (h, w) in [(272, 264), (135, 248), (64, 64)]:
     w1 = dev(rng.standard_normal((hid, C, 3, 3)) / np.sqrt(9 * C))
     wg = dev(rng.standard_normal((2 * hid, 2 * hid, 3, 3)) / np.sqrt(18 * hid)); wc = dev(rng.standard_normal((hid, 2 * hid, 3, 3)) / np.sqrt(18 * hid))
     bg, bc = dev(rng.standard_normal(2 * hid)), dev(rng.standard_normal(hid))
+    if MODE == "nocand": wc.zero_(); bc.zero_()
+    if MODE == "nostate": state.zero_()
+    if MODE == "nogate": wg.zero_()
     with ops.h16_convs():
         outs = [ops.gru_cell_conv_fused(cost, state, w1, wg, bg, wc, bc, 2) for _ in range(3)]
         x = ops.conv2d_s2_zs(cost, w1, None, None, None, 1)
