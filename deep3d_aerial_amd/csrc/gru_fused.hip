@@ -495,6 +495,10 @@ const char* gru_build_flags() {
 
 }  // namespace d3d
 
+#ifndef D3D_GRU1_TY
+#define D3D_GRU1_TY 8   // tile rows of the 8-channel stride-1 cell (the last cascade stage)
+#endif
+
 using namespace d3d;
 
 // relu(conv3x3(cost)) -> conv-GRU cell, one launch (bf16 matrix-core operands, fp32 accumulation and state).
@@ -520,7 +524,7 @@ extern "C" int d3d_gru_cell_fused_h16(const float* cost, int CP, int HI, int WI,
     p.wc = reinterpret_cast<const u4*>(wc); p.bg = bg; p.bc = bc; p.H = H; p.W = W; p.HI = HI; p.WI = WI;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1 && HID == 8) {
-        if (CP == 8) return launch_gru<8, 8, 1, 4, 8>(p, st);   // (12- / 16-row tiles at one workgroup per CU: 306 / 283 against 244-254 us at stage 3)
+        if (CP == 8) return launch_gru<8, 8, 1, 4, D3D_GRU1_TY>(p, st);   // (12- / 16-row tiles at one workgroup per CU: 306 / 283 against 244-254 us at stage 3)
         if (CP == 16) return launch_gru<16, 8, 1, 4, 8>(p, st);
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8>(p, st);
     }
@@ -556,7 +560,7 @@ extern "C" int d3d_gru_cell_fused_cl8_h16(const void* cost_cl8, int CP, const fl
     p.wc = reinterpret_cast<const u4*>(wc); p.bg = bg; p.bc = bc; p.H = H; p.W = W; p.HI = H; p.WI = W;
     hipStream_t st = (hipStream_t)stream;
     if (HID == 8) {
-        if (CP == 8) return launch_gru<8, 8, 1, 4, 8, true>(p, st);
+        if (CP == 8) return launch_gru<8, 8, 1, 4, D3D_GRU1_TY, true>(p, st);
         if (CP == 16) return launch_gru<16, 8, 1, 4, 8, true>(p, st);
         if (CP == 32) return launch_gru<32, 8, 1, 4, 8, true>(p, st);
     }
