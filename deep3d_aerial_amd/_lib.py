@@ -86,6 +86,7 @@ SIGNATURES = {
     "d3d_convtranspose2d_k3s2_wide_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3_pair3_bf16x3": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "d3d_slice_tail_regress_h16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "d3d_slice_tail_regress_same_h16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_conv3d_k3s2_zs_bf16x3": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_convtranspose3d_prob_cl_h16": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
     "d3d_volume_planar_to_cl_h16": [_vp, _i, _sz, _vp, _vp],

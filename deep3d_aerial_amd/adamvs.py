@@ -215,6 +215,9 @@ class SliceCostRegNetRED(nn.Module):
         if self.up:
             return ops.slice_tail_regress(s2, self.upconv1.weight, self.upconv1.bias, s1, self.upconv2d.weight, self.upconv2d.bias,
                                           dplane, max_p, sum_d, sum_p)
+        if ops.slice_tail_regress_same(s2, self.upconv1.weight, self.upconv1.bias, s1, False, self.upconv2d.weight, self.upconv2d.bias,
+                                       dplane, max_p, sum_d, sum_p):   # (last stage: the head keeps `up`'s resolution)
+            return True
         up = ops.convtranspose2d_k3s2(s2, self.upconv1.weight, None, self.upconv1.bias, s1, skip_after_act=False, act=1)
         return ops.slice_head_regress(up, self.upconv2d.weight, self.upconv2d.bias, self.up, dplane, max_p, sum_d, sum_p)
 
@@ -229,8 +232,13 @@ class SliceCostRegNetRED(nn.Module):
                     return s1, s2
                 up = ops.convtranspose2d_k3s2(s2, self.upconv1.weight, None, self.upconv1.bias, s1, skip_after_act=False, act=1)
                 state1, state2 = s1, s2
-            else:
-                up, state1, state2 = self._trunk(cost, state1, state2)
+            else:         # (last stage: the same with the head at `up`'s resolution)
+                s1, s2 = self._cells(cost, state1, state2)
+                if ops.slice_tail_regress_same(s2, self.upconv1.weight, self.upconv1.bias, s1, False, self.upconv2d.weight,
+                                               self.upconv2d.bias, dplane, max_p, sum_d, sum_p):
+                    return s1, s2
+                up = ops.convtranspose2d_k3s2(s2, self.upconv1.weight, None, self.upconv1.bias, s1, skip_after_act=False, act=1)
+                state1, state2 = s1, s2
             if not ops.slice_head_regress(up, self.upconv2d.weight, self.upconv2d.bias, self.up, dplane, max_p, sum_d, sum_p):
                 ops.online_regress_update(self._head(up)[0], dplane, max_p, sum_d, sum_p)
         return state1, state2

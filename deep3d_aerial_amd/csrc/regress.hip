@@ -433,6 +433,10 @@ typedef unsigned u4t __attribute__((ext_vector_type(4)));
 constexpr int CI = 16, TXI = 32, TYI = 8, PXI = TXI + 1, PYI = TYI + 1, CS = 32;   // state2 tile, staged patch, bytes per cell
 constexpr int NT = 64 * TYI;
 constexpr int SX = TXI - 1, SY = TYI - 1;                    // tile step in state2 pixels
+// SAME-resolution head (round 5: adamvs.py's last stage, msrednet.py:361-363 -- Conv2d(8, 1, 3, pad 1) on `up`): the head reaches one `up`
+// pixel to every side, so the patch starts one state2 pixel up and to the left of the tile and a tile's outputs are the `up` pixels
+// [60 bx, 60 bx + 60) x [14 by - 1, 14 by + 13) -- whole aligned quads per row (tiles step by 30 x 7 state2 pixels).
+constexpr int SXS = 30;
 constexpr int PATCH = PXI * PYI * CS;
 constexpr int UW = 2 * TXI, UH = 2 * TYI;                    // `up` region in LDS: 16-byte cells (8 channels)
 constexpr int UBYTES = UW * UH * 16;
@@ -450,16 +454,19 @@ struct Params {
     const float* wh;      // [8][3][3] head weights, already rounded to bf16 (host)
     const float* bh;      // [1]
     const float* dplane;
-    float *max_p, *sum_d, *sum_p;   // [4h, 4w]
+    float *max_p, *sum_d, *sum_p;   // [4h, 4w] (transposed head) | [2h, 2w] (same-resolution head)
     int hd, wd, h, w, tper;
+    int skip_after;       // 0: up = relu(upconv1 + b + s1) (adamvs.py:413-416); 1: up = relu(upconv1 + b) + s1 (module.py:287-294 ConvTransReLU + skip)
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* origin) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(origin), 0, (int)0xfffffffeu, 0x00020000);
 }
 }  // namespace tail
 
+template <bool TH>   // TH: the head is the stride-2 ConvTranspose2d (stages that up-sample); else Conv2d(8, 1, 3, pad 1) at `up`'s resolution
 __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p) {
     using namespace tail;
+    constexpr int STX = TH ? SX : SXS, ORG = TH ? 0 : 1;   // tile step along x; patch origin = tile origin - ORG state2 pixels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const ubuf = smem;                         // first: its cell offsets fit the DS instructions' immediates
     unsigned char* const pbuf = smem + UBYTES;
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = p.h, w = p.w, H = 2 * h, W = 2 * w;
     const unsigned plane4 = (unsigned)h * w * 4, uplane4 = (unsigned)H * W * 4;   // (host: tensors < 2^31 bytes)
-    const int ix0 = blockIdx.x * SX;
-    const int nty = (h + SY - 1) / SY;
+    const int ix0 = blockIdx.x * STX - ORG;
+    const int nty = TH ? (h + SY - 1) / SY : (h + SY) / SY;   // (same-resolution head: the last tile's outputs end at `up` row 14 by + 12)
     const int t0 = blockIdx.y * p.tper, t1 = min(t0 + p.tper, nty);
     for (int i = tid; i < NFRAG * 64; i += NT) wlds[i] = p.wup[i];
 
@@ -482,18 +489,18 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
         const int task = tid + r * NT;
         const int pix = task >> 1, g = task & 1;
         const int py = pix / PXI, px = pix - py * PXI;
-        svo[r] = task < NTASK && ix0 + px < w ? (unsigned)(8 * g) * plane4 + (unsigned)(py * w + px) * 4 : OOB;
+        svo[r] = task < NTASK && ix0 + px >= 0 && ix0 + px < w ? (unsigned)(8 * g) * plane4 + (unsigned)(py * w + px) * 4 : OOB;
         spy[r] = py;
         scell[r] = task < NTASK ? pix * CS + g * 16 : -1;
     }
     auto issue = [&](int ty) {
-        const int iy0 = ty * SY;
-        const bool inner = iy0 + PYI <= h;
-        const __amdgpu_buffer_rsrc_t rs = rsrc(p.s2 + ((long)iy0 * w + ix0));
+        const int iy0 = ty * SY - ORG;
+        const bool inner = iy0 >= 0 && iy0 + PYI <= h;
+        const __amdgpu_buffer_rsrc_t rs = rsrc(p.s2 + ((long)iy0 * w + ix0));   // (may lie before the tensor: those lanes carry OOB offsets)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             unsigned vo = svo[r];
-            if (!inner) vo = spy[r] + iy0 < h ? vo : OOB;
+            if (!inner) vo = (unsigned)(spy[r] + iy0) < (unsigned)h ? vo : OOB;
 #pragma unroll
             for (int k = 0; k < 8; ++k) stg[r][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, k * plane4, 0));
         }
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
         }
     // D row = state2 pixel 4 kg + register, column = channel m: the lane's eight `up` pixels 2 (16 mg + 4 kg) .. + 7 of rows 2 wave + PY
     const bool chan = m < 8;
-    const float bup = chan ? p.bup[m] : 0.0f;
+    const float bup = chan && p.bup ? p.bup[m] : 0.0f;
     // state1 / `up` of the lane's pixels in PAIRS (tiles step by 31 state2 pixels, so a lane's eight pixels may straddle the right
     // edge; W is even): byte offset of pair j from the tile origin of an `up` row pair, OOB where the pair does not exist
     typedef float f2t __attribute__((ext_vector_type(2)));
@@ -532,18 +539,18 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
         const int xl = 2 * (16 * mg + 4 * kg);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            kvo[mg][j] = chan && 2 * ix0 + xl + 2 * j < W ? (unsigned)m * uplane4 + (unsigned)(2 * wave * W + xl + 2 * j) * 4 : OOB;
+            kvo[mg][j] = chan && 2 * ix0 + xl + 2 * j >= 0 && 2 * ix0 + xl + 2 * j < W ? (unsigned)m * uplane4 + (unsigned)(2 * wave * W + xl + 2 * j) * 4 : OOB;
         uwr[mg] = ((2 * wave) * UW + xl) * 16 + m * 2;
     }
     // ---- head: thread = two `up` pixels (yy, 2 q), (yy, 2 q + 1) of the first 62 columns x 14 rows -----------------------------
-    const int hq = tid % (SX), hy = tid / SX;                 // 31 pairs per row
-    const bool htask = tid < SX * 2 * SY;                     // 31 x 14 = 434 tasks
-    const int urd = (hy * UW + 2 * hq) * 16;
+    const int hq = TH ? tid % (SX) : tid % 15, hy = TH ? tid / SX : tid / 15;   // 31 pairs | 15 quads per row
+    const bool htask = TH ? tid < SX * 2 * SY : tid < 15 * 2 * SY;                 // 31 x 14 = 434 | 15 x 14 = 210 tasks
+    const int urd = TH ? (hy * UW + 2 * hq) * 16 : (hy * UW + 4 * hq + 1) * 16;     // same-resolution head: the cell left of the quad's first pixel, one row up
     const float bh = p.bh[0];
 
     auto tile = [&](int ty, const unsigned char* buf) {
-        const int iy0 = ty * SY, Y0 = 2 * iy0;
-        const bool rowin = iy0 + wave < h;                    // this wave's state2 row (= two `up` rows) exists
+        const int iy0 = ty * SY - ORG, Y0 = 2 * iy0;
+        const bool rowin = (unsigned)(iy0 + wave) < (unsigned)h;   // this wave's state2 row (= two `up` rows) exists
         const __amdgpu_buffer_rsrc_t rk = rsrc(p.s1 + ((long)Y0 * W + 2 * ix0));
         f2t sk[2][2][4];                                      // [PY][mg][pair]: state1 of the lane's pixels, requested before the GEMMs
 #pragma unroll
@@ -579,9 +586,11 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
             for (int mg = 0; mg < 2; ++mg) {
                 const f4t e = acc[0][mg] * 1.0f + bup, od = acc[1][mg] * 1.0f + bup;
                 f4t lo = {e[0], od[0], e[1], od[1]}, hi = {e[2], od[2], e[3], od[3]};
-                lo += (f4t){sk[PY][mg][0][0], sk[PY][mg][0][1], sk[PY][mg][1][0], sk[PY][mg][1][1]};
-                hi += (f4t){sk[PY][mg][2][0], sk[PY][mg][2][1], sk[PY][mg][3][0], sk[PY][mg][3][1]};
+                const f4t slo = {sk[PY][mg][0][0], sk[PY][mg][0][1], sk[PY][mg][1][0], sk[PY][mg][1][1]};
+                const f4t shi = {sk[PY][mg][2][0], sk[PY][mg][2][1], sk[PY][mg][3][0], sk[PY][mg][3][1]};
+                if (!p.skip_after) { lo += slo; hi += shi; }
                 lo = __builtin_elementwise_max(lo, (f4t){0, 0, 0, 0}); hi = __builtin_elementwise_max(hi, (f4t){0, 0, 0, 0});
+                if (p.skip_after) { lo = slo + lo; hi = shi + hi; }   // (ConvTransReLU, then the skip: the tile kernel's `skip + y`)
                 // zeros outside the image: what the head's bounds tests read there
                 unsigned q0 = pack_h16x2(lo[0], lo[1]), q1 = pack_h16x2(lo[2], lo[3]), q2 = pack_h16x2(hi[0], hi[1]), q3 = pack_h16x2(hi[2], hi[3]);
                 if (!rowin || kvo[mg][0] == OOB) q0 = 0;
@@ -604,6 +613,41 @@ __global__ __launch_bounds__(tail::NT, 2) void slice_tail_kernel(tail::Params p)
         rows(std::integral_constant<int, 0>{});
         rows(std::integral_constant<int, 1>{});
         lds_barrier();                                        // the `up` region is complete
+        if constexpr (!TH) {
+            if (htask) {
+                // outputs (Y, X .. X + 3) with X = 2 ix0 + 2 + 4 hq (a multiple of 4), Y = Y0 + 1 + hy; slice_head_regress_kernel<false>'s
+                // arithmetic in its order: channel, kernel row, then fma(right, k2, fma(mid, k1, fma(left, k0, o))).  (As 30 pairs per row
+                // on 420 threads with 8-byte accumulator accesses the kernel is slower: 187 against 175 us at the last stage.)
+                const int X = 2 * ix0 + 2 + 4 * hq, Y = Y0 + 1 + hy;
+                if (X < W && Y >= 0 && Y < H) {
+                    float o[4] = {0, 0, 0, 0};
+                    u4t c[3][6];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) c[ky][cc] = *reinterpret_cast<const u4t*>(ubuf + urd + (ky * UW + cc) * 16);
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            float a[6];
+#pragma unroll
+                            for (int cc = 0; cc < 6; ++cc) {
+                                const unsigned d = c[ky][cc][ch >> 1];
+                                a[cc] = (ch & 1) ? h16_hi(d) : h16_lo(d);
+                            }
+                            const float* __restrict__ k = p.wh + ch * 9 + ky * 3;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = fmaf(a[j + 2], k[2], fmaf(a[j + 1], k[1], fmaf(a[j], k[0], o[j])));
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = o[k] * 1.0f + bh;
+                    regress_row4(o, (long)Y * W + X, X, Y, p.dplane, p.hd, p.wd, H, W, p.max_p, p.sum_d, p.sum_p);
+                }
+            }
+            return;
+        }
         if (htask) {
             const int X = 2 * ix0 + 2 * hq, Y = Y0 + hy;      // the task's first `up` pixel
             if (X < W && Y < H) {
@@ -1102,7 +1146,7 @@ int d3d_slice_tail_regress_h16(const float* state2, const void* wup_packed, cons
         set_error("d3d_slice_tail_regress_h16: w = %d (a multiple of 4), 16-byte aligned maps and tensors below 2 GiB needed", w);
         return D3D_ERR_UNSUPPORTED;
     }
-    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(slice_tail_kernel), tail::LDS_BYTES);
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(slice_tail_kernel<true>), tail::LDS_BYTES);
     if (rc != D3D_OK) return rc;
     tail::Params p = {};
     p.s2 = state2; p.wup = reinterpret_cast<const tail::u4t*>(wup_packed); p.bup = bup; p.s1 = state1; p.wh = whead; p.bh = bhead;
@@ -1112,8 +1156,44 @@ int d3d_slice_tail_regress_h16(const float* state2, const void* wup_packed, cons
     p.tper = tper;
     const int gy = ceil_div(nty, tper);
     if (gy > 65535) return D3D_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(slice_tail_kernel, dim3(gx, gy), dim3(tail::NT), tail::LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(slice_tail_kernel<true>, dim3(gx, gy), dim3(tail::NT), tail::LDS_BYTES, (hipStream_t)stream, p);
     D3D_LAUNCH_CHECK("slice_tail_kernel launch");
+    return D3D_OK;
+}
+
+// The same tail with the head at `up`'s own resolution (adamvs.py:413-418 at the last stage; msrednet.py:361-363: upconv1 + skip,
+// upconv2d, and the update of msrednet.py:418-437): up = relu(ConvTranspose2d_16->8(state2) + bup + state1) or, with
+// skip_after_act, relu(ConvTranspose2d_16->8(state2) + bup) + state1 (module.py:287-294 ConvTransReLU followed by the skip);
+// reg = Conv2d(8, 1, 3, pad 1)(up) + bhead; accumulators [2h, 2w].  bup may be null.  whead: the nn.Conv2d [1,8,3,3] weights
+// [c][k_y][k_x] rounded to the 16-bit format.  Bit-identical to d3d_convtranspose2d_k3s2_zs_h16 followed by
+// d3d_slice_head_regress_h16(transposed = 0).  w % 4 == 0, 16-byte aligned maps; D3D_ERR_UNSUPPORTED otherwise (nothing launched).
+int d3d_slice_tail_regress_same_h16(const float* state2, const void* wup_packed, const float* bup, const float* state1, int skip_after_act,
+                                    const float* whead, const float* bhead, const float* dplane, int hd, int wd, int h, int w,
+                                    float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream) {
+    D3D_REQUIRE(state2 && wup_packed && state1 && whead && bhead && dplane && max_p && sum_d && sum_p, "null pointer");
+    D3D_REQUIRE(hd > 0 && wd > 0 && h > 0 && w > 0, "bad dims %dx%d / %dx%d", hd, wd, h, w);
+    const bool dquad = hd == 2 * h && wd == 2 * w;
+    // (w % 4: as the two launches it replaces -- the transposed tile kernel takes rows of whole quads only, and narrower maps go through
+    //  kernels that are not bit-identical to it)
+    if (w % 4 != 0 || (long)h * w * 64 * 4 >= (1L << 31) ||
+        ((reinterpret_cast<uintptr_t>(max_p) | reinterpret_cast<uintptr_t>(sum_d) | reinterpret_cast<uintptr_t>(sum_p) |
+          (dquad ? reinterpret_cast<uintptr_t>(dplane) : 0) | reinterpret_cast<uintptr_t>(state1)) & 15)) {
+        set_error("d3d_slice_tail_regress_same_h16: w = %d (a multiple of 4), 16-byte aligned maps and tensors below 2 GiB needed", w);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(slice_tail_kernel<false>), tail::LDS_BYTES);
+    if (rc != D3D_OK) return rc;
+    tail::Params p = {};
+    p.s2 = state2; p.wup = reinterpret_cast<const tail::u4t*>(wup_packed); p.bup = bup; p.s1 = state1; p.wh = whead; p.bh = bhead;
+    p.dplane = dplane; p.max_p = max_p; p.sum_d = sum_d; p.sum_p = sum_p; p.hd = hd; p.wd = wd; p.h = h; p.w = w;
+    p.skip_after = skip_after_act ? 1 : 0;
+    const int gx = ceil_div(w, tail::SXS), nty = (h + tail::SY) / tail::SY;
+    const int tper = pick_tper(gx, nty, tail::LDS_BYTES, tail::NFRAG * 64 * 16 + 8 * 1024, 2 * tail::PATCH);
+    p.tper = tper;
+    const int gy = ceil_div(nty, tper);
+    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(slice_tail_kernel<false>, dim3(gx, gy), dim3(tail::NT), tail::LDS_BYTES, (hipStream_t)stream, p);
+    D3D_LAUNCH_CHECK("slice_tail_kernel<same> launch");
     return D3D_OK;
 }
 

@@ -49,6 +49,16 @@ class slice_RED_Regularization(nn.Module):
             ops.online_regress_update(reg[0], *regress)
         return reg
 
+    def _tail(self, up22, state1, regress):
+        """upconv1 + skip, upconv2d and -- with `regress` -- the regression update: one kernel where it applies (h16 mode,
+        ops.slice_tail_regress_same: `up11` and `reg` never reach memory; returns None), else the layers one by one."""
+        if regress is not None:
+            dplane, max_p, sum_d, sum_p = regress
+            wc = ops.derived_weight(self.upconv2d.weight, "flipT", lambda w: w.flip(2, 3).transpose(0, 1))
+            if ops.slice_tail_regress_same(up22, self.upconv1.conv.weight, None, state1, True, wc, self.upconv2d.bias, dplane, max_p, sum_d, sum_p):
+                return None
+        return self._head(self.upconv1(up22, skip=state1), regress)
+
     def forward(self, cost, state1, state2, state3, state4, regress=None):
         w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
         if cost.is_cuda and not _cfg.off("red_streams"):
@@ -86,8 +96,7 @@ class slice_RED_Regularization(nn.Module):
             main.wait_event(d2)
             up22 = self.upconv2(up33, skip=state2)
             main.wait_event(d1)
-            up11 = self.upconv1(up22, skip=state1)
-            return self._head(up11, regress), state1, state2, state3, state4
+            return self._tail(up22, state1, regress), state1, state2, state3, state4
         c1 = ops.conv2d_k3(cost, w1, None, None, None, act=1, stride=2)             # conv1(-cost)
         c2 = self.conv2(c1)
         c3 = self.conv3(c2)
@@ -97,8 +106,7 @@ class slice_RED_Regularization(nn.Module):
         state2, _ = self.conv_gru2(c1, state2)
         up22 = self.upconv2(up33, skip=state2)
         state1, _ = self.conv_gru1(cost, state1, negate_x=True)                       # conv_gru1(-cost)
-        up11 = self.upconv1(up22, skip=state1)
-        return self._head(up11, regress), state1, state2, state3, state4
+        return self._tail(up22, state1, regress), state1, state2, state3, state4
 
 
 class InferDepthNet(nn.Module):

@@ -425,6 +425,32 @@ def slice_head_regress(up, weight, bias, transposed, dplane, max_p, sum_d, sum_p
     return True
 
 
+def slice_tail_regress_same(state2, w_up, b_up, state1, skip_after_act, w_head, b_head, dplane, max_p, sum_d, sum_p):
+    """upconv1 + skip -> Conv2d(8, 1, 3, pad 1) head -> online regression update in ONE kernel for the stages whose head keeps `up`'s
+    resolution (adamvs.py:413-418 at the last stage: relu(upconv1 + bias + state1); msrednet.py:361-363: relu(upconv1) + state1 with
+    skip_after_act): `up` and `reg` never reach memory (d3d_slice_tail_regress_same_h16; bit for bit what convtranspose2d_k3s2 +
+    slice_head_regress give).  w_head: the [1,8,3,3] Conv2d weight.  h16 mode only; False when it does not apply."""
+    if conv_precision() != "h16" or _cfg.off("tail_fused") or _cfg.off("head_fused") or _cfg.off("tail_same") or state2.dim() != 3 \
+            or state2.shape[0] != 16 or b_head is None:
+        return False
+    _, h, w = state2.shape
+    if tuple(state1.shape) != (8, 2 * h, 2 * w) or tuple(max_p.shape) != (2 * h, 2 * w) or w % 4 \
+            or tuple(w_up.shape) != (16, 8, 3, 3) or tuple(w_head.shape) != (1, 8, 3, 3):
+        return False
+    hd, wd = dplane.shape
+    wp = derived_weight(w_up, "t2dbf16", _pack_t2d_bf16)
+    wr = derived_weight(w_head, "h16round", lambda t: t.to(h16_dtype()).float().contiguous())
+    rc = _lib.load().d3d_slice_tail_regress_same_h16(_chk(state2, "state2", 3), ctypes.c_void_p(wp.data_ptr()), _opt(b_up, "b_up"),
+                                                      _chk(state1, "state1", 3), int(bool(skip_after_act)), _chk(wr, "w_head"),
+                                                      _chk(b_head, "b_head"), _chk(dplane, "dplane", 2), hd, wd, h, w,
+                                                      _chk(max_p, "max_p", 2), _chk(sum_d, "sum_d", 2), _chk(sum_p, "sum_p", 2), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return False
+    _lib.check(rc, "d3d_slice_tail_regress_same_h16")
+    dispatch_counts["slice_tail_regress_same"] += 1
+    return True
+
+
 def slice_tail_regress(state2, w_up, b_up, state1, w_head, b_head, dplane, max_p, sum_d, sum_p):
     """relu(upconv1(state2) + state1) -> upconv2d -> online regression update (adamvs.py:413-418, 423-425, 514-525) in ONE kernel
     for the stages whose head is the stride-2 ConvTranspose2d: `up` and `reg` never reach memory (d3d_slice_tail_regress_h16; bit

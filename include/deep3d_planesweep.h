@@ -276,6 +276,15 @@ int d3d_conv2d_k3_pair3_bf16x3(const float* img, const float* w0packed, const fl
 int d3d_slice_tail_regress_h16(const float* state2, const void* wup_packed, const float* bup, const float* state1, const float* whead,
                                 const float* bhead, const float* dplane, int hd, int wd, int h, int w, float* max_p, float* sum_d,
                                 float* sum_p, d3d_stream_t stream);
+/* The same tail with the head at `up`'s own resolution (ABI 10; adamvs.py:413-418 at the last stage, msrednet.py:361-363 + 418-437):
+ * up = relu(ConvTranspose2d_16->8(state2) + bup + state1), or with skip_after_act relu(ConvTranspose2d_16->8(state2) + bup) + state1
+ * (module.py:287-294 ConvTransReLU followed by the skip); reg = Conv2d(8, 1, 3, pad 1)(up) + bhead; the online regression update of
+ * (max_p, sum_d, sum_p) [2h, 2w] at `dplane`.  `up` and `reg` stay in LDS.  bup may be null; whead = the [1,8,3,3] weights [c][k_y][k_x]
+ * rounded to the 16-bit format (fp32 values).  Bit-identical to d3d_convtranspose2d_k3s2_zs_h16 followed by
+ * d3d_slice_head_regress_h16(transposed = 0).  w % 4 == 0, 16-byte aligned maps; D3D_ERR_UNSUPPORTED otherwise (nothing launched). */
+int d3d_slice_tail_regress_same_h16(const float* state2, const void* wup_packed, const float* bup, const float* state1, int skip_after_act,
+                                    const float* whead, const float* bhead, const float* dplane, int hd, int wd, int h, int w,
+                                    float* max_p, float* sum_d, float* sum_p, d3d_stream_t stream);
 int d3d_online_regress_finalize(const float* max_p, const float* sum_d, const float* sum_p, int64_t n,
                                 float* depth_out, float* conf_out, d3d_stream_t stream);
 

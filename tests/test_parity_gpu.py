@@ -1326,12 +1326,14 @@ def test_model_forward_at_production_kernel_size_matches_reference(ops, name, mo
             assert counts.get("gru_cell_fused", 0) == 2 * (48 + 32 + 8), counts   # both cells of every slice of every stage
             # upconv1 + skip + head + regression update of every slice of the up-sampling stages in one kernel, the last stage's head fused
             if not config.off("tail_fused"):
-                assert counts.get("slice_tail_regress", 0) == 48 + 32 and counts.get("slice_head_regress", 0) == 8, counts
+                last = "slice_tail_regress_same" if not config.off("tail_same") else "slice_head_regress"   # (the last stage's head keeps `up`'s resolution)
+                assert counts.get("slice_tail_regress", 0) == 48 + 32 and counts.get(last, 0) == 8, counts
     # (the asserts on this round's fused kernels hold for the default dispatch: D3D_KERNELS_OFF=<name> takes a kernel out on purpose)
     if name == "msrednet" and mode == "h16" and not config.off("gn_fused"):   # GroupNorm statistics ride on the convolutions
         assert counts.get("conv2d_gn_fused", 0) >= 2 * 2 * (48 + 32 + 8), counts   # (at least the two wide levels of every slice)
         if not config.off("head_fused"):   # upconv2d + the online regression update of every slice in one kernel
-            assert counts.get("slice_head_regress", 0) == 48 + 32 + 8, counts
+            # ... and, round 5, upconv1 + skip with them (`up11` stays in LDS)
+            assert counts.get("slice_tail_regress_same" if not config.off("tail_same") else "slice_head_regress", 0) == 48 + 32 + 8, counts
     if name in ("casmvsnet", "adamvs") and not config.off("conv0_pair"):   # conv0 of the feature trunk of every view in one launch (the feature nets are fp32 in both modes)
         assert counts.get("conv2d_pair3", 0) == imgs.shape[1], counts
     # ---- and what they produced is the reference's
@@ -1985,6 +1987,38 @@ def test_slice_tail_fused_is_the_two_launches(ops, bf16_mode, monkeypatch, h, w,
         assert torch.equal(p_, q_), (name, float((p_ - q_).abs().max()))
     set_kernel(monkeypatch, "tail_fused", False)
     assert not ops.slice_tail_regress(s2, wu, bu, s1, wh, bh, dpl, *a)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("skip_after,bias", [(False, True), (True, False)])
+@pytest.mark.parametrize("h,w", [(8, 32), (7, 28), (13, 64), (15, 36), (6, 92), (29, 16), (1, 4), (14, 60)])
+def test_slice_tail_same_resolution_is_the_two_launches(ops, bf16_mode, monkeypatch, h, w, skip_after, bias, mode):
+    """d3d_slice_tail_regress_same_h16 (upconv1 + skip, the Conv2d(8, 1, 3) head at `up`'s resolution and the online regression
+    update in one kernel: adamvs.py:413-418 at the last stage -- relu(upconv1 + b + state1) -- and msrednet.py:361-363 + 418-437 --
+    relu(upconv1) + state1) against the two launches it replaces (transposed tile kernel, then the fused head): the three
+    regression maps bit for bit -- sizes over tile edges (30 x 7 state2 pixels per workgroup step, patches that start one pixel
+    outside the image), both epilogue orders, every depth-plane form."""
+    rng = np.random.default_rng(h * 100 + w + skip_after)
+    s2, s1 = dev(rng.standard_normal((16, h, w))), dev(rng.standard_normal((8, 2 * h, 2 * w)))
+    wu, bu = dev(0.2 * rng.standard_normal((16, 8, 3, 3))), (dev(rng.standard_normal(8)) if bias else None)
+    wh, bh = dev(0.3 * rng.standard_normal((1, 8, 3, 3))), dev(rng.standard_normal(1))
+    H, W = 2 * h, 2 * w
+    dpl = dev(600 + 50 * rng.standard_normal((1, 1) if mode == 0 else (h, w) if mode == 1 else (H, W)))
+    acc0 = [dev(np.abs(rng.standard_normal((H, W)))) for _ in range(3)]
+    a = [t.clone() for t in acc0]
+    before = ops.dispatch_counts["slice_tail_regress_same"]
+    assert ops.slice_tail_regress_same(s2, wu, bu, s1, skip_after, wh, bh, dpl, *a)
+    assert ops.dispatch_counts["slice_tail_regress_same"] == before + 1
+    b = [t.clone() for t in acc0]
+    up = ops.convtranspose2d_k3s2(s2, wu, None, bu, s1, skip_after_act=skip_after, act=1)
+    assert ops.slice_head_regress(up, wh, bh, False, dpl, *b)
+    for name, p_, q_ in zip(("max_p", "sum_d", "sum_p"), a, b):
+        assert torch.isfinite(p_).all()
+        assert torch.equal(p_, q_), (name, float((p_ - q_).abs().max()))
+    assert not ops.slice_tail_regress_same(s2[:, :, :w - 2].contiguous(), wu, bu, s1[:, :, :W - 4].contiguous(), skip_after, wh, bh, dpl,
+                                           *[t[:, :W - 4].contiguous() for t in a])   # (rows of whole quads only)
+    set_kernel(monkeypatch, "tail_same", False)
+    assert not ops.slice_tail_regress_same(s2, wu, bu, s1, skip_after, wh, bh, dpl, *a)
 
 
 def test_conv11_prob_fused_odd_width_not_taken(ops):
@@ -2665,10 +2699,10 @@ def test_adamvs_slice_graph_is_the_serial_loop(ops, monkeypatch):
                 o = net(*args)
             torch.cuda.synchronize()
             outs.append([o[s][k].clone() for s in ("stage1", "stage2", "stage3") for k in ("depth", "photometric_confidence")])
-            counts.append({k: ops.dispatch_counts[k] for k in ("gru_cell_fused", "slice_tail_regress", "slice_head_regress")})
+            counts.append({k: ops.dispatch_counts[k] for k in ("gru_cell_fused", "slice_tail_regress", "slice_tail_regress_same")})
     finally:
         ops.set_conv_precision(None)
-    assert all(c == {"gru_cell_fused": 176, "slice_tail_regress": 80, "slice_head_regress": 8} for c in counts), counts
+    assert all(c == {"gru_cell_fused": 176, "slice_tail_regress": 80, "slice_tail_regress_same": 8} for c in counts), counts
     for per_output in zip(*outs):
         assert all(torch.equal(per_output[0], o) for o in per_output[1:])
     from deep3d_aerial_amd.adamvs import SliceLoopGraph
