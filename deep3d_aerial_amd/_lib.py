@@ -65,6 +65,7 @@ SIGNATURES = {
     "d3d_conv2d_k1_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv1x1_context": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "d3d_conv2d_k3s2_zs_h16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "d3d_conv2d_k3s2_zs_h16_batched": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i64, _vp, _vp],
     "d3d_conv2d_k3_wide_h16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "d3d_slice_head_regress_h16": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "d3d_gru_cell_fused_h16": [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -58,6 +58,10 @@ struct Z2Params {
     // GroupNorm statistics of the output (gn_stats.h; act 0, no skip): fp64 pairs, zeroed by the caller; channels >= gn_split are group 1
     double* gn;
     int gn_split;
+    // batched launch (round 5: RED-Net's encoder for every depth slice of a stage at once -- blockIdx.z is the item): element strides of
+    // `in` and `out` between items; 0 for the single-item launches.  (in2 / skip / aux1 / gn are not batched.)
+    long in_bstride, out_bstride;
+    int nbatch;
 };
 
 __device__ __forceinline__ unsigned pack_bf16_z2(float a, float b) {   // the split (fp32-mode) operands: three bf16 pieces
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(NTZ, GN && CI == 40 ? 4 : 2) void conv2d_zs_bf16_ke
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.nbatch > 1) { p.in += (size_t)blockIdx.z * p.in_bstride; p.out += (size_t)blockIdx.z * p.out_bstride; }   // (batched launch: this workgroup's item)
     const int H = p.H, W = p.W;
     const int x0 = blockIdx.x * TX;
     const int nty = (H + TYZ - 1) / TYZ;
@@ -582,12 +587,12 @@ static int launch_z2(const Z2Params& p, hipStream_t stream) {
     int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
-    const int gx = ceil_div(p.W, TX), nty = ceil_div(p.H, TYZ);
-    const int tper = pick_tper(gx, nty, lds, WBYTES, PATCH, GN && CI == 40 ? 4 : 2);
+    const int gx = ceil_div(p.W, TX), nty = ceil_div(p.H, TYZ), nb = p.nbatch > 1 ? p.nbatch : 1;
+    const int tper = pick_tper(gx * nb, nty, lds, WBYTES, PATCH, GN && CI == 40 ? 4 : 2);
     q.tper = tper;
     const int gy = ceil_div(nty, tper);
-    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NTZ), lds, stream, q);
+    if (gy > 65535 || nb > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(gx, gy, nb), dim3(NTZ), lds, stream, q);
     D3D_LAUNCH_CHECK("conv2d_zs_bf16_kernel launch");
     return D3D_OK;
 }
@@ -611,6 +616,7 @@ __global__ __launch_bounds__(NTZ, 2) void conv2d_s2_zs_bf16_kernel(Z2Params p) {
     u4* wlds = reinterpret_cast<u4*>(smem + NBUF * PATCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.nbatch > 1) { p.in += (size_t)blockIdx.z * p.in_bstride; p.out += (size_t)blockIdx.z * p.out_bstride; }   // (batched launch: this workgroup's item)
     const int H = p.H, W = p.W, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int xo0 = blockIdx.x * TXO;
     const int nty = (Ho + TYZ - 1) / TYZ;
@@ -1048,13 +1054,13 @@ static int launch_s2z(const Z2Params& p, hipStream_t stream) {
     if (rc != D3D_OK) return rc;
     Z2Params q = p;
     const int Ho = (p.H - 1) / 2 + 1, Wo = (p.W - 1) / 2 + 1;
-    const int gx = ceil_div(Wo, 16 * MG), nty = ceil_div(Ho, TYZ);
+    const int gx = ceil_div(Wo, 16 * MG), nty = ceil_div(Ho, TYZ), nb = p.nbatch > 1 ? p.nbatch : 1;
     constexpr int PATCH_S2 = (32 * MG + KS - 2) * (2 * TYZ + KS - 2) * CS;
-    const int tper = pick_tper(gx, nty, lds, lds - (X3 ? 1 : 2) * PATCH_S2, PATCH_S2);
+    const int tper = pick_tper(gx * nb, nty, lds, lds - (X3 ? 1 : 2) * PATCH_S2, PATCH_S2);
     q.tper = tper;
     const int gy = ceil_div(nty, tper);
-    if (gy > 65535) return D3D_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(NTZ), lds, stream, q);
+    if (gy > 65535 || nb > 65535) return D3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(gx, gy, nb), dim3(NTZ), lds, stream, q);
     D3D_LAUNCH_CHECK("conv2d_s2_zs_bf16_kernel launch");
     return D3D_OK;
 }
@@ -1180,7 +1186,8 @@ extern "C" int d3d_conv2d_k3_pair3_bf16x3(const float* img, const float* w0packe
 enum { PREC_BF16 = 0, PREC_F32 = 1, PREC_X3 = 2 };   // operand format of the stride-2 / transposed tile kernels
 
 static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
-                          int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+                          int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream, int nbatch = 1,
+                          long in_bstride = 0, long out_bstride = 0);
 
 extern "C" int d3d_conv2d_k5s2_zs_bf16x3(const float* in, const void* wpacked, const float* scale, const float* shift,
                                          const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
@@ -1213,6 +1220,17 @@ extern "C" int d3d_conv2d_k3s2_zs_h16(const float* in, const void* wpacked, cons
     return conv2d_k3s2_zs(PREC_BF16, in, wpacked, scale, shift, skip, act, skip_after_act, Ci, Co, H, W, out, stream);
 }
 
+// The same layer over `nbatch` images in ONE launch (RED-Net's encoder, msrednet.py:352-356, for every depth slice of a stage before the
+// recurrent loop: the stride-2 ConvReLUs depend on the cost slices only): in [nbatch][Ci,H,W] and out [nbatch][Co,Ho,Wo] with the given
+// element strides between items; no skip.  Per item bit for bit d3d_conv2d_k3s2_zs_h16.
+extern "C" int d3d_conv2d_k3s2_zs_h16_batched(const float* in, const void* wpacked, const float* scale, const float* shift, int act, int Ci,
+                                               int Co, int H, int W, int nbatch, int64_t in_bstride, int64_t out_bstride, float* out,
+                                               d3d_stream_t stream) {
+    D3D_REQUIRE(nbatch >= 1 && in_bstride >= (int64_t)Ci * H * W && out_bstride > 0, "bad batch arguments");
+    return conv2d_k3s2_zs(PREC_BF16, in, wpacked, scale, shift, nullptr, act, 1, Ci, Co, H, W, out, stream, nbatch, (long)in_bstride,
+                          (long)out_bstride);
+}
+
 extern "C" int d3d_conv2d_k3s2_zs_f32(const float* in, const void* wpacked, const float* scale, const float* shift,
                                       const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                       d3d_stream_t stream) {
@@ -1220,7 +1238,8 @@ extern "C" int d3d_conv2d_k3s2_zs_f32(const float* in, const void* wpacked, cons
 }
 
 static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
-                          int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream) {
+                          int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream, int nbatch,
+                          long in_bstride, long out_bstride) {
     const bool f32 = prec == PREC_F32;
     D3D_REQUIRE(in && wpacked && out, "null pointer");
     D3D_REQUIRE(H > 0 && W > 0 && Ci > 0 && Co > 0, "bad dims");
@@ -1231,7 +1250,7 @@ static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const 
         // sizes the layer is latency, not work -- the stride-1 tile kernel computes every position and keeps the even ones
         Z2Params p = {};
         p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
-        p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.sub2 = 1;
+        p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.sub2 = 1; p.nbatch = nbatch; p.in_bstride = in_bstride; p.out_bstride = out_bstride;
         hipStream_t st = (hipStream_t)stream;
         if (f32) return Co > 32 ? launch_z2<48, 3, 2, true>(p, st) : Co > 16 ? launch_z2<48, 2, 2, true>(p, st) : launch_z2<48, 1, 2, true>(p, st);
         return Co > 32 ? launch_z2<48, 3, 2>(p, st) : Co > 16 ? launch_z2<48, 2, 2>(p, st) : launch_z2<48, 1, 2>(p, st);
@@ -1242,7 +1261,7 @@ static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const 
         // products are dropped, at these image sizes the layer is latency: 87 us on the round-1 stream kernel, 88 calls per view)
         Z2Params p = {};
         p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
-        p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.sub2 = 1;
+        p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.sub2 = 1; p.nbatch = nbatch; p.in_bstride = in_bstride; p.out_bstride = out_bstride;
         hipStream_t st = (hipStream_t)stream;
         return Co > 48 ? launch_z2<32, 4, 2>(p, st) : Co > 32 ? launch_z2<32, 3, 2>(p, st) : Co > 16 ? launch_z2<32, 2, 2>(p, st) : launch_z2<32, 1, 2>(p, st);
     }
@@ -1254,7 +1273,7 @@ static int conv2d_k3s2_zs(int prec, const float* in, const void* wpacked, const 
     }
     Z2Params p = {};
     p.in = in; p.C1 = Ci; p.wpk = reinterpret_cast<const u4*>(wpacked); p.scale = scale; p.shift = shift; p.skip = skip; p.out = out;
-    p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act;
+    p.H = H; p.W = W; p.CO = Co; p.act = act; p.skip_after_act = skip_after_act; p.nbatch = nbatch; p.in_bstride = in_bstride; p.out_bstride = out_bstride;
     hipStream_t st = (hipStream_t)stream;
     if (f32) return Co > 16 ? launch_s2z<8, 2, true>(p, st) : launch_s2z<8, 1, true>(p, st);
     if (prec == PREC_X3) {

@@ -59,8 +59,55 @@ class slice_RED_Regularization(nn.Module):
                 return None
         return self._head(self.upconv1(up22, skip=state1), regress)
 
-    def forward(self, cost, state1, state2, state3, state4, regress=None):
+    def encode_all(self, var):
+        """The encoder of EVERY depth slice of a stage in three batched launches (msrednet.py:352-356: conv1(-cost), conv2, conv3 depend
+        on the cost slices only, not on the recurrent state): var [D,C,h,w] -> (c1 [D,16,h/2,w/2], c2 [D,32,..], c3 [D,64,..]), slice
+        d of each bit for bit what forward() computes itself; None where the batched kernel does not apply (h16 mode only).  Takes the
+        three small convolutions out of every slice's chain -- 3 of 10 serial launches per slice -- and runs them on full grids."""
+        # (conv3's input -- a sixteenth of the slice -- must still be a map the per-slice dispatch gives to the tile kernel, ops.conv2d_k3:
+        #  the batched form runs that kernel at any size, and smaller maps would no longer be the per-slice forward bit for bit)
+        if not var.is_cuda or _cfg.off("red_encoder") or (var.shape[2] // 4) * (var.shape[3] // 4) < 128 * 128:
+            return None
         w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
+        c1 = ops.conv2d_s2_zs_batched(var, w1, act=1)
+        c2 = None if c1 is None else ops.conv2d_s2_zs_batched(c1, self.conv2.conv.weight, act=1)
+        c3 = None if c2 is None else ops.conv2d_s2_zs_batched(c2, self.conv3.conv.weight, act=1)
+        return None if c3 is None else (c1, c2, c3)
+
+    def forward(self, cost, state1, state2, state3, state4, regress=None, enc=None):
+        """enc: (c1, c2, c3) of this slice from encode_all(), or None (the encoder runs here)."""
+        w1 = ops.derived_weight(self.conv1.conv.weight, "neg", lambda w: -w)
+        if enc is not None and cost.is_cuda and not _cfg.off("red_streams"):
+            # encoder precomputed: the three side levels start at once, level 4 and the decoder follow on the caller's stream
+            c1, c2, c3 = enc
+            main = torch.cuda.current_stream(cost.device)
+            side = ops.side_streams(cost.device, 3, "red")
+            e0 = main.record_event()                                                  # (the states of the previous slice exist)
+            news = []
+            for st, cell, x, h, neg in ((side[2], self.conv_gru1, cost, state1, True), (side[0], self.conv_gru2, c1, state2, False),
+                                        (side[1], self.conv_gru3, c2, state3, False)):
+                with torch.cuda.stream(st):
+                    st.wait_event(e0)
+                    hn, _ = cell(x, h, negate_x=True) if neg else cell(x, h)
+                    news.append((hn, st.record_event()))
+                ops.hand_over(hn, main)
+            (state1, d1), (state2, d2), (state3, d3) = news
+            state4, _ = self.conv_gru4(c3, state4)
+            main.wait_event(d3)
+            up33 = self.upconv3(state4, skip=state3)
+            main.wait_event(d2)
+            up22 = self.upconv2(up33, skip=state2)
+            main.wait_event(d1)
+            return self._tail(up22, state1, regress), state1, state2, state3, state4
+        if enc is not None:
+            c1, c2, c3 = enc
+            state4, _ = self.conv_gru4(c3, state4)
+            state3, _ = self.conv_gru3(c2, state3)
+            up33 = self.upconv3(state4, skip=state3)
+            state2, _ = self.conv_gru2(c1, state2)
+            up22 = self.upconv2(up33, skip=state2)
+            state1, _ = self.conv_gru1(cost, state1, negate_x=True)
+            return self._tail(up22, state1, regress), state1, state2, state3, state4
         if cost.is_cuda and not _cfg.off("red_streams"):
             # The four recurrent cells of a slice depend on the encoder's maps only (msrednet.py:352-367), and at the first two
             # stages their kernels are tens of workgroups each: level 1 starts on a side stream beside the encoder, levels 2 / 3
@@ -141,12 +188,14 @@ class InferDepthNet(nn.Module):
             # whole variance volume of a stage is at most 2.6 GB here, so it is swept in ONE fused launch and the
             # recurrent regulariser then walks its depth slices.
             var = ops.variance_volume(feats, p34, dvb, plane_major=True)  # [D,C,h,w]: a slice is one contiguous block
+            enc = cost_regularization.encode_all(var)   # (the encoder of every slice in three batched launches; None: inside the slices)
             for d in range(num_depth):
                 if dvb.dim() == 1:   # [D] uniform planes: a [1,1] map (the update resamples it to the image, a constant)
                     dplane = dvb[d:d + 1].view(1, 1)
                 else:                # [D,h,w] per-pixel hypotheses
                     dplane = dvb[d]
-                _, *states = cost_regularization(var[d], *states, regress=(dplane, max_p, sum_d, sum_p))
+                _, *states = cost_regularization(var[d], *states, regress=(dplane, max_p, sum_d, sum_p),
+                                                 enc=None if enc is None else tuple(c[d] for c in enc))
             dep, conf = ops.online_regress_finalize(max_p, sum_d, sum_p)
             depths.append(dep)
             confs.append(conf)
@@ -237,8 +286,10 @@ class RedLoopGraph(object):
         cr = self.cr()
         before = dict(ops.dispatch_counts)
         states = self._zero_states()          # one eager slice first: packed weights, LDS attributes, slot arenas of the eager streams
-        _, *states = cr(self.var[0], *states, regress=(self._dplane(0), self.max_p, self.sum_d, self.sum_p))
-        del states
+        enc = cr.encode_all(self.var)
+        _, *states = cr(self.var[0], *states, regress=(self._dplane(0), self.max_p, self.sum_d, self.sum_p),
+                        enc=None if enc is None else tuple(c[0] for c in enc))
+        del states, enc
         ops.dispatch_counts.clear()
         ops.dispatch_counts.update(before)
         graph = torch.cuda.CUDAGraph()
@@ -248,9 +299,11 @@ class RedLoopGraph(object):
         with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
             states = self._zero_states()
             self.max_p.zero_(); self.sum_d.zero_(); self.sum_p.zero_()
+            enc = cr.encode_all(self.var)   # (inside the capture: three nodes in front of the slices)
             for d in range(self.D):
-                _, *states = cr(self.var[d], *states, regress=(self._dplane(d), self.max_p, self.sum_d, self.sum_p))
-            del states
+                _, *states = cr(self.var[d], *states, regress=(self._dplane(d), self.max_p, self.sum_d, self.sum_p),
+                                enc=None if enc is None else tuple(c[d] for c in enc))
+            del states, enc
         after = dict(ops.dispatch_counts)
         self.counts = {k: v - before.get(k, 0) for k, v in after.items() if v != before.get(k, 0)}
         for k, v in self.counts.items():

@@ -1264,6 +1264,31 @@ def conv2d_s2_zs(x, weight, scale=None, shift=None, skip=None, act=0, skip_after
     return out
 
 
+def conv2d_s2_zs_batched(x, weight, act=1):
+    """3 x 3 stride-2 conv (pad 1, no bias) over a BATCH of maps x [B,Ci,H,W] in one launch of the tile kernel (h16 mode:
+    d3d_conv2d_k3s2_zs_h16_batched; RED-Net's encoder for every depth slice of a stage, msrednet.py:352-356).  Per item bit for
+    bit conv2d_s2_zs.  Returns [B,Co,Ho,Wo], or None for shapes / modes the kernel does not take."""
+    if x.dim() != 4 or conv_precision() != "h16" or _cfg.off("conv2d_zs") or act not in (0, 1):
+        return None
+    B, Ci, H, W = x.shape
+    Co = weight.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    wide = Ci == 32 and Co <= 64 and W % 4 == 0
+    if not wide and (Ci not in (8, 16) or Co > 32 or Wo % 4):
+        return None
+    if tuple(weight.shape) != (Co, Ci, 3, 3):
+        raise ValueError("weight must be [Co,%d,3,3] (got %s)" % (Ci, tuple(weight.shape)))
+    wp = derived_weight(weight, "z2bf16", _pack_z2_bf16)
+    out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    rc = _lib.load().d3d_conv2d_k3s2_zs_h16_batched(_chk(x, "x", 4), ctypes.c_void_p(wp.data_ptr()), None, None, int(act), Ci, Co, H, W, B,
+                                                     Ci * H * W, Co * Ho * Wo, _chk(out, "out"), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "d3d_conv2d_k3s2_zs_h16_batched")
+    dispatch_counts["conv2d_s2_batched"] += 1
+    return out
+
+
 def _pack_t2d_bf16(w, dt=None):
     """nn.ConvTranspose2d weight [Ci,Co,3,3] -> B operands for d3d_convtranspose2d_k3s2_zs_h16: per output parity class
     (py,px), order py*2 + px, taps (dy,dx) with d <= p per dimension, dy-major; an even output coordinate uses kernel index 1

@@ -445,6 +445,11 @@ int d3d_conv1x1_context(const float* f, int Ci, const float* weight, const float
  * C_in = 8 | 16 | 32, C_out <= 16, W % 4 == 0.  wpacked: ops._pack_z2_bf16 / ops._pack_t2d_bf16 (per output parity class, as the 3-D form). */
 int d3d_conv2d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift, const float* skip,
                             int act, int skip_after_act, int Ci, int Co, int H, int W, float* out, d3d_stream_t stream);
+/* The same layer over `nbatch` images in ONE launch (ABI 10; msrednet.py:352-356: the encoder's stride-2 ConvReLUs depend on the cost
+ * slices only, so the three of them run for every depth slice of a stage before the recurrent loop): in [nbatch][Ci,H,W],
+ * out [nbatch][Co,Ho,Wo] with the given element strides between items; no skip.  Per item bit for bit d3d_conv2d_k3s2_zs_h16. */
+int d3d_conv2d_k3s2_zs_h16_batched(const float* in, const void* wpacked, const float* scale, const float* shift, int act, int Ci, int Co,
+                                   int H, int W, int nbatch, int64_t in_bstride, int64_t out_bstride, float* out, d3d_stream_t stream);
 int d3d_convtranspose2d_k3s2_zs_h16(const float* in, const void* wpacked, const float* scale, const float* shift,
                                      const float* skip, int act, int skip_after_act, int Ci, int Co, int H, int W, float* out,
                                      d3d_stream_t stream);

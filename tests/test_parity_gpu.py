@@ -2721,6 +2721,52 @@ def test_adamvs_slice_graph_is_the_serial_loop(ops, monkeypatch):
     assert not torch.equal(fresh[0], outs[0][4]) and all(torch.equal(fresh[0], f) for f in fresh[1:])
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [(5, 8, 16, 40, 56), (3, 16, 32, 37, 72), (4, 32, 64, 24, 36), (2, 32, 16, 70, 100), (7, 16, 16, 9, 8)])
+def test_batched_stride2_convolution_is_the_per_item_launch(ops, bf16_mode, B, Ci, Co, H, W):
+    """d3d_conv2d_k3s2_zs_h16_batched (RED-Net's encoder for every depth slice of a stage in one launch, msrednet.py:352-356): every
+    item bit for bit the single-image entry point's -- the stride-2 tile kernel at 8 / 16 input channels and the stride-1 kernel
+    with a subsampled store at 32."""
+    rng = np.random.default_rng(B * 10 + Ci)
+    x = dev(rng.standard_normal((B, Ci, H, W)))
+    w = dev(0.2 * rng.standard_normal((Co, Ci, 3, 3)))
+    y = ops.conv2d_s2_zs_batched(x, w, act=1)
+    assert y is not None and tuple(y.shape) == (B, Co, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    for b in range(B):
+        one = ops.conv2d_s2_zs(x[b], w, None, None, None, 1)
+        assert one is not None and torch.equal(y[b], one), b
+
+
+def test_msrednet_batched_encoder_is_the_per_slice_encoder(ops, monkeypatch):
+    """slice_RED_Regularization.encode_all: conv1 .. conv3 of every depth slice of a stage in three batched launches before the
+    recurrent loop instead of inside every slice -- the same kernels on the same operands: a rollout over the slices with the
+    precomputed maps agrees with the per-slice form to the order of the GroupNorm statistics' fp64 atomics (as two runs of either
+    form do); slices too small for the per-slice dispatch to use the tile kernel are declined."""
+    from deep3d_aerial_amd.msrednet import slice_RED_Regularization
+
+    D, C, h, w = 3, 8, 512, 640
+    net = _fill(slice_RED_Regularization(C, 8), 7303)
+    rng = np.random.default_rng(7303)
+    var = dev(np.abs(rng.standard_normal((D, C, h, w))))
+    ops.set_conv_precision("h16")
+    try:
+        with torch.no_grad():
+            enc = net.encode_all(var)
+            assert enc is not None and [tuple(c.shape) for c in enc] == [(D, 16, h // 2, w // 2), (D, 32, h // 4, w // 4), (D, 64, h // 8, w // 8)]
+            assert net.encode_all(var[:, :, :256, :256].contiguous()) is None
+            outs = []
+            for use in (True, False):
+                st = [torch.zeros(8 << j, h >> j, w >> j, device="cuda") for j in range(4)]
+                regs = []
+                for d in range(D):
+                    reg, *st = net(var[d], *st, enc=tuple(c[d] for c in enc) if use else None)
+                    regs.append(host(reg))
+                outs.append(regs + [host(t) for t in st])
+    finally:
+        ops.set_conv_precision(None)
+    for a_, b_ in zip(*outs):
+        assert rel_l1(a_, b_) <= 1e-6
+
+
 def test_msrednet_loop_graph_is_the_eager_loop(ops, monkeypatch):
     """The slice loop of a RED-Net stage captured as one HIP graph (msrednet.RedLoopGraph: the four-stream slice, the GroupNorm
     slot arenas and the zeroing of the states all inside the capture; first call of a shape eager, second captures, later ones
