@@ -111,6 +111,7 @@ SIGNATURES = {
     "d3d_gru_update_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp],
     "d3d_gru_reset_gn": [_vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp],
     "d3d_gru_update_gates_gn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, ctypes.c_float, _i, _vp, _vp],
+    "d3d_gru2_cell_gn_h16": [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "d3d_softargmin_conf4_var": [_vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _vp, _vp],
     "d3d_uncertainty_samples": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "d3d_pair_softmax_max": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -55,6 +55,7 @@ KERNELS = {
     "conv2d_k1": "1 x 1 convolutions of the feature pyramids on the fp32 streaming kernel (the round-1 matrix-core stream kernel instead)",
     "tail_same": "upconv1 + skip + same-resolution head + regression update in one kernel (AdaMVS's last stage, RED-Net; two launches instead)",
     "red_encoder": "RED-Net's encoder (conv1 .. conv3) for every depth slice of a stage in three batched launches before the loop (inside every slice instead)",
+    "gru2_cell": "ConvGRUCell2 as one library call that issues its four launches (the four entry points from Python instead)",
     "red_graph": "RED-Net's slice loop of a stage as ONE captured HIP graph (the launch loop instead)",
     "slice_graph": "AdaMVS's slice loop of a stage as ONE captured HIP graph of three chains on three streams -- cell 1 of slice d + 2, cell 2 of slice d + 1, head / regression of slice d in flight together (the serial launch loop instead)",
     "red_streams": "the four conv-GRU levels of a RED-Net depth slice on four HIP streams (they depend on the encoder only; one stream instead)",

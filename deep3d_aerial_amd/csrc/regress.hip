@@ -1328,5 +1328,44 @@ int d3d_gru_update_gates_gn(const float* o, const double* stats_o, const float* 
     return D3D_OK;
 }
 
+// One ConvGRUCell2 step (module.py:53-99) as ONE call of the library: the four launches of the cell -- gate convolution with the
+// GroupNorm statistics in its epilogue, the reset pass, candidate convolution with its statistics, the state update with the update
+// gate evaluated in place -- issued back to back from C.  Same kernels, same operands as the four entry points called one by one
+// (d3d_conv2d_k3_{zs|wide}_h16_gn, d3d_gru_reset_gn, d3d_gru_update_gates_gn); what goes away is the host's work between them: a
+// RED-Net view is 352 cells, and issued from Python its four free-running level chains are paced by the host, not the card.
+//   x [Cx,H,W], h [Hc,H,W] -> hout [Hc,H,W];  wg / wc = ops._pack_z2_bf16 of the gate [2Hc, Cx+Hc, 3, 3] / candidate [Hc, Cx+Hc, 3, 3]
+//   weights; stats_g [2][2] and stats_o [2] fp64 ZEROED by the caller; gates [2Hc,H,W], rh [Hc,H,W], o [Hc,H,W]: scratch.
+// Shapes: Cx + Hc = 16 | 24 | 32 | 40 (tile kernel: W % 4 == 0) or 64 | 128 (wide kernel: parts of 32); H * W % 4 == 0; 16-byte aligned
+// tensors.  D3D_ERR_UNSUPPORTED otherwise, with nothing launched.
+int d3d_gru2_cell_gn_h16(const float* x, int Cx, const float* h, int Hc, int H, int W, const void* wg, const float* bg, const void* wc,
+                         const float* bc, const float* gamma_r, const float* beta_r, const float* gamma_u, const float* beta_u,
+                         const float* gamma_o, const float* beta_o, float eps, int fast, double* stats_g, double* stats_o, float* gates,
+                         float* rh, float* o, float* hout, d3d_stream_t stream) {
+    D3D_REQUIRE(x && h && wg && bg && wc && bc && gamma_r && beta_r && gamma_u && beta_u && gamma_o && beta_o && stats_g && stats_o && gates &&
+                rh && o && hout, "null pointer");
+    D3D_REQUIRE(Cx > 0 && Hc > 0 && H > 0 && W > 0 && eps >= 0.0f, "bad dims");
+    const int Ci = Cx + Hc;
+    const long plane = (long)H * W;
+    const bool tile = (Ci == 16 || Ci == 24 || Ci == 32 || Ci == 40) && Cx % 8 == 0 && Hc % 8 == 0 && W % 4 == 0 &&
+                      2 * Hc <= (Ci == 24 || Ci == 40 ? 16 : 32);
+    const bool wide = (Ci == 64 || Ci == 128) && Cx % 32 == 0 && Hc % 32 == 0 && (Hc == 32 || Hc == 64);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(gates) |
+                         reinterpret_cast<uintptr_t>(rh) | reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(hout);
+    if (!(tile || wide) || plane % 4 != 0 || Hc > 65535 || (al & 15) || (long)(Ci > 2 * Hc ? Ci : 2 * Hc) * plane * 4 >= (1L << 31)) {
+        set_error("d3d_gru2_cell_gn_h16: %d + %d channels at %d x %d not taken", Cx, Hc, H, W);
+        return D3D_ERR_UNSUPPORTED;
+    }
+    int rc = tile ? d3d_conv2d_k3_zs_h16_gn(x, Cx, h, Hc, wg, bg, 2 * Hc, H, W, gates, stats_g, Hc, stream)
+                  : d3d_conv2d_k3_wide_h16_gn(x, Cx, h, Hc, wg, bg, 2 * Hc, H, W, gates, stats_g, Hc, stream);
+    if (rc != D3D_OK) return rc;   // (shape rules checked above: an error here is a real one)
+    rc = d3d_gru_reset_gn(gates, stats_g, gamma_r, beta_r, h, Hc, plane, eps, fast, rh, stream);
+    if (rc != D3D_OK) return rc == D3D_ERR_UNSUPPORTED ? D3D_ERR_INVALID_ARG : rc;
+    rc = tile ? d3d_conv2d_k3_zs_h16_gn(x, Cx, rh, Hc, wc, bc, Hc, H, W, o, stats_o, Hc, stream)
+              : d3d_conv2d_k3_wide_h16_gn(x, Cx, rh, Hc, wc, bc, Hc, H, W, o, stats_o, Hc, stream);
+    if (rc != D3D_OK) return rc == D3D_ERR_UNSUPPORTED ? D3D_ERR_INVALID_ARG : rc;
+    rc = d3d_gru_update_gates_gn(o, stats_o, gamma_o, beta_o, gates, stats_g + 2, gamma_u, beta_u, h, Hc, plane, eps, fast, hout, stream);
+    return rc == D3D_ERR_UNSUPPORTED ? D3D_ERR_INVALID_ARG : rc;
+}
+
 }  // extern "C"
 

@@ -208,6 +208,12 @@ class ConvGRUCell2(nn.Module):
     def forward(self, x, h=None, negate_x=False):
         if h is None:
             h = torch.zeros((self.output_channel,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        rn, un, on = self.reset_gate_norm, self.update_gate_norm, self.output_norm
+        if x.is_cuda:   # fast mode: the cell's four launches issued by ONE library call (ops.gru2_cell_gn); None: layer by layer below
+            out = ops.gru2_cell_gn(x, h, self._w(self.gate_conv, negate_x), self.gate_conv.bias, self._w(self.output_conv, negate_x),
+                                   self.output_conv.bias, rn, un, on)
+            if out is not None:
+                return out, out
         # (the GroupNorm statistics ride on the convolutions' epilogues where the kernel has that form: ops.GnStats)
         gs = ops.GnStats(2)
         f = ops.conv2d_k3(x, self._w(self.gate_conv, negate_x), None, self.gate_conv.bias, None, act=0, stride=1, x2=h, gn=gs)

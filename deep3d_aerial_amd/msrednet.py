@@ -223,7 +223,10 @@ class RedLoopGraph(object):
     2 / 3 unchanged.  Stage 1 replays 1 584 nodes in 14.7 ms, 9 us per node whatever the branches: the node rate bounds it, not the
     slices' dependency chain; stages 2 / 3 are bound by their kernels' durations.  The lighter variant -- only the decoder of slice d
     on its own stream beside the encoder and cells of slice d + 1 -- is slower as well (58.3 -> 63.3 ms per view): more branches in
-    flight cost this graph executor more than the overlap returns."""
+    flight cost this graph executor more than the overlap returns.  With the encoder hoisted out of the loop (encode_all) the four
+    conv-GRU levels are four independent recurrences; as four free-running chains they take 62.3 ms captured and 55.5 ms as launches
+    against 53.2 ms for the fork-join slices captured: the card is saturated by the kernels themselves (their durations add up to the
+    view), not waiting on the slices' dependency chain."""
 
     _cache = {}
     _lock = __import__("threading").Lock()

@@ -1604,6 +1604,54 @@ def gru_update_gates_gn(o, gates, h, gamma, beta, gamma_u, beta_u, eps, stats_o,
     return out
 
 
+_gru2_scratch = {}
+
+
+def gru2_cell_gn(x, h, w_gates, b_gates, w_cand, b_cand, norm_r, norm_u, norm_o):
+    """One ConvGRUCell2 step (module.py:53-99) as ONE library call (d3d_gru2_cell_gn_h16): the cell's four launches issued back to back
+    from C -- the gate / candidate convolutions with the GroupNorm statistics in their epilogues, the reset pass, the state update
+    with the update gate evaluated in place: the kernels and operands of conv2d_k3(gn=) + gru_reset_gn + conv2d_k3(gn=) +
+    gru_update_gates_gn, without the host's work between them.  The intermediates (pre-norm gates, r*h, pre-norm candidate) live in a
+    scratch set per (stream, shape), reused from cell to cell in stream order.  norm_*: the three nn.GroupNorm(1, C) modules.
+    h16 mode; returns the new state, or None where the entry point does not take the shapes (the caller runs the layers)."""
+    if conv_precision() != "h16" or not _use_mfma() or _cfg.off("gru2_cell") or _cfg.off("gn_fused") or _cfg.off("gru_gates_split") \
+            or _cfg.off("conv2d_zs") or _cfg.off("conv2d_wide") or b_gates is None or b_cand is None:
+        return None
+    Cx, H, W = x.shape
+    Hc = h.shape[0]
+    if not (norm_r.eps == norm_u.eps == norm_o.eps) or tuple(h.shape[1:]) != (H, W) or (H * W) % 4:
+        return None
+    Ci = Cx + Hc
+    if not ((Ci in (16, 24, 32, 40) and W % 4 == 0 and Cx % 8 == 0 and 2 * Hc <= (16 if Ci in (24, 40) else 32))
+            or (Ci in (64, 128) and Cx % 32 == 0 and Hc in (32, 64))):
+        return None
+    dev = x.device
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, Hc, H, W)
+    sc = _gru2_scratch.get(key)
+    if sc is None:
+        if len(_gru2_scratch) > 256:
+            _gru2_scratch.clear()
+        sc = _gru2_scratch[key] = (torch.empty((2 * Hc, H, W), dtype=torch.float32, device=dev), torch.empty((Hc, H, W), dtype=torch.float32, device=dev),
+                                   torch.empty((Hc, H, W), dtype=torch.float32, device=dev))
+    wg = derived_weight(w_gates, "z2bf16", _pack_z2_bf16)
+    wc = derived_weight(w_cand, "z2bf16", _pack_z2_bf16)
+    sg, so = GnStats(2).take_slot(dev), GnStats(1).take_slot(dev)
+    out = torch.empty_like(h)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = _lib.load().d3d_gru2_cell_gn_h16(_chk(x, "x", 3), Cx, _chk(h, "h", 3), Hc, H, W, p(wg), _chk(b_gates, "b_gates"), p(wc), _chk(b_cand, "b_cand"),
+                                          _chk(norm_r.weight, "gamma_r"), _chk(norm_r.bias, "beta_r"), _chk(norm_u.weight, "gamma_u"),
+                                          _chk(norm_u.bias, "beta_u"), _chk(norm_o.weight, "gamma_o"), _chk(norm_o.bias, "beta_o"),
+                                          float(norm_r.eps), 1, p(sg), p(so), p(sc[0]), p(sc[1]), p(sc[2]), p(out), _stream())
+    if rc == _lib.ERR_UNSUPPORTED:
+        _gn_arenas[(dev.index, torch.cuda.current_stream(dev).cuda_stream)][1] -= 2   # (nothing was launched: the two slots stay zero)
+        return None
+    _lib.check(rc, "d3d_gru2_cell_gn_h16")
+    dispatch_counts["gru2_cell"] += 1
+    dispatch_counts["conv2d_gn_fused"] += 2
+    dispatch_counts["conv2d_wide" if Ci >= 64 else "conv2d_tile"] += 2
+    return out
+
+
 def _dptr(t):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.numel() == 2):
         raise TypeError("statistics must be a CUDA float64 pair")

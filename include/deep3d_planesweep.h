@@ -690,6 +690,17 @@ int d3d_gru_reset_gn(const float* gates, const double* stats_r, const float* gam
 int d3d_gru_update_gates_gn(const float* o, const double* stats_o, const float* gamma, const float* beta, const float* gates,
                             const double* stats_u, const float* gamma_u, const float* beta_u, const float* h, int Hc, int64_t plane,
                             float eps, int fast, float* h_out, d3d_stream_t stream);
+/* One ConvGRUCell2 step as ONE call (ABI 10): the gate convolution with the GroupNorm statistics in its epilogue, d3d_gru_reset_gn, the
+ * candidate convolution with its statistics and d3d_gru_update_gates_gn issued back to back -- the same kernels on the same operands as
+ * the four entry points one by one; what goes away is the host's work between them (a RED-Net view is 352 cells).
+ *   x [Cx,H,W], h [Hc,H,W] -> hout [Hc,H,W]; wg / wc = ops._pack_z2_bf16 of the gate [2Hc,Cx+Hc,3,3] / candidate [Hc,Cx+Hc,3,3] weights;
+ *   stats_g [2][2], stats_o [2]: fp64, ZEROED by the caller; gates [2Hc,H,W], rh [Hc,H,W], o [Hc,H,W]: scratch.
+ * Cx + Hc = 16 | 24 | 32 | 40 (W % 4 == 0) or 64 | 128 (parts of 32); H * W % 4 == 0; 16-byte aligned tensors.  D3D_ERR_UNSUPPORTED
+ * otherwise, with nothing launched. */
+int d3d_gru2_cell_gn_h16(const float* x, int Cx, const float* h, int Hc, int H, int W, const void* wg, const float* bg, const void* wc,
+                         const float* bc, const float* gamma_r, const float* beta_r, const float* gamma_u, const float* beta_u,
+                         const float* gamma_o, const float* beta_o, float eps, int fast, double* stats_g, double* stats_o, float* gates,
+                         float* rh, float* o, float* hout, d3d_stream_t stream);
 
 /* ucsnet.py:137-151 (compute_depth of UCS-Net): d3d_softargmin_conf4 plus the spread of the per-pixel distribution,
  * var_out = lamb * sqrt(sum_d softmax(cost)_d * (depth_d - depth_out)^2)  [h,w]. */
