@@ -204,11 +204,12 @@ class InferDepthNet(nn.Module):
 
 class RedLoopGraph(object):
     """The slice loop of one RED-Net cascade stage (msrednet.py:400-437: D times the four-level conv-GRU encoder-decoder and the
-    online regression update, ~33 launches per slice) captured once as a HIP graph and replayed per reference view.
+    online regression update, ~23 launches per slice) captured once as a HIP graph and replayed per reference view.
 
-    Why: a RED-Net view is ~2 900 launches of 10 - 90 us kernels; the host thread, not the card, paces it (22 us per launch;
-    taking 9 ms of kernel time out of it did not move the view -- DESIGN.md 4.3).  Captured, the host issues one graph launch per
-    stage.  What is captured is the forward as it runs eagerly, including the four-stream form of a slice
+    Why: a RED-Net view is ~2 000 launches of 10 - 200 us kernels on four streams per slice.  On ONE stream the card paces the loop
+    (launch loop and graph take the same time); what the host cannot do is issue four streams' launches and event operations fast
+    enough -- the four-stream slices are 6 ms per view faster captured than launched.  Captured, the host issues one
+    graph launch per stage.  What is captured is the forward as it runs eagerly, including the four-stream form of a slice
     (slice_RED_Regularization.forward: ops.side_streams / events / ops.hand_over -- tensors that cross streams are recorded, which
     keeps the capture's allocator from handing their blocks to another stream before the capture ends), the GroupNorm slot arenas
     (created and zeroed INSIDE the capture, per captured stream: every replay zeroes them again) and the zeroing of the states and
